@@ -1,0 +1,712 @@
+"""CPU ORACLE (test infrastructure, NOT the product): numpy restatement of one HULC / GCBC training step.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module; the product path (``hulc_amd``) never does and fails loudly if its HIP library is missing.
+
+It restates, in plain numpy fp32 (float64 only inside reductions where noted), the algorithm of the
+reference's ``Hulc.training_step`` + autograd backward + ``torch.optim.Adam`` step.  Every function cites
+the reference file:line it follows (paths relative to /root/reference).  Layouts are the reference's
+(NCHW images, (out,in) Linear weights), parameters are addressed by their reference ``state_dict`` names.
+
+Parity pin: ``tools/gen_golden.py`` imports the unmodified reference in the build container and writes
+losses / intermediate activations / per-parameter gradients / post-Adam parameters for several small
+configurations into ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this oracle against
+them (fp32, <=2e-5 relative).  Stochastic draws (the categorical plan sample) are injected as inputs
+(``plan_idx``); dropout is off (``model.eval()``-style) in all fixtures — see DESIGN.md "parity".
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------------------
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def linear(x, w, b=None):
+    y = x @ w.T
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def linear_bwd(x, w, dy):
+    """returns dx, dw, db for y = x w^T + b ; x (M,K), w (N,K), dy (M,N)"""
+    return (dy @ w).astype(F32), (dy.T @ x).astype(F32), dy.sum(0).astype(F32)
+
+
+def _im2col(x, kh, kw, s):
+    n, c, h, w = x.shape
+    oh, ow = (h - kh) // s + 1, (w - kw) // s + 1
+    st = x.strides
+    v = np.lib.stride_tricks.as_strided(
+        x, (n, oh, ow, c, kh, kw), (st[0], st[2] * s, st[3] * s, st[1], st[2], st[3]), writeable=False)
+    return v.reshape(n * oh * ow, c * kh * kw), oh, ow
+
+
+def conv2d(x, w, b, s):
+    """nn.Conv2d, no padding (vision_network.py:38-45, vision_network_gripper.py:12-17)."""
+    o, c, kh, kw = w.shape
+    col, oh, ow = _im2col(np.ascontiguousarray(x), kh, kw, s)
+    y = col @ w.reshape(o, -1).T + b
+    return np.ascontiguousarray(y.reshape(x.shape[0], oh, ow, o).transpose(0, 3, 1, 2)).astype(F32)
+
+
+def conv2d_bwd(x, w, dy, s, need_dx=True):
+    o, c, kh, kw = w.shape
+    n = x.shape[0]
+    col, oh, ow = _im2col(np.ascontiguousarray(x), kh, kw, s)
+    dy2 = dy.transpose(0, 2, 3, 1).reshape(-1, o)
+    dw = (dy2.T @ col).reshape(w.shape).astype(F32)
+    db = dy2.sum(0).astype(F32)
+    dx = None
+    if need_dx:
+        dcol = (dy2 @ w.reshape(o, -1)).reshape(n, oh, ow, c, kh, kw)
+        dx = np.zeros_like(x)
+        for i in range(kh):
+            for j in range(kw):
+                dx[:, :, i:i + s * oh:s, j:j + s * ow:s] += dcol[:, :, :, :, i, j].transpose(0, 3, 1, 2)
+    return dx, dw, db
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xh = (x - mu) * rstd
+    return (xh * g + b).astype(F32), (xh.astype(F32), rstd.astype(F32))
+
+
+def layer_norm_bwd(dy, g, cache):
+    xh, rstd = cache
+    dxh = dy * g
+    dx = rstd * (dxh - dxh.mean(-1, keepdims=True) - xh * (dxh * xh).mean(-1, keepdims=True))
+    red = tuple(range(dy.ndim - 1))
+    return dx.astype(F32), (dy * xh).sum(red).astype(F32), dy.sum(red).astype(F32)
+
+
+def softmax(x, axis=-1):
+    m = x.max(axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis, keepdims=True)
+
+
+def log_softmax(x, axis=-1):
+    m = x.max(axis, keepdims=True)
+    z = x - m
+    return z - np.log(np.exp(z).sum(axis, keepdims=True))
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+# ----------------------------------------------------------------------------------------------------
+# perceptual encoders  (perceptual_encoders/vision_network.py, vision_network_gripper.py, concat_encoders.py)
+# ----------------------------------------------------------------------------------------------------
+def spatial_softmax(f, temp=1.0):
+    """vision_network.py:100-108 ; f (N,C,H,W) -> (N,2C) interleaved [ex_c, ey_c]; x follows the ROW index."""
+    n, c, h, w = f.shape
+    p = softmax(f.reshape(n, c, h * w) / temp, -1)
+    lin_h = np.linspace(-1.0, 1.0, h, dtype=F32)
+    lin_w = np.linspace(-1.0, 1.0, w, dtype=F32)
+    xm = np.repeat(lin_h, w)            # x_map[i*w+j] = lin[i]   (meshgrid indexing="ij", :88-92)
+    ym = np.tile(lin_w, h)              # y_map[i*w+j] = lin[j]
+    ex = (p * xm).sum(-1)
+    ey = (p * ym).sum(-1)
+    out = np.stack([ex, ey], -1).reshape(n, 2 * c).astype(F32)
+    return out, (p.astype(F32), xm, ym, ex, ey)
+
+
+def spatial_softmax_bwd(dout, cache, shape, temp=1.0):
+    p, xm, ym, ex, ey = cache
+    n, c, h, w = shape
+    d = dout.reshape(n, c, 2)
+    dex, dey = d[..., 0:1], d[..., 1:2]
+    ds = p * (dex * (xm - ex[..., None]) + dey * (ym - ey[..., None])) / temp
+    return ds.reshape(n, c, h, w).astype(F32)
+
+
+def static_encoder_fwd(P, pre, x):
+    """vision_network.py:55-65"""
+    c = {}
+    c["x"] = x
+    c["a1"] = relu(conv2d(x, P[pre + "conv_model.0.weight"], P[pre + "conv_model.0.bias"], 4))
+    c["a2"] = relu(conv2d(c["a1"], P[pre + "conv_model.2.weight"], P[pre + "conv_model.2.bias"], 2))
+    c["a3"] = relu(conv2d(c["a2"], P[pre + "conv_model.4.weight"], P[pre + "conv_model.4.bias"], 1))
+    c["ss"], c["ss_cache"] = spatial_softmax(c["a3"])
+    c["f1"] = relu(linear(c["ss"], P[pre + "fc1.0.weight"], P[pre + "fc1.0.bias"]))
+    c["f2"] = linear(c["f1"], P[pre + "fc2.weight"], P[pre + "fc2.bias"])
+    c["out"], c["ln_cache"] = layer_norm(c["f2"], P[pre + "ln.weight"], P[pre + "ln.bias"])
+    return c["out"], c
+
+
+def static_encoder_bwd(P, G, pre, c, dout):
+    d, dg, db = layer_norm_bwd(dout, P[pre + "ln.weight"], c["ln_cache"])
+    _acc(G, pre + "ln.weight", dg)
+    _acc(G, pre + "ln.bias", db)
+    d, dw, db = linear_bwd(c["f1"], P[pre + "fc2.weight"], d)
+    _acc(G, pre + "fc2.weight", dw)
+    _acc(G, pre + "fc2.bias", db)
+    d = d * (c["f1"] > 0)
+    d, dw, db = linear_bwd(c["ss"], P[pre + "fc1.0.weight"], d)
+    _acc(G, pre + "fc1.0.weight", dw)
+    _acc(G, pre + "fc1.0.bias", db)
+    d = spatial_softmax_bwd(d, c["ss_cache"], c["a3"].shape) * (c["a3"] > 0)
+    _conv_stack_bwd(P, G, pre, c, d)
+
+
+def _conv_stack_bwd(P, G, pre, c, d3):
+    d, dw, db = conv2d_bwd(c["a2"], P[pre + "conv_model.4.weight"], d3, 1)
+    _acc(G, pre + "conv_model.4.weight", dw)
+    _acc(G, pre + "conv_model.4.bias", db)
+    d = d * (c["a2"] > 0)
+    d, dw, db = conv2d_bwd(c["a1"], P[pre + "conv_model.2.weight"], d, 2)
+    _acc(G, pre + "conv_model.2.weight", dw)
+    _acc(G, pre + "conv_model.2.bias", db)
+    d = d * (c["a1"] > 0)
+    _, dw, db = conv2d_bwd(c["x"], P[pre + "conv_model.0.weight"], d, 4, need_dx=False)
+    _acc(G, pre + "conv_model.0.weight", dw)
+    _acc(G, pre + "conv_model.0.bias", db)
+
+
+def gripper_encoder_fwd(P, pre, x):
+    """vision_network_gripper.py:10-20,49-57 ; Flatten is (C,H,W) order."""
+    c = {}
+    c["x"] = x
+    c["a1"] = relu(conv2d(x, P[pre + "conv_model.0.weight"], P[pre + "conv_model.0.bias"], 4))
+    c["a2"] = relu(conv2d(c["a1"], P[pre + "conv_model.2.weight"], P[pre + "conv_model.2.bias"], 2))
+    c["a3"] = relu(conv2d(c["a2"], P[pre + "conv_model.4.weight"], P[pre + "conv_model.4.bias"], 1))
+    c["flat"] = c["a3"].reshape(x.shape[0], -1)
+    c["g0"] = relu(linear(c["flat"], P[pre + "conv_model.7.weight"], P[pre + "conv_model.7.bias"]))
+    c["f1"] = relu(linear(c["g0"], P[pre + "fc1.0.weight"], P[pre + "fc1.0.bias"]))
+    c["f2"] = linear(c["f1"], P[pre + "fc2.weight"], P[pre + "fc2.bias"])
+    c["out"], c["ln_cache"] = layer_norm(c["f2"], P[pre + "ln.weight"], P[pre + "ln.bias"])
+    return c["out"], c
+
+
+def gripper_encoder_bwd(P, G, pre, c, dout):
+    d, dg, db = layer_norm_bwd(dout, P[pre + "ln.weight"], c["ln_cache"])
+    _acc(G, pre + "ln.weight", dg)
+    _acc(G, pre + "ln.bias", db)
+    d, dw, db = linear_bwd(c["f1"], P[pre + "fc2.weight"], d)
+    _acc(G, pre + "fc2.weight", dw)
+    _acc(G, pre + "fc2.bias", db)
+    d = d * (c["f1"] > 0)
+    d, dw, db = linear_bwd(c["g0"], P[pre + "fc1.0.weight"], d)
+    _acc(G, pre + "fc1.0.weight", dw)
+    _acc(G, pre + "fc1.0.bias", db)
+    d = d * (c["g0"] > 0)
+    d, dw, db = linear_bwd(c["flat"], P[pre + "conv_model.7.weight"], d)
+    _acc(G, pre + "conv_model.7.weight", dw)
+    _acc(G, pre + "conv_model.7.bias", db)
+    d = d.reshape(c["a3"].shape) * (c["a3"] > 0)
+    _conv_stack_bwd(P, G, pre, c, d)
+
+
+def _acc(G, name, g):
+    g = np.asarray(g, F32)
+    if name in G:
+        G[name] = G[name] + g
+    else:
+        G[name] = g.copy()
+
+
+# ----------------------------------------------------------------------------------------------------
+# MLP helpers (goal encoders goal_encoders.py:31-36/64-69, plan proposal plan_proposal_net.py:42-47)
+# ----------------------------------------------------------------------------------------------------
+def mlp_fwd(P, names, x, last_relu):
+    acts = [x]
+    for i, n in enumerate(names):
+        y = linear(acts[-1], P[n + ".weight"], P[n + ".bias"])
+        if i < len(names) - 1 or last_relu:
+            y = relu(y)
+        acts.append(y)
+    return acts[-1], acts
+
+
+def mlp_bwd(P, G, names, acts, d, last_relu):
+    for i in reversed(range(len(names))):
+        n = names[i]
+        if i < len(names) - 1 or last_relu:
+            d = d * (acts[i + 1] > 0)
+        d, dw, db = linear_bwd(acts[i], P[n + ".weight"], d)
+        _acc(G, n + ".weight", dw)
+        _acc(G, n + ".bias", db)
+    return d
+
+
+# ----------------------------------------------------------------------------------------------------
+# plan recognition transformer (plan_recognition_net.py:94-117 ; nn.TransformerEncoderLayer post-LN, relu)
+# ----------------------------------------------------------------------------------------------------
+def plan_recognition_fwd(P, emb, heads=8):
+    pr = "plan_recognition."
+    B, S, D = emb.shape
+    hd = D // heads
+    c = {"layers": []}
+    x = (emb + P[pr + "position_embeddings.weight"][:S][None]).astype(F32)      # :101-105
+    for l in range(2):
+        L = f"{pr}transformer_encoder.layers.{l}."
+        lc = {"x_in": x}
+        qkv = linear(x.reshape(B * S, D), P[L + "self_attn.in_proj_weight"], P[L + "self_attn.in_proj_bias"])
+        qkv = qkv.reshape(B, S, 3, heads, hd).transpose(2, 0, 3, 1, 4)          # (3,B,H,S,hd)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        sc = (q * F32(1.0 / math.sqrt(hd))) @ k.transpose(0, 1, 3, 2)
+        pa = softmax(sc, -1).astype(F32)
+        ao = (pa @ v).transpose(0, 2, 1, 3).reshape(B * S, D).astype(F32)
+        lc.update(q=q, k=k, v=v, pa=pa, ao=ao)
+        sa = linear(ao, P[L + "self_attn.out_proj.weight"], P[L + "self_attn.out_proj.bias"]).reshape(B, S, D)
+        x1, lc["ln1"] = layer_norm(x + sa, P[L + "norm1.weight"], P[L + "norm1.bias"])
+        lc["x1"] = x1
+        h = relu(linear(x1.reshape(B * S, D), P[L + "linear1.weight"], P[L + "linear1.bias"]))
+        lc["h"] = h
+        ff = linear(h, P[L + "linear2.weight"], P[L + "linear2.bias"]).reshape(B, S, D)
+        x, lc["ln2"] = layer_norm(x1 + ff, P[L + "norm2.weight"], P[L + "norm2.bias"])
+        lc["x_out"] = x
+        c["layers"].append(lc)
+    c["x_final"] = x
+    y = linear(x.reshape(B * S, D), P[pr + "fc.weight"], P[pr + "fc.bias"]).reshape(B, S, -1)   # :113
+    seq_feat = y.mean(1).astype(F32)                                                          # :114
+    logits = linear(seq_feat, P[pr + "fc_state.0.weight"], P[pr + "fc_state.0.bias"])          # :115
+    c["seq_feat"] = seq_feat
+    return logits, seq_feat, c
+
+
+def plan_recognition_bwd(P, G, c, dlogits, dseq_feat, heads=8, fc_state_used=True):
+    pr = "plan_recognition."
+    x = c["x_final"]
+    B, S, D = x.shape
+    hd = D // heads
+    dsf = np.zeros_like(c["seq_feat"]) if dseq_feat is None else dseq_feat.astype(F32).copy()
+    if fc_state_used and dlogits is not None:
+        d, dw, db = linear_bwd(c["seq_feat"], P[pr + "fc_state.0.weight"], dlogits)
+        _acc(G, pr + "fc_state.0.weight", dw)
+        _acc(G, pr + "fc_state.0.bias", db)
+        dsf = dsf + d
+    dy = np.repeat((dsf / S)[:, None, :], S, 1).reshape(B * S, -1).astype(F32)
+    d, dw, db = linear_bwd(x.reshape(B * S, D), P[pr + "fc.weight"], dy)
+    _acc(G, pr + "fc.weight", dw)
+    _acc(G, pr + "fc.bias", db)
+    dx = d.reshape(B, S, D)
+    for l in (1, 0):
+        L = f"{pr}transformer_encoder.layers.{l}."
+        lc = c["layers"][l]
+        dr, dg, db = layer_norm_bwd(dx, P[L + "norm2.weight"], lc["ln2"])
+        _acc(G, L + "norm2.weight", dg)
+        _acc(G, L + "norm2.bias", db)
+        dh, dw, db = linear_bwd(lc["h"], P[L + "linear2.weight"], dr.reshape(B * S, D))
+        _acc(G, L + "linear2.weight", dw)
+        _acc(G, L + "linear2.bias", db)
+        dh = dh * (lc["h"] > 0)
+        dx1, dw, db = linear_bwd(lc["x1"].reshape(B * S, D), P[L + "linear1.weight"], dh)
+        _acc(G, L + "linear1.weight", dw)
+        _acc(G, L + "linear1.bias", db)
+        dx1 = dx1.reshape(B, S, D) + dr
+        dr1, dg, db = layer_norm_bwd(dx1, P[L + "norm1.weight"], lc["ln1"])
+        _acc(G, L + "norm1.weight", dg)
+        _acc(G, L + "norm1.bias", db)
+        dao, dw, db = linear_bwd(lc["ao"], P[L + "self_attn.out_proj.weight"], dr1.reshape(B * S, D))
+        _acc(G, L + "self_attn.out_proj.weight", dw)
+        _acc(G, L + "self_attn.out_proj.bias", db)
+        dao = dao.reshape(B, S, heads, hd).transpose(0, 2, 1, 3)                  # (B,H,S,hd)
+        pa, q, k, v = lc["pa"], lc["q"], lc["k"], lc["v"]
+        dv = pa.transpose(0, 1, 3, 2) @ dao
+        dpa = dao @ v.transpose(0, 1, 3, 2)
+        dsc = pa * (dpa - (dpa * pa).sum(-1, keepdims=True))
+        scale = F32(1.0 / math.sqrt(hd))
+        dq = (dsc @ k) * scale
+        dk = dsc.transpose(0, 1, 3, 2) @ (q * scale)
+        dqkv = np.stack([dq, dk, dv], 0).transpose(1, 3, 0, 2, 4).reshape(B * S, 3 * D).astype(F32)
+        dxin, dw, db = linear_bwd(lc["x_in"].reshape(B * S, D), P[L + "self_attn.in_proj_weight"], dqkv)
+        _acc(G, L + "self_attn.in_proj_weight", dw)
+        _acc(G, L + "self_attn.in_proj_bias", db)
+        dx = dxin.reshape(B, S, D) + dr1
+    dpos = np.zeros_like(P[pr + "position_embeddings.weight"])
+    dpos[:S] = dx.sum(0)
+    _acc(G, pr + "position_embeddings.weight", dpos)
+    return dx.astype(F32)      # grad w.r.t. perceptual_emb
+
+
+# ----------------------------------------------------------------------------------------------------
+# action decoder (decoders/logistic_decoder_rnn.py, utils/rnn.py, utils/gripper_control.py)
+# ----------------------------------------------------------------------------------------------------
+def euler_xyz_to_matrix(e):
+    """pytorch3d_transforms.py:162-218, convention "XYZ": R = Rx(a) Ry(b) Rz(c)."""
+    a, b, c = e[..., 0], e[..., 1], e[..., 2]
+    ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+    R = np.empty(e.shape[:-1] + (3, 3), F32)
+    R[..., 0, 0] = cb * cc
+    R[..., 0, 1] = -cb * sc
+    R[..., 0, 2] = sb
+    R[..., 1, 0] = ca * sc + sa * sb * cc
+    R[..., 1, 1] = ca * cc - sa * sb * sc
+    R[..., 1, 2] = -sa * cb
+    R[..., 2, 0] = sa * sc - ca * sb * cc
+    R[..., 2, 1] = sa * cc + ca * sb * sc
+    R[..., 2, 2] = ca * cb
+    return R
+
+
+def world_to_tcp_frame(action, robot_obs):
+    """gripper_control.py:16-36 (fp32); inverse(R) == R^T."""
+    act = action.astype(F32)
+    e = robot_obs[..., 3:6].astype(F32)
+    R = euler_xyz_to_matrix(e)
+    Rt = np.swapaxes(R, -1, -2)
+    pos = (Rt @ act[..., :3, None])[..., 0]
+    Rn = euler_xyz_to_matrix(e + act[..., 3:6] * F32(0.01))
+    M = np.swapaxes(Rn, -1, -2) @ R
+    # matrix_to_euler_angles "XYZ" (pytorch3d_transforms.py:221-303)
+    o0 = np.arctan2(-M[..., 1, 2], M[..., 2, 2])
+    o1 = np.arcsin(M[..., 0, 2])
+    o2 = np.arctan2(-M[..., 0, 1], M[..., 0, 0])
+    orn = np.stack([o0, o1, o2], -1).astype(F32)
+    orn = np.where(orn < -np.pi, orn + 2 * np.pi, orn)
+    orn = np.where(orn > np.pi, orn - 2 * np.pi, orn)
+    orn = (orn * 100).astype(F32)
+    return np.concatenate([pos, orn, act[..., -1:]], -1).astype(F32)
+
+
+def rnn_fwd(P, pre, x):
+    """utils/rnn.py:5-14 : 2-layer ReLU nn.RNN, batch_first, h0 = 0."""
+    B, S, _ = x.shape
+    c = {"x": x}
+    inp = x
+    for l in range(2):
+        wih, whh = P[f"{pre}weight_ih_l{l}"], P[f"{pre}weight_hh_l{l}"]
+        b = P[f"{pre}bias_ih_l{l}"] + P[f"{pre}bias_hh_l{l}"]
+        zx = (inp.reshape(B * S, -1) @ wih.T + b).reshape(B, S, -1)
+        H = np.zeros((B, S, whh.shape[0]), F32)
+        h = np.zeros((B, whh.shape[0]), F32)
+        for t in range(S):
+            h = relu(zx[:, t] + h @ whh.T).astype(F32)
+            H[:, t] = h
+        c[f"H{l}"] = H
+        inp = H
+    return inp, c
+
+
+def rnn_bwd(P, G, pre, c, dH1):
+    B, S, Hn = dH1.shape
+    dout = dH1
+    for l in (1, 0):
+        wih, whh = P[f"{pre}weight_ih_l{l}"], P[f"{pre}weight_hh_l{l}"]
+        H = c[f"H{l}"]
+        inp = c["H0"] if l == 1 else c["x"]
+        dZ = np.zeros((B, S, Hn), F32)
+        carry = np.zeros((B, Hn), F32)
+        for t in reversed(range(S)):
+            dz = (dout[:, t] + carry) * (H[:, t] > 0)
+            dZ[:, t] = dz
+            carry = dz @ whh
+        dz2 = dZ.reshape(B * S, Hn)
+        Hprev = np.concatenate([np.zeros((B, 1, Hn), F32), H[:, :-1]], 1).reshape(B * S, Hn)
+        _acc(G, f"{pre}weight_hh_l{l}", dz2.T @ Hprev)
+        _acc(G, f"{pre}weight_ih_l{l}", dz2.T @ inp.reshape(B * S, -1))
+        _acc(G, f"{pre}bias_ih_l{l}", dz2.sum(0))
+        _acc(G, f"{pre}bias_hh_l{l}", dz2.sum(0))
+        dout = (dz2 @ wih).reshape(B, S, -1).astype(F32)
+    return dout       # grad w.r.t. decoder input x
+
+
+def logistic_loss(logit_probs, log_scales_raw, means, gripper_logits, actions_tcp,
+                  num_classes=10, log_scale_min=-7.0, gripper_alpha=1.0, amin=-1.0, amax=1.0):
+    """logistic_decoder_rnn.py:136-152 (_loss), :184-231 (_logistic_loss), :19-24 (log_sum_exp).
+
+    Returns loss and grads w.r.t. (logit_probs, log_scales_raw, means, gripper_logits)."""
+    B, S, Dd, K = means.shape
+    a = actions_tcp[..., :Dd, None].astype(F32) * np.ones((1, 1, 1, K), F32)
+    ls = np.maximum(log_scales_raw, F32(log_scale_min))
+    inv = np.exp(-ls)
+    hb = F32(((amax - amin) / 2.0) / (num_classes - 1))
+    cen = a - means
+    plus = inv * (cen + hb)
+    minus = inv * (cen - hb)
+    mid = inv * cen
+    sp, sm = sigmoid(plus), sigmoid(minus)
+    delta = sp - sm
+    caseA = a < amin + 1e-3
+    caseB = (~caseA) & (a > amax - 1e-3)
+    caseC = (~caseA) & (~caseB) & (delta > 1e-5)
+    caseD = ~(caseA | caseB | caseC)
+    logp = np.where(caseA, plus - softplus(plus),
+                    np.where(caseB, -softplus(minus),
+                             np.where(caseC, np.log(np.maximum(delta, 1e-12)),
+                                      mid - ls - 2.0 * softplus(mid) - np.log((num_classes - 1) / 2.0))))
+    lsm = log_softmax(logit_probs, -1)
+    lp = logp + lsm
+    m = lp.max(-1, keepdims=True)
+    lse = m[..., 0] + np.log(np.exp(lp - m).sum(-1))
+    logistics = -(lse.sum(-1)).mean()
+    # gripper cross entropy (:144-151) ; labels: -1 -> 0, else long(value)
+    g = actions_tcp[..., -1]
+    lab = np.where(g == -1, 0, g).astype(np.int64)
+    glsm = log_softmax(gripper_logits, -1)
+    ce = -np.take_along_axis(glsm, lab[..., None], -1)[..., 0].mean()
+    loss = F32(logistics + gripper_alpha * ce)
+    # ---- backward
+    n = B * S
+    wk = np.exp(lp - lse[..., None])
+    dlogp = -wk / n
+    dlogit = -(wk - np.exp(lsm)) / n
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        g_plus = np.where(caseA, sigmoid(-plus), np.where(caseC, sp * (1 - sp) / np.where(caseC, delta, 1.0), 0.0))
+        g_minus = np.where(caseB, -sm, np.where(caseC, -sm * (1 - sm) / np.where(caseC, delta, 1.0), 0.0))
+    g_mid = np.where(caseD, 1.0 - 2.0 * sigmoid(mid), 0.0)
+    dmean = dlogp * (-inv) * (g_plus + g_minus + g_mid)
+    dls = dlogp * (-(g_plus * plus + g_minus * minus + g_mid * mid) - np.where(caseD, 1.0, 0.0))
+    dls_raw = np.where(log_scales_raw >= log_scale_min, dls, 0.0)
+    dgl = np.exp(glsm)
+    np.put_along_axis(dgl, lab[..., None], np.take_along_axis(dgl, lab[..., None], -1) - 1.0, -1)
+    dgl = gripper_alpha * dgl / n
+    return loss, (dlogit.astype(F32), dls_raw.astype(F32), dmean.astype(F32), dgl.astype(F32))
+
+
+def decoder_loss_fwd(P, plan, emb, goal, actions, robot_obs, dims):
+    """LogisticDecoderRNN.loss :121-134 -> forward :260-287."""
+    ad = "action_decoder."
+    B, S, _ = emb.shape
+    pe = emb[..., 64:128]
+    parts = []
+    if plan is not None and plan.shape[-1] > 0:
+        parts.append(np.repeat(plan[:, None, :], S, 1))
+    parts += [pe, np.repeat(goal[:, None, :], S, 1)]
+    x = np.concatenate(parts, -1).astype(F32)
+    H1, rc = rnn_fwd(P, ad + "rnn.", x)
+    h2 = H1.reshape(B * S, -1)
+    K, Dd = dims.n_mix, dims.act_dims
+    probs = linear(h2, P[ad + "prob_fc.weight"], P[ad + "prob_fc.bias"]).reshape(B, S, Dd, K)
+    means = linear(h2, P[ad + "mean_fc.weight"], P[ad + "mean_fc.bias"]).reshape(B, S, Dd, K)
+    lsr = linear(h2, P[ad + "log_scale_fc.weight"], P[ad + "log_scale_fc.bias"]).reshape(B, S, Dd, K)
+    grip = linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
+    a_tcp = world_to_tcp_frame(actions, robot_obs)
+    loss, grads = logistic_loss(probs, lsr, means, grip, a_tcp, num_classes=dims.num_classes)
+    c = dict(rc=rc, x=x, H1=H1, probs=probs, means=means, log_scales=lsr, gripper=grip, a_tcp=a_tcp, grads=grads)
+    return loss, c
+
+
+def decoder_loss_bwd(P, G, c, dims, scale):
+    ad = "action_decoder."
+    H1 = c["H1"]
+    B, S, Hn = H1.shape
+    h2 = H1.reshape(B * S, Hn)
+    dlogit, dls, dmean, dgl = [g * F32(scale) for g in c["grads"]]
+    dH = np.zeros((B * S, Hn), F32)
+    for nm, d in (("prob_fc", dlogit), ("mean_fc", dmean), ("log_scale_fc", dls), ("gripper_fc", dgl)):
+        dx, dw, db = linear_bwd(h2, P[f"{ad}{nm}.weight"], d.reshape(B * S, -1))
+        _acc(G, f"{ad}{nm}.weight", dw)
+        _acc(G, f"{ad}{nm}.bias", db)
+        dH += dx
+    dx = rnn_bwd(P, G, ad + "rnn.", c["rc"], dH.reshape(B, S, Hn))
+    np_ = dims.dec_plan
+    dplan = dx[..., :np_].sum(1) if np_ > 0 else None
+    dpe = dx[..., np_:np_ + 64]
+    dgoal = dx[..., np_ + 64:].sum(1)
+    return dplan, dpe, dgoal
+
+
+# ----------------------------------------------------------------------------------------------------
+# KL (hulc.py:539-561), straight-through sample (distributions.py:23-27), CLIP aux (hulc.py:650-695)
+# ----------------------------------------------------------------------------------------------------
+def kl_loss(pp_logits, pr_logits, dims, beta=0.01, alpha=0.8):
+    B = pp_logits.shape[0]
+    a = log_softmax(pr_logits.reshape(B, dims.n_cat, dims.n_cls), -1)
+    b = log_softmax(pp_logits.reshape(B, dims.n_cat, dims.n_cls), -1)
+    p, q = np.exp(a), np.exp(b)
+    klc = (p * (a - b)).sum(-1)                 # (B, n_cat)
+    kl = klc.sum(-1).mean()
+    loss = F32(beta * (alpha * kl + (1 - alpha) * kl))
+    dpp = (beta * alpha / B) * (q - p)
+    dpr = (beta * (1 - alpha) / B) * p * ((a - b) - klc[..., None])
+    return loss, dpp.reshape(B, -1).astype(F32), dpr.reshape(B, -1).astype(F32)
+
+
+def clip_loss(P, seq_feat, goal, mask):
+    if not mask.any():
+        return F32(0.0), None
+    sf, lg = seq_feat[mask], goal[mask]
+    n = sf.shape[0]
+    names_im = ["proj_vis_lang.mlp_im.0", "proj_vis_lang.mlp_im.2"]
+    names_la = ["proj_vis_lang.mlp_lang.0", "proj_vis_lang.mlp_lang.2"]
+    img, acts_i = mlp_fwd(P, names_im, sf, False)
+    txt, acts_t = mlp_fwd(P, names_la, lg, False)
+    ni = np.linalg.norm(img, axis=-1, keepdims=True)
+    nt = np.linalg.norm(txt, axis=-1, keepdims=True)
+    i_n, t_n = img / ni, txt / nt
+    s = np.exp(P["logit_scale"])
+    cos = i_n @ t_n.T
+    logits = s * cos
+    lr, lc = log_softmax(logits, 1), log_softmax(logits, 0)
+    idx = np.arange(n)
+    loss = F32((-lr[idx, idx].mean() - lc[idx, idx].mean()) / 2)
+    eye = np.eye(n, dtype=F32)
+    dlog = ((np.exp(lr) - eye) + (np.exp(lc) - eye)) / (2 * n)
+    cache = dict(mask=mask, acts_i=acts_i, acts_t=acts_t, names_im=names_im, names_la=names_la,
+                 i_n=i_n, t_n=t_n, ni=ni, nt=nt, s=s, cos=cos, dlog=dlog)
+    return loss, cache
+
+
+def clip_loss_bwd(P, G, c, scale, B):
+    dlog = c["dlog"] * F32(scale)
+    s = c["s"]
+    _acc(G, "logit_scale", np.asarray((dlog * c["cos"]).sum() * s, F32).reshape(()))
+    din = s * (dlog @ c["t_n"])
+    dtn = s * (dlog.T @ c["i_n"])
+    dimg = (din - c["i_n"] * (c["i_n"] * din).sum(-1, keepdims=True)) / c["ni"]
+    dtxt = (dtn - c["t_n"] * (c["t_n"] * dtn).sum(-1, keepdims=True)) / c["nt"]
+    dsf_m = mlp_bwd(P, G, c["names_im"], c["acts_i"], dimg.astype(F32), False)
+    dg_m = mlp_bwd(P, G, c["names_la"], c["acts_t"], dtxt.astype(F32), False)
+    dsf = np.zeros((B, dsf_m.shape[1]), F32)
+    dg = np.zeros((B, dg_m.shape[1]), F32)
+    dsf[c["mask"]] = dsf_m
+    dg[c["mask"]] = dg_m
+    return dsf, dg
+
+
+# ----------------------------------------------------------------------------------------------------
+# one modality pass + whole step  (hulc.py:390-537, gcbc.py:50-181)
+# ----------------------------------------------------------------------------------------------------
+PP_NAMES = ["plan_proposal.fc_model.0", "plan_proposal.fc_model.2", "plan_proposal.fc_model.4",
+            "plan_proposal.fc_model.6", "plan_proposal.fc_state.0"]
+VG_NAMES = ["visual_goal.mlp.0", "visual_goal.mlp.2", "visual_goal.mlp.4"]
+LG_NAMES = ["language_goal.mlp.1", "language_goal.mlp.3", "language_goal.mlp.5"]
+
+
+def modality_fwd(P, dims, mb, is_lang):
+    """mb: dict(rgb_static (B,S,3,200,200), rgb_gripper (B,S,3,84,84), actions (B,S,7), robot_obs (B,S,15),
+    plan_idx (B,n_cat) int [hulc], lang (B,384), use_for_aux (B,) bool [lang])."""
+    c = {}
+    B, S = mb["actions"].shape[:2]
+    xs = mb["rgb_static"].reshape((B * S,) + mb["rgb_static"].shape[2:]).astype(F32)
+    xg = mb["rgb_gripper"].reshape((B * S,) + mb["rgb_gripper"].shape[2:]).astype(F32)
+    es, c["enc_s"] = static_encoder_fwd(P, "perceptual_encoder.rgb_static_encoder.", xs)
+    eg, c["enc_g"] = gripper_encoder_fwd(P, "perceptual_encoder.rgb_gripper_encoder.", xg)
+    emb = np.concatenate([es.reshape(B, S, -1), eg.reshape(B, S, -1)], -1).astype(F32)   # concat_encoders.py:86
+    c["emb"] = emb
+    if is_lang:
+        gpre, c["goal_acts"] = mlp_fwd(P, LG_NAMES, mb["lang"].astype(F32), False)
+        goal, c["goal_ln"] = layer_norm(gpre, P["language_goal.ln.weight"], P["language_goal.ln.bias"])
+    else:
+        gpre, c["goal_acts"] = mlp_fwd(P, VG_NAMES, emb[:, -1], False)
+        goal, c["goal_ln"] = layer_norm(gpre, P["visual_goal.ln.weight"], P["visual_goal.ln.bias"])
+    c["goal"] = goal
+    pr_logits, seq_feat, c["pr"] = plan_recognition_fwd(P, emb, dims.heads)
+    c["pr_logits"], c["seq_feat"] = pr_logits, seq_feat
+    out = {}
+    if dims.kind == "hulc":
+        ppx = np.concatenate([emb[:, 0], goal], -1)
+        pp_logits, c["pp_acts"] = mlp_fwd(P, PP_NAMES, ppx, False)
+        # fc_model layers all have ReLU, fc_state has none: names[-1] is fc_state (plan_proposal_net.py:26-40)
+        c["pp_logits"] = pp_logits
+        idx = mb["plan_idx"]
+        probs = softmax(pr_logits.reshape(B, dims.n_cat, dims.n_cls), -1).astype(F32)
+        onehot = np.zeros_like(probs)
+        np.put_along_axis(onehot, idx[..., None], 1.0, -1)
+        plan = (onehot + probs - probs).reshape(B, -1).astype(F32)      # distributions.py:27 / hulc.py:289-291
+        c["pr_probs"] = probs
+        c["plan"] = plan
+        act, c["dec"] = decoder_loss_fwd(P, plan, emb, goal, mb["actions"], mb["robot_obs"], dims)
+        kl, c["dpp_kl"], c["dpr_kl"] = kl_loss(pp_logits, pr_logits, dims)
+        out.update(kl=kl, action=act, total=F32(act + kl))
+    else:
+        act, c["dec"] = decoder_loss_fwd(P, None, emb, goal, mb["actions"], mb["robot_obs"], dims)
+        out.update(kl=F32(0), action=act, total=act)
+    out["clip"] = F32(0)
+    c["clip"] = None
+    if is_lang and dims.use_clip:
+        out["clip"], c["clip"] = clip_loss(P, seq_feat, goal, mb["use_for_aux"].astype(bool))
+    return out, c
+
+
+def modality_bwd(P, G, dims, c, is_lang, w_mod, w_clip):
+    emb = c["emb"]
+    B, S, _ = emb.shape
+    demb = np.zeros_like(emb)
+    dplan, dpe, dgoal = decoder_loss_bwd(P, G, c["dec"], dims, w_mod)
+    demb[..., 64:128] += dpe
+    dsf = None
+    if c["clip"] is not None:
+        dsf, dg_clip = clip_loss_bwd(P, G, c["clip"], w_clip, B)
+        dgoal = dgoal + dg_clip
+    dpr_logits = None
+    if dims.kind == "hulc":
+        probs = c["pr_probs"]
+        dpl = dplan.reshape(B, dims.n_cat, dims.n_cls)
+        dst = probs * (dpl - (dpl * probs).sum(-1, keepdims=True))      # straight-through softmax Jacobian
+        dpr_logits = (dst.reshape(B, -1) + c["dpr_kl"] * F32(w_mod)).astype(F32)
+        dpp = (c["dpp_kl"] * F32(w_mod)).astype(F32)
+        dppx = mlp_bwd(P, G, PP_NAMES, c["pp_acts"], dpp, False)
+        demb[:, 0] += dppx[:, :dims.emb]
+        dgoal = dgoal + dppx[:, dims.emb:]
+    if dpr_logits is not None or dsf is not None:
+        demb += plan_recognition_bwd(P, G, c["pr"], dpr_logits, dsf, dims.heads,
+                                     fc_state_used=dims.kind == "hulc")
+    lnn = "language_goal.ln" if is_lang else "visual_goal.ln"
+    dgp, dg, db = layer_norm_bwd(dgoal.astype(F32), P[lnn + ".weight"], c["goal_ln"])
+    _acc(G, lnn + ".weight", dg)
+    _acc(G, lnn + ".bias", db)
+    din = mlp_bwd(P, G, LG_NAMES if is_lang else VG_NAMES, c["goal_acts"], dgp, False)
+    if not is_lang:
+        demb[:, -1] += din
+    static_encoder_bwd(P, G, "perceptual_encoder.rgb_static_encoder.", c["enc_s"],
+                       np.ascontiguousarray(demb[..., :64]).reshape(B * S, 64))
+    gripper_encoder_bwd(P, G, "perceptual_encoder.rgb_gripper_encoder.", c["enc_g"],
+                        np.ascontiguousarray(demb[..., 64:]).reshape(B * S, 64))
+
+
+def training_step(P, dims, batch, clip_beta=3.0, want_grads=True, keep_cache=False):
+    """batch: {"vis": mb, "lang": mb} (either may be absent), iterated in that insertion order.
+
+    Returns (losses dict, grads dict or None[, caches])."""
+    losses = {}
+    caches = {}
+    nmod = len(batch)
+    tot = F32(0)
+    for scope, mb in batch.items():
+        o, c = modality_fwd(P, dims, mb, "lang" in scope)
+        caches[scope] = c
+        for k, v in o.items():
+            losses[f"{k}_{scope}"] = F32(v)
+        tot = tot + o["total"]
+    tot = tot / nmod
+    clip = sum(losses.get(f"clip_{s}", 0.0) for s in batch)
+    if dims.use_clip:
+        tot = tot + clip_beta * clip
+    losses["total"] = F32(tot)
+    losses["kl"] = F32(sum(losses[f"kl_{s}"] for s in batch) / nmod)
+    losses["action"] = F32(sum(losses[f"action_{s}"] for s in batch) / nmod)
+    losses["clip"] = F32(clip_beta * clip)
+    G = None
+    if want_grads:
+        G = {}
+        for scope in batch:
+            modality_bwd(P, G, dims, caches[scope], "lang" in scope, 1.0 / nmod, clip_beta)
+        for n in P:                       # params untouched this step get an explicit zero gradient
+            G.setdefault(n, np.zeros_like(P[n]))
+    if keep_cache:
+        return losses, G, caches
+    return losses, G
+
+
+def adam_step(P, G, state, step, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (conf/model/optimizer/adam.yaml:1-2; hulc.py:239-252). step counts from 1."""
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    for n, g in G.items():
+        m = state.setdefault("m." + n, np.zeros_like(P[n]))
+        v = state.setdefault("v." + n, np.zeros_like(P[n]))
+        m[...] = b1 * m + (1 - b1) * g
+        v[...] = b2 * v + (1 - b2) * g * g
+        denom = np.sqrt(v) / math.sqrt(bc2) + eps
+        P[n] = (P[n] - (lr / bc1) * m / denom).astype(F32)

@@ -1,0 +1,84 @@
+"""Shared helpers for the golden-fixture tests (fixtures come from tools/gen_golden.py = the reference)."""
+import os
+
+import numpy as np
+
+from hulc_amd import spec
+from hulc_amd.utils import portable_rng as prng
+from hulc_amd.utils import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NSAMP = 64
+# name: (kind, Bv, Bl, S, use_clip, aux_mask, edge_frac, seed)  -- must mirror tools/gen_golden.py CASES
+CASES = {
+    "hulc_tiny": ("hulc", 2, 2, 4, True, "all", 0.05, 1),
+    "hulc_s32": ("hulc", 2, 3, 32, True, "some", 0.05, 2),
+    "hulc_visonly": ("hulc", 3, 0, 8, False, "all", 0.05, 3),
+    "gcbc_s16": ("gcbc", 2, 2, 16, True, "all", 0.05, 4),
+    "hulc_edge": ("hulc", 1, 2, 5, True, "none", 0.6, 5),
+}
+
+
+def load_case(name):
+    kind, Bv, Bl, S, use_clip, aux_mask, edge_frac, seed = CASES[name]
+    dims = spec.ModelDims(kind=kind, max_window=32, use_clip=use_clip)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=edge_frac, aux_mask=aux_mask)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    for sc in batch:
+        if f"plan_idx_{sc}" in fx.files:
+            batch[sc]["plan_idx"] = fx[f"plan_idx_{sc}"]
+    return dims, P, batch, fx
+
+
+def sample_idx(name, n):
+    return prng.randint("sample." + name, (NSAMP,), n, 0)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def check_grads(G, fx, tol_l2=5e-3, tol_norm=2e-3, label=""):
+    """G: name -> full gradient array (reference layout). Compares with the reference's fixture entries."""
+    bad = []
+    for key in fx.files:
+        if key.startswith("gradnorm/"):
+            n = key[len("gradnorm/"):]
+            ref_norm = float(fx[key])
+            g = np.asarray(G[n], np.float64)
+            norm = float(np.sqrt((g ** 2).sum()))
+            if ref_norm < 1e-12:
+                if norm > 1e-7:
+                    bad.append((n, "norm-nonzero", norm))
+                continue
+            if abs(norm - ref_norm) / ref_norm > tol_norm:
+                bad.append((n, "norm", norm, ref_norm))
+            if "grad/" + n in fx.files:
+                e = rel_l2(g, fx["grad/" + n])
+            else:
+                e = rel_l2(g.reshape(-1)[sample_idx(n, g.size)], fx["gradsamp/" + n])
+            if e > tol_l2:
+                bad.append((n, "rel_l2", e))
+    assert not bad, f"{label} gradient mismatches: {bad[:8]} (+{max(0, len(bad) - 8)} more)"
+
+
+def grad_entries(fx, n):
+    """the reference gradient at the same entries the adam1/adam2 fixtures hold (None if grad was None)."""
+    if "grad/" + n in fx.files:
+        return fx["grad/" + n].reshape(-1)
+    if "gradsamp/" + n in fx.files:
+        return fx["gradsamp/" + n]
+    return None
+
+
+def adam_close(got, ref, g, lr=2e-4, steps=1):
+    """Adam's update is lr*g/(|g|+1e-8)-like: entries whose gradient is at fp32-noise level (|g| ~ eps) may
+    legitimately differ by up to 2*lr per step (sign flip); everywhere else the parameters must agree tightly."""
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    if g is None:
+        return bool((err <= 2 * steps * lr * 1.05 + 1e-6).all()) and float(np.median(err)) < 1e-5
+    big = np.abs(g) > 1e-5
+    return bool((err[big] <= 4e-6 + 2e-3 * lr).all()) and bool((err[~big] <= 2 * lr * 1.05 + 1e-6).all())

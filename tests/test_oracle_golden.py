@@ -1,0 +1,81 @@
+"""CPU: the numpy oracle (oracle/hulc_oracle.py) against the reference's own outputs (tests/golden/*.npz).
+
+The fixtures were produced by tools/gen_golden.py, which runs the unmodified reference on CPU; this pins
+the oracle that the GPU parity tests use as their checker.
+"""
+import numpy as np
+import pytest
+
+import hulc_oracle as O
+from golden_util import CASES, adam_close, check_grads, grad_entries, load_case, rel_l2, sample_idx
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference(name):
+    dims, P, batch, fx = load_case(name)
+    losses, G, caches = O.training_step(P, dims, batch, keep_cache=True)
+    assert abs(float(losses["total"]) - float(fx["loss_total"])) <= 2e-5 * abs(float(fx["loss_total"]))
+    # logged metric names of the reference (hulc.py:470-536)
+    for sc in batch:
+        c = caches[sc]
+        assert rel_l2(c["emb"], fx[f"emb_{sc}"]) < 2e-5
+        assert rel_l2(c["goal"], fx[f"goal_{sc}"]) < 2e-5
+        assert rel_l2(c["seq_feat"], fx[f"seq_feat_{sc}"]) < 2e-5
+        assert rel_l2(c["pr_logits"], fx[f"pr_logits_{sc}"]) < 2e-5
+        if dims.kind == "hulc":
+            assert rel_l2(c["pp_logits"], fx[f"pp_logits_{sc}"]) < 2e-5
+            assert abs(float(losses[f"kl_{sc}"]) - float(fx[f"log/train/kl_loss_scaled_{sc}"])) < 1e-6
+        d = c["dec"]
+        assert rel_l2(d["probs"], fx[f"logit_probs_{sc}"]) < 2e-5
+        assert rel_l2(d["means"], fx[f"means_{sc}"]) < 2e-5
+        assert rel_l2(np.maximum(d["log_scales"], -7.0), fx[f"log_scales_{sc}"]) < 2e-5
+        assert rel_l2(d["gripper"], fx[f"gripper_{sc}"]) < 2e-5
+        # world->tcp: the x0.01 / x100 rescale amplifies fp32 rounding -> abs tolerance
+        assert np.abs(d["a_tcp"] - fx[f"a_tcp_{sc}"]).max() < 2e-4
+        assert abs(float(losses[f"action_{sc}"]) - float(fx[f"log/train/action_loss_{sc}"])) < 3e-5
+    if dims.use_clip and "lang" in batch:
+        assert abs(float(losses["clip"]) - float(fx["log/train/lang_clip_loss"])) < 3e-5
+    check_grads(G, fx, label=name)
+    for key in fx.files:
+        if key.startswith("gradnone/"):        # GCBC leaves 12 tensors without a gradient
+            assert not np.any(G[key[len("gradnone/"):]])
+    # one Adam step
+    state = {}
+    O.adam_step(P, G, state, 1)
+    for key in fx.files:
+        if key.startswith("adam1/"):
+            n = key[len("adam1/"):]
+            flat = P[n].reshape(-1)
+            got = flat if flat.size <= 4096 else flat[sample_idx(n, flat.size)]
+            assert adam_close(got, fx[key], grad_entries(fx, n)), n
+
+
+def test_oracle_second_adam_step():
+    dims, P, batch, fx = load_case("hulc_tiny")
+    state = {}
+    _, G = O.training_step(P, dims, batch)
+    O.adam_step(P, G, state, 1)
+    for sc in batch:
+        batch[sc]["plan_idx"] = fx[f"plan_idx_step2_{sc}"]
+    losses, G = O.training_step(P, dims, batch)
+    assert abs(float(losses["total"]) - float(fx["loss_total_step2"])) <= 5e-5 * abs(float(fx["loss_total_step2"]))
+    O.adam_step(P, G, state, 2)
+    for key in fx.files:
+        if key.startswith("adam2/"):
+            n = key[len("adam2/"):]
+            flat = P[n].reshape(-1)
+            got = flat if flat.size <= 4096 else flat[sample_idx(n, flat.size)]
+            assert adam_close(got, fx[key], None, steps=2), n
+
+
+def test_world_to_tcp_edge_angles():
+    """euler angles near +-pi/2 (asin edge) stay finite and round-trip the gripper channel (a13)."""
+    act = np.zeros((1, 4, 7), np.float32)
+    act[..., 3:6] = [[0.9, -0.9, 0.5]]
+    act[..., 6] = [1, -1, 1, -1]
+    ro = np.zeros((1, 4, 15), np.float32)
+    ro[0, :, 3:6] = [[0, np.pi / 2 - 1e-3, 0], [3.1, 0.2, -3.1], [-1.5, 1.5, 1.5], [0.1, -np.pi / 2 + 1e-3, 2.0]]
+    out = O.world_to_tcp_frame(act, ro)
+    assert np.isfinite(out).all()
+    assert np.array_equal(out[..., 6], act[..., 6])
+    assert np.abs(out[..., 3:6]).max() <= 100 * np.pi + 1e-3
