@@ -1,0 +1,92 @@
+// hulc_amd/csrc/capi.hip — extern "C" boundary of libhulc_hip.so (see include/hulc_hip.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
+#include <stdexcept>
+
+#include "engine.h"
+
+static thread_local char g_err[1024] = "";
+void hulc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct hulc_ctx {
+    IEngine* e = nullptr;
+};
+
+extern "C" {
+
+const char* hulc_last_error(void) { return g_err; }
+
+int hulc_ctx_create(const hulc_config* cfg, hulc_ctx** out) {
+    if (!cfg || !out) { hulc_set_error("hulc_ctx_create: null argument"); return 1; }
+    if (cfg->max_seq > 64 || cfg->max_seq < 1 || cfg->max_batch < 1 || cfg->max_window < cfg->max_seq) {
+        hulc_set_error("hulc_ctx_create: need 1 <= max_seq <= 64, max_batch >= 1, max_window >= max_seq");
+        return 1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hulc_set_error("hulc_ctx_create: no HIP device visible"); return 1; }
+    hulc_ctx* c = new hulc_ctx();
+    int rc;
+    if (cfg->dtype == HULC_DTYPE_F32) { auto* e = new Engine<float>(*cfg); rc = e->alloc_all(); c->e = e; }
+    else if (cfg->dtype == HULC_DTYPE_BF16) { auto* e = new Engine<bf16_t>(*cfg); rc = e->alloc_all(); c->e = e; }
+    else { hulc_set_error("hulc_ctx_create: unknown dtype %d", cfg->dtype); delete c; return 1; }
+    if (rc) { delete c->e; delete c; return rc; }
+    *out = c;
+    return 0;
+}
+int hulc_ctx_destroy(hulc_ctx* ctx) {
+    if (!ctx) return 0;
+    hipDeviceSynchronize();
+    delete ctx->e;
+    delete ctx;
+    return 0;
+}
+int hulc_set_stream(hulc_ctx* ctx, void* s) { ctx->e->st = (hipStream_t)s; return 0; }
+int64_t hulc_workspace_bytes(const hulc_ctx* ctx) { return ctx->e->workspace_bytes(); }
+int hulc_bind_params(hulc_ctx* ctx, float* p, float* g, float* m, float* v, int64_t numel, int32_t n, const char* const* names, const int64_t* offs,
+                     const int64_t* numels) {
+    if (!ctx || !p || !g || !m || !v) { hulc_set_error("hulc_bind_params: null argument"); return 1; }
+    return ctx->e->bind(p, g, m, v, numel, n, names, offs, numels);
+}
+int hulc_prepare_weights(hulc_ctx* ctx) { return ctx->e->prepare_weights(); }
+int hulc_zero_grads(hulc_ctx* ctx) { return ctx->e->zero_grads(); }
+int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* b, float lw, float cw, float* out, int32_t on_host) {
+    if (!ctx || !b) { hulc_set_error("hulc_forward_loss: null argument"); return 1; }
+    return ctx->e->forward(b, lw, cw, out, on_host);
+}
+int hulc_backward(hulc_ctx* ctx) { return ctx->e->backward(); }
+int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
+int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* out, int64_t cap, int64_t* n) { return ctx->e->get_tensor(name, out, cap, n); }
+int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* out, int64_t cap) { return ctx->e->get_plan_idx(out, cap); }
+
+int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                   const float* bias, int32_t relu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    EpiP ep; ep.out = C; ep.out_f32 = 1; ep.bias = bias; ep.relu = relu;
+    if (dtype == HULC_DTYPE_F32) {
+        if (M >= 512 && N >= 128) launch_gemm<float, 128, 128>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+        else launch_gemm<float, 64, 64>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+    } else {
+        if (M >= 512 && N >= 128) launch_gemm<bf16_t, 128, 128>(st, dense<bf16_t>((const bf16_t*)A, M, lda), dense<bf16_t>((const bf16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+        else launch_gemm<bf16_t, 64, 64>(st, dense<bf16_t>((const bf16_t*)A, M, lda), dense<bf16_t>((const bf16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+    }
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
+    return 0;
+}
+int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HULC_DTYPE_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(1024), dim3(256), 0, st, src, (float*)dst, (long long)n);
+    else hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(1024), dim3(256), 0, st, src, (bf16_t*)dst, (long long)n);
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_cast: launch failed"); return 1; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// hulc_amd/csrc/common.h — shared device helpers for the gfx950 (MI355X) HULC training-step kernels.
+// Wave = 64 lanes everywhere; bf16 is stored as raw uint16 and converted with bit ops (RNE).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+#define DEVI __device__ __forceinline__
+
+DEVI float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+DEVI bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even (NaN payloads are not preserved; inputs are finite)
+    return (bf16_t)(u >> 16);
+}
+template <typename T> DEVI float to_f(T x);
+template <> DEVI float to_f<float>(float x) { return x; }
+template <> DEVI float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <typename T> DEVI T from_f(float x);
+template <> DEVI float from_f<float>(float x) { return x; }
+template <> DEVI bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
+
+// 8 contiguous elements of T (16 B for bf16, 32 B for fp32)
+template <typename T> struct Vec8 { T v[8]; };
+
+template <typename T> DEVI void load8(const T* p, T (&v)[8]);
+template <> DEVI void load8<bf16_t>(const bf16_t* p, bf16_t (&v)[8]) {
+    if ((((uintptr_t)p) & 15) == 0) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        *reinterpret_cast<uint4*>(v) = u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+}
+template <> DEVI void load8<float>(const float* p, float (&v)[8]) {
+    if ((((uintptr_t)p) & 15) == 0) {
+        float4 a = reinterpret_cast<const float4*>(p)[0];
+        float4 b = reinterpret_cast<const float4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[i];
+    }
+}
+template <typename T> DEVI void load8_guard(const T* p, int nvalid, T (&v)[8]) {
+    if (nvalid >= 8) { load8<T>(p, v); return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i < nvalid) ? p[i] : from_f<T>(0.f);
+}
+template <typename T> DEVI void zero8(T (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = from_f<T>(0.f);
+}
+
+// wave-level reductions (64 lanes)
+DEVI float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+DEVI float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+// counter-based RNG (dropout masks, Gumbel noise): splitmix-style 64->32 hash, uniform in (0,1)
+DEVI uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+DEVI float hash_uniform(uint64_t seed, uint64_t idx) {
+    return ((hash_u32(seed, idx) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+#define HIP_CHECK(x)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) {                                                                          \
+            hulc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));            \
+            return 1;                                                                                    \
+        }                                                                                                \
+    } while (0)
+
+void hulc_set_error(const char* fmt, ...);

@@ -1,0 +1,846 @@
+// hulc_amd/csrc/engine.h — host-side orchestration of one HULC / GCBC training step on one MI355X.
+// Engine<T> owns the workspace (saved activations, packed/transposed weight copies) and enqueues the kernels of
+// forward+loss, backward and Adam on one HIP stream.  T = float (parity mode) or bf16_t (bench mode).
+// Reference call stack restated here: SURVEY.md §3.2 (hulc/models/hulc.py:390-537).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hulc_hip.h"
+#include "gemm.h"
+#include "kernels.h"
+
+struct IEngine {
+    virtual ~IEngine() {}
+    virtual int bind(float* p, float* g, float* m, float* v, int64_t numel, int n, const char* const* names, const int64_t* offs,
+                     const int64_t* numels) = 0;
+    virtual int prepare_weights() = 0;
+    virtual int zero_grads() = 0;
+    virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
+    virtual int backward() = 0;
+    virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
+    virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
+    virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
+    virtual int64_t workspace_bytes() const = 0;
+    hipStream_t st = nullptr;
+};
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// HULC_DEBUG_SYNC=1: synchronise after every stage and trace its name to stderr (bring-up / fault localisation)
+static inline bool hulc_dbg() { static int v = -1; if (v < 0) { const char* e = getenv("HULC_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+#define STAGE(name) do { if (hulc_dbg()) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[hulc] stage %s -> %s\n", name, hipGetErrorString(e_)); fflush(stderr); } } while (0)
+#define HIP_CHECK_VOID(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { hulc_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e_)); } } while (0)
+
+template <typename T>
+struct Engine : IEngine {
+    hulc_config cfg;
+    // ---- model dims
+    static constexpr int EMB = 128, VF = 64, GOAL = 32, LANG = 384, HID = 2048, NCAT = 32, NCLS = 32, PLAN = 1024, NH = 8, FF = 2048,
+                         FCH = 4096, NMIX = 10, NDIM = 6, NHEAD = 192, NO = 60;
+    int dec_plan, KIN;
+    int maxB, maxS, maxN;
+    // ---- bound flat buffers
+    float *P = nullptr, *G = nullptr, *AM = nullptr, *AV = nullptr;
+    int64_t numel = 0;
+    struct Ref { int64_t off, n; };
+    std::map<std::string, Ref> tab;
+    // ---- arena
+    std::vector<void*> allocs;
+    int64_t ws_bytes = 0;
+    struct Named { void* p; int64_t n; int kind; };   // kind 0: f32, 1: T, 2: int32
+    std::map<std::string, Named> named;
+
+    template <typename U> U* alloc(int64_t n, const char* name = nullptr, int kind = -1) {
+        void* p = nullptr;
+        int64_t bytes = ((n * (int64_t)sizeof(U) + 255) / 256) * 256 + 256;
+        if (hipMalloc(&p, bytes) != hipSuccess) { alloc_failed = true; return nullptr; }
+        hipMemsetAsync(p, 0, bytes, st);
+        allocs.push_back(p);
+        ws_bytes += bytes;
+        if (name) named[name] = Named{p, n, kind >= 0 ? kind : (std::is_same<U, float>::value ? 0 : (std::is_same<U, int>::value ? 2 : 1))};
+        return (U*)p;
+    }
+    bool alloc_failed = false;
+
+    // ---- weights
+    struct LinW {
+        const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
+        T* W = nullptr; T* Wt = nullptr; int N = 0, K = 0; bool own_w = false;
+    };
+    struct ConvW {
+        const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
+        T* Wf = nullptr; T* Wd = nullptr; int O = 0, I = 0, KH = 0, KW = 0, S = 0; int nhwc = 0;   // nhwc: packed (kh,kw,ci) order (conv2/3)
+    };
+    struct EncW { ConvW c1, c2, c3; LinW fc7, fc1, fc2; const float *lng = nullptr, *lnb = nullptr; float *dlng = nullptr, *dlnb = nullptr; bool gripper = false; int IH = 0; int H1 = 0, H2 = 0, H3 = 0; };
+    EncW encS, encG;
+    LinW pp[5], vg[3], lg[3], tr_in[2], tr_out[2], tr_l1[2], tr_l2[2], pr_fc, pr_fs, whh0, wih1, whh1, cl_im0, cl_im2, cl_la0, cl_la2;
+    const float *ln_vg_g, *ln_vg_b, *ln_lg_g, *ln_lg_b, *tr_n1g[2], *tr_n1b[2], *tr_n2g[2], *tr_n2b[2], *pos32, *logit_scale;
+    float *d_ln_vg_g, *d_ln_vg_b, *d_ln_lg_g, *d_ln_lg_b, *d_tr_n1g[2], *d_tr_n1b[2], *d_tr_n2g[2], *d_tr_n2b[2], *dpos, *dlogit_scale;
+    // decoder input weights W_ih0 [HID][KIN] (sub-blocked) + packed heads
+    const float *wih0_32, *bih0, *bhh0, *bih1, *bhh1;
+    float *dwih0, *dbih0, *dbhh0, *dbih1, *dbhh1;
+    T *wih0 = nullptr, *wih0T = nullptr;
+    T *wheads = nullptr, *wheadsT = nullptr; float* bheads = nullptr; float *dwheads_tmp = nullptr, *dbheads_tmp = nullptr;
+    const float *head_w32[4], *head_b32[4]; float *head_dw[4], *head_db[4]; int head_rows[4] = {60, 60, 60, 2};
+    float* dw7_tmp = nullptr;
+    bool bound = false;
+
+    // ---- workspace (per modality pass)
+    struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; } aS, aG;
+    T *dact1, *dact2, *dact3, *d_g0, *d_f1, *d_f2t; float* d_ss;
+    T *emb, *lang_t, *gl1, *gl2, *goal_t, *ppx, *ppa[4], *xm, *seqf_t, *embg, *Cb, *Zx0, *Zx1, *H0, *H1, *dheads, *dH1, *dZ1, *dH0, *dZ0, *dC;
+    float *gl3, *goal_st, *pp_logits, *seqf, *pr_logits, *probs, *klcat, *dpp_kl, *dpr_kl, *Cplan, *heads, *rowloss, *a_tcp;
+    int* pidx; int* pidx_in;
+    T *xt[3], *qkv[2], *ao[2], *x1t[2], *hff[2];
+    float *xf[3], *Pat[2], *y1[2], *st1[2], *x1f[2], *y2[2], *st2[2];
+    float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
+    T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
+    T *tA, *tB; int64_t tcap;
+    float *part; int64_t partcap; float* cspart;
+    // clip
+    int* auxrows; T *sf_m, *im1, *g_m, *la1, *img_t, *txt_t; float *img, *txt, *dimg, *dtxt, *dsf_m, *dg_m; T *dimg_t, *dtxt_t, *dim1, *dla1;
+    float* losses;   // [8]: 0 action, 1 kl(sum klcat), 2 clip
+    // ---- state of the last forward
+    hulc_batch cur; float cur_lw = 0, cur_cw = 0; bool have_fwd = false;
+
+    // =====================================================================================================
+    Engine(const hulc_config& c) : cfg(c) {
+        dec_plan = cfg.kind == HULC_KIND_GCBC ? 0 : PLAN;
+        KIN = dec_plan + 64 + GOAL;
+        maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
+    }
+    ~Engine() override { for (void* p : allocs) hipFree(p); }
+    int64_t workspace_bytes() const override { return ws_bytes; }
+
+    uint64_t site_seed(int site) const {
+        uint64_t z = cfg.seed + 0x9E3779B97F4A7C15ull * (cur.step * 64 + (cur.is_lang ? 32 : 0) + site + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+    }
+
+    // ---------------------------------------------------------------- allocation
+    void alloc_enc(EncA& a, int IH, bool gripper, const char* pre) {
+        const int H1 = (IH - 8) / 4 + 1, H2 = (H1 - 4) / 2 + 1, H3 = H2 - 2;
+        std::string s(pre);
+        a.a1 = alloc<T>((int64_t)maxN * H1 * H1 * 32, (s + "a1").c_str());
+        a.a2 = alloc<T>((int64_t)maxN * H2 * H2 * 64, (s + "a2").c_str());
+        a.a3 = alloc<T>((int64_t)maxN * H3 * H3 * 64, (s + "a3").c_str());
+        a.ss = gripper ? nullptr : alloc<T>((int64_t)maxN * 128, (s + "ss").c_str());
+        a.ssstats = gripper ? nullptr : alloc<float>((int64_t)maxN * 64 * 4);
+        a.g0 = gripper ? alloc<T>((int64_t)maxN * 128, (s + "g0").c_str()) : nullptr;
+        a.f1 = alloc<T>((int64_t)maxN * 512, (s + "f1").c_str());
+        a.f2 = alloc<float>((int64_t)maxN * 64, (s + "f2").c_str());
+        a.lnst = alloc<float>((int64_t)maxN * 2);
+    }
+    int alloc_all() {
+        const int64_t N = maxN, B = maxB, S = maxS, SB = (int64_t)maxS * maxB;
+        alloc_enc(aS, 200, false, "s_");
+        alloc_enc(aG, 84, true, "g_");
+        dact1 = alloc<T>(N * 49 * 49 * 32, "dact1"); dact2 = alloc<T>(N * 23 * 23 * 64, "dact2"); dact3 = alloc<T>(N * 21 * 21 * 64, "dact3");
+        d_g0 = alloc<T>(N * 128); d_f1 = alloc<T>(N * 512); d_f2t = alloc<T>(N * 64); d_ss = alloc<float>(N * 128, "d_ss");
+        emb = alloc<T>(N * EMB, "emb"); lang_t = alloc<T>(B * LANG); gl1 = alloc<T>(B * HID); gl2 = alloc<T>(B * HID);
+        gl3 = alloc<float>(B * GOAL, "goal_pre"); goal_t = alloc<T>(B * GOAL, "goal"); goal_st = alloc<float>(B * 2);
+        ppx = alloc<T>(B * (EMB + GOAL)); for (int i = 0; i < 4; ++i) ppa[i] = alloc<T>(B * HID);
+        pp_logits = alloc<float>(B * PLAN, "pp_logits");
+        for (int l = 0; l < 3; ++l) { xt[l] = alloc<T>(N * EMB); xf[l] = alloc<float>(N * EMB, l == 2 ? "pr_x_final" : (l == 0 ? "pr_x0" : "pr_x1")); }
+        for (int l = 0; l < 2; ++l) {
+            qkv[l] = alloc<T>(N * 3 * EMB); Pat[l] = alloc<float>(B * NH * S * S, l ? "attn_p1" : "attn_p0"); ao[l] = alloc<T>(N * EMB);
+            y1[l] = alloc<float>(N * EMB); st1[l] = alloc<float>(N * 2); x1t[l] = alloc<T>(N * EMB); x1f[l] = alloc<float>(N * EMB);
+            hff[l] = alloc<T>(N * FF); y2[l] = alloc<float>(N * EMB); st2[l] = alloc<float>(N * 2);
+        }
+        xm = alloc<T>(B * EMB); seqf = alloc<float>(B * FCH, "seq_feat"); seqf_t = alloc<T>(B * FCH); pr_logits = alloc<float>(B * PLAN, "pr_logits");
+        probs = alloc<float>(B * PLAN, "pr_probs"); klcat = alloc<float>(B * NCAT); dpp_kl = alloc<float>(B * PLAN); dpr_kl = alloc<float>(B * PLAN);
+        pidx = alloc<int>(B * NCAT, "plan_idx"); pidx_in = alloc<int>(B * NCAT);
+        embg = alloc<T>(SB * 64); Cplan = alloc<float>(B * HID); Cb = alloc<T>(B * HID, "dec_cb");
+        Zx0 = alloc<T>(SB * HID); Zx1 = alloc<T>(SB * HID); H0 = alloc<T>(SB * HID, "dec_h0"); H1 = alloc<T>(SB * HID, "dec_h1");
+        heads = alloc<float>(SB * NHEAD, "heads"); dheads = alloc<T>(SB * NHEAD, "dheads"); rowloss = alloc<float>(SB); a_tcp = alloc<float>(SB * 7, "a_tcp");
+        dH1 = alloc<T>(SB * HID); dZ1 = alloc<T>(SB * HID, "dec_dz1"); dH0 = alloc<T>(SB * HID); dZ0 = alloc<T>(SB * HID, "dec_dz0"); dC = alloc<T>(B * HID);
+        demb = alloc<float>(N * EMB, "demb"); dgoal = alloc<float>(B * GOAL, "dgoal"); dseqf = alloc<float>(B * FCH, "dseq_feat");
+        dplan = alloc<float>(B * PLAN, "dplan"); dprl = alloc<float>(B * PLAN, "dpr_logits"); dppx = alloc<float>(B * (EMB + GOAL));
+        dxa = alloc<float>(N * EMB); dxb = alloc<float>(N * EMB); dy_f = alloc<float>(N * EMB); dxm = alloc<float>(B * EMB);
+        dprl_t = alloc<T>(B * PLAN); dppl_t = alloc<T>(B * PLAN); dseq_t = alloc<T>(B * FCH);
+        dt_a = alloc<T>(std::max<int64_t>(N * FF, 2 * B * HID)); dt_b = alloc<T>(N * 3 * EMB); dt_c = alloc<T>(N * EMB); dgl3_t = alloc<T>(B * GOAL);
+        tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>(HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
+        tA = alloc<T>(tcap); tB = alloc<T>(tcap);
+        partcap = 1024ll * 64 * 576; part = alloc<float>(partcap); cspart = alloc<float>(1024 * 2048);
+        auxrows = alloc<int>(B); sf_m = alloc<T>(B * FCH); im1 = alloc<T>(B * 128); g_m = alloc<T>(B * GOAL); la1 = alloc<T>(B * 128);
+        img = alloc<float>(B * GOAL, "clip_img"); txt = alloc<float>(B * GOAL, "clip_txt"); img_t = alloc<T>(B * GOAL); txt_t = alloc<T>(B * GOAL);
+        dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
+        dim1 = alloc<T>(B * 128); dla1 = alloc<T>(B * 128); dsf_m = alloc<float>(B * FCH); dg_m = alloc<float>(B * GOAL);
+        losses = alloc<float>(8);
+        dwheads_tmp = alloc<float>((int64_t)NHEAD * HID); dbheads_tmp = alloc<float>(NHEAD); dw7_tmp = alloc<float>(128 * 3136);
+        bheads = alloc<float>(NHEAD); wheads = alloc<T>((int64_t)NHEAD * HID); wheadsT = alloc<T>((int64_t)HID * NHEAD);
+        if (alloc_failed) { hulc_set_error("hipMalloc failed while sizing the workspace (B=%d S=%d)", maxB, maxS); return 1; }
+        return 0;
+    }
+
+    // ---------------------------------------------------------------- binding
+    bool has(const std::string& n) const { return tab.count(n) > 0; }
+    const float* pw(const std::string& n) { return P + tab.at(n).off; }
+    float* gw(const std::string& n) { return G + tab.at(n).off; }
+    void bind_lin(LinW& L, const std::string& name, int N, int K, bool bias_suffix = true) {
+        L.W32 = pw(name + (bias_suffix ? ".weight" : "")); L.dW = gw(name + (bias_suffix ? ".weight" : ""));
+        if (bias_suffix) { L.b32 = pw(name + ".bias"); L.db = gw(name + ".bias"); }
+        L.N = N; L.K = K;
+        if (std::is_same<T, float>::value) { L.W = (T*)L.W32; L.own_w = false; }
+        else if (!L.W) { L.W = alloc<T>((int64_t)N * K); L.own_w = true; }
+        if (!L.Wt) L.Wt = alloc<T>((int64_t)N * K);
+    }
+    void bind_conv(ConvW& c, const std::string& name, int O, int I, int K, int S, int nhwc) {
+        c.W32 = pw(name + ".weight"); c.b32 = pw(name + ".bias"); c.dW = gw(name + ".weight"); c.db = gw(name + ".bias");
+        c.O = O; c.I = I; c.KH = c.KW = K; c.S = S; c.nhwc = nhwc;
+        if (!c.Wf) c.Wf = alloc<T>((int64_t)O * I * K * K);
+        if (nhwc && !c.Wd) c.Wd = alloc<T>((int64_t)O * I * K * K);
+    }
+    void bind_enc(EncW& e, const std::string& pre, bool gripper, int IH) {
+        e.gripper = gripper; e.IH = IH; e.H1 = (IH - 8) / 4 + 1; e.H2 = (e.H1 - 4) / 2 + 1; e.H3 = e.H2 - 2;
+        bind_conv(e.c1, pre + "conv_model.0", 32, 3, 8, 4, 0);
+        bind_conv(e.c2, pre + "conv_model.2", 64, 32, 4, 2, 1);
+        bind_conv(e.c3, pre + "conv_model.4", 64, 64, 3, 1, 1);
+        if (gripper) {
+            // fc7 consumes the NHWC flatten: keep packed copies (W, Wt own storage even in fp32 mode)
+            e.fc7.W32 = pw(pre + "conv_model.7.weight"); e.fc7.b32 = pw(pre + "conv_model.7.bias");
+            e.fc7.dW = gw(pre + "conv_model.7.weight"); e.fc7.db = gw(pre + "conv_model.7.bias");
+            e.fc7.N = 128; e.fc7.K = 3136;
+            if (!e.fc7.W) { e.fc7.W = alloc<T>(128 * 3136); e.fc7.Wt = alloc<T>(128 * 3136); e.fc7.own_w = true; }
+        }
+        bind_lin(e.fc1, pre + "fc1.0", 512, 128);
+        bind_lin(e.fc2, pre + "fc2", 64, 512);
+        e.lng = pw(pre + "ln.weight"); e.lnb = pw(pre + "ln.bias"); e.dlng = gw(pre + "ln.weight"); e.dlnb = gw(pre + "ln.bias");
+    }
+    int bind(float* p, float* g, float* m, float* v, int64_t n_, int n, const char* const* names, const int64_t* offs,
+             const int64_t* numels) override {
+        P = p; G = g; AM = m; AV = v; numel = n_;
+        tab.clear();
+        for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
+        try {
+            bind_enc(encS, "perceptual_encoder.rgb_static_encoder.", false, 200);
+            bind_enc(encG, "perceptual_encoder.rgb_gripper_encoder.", true, 84);
+            const char* ppn[5] = {"plan_proposal.fc_model.0", "plan_proposal.fc_model.2", "plan_proposal.fc_model.4", "plan_proposal.fc_model.6",
+                                  "plan_proposal.fc_state.0"};
+            const int ppN[5] = {HID, HID, HID, HID, PLAN}, ppK[5] = {EMB + GOAL, HID, HID, HID, HID};
+            for (int i = 0; i < 5; ++i) bind_lin(pp[i], ppn[i], ppN[i], ppK[i]);
+            const char* vgn[3] = {"visual_goal.mlp.0", "visual_goal.mlp.2", "visual_goal.mlp.4"};
+            const char* lgn[3] = {"language_goal.mlp.1", "language_goal.mlp.3", "language_goal.mlp.5"};
+            const int gN[3] = {HID, HID, GOAL};
+            const int vK[3] = {EMB, HID, HID}, lK[3] = {LANG, HID, HID};
+            for (int i = 0; i < 3; ++i) { bind_lin(vg[i], vgn[i], gN[i], vK[i]); bind_lin(lg[i], lgn[i], gN[i], lK[i]); }
+            ln_vg_g = pw("visual_goal.ln.weight"); ln_vg_b = pw("visual_goal.ln.bias"); d_ln_vg_g = gw("visual_goal.ln.weight"); d_ln_vg_b = gw("visual_goal.ln.bias");
+            ln_lg_g = pw("language_goal.ln.weight"); ln_lg_b = pw("language_goal.ln.bias"); d_ln_lg_g = gw("language_goal.ln.weight"); d_ln_lg_b = gw("language_goal.ln.bias");
+            const std::string pr = "plan_recognition.";
+            pos32 = pw(pr + "position_embeddings.weight"); dpos = gw(pr + "position_embeddings.weight");
+            for (int l = 0; l < 2; ++l) {
+                const std::string L = pr + "transformer_encoder.layers." + std::to_string(l) + ".";
+                tr_in[l].W32 = pw(L + "self_attn.in_proj_weight"); tr_in[l].dW = gw(L + "self_attn.in_proj_weight");
+                tr_in[l].b32 = pw(L + "self_attn.in_proj_bias"); tr_in[l].db = gw(L + "self_attn.in_proj_bias");
+                tr_in[l].N = 3 * EMB; tr_in[l].K = EMB;
+                if (std::is_same<T, float>::value) tr_in[l].W = (T*)tr_in[l].W32; else if (!tr_in[l].W) tr_in[l].W = alloc<T>(3 * EMB * EMB);
+                if (!tr_in[l].Wt) tr_in[l].Wt = alloc<T>(3 * EMB * EMB);
+                bind_lin(tr_out[l], L + "self_attn.out_proj", EMB, EMB);
+                bind_lin(tr_l1[l], L + "linear1", FF, EMB);
+                bind_lin(tr_l2[l], L + "linear2", EMB, FF);
+                tr_n1g[l] = pw(L + "norm1.weight"); tr_n1b[l] = pw(L + "norm1.bias"); d_tr_n1g[l] = gw(L + "norm1.weight"); d_tr_n1b[l] = gw(L + "norm1.bias");
+                tr_n2g[l] = pw(L + "norm2.weight"); tr_n2b[l] = pw(L + "norm2.bias"); d_tr_n2g[l] = gw(L + "norm2.weight"); d_tr_n2b[l] = gw(L + "norm2.bias");
+            }
+            bind_lin(pr_fc, pr + "fc", FCH, EMB);
+            bind_lin(pr_fs, pr + "fc_state.0", PLAN, FCH);
+            const std::string ad = "action_decoder.";
+            wih0_32 = pw(ad + "rnn.weight_ih_l0"); dwih0 = gw(ad + "rnn.weight_ih_l0");
+            bih0 = pw(ad + "rnn.bias_ih_l0"); bhh0 = pw(ad + "rnn.bias_hh_l0"); bih1 = pw(ad + "rnn.bias_ih_l1"); bhh1 = pw(ad + "rnn.bias_hh_l1");
+            dbih0 = gw(ad + "rnn.bias_ih_l0"); dbhh0 = gw(ad + "rnn.bias_hh_l0"); dbih1 = gw(ad + "rnn.bias_ih_l1"); dbhh1 = gw(ad + "rnn.bias_hh_l1");
+            if (std::is_same<T, float>::value) wih0 = (T*)wih0_32; else if (!wih0) wih0 = alloc<T>((int64_t)HID * KIN);
+            if (!wih0T) wih0T = alloc<T>((int64_t)HID * KIN);
+            bind_lin(whh0, ad + "rnn.weight_hh_l0", HID, HID, false);
+            bind_lin(wih1, ad + "rnn.weight_ih_l1", HID, HID, false);
+            bind_lin(whh1, ad + "rnn.weight_hh_l1", HID, HID, false);
+            const char* hn[4] = {"prob_fc", "mean_fc", "log_scale_fc", "gripper_fc"};
+            for (int i = 0; i < 4; ++i) {
+                head_w32[i] = pw(ad + hn[i] + ".weight"); head_b32[i] = pw(ad + hn[i] + ".bias");
+                head_dw[i] = gw(ad + hn[i] + ".weight"); head_db[i] = gw(ad + hn[i] + ".bias");
+            }
+            if (cfg.use_clip) {
+                bind_lin(cl_im0, "proj_vis_lang.mlp_im.0", 128, FCH); bind_lin(cl_im2, "proj_vis_lang.mlp_im.2", GOAL, 128);
+                bind_lin(cl_la0, "proj_vis_lang.mlp_lang.0", 128, GOAL); bind_lin(cl_la2, "proj_vis_lang.mlp_lang.2", GOAL, 128);
+                logit_scale = pw("logit_scale"); dlogit_scale = gw("logit_scale");
+            }
+        } catch (const std::out_of_range&) {
+            hulc_set_error("hulc_bind_params: a required parameter name is missing from the table");
+            return 1;
+        }
+        if (alloc_failed) { hulc_set_error("hipMalloc failed while allocating weight copies"); return 1; }
+        bound = true;
+        return prepare_weights();
+    }
+
+    // ---------------------------------------------------------------- small launch helpers
+    template <typename TS, typename TD>
+    void cast_tr(const TS* src, long long lds_, TD* dst, long long ldd, TD* dstT, long long ldt, int R, int C) {
+        dim3 grid(cdiv(C, 32), cdiv(R, 32));
+        hipLaunchKernelGGL((cast_transpose_kernel<TS, TD>), grid, dim3(256), 0, st, src, lds_, dst, ldd, dstT, ldt, R, C);
+    }
+    static int ldpad(int m) { return (m + 7) / 8 * 8; }
+    template <typename TS, typename TD>
+    void copy2d(const TS* src, long long lds_, TD* dst, long long ldd, int R, int C, int acc, float scale = 1.f) {
+        hipLaunchKernelGGL((copy2d_kernel<TS, TD>), dim3(cdiv((long long)R * C, 256)), dim3(256), 0, st, src, lds_, dst, ldd, R, C, acc, scale);
+    }
+    void colsum(const T* x, long long ld, int M, int N, float* out, float* out2 = nullptr, float scale = 1.f) {
+        int nsplit = std::min(1024, std::max(1, M / 4096));
+        if (nsplit == 1 && !out2) {
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, x, ld, M, N, out, M, 1, scale);
+        } else {
+            int rps = cdiv(M, nsplit);
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, cspart, rps, 0, 1.f);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, cspart, nsplit, N, out, out2, scale);
+        }
+    }
+    // dense NT GEMM with tile selection
+    void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+        if (M >= 512 && N >= 128) launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
+        else launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
+    }
+    static EpiP epi(void* out, bool f32) { EpiP e; e.out = out; e.out_f32 = f32 ? 1 : 0; return e; }
+
+    // Y[M][N] = X[M][K] W^T (+bias) ...
+    void lin_fwd(const T* X, long long ldx, int M, const LinW& L, EpiP ep, long long ldo) {
+        if (!ep.bias) ep.bias = L.b32;
+        gemm(dense<T>(X, M, ldx), dense<T>(L.W, L.N, L.K), dense_out(ldo), ep, M, L.N, L.K);
+    }
+    // weight + bias grads of Y = X W^T: dW[N][K] += dY^T X ; db += colsum(dY).  dY [M][N] dense, X [M][K] (ldx)
+    void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
+        const int mp = ldpad(M);
+        cast_tr<T, T>(dY, N, nullptr, 0, tA, mp, M, N);
+        cast_tr<T, T>(X, ldx, nullptr, 0, tB, mp, M, K);
+        EpiP ep = epi(dW, true); ep.accumulate = 1;
+        gemm(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dense_out(lddw), ep, N, K, M);
+        if (db) colsum(dY, N, M, N, db, db2);
+    }
+    // dX[M][K] = dY[M][N] W   (via the transposed copy Wt [K][N])
+    void lin_dgrad(const T* dY, int M, const LinW& L, EpiP ep, const DenseOut& om) {
+        gemm(dense<T>(dY, M, L.N), dense<T>(L.Wt, L.K, L.N), om, ep, M, L.K, L.N);
+    }
+    void ln_fwd(const float* x, long long ldx, int rows, int n, const float* g, const float* b, T* out, long long ldo, float* outf, long long ldf,
+                float* stats) {
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, rows, n, g, b, out, ldo, outf, ldf, stats);
+    }
+    void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
+                long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db) {
+        hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt);
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, dg, db);
+    }
+
+    // ---------------------------------------------------------------- weight preparation
+    void prep_lin(LinW& L) {
+        if (!L.W32) return;
+        cast_tr<float, T>(L.W32, L.K, L.own_w ? L.W : nullptr, L.K, L.Wt, L.N, L.N, L.K);
+    }
+    void prep_conv(ConvW& c) {
+        const int total = c.O * c.I * c.KH * c.KW;
+        hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, c.W32, c.Wf, c.nhwc ? c.Wd : (T*)nullptr, c.O, c.I, c.KH,
+                           c.KW, c.S, c.nhwc);
+    }
+    int prepare_weights() override {
+        if (!bound) { hulc_set_error("hulc_prepare_weights before hulc_bind_params"); return 1; }
+        for (EncW* e : {&encS, &encG}) {
+            prep_conv(e->c1); prep_conv(e->c2); prep_conv(e->c3);
+            prep_lin(e->fc1); prep_lin(e->fc2);
+            if (e->gripper) {
+                // W7p[o][p*64+c] = W7[o][c*49+p]; then transposed copy
+                hipLaunchKernelGGL((permute_cols_kernel<float, T>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, e->fc7.W32, e->fc7.W, 128, 64, 49, 0, 0);
+                cast_tr<T, T>(e->fc7.W, 3136, nullptr, 0, e->fc7.Wt, 128, 128, 3136);
+            }
+        }
+        for (auto& l : pp) prep_lin(l);
+        for (auto& l : vg) prep_lin(l);
+        for (auto& l : lg) prep_lin(l);
+        for (int l = 0; l < 2; ++l) {
+            cast_tr<float, T>(tr_in[l].W32, EMB, std::is_same<T, float>::value ? nullptr : tr_in[l].W, EMB, tr_in[l].Wt, 3 * EMB, 3 * EMB, EMB);
+            prep_lin(tr_out[l]); prep_lin(tr_l1[l]); prep_lin(tr_l2[l]);
+        }
+        prep_lin(pr_fc); prep_lin(pr_fs); prep_lin(whh0); prep_lin(wih1); prep_lin(whh1);
+        cast_tr<float, T>(wih0_32, KIN, std::is_same<T, float>::value ? nullptr : wih0, KIN, wih0T, HID, HID, KIN);
+        // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
+        int r0 = 0;
+        for (int i = 0; i < 4; ++i) {
+            copy2d<float, T>(head_w32[i], HID, wheads + (int64_t)r0 * HID, HID, head_rows[i], HID, 0);
+            copy2d<float, float>(head_b32[i], 1, bheads + r0, 1, head_rows[i], 1, 0);
+            r0 += head_rows[i];
+        }
+        cast_tr<T, T>(wheads, HID, nullptr, 0, wheadsT, NHEAD, NHEAD, HID);
+        if (cfg.use_clip) { prep_lin(cl_im0); prep_lin(cl_im2); prep_lin(cl_la0); prep_lin(cl_la2); }
+        STAGE("prepare_weights");
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
+        return 0;
+    }
+    int zero_grads() override {
+        if (!bound) { hulc_set_error("hulc_zero_grads before hulc_bind_params"); return 1; }
+        HIP_CHECK(hipMemsetAsync(G, 0, numel * sizeof(float), st));
+        return 0;
+    }
+
+    // ---------------------------------------------------------------- encoders
+    ConvGeom geom(int Nf, int IH, int C, int K, int S) const {
+        ConvGeom g; g.Nf = Nf; g.IH = g.IW = IH; g.C = C; g.KH = g.KW = K; g.S = S; g.OH = g.OW = (IH - K) / S + 1; return g;
+    }
+    void enc_fwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
+        ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
+        {
+            Conv1Loader<T> l{x, g1};
+            EpiP ep = epi(a.a1, false); ep.bias = e.c1.b32; ep.relu = 1;
+            launch_gemm<T, 128, 32>(st, l, dense<T>(e.c1.Wf, 32, 192), dense_out(32), ep, Nf * g1.OH * g1.OW, 32, 192);
+        }
+        {
+            ConvNHWCLoader<T> l{a.a1, g2};
+            EpiP ep = epi(a.a2, false); ep.bias = e.c2.b32; ep.relu = 1;
+            launch_gemm<T, 128, 64>(st, l, dense<T>(e.c2.Wf, 64, 512), dense_out(64), ep, Nf * g2.OH * g2.OW, 64, 512);
+        }
+        {
+            ConvNHWCLoader<T> l{a.a2, g3};
+            EpiP ep = epi(a.a3, false); ep.bias = e.c3.b32; ep.relu = 1;
+            launch_gemm<T, 128, 64>(st, l, dense<T>(e.c3.Wf, 64, 576), dense_out(64), ep, Nf * g3.OH * g3.OW, 64, 576);
+        }
+        const T* fin; int fk;
+        if (!e.gripper) {
+            hipLaunchKernelGGL((spatial_softmax_fwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, 64, a.ss, (float*)nullptr, a.ssstats);
+            fin = a.ss; fk = 128;
+        } else {
+            EpiP ep = epi(a.g0, false); ep.relu = 1;
+            lin_fwd(a.a3, 3136, Nf, e.fc7, ep, 128);
+            fin = a.g0; fk = 128;
+        }
+        { EpiP ep = epi(a.f1, false); ep.relu = 1; lin_fwd(fin, fk, Nf, e.fc1, ep, 512); }
+        { EpiP ep = epi(a.f2, true); lin_fwd(a.f1, 512, Nf, e.fc2, ep, 64); }
+        ln_fwd(a.f2, 64, Nf, 64, e.lng, e.lnb, emb + col0, EMB, nullptr, 0, a.lnst);
+    }
+    void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {
+        const int Kc = c.I * c.KH * c.KW;
+        const long long npix = (long long)g.Nf * g.OH * g.OW;
+        int nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 4096), partcap / ((long long)c.O * Kc));
+        nsplit = std::min(nsplit, 512);
+        EpiP ep = epi(part, true); ep.z_stride = (long long)c.O * Kc;
+        PixMajorLoaderT<T> la{}; la.p = dy; la.rows = c.O; la.ld = c.O;
+        if (conv1) {
+            Conv1LoaderT<T> lb{(const float*)xin, g};
+            launch_gemm<T, 32, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
+        } else {
+            ConvNHWCLoaderT<T> lb{(const T*)xin, g};
+            launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
+        }
+        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256)), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc, c.dW, c.O, c.I, c.KH,
+                           c.KW, c.nhwc);
+        colsum(dy, c.O, (int)npix, c.O, c.db);
+    }
+    void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask) {
+        ConvDgradLoader<T> l{dy, g, c.O};
+        DgradOut om{g};
+        EpiP ep = epi(dx, false); ep.mask = mask;
+        const int ncls = g.S * g.S;
+        const int Kd = (g.KH / g.S) * (g.KW / g.S) * c.O;
+        const int Ic = (g.IH + g.S - 1) / g.S;
+        const int Mmax = g.Nf * Ic * Ic;
+        for (int zc = 0; zc < ncls; ++zc)   // one launch per parity class: the packed weight slab differs per class
+            launch_dgrad(l, dense<T>(c.Wd + (long long)zc * c.I * Kd, c.I, Kd), om, ep, Mmax, c.I, Kd, zc);
+    }
+    void launch_dgrad(const ConvDgradLoader<T>& l, const DenseLoader<T>& wb, const DgradOut& om, const EpiP& ep, int Mmax, int N, int K, int zc) {
+        // one parity class per launch: wrap the loader/out-map so that blockIdx.z == 0 maps to class zc
+        ClassShift<ConvDgradLoader<T>> ls{l, zc};
+        ClassShiftOut<DgradOut> os{om, zc};
+        if (N <= 32) launch_gemm<T, 128, 32>(st, ls, wb, os, ep, Mmax, N, K);
+        else launch_gemm<T, 128, 64>(st, ls, wb, os, ep, Mmax, N, K);
+    }
+    template <typename L> struct ClassShift {
+        static constexpr bool TRANSPOSED = false;
+        L l; int zc;
+        using Row = typename L::Row;
+        DEVI int num_rows(int) const { return l.num_rows(zc); }
+        DEVI Row row(int r, int) const { return l.row(r, zc); }
+        DEVI void fetch(const Row& c, int k0, int kend, T (&v)[8]) const { l.fetch(c, k0, kend, v); }
+    };
+    template <typename O> struct ClassShiftOut {
+        O o; int zc;
+        DEVI long long offset(int r, int) const { return o.offset(r, zc); }
+    };
+    void enc_bwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
+        ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
+        // LN bwd on demb[:, col0:col0+64]
+        ln_bwd(demb + col0, EMB, a.f2, 64, a.lnst, e.lng, Nf, 64, nullptr, 0, 0, d_f2t, 64, e.dlng, e.dlnb);
+        // fc2
+        { EpiP ep = epi(d_f1, false); ep.mask = a.f1; lin_dgrad(d_f2t, Nf, e.fc2, ep, dense_out(512)); }
+        lin_wgrad(d_f2t, a.f1, 512, Nf, 64, 512, e.fc2.dW, 512, e.fc2.db);
+        const int H3 = e.H3;
+        if (!e.gripper) {
+            { EpiP ep = epi(d_ss, true); lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
+            lin_wgrad(d_f1, a.ss, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
+            hipLaunchKernelGGL((spatial_softmax_bwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, 64, dact3);
+        } else {
+            { EpiP ep = epi(d_g0, false); ep.mask = a.g0; lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
+            lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
+            { EpiP ep = epi(dact3, false); ep.mask = a.a3; lin_dgrad(d_g0, Nf, e.fc7, ep, dense_out(3136)); }
+            // dW7 in packed (NHWC) column order -> temp, then permute-accumulate into the torch-layout grad
+            HIP_CHECK_VOID(hipMemsetAsync(dw7_tmp, 0, sizeof(float) * 128 * 3136, st));
+            lin_wgrad(d_g0, a.a3, 3136, Nf, 128, 3136, dw7_tmp, 3136, e.fc7.db);
+            hipLaunchKernelGGL((permute_cols_kernel<float, float>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, dw7_tmp, e.fc7.dW, 128, 64, 49, 1, 1);
+        }
+        conv_wgrad(e.c3, dact3, a.a2, g3, false);
+        conv_dgrad(e.c3, dact3, g3, dact2, a.a2);
+        conv_wgrad(e.c2, dact2, a.a1, g2, false);
+        conv_dgrad(e.c2, dact2, g2, dact1, a.a1);
+        conv_wgrad(e.c1, dact1, x, g1, true);
+    }
+
+    // ---------------------------------------------------------------- MLP helper (ReLU between layers, none after last)
+    // acts[i] = output of layer i (T) ; last layer output fp32 (outf)
+    void mlp_fwd(const T* x, long long ldx, int M, LinW* L, int n, T** acts, float* outf, T* outt) {
+        const T* in = x; long long ld = ldx;
+        for (int i = 0; i < n; ++i) {
+            if (i < n - 1) { EpiP ep = epi(acts[i], false); ep.relu = 1; lin_fwd(in, ld, M, L[i], ep, L[i].N); in = acts[i]; ld = L[i].N; }
+            else {
+                if (outf) { EpiP ep = epi(outf, true); lin_fwd(in, ld, M, L[i], ep, L[i].N); }
+                if (outt) { EpiP ep = epi(outt, false); lin_fwd(in, ld, M, L[i], ep, L[i].N); }
+            }
+        }
+    }
+    // dy: T [M][N_last]; x: first-layer input (ldx). dxf: optional fp32 output (accumulating) with map
+    void mlp_bwd(const T* dy, const T* x, long long ldx, int M, LinW* L, int n, T** acts, T* s0, T* s1, float* dxf, const DenseOut* om, int dx_acc) {
+        const T* d = dy;
+        T* scratch[2] = {s0, s1};
+        for (int i = n - 1; i >= 0; --i) {
+            const T* in = i > 0 ? acts[i - 1] : x;
+            const long long ld = i > 0 ? L[i - 1].N : ldx;
+            lin_wgrad(d, in, ld, M, L[i].N, L[i].K, L[i].dW, L[i].K, L[i].db);
+            if (i > 0) {
+                T* o = scratch[i & 1];
+                EpiP ep = epi(o, false); ep.mask = acts[i - 1];
+                lin_dgrad(d, M, L[i], ep, dense_out(L[i].K));
+                d = o;
+            } else if (dxf) {
+                EpiP ep = epi(dxf, true); ep.accumulate = dx_acc;
+                lin_dgrad(d, M, L[i], ep, *om);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- forward
+    int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) override {
+        if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
+        if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
+            hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
+            return 1;
+        }
+        if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
+        cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false;
+        const int B = b->B, S = b->S, N = B * S, SB = S * B;
+        const bool hulc = cfg.kind == HULC_KIND_HULC;
+        const float dp = cfg.dropout_p;
+        HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
+        // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
+        enc_fwd(encS, aS, b->rgb_static, N, 0);
+        STAGE("enc_static_fwd");
+        enc_fwd(encG, aG, b->rgb_gripper, N, 64);
+        STAGE("enc_gripper_fwd");
+        // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
+        {
+            T* acts[2] = {gl1, gl2};
+            if (b->is_lang) {
+                hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * LANG, 256)), dim3(256), 0, st, b->lang, lang_t, (long long)B * LANG);
+                mlp_fwd(lang_t, LANG, B, lg, 3, acts, gl3, nullptr);
+                ln_fwd(gl3, GOAL, B, GOAL, ln_lg_g, ln_lg_b, goal_t, GOAL, nullptr, 0, goal_st);
+            } else {
+                mlp_fwd(emb + (long long)(S - 1) * EMB, (long long)S * EMB, B, vg, 3, acts, gl3, nullptr);
+                ln_fwd(gl3, GOAL, B, GOAL, ln_vg_g, ln_vg_b, goal_t, GOAL, nullptr, 0, goal_st);
+            }
+        }
+        // ---- plan proposal (plan_proposal_net.py:42-47)
+        if (hulc) {
+            hipLaunchKernelGGL((concat_pp_kernel<T>), dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, emb, (long long)S * EMB, EMB, goal_t, GOAL, B, ppx);
+            mlp_fwd(ppx, EMB + GOAL, B, pp, 5, ppa, pp_logits, nullptr);
+        }
+        STAGE("goal+pp_fwd");
+        // ---- plan recognition transformer (plan_recognition_net.py:94-117)
+        hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0));
+        for (int l = 0; l < 2; ++l) {
+            { EpiP ep = epi(qkv[l], false); lin_fwd(xt[l], EMB, N, tr_in[l], ep, 3 * EMB); }
+            hipLaunchKernelGGL((attention_fwd_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
+            { EpiP ep = epi(y1[l], true); ep.res = xf[l]; ep.res_f32 = 1; ep.res_ld = EMB; ep.res_late = 1; ep.drop_p = dp; ep.drop_seed = site_seed(2 + 4 * l);
+              lin_fwd(ao[l], EMB, N, tr_out[l], ep, EMB); }
+            ln_fwd(y1[l], EMB, N, EMB, tr_n1g[l], tr_n1b[l], x1t[l], EMB, x1f[l], EMB, st1[l]);
+            { EpiP ep = epi(hff[l], false); ep.relu = 1; ep.drop_p = dp; ep.drop_seed = site_seed(3 + 4 * l); lin_fwd(x1t[l], EMB, N, tr_l1[l], ep, FF); }
+            { EpiP ep = epi(y2[l], true); ep.res = x1f[l]; ep.res_f32 = 1; ep.res_ld = EMB; ep.res_late = 1; ep.drop_p = dp; ep.drop_seed = site_seed(4 + 4 * l);
+              lin_fwd(hff[l], FF, N, tr_l2[l], ep, EMB); }
+            ln_fwd(y2[l], EMB, N, EMB, tr_n2g[l], tr_n2b[l], xt[l + 1], EMB, xf[l + 1], EMB, st2[l]);
+        }
+        // mean over S commutes with the affine fc (:113-114): seq_feat = fc(mean_t x)
+        hipLaunchKernelGGL((mean_over_s_kernel<T>), dim3(cdiv(B * EMB, 256)), dim3(256), 0, st, xf[2], B, S, EMB, xm);
+        { EpiP ep = epi(seqf, true); lin_fwd(xm, EMB, B, pr_fc, ep, FCH); }
+        hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, seqf, seqf_t, (long long)B * FCH);
+        { EpiP ep = epi(pr_logits, true); lin_fwd(seqf_t, FCH, B, pr_fs, ep, PLAN); }
+        STAGE("plan_recognition_fwd");
+        // ---- sample + KL (hulc.py:289-296, 539-561)
+        if (hulc) {
+            const int* idx_in = nullptr;
+            if (b->plan_idx) { HIP_CHECK(hipMemcpyAsync(pidx_in, b->plan_idx, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); idx_in = pidx_in; }
+            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / B, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / B;
+            hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, idx_in, pidx, probs, klcat, dpp_kl,
+                               dpr_kl, wpp, wpr, site_seed(20));
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, B * NCAT, cfg.kl_beta / B, losses + 1);
+        }
+        // ---- action decoder (logistic_decoder_rnn.py:260-287): plan/goal terms hoisted out of the time loop
+        {
+            // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
+            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * 64, 256)), dim3(256), 0, st, emb, embg, B, S);
+            hipLaunchKernelGGL(plan_gather_kernel, dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0_32, KIN, pidx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
+            { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
+              gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + 64, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
+            { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
+              gemm(dense<T>(embg, SB, 64), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, 64); }
+            rnn_fwd(Zx0, H0, whh0, B, S);
+            { EpiP ep = epi(Zx1, false); ep.bias = bih1; ep.bias2 = bhh1;
+              gemm(dense<T>(H0, SB, HID), dense<T>(wih1.W, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            rnn_fwd(Zx1, H1, whh1, B, S);
+            { EpiP ep = epi(heads, true); ep.bias = bheads;
+              gemm(dense<T>(H1, SB, HID), dense<T>(wheads, NHEAD, HID), dense_out(NHEAD), ep, SB, NHEAD, HID); }
+            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, lw / (float)SB, rowloss, a_tcp, dheads);
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, 1.f / SB, losses + 0);
+        }
+        STAGE("decoder_fwd");
+        // ---- CLIP auxiliary loss (hulc.py:650-695), lang modality, masked rows
+        clip_n = 0;
+        if (b->is_lang && cfg.use_clip && b->n_aux > 0) {
+            const int n = b->n_aux;
+            if (n > 64 || n > B) { hulc_set_error("clip aux rows n=%d unsupported (max 64, <= B)", n); return 1; }
+            clip_n = n;
+            HIP_CHECK(hipMemcpyAsync(auxrows, b->aux_rows, sizeof(int) * n, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((gather_rows_kernel<T, T>), dim3(cdiv(n * FCH, 256)), dim3(256), 0, st, seqf_t, (long long)FCH, auxrows, n, FCH, sf_m);
+            hipLaunchKernelGGL((gather_rows_kernel<T, T>), dim3(cdiv(n * GOAL, 256)), dim3(256), 0, st, goal_t, (long long)GOAL, auxrows, n, GOAL, g_m);
+            { EpiP ep = epi(im1, false); ep.relu = 1; lin_fwd(sf_m, FCH, n, cl_im0, ep, 128); }
+            { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
+            { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
+            { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
+            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, losses + 2, dimg, dtxt, dlogit_scale);
+        }
+        STAGE("clip_fwd");
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in forward"); return 1; }
+        have_fwd = true;
+        if (out) {
+            // [total_mod, kl, action, clip]
+            hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses);
+            if (on_host) { HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st)); }
+            else HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        return 0;
+    }
+    int clip_n = 0;
+
+    // H[t] = relu(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID]
+    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S) {
+        const long long BH = (long long)B * HID;
+        hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
+        for (int t = 1; t < S; ++t) {
+            EpiP ep = epi(H + t * BH, false); ep.res = Zx + t * BH; ep.res_ld = HID; ep.relu = 1;
+            gemm(dense<T>(H + (t - 1) * BH, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
+        }
+    }
+    // dZ[t] = (dH[t] + dZ[t+1] Whh) * (H[t] > 0)
+    void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S) {
+        const long long BH = (long long)B * HID;
+        hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH + (S - 1) * BH, H + (S - 1) * BH, dZ + (S - 1) * BH, BH);
+        for (int t = S - 2; t >= 0; --t) {
+            EpiP ep = epi(dZ + t * BH, false); ep.res = dH + t * BH; ep.res_ld = HID; ep.mask = H + t * BH;
+            gemm(dense<T>(dZ + (t + 1) * BH, B, HID), dense<T>(whh.Wt, HID, HID), dense_out(HID), ep, B, HID, HID);
+        }
+    }
+
+    // ---------------------------------------------------------------- backward
+    int backward() override {
+        if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
+        const hulc_batch* b = &cur;
+        const int B = b->B, S = b->S, N = B * S, SB = S * B;
+        const bool hulc = cfg.kind == HULC_KIND_HULC;
+        const float dp = cfg.dropout_p;
+        const long long BH = (long long)B * HID;
+        HIP_CHECK(hipMemsetAsync(demb, 0, sizeof(float) * N * EMB, st));
+        HIP_CHECK(hipMemsetAsync(dgoal, 0, sizeof(float) * B * GOAL, st));
+        HIP_CHECK(hipMemsetAsync(dseqf, 0, sizeof(float) * B * FCH, st));
+        bool have_dseq = false;
+        // ---- CLIP backward
+        if (clip_n > 0) {
+            const int n = clip_n;
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, dimg, dimg_t, (long long)n * GOAL);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, dtxt, dtxt_t, (long long)n * GOAL);
+            // image branch: img = im2(relu(im0(sf)))
+            lin_wgrad(dimg_t, im1, 128, n, GOAL, 128, cl_im2.dW, 128, cl_im2.db);
+            { EpiP ep = epi(dim1, false); ep.mask = im1; lin_dgrad(dimg_t, n, cl_im2, ep, dense_out(128)); }
+            lin_wgrad(dim1, sf_m, FCH, n, 128, FCH, cl_im0.dW, FCH, cl_im0.db);
+            { EpiP ep = epi(dsf_m, true); lin_dgrad(dim1, n, cl_im0, ep, dense_out(FCH)); }
+            hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(n * FCH, 256)), dim3(256), 0, st, dsf_m, auxrows, n, FCH, dseqf, (long long)FCH);
+            // text branch
+            lin_wgrad(dtxt_t, la1, 128, n, GOAL, 128, cl_la2.dW, 128, cl_la2.db);
+            { EpiP ep = epi(dla1, false); ep.mask = la1; lin_dgrad(dtxt_t, n, cl_la2, ep, dense_out(128)); }
+            lin_wgrad(dla1, g_m, GOAL, n, 128, GOAL, cl_la0.dW, GOAL, cl_la0.db);
+            { EpiP ep = epi(dg_m, true); lin_dgrad(dla1, n, cl_la0, ep, dense_out(GOAL)); }
+            hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(n * GOAL, 256)), dim3(256), 0, st, dg_m, auxrows, n, GOAL, dgoal, (long long)GOAL);
+            have_dseq = true;
+        }
+        // ---- decoder backward
+        STAGE("clip_bwd");
+        {
+            // heads
+            { EpiP ep = epi(dH1, false); gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
+            HIP_CHECK(hipMemsetAsync(dwheads_tmp, 0, sizeof(float) * NHEAD * HID, st));
+            HIP_CHECK(hipMemsetAsync(dbheads_tmp, 0, sizeof(float) * NHEAD, st));
+            lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
+            int r0 = 0;
+            for (int i = 0; i < 4; ++i) {
+                copy2d<float, float>(dwheads_tmp + (int64_t)r0 * HID, HID, head_dw[i], HID, head_rows[i], HID, 1);
+                copy2d<float, float>(dbheads_tmp + r0, 1, head_db[i], 1, head_rows[i], 1, 1);
+                r0 += head_rows[i];
+            }
+            // layer 1 BPTT
+            rnn_bwd(dH1, H1, dZ1, whh1, B, S);
+            {
+                const int mp = ldpad(SB);
+                cast_tr<T, T>(dZ1, HID, nullptr, 0, tA, mp, SB, HID);
+                cast_tr<T, T>(H1, HID, nullptr, 0, tB, mp, SB, HID);
+                if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
+                  gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
+                cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
+                { EpiP ep = epi(wih1.dW, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
+                colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
+            }
+            { EpiP ep = epi(dH0, false); gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            // layer 0 BPTT
+            rnn_bwd(dH0, H0, dZ0, whh0, B, S);
+            {
+                const int mp = ldpad(SB);
+                cast_tr<T, T>(dZ0, HID, nullptr, 0, tA, mp, SB, HID);
+                cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
+                if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
+                  gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
+                cast_tr<T, T>(embg, 64, nullptr, 0, tB, mp, SB, 64);
+                { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, 64, mp), dense_out(KIN), ep, HID, 64, SB); }
+            }
+            // d emb (gripper half), scattered back to (B,S,128)[..., 64:128]
+            { EpiP ep = epi(demb + 64, true); ep.accumulate = 1;
+              gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, 64, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, 64, HID); }
+            hipLaunchKernelGGL((sum_over_t_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dZ0, S, BH, dC);
+            colsum(dC, HID, B, HID, dbih0, dbhh0);
+            { EpiP ep = epi(dgoal, true); ep.accumulate = 1;
+              gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + 64) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
+            {
+                const int mp = ldpad(B);
+                cast_tr<T, T>(dC, HID, nullptr, 0, tA, mp, B, HID);
+                cast_tr<T, T>(goal_t, GOAL, nullptr, 0, tB, mp, B, GOAL);
+                EpiP ep = epi(dwih0 + dec_plan + 64, true); ep.accumulate = 1;
+                gemm(dense<T>(tA, HID, mp), dense<T>(tB, GOAL, mp), dense_out(KIN), ep, HID, GOAL, B);
+            }
+            if (hulc) {
+                { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, PLAN, HID), dense_out(PLAN), ep, B, PLAN, HID); }
+                hipLaunchKernelGGL((plan_scatter_grad_kernel<T>), dim3(cdiv(HID * NCAT, 256)), dim3(256), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
+            }
+        }
+        STAGE("decoder_bwd");
+        // ---- straight-through + KL -> logits grads; plan proposal backward
+        if (hulc) {
+            hipLaunchKernelGGL(st_softmax_bwd_kernel, dim3(B * NCAT), dim3(64), 0, st, probs, dplan, dpr_kl, NCLS, dprl);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dprl, dprl_t, (long long)B * PLAN);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dpp_kl, dppl_t, (long long)B * PLAN);
+            DenseOut om = dense_out(EMB + GOAL);
+            mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
+            copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
+            copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            // fc_state of plan recognition
+            lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
+            { EpiP ep = epi(dseqf, true); ep.accumulate = 1; lin_dgrad(dprl_t, B, pr_fs, ep, dense_out(FCH)); }
+            have_dseq = true;
+        }
+        // ---- plan recognition backward
+        if (have_dseq) {
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, dseqf, dseq_t, (long long)B * FCH);
+            lin_wgrad(dseq_t, xm, EMB, B, FCH, EMB, pr_fc.dW, EMB, pr_fc.db);
+            { EpiP ep = epi(dxm, true); lin_dgrad(dseq_t, B, pr_fc, ep, dense_out(EMB)); }
+            float* dx = dxa; float* dnext = dxb;
+            hipLaunchKernelGGL(bcast_over_s_kernel, dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dxm, B, S, EMB, dx);
+            for (int l = 1; l >= 0; --l) {
+                // LN2
+                ln_bwd(dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, nullptr, 0, d_tr_n2g[l], d_tr_n2b[l]);
+                hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dy_f, (float*)nullptr, dt_c, (long long)N * EMB, dp, site_seed(4 + 4 * l));
+                lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
+                { EpiP ep = epi(dt_a, false); ep.mask = hff[l]; ep.alpha = dp > 0.f ? 1.f / (1.f - dp) : 1.f; lin_dgrad(dt_c, N, tr_l2[l], ep, dense_out(FF)); }
+                lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
+                { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
+                // LN1
+                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, nullptr, 0, d_tr_n1g[l], d_tr_n1b[l]);
+                hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dy_f, (float*)nullptr, dt_c, (long long)N * EMB, dp, site_seed(2 + 4 * l));
+                lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
+                { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
+                hipLaunchKernelGGL((attention_bwd_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
+                { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
+            }
+            // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
+            hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dx, dy_f, (T*)nullptr, (long long)N * EMB, dp, site_seed(0));
+            copy2d<float, float>(dy_f, EMB, demb, EMB, N, EMB, 1);
+            hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dy_f, B, S, EMB, dpos);
+        }
+        STAGE("plan_recognition_bwd");
+        // ---- goal encoder backward
+        {
+            T* acts[2] = {gl1, gl2};
+            if (b->is_lang) {
+                ln_bwd(dgoal, GOAL, gl3, GOAL, goal_st, ln_lg_g, B, GOAL, nullptr, 0, 0, dgl3_t, GOAL, d_ln_lg_g, d_ln_lg_b);
+                mlp_bwd(dgl3_t, lang_t, LANG, B, lg, 3, acts, dt_a, dt_a + (long long)B * HID, nullptr, nullptr, 0);
+            } else {
+                ln_bwd(dgoal, GOAL, gl3, GOAL, goal_st, ln_vg_g, B, GOAL, nullptr, 0, 0, dgl3_t, GOAL, d_ln_vg_g, d_ln_vg_b);
+                DenseOut om = dense_out((long long)S * EMB);
+                mlp_bwd(dgl3_t, emb + (long long)(S - 1) * EMB, (long long)S * EMB, B, vg, 3, acts, dt_a, dt_a + (long long)B * HID,
+                        demb + (long long)(S - 1) * EMB, &om, 1);
+            }
+        }
+        // ---- encoders backward
+        enc_bwd(encS, aS, b->rgb_static, N, 0);
+        STAGE("enc_static_bwd");
+        enc_bwd(encG, aG, b->rgb_gripper, N, 64);
+        STAGE("enc_gripper_bwd");
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
+        have_fwd = false;
+        return 0;
+    }
+
+    int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) override {
+        if (!bound) { hulc_set_error("hulc_adam_step before hulc_bind_params"); return 1; }
+        const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+        const double bc1d = 1.0 - pow((double)b1, (double)step), bc2d = 1.0 - pow((double)b2, (double)step);
+        (void)bc1; (void)bc2;
+        hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale);
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("adam launch failed"); return 1; }
+        return prepare_weights();
+    }
+
+    int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) override {
+        auto it = named.find(name);
+        if (it == named.end()) { hulc_set_error("hulc_get_tensor: unknown tensor '%s'", name); return 1; }
+        const Named& t = it->second;
+        int64_t cnt = std::min<int64_t>(cap, t.n);
+        *n = cnt;
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (t.kind == 0) { HIP_CHECK(hipMemcpy(out, t.p, cnt * sizeof(float), hipMemcpyDeviceToHost)); }
+        else if (t.kind == 1) {
+            std::vector<T> tmp(cnt);
+            HIP_CHECK(hipMemcpy(tmp.data(), t.p, cnt * sizeof(T), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < cnt; ++i) out[i] = host_to_f(tmp[i]);
+        } else {
+            std::vector<int> tmp(cnt);
+            HIP_CHECK(hipMemcpy(tmp.data(), t.p, cnt * sizeof(int), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < cnt; ++i) out[i] = (float)tmp[i];
+        }
+        return 0;
+    }
+    static float host_to_f(float x) { return x; }
+    static float host_to_f(bf16_t x) { uint32_t u = ((uint32_t)x) << 16; float f; memcpy(&f, &u, 4); return f; }
+    int get_plan_idx(int32_t* out, int64_t cap) override {
+        HIP_CHECK(hipStreamSynchronize(st));
+        int64_t cnt = std::min<int64_t>(cap, (int64_t)cur.B * NCAT);
+        HIP_CHECK(hipMemcpy(out, pidx, cnt * sizeof(int), hipMemcpyDeviceToHost));
+        return 0;
+    }
+};

@@ -1,0 +1,423 @@
+// hulc_amd/csrc/gemm.h — the one MFMA GEMM core of the HULC step (gfx950 / CDNA4).
+//
+//   C[M][N] (+)= epilogue( A[M][K] * B[N][K]^T )       ("NT": both operands reduction-contiguous in LDS)
+//
+// * 256 threads = 4 waves (2x2), tile BM x BN x 32, one LDS buffer + register prefetch of the next K slab
+//   (global latency hides behind the MFMAs of the current slab; two barriers per slab).
+// * bf16 path: v_mfma_f32_16x16x32_bf16, fragments by ds_read_b128 from an [row][32+8] LDS image;
+//   fp32 path (parity mode): v_mfma_f32_16x16x4_f32 (exact f32 FMA chain), [row][32+2] image.
+// * Operands come through *loader* functors, which is how the convolutions become implicit GEMMs without an
+//   im2col buffer: a loader maps (row, k) -> global address (NCHW fp32 frames for conv1, NHWC activations
+//   for conv2/3, zero-padded dY gathers for dgrad).  "Transposed" loaders fetch reduction-major data
+//   (dY[pix][co], patch[pix][k]) with coalesced vector loads and transpose on the LDS write — the wgrad path.
+// * Output goes through an *output map* (dense with 2-level row map, conv-dgrad parity scatter) and a fused
+//   runtime epilogue: alpha, bias(es), residual (optionally row-broadcast), ReLU, ReLU-mask, dropout,
+//   accumulate, fp32 or T store, split-K partial slabs.
+#pragma once
+#include "common.h"
+
+struct EpiP {
+    void* out = nullptr;
+    int out_f32 = 0;
+    int accumulate = 0;
+    long long z_stride = 0;      // element offset between split-K partial slabs
+    const float* bias = nullptr;
+    const float* bias2 = nullptr;
+    const void* res = nullptr;   // residual, dense [rows][res_ld]
+    int res_f32 = 0;
+    long long res_ld = 0;
+    int res_rowmod = 0;          // >0: residual row = r % res_rowmod (broadcast over time)
+    int res_late = 0;            // 0: residual added before relu/mask (RNN); 1: after dropout (transformer x + drop(f(x)))
+    const void* mask = nullptr;  // T*, same element offsets as out: v *= (mask > 0)
+    int relu = 0;
+    float alpha = 1.f;
+    float drop_p = 0.f;          // inverted dropout applied after relu/mask (seeded by element offset)
+    unsigned long long drop_seed = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// loaders
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct DenseLoader {   // rows x K, K contiguous; row r lives at (r / R1) * s0 + (r % R1) * s1
+    static constexpr bool TRANSPOSED = false;
+    const T* p;
+    int rows;
+    int R1;
+    long long s0, s1;
+    struct Row { const T* base; bool ok; };
+    DEVI int num_rows(int) const { return rows; }
+    DEVI Row row(int r, int) const {
+        Row c;
+        c.ok = r < rows;
+        long long off = c.ok ? ((long long)(r / R1) * s0 + (long long)(r % R1) * s1) : 0;
+        c.base = p + off;
+        return c;
+    }
+    DEVI void fetch(const Row& c, int k0, int kend, T (&v)[8]) const {
+        if (!c.ok || k0 >= kend) { zero8<T>(v); return; }
+        load8_guard<T>(c.base + k0, kend - k0, v);
+    }
+};
+template <typename T>
+static inline DenseLoader<T> dense(const T* p, int rows, long long ld) {
+    DenseLoader<T> l; l.p = p; l.rows = rows; l.R1 = 0x7fffffff; l.s0 = 0; l.s1 = ld; return l;
+}
+template <typename T>
+static inline DenseLoader<T> dense_map(const T* p, int rows, int R1, long long s0, long long s1) {
+    DenseLoader<T> l; l.p = p; l.rows = rows; l.R1 = R1; l.s0 = s0; l.s1 = s1; return l;
+}
+
+// conv geometry shared by the conv loaders
+struct ConvGeom {
+    int Nf;          // frames
+    int IH, IW, C;   // input
+    int OH, OW;      // output
+    int KH, KW, S;   // kernel, stride
+};
+
+// conv1: fp32 NCHW frames (the boundary layout, hulc.py:395-414), K order = (c, kh, kw) = torch weight order
+template <typename T>
+struct Conv1Loader {
+    static constexpr bool TRANSPOSED = false;
+    const float* x;
+    ConvGeom g;
+    struct Row { const float* base; bool ok; };
+    DEVI int num_rows(int) const { return g.Nf * g.OH * g.OW; }
+    DEVI Row row(int r, int) const {
+        Row c;
+        c.ok = r < g.Nf * g.OH * g.OW;
+        int n = r / (g.OH * g.OW), rem = r % (g.OH * g.OW);
+        int oh = rem / g.OW, ow = rem % g.OW;
+        c.base = c.ok ? x + ((long long)n * g.C * g.IH + oh * g.S) * g.IW + ow * g.S : x;
+        return c;
+    }
+    DEVI void fetch(const Row& c, int k0, int kend, T (&v)[8]) const {   // KW == 8: one (c,kh) row per piece
+        if (!c.ok || k0 >= kend) { zero8<T>(v); return; }
+        int ck = k0 >> 3;
+        int ch = ck / g.KH, kh = ck % g.KH;
+        const float* p = c.base + ((long long)ch * g.IH + kh) * g.IW;
+        float f[8];
+        load8<float>(p, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = from_f<T>(f[i]);
+    }
+};
+
+// conv2/3: NHWC activations of T, K order = (kh, kw, ci); KW*C % 8 == 0
+template <typename T>
+struct ConvNHWCLoader {
+    static constexpr bool TRANSPOSED = false;
+    const T* x;
+    ConvGeom g;
+    struct Row { const T* base; bool ok; };
+    DEVI int num_rows(int) const { return g.Nf * g.OH * g.OW; }
+    DEVI Row row(int r, int) const {
+        Row c;
+        c.ok = r < g.Nf * g.OH * g.OW;
+        int n = r / (g.OH * g.OW), rem = r % (g.OH * g.OW);
+        int oh = rem / g.OW, ow = rem % g.OW;
+        c.base = c.ok ? x + (((long long)n * g.IH + oh * g.S) * g.IW + ow * g.S) * g.C : x;
+        return c;
+    }
+    DEVI void fetch(const Row& c, int k0, int kend, T (&v)[8]) const {
+        if (!c.ok || k0 >= kend) { zero8<T>(v); return; }
+        int rowlen = g.KW * g.C;
+        int kh = k0 / rowlen, off = k0 % rowlen;
+        load8<T>(c.base + (long long)kh * g.IW * g.C + off, v);
+    }
+};
+
+// conv dgrad: rows = input pixels of parity class zc=(ph,pw); K order = (a, b, co), taps kh = ph + S*a, kw = pw + S*b
+template <typename T>
+struct ConvDgradLoader {
+    static constexpr bool TRANSPOSED = false;
+    const T* dy;     // [Nf][OH][OW][CO]
+    ConvGeom g;      // geometry of the forward conv (C = its input channels)
+    int CO;
+    struct Row { int n, i, j; bool ok; };
+    DEVI void cls(int zc, int& ph, int& pw, int& Ic, int& Jc) const {
+        ph = zc / g.S; pw = zc % g.S;
+        Ic = (g.IH - ph + g.S - 1) / g.S; Jc = (g.IW - pw + g.S - 1) / g.S;
+    }
+    DEVI int num_rows(int zc) const { int ph, pw, Ic, Jc; cls(zc, ph, pw, Ic, Jc); return g.Nf * Ic * Jc; }
+    DEVI Row row(int r, int zc) const {
+        int ph, pw, Ic, Jc; cls(zc, ph, pw, Ic, Jc);
+        Row c;
+        c.ok = r < g.Nf * Ic * Jc;
+        c.n = r / (Ic * Jc);
+        int rem = r % (Ic * Jc);
+        c.i = rem / Jc; c.j = rem % Jc;
+        return c;
+    }
+    DEVI void fetch(const Row& c, int k0, int kend, T (&v)[8]) const {
+        if (!c.ok || k0 >= kend) { zero8<T>(v); return; }
+        int tap = k0 / CO, co = k0 % CO;
+        int TB = g.KW / g.S;
+        int a = tap / TB, b = tap % TB;
+        int oh = c.i - a, ow = c.j - b;
+        if (oh < 0 || oh >= g.OH || ow < 0 || ow >= g.OW) { zero8<T>(v); return; }
+        load8<T>(dy + (((long long)c.n * g.OH + oh) * g.OW + ow) * CO + co, v);
+    }
+};
+
+// ---- transposed loaders (wgrad): a piece is 8 consecutive ROWS at one reduction index (= pixel) ----------
+template <typename T>
+struct PixMajorLoaderT {   // operand[r][k] = src[k][r]   (dY^T: rows = co, k = pixel); row-contiguous source
+    static constexpr bool TRANSPOSED = true;
+    struct Row {};
+    DEVI Row row(int, int) const { return Row{}; }
+    const T* p;
+    int rows;        // number of rows (Cout)
+    long long ld;    // pixel stride
+    DEVI int num_rows(int) const { return rows; }
+    DEVI void fetchT(int r0, int k, int kend, T (&v)[8]) const {
+        if (r0 >= rows || k >= kend) { zero8<T>(v); return; }
+        load8_guard<T>(p + (long long)k * ld + r0, rows - r0, v);
+    }
+};
+template <typename T>
+struct Conv1LoaderT {      // operand[r=(c,kh,kw)][k=pixel] from fp32 NCHW frames
+    static constexpr bool TRANSPOSED = true;
+    struct Row {};
+    DEVI Row row(int, int) const { return Row{}; }
+    const float* x;
+    ConvGeom g;
+    DEVI int num_rows(int) const { return g.C * g.KH * g.KW; }
+    DEVI void fetchT(int r0, int k, int kend, T (&v)[8]) const {
+        if (r0 >= g.C * g.KH * g.KW || k >= kend) { zero8<T>(v); return; }
+        int n = k / (g.OH * g.OW), rem = k % (g.OH * g.OW);
+        int oh = rem / g.OW, ow = rem % g.OW;
+        int ck = r0 >> 3, ch = ck / g.KH, kh = ck % g.KH;
+        const float* p = x + (((long long)n * g.C + ch) * g.IH + oh * g.S + kh) * g.IW + ow * g.S;
+        float f[8];
+        load8<float>(p, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = from_f<T>(f[i]);
+    }
+};
+template <typename T>
+struct ConvNHWCLoaderT {   // operand[r=(kh,kw,ci)][k=pixel] from NHWC activations
+    static constexpr bool TRANSPOSED = true;
+    struct Row {};
+    DEVI Row row(int, int) const { return Row{}; }
+    const T* x;
+    ConvGeom g;
+    DEVI int num_rows(int) const { return g.KH * g.KW * g.C; }
+    DEVI void fetchT(int r0, int k, int kend, T (&v)[8]) const {
+        if (r0 >= g.KH * g.KW * g.C || k >= kend) { zero8<T>(v); return; }
+        int n = k / (g.OH * g.OW), rem = k % (g.OH * g.OW);
+        int oh = rem / g.OW, ow = rem % g.OW;
+        int rowlen = g.KW * g.C;
+        int kh = r0 / rowlen, off = r0 % rowlen;
+        load8<T>(x + (((long long)n * g.IH + oh * g.S + kh) * g.IW + ow * g.S) * g.C + off, v);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// output maps
+// ---------------------------------------------------------------------------------------------------------
+struct DenseOut {
+    int R1;
+    long long s0, s1;
+    DEVI long long offset(int r, int) const { return (long long)(r / R1) * s0 + (long long)(r % R1) * s1; }
+};
+static inline DenseOut dense_out(long long ld) { DenseOut o; o.R1 = 0x7fffffff; o.s0 = 0; o.s1 = ld; return o; }
+static inline DenseOut dense_out_map(int R1, long long s0, long long s1) { DenseOut o; o.R1 = R1; o.s0 = s0; o.s1 = s1; return o; }
+
+struct DgradOut {   // scatter rows of parity class zc back to NHWC input pixels
+    ConvGeom g;
+    DEVI long long offset(int r, int zc) const {
+        int ph = zc / g.S, pw = zc % g.S;
+        int Ic = (g.IH - ph + g.S - 1) / g.S, Jc = (g.IW - pw + g.S - 1) / g.S;
+        int n = r / (Ic * Jc), rem = r % (Ic * Jc);
+        int i = rem / Jc, j = rem % Jc;
+        return (((long long)n * g.IH + g.S * i + ph) * g.IW + g.S * j + pw) * g.C;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct LdsLd;
+template <> struct LdsLd<bf16_t> { static constexpr int v = 40; };   // 80 B rows: 16-B aligned b128 reads
+template <> struct LdsLd<float> { static constexpr int v = 34; };    // 2*row + g distinct banks for b32 reads
+
+// piece numbering inside a [BR rows][32 k] operand tile:
+//   normal loader:      q -> row = q >> 2, k-piece = q & 3          (8 contiguous k per piece)
+//   transposed loader:  q -> row-group = q % (BR/8), kk = q / (BR/8) (8 consecutive rows at one k)
+template <typename T, int BR, typename L>
+DEVI void tile_fetch(const L& l, const typename L::Row& rc, int r0blk, int q, int k, int kend, T (&v)[8]) {
+    if constexpr (L::TRANSPOSED) {
+        l.fetchT(r0blk + (q % (BR / 8)) * 8, k + q / (BR / 8), kend, v);
+    } else {
+        l.fetch(rc, k + (q & 3) * 8, kend, v);
+    }
+}
+template <typename T, int BR, bool TRANSPOSED>
+DEVI void tile_commit(T* S, const T (&v)[8], int q) {
+    constexpr int LD = LdsLd<T>::v;
+    if constexpr (TRANSPOSED) {
+        const int rg = q % (BR / 8), kk = q / (BR / 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) S[(rg * 8 + e) * LD + kk] = v[e];
+    } else {
+        T* d = S + (q >> 2) * LD + (q & 3) * 8;
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reinterpret_cast<float2*>(d)[e] = reinterpret_cast<const float2*>(v)[e];
+        }
+    }
+}
+
+template <typename T, int BM, int BN, typename AL, typename BL, typename OM>
+__global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep, int N, int K, int nsplit, int ksplit) {
+    constexpr int BK = 32;
+    constexpr int LD = LdsLd<T>::v;
+    constexpr int APT = (BM * 4 + 255) / 256;
+    constexpr int BPT = (BN * 4 + 255) / 256;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
+    T* As = smem;
+    T* Bs = smem + BM * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int zs = blockIdx.z % nsplit, zc = blockIdx.z / nsplit;
+    const int M = al.num_rows(zc);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M) return;
+    const int kbeg = zs * ksplit;
+    const int kend = min(K, kbeg + ksplit);
+
+    typename AL::Row arow[APT];
+    typename BL::Row brow[BPT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) arow[i] = al.row(m0 + ((tid + i * 256) >> 2), zc);
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) brow[i] = bl.row(n0 + ((tid + i * 256) >> 2), zc);
+
+    T ra[APT][8], rb[BPT][8];
+    auto fetch_all = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int q = tid + i * 256;
+            if (q < BM * 4) tile_fetch<T, BM, AL>(al, arow[i], m0, q, k, kend, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int q = tid + i * 256;
+            if (q < BN * 4) tile_fetch<T, BN, BL>(bl, brow[i], n0, q, k, kend, rb[i]);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave >> 1, wn = wave & 1;
+    if (kbeg < kend) fetch_all(kbeg);
+    for (int k = kbeg; k < kend; k += BK) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int q = tid + i * 256;
+            if (q < BM * 4) tile_commit<T, BM, AL::TRANSPOSED>(As, ra[i], q);
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int q = tid + i * 256;
+            if (q < BN * 4) tile_commit<T, BN, BL::TRANSPOSED>(Bs, rb[i], q);
+        }
+        __syncthreads();
+        if (k + BK < kend) fetch_all(k + BK);
+        if constexpr (sizeof(T) == 2) {
+            bf16x8_t a[TM], b[TN];
+            const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4) * 8;
+            const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4) * 8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 16 * LD);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 16 * LD);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+            const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4);
+            const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = ap[i * 16 * LD + kk * 4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bp[j * 16 * LD + kk * 4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+            if (row < M) {
+                const long long obase = om.offset(row, zc) + (long long)zs * ep.z_stride;
+                const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WN + j * 16 + (lane & 15);
+                    if (col < N) {
+                        float v = acc[i][j][r] * ep.alpha;
+                        if (ep.bias) v += ep.bias[col];
+                        if (ep.bias2) v += ep.bias2[col];
+                        float resv = 0.f;
+                        if (ep.res) {
+                            const long long ro = (long long)rrow * ep.res_ld + col;
+                            resv = ep.res_f32 ? reinterpret_cast<const float*>(ep.res)[ro]
+                                              : to_f<T>(reinterpret_cast<const T*>(ep.res)[ro]);
+                        }
+                        if (!ep.res_late) v += resv;
+                        if (ep.relu) v = fmaxf(v, 0.f);
+                        const long long o = obase + col;
+                        if (ep.mask) v = (to_f<T>(reinterpret_cast<const T*>(ep.mask)[o]) > 0.f) ? v : 0.f;
+                        if (ep.drop_p > 0.f) {
+                            const float u = hash_uniform(ep.drop_seed, (unsigned long long)o);
+                            v = (u < ep.drop_p) ? 0.f : v * (1.f / (1.f - ep.drop_p));
+                        }
+                        if (ep.res_late) v += resv;
+                        if (ep.out_f32) {
+                            float* op = reinterpret_cast<float*>(ep.out) + o;
+                            *op = ep.accumulate ? (*op + v) : v;
+                        } else {
+                            T* op = reinterpret_cast<T*>(ep.out) + o;
+                            *op = from_f<T>(ep.accumulate ? (to_f<T>(*op) + v) : v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// host launcher: grid.x over M tiles, grid.y over N tiles, grid.z = classes * nsplit
+template <typename T, int BM, int BN, typename AL, typename BL, typename OM>
+static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const OM& om, const EpiP& ep, int Mmax, int N,
+                               int K, int nclass = 1, int nsplit = 1) {
+    if (Mmax <= 0 || N <= 0) return;
+    int ksplit = K;
+    if (nsplit > 1) ksplit = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;   // empty slabs still write zeros
+    dim3 grid((Mmax + BM - 1) / BM, (N + BN - 1) / BN, nclass * nsplit);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AL, BL, OM>), grid, dim3(256), 0, st, al, bl, om, ep, N, K, nsplit, ksplit);
+}

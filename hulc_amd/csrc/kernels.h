@@ -1,0 +1,816 @@
+// hulc_amd/csrc/kernels.h — the non-GEMM kernels of the HULC step (gfx950): layout packs/transposes, column sums,
+// spatial softmax, LayerNorm, tiny-S attention, plan sample/KL, decoder glue, logistic-mixture loss, CLIP loss, Adam.
+// All reductions are wave64 shuffles or LDS trees; everything HBM-facing is coalesced along the fastest dim.
+#pragma once
+#include "common.h"
+
+// =========================================================================================================
+// casts, transposes, packs
+// =========================================================================================================
+// dst[r][c] = src[r][c] (cast) and/or dstT[c][r] = src[r][c]   (32x32 tiles through LDS, 256 threads)
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) cast_transpose_kernel(const TS* __restrict__ src, long long lds_, TD* __restrict__ dst,
+                                                             long long ldd, TD* __restrict__ dstT, long long ldt, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = to_f<TS>(src[(long long)r * lds_ + c]);
+            if (dst) dst[(long long)r * ldd + c] = from_f<TD>(v);
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < R && c < C) dstT[(long long)c * ldt + r] = from_f<TD>(tile[tx][ty + i * 8]);
+    }
+}
+
+// conv weights: torch (O, I, KH, KW) fp32 ->
+//   fwd pack  Wf[o][(kh,kw,ci)]                       (conv2/3; conv1 keeps torch's (c,kh,kw) order = plain cast)
+//   dgrad pack Wd[zc][ci][(a,b,co)] = W[co][ci][ph+S*a][pw+S*b],  zc = ph*S+pw
+template <typename T>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int O, int I, int KH,
+                                   int KW, int S, int nhwc_fwd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = O * I * KH * KW;
+    if (idx >= total) return;
+    int kw = idx % KW, t = idx / KW;
+    int kh = t % KH; t /= KH;
+    int ci = t % I, o = t / I;
+    const float v = w[idx];
+    if (wf) {
+        if (nhwc_fwd) wf[(long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci] = from_f<T>(v);
+        else wf[idx] = from_f<T>(v);
+    }
+    if (wd) {
+        const int ph = kh % S, a = kh / S, pw = kw % S, b = kw / S;
+        const int TA = KH / S, TB = KW / S;
+        const int zc = ph * S + pw;
+        wd[((long long)zc * I + ci) * (TA * TB * O) + (a * TB + b) * O + o] = from_f<T>(v);
+    }
+}
+
+// conv wgrad partial slabs [nsplit][O][Kc] (packed K order) -> summed, un-permuted, accumulated into torch-layout grad
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsplit, long long slab, float* __restrict__ grad,
+                                         int O, int I, int KH, int KW, int nhwc_fwd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // index in torch layout
+    const int total = O * I * KH * KW;
+    if (idx >= total) return;
+    int kw = idx % KW, t = idx / KW;
+    int kh = t % KH; t /= KH;
+    int ci = t % I, o = t / I;
+    const long long src = nhwc_fwd ? ((long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci) : idx;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * slab + src];
+    grad[idx] += s;
+}
+
+// dst[r][perm(c)] = src[r][c] with c = ch*P + p  ->  perm(c) = p*CH + ch   (torch Flatten(C,H,W) <-> NHWC flatten)
+template <typename TS, typename TD>
+__global__ void permute_cols_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int R, int CH, int P, int inverse,
+                                    int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)R * CH * P;
+    if (idx >= total) return;
+    const int c = idx % (CH * P);
+    const long long r = idx / (CH * P);
+    // forward: src col (ch*P+p) -> dst col (p*CH+ch); inverse: src col (p*CH+ch) -> dst col (ch*P+p)
+    int d;
+    if (!inverse) { int ch = c / P, p = c % P; d = p * CH + ch; }
+    else { int p = c / CH, ch = c % CH; d = ch * P + p; }
+    const float v = to_f<TS>(src[idx]);
+    TD* o = dst + r * (CH * P) + d;
+    *o = from_f<TD>(accumulate ? to_f<TD>(*o) + v : v);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = from_f<TD>(to_f<TS>(src[i]));
+}
+
+// generic strided 2D copy/cast: dst[r*ldd + c] (+)= src[r*lds + c]
+template <typename TS, typename TD>
+__global__ void copy2d_kernel(const TS* __restrict__ src, long long lds_, TD* __restrict__ dst, long long ldd, int R, int C,
+                              int accumulate, float scale) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * C) return;
+    const int c = idx % C;
+    const long long r = idx / C;
+    const float v = to_f<TS>(src[r * lds_ + c]) * scale;
+    TD* o = dst + r * ldd + c;
+    *o = from_f<TD>(accumulate ? to_f<TD>(*o) + v : v);
+}
+
+// =========================================================================================================
+// column sums (bias grads): out[n] (+)= scale * sum_m X[m][n]; two-stage when rows are split
+// =========================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, long long ld, int M, int N, float* __restrict__ out,
+                                                     int rows_per_split, int direct_accumulate, float scale) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(M, rbeg + rows_per_split);
+    float s = 0.f;
+    if (c < N)
+        for (int r = rbeg + rl; r < rend; r += 4) s += to_f<T>(x[(long long)r * ld + c]);
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (direct_accumulate) out[c] += s * scale;
+        else out[(long long)blockIdx.y * N + c] = s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int N, float* __restrict__ out, float* __restrict__ out2,
+                                    float scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * N + c];
+    out[c] += s * scale;
+    if (out2) out2[c] += s * scale;
+}
+
+// =========================================================================================================
+// spatial softmax (vision_network.py:100-108) on NHWC features [N][HW][C]; one block per frame, 4 x C threads
+// out[n][2c] = sum p * lin[h], out[n][2c+1] = sum p * lin[w]; also saves (max, 1/sum) for backward
+// =========================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) spatial_softmax_fwd_kernel(const T* __restrict__ f, int H, int W, int C, T* __restrict__ out,
+                                                                  float* __restrict__ out_f32, float* __restrict__ stats /*[N][C][4]*/) {
+    __shared__ float sm[4][64], ss[4][64], sx[4][64], sy[4][64];
+    const int n = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int HW = H * W;
+    const T* p = f + (long long)n * HW * C + c;
+    float m = -INFINITY, s = 0.f, ax = 0.f, ay = 0.f;
+    const float sh = 2.f / (H - 1), sw = 2.f / (W - 1);
+    if (c < C) {
+        for (int q = part; q < HW; q += 4) {
+            const float v = to_f<T>(p[(long long)q * C]);
+            const int h = q / W, w = q % W;
+            const float lx = -1.f + sh * h, ly = -1.f + sw * w;
+            if (v > m) {
+                const float sc = __expf(m - v);
+                s *= sc; ax *= sc; ay *= sc;
+                m = v;
+            }
+            const float e = __expf(v - m);
+            s += e; ax += e * lx; ay += e * ly;
+        }
+    }
+    sm[part][c] = m; ss[part][c] = s; sx[part][c] = ax; sy[part][c] = ay;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        float M = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+        float S = 0.f, X = 0.f, Y = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sc = (sm[k][c] == -INFINITY) ? 0.f : __expf(sm[k][c] - M);
+            S += ss[k][c] * sc; X += sx[k][c] * sc; Y += sy[k][c] * sc;
+        }
+        const float inv = 1.f / S;
+        const float ex = X * inv, ey = Y * inv;
+        const long long o = (long long)n * 2 * C + 2 * c;
+        if (out) { out[o] = from_f<T>(ex); out[o + 1] = from_f<T>(ey); }
+        if (out_f32) { out_f32[o] = ex; out_f32[o + 1] = ey; }
+        float* st = stats + ((long long)n * C + c) * 4;
+        st[0] = M; st[1] = inv; st[2] = ex; st[3] = ey;
+    }
+}
+// dF[n][q][c] = p * (dex*(lin_h - ex) + dey*(lin_w - ey)) * (F > 0)      (ReLU of conv3 fused)
+template <typename T>
+__global__ void __launch_bounds__(256) spatial_softmax_bwd_kernel(const T* __restrict__ f, const float* __restrict__ stats,
+                                                                  const float* __restrict__ dout /*[N][2C] fp32*/, int H, int W, int C,
+                                                                  T* __restrict__ df) {
+    const int n = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int HW = H * W;
+    if (c >= C) return;
+    const float* st = stats + ((long long)n * C + c) * 4;
+    const float M = st[0], inv = st[1], ex = st[2], ey = st[3];
+    const float dex = dout[(long long)n * 2 * C + 2 * c], dey = dout[(long long)n * 2 * C + 2 * c + 1];
+    const float sh = 2.f / (H - 1), sw = 2.f / (W - 1);
+    const long long base = (long long)n * HW * C + c;
+    for (int q = part; q < HW; q += 4) {
+        const float v = to_f<T>(f[base + (long long)q * C]);
+        const int h = q / W, w = q % W;
+        const float lx = -1.f + sh * h, ly = -1.f + sw * w;
+        const float p = __expf(v - M) * inv;
+        const float g = (v > 0.f) ? p * (dex * (lx - ex) + dey * (ly - ey)) : 0.f;
+        df[base + (long long)q * C] = from_f<T>(g);
+    }
+}
+
+// =========================================================================================================
+// LayerNorm over the last dim n (32/64/128), one wave per row; biased variance, eps 1e-5
+// =========================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, long long ldx, int rows, int n,
+                                                            const float* __restrict__ g, const float* __restrict__ b, T* __restrict__ out,
+                                                            long long ldo, float* __restrict__ out_f32, long long ldf,
+                                                            float* __restrict__ stats /*[rows][2]*/) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * ldx;
+    float v0 = lane < n ? xr[lane] : 0.f, v1 = lane + 64 < n ? xr[lane + 64] : 0.f;
+    const float mean = wave_sum(v0 + v1) / n;
+    const float d0 = lane < n ? v0 - mean : 0.f, d1 = lane + 64 < n ? v1 - mean : 0.f;
+    const float var = wave_sum(d0 * d0 + d1 * d1) / n;
+    const float rstd = rsqrtf(var + 1e-5f);
+    if (lane < n) {
+        const float y = d0 * rstd * g[lane] + b[lane];
+        if (out) out[(long long)row * ldo + lane] = from_f<T>(y);
+        if (out_f32) out_f32[(long long)row * ldf + lane] = y;
+    }
+    if (lane + 64 < n) {
+        const float y = d1 * rstd * g[lane + 64] + b[lane + 64];
+        if (out) out[(long long)row * ldo + lane + 64] = from_f<T>(y);
+        if (out_f32) out_f32[(long long)row * ldf + lane + 64] = y;
+    }
+    if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+// dx = rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)),  dxh = dy*g ; writes fp32 dx (optionally accumulating) and/or T dx
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                            long long ldx, const float* __restrict__ stats, const float* __restrict__ g,
+                                                            int rows, int n, float* __restrict__ dx_f32, long long ldd, int accumulate,
+                                                            T* __restrict__ dx_t, long long ldt) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + (long long)row * ldx;
+    const float* dr = dy + (long long)row * lddy;
+    float xh0 = 0.f, xh1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (lane < n) { xh0 = (xr[lane] - mean) * rstd; q0 = dr[lane] * g[lane]; }
+    if (lane + 64 < n) { xh1 = (xr[lane + 64] - mean) * rstd; q1 = dr[lane + 64] * g[lane + 64]; }
+    const float m1 = wave_sum(q0 + q1) / n;
+    const float m2 = wave_sum(q0 * xh0 + q1 * xh1) / n;
+    if (lane < n) {
+        const float d = rstd * (q0 - m1 - xh0 * m2);
+        if (dx_f32) { float* o = dx_f32 + (long long)row * ldd + lane; *o = accumulate ? *o + d : d; }
+        if (dx_t) dx_t[(long long)row * ldt + lane] = from_f<T>(d);
+    }
+    if (lane + 64 < n) {
+        const float d = rstd * (q1 - m1 - xh1 * m2);
+        if (dx_f32) { float* o = dx_f32 + (long long)row * ldd + lane + 64; *o = accumulate ? *o + d : d; }
+        if (dx_t) dx_t[(long long)row * ldt + lane + 64] = from_f<T>(d);
+    }
+}
+// dgamma[c] += sum_r dy*xhat ; dbeta[c] += sum_r dy   (one block per 64 columns, 4 row lanes, LDS tree)
+__global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                                   long long ldx, const float* __restrict__ stats, int rows, int n,
+                                                                   float* __restrict__ dg, float* __restrict__ db) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    if (c < n)
+        for (int r = rl; r < rows; r += 4) {
+            const float d = dy[(long long)r * lddy + c];
+            a += d * (x[(long long)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
+            b += d;
+        }
+    r1[rl][threadIdx.x & 63] = a; r2[rl][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (rl == 0 && c < n) {
+        const int t = threadIdx.x;
+        dg[c] += (r1[0][t] + r1[1][t]) + (r1[2][t] + r1[3][t]);
+        db[c] += (r2[0][t] + r2[1][t]) + (r2[2][t] + r2[3][t]);
+    }
+}
+
+// =========================================================================================================
+// plan-recognition transformer glue (plan_recognition_net.py:94-117)
+// =========================================================================================================
+// x0[b,t,:] = emb[b,t,:] + pos[t,:] (+ dropout)  -> fp32 residual stream and T GEMM operand
+template <typename T>
+__global__ void posadd_kernel(const T* __restrict__ emb, const float* __restrict__ pos, int B, int S, int D, float* __restrict__ xf,
+                              T* __restrict__ xt, float drop_p, unsigned long long seed) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * S * D) return;
+    const int d = idx % D;
+    const int t = (idx / D) % S;
+    float v = to_f<T>(emb[idx]) + pos[t * D + d];
+    if (drop_p > 0.f) v = hash_uniform(seed, idx) < drop_p ? 0.f : v / (1.f - drop_p);
+    xf[idx] = v;
+    xt[idx] = from_f<T>(v);
+}
+// elementwise dropout mask application (backward of a dropout whose forward was fused elsewhere)
+template <typename T>
+__global__ void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dstf, T* __restrict__ dstt, long long n, float drop_p,
+                                     unsigned long long seed) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float v = src[idx];
+    if (drop_p > 0.f) v = hash_uniform(seed, idx) < drop_p ? 0.f : v / (1.f - drop_p);
+    if (dstf) dstf[idx] = v;
+    if (dstt) dstt[idx] = from_f<T>(v);
+}
+
+// attention for tiny S (<=64), head_dim 16: one block (64 threads) per (b, head); qkv [B*S][3D] T, row = b*S+t
+// P saved as fp32 [B][H][S][S] (post-softmax, pre-dropout); out ao [B*S][D] T
+template <typename T>
+__global__ void __launch_bounds__(64) attention_fwd_kernel(const T* __restrict__ qkv, int B, int S, int D, int NH, float* __restrict__ P,
+                                                           T* __restrict__ ao, float drop_p, unsigned long long seed) {
+    constexpr int HD = 16;
+    __shared__ float q[64][HD + 1], k[64][HD + 1], v[64][HD + 1];
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); v[i][d] = to_f<T>(r[2 * D + d]); }
+    }
+    __syncthreads();
+    if (i >= S) return;
+    float sc[64];
+    float m = -INFINITY;
+    for (int j = 0; j < S; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[i][d] * k[j][d];
+        sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    float den = 0.f;
+    for (int j = 0; j < S; ++j) { sc[j] = __expf(sc[j] - m); den += sc[j]; }
+    const float inv = 1.f / den;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float* Pr = P + (((long long)b * NH + h) * S + i) * S;
+    for (int j = 0; j < S; ++j) {
+        float p = sc[j] * inv;
+        Pr[j] = p;
+        if (drop_p > 0.f) p = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : p / (1.f - drop_p);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] += p * v[j][d];
+    }
+    T* orow = ao + (long long)(b * S + i) * D + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) orow[d] = from_f<T>(o[d]);
+}
+// backward: dao [B*S][D] (T) -> dqkv [B*S][3D] (T)
+template <typename T>
+__global__ void __launch_bounds__(64) attention_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ P, const T* __restrict__ dao,
+                                                           int B, int S, int D, int NH, T* __restrict__ dqkv, float drop_p,
+                                                           unsigned long long seed) {
+    constexpr int HD = 16;
+    __shared__ float q[64][HD + 1], k[64][HD + 1], v[64][HD + 1], dO[64][HD + 1];
+    __shared__ float dS[64][65];    // dS[i][j]
+    __shared__ float Pd[64][65];    // dropped P[i][j] (for dV)
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+        const T* g = dao + (long long)(b * S + i) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); v[i][d] = to_f<T>(r[2 * D + d]);
+            dO[i][d] = to_f<T>(g[d]);
+        }
+    }
+    __syncthreads();
+    if (i < S) {
+        const float* Pr = P + (((long long)b * NH + h) * S + i) * S;
+        float dot = 0.f;
+        float dp[64];
+        for (int j = 0; j < S; ++j) {
+            float dpj = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dpj += dO[i][d] * v[j][d];
+            const float p = Pr[j];
+            float keep = 1.f;
+            if (drop_p > 0.f) keep = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : 1.f / (1.f - drop_p);
+            Pd[i][j] = p * keep;
+            dpj *= keep;              // grad w.r.t. pre-dropout P
+            dp[j] = dpj;
+            dot += dpj * p;
+        }
+        for (int j = 0; j < S; ++j) dS[i][j] = Pr[j] * (dp[j] - dot);
+    }
+    __syncthreads();
+    if (i >= S) return;
+    float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dq[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int j = 0; j < S; ++j) {
+        const float s_ij = dS[i][j], s_ji = dS[j][i], p_ji = Pd[j][i];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            dq[d] += s_ij * k[j][d];
+            dk[d] += s_ji * q[j][d];          // q already carries the 1/sqrt(hd) scale
+            dv[d] += p_ji * dO[j][d];
+        }
+    }
+    T* o = dqkv + (long long)(b * S + i) * 3 * D + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { o[d] = from_f<T>(dq[d] * 0.25f); o[D + d] = from_f<T>(dk[d]); o[2 * D + d] = from_f<T>(dv[d]); }
+}
+
+// xm[b][d] = mean_t x[b][t][d]   (fp32 in, T out)
+template <typename T>
+__global__ void mean_over_s_kernel(const float* __restrict__ x, int B, int S, int D, T* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, d = idx % D;
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += x[((long long)b * S + t) * D + d];
+    out[idx] = from_f<T>(s / S);
+}
+// dx[b][t][d] = dxm[b][d] / S
+__global__ void bcast_over_s_kernel(const float* __restrict__ dxm, int B, int S, int D, float* __restrict__ dx) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * S * D) return;
+    const int d = idx % D;
+    const int b = idx / ((long long)S * D);
+    dx[idx] = dxm[b * D + d] / S;
+}
+// dpos[t][d] += sum_b dx[b][t][d]
+__global__ void pos_grad_kernel(const float* __restrict__ dx, int B, int S, int D, float* __restrict__ dpos) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(long long)b * S * D + idx];
+    dpos[idx] += s;
+}
+
+// =========================================================================================================
+// plan distribution: categorical sample, KL balancing (hulc.py:539-561), straight-through (distributions.py:23-27)
+// one wave per (b, category); NCLS <= 64
+// =========================================================================================================
+__global__ void __launch_bounds__(64) plan_kl_sample_kernel(const float* __restrict__ pr_logits, const float* __restrict__ pp_logits, int B,
+                                                            int NCAT, int NCLS, const int* __restrict__ idx_in, int* __restrict__ idx_out,
+                                                            float* __restrict__ probs /*[B][NCAT][NCLS]*/, float* __restrict__ kl_cat /*[B][NCAT]*/,
+                                                            float* __restrict__ dpp, float* __restrict__ dpr, float w_pp, float w_pr,
+                                                            unsigned long long seed) {
+    const int bc = blockIdx.x, lane = threadIdx.x;
+    const long long base = (long long)bc * NCLS;
+    const bool ok = lane < NCLS;
+    const float y = ok ? pr_logits[base + lane] : -INFINITY;
+    const float my = wave_max(y);
+    const float ey = ok ? __expf(y - my) : 0.f;
+    const float sy = wave_sum(ey);
+    const float a = ok ? (y - my) - __logf(sy) : 0.f;
+    const float p = ey / sy;
+    if (ok) probs[base + lane] = p;
+    if (pp_logits) {
+        const float z = ok ? pp_logits[base + lane] : -INFINITY;
+        const float mz = wave_max(z);
+        const float ez = ok ? __expf(z - mz) : 0.f;
+        const float sz = wave_sum(ez);
+        const float bb = ok ? (z - mz) - __logf(sz) : 0.f;
+        const float q = ez / sz;
+        const float klc = wave_sum(ok ? p * (a - bb) : 0.f);
+        if (lane == 0) kl_cat[bc] = klc;
+        if (ok) {
+            dpp[base + lane] = w_pp * (q - p);
+            dpr[base + lane] = w_pr * p * ((a - bb) - klc);
+        }
+    }
+    // categorical sample by Gumbel-max unless injected
+    int sel;
+    if (idx_in) sel = idx_in[bc];
+    else {
+        float gmb = ok ? y - __logf(-__logf(hash_uniform(seed, base + lane))) : -INFINITY;
+        const float gm = wave_max(gmb);
+        unsigned long long ball = __ballot(ok && gmb == gm);
+        sel = __ffsll((long long)ball) - 1;
+    }
+    if (lane == 0) idx_out[bc] = sel;
+}
+// dpr_logits[b][cat][:] = probs * (dplan - sum(probs*dplan)) + dpr_kl
+__global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dplan,
+                                                            const float* __restrict__ dpr_kl, int NCLS, float* __restrict__ out) {
+    const long long base = (long long)blockIdx.x * NCLS;
+    const int lane = threadIdx.x;
+    const bool ok = lane < NCLS;
+    const float p = ok ? probs[base + lane] : 0.f, d = ok ? dplan[base + lane] : 0.f;
+    const float dot = wave_sum(p * d);
+    if (ok) out[base + lane] = p * (d - dot) + dpr_kl[base + lane];
+}
+
+// =========================================================================================================
+// decoder glue (logistic_decoder_rnn.py:260-287 with the plan/goal terms hoisted out of the time loop)
+// =========================================================================================================
+// Cplan[b][i] = b_ih[i] + b_hh[i] + sum_cat WihT[cat*NCLS + idx[b][cat]][i]     (one-hot plan x W_ih[:, plan]^T)
+__global__ void plan_gather_kernel(const float* __restrict__ w_ih /*[H][KIN] master fp32*/, int KIN, const int* __restrict__ idx, int B,
+                                   int NCAT, int NCLS, int H, const float* __restrict__ b1, const float* __restrict__ b2,
+                                   float* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * H) return;
+    const int b = gid / H, i = gid % H;
+    float s = b1[i] + b2[i];
+    const float* wr = w_ih + (long long)i * KIN;
+    for (int c = 0; c < NCAT; ++c) s += wr[c * NCLS + idx[b * NCAT + c]];
+    out[gid] = s;
+}
+// dW_ih[i][cat*NCLS + idx[b][cat]] += dC[b][i]  — thread (i, cat) owns its NCLS columns: race-free, b-ordered
+template <typename T>
+__global__ void plan_scatter_grad_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H, int KIN,
+                                         float* __restrict__ dw) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= H * NCAT) return;
+    const int i = gid / NCAT, c = gid % NCAT;
+    float* row = dw + (long long)i * KIN + c * NCLS;
+    for (int b = 0; b < B; ++b) row[idx[b * NCAT + c]] += to_f<T>(dC[(long long)b * H + i]);
+}
+// out[r][c] = relu(x[r][c])
+template <typename T>
+__global__ void relu_copy_kernel(const T* __restrict__ x, T* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = from_f<T>(fmaxf(to_f<T>(x[i]), 0.f));
+}
+// out = g * (h > 0)
+template <typename T>
+__global__ void mask_mul_kernel(const T* __restrict__ g, const T* __restrict__ h, T* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_f<T>(h[i]) > 0.f ? g[i] : from_f<T>(0.f);
+}
+// out[b][c] = sum_t x[t][b][c]   (time-major), fp32 accumulate
+template <typename T>
+__global__ void sum_over_t_kernel(const T* __restrict__ x, int S, long long BH, T* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BH) return;
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += to_f<T>(x[(long long)t * BH + i]);
+    out[i] = from_f<T>(s);
+}
+// pack [emb[:,0,:] | goal] rows for the plan proposal input
+template <typename T>
+__global__ void concat_pp_kernel(const T* __restrict__ emb, long long ld_emb_b, int E, const T* __restrict__ goal, int G, int B,
+                                 T* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * (E + G)) return;
+    const int b = idx / (E + G), c = idx % (E + G);
+    out[idx] = c < E ? emb[(long long)b * ld_emb_b + c] : goal[b * G + (c - E)];
+}
+
+// =========================================================================================================
+// world->tcp action transform (gripper_control.py:16-36) + discretized logistic mixture NLL + gripper CE
+// (logistic_decoder_rnn.py:136-152,184-231), forward + gradient w.r.t. the 182 head outputs, one thread per (t,b) row.
+// heads row layout (packed): [prob 0..59 | mean 60..119 | log_scale 120..179 | gripper 180..181 | pad], ldh = 192
+// =========================================================================================================
+DEVI void euler_xyz(float a, float b, float c, float (&R)[9]) {
+    float sa, ca, sb, cb, sc, cc;
+    sincosf(a, &sa, &ca); sincosf(b, &sb, &cb); sincosf(c, &sc, &cc);
+    R[0] = cb * cc;                 R[1] = -cb * sc;                R[2] = sb;
+    R[3] = ca * sc + sa * sb * cc;  R[4] = ca * cc - sa * sb * sc;  R[5] = -sa * cb;
+    R[6] = sa * sc - ca * sb * cc;  R[7] = sa * cc + ca * sb * sc;  R[8] = ca * cb;
+}
+DEVI float softplusf(float x) { return x > 20.f ? x : (x < -20.f ? __expf(x) : log1pf(__expf(x))); }
+DEVI float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
+                                     const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
+                                     float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
+                                     float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;    // time-major row: r = t*B + b
+    if (r >= B * S) return;
+    const int t = r / B, b = r % B;
+    const float* act = actions + ((long long)b * S + t) * 7;
+    float at[7];
+    if (gripper_control) {
+        const float* ro = robot_obs + ((long long)b * S + t) * 15;
+        float R[9], Rn[9];
+        euler_xyz(ro[3], ro[4], ro[5], R);
+        euler_xyz(ro[3] + act[3] * 0.01f, ro[4] + act[4] * 0.01f, ro[5] + act[5] * 0.01f, Rn);
+        // pos_tcp = R^T act[0:3]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) at[i] = R[0 + i] * act[0] + R[3 + i] * act[1] + R[6 + i] * act[2];
+        // M = Rn^T R ; need M12, M22, M02, M01, M00
+        auto Mij = [&](int i, int j) { return Rn[0 + i] * R[0 + j] + Rn[3 + i] * R[3 + j] + Rn[6 + i] * R[6 + j]; };
+        float o0 = atan2f(-Mij(1, 2), Mij(2, 2));
+        float o1 = asinf(fminf(1.f, fmaxf(-1.f, Mij(0, 2))));
+        float o2 = atan2f(-Mij(0, 1), Mij(0, 0));
+        const float PI = 3.14159265358979323846f;
+        float o[3] = {o0, o1, o2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (o[i] < -PI) o[i] += 2.f * PI;
+            if (o[i] > PI) o[i] -= 2.f * PI;
+            at[3 + i] = o[i] * 100.f;
+        }
+        at[6] = act[6];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) at[i] = act[i];
+    }
+    if (a_tcp_out)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a_tcp_out[((long long)b * S + t) * 7 + i] = at[i];
+
+    const float* hr = heads + (long long)r * ldh;
+    T* dr = dheads + (long long)r * ldh;
+    const int NO = NMIX * NDIM;
+    const float hb = 1.f / (num_classes - 1);        // (max-min)/2/(nc-1) with bounds +-1 (conf/datamodule/default.yaml)
+    const float logc = __logf((num_classes - 1) * 0.5f);
+    float loss = 0.f;
+    for (int d = 0; d < NDIM; ++d) {
+        const float a = at[d];
+        float lp[16], dlogp_dmean[16], dlogp_dls[16];
+        float mlog = -INFINITY;
+        for (int k = 0; k < NMIX; ++k) mlog = fmaxf(mlog, hr[d * NMIX + k]);
+        float slog = 0.f;
+        for (int k = 0; k < NMIX; ++k) slog += __expf(hr[d * NMIX + k] - mlog);
+        const float lz = mlog + __logf(slog);
+        float mx = -INFINITY;
+        for (int k = 0; k < NMIX; ++k) {
+            const float mu = hr[NO + d * NMIX + k];
+            const float lsr = hr[2 * NO + d * NMIX + k];
+            const float ls = fmaxf(lsr, log_scale_min);
+            const float inv = __expf(-ls);
+            const float cen = a - mu;
+            const float plus = inv * (cen + hb), minus = inv * (cen - hb), mid = inv * cen;
+            const float sp = sigmoidf(plus), sm = sigmoidf(minus);
+            const float delta = sp - sm;
+            float logp, gp = 0.f, gm = 0.f, gmid = 0.f, direct = 0.f;
+            if (a < -1.f + 1e-3f) { logp = plus - softplusf(plus); gp = sigmoidf(-plus); }
+            else if (a > 1.f - 1e-3f) { logp = -softplusf(minus); gm = -sm; }
+            else if (delta > 1e-5f) { logp = __logf(fmaxf(delta, 1e-12f)); gp = sp * (1.f - sp) / delta; gm = -sm * (1.f - sm) / delta; }
+            else { logp = mid - ls - 2.f * softplusf(mid) - logc; gmid = 1.f - 2.f * sigmoidf(mid); direct = -1.f; }
+            dlogp_dmean[k] = -inv * (gp + gm + gmid);
+            dlogp_dls[k] = (lsr >= log_scale_min) ? (-(gp * plus + gm * minus + gmid * mid) + direct) : 0.f;
+            lp[k] = logp + (hr[d * NMIX + k] - lz);
+            mx = fmaxf(mx, lp[k]);
+        }
+        float se = 0.f;
+        for (int k = 0; k < NMIX; ++k) se += __expf(lp[k] - mx);
+        const float lse = mx + __logf(se);
+        loss -= lse;
+        for (int k = 0; k < NMIX; ++k) {
+            const float w = __expf(lp[k] - lse);
+            const float pi = __expf(hr[d * NMIX + k] - lz);
+            dr[d * NMIX + k] = from_f<T>(-(w - pi) * grad_scale);
+            dr[NO + d * NMIX + k] = from_f<T>(-w * dlogp_dmean[k] * grad_scale);
+            dr[2 * NO + d * NMIX + k] = from_f<T>(-w * dlogp_dls[k] * grad_scale);
+        }
+    }
+    // gripper cross entropy: label -1 -> 0 else (long)value  (logistic_decoder_rnn.py:144-151)
+    {
+        const float g0 = hr[3 * NO], g1 = hr[3 * NO + 1];
+        const int lab = (at[6] == -1.f) ? 0 : (int)at[6];
+        const float m = fmaxf(g0, g1);
+        const float lz = m + __logf(__expf(g0 - m) + __expf(g1 - m));
+        loss += gripper_alpha * (lz - (lab == 0 ? g0 : g1));
+        const float p0 = __expf(g0 - lz), p1 = __expf(g1 - lz);
+        dr[3 * NO] = from_f<T>(gripper_alpha * (p0 - (lab == 0 ? 1.f : 0.f)) * grad_scale);
+        dr[3 * NO + 1] = from_f<T>(gripper_alpha * (p1 - (lab == 1 ? 1.f : 0.f)) * grad_scale);
+    }
+    for (int c = 3 * NO + 2; c < ldh; ++c) dr[c] = from_f<T>(0.f);
+    row_loss[r] = loss;
+}
+
+// out[0] = scale * sum(x[0..n))   (single block, deterministic tree)
+__global__ void __launch_bounds__(256) sum_reduce_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// =========================================================================================================
+// CLIP-style auxiliary loss (hulc.py:679-695) on n <= 64 rows of 32-d projections; single block of 64 threads
+// writes loss, d img, d txt (already times `w`), d logit_scale (accumulated)
+// =========================================================================================================
+__global__ void __launch_bounds__(64) clip_loss_kernel(const float* __restrict__ img, const float* __restrict__ txt, int n, int D,
+                                                       const float* __restrict__ logit_scale, float w, float* __restrict__ loss_out,
+                                                       float* __restrict__ dimg, float* __restrict__ dtxt, float* __restrict__ dlogit_scale) {
+    __shared__ float in_[64][33], tn_[64][33], ni[64], nt[64], L[64][65], dL[64][65], rowlse[64], collse[64], red[64];
+    const int i = threadIdx.x;
+    const float s = __expf(logit_scale[0]);
+    if (i < n) {
+        float a = 0.f, b = 0.f;
+        for (int d = 0; d < D; ++d) { a += img[i * D + d] * img[i * D + d]; b += txt[i * D + d] * txt[i * D + d]; }
+        ni[i] = sqrtf(a); nt[i] = sqrtf(b);
+        for (int d = 0; d < D; ++d) { in_[i][d] = img[i * D + d] / ni[i]; tn_[i][d] = txt[i * D + d] / nt[i]; }
+    }
+    __syncthreads();
+    if (i < n) {
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            float c = 0.f;
+            for (int d = 0; d < D; ++d) c += in_[i][d] * tn_[j][d];
+            L[i][j] = s * c;
+            m = fmaxf(m, L[i][j]);
+        }
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += __expf(L[i][j] - m);
+        rowlse[i] = m + __logf(se);
+    }
+    __syncthreads();
+    if (i < n) {
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) m = fmaxf(m, L[j][i]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += __expf(L[j][i] - m);
+        collse[i] = m + __logf(se);
+    }
+    __syncthreads();
+    float part = 0.f, dsp = 0.f;
+    if (i < n) {
+        part = (rowlse[i] - L[i][i]) + (collse[i] - L[i][i]);
+        for (int j = 0; j < n; ++j) {
+            const float g = ((__expf(L[i][j] - rowlse[i]) - (i == j)) + (__expf(L[i][j] - collse[j]) - (i == j))) / (2.f * n);
+            dL[i][j] = g;
+            dsp += g * (L[i][j] / s);
+        }
+    }
+    red[i] = part;
+    __syncthreads();
+    if (i == 0) {
+        float t = 0.f;
+        for (int j = 0; j < n; ++j) t += red[j];
+        loss_out[0] = t / (2.f * n);
+    }
+    __syncthreads();
+    red[i] = dsp;
+    __syncthreads();
+    if (i == 0) {
+        float t = 0.f;
+        for (int j = 0; j < n; ++j) t += red[j];
+        dlogit_scale[0] += w * t * s;
+    }
+    if (i < n) {
+        float din[32], dtn[32];
+        for (int d = 0; d < D; ++d) { din[d] = 0.f; dtn[d] = 0.f; }
+        for (int j = 0; j < n; ++j) {
+            const float gij = dL[i][j], gji = dL[j][i];
+            for (int d = 0; d < D; ++d) { din[d] += s * gij * tn_[j][d]; dtn[d] += s * gji * in_[j][d]; }
+        }
+        float di = 0.f, dt = 0.f;
+        for (int d = 0; d < D; ++d) { di += in_[i][d] * din[d]; dt += tn_[i][d] * dtn[d]; }
+        for (int d = 0; d < D; ++d) {
+            dimg[i * D + d] = w * (din[d] - in_[i][d] * di) / ni[i];
+            dtxt[i * D + d] = w * (dtn[d] - tn_[i][d] * dt) / nt[i];
+        }
+    }
+}
+// gather rows by index list: dst[i][:] = src[rows[i]][:]  ; scatter-add reverse
+template <typename TS, typename TD>
+__global__ void gather_rows_kernel(const TS* __restrict__ src, long long lds_, const int* __restrict__ rows, int n, int C, TD* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * C) return;
+    const int i = idx / C, c = idx % C;
+    dst[idx] = from_f<TD>(to_f<TS>(src[(long long)rows[i] * lds_ + c]));
+}
+__global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int* __restrict__ rows, int n, int C, float* __restrict__ dst,
+                                        long long ldd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * C) return;
+    const int i = idx / C, c = idx % C;
+    dst[(long long)rows[i] * ldd + c] += src[idx];
+}
+
+// =========================================================================================================
+// Adam (torch.optim.Adam defaults; conf/model/optimizer/adam.yaml) over the flat parameter buffer,
+// fused with the gradient scale (1/world for the DP mean) — one pass over p, g, m, v.
+// =========================================================================================================
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
+        float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = G[e] * gscale;
+            Mv[e] = b1 * Mv[e] + (1.f - b1) * gr;
+            V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
+            P[e] -= (lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
+        }
+        *reinterpret_cast<float4*>(p + i) = pp;
+        *reinterpret_cast<float4*>(m + i) = mm;
+        *reinterpret_cast<float4*>(v + i) = vv;
+    }
+}
+
+// embg[(t*B+b)*64 + c] = emb[(b*S+t)*128 + 64 + c]   (time-major copy of the gripper half, perceptual_emb_slice [64,128])
+template <typename T>
+__global__ void gather_embg_kernel(const T* __restrict__ emb, T* __restrict__ out, int B, int S) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * B * 64) return;
+    const int c = idx & 63, r = idx >> 6;
+    const int t = r / B, b = r % B;
+    out[idx] = emb[((long long)b * S + t) * 128 + 64 + c];
+}
+// losses[4..7] = [action + kl, kl, action, clip]
+__global__ void pack_losses_kernel(float* __restrict__ l) {
+    l[4] = l[0] + l[1]; l[5] = l[1]; l[6] = l[0]; l[7] = l[2];
+}

@@ -1,0 +1,139 @@
+"""StepEngine — thin Python owner of one libhulc_hip context + the flat fp32 parameter/gradient/Adam buffers.
+
+torch is plumbing here (device memory, streams, torch.distributed); every FLOP of the step runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import spec
+
+
+class StepEngine:
+    def __init__(self, dims: spec.ModelDims, max_batch: int, max_seq: int, dtype: str = "bf16", device: str = "cuda:0",
+                 kl_beta: float = 0.01, kl_balancing_mix: float = 0.8, dropout_p: float = 0.1, num_classes: int = 10,
+                 gripper_alpha: float = 1.0, log_scale_min: float = -7.0, seed: int = 42):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("hulc_amd.StepEngine needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        self.dims = dims
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dtype = dtype
+        self.layout, self.numel = spec.layout(dims)
+        dev = self.device
+        self.flat_params = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        cfg = L.HulcConfig(kind=L.KIND[dims.kind], dtype=L.DTYPE[dtype], max_batch=max_batch, max_seq=max_seq,
+                           max_window=dims.max_window, use_clip=int(dims.use_clip), kl_beta=kl_beta,
+                           kl_balancing_mix=kl_balancing_mix, dropout_p=dropout_p, num_classes=num_classes,
+                           gripper_alpha=gripper_alpha, log_scale_min=log_scale_min, seed=seed)
+        self.cfg = cfg
+        self.ctx = C.c_void_p()
+        L.check(self.lib.hulc_ctx_create(C.byref(cfg), C.byref(self.ctx)))
+        L.check(self.lib.hulc_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        names = list(self.layout.keys())
+        self._names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        self._offs = (C.c_int64 * len(names))(*[self.layout[n][0] for n in names])
+        self._nums = (C.c_int64 * len(names))(*[int(np.prod(self.layout[n][1])) if len(self.layout[n][1]) else 1 for n in names])
+        self._bound = False
+        self._keep = []
+        self.adam_t = 0
+
+    # ---- parameters -------------------------------------------------------------------------------------------
+    def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for n, (off, shape) in self.layout.items():
+            k = int(np.prod(shape)) if len(shape) else 1
+            out[n] = flat[off:off + k].view(*shape) if len(shape) else flat[off:off + 1].view(())
+        return out
+
+    def bind(self):
+        L.check(self.lib.hulc_bind_params(self.ctx, self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.adam_m.data_ptr(),
+                                          self.adam_v.data_ptr(), self.numel, len(self.layout), self._names, self._offs, self._nums))
+        self._bound = True
+
+    def load_numpy(self, params: Dict[str, np.ndarray]):
+        v = self.views(self.flat_params)
+        for n, t in v.items():
+            t.copy_(torch.from_numpy(np.asarray(params[n], np.float32)).reshape(t.shape))
+        if self._bound:
+            self.prepare_weights()
+        else:
+            self.bind()
+
+    def prepare_weights(self):
+        L.check(self.lib.hulc_prepare_weights(self.ctx))
+
+    def zero_grads(self):
+        L.check(self.lib.hulc_zero_grads(self.ctx))
+
+    # ---- step pieces ------------------------------------------------------------------------------------------
+    def forward_loss(self, mb: Dict, is_lang: bool, loss_weight: float, clip_weight: float, step: int = 0,
+                     sync_losses: bool = True):
+        """mb: device tensors rgb_static (B,S,3,200,200) f32, rgb_gripper, actions, robot_obs(15), [lang], [plan_idx int32],
+        [aux_rows: host int32 numpy]."""
+        B, S = mb["actions"].shape[:2]
+        keep = []
+
+        def ptr(t):
+            t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        b = L.HulcBatch(B=B, S=S, is_lang=int(is_lang), rgb_static=ptr(mb["rgb_static"]), rgb_gripper=ptr(mb["rgb_gripper"]),
+                        actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
+                        plan_idx=ptr(mb["plan_idx"]) if mb.get("plan_idx") is not None else None, aux_rows=None, n_aux=0, step=step)
+        if is_lang and mb.get("aux_rows") is not None and len(mb["aux_rows"]) > 0:
+            rows = np.ascontiguousarray(mb["aux_rows"], np.int32)
+            keep.append(rows)
+            b.aux_rows = rows.ctypes.data
+            b.n_aux = len(rows)
+        self._keep = keep
+        if sync_losses:
+            out = (C.c_float * 4)()
+            L.check(self.lib.hulc_forward_loss(self.ctx, C.byref(b), loss_weight, clip_weight, out, 1))
+            return dict(total_mod=out[0], kl=out[1], action=out[2], clip=out[3])
+        if not hasattr(self, "_loss_dev"):
+            self._loss_dev = torch.zeros(4, dtype=torch.float32, device=self.device)
+        L.check(self.lib.hulc_forward_loss(self.ctx, C.byref(b), loss_weight, clip_weight, self._loss_dev.data_ptr(), 0))
+        return self._loss_dev
+
+    def backward(self):
+        L.check(self.lib.hulc_backward(self.ctx))
+
+    def adam_step(self, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+        self.adam_t += 1
+        L.check(self.lib.hulc_adam_step(self.ctx, lr, b1, b2, eps, self.adam_t, grad_scale))
+
+    def get_tensor(self, name: str, n: int) -> np.ndarray:
+        out = np.zeros(n, np.float32)
+        got = C.c_int64()
+        L.check(self.lib.hulc_get_tensor(self.ctx, name.encode(), out.ctypes.data, n, C.byref(got)))
+        return out[:got.value]
+
+    def plan_idx(self, B: int) -> np.ndarray:
+        out = np.zeros(B * 32, np.int32)
+        L.check(self.lib.hulc_get_plan_idx(self.ctx, out.ctypes.data, out.size))
+        return out.reshape(B, 32)
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.hulc_workspace_bytes(self.ctx))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.hulc_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

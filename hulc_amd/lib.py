@@ -1,0 +1,67 @@
+"""ctypes binding of libhulc_hip.so (include/hulc_hip.h).  No CPU fallback: a missing library raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhulc_hip.so")
+
+KIND = {"hulc": 0, "gcbc": 1}
+DTYPE = {"fp32": 0, "bf16": 1}
+
+
+class HulcConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_seq", C.c_int32),
+                ("max_window", C.c_int32), ("use_clip", C.c_int32), ("kl_beta", C.c_float),
+                ("kl_balancing_mix", C.c_float), ("dropout_p", C.c_float), ("num_classes", C.c_int32),
+                ("gripper_alpha", C.c_float), ("log_scale_min", C.c_float), ("seed", C.c_uint64)]
+
+
+class HulcBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("is_lang", C.c_int32), ("rgb_static", C.c_void_p),
+                ("rgb_gripper", C.c_void_p), ("actions", C.c_void_p), ("robot_obs", C.c_void_p), ("lang", C.c_void_p),
+                ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64)]
+
+
+EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
+           "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward",
+           "hulc_adam_step", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast"]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises RuntimeError (never falls back) when it is absent or unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"hulc_amd: {LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback for the product path")
+    lib = C.CDLL(LIB_PATH)
+    lib.hulc_last_error.restype = C.c_char_p
+    lib.hulc_workspace_bytes.restype = C.c_int64
+    lib.hulc_ctx_create.argtypes = [C.POINTER(HulcConfig), C.POINTER(C.c_void_p)]
+    lib.hulc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.hulc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hulc_workspace_bytes.argtypes = [C.c_void_p]
+    lib.hulc_bind_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                     C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.hulc_prepare_weights.argtypes = [C.c_void_p]
+    lib.hulc_zero_grads.argtypes = [C.c_void_p]
+    lib.hulc_forward_loss.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
+    lib.hulc_backward.argtypes = [C.c_void_p]
+    lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]
+    lib.hulc_get_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.hulc_get_plan_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.hulc_k_gemm_nt.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.hulc_k_cast.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("libhulc_hip: " + load().hulc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,106 @@
+/* hulc_hip.h — C ABI of libhulc_hip.so: the MI355X-native (gfx950) HULC / GCBC training step.
+ *
+ * The reference (lukashermann/hulc) is pure PyTorch-Lightning Python and has no FFI; this header is the boundary a
+ * maintainer binds instead of the bodies of the hot-path functions listed below.  Plain pointers
+ * and sizes only, no torch types.  All pointers are DEVICE pointers unless a parameter says "host".  Every function
+ * returns 0 on success; on failure it returns non-zero and hulc_last_error() holds a message.  One context per
+ * process / GPU, not thread-safe; all kernels are enqueued on the context's stream (hulc_set_stream) and the calls
+ * are asynchronous w.r.t. the host except where noted.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   hulc_forward_loss  <- Hulc.training_step per-modality body   hulc/models/hulc.py:433-469  (GCBC: gcbc.py:91-136)
+ *                         = ConcatEncoders.forward                perceptual_encoders/concat_encoders.py:59-109
+ *                         + Visual/LanguageGoalEncoder.forward    encoders/goal_encoders.py:31-36 / 64-69
+ *                         + Hulc.lmp_train                        hulc/models/hulc.py:254-299
+ *                         + LogisticDecoderRNN.loss               decoders/logistic_decoder_rnn.py:121-134
+ *                         + Hulc.compute_kl_loss                  hulc/models/hulc.py:539-561
+ *                         + Hulc.clip_auxiliary_loss              hulc/models/hulc.py:650-695
+ *   hulc_backward      <- autograd backward of the above (Lightning: loss.backward())
+ *   hulc_adam_step     <- torch.optim.Adam.step                   hulc/models/hulc.py:239-252, conf/model/optimizer/adam.yaml
+ *   hulc_zero_grads    <- optimizer.zero_grad()
+ * The gradient all-reduce (DDPStrategy, hulc/training.py:64-69) stays on the host side: one RCCL all-reduce over the
+ * flat gradient buffer this library writes.
+ */
+#ifndef HULC_HIP_H
+#define HULC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hulc_ctx hulc_ctx;
+
+enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1 };
+enum { HULC_DTYPE_F32 = 0, HULC_DTYPE_BF16 = 1 };
+
+typedef struct hulc_config {
+    int32_t kind;            /* HULC_KIND_*  (conf/model/hulc.yaml:16, gcbc.yaml:16) */
+    int32_t dtype;           /* HULC_DTYPE_* : storage/MFMA operand type; accumulation is always fp32 */
+    int32_t max_batch;       /* largest per-modality batch B the workspace is sized for */
+    int32_t max_seq;         /* largest window length S (<= 64) */
+    int32_t max_window;      /* rows of plan_recognition.position_embeddings (>= max_seq) */
+    int32_t use_clip;        /* use_clip_auxiliary_loss (conf/model/hulc.yaml:28) */
+    float kl_beta;           /* conf/loss/default.yaml:1 */
+    float kl_balancing_mix;  /* conf/loss/default.yaml:3 */
+    float dropout_p;         /* plan_recognition dropout_p (transformers.yaml:9); 0 = eval-mode parity */
+    int32_t num_classes;     /* action_decoder.num_classes (hulc_default.yaml:11) */
+    float gripper_alpha;     /* hulc_default.yaml:14 */
+    float log_scale_min;     /* hulc_default.yaml:5 */
+    uint64_t seed;           /* base seed of the counter RNG (dropout masks, plan sample) */
+} hulc_config;
+
+typedef struct hulc_batch {
+    int32_t B, S;                /* windows, window length */
+    int32_t is_lang;             /* 0: 'vis' modality (visual goal = emb[:, -1]); 1: 'lang' modality */
+    const float* rgb_static;     /* (B,S,3,200,200) fp32 NCHW in [-1,1]   hulc.py:398 */
+    const float* rgb_gripper;    /* (B,S,3,84,84)   fp32 NCHW */
+    const float* actions;        /* (B,S,7) relative actions, last = +-1 gripper */
+    const float* robot_obs;      /* (B,S,15) state_info.robot_obs (raw; euler angles in [3:6]) */
+    const float* lang;           /* (B,384) language embedding, lang modality only */
+    const int32_t* plan_idx;     /* optional (B,32) injected categorical sample (parity tests); NULL = sample on device */
+    const int32_t* aux_rows;     /* HOST: indices b with use_for_aux_lang_loss[b] != 0 (lang modality, clip loss) */
+    int32_t n_aux;
+    uint64_t step;               /* optimizer step index, mixed into the dropout / sampling seeds */
+} hulc_batch;
+
+/* out_losses (device or host pointer, see `losses_on_host`): [total_mod, kl_scaled, action, clip] of this modality,
+ * unweighted: total_mod = action + kl (hulc.py:297); clip is the raw contrastive loss (hulc.py:692). */
+#define HULC_N_LOSSES 4
+
+const char* hulc_last_error(void);
+int hulc_ctx_create(const hulc_config* cfg, hulc_ctx** out);
+int hulc_ctx_destroy(hulc_ctx* ctx);
+int hulc_set_stream(hulc_ctx* ctx, void* hip_stream);
+int64_t hulc_workspace_bytes(const hulc_ctx* ctx);
+
+/* Borrow the flat fp32 parameter / gradient / Adam-moment buffers (numel elements each) and the table of tensors inside
+ * them.  names are the reference state_dict keys; offsets are element offsets (multiples of 4). */
+int hulc_bind_params(hulc_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v, int64_t numel,
+                     int32_t n_tensors, const char* const* names, const int64_t* offsets, const int64_t* numels);
+/* Refresh the compute-precision / packed / transposed weight copies after the fp32 parameters changed. */
+int hulc_prepare_weights(hulc_ctx* ctx);
+int hulc_zero_grads(hulc_ctx* ctx);
+
+/* Forward + loss of ONE modality batch; keeps activations for hulc_backward.  loss_weight = 1/len(batch) (hulc.py:491),
+ * clip_weight = clip_auxiliary_loss_beta (hulc.py:525) — used to scale the gradients in hulc_backward. */
+int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* batch, float loss_weight, float clip_weight, float* out_losses,
+                      int32_t losses_on_host);
+/* Backward of the last hulc_forward_loss; ACCUMULATES into the bound gradient buffer. */
+int hulc_backward(hulc_ctx* ctx);
+/* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
+int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+
+/* Inspection (tests): copy a named internal tensor to HOST fp32. Returns element count in *n (cap = capacity). */
+int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* host_out, int64_t cap, int64_t* n);
+int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* host_out, int64_t cap);
+
+/* Per-kernel test entry points (device pointers; dtype selects fp32 / bf16(uint16) storage of A, B). */
+int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                   int64_t ldb, int64_t ldc, const float* bias, int32_t relu, void* hip_stream);
+int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
