@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py — trajectory-windows/s of the HULC training step on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + loss + backward + gradient all-reduce (N>1, RCCL via torch.distributed "nccl") + Adam, on one
+batch of synthetic CALVIN-shaped windows already resident in HBM.  Workload (BASELINE.json configs[1]):
+HULC, vision goal only (use_clip_auxiliary_loss=false), B=64 windows/GPU, seq_len=32, 200x200 static + 84x84
+gripper frames, bf16 MFMA operands with fp32 accumulation / fp32 master weights, transformer dropout 0.1 (train mode).
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hulc_amd import spec  # noqa: E402
+from hulc_amd.engine import StepEngine  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+FLOP_PER_WINDOW_S32 = 13.02e9   # fwd+bwd algorithmic FLOPs per window at S=32
+
+
+def synth_batch(B, S, dev, seed, lang=False):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    def u8img(h):
+        u = torch.randint(0, 256, (B, S, 3, h, h), device=dev, generator=g, dtype=torch.int32).float()
+        return ((u / 255.0 - 0.5) / 0.5).contiguous()
+    act = torch.rand(B, S, 7, device=dev, generator=g) * 2 - 1
+    e = torch.rand(B, S, 7, device=dev, generator=g)
+    act = torch.where(e < 0.025, -torch.ones_like(act), torch.where(e > 0.975, torch.ones_like(act), act))
+    act[..., 6] = torch.where(torch.rand(B, S, device=dev, generator=g) < 0.5, -1.0, 1.0)
+    ro = torch.randn(B, S, 15, device=dev, generator=g) * 0.3
+    ro[..., 3:6] = torch.rand(B, S, 3, device=dev, generator=g) * 2 - 1
+    mb = dict(rgb_static=u8img(200), rgb_gripper=u8img(84), actions=act.contiguous(), robot_obs=ro.contiguous())
+    if lang:
+        l = torch.randn(B, 384, device=dev, generator=g)
+        mb["lang"] = (l / l.norm(dim=-1, keepdim=True)).contiguous()
+        mb["aux_rows"] = np.arange(B, dtype=np.int32)
+    return mb
+
+
+def cpu_baseline(S, budget_s=20.0):
+    """Oracle (numpy port of the reference step) timed on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hulc_oracle as O
+    from hulc_amd.utils import synthetic
+    dims = spec.ModelDims(kind="hulc", max_window=max(32, S), use_clip=False)
+    P = spec.init_all(dims, seed=0)
+    Bc = 4
+    batch = synthetic.make_batch(Bc, 0, S, seed=0)
+    st = {}
+    t0 = time.time()
+    n = 0
+    while True:
+        _, G = O.training_step(P, dims, batch)
+        O.adam_step(P, G, st, n + 1)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 3:
+            break
+    dt = time.time() - t0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    return dict(value=round(Bc * n / dt, 3), unit="windows/s", cores=cores, kind="port",
+                sample=f"{n} step(s) of B={Bc} S={S} vis windows, numpy oracle fp32 (fwd+bwd+Adam), OpenBLAS threads = all {cores} host cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
+    ap.add_argument("--seq", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--lang", type=int, default=0, help="1: 32 vis + 32 lang per GPU with CLIP aux loss (config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    B, S = args.batch, args.seq
+    use_clip = bool(args.lang)
+    dims = spec.ModelDims(kind="hulc", max_window=max(32, S), use_clip=use_clip)
+    Bmod = B // 2 if args.lang else B
+    eng = StepEngine(dims, Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.1, seed=42)
+    eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
+    mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False))]
+    if args.lang:
+        mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True)))
+    nmod = len(mods)
+
+    def step(i):
+        eng.zero_grads()
+        for name, mb in mods:
+            eng.forward_loss(mb, name == "lang", 1.0 / nmod, 3.0, step=i, sync_losses=False)
+            eng.backward()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(eng.flat_grads)          # RCCL over xGMI, one flat 188 MB fp32 bucket
+        eng.adam_step(lr=2e-4, grad_scale=1.0 / world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    wps = B * world / (dt / args.steps)
+    loss = eng._loss_dev.cpu().numpy().tolist()
+
+    if rank == 0:
+        rl = eng.roofline_report() if hasattr(eng, "roofline_report") else None
+        out = {
+            "metric": "trajectory-windows/sec (seq_len=%d, bs=%d/GPU)" % (S, B), "value": round(wps, 2), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "HULC training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper fp32 NCHW frames, "
+                                   "fwd+loss+bwd+%sAdam, dropout 0.1" % ("32 vis + 32 lang + CLIP aux" if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
+                                                                        B, S, "RCCL all-reduce+" if world > 1 else ""),
+                       "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
+            "last_losses": {"total_mod": loss[0], "kl": loss[1], "action": loss[2], "clip": loss[3]},
+            "model_flops_per_window": FLOP_PER_WINDOW_S32 * S / 32.0,
+            "step_tflops": round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
+            "roofline": rl,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(S),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

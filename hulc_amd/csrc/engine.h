@@ -284,17 +284,20 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((copy2d_kernel<TS, TD>), dim3(cdiv((long long)R * C, 256)), dim3(256), 0, st, src, lds_, dst, ldd, R, C, acc, scale);
     }
     void colsum(const T* x, long long ld, int M, int N, float* out, float* out2 = nullptr, float scale = 1.f) {
-        int nsplit = std::min(1024, std::max(1, M / 4096));
-        if (nsplit == 1 && !out2) {
-            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), 1), dim3(256), 0, st, x, ld, M, N, out, M, 1, scale);
-        } else {
-            int rps = cdiv(M, nsplit);
-            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, cspart, rps, 0, 1.f);
-            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, cspart, nsplit, N, out, out2, scale);
-        }
+        // two-stage, deterministic: <=256 row chunks of >=256 rows, then a 4-lane final per column
+        const int nsplit = std::max(1, std::min(256, cdiv(M, 256)));
+        const int rps = cdiv(M, nsplit);
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, cspart, rps, 0, 1.f);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, cspart, nsplit, N, out, out2, scale);
     }
     // dense NT GEMM with tile selection
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
+                hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16), dim3(256), 0, st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
+                return;
+            }
+        }
         if (M >= 512 && N >= 128) launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
         else launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
     }
@@ -325,7 +328,10 @@ struct Engine : IEngine {
     void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
                 long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db) {
         hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt);
-        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, dg, db);
+        const int nsplit = std::max(1, std::min(64, cdiv(rows, 64)));
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64), nsplit), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, cdiv(rows, nsplit), cspart);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, cspart, nsplit, n, dg, (float*)nullptr, 1.f);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, cspart + (long long)nsplit * n, nsplit, n, db, (float*)nullptr, 1.f);
     }
 
     // ---------------------------------------------------------------- weight preparation
@@ -414,8 +420,8 @@ struct Engine : IEngine {
     void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {
         const int Kc = c.I * c.KH * c.KW;
         const long long npix = (long long)g.Nf * g.OH * g.OW;
-        int nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 4096), partcap / ((long long)c.O * Kc));
-        nsplit = std::min(nsplit, 512);
+        int nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
+        nsplit = std::min(nsplit, 256);
         EpiP ep = epi(part, true); ep.z_stride = (long long)c.O * Kc;
         PixMajorLoaderT<T> la{}; la.p = dy; la.rows = c.O; la.ld = c.O;
         if (conv1) {

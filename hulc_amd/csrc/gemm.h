@@ -236,6 +236,35 @@ struct DgradOut {   // scatter rows of parity class zc back to NHWC input pixels
     }
 };
 
+// fused epilogue for one output element: alpha, bias(es), early residual, ReLU, ReLU-mask, dropout, late residual,
+// accumulate, fp32 / T store.  `o` = element offset in out (and mask); rrow = residual row.
+template <typename T>
+DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) {
+    float v = accv * ep.alpha;
+    if (ep.bias) v += ep.bias[col];
+    if (ep.bias2) v += ep.bias2[col];
+    float resv = 0.f;
+    if (ep.res) {
+        const long long ro = (long long)rrow * ep.res_ld + col;
+        resv = ep.res_f32 ? reinterpret_cast<const float*>(ep.res)[ro] : to_f<T>(reinterpret_cast<const T*>(ep.res)[ro]);
+    }
+    if (!ep.res_late) v += resv;
+    if (ep.relu) v = fmaxf(v, 0.f);
+    if (ep.mask) v = (to_f<T>(reinterpret_cast<const T*>(ep.mask)[o]) > 0.f) ? v : 0.f;
+    if (ep.drop_p > 0.f) {
+        const float u = hash_uniform(ep.drop_seed, (unsigned long long)o);
+        v = (u < ep.drop_p) ? 0.f : v * (1.f / (1.f - ep.drop_p));
+    }
+    if (ep.res_late) v += resv;
+    if (ep.out_f32) {
+        float* op = reinterpret_cast<float*>(ep.out) + o;
+        *op = ep.accumulate ? (*op + v) : v;
+    } else {
+        T* op = reinterpret_cast<T*>(ep.out) + o;
+        *op = from_f<T>(ep.accumulate ? (to_f<T>(*op) + v) : v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------
@@ -379,31 +408,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
                 for (int j = 0; j < TN; ++j) {
                     const int col = n0 + wn * WN + j * 16 + (lane & 15);
                     if (col < N) {
-                        float v = acc[i][j][r] * ep.alpha;
-                        if (ep.bias) v += ep.bias[col];
-                        if (ep.bias2) v += ep.bias2[col];
-                        float resv = 0.f;
-                        if (ep.res) {
-                            const long long ro = (long long)rrow * ep.res_ld + col;
-                            resv = ep.res_f32 ? reinterpret_cast<const float*>(ep.res)[ro]
-                                              : to_f<T>(reinterpret_cast<const T*>(ep.res)[ro]);
-                        }
-                        if (!ep.res_late) v += resv;
-                        if (ep.relu) v = fmaxf(v, 0.f);
-                        const long long o = obase + col;
-                        if (ep.mask) v = (to_f<T>(reinterpret_cast<const T*>(ep.mask)[o]) > 0.f) ? v : 0.f;
-                        if (ep.drop_p > 0.f) {
-                            const float u = hash_uniform(ep.drop_seed, (unsigned long long)o);
-                            v = (u < ep.drop_p) ? 0.f : v * (1.f / (1.f - ep.drop_p));
-                        }
-                        if (ep.res_late) v += resv;
-                        if (ep.out_f32) {
-                            float* op = reinterpret_cast<float*>(ep.out) + o;
-                            *op = ep.accumulate ? (*op + v) : v;
-                        } else {
-                            T* op = reinterpret_cast<T*>(ep.out) + o;
-                            *op = from_f<T>(ep.accumulate ? (to_f<T>(*op) + v) : v);
-                        }
+                        epi_store<T>(ep, acc[i][j][r], rrow, col, obase + col);
                     }
                 }
             }
@@ -420,4 +425,59 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
     if (nsplit > 1) ksplit = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;   // empty slabs still write zeros
     dim3 grid((Mmax + BM - 1) / BM, (N + BN - 1) / BN, nclass * nsplit);
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AL, BL, OM>), grid, dim3(256), 0, st, al, bl, om, ep, N, K, nsplit, ksplit);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// skinny GEMM (bf16): M <= 64 rows (the per-timestep recurrent GEMMs and every M = B MLP layer).
+//   out[M][N] = epi(A[M][K] W[N][K]^T), weight-bandwidth bound: one workgroup per 16 output columns (N/16 WGs fill
+//   the chip at N = 2048), its 4 waves split K and stream W / A fragments straight from L2 into MFMA operands
+//   (no LDS staging: nothing is reused across waves), then a 16 KB LDS tree combines the 4 K-partials.
+// Requirements: K % 128 == 0, N % 16 == 0, 16-B aligned rows.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) skinny_gemm_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+                                                          long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
+    __shared__ float red[4][1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int kq = K >> 2, kb = wave * kq;
+    const int g = lane >> 4, i = lane & 15;
+    const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    const bf16_t* ap[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ap[mt] = A + (long long)min(mt * 16 + i, M - 1) * lda + kb + g * 8;
+    const int MT = (M + 15) >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < kq; k += 32) {
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + k);
+        bf16x8_t a[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (mt < MT) a[mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (mt < MT) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(mt * 4 + r) * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    // thread (r = tid>>6, lane) finishes tile mt = j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = j * 256 + tid;
+        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        const int row = j * 16 + (lane >> 4) * 4 + (tid >> 6);
+        const int col = n0 + (lane & 15);
+        if (row < M && col < N) {
+            const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
+            epi_store<bf16_t>(ep, v, rrow, col, om.offset(row, 0) + col);
+        }
+    }
+}
+static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, const void* A, const void* W) {
+    return M <= 64 && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }

@@ -61,16 +61,21 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ 
 // conv wgrad partial slabs [nsplit][O][Kc] (packed K order) -> summed, un-permuted, accumulated into torch-layout grad
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsplit, long long slab, float* __restrict__ grad,
                                          int O, int I, int KH, int KW, int nhwc_fwd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // index in torch layout
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // index in packed layout (coalesced slab reads)
     const int total = O * I * KH * KW;
     if (idx >= total) return;
-    int kw = idx % KW, t = idx / KW;
-    int kh = t % KH; t /= KH;
-    int ci = t % I, o = t / I;
-    const long long src = nhwc_fwd ? ((long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci) : idx;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * slab + src];
-    grad[idx] += s;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < nsplit; z += 2) { s0 += part[(long long)z * slab + idx]; s1 += part[(long long)(z + 1) * slab + idx]; }
+    if (z < nsplit) s0 += part[(long long)z * slab + idx];
+    int dst = idx;
+    if (nhwc_fwd) {   // packed idx = o*(KH*KW*I) + (kh*KW+kw)*I + ci  ->  torch ((o*I+ci)*KH+kh)*KW+kw
+        int ci = idx % I, t = idx / I;
+        int kw = t % KW; t /= KW;
+        int kh = t % KH, o = t / KH;
+        dst = ((o * I + ci) * KH + kh) * KW + kw;
+    }
+    grad[dst] += s0 + s1;
 }
 
 // dst[r][perm(c)] = src[r][c] with c = ch*P + p  ->  perm(c) = p*CH + ch   (torch Flatten(C,H,W) <-> NHWC flatten)
@@ -121,25 +126,39 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, lo
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
     const int rbeg = blockIdx.y * rows_per_split, rend = min(M, rbeg + rows_per_split);
-    float s = 0.f;
-    if (c < N)
-        for (int r = rbeg + rl; r < rend; r += 4) s += to_f<T>(x[(long long)r * ld + c]);
-    red[rl][threadIdx.x & 63] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        const T* p = x + c;
+        int r = rbeg + rl;
+        for (; r + 12 < rend; r += 16) {
+            s0 += to_f<T>(p[(long long)r * ld]); s1 += to_f<T>(p[(long long)(r + 4) * ld]);
+            s2 += to_f<T>(p[(long long)(r + 8) * ld]); s3 += to_f<T>(p[(long long)(r + 12) * ld]);
+        }
+        for (; r < rend; r += 4) s0 += to_f<T>(p[(long long)r * ld]);
+    }
+    red[rl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && c < N) {
-        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (direct_accumulate) out[c] += s * scale;
         else out[(long long)blockIdx.y * N + c] = s;
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int N, float* __restrict__ out, float* __restrict__ out2,
-                                    float scale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// out[c] (+out2[c]) += scale * sum_z part[z][c] : 64 columns x 4 partial-lanes per block
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nsplit, int N, float* __restrict__ out,
+                                                           float* __restrict__ out2, float scale) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * N + c];
-    out[c] += s * scale;
-    if (out2) out2[c] += s * scale;
+    if (c < N)
+        for (int z = zl; z < nsplit; z += 4) s += part[(long long)z * N + c];
+    red[zl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (zl == 0 && c < N) {
+        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[c] += s * scale;
+        if (out2) out2[c] += s * scale;
+    }
 }
 
 // =========================================================================================================
@@ -266,15 +285,16 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         if (dx_t) dx_t[(long long)row * ldt + lane + 64] = from_f<T>(d);
     }
 }
-// dgamma[c] += sum_r dy*xhat ; dbeta[c] += sum_r dy   (one block per 64 columns, 4 row lanes, LDS tree)
+// partial sums for dgamma[c] = sum_r dy*xhat and dbeta[c] = sum_r dy over a row chunk (grid.y); part = [2][nsplit][n]
 __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                                    long long ldx, const float* __restrict__ stats, int rows, int n,
-                                                                   float* __restrict__ dg, float* __restrict__ db) {
+                                                                   int rows_per_split, float* __restrict__ part) {
     __shared__ float r1[4][64], r2[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_split, rend = min(rows, rbeg + rows_per_split);
     float a = 0.f, b = 0.f;
     if (c < n)
-        for (int r = rl; r < rows; r += 4) {
+        for (int r = rbeg + rl; r < rend; r += 4) {
             const float d = dy[(long long)r * lddy + c];
             a += d * (x[(long long)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
             b += d;
@@ -283,8 +303,8 @@ __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* 
     __syncthreads();
     if (rl == 0 && c < n) {
         const int t = threadIdx.x;
-        dg[c] += (r1[0][t] + r1[1][t]) + (r1[2][t] + r1[3][t]);
-        db[c] += (r2[0][t] + r2[1][t]) + (r2[2][t] + r2[3][t]);
+        part[(long long)blockIdx.y * n + c] = (r1[0][t] + r1[1][t]) + (r1[2][t] + r1[3][t]);
+        part[((long long)gridDim.y + blockIdx.y) * n + c] = (r2[0][t] + r2[1][t]) + (r2[2][t] + r2[3][t]);
     }
 }
 
