@@ -64,6 +64,12 @@ int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* b, float lw, float cw, fl
 }
 int hulc_backward(hulc_ctx* ctx) { return ctx->e->backward(); }
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
+int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }
+int hulc_set_dropout(hulc_ctx* ctx, float p) {
+    if (p < 0.f || p >= 1.f) { hulc_set_error("hulc_set_dropout: p must be in [0,1)"); return 1; }
+    ctx->e->set_dropout(p);
+    return 0;
+}
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* out, int64_t cap, int64_t* n) { return ctx->e->get_tensor(name, out, cap, n); }
 int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* out, int64_t cap) { return ctx->e->get_plan_idx(out, cap); }
 

@@ -23,6 +23,8 @@ struct IEngine {
     virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
     virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
     virtual int64_t workspace_bytes() const = 0;
+    virtual void set_kl_beta(float b) = 0;
+    virtual void set_dropout(float p) = 0;
     hipStream_t st = nullptr;
 };
 
@@ -112,6 +114,8 @@ struct Engine : IEngine {
     }
     ~Engine() override { for (void* p : allocs) hipFree(p); }
     int64_t workspace_bytes() const override { return ws_bytes; }
+    void set_kl_beta(float b) override { cfg.kl_beta = b; }
+    void set_dropout(float p) override { cfg.dropout_p = p; }
 
     uint64_t site_seed(int site) const {
         uint64_t z = cfg.seed + 0x9E3779B97F4A7C15ull * (cur.step * 64 + (cur.is_lang ? 32 : 0) + site + 1);

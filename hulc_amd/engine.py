@@ -106,6 +106,12 @@ class StepEngine:
         L.check(self.lib.hulc_forward_loss(self.ctx, C.byref(b), loss_weight, clip_weight, self._loss_dev.data_ptr(), 0))
         return self._loss_dev
 
+    def set_kl_beta(self, kl_beta: float):
+        L.check(self.lib.hulc_set_kl_beta(self.ctx, float(kl_beta)))
+
+    def set_dropout(self, p: float):
+        L.check(self.lib.hulc_set_dropout(self.ctx, float(p)))
+
     def backward(self):
         L.check(self.lib.hulc_backward(self.ctx))
 

@@ -1,0 +1,308 @@
+"""`Hulc` / `GCBC` — the reference's LightningModule surface over the MI355X-native step engine.
+
+Drop-in for `hulc.models.hulc.Hulc` (reference hulc/models/hulc.py:27-153) and `hulc.models.gcbc.GCBC`
+(hulc/models/gcbc.py:11-48): same constructor keywords (the Hydra `conf/model/*.yaml` tree instantiates it unchanged),
+same hooks (`training_step`, `configure_optimizers`, `set_kl_beta`, `on_fit_start`, `log`), same `state_dict` keys and
+shapes, same logged metric names (hulc.py:470-536).  Differences forced by the design, both documented in INTEGRATION.md:
+
+* the step's forward AND backward run inside `training_step` (C-ABI `hulc_forward_loss` + `hulc_backward` per
+  modality): the returned loss is a detached scalar tensor, gradients are already in `.grad` (views of one flat
+  buffer) — Lightning users set `automatic_optimization = False`-style manual optimisation, or use
+  `hulc_amd.trainer.fit`;
+* `configure_optimizers()` returns a `FusedAdam` handle (one HIP kernel over the flat buffer, DP mean folded in).
+
+There is no torch/CPU fallback: constructing the module without the HIP library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import parallel, spec
+from .engine import StepEngine
+
+
+def _get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class FusedAdam:
+    """Optimizer handle with the torch.optim surface Lightning touches (step / zero_grad / param_groups / state_dict)."""
+
+    def __init__(self, module: "Hulc", lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if weight_decay:
+            raise NotImplementedError("weight_decay != 0 is not implemented by the fused Adam kernel (reference default is 0)")
+        self.module = module
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, params=list(module.parameters()))]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.module.engine.zero_grads()
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        world = parallel.world_size()
+        parallel.allreduce_sum_(self.module.engine.flat_grads)
+        self.module.engine.adam_step(lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], grad_scale=1.0 / world)
+        return loss
+
+    def state_dict(self):
+        e = self.module.engine
+        return dict(step=e.adam_t, exp_avg=e.adam_m.clone(), exp_avg_sq=e.adam_v.clone(),
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        e = self.module.engine
+        e.adam_t = int(sd["step"])
+        e.adam_m.copy_(sd["exp_avg"])
+        e.adam_v.copy_(sd["exp_avg_sq"])
+
+
+class ConstantSchedule:
+    """transformers.get_constant_schedule (conf/model/lr_scheduler/constant.yaml:1) == LambdaLR(lambda _: 1.0)."""
+
+    def __init__(self, optimizer: FusedAdam):
+        self.optimizer = optimizer
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+
+class Hulc(torch.nn.Module):
+    KIND = "hulc"
+
+    def __init__(
+        self,
+        perceptual_encoder=None,
+        plan_proposal=None,
+        plan_recognition=None,
+        language_goal=None,
+        visual_goal=None,
+        action_decoder=None,
+        kl_beta: float = 0.01,
+        kl_balancing_mix: float = 0.8,
+        state_recons: bool = False,
+        state_recon_beta: float = 0.5,
+        use_bc_z_auxiliary_loss: bool = False,
+        bc_z_auxiliary_loss_beta: float = 1.0,
+        use_mia_auxiliary_loss: bool = False,
+        mia_auxiliary_loss_beta: float = 1.0,
+        optimizer=None,
+        lr_scheduler=None,
+        distribution=None,
+        val_instructions=None,
+        use_clip_auxiliary_loss: bool = True,
+        clip_auxiliary_loss_beta: float = 3.0,
+        replan_freq: int = 30,
+        bc_z_lang_decoder=None,
+        mia_lang_discriminator=None,
+        proj_vis_lang=None,
+        # ---- engine options (not in the reference; defaults keep the reference behaviour)
+        precision: str = "bf16",
+        max_batch_size: int = 64,
+        max_seq_len: Optional[int] = None,
+        device: str = "cuda:0",
+        seed: int = 42,
+    ):
+        super().__init__()
+        # ---- options outside the hot path are rejected loudly instead of silently ignored (SURVEY §2.1 OUT OF SCOPE rows)
+        if state_recons or use_bc_z_auxiliary_loss or use_mia_auxiliary_loss or bc_z_lang_decoder or mia_lang_discriminator:
+            raise NotImplementedError("state_recons / bc_z / mia auxiliary losses are disabled in every BASELINE config and not built")
+        if _get(distribution, "dist", "discrete") != "discrete":
+            raise NotImplementedError("continuous plan distribution (mcil) is a later scope row (SURVEY §8 a19)")
+        pr = plan_recognition
+        if pr is not None and "Transformers" not in str(_get(pr, "_target_", "Transformers")):
+            raise NotImplementedError("only the transformer plan recognition network is built (birnn = mcil, later row)")
+        ad = action_decoder
+        chk = [(_get(ad, "n_mixtures", 10), 10), (_get(ad, "hidden_size", 2048), 2048), (_get(ad, "num_layers", 2), 2),
+               (_get(ad, "rnn_model", "rnn_decoder"), "rnn_decoder"), (_get(ad, "gripper_control", True), True),
+               (_get(ad, "discrete_gripper", True), True), (_get(ad, "policy_rnn_dropout_p", 0.0), 0.0),
+               (_get(pr, "num_heads", 8), 8), (_get(pr, "num_layers", 2), 2), (_get(pr, "encoder_hidden_size", 2048), 2048),
+               (_get(pr, "fc_hidden_size", 4096), 4096), (_get(distribution, "category_size", 32), 32),
+               (_get(distribution, "class_size", 32), 32), (_get(visual_goal, "latent_goal_features", 32), 32)]
+        for got, want in chk:
+            if got != want:
+                raise NotImplementedError(f"configuration value {got!r} differs from the built HULC architecture ({want!r})")
+        self.use_clip_auxiliary_loss = bool(use_clip_auxiliary_loss)
+        self.clip_auxiliary_loss_beta = float(clip_auxiliary_loss_beta)
+        self.kl_beta = float(kl_beta)
+        self.kl_balancing_mix = float(kl_balancing_mix)
+        self.replan_freq = replan_freq
+        self.modality_scope = "vis"
+        self.optimizer_config = optimizer
+        self.lr_scheduler = lr_scheduler
+        mw = _get(pr, "max_position_embeddings", 32) or 32
+        max_window = 32 if isinstance(mw, str) else int(mw)      # a dangling ${...} (vision_only datasets) falls back to 32
+        self.dims = spec.ModelDims(kind=self.KIND, max_window=max_window, use_clip=self.use_clip_auxiliary_loss)
+        self.precision = {"16": "bf16", "bf16": "bf16", "32": "fp32", "fp32": "fp32"}[str(precision)]
+        self.dropout_p = float(_get(pr, "dropout_p", 0.1))
+        self._engine_kw = dict(max_batch=int(max_batch_size), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,
+                               kl_beta=self.kl_beta, kl_balancing_mix=self.kl_balancing_mix,
+                               num_classes=int(_get(ad, "num_classes", 10)), gripper_alpha=float(_get(ad, "gripper_alpha", 1.0)),
+                               log_scale_min=float(_get(ad, "log_scale_min", -7.0)), seed=int(seed))
+        self.engine = StepEngine(self.dims, dropout_p=self.dropout_p, **self._engine_kw)
+        self._train_mode = True
+        self._params = {n: torch.nn.Parameter(v, requires_grad=True) for n, v in self.engine.views(self.engine.flat_params).items()}
+        for n, g in self.engine.views(self.engine.flat_grads).items():
+            self._params[n].grad = g
+        self.reset_parameters(seed)
+        self.logged: Dict[str, float] = {}
+        self.global_step = 0
+        self.rollout_step_counter = 0
+        self.latent_goal = None
+        self.plan = None
+        self.lang_embeddings = None
+
+    # ---- parameters / state dict (reference key names) -------------------------------------------
+    def reset_parameters(self, seed: int = 0):
+        self.engine.load_numpy(spec.init_all(self.dims, seed=seed))
+        parallel.broadcast_(self.engine.flat_params)
+        self.engine.prepare_weights()
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True) -> Iterator[Tuple[str, torch.nn.Parameter]]:  # type: ignore[override]
+        for n, p in self._params.items():
+            yield (prefix + ("." if prefix else "") + n, p)
+
+    def parameters(self, recurse: bool = True):  # type: ignore[override]
+        for _, p in self.named_parameters():
+            yield p
+
+    def _buffers_dict(self) -> Dict[str, torch.Tensor]:
+        lin = torch.linspace(-1.0, 1.0, 21)
+        ad = "action_decoder."
+        ss = "perceptual_encoder.rgb_static_encoder.spatial_softmax."
+        return {ss + "x_map": lin.repeat_interleave(21), ss + "y_map": lin.repeat(21), ss + "temperature": torch.ones(1),
+                ad + "one_hot_embedding_eye": torch.eye(10), ad + "ones": torch.ones(1, 1, 10),
+                ad + "gripper_bounds": torch.tensor([-1.0, 1.0]), ad + "action_max_bound": torch.ones(1, 1, 6, 10),
+                ad + "action_min_bound": -torch.ones(1, 1, 6, 10)}
+
+    def state_dict(self, *args, **kwargs):  # type: ignore[override]
+        sd = {n: p.detach().clone() for n, p in self._params.items()}
+        sd.update(self._buffers_dict())
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True):  # type: ignore[override]
+        missing = [n for n in self._params if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._params and k not in self._buffers_dict()]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for n, p in self._params.items():
+                if n in state_dict:
+                    src = state_dict[n]
+                    if n.endswith("position_embeddings.weight") and src.shape[0] > p.shape[0]:
+                        src = src[: p.shape[0]]          # hulc/utils/utils.py:9-11 trims position-embedding rows
+                    p.copy_(src.to(p.device, torch.float32).reshape(p.shape))
+        self.engine.prepare_weights()
+        return missing, unexpected
+
+    # ---- Lightning-style hooks -------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.engine.device
+
+    def train(self, mode: bool = True):  # type: ignore[override]
+        self._train_mode = bool(mode)
+        self.engine.set_dropout(self.dropout_p if self._train_mode else 0.0)
+        return self
+
+    def eval(self):  # type: ignore[override]
+        return self.train(False)
+
+    def log(self, name: str, value, **kw):
+        self.logged[name] = float(value)
+
+    def set_kl_beta(self, kl_beta):
+        """hulc.py:563-565 — called by the KL-schedule callbacks."""
+        self.kl_beta = float(kl_beta)
+        self.engine.set_kl_beta(self.kl_beta)
+
+    def on_fit_start(self) -> None:
+        """hulc.py:697-737 only builds CLIP-plot metadata from the datamodule (not used for training): no-op here."""
+
+    def configure_optimizers(self):
+        """hulc.py:239-252: Adam over all parameters + per-step scheduler."""
+        oc = self.optimizer_config
+        tgt = str(_get(oc, "_target_", "torch.optim.Adam"))
+        if not tgt.endswith("Adam"):
+            raise NotImplementedError(f"optimizer {tgt}: only torch.optim.Adam (conf/model/optimizer/adam.yaml) has a fused kernel")
+        opt = FusedAdam(self, lr=float(_get(oc, "lr", 2e-4)), betas=tuple(_get(oc, "betas", (0.9, 0.999))), eps=float(_get(oc, "eps", 1e-8)),
+                        weight_decay=float(_get(oc, "weight_decay", 0.0) or 0.0))
+        sc = str(_get(self.lr_scheduler, "_target_", "transformers.get_constant_schedule"))
+        if "constant_schedule" not in sc or "warmup" in sc:
+            raise NotImplementedError(f"lr scheduler {sc}: only the constant schedule (conf/model/lr_scheduler/constant.yaml) is built")
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": ConstantSchedule(opt), "interval": "step", "frequency": 1}}
+
+    @staticmethod
+    def _modality_batch(dataset_batch: Dict[str, Any], is_lang: bool, device) -> Dict[str, Any]:
+        """Reference batch dict (hulc.py:395-414) -> engine inputs."""
+        f = lambda t: t.to(device=device, dtype=torch.float32, non_blocking=True)
+        mb = dict(rgb_static=f(dataset_batch["rgb_obs"]["rgb_static"]), rgb_gripper=f(dataset_batch["rgb_obs"]["rgb_gripper"]),
+                  actions=f(dataset_batch["actions"]), robot_obs=f(dataset_batch["state_info"]["robot_obs"]))
+        if is_lang:
+            mb["lang"] = f(dataset_batch["lang"])            # KeyError 'lang' like the reference (hulc.py:440)
+            m = dataset_batch["use_for_aux_lang_loss"]
+            mb["aux_rows"] = torch.nonzero(m.reshape(-1)).reshape(-1).to("cpu", torch.int32).numpy()
+        if "plan_idx" in dataset_batch and dataset_batch["plan_idx"] is not None:
+            mb["plan_idx"] = dataset_batch["plan_idx"].to(device=device, dtype=torch.int32)
+        return mb
+
+    def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
+        """hulc.py:390-537.  Computes the loss AND accumulates its gradients (see module docstring)."""
+        eng = self.engine
+        eng.zero_grads()
+        nmod = len(batch)
+        if self.use_clip_auxiliary_loss and not any("lang" in s for s in batch):
+            raise KeyError("aux_lang")                       # SURVEY trap T4: reference raises at hulc.py:531
+        kl = act = tot = clip = 0.0
+        total_bs = 0
+        bs: Dict[str, int] = {}
+        for self.modality_scope, dataset_batch in batch.items():
+            is_lang = "lang" in self.modality_scope
+            mb = self._modality_batch(dataset_batch, is_lang, eng.device)
+            l = eng.forward_loss(mb, is_lang, 1.0 / nmod, self.clip_auxiliary_loss_beta, step=self.global_step)
+            eng.backward()
+            b = mb["actions"].shape[0]
+            bs[self.modality_scope] = b
+            total_bs += b
+            if self.KIND == "hulc":
+                self.log(f"train/kl_loss_scaled_{self.modality_scope}", l["kl"], on_step=False, on_epoch=True, batch_size=b)
+            self.log(f"train/action_loss_{self.modality_scope}", l["action"], on_step=False, on_epoch=True, batch_size=b)
+            if self.KIND == "hulc":
+                self.log(f"train/total_loss_{self.modality_scope}", l["total_mod"], on_step=False, on_epoch=True, batch_size=b)
+            kl += l["kl"]; act += l["action"]; tot += l["total_mod"]
+            if is_lang and self.use_clip_auxiliary_loss:
+                clip += l["clip"]
+        total = tot / nmod
+        if self.use_clip_auxiliary_loss:
+            total = total + self.clip_auxiliary_loss_beta * clip
+            self.log("train/lang_clip_loss", parallel.mean_scalar(self.clip_auxiliary_loss_beta * clip), on_step=False, on_epoch=True, sync_dist=True)
+        if self.KIND == "hulc":
+            self.log("train/kl_loss", kl / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/action_loss", act / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.log("train/total_loss", total, on_step=False, on_epoch=True, batch_size=total_bs)
+        self.global_step += 1
+        return torch.tensor(total, dtype=torch.float32, device=eng.device)
+
+    def validation_step(self, batch, batch_idx):
+        raise NotImplementedError("validation / rollout forward (lmp_val, act, step) is SURVEY §8(f) row 2 — not built yet")
+
+    step = reset = load_lang_embeddings = validation_step
+
+
+class GCBC(Hulc):
+    """Goal-conditioned behaviour cloning ablation (reference hulc/models/gcbc.py:11-181): no latent plan in the decoder,
+    loss = action loss (+ CLIP aux), plan_proposal.* and plan_recognition.fc_state.* never receive a gradient."""
+
+    KIND = "gcbc"

@@ -1,0 +1,166 @@
+"""Minimal fit loop standing in for `pytorch_lightning.Trainer.fit` (reference hulc/training.py:27-74), plus the callbacks the
+hot path touches: KL-beta schedules (hulc/utils/kl_callbacks.py), epoch checkpoints (conf/callbacks/checkpoint/all.yaml,
+Lightning-style `{"state_dict", "hyper_parameters", ...}` files, resume via the newest checkpoint as in training.py:38-46),
+and a synthetic CALVIN-shaped datamodule (the real CalvinDataModule lives in the absent calvin_agent package).
+One process per GPU; gradients are combined by hulc_amd.parallel (RCCL).
+"""
+from __future__ import annotations
+
+import glob
+import math
+import os
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import parallel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class SyntheticDataModule:
+    """Yields reference-shaped batch dicts (hulc/models/hulc.py:395-414) of random windows resident on the device."""
+
+    def __init__(self, batch_size: int = 32, max_window_size: int = 32, min_window_size: int = 20, modalities=("vis", "lang"),
+                 steps_per_epoch: int = 50, device: str = "cuda:0", seed: int = 0, **_unused):
+        self.batch_size, self.S = int(batch_size), int(max_window_size)
+        self.modalities = list(modalities)
+        self.steps_per_epoch = int(steps_per_epoch)
+        self.device = torch.device(device)
+        self.seed = seed
+
+    def _modality(self, lang: bool, g: torch.Generator):
+        B, S, dev = self.batch_size, self.S, self.device
+
+        def img(h):
+            u = torch.randint(0, 256, (B, S, 3, h, h), device=dev, generator=g, dtype=torch.int32).float()
+            return (u / 255.0 - 0.5) / 0.5
+
+        act = torch.rand(B, S, 7, device=dev, generator=g) * 2 - 1
+        act[..., 6] = torch.where(torch.rand(B, S, device=dev, generator=g) < 0.5, -1.0, 1.0)
+        ro = torch.randn(B, S, 15, device=dev, generator=g) * 0.3
+        ro[..., 3:6] = torch.rand(B, S, 3, device=dev, generator=g) * 2 - 1
+        d = dict(rgb_obs=dict(rgb_static=img(200), rgb_gripper=img(84)), depth_obs={}, robot_obs=torch.zeros(B, S, 8, device=dev),
+                 actions=act, state_info=dict(robot_obs=ro), idx=torch.arange(B, device=dev))
+        if lang:
+            l = torch.randn(B, 384, device=dev, generator=g)
+            d["lang"] = l / l.norm(dim=-1, keepdim=True)
+            d["use_for_aux_lang_loss"] = torch.ones(B, dtype=torch.bool, device=dev)
+        return d
+
+    def train_dataloader(self, rank: int = 0):
+        g = torch.Generator(device=self.device)
+        for i in range(self.steps_per_epoch):
+            g.manual_seed(self.seed + 1000 * rank + i)
+            yield {m: self._modality("lang" in m, g) for m in self.modalities}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class KLConstantSchedule:
+    """kl_callbacks.py:28-36 — constant beta: nothing to do."""
+
+    def on_train_epoch_start(self, trainer, module):
+        pass
+
+
+class KLLinearSchedule:
+    """kl_callbacks.py:62-80."""
+
+    def __init__(self, start_epoch: int, end_epoch: int, max_kl_beta: float):
+        self.start, self.end, self.max = start_epoch, end_epoch, max_kl_beta
+
+    def _beta(self, epoch):
+        if epoch < self.start:
+            return 0.0
+        if epoch > self.end:
+            return self.max
+        return self.max * (epoch - self.start) / max(1, (self.end - self.start))
+
+    def on_train_epoch_start(self, trainer, module):
+        module.set_kl_beta(self._beta(trainer.current_epoch))
+
+
+class KLSigmoidSchedule(KLLinearSchedule):
+    """kl_callbacks.py:39-59: sigmoid ramp between start and end epoch."""
+
+    def _beta(self, epoch):
+        x = (epoch - self.start) / max(1, (self.end - self.start))
+        return self.max / (1.0 + math.exp(-(12.0 * x - 6.0)))
+
+
+class ModelCheckpoint:
+    def __init__(self, dirpath: str = "saved_models", filename: str = "{epoch}", save_top_k: int = -1, verbose: bool = False, **_):
+        self.dirpath, self.filename = dirpath, filename
+
+    def on_train_epoch_end(self, trainer, module):
+        if trainer.rank != 0:
+            return
+        os.makedirs(os.path.join(trainer.log_dir, self.dirpath), exist_ok=True)
+        path = os.path.join(trainer.log_dir, self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt")
+        save_checkpoint(path, module, trainer.optimizer, trainer.current_epoch, trainer.global_step)
+
+
+def save_checkpoint(path, module, optimizer, epoch, global_step):
+    """Lightning-style checkpoint dict; `state_dict` keys are the reference's."""
+    torch.save({"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in module.state_dict().items()},
+                "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()}],
+                "hyper_parameters": {"kind": module.KIND, "use_clip_auxiliary_loss": module.use_clip_auxiliary_loss}}, path)
+
+
+def get_last_checkpoint(log_dir: str) -> Optional[str]:
+    """training.py:38-46 / calvin_agent.utils.utils.get_last_checkpoint: newest *.ckpt under saved_models."""
+    files = sorted(glob.glob(os.path.join(log_dir, "saved_models", "*.ckpt")), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Trainer:
+    def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_dir: str = "./runs", callbacks: Optional[List] = None,
+                 log_every: int = 10, **_unused):
+        self.max_epochs, self.max_steps, self.log_dir = int(max_epochs), int(max_steps), log_dir
+        self.callbacks = callbacks or []
+        self.log_every = log_every
+        self.current_epoch = 0
+        self.global_step = 0
+        self.rank, self.world, self.local = 0, 1, 0
+        self.optimizer = None
+        self.history: List[Dict[str, float]] = []
+
+    def fit(self, module, datamodule, ckpt_path: Optional[str] = None):
+        self.rank, self.world, self.local = parallel.init_from_env()
+        oc = module.configure_optimizers()
+        self.optimizer, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        if ckpt_path:
+            ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+            module.load_state_dict(ck["state_dict"])
+            self.optimizer.load_state_dict({k: (v.to(module.device) if torch.is_tensor(v) else v) for k, v in ck["optimizer_states"][0].items()})
+            self.current_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
+            module.global_step = self.global_step
+        module.on_fit_start()
+        module.train()
+        t0 = time.time()
+        done = False
+        while self.current_epoch < self.max_epochs and not done:
+            for cb in self.callbacks:
+                if hasattr(cb, "on_train_epoch_start"):
+                    cb.on_train_epoch_start(self, module)
+            for batch in datamodule.train_dataloader(self.rank):
+                loss = module.training_step(batch, self.global_step)      # forward + loss + backward (grads accumulated)
+                self.optimizer.step()                                      # RCCL all-reduce (mean) + fused Adam
+                sched.step()
+                self.global_step += 1
+                if self.rank == 0 and self.global_step % self.log_every == 0:
+                    rec = dict(step=self.global_step, epoch=self.current_epoch, loss=float(loss), time=time.time() - t0, **module.logged)
+                    self.history.append(rec)
+                    print(f"[hulc_amd] epoch {self.current_epoch} step {self.global_step} loss {float(loss):.4f} "
+                          f"action {module.logged.get('train/action_loss', float('nan')):.4f}", flush=True)
+                if 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            for cb in self.callbacks:
+                if hasattr(cb, "on_train_epoch_end"):
+                    cb.on_train_epoch_end(self, module)
+            self.current_epoch += 1
+        torch.cuda.synchronize()
+        return self.history

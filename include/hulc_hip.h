@@ -91,6 +91,11 @@ int hulc_backward(hulc_ctx* ctx);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
 
+/* Runtime knobs: kl_beta (Hulc.set_kl_beta, hulc/models/hulc.py:563-565; called by hulc/utils/kl_callbacks.py:19-22) and the
+ * transformer dropout probability (module.train()/eval(): 0 in eval mode). Take effect from the next hulc_forward_loss. */
+int hulc_set_kl_beta(hulc_ctx* ctx, float kl_beta);
+int hulc_set_dropout(hulc_ctx* ctx, float p);
+
 /* Inspection (tests): copy a named internal tensor to HOST fp32. Returns element count in *n (cap = capacity). */
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* host_out, int64_t cap, int64_t* n);
 int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* host_out, int64_t cap);

@@ -1,0 +1,94 @@
+"""CPU: the mini-Hydra loader on the repo's conf/ tree; data-parallel semantics over gloo (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hulc_amd import config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONF = os.path.join(ROOT, "conf")
+
+
+def test_compose_defaults_and_interpolation():
+    c = config.compose(CONF, "config")
+    m = c.model
+    assert m._target_ == "hulc.models.hulc.Hulc" and m._recursive_ is False
+    assert m.kl_beta == 0.01 and m.kl_balancing_mix == 0.8 and m.clip_auxiliary_loss_beta == 3.0        # ${loss.*}
+    assert m.plan_recognition.max_position_embeddings == 32                                            # ${datamodule.max_window_size}
+    assert m.action_decoder.out_features == 7 and m.action_decoder.act_max_bound == [1.0] * 7
+    assert m.proj_vis_lang.im_dim == 4096 and m.proj_vis_lang.lang_dim == 32                          # nested ${model.*}
+    assert m.optimizer.lr == 2e-4
+    assert m.perceptual_encoder.rgb_static.visual_features == 64 and m.perceptual_encoder.proprio == {}
+    assert sorted(config.missing_keys(c)) == sorted([
+        "model.plan_proposal.perceptual_features", "model.plan_proposal.plan_features", "model.plan_recognition.in_features",
+        "model.plan_recognition.plan_features", "model.visual_goal.in_features", "model.action_decoder.plan_features",
+        "model.action_decoder.perceptual_features"])   # filled by setup_input_sizes in the reference (hulc.py:155-187)
+
+
+def test_overrides_group_value_delete():
+    c = config.compose(CONF, "config", ["model=gcbc", "trainer.precision=fp32", "datamodule.batch_size=8", "loss.kl_beta=0.5",
+                                        "callbacks/kl_schedule=sigmoid", "~callbacks/checkpoint", "+extra.flag=true"])
+    assert c.model._target_ == "hulc.models.gcbc.GCBC"
+    assert c.model.precision == "fp32" and c.model.max_batch_size == 8 and c.model.kl_beta == 0.5
+    assert c.callbacks.kl_schedule._target_.endswith("KLSigmoidSchedule") and c.callbacks.kl_schedule.max_kl_beta == 0.5
+    assert "checkpoint" not in c.callbacks and c.extra.flag is True
+
+
+def test_instantiate_target_map():
+    assert config.TARGET_MAP["hulc.models.hulc.Hulc"] == "hulc_amd.hulc.Hulc"
+    obj = config.instantiate({"_target_": "collections.OrderedDict", "a": 1})
+    assert obj["a"] == 1 and config.instantiate({}) is None and config.instantiate(None) is None
+
+
+def test_kl_schedules():
+    from hulc_amd.trainer import KLLinearSchedule, KLSigmoidSchedule
+    lin = KLLinearSchedule(10, 50, 0.01)
+    assert lin._beta(0) == 0 and abs(lin._beta(30) - 0.005) < 1e-9 and lin._beta(60) == 0.01
+    sig = KLSigmoidSchedule(10, 50, 0.01)
+    assert sig._beta(10) < 1e-4 and abs(sig._beta(30) - 0.005) < 1e-9 and sig._beta(50) > 0.0099
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hulc_amd import parallel, spec
+    parallel.init_from_env("gloo")
+    d = spec.ModelDims()
+    lay, total = spec.layout(d)
+    # each rank: a different deterministic "gradient"; unused tensors (GCBC-style) stay zero on both
+    g = torch.zeros(total)
+    torch.manual_seed(100 + rank)
+    g[: total // 2] = torch.randn(total // 2)
+    flat = g.clone()
+    parallel.allreduce_sum_(flat, bucket_elems=0 if rank == 0 else 0)
+    flat_b = g.clone()
+    parallel.allreduce_sum_(flat_b, bucket_elems=5_000_000)          # bucketed path must agree with the single collective
+    p = torch.full((8,), float(rank))
+    parallel.broadcast_(p, 0)
+    m = parallel.mean_scalar(float(rank + 1))
+    out[rank] = (flat[:1000].clone(), bool(torch.equal(flat, flat_b)), g[:1000].clone(), p, m, float(flat[total // 2:].abs().max()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_mean_gradient_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    (s0, eq0, g0, p0, m0, z0), (s1, eq1, g1, p1, m1, z1) = out[0], out[1]
+    assert eq0 and eq1
+    assert torch.allclose(s0, g0 + g1) and torch.equal(s0, s1)            # both ranks hold the SUM; Adam folds 1/world
+    assert torch.equal(p1, torch.zeros(8)) and m0 == m1 == 1.5
+    assert z0 == 0.0 and z1 == 0.0                                        # tensors without a gradient stay exactly zero
+    # mean-of-rank-gradients + Adam(grad_scale=1/world) == Adam on the averaged gradient (oracle Adam as the checker)
+    import hulc_oracle as O
+    P = {"w": np.ones(1000, np.float32)}
+    Pa = {"w": np.ones(1000, np.float32)}
+    O.adam_step(P, {"w": ((g0 + g1) / 2).numpy()}, {}, 1)
+    O.adam_step(Pa, {"w": (s0 * 0.5).numpy()}, {}, 1)
+    assert np.array_equal(P["w"], Pa["w"])
