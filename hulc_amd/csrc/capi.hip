@@ -95,4 +95,39 @@ int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* str
     return 0;
 }
 
+// conv wgrad unit-test entry (bf16 NHWC): out[CO][KH*KW*CI] (packed (kh,kw,ci) order, fp32, overwritten)
+int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    float* part = nullptr;
+    const int KC = which == 3 ? 576 : 512;
+    if (hipMalloc(&part, sizeof(float) * 512ll * 64 * KC) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
+    int ns;
+    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
+    else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 2 or 3"); return 1; }
+    hipMemsetAsync(out, 0, sizeof(float) * 64 * KC, st);
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((64 * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)64 * KC, out, 64, KC, 1, 1, 0);
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(part);
+    if (e != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// probe of ds_read_b64_tr_b16 semantics (tests/tools only): LDS image lds[i] = i (uint16), lane l reads at element index addr[l]
+__global__ void trread_probe_kernel(const int* __restrict__ addr_in, unsigned short* __restrict__ out) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned short lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (unsigned short)i;
+    __syncthreads();
+    const int a = addr_in[threadIdx.x];
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + a));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (unsigned short)v[j];
+}
+int hulc_k_trread_probe(const int32_t* addr, uint16_t* out, void* stream) {
+    hipLaunchKernelGGL(trread_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)addr, (unsigned short*)out);
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("trread probe launch failed"); return 1; }
+    return 0;
+}
+
 }  // extern "C"

@@ -1,0 +1,157 @@
+// hulc_amd/csrc/conv_wgrad.h — convolution weight gradients for NHWC bf16 activations on gfx950.
+//
+//   dW[co][(kh,kw,ci)] = sum_{n,oh,ow} dY[n][oh][ow][co] * X[n][oh*S+kh][ow*S+kw][ci]
+//
+// Both MFMA operands are reduction-strided in memory (the reduction runs over pixels, the layouts are channel-fastest),
+// which is exactly what ds_read_b64_tr_b16 exists for: the RAW tiles — a band of dY rows and the band of X rows under it —
+// are copied once into LDS in their natural [pixel][channel] order, and every operand fragment is produced by transposing
+// LDS reads.  No im2col: the (kh,kw) taps are address offsets into the X image, so each input element is fetched from HBM
+// once per band instead of KH*KW times.  The reduction unit is an 8-pixel run inside one output row (rows are padded to a
+// multiple of 8 with zero dY pixels), so each 16-lane group of an MFMA (k = 32 = 4 groups x 8) can address its own run.
+//
+// tr-read semantics (probed on MI355X, tools/probe_trread.py): within a 16-lane group, lane i receives element (i & 3) of the
+// 8-byte chunks addressed by lanes (j*4 + (i >> 2)), j = 0..3.  So lane a addresses chunk [k-row = a >> 2][cols (a & 3)*4 ..+3]
+// and lane i ends up with column i of the 4 x 16 block, rows 0..3 — the K-contiguous fragment the bf16 MFMA wants.
+//
+// Work split: persistent workgroups (4 waves) loop over frames and row bands, keep the whole CO x (KH*KW*CI) gradient in
+// accumulator registers (wave w owns a quarter of the n-tiles), and write one fp32 partial slab each at the end; the existing
+// deterministic slab reduction (unpack_conv_wgrad_kernel) finishes the job.
+#pragma once
+#include "common.h"
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
+
+typedef __attribute__((address_space(3))) char lds_char;      // 32-bit LDS pointers: half the address registers of generic ones
+DEVI bf16x8_t tr_read8(lds_char* p0, lds_char* p1) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int CI, int CO, int KH, int KW, int S>
+struct WgradCfg {
+    static constexpr int XS = CI * 2 + 16;          // bytes per input pixel row in LDS (padded: spreads tr-read banks)
+    static constexpr int DYS = CO * 2 + 16;         // bytes per dY pixel row in LDS
+    static constexpr int CGN = CI / 16;             // channel groups per tap
+    static constexpr int NT = KH * KW * CGN;        // n-tiles (16 columns of the packed K dimension each)
+    static constexpr int NTW = NT / 4;              // n-tiles per wave
+    static constexpr int CT = CO / 16;              // co-tiles
+    static_assert(NT % 4 == 0, "n-tiles must split over 4 waves");
+    static size_t lds_bytes(int R, int IW, int OW) {
+        const int OWp = (OW + 7) / 8 * 8;
+        const int XR = (R - 1) * S + KH;
+        return (size_t)(XR * IW + 8 * S + KW) * XS + (size_t)(R * OWp + 8) * DYS;
+    }
+};
+
+template <int CI, int CO, int KH, int KW, int S>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+                                                            int Nf, int IH, int IW, int OH, int OW, int R) {
+    using C = WgradCfg<CI, CO, KH, KW, S>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * S + KH;
+    const int xpix = XR * IW + 8 * S + KW;          // incl. zero tail read by the padded pixels of the last row
+    const int dypix = R * OWp + 8;                  // last 8 pixels: permanent zeros (target of idle lane groups)
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xpix * C::XS;
+    // zero everything once: pads must be finite (0 * NaN would poison the sum) and dY pads must be 0
+    for (int i = tid * 16; i < xpix * C::XS + dypix * C::DYS; i += 256 * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    f32x4 acc[C::NTW][C::CT];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2;                         // pixel (k-row) this lane addresses inside an 8-pixel run: prow, prow + 4
+    const int ccol = (a & 3) * 8;                    // byte offset of this lane's 4-channel chunk inside a 16-channel group
+    const int nt0 = wave * C::NTW;
+
+    for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
+        for (int oh0 = 0; oh0 < OH; oh0 += R) {
+            __syncthreads();                         // previous band fully consumed
+            // ---- stage dY band [R][OWp][CO] (rows/pixels outside the frame -> zeros)
+            {
+                constexpr int CH = CO / 8;           // 16-byte chunks per pixel
+                const int total = R * OW * CH;
+                for (int i = tid; i < total; i += 256) {
+                    const int c = i % CH, p = i / CH;
+                    const int r = p / OW, ow = p % OW;
+                    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+                    if (oh0 + r < OH) v = *reinterpret_cast<const u32x4_t*>(dY + (((long long)f * OH + oh0 + r) * OW + ow) * CO + c * 8);
+                    *(lds_u32x4*)(dyimg + (r * OWp + ow) * C::DYS + c * 16) = v;
+                }
+            }
+            // ---- stage X band [XR][IW][CI] (rows below the frame keep stale finite data: they only meet zero dY rows)
+            {
+                constexpr int CH = CI / 8;
+                const int ih0 = oh0 * S;
+                const int rows = min(XR, IH - ih0);
+                const int total = rows * IW * CH;
+                const bf16_t* src = X + ((long long)f * IH + ih0) * IW * CI;
+                for (int i = tid; i < total; i += 256) {
+                    const int c = i % CH, p = i / CH;
+                    *(lds_u32x4*)(ximg + p * C::XS + c * 16) = *reinterpret_cast<const u32x4_t*>(src + (long long)p * CI + c * 8);
+                }
+            }
+            __syncthreads();
+            // ---- MFMA over the band: 4 eight-pixel runs (one per lane group) per step
+            const int units = R * U;
+            for (int u0 = 0; u0 < units; u0 += 4) {
+                const int u = u0 + g;
+                const bool valid = u < units;
+                const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
+                const int pixA = valid ? r * OWp + ow0 : R * OWp;      // idle groups read the permanent zero pixels
+                lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccol;
+                bf16x8_t af[C::CT];
+#pragma unroll
+                for (int c = 0; c < C::CT; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
+                const int pixB0 = (r * S) * IW + ow0 * S;
+#pragma unroll
+                for (int j = 0; j < C::NTW; ++j) {
+                    const int nt = nt0 + j;
+                    const int tap = nt / C::CGN, cg = nt % C::CGN;
+                    const int kh = tap / KW, kw = tap % KW;
+                    lds_char* bbase = ximg + (pixB0 + kh * IW + kw + prow * S) * C::XS + cg * 32 + ccol;
+                    const bf16x8_t bf = tr_read8(bbase, bbase + 4 * S * C::XS);
+#pragma unroll
+                    for (int c = 0; c < C::CT; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab: part[block][co][nt*16 + n], D layout: row (co) = (lane>>4)*4 + r, col (n) = lane & 15
+    constexpr int KC = KH * KW * CI;
+    float* out = part + (long long)blockIdx.x * CO * KC;
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+}
+
+template <int CI, int CO, int KH, int KW, int S>
+static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, int Nf, int IH, int IW, int OH, int OW,
+                                       int max_blocks) {
+    using C = WgradCfg<CI, CO, KH, KW, S>;
+    int R = OH;                                              // largest band that keeps two workgroups per CU (<= 78 KB)
+    while (R > 1 && C::lds_bytes(R, IW, OW) > 78 * 1024) --R;
+    const size_t lds = C::lds_bytes(R, IW, OW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<CI, CO, KH, KW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = Nf < max_blocks ? Nf : max_blocks;
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(256), lds, st, X, dY, part, Nf, IH, IW, OH, OW, R);
+    return grid;                                             // = number of partial slabs written
+}

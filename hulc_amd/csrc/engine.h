@@ -10,6 +10,7 @@
 #include "../../include/hulc_hip.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "conv_wgrad.h"
 
 struct IEngine {
     virtual ~IEngine() {}
@@ -288,6 +289,12 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((copy2d_kernel<TS, TD>), dim3(cdiv((long long)R * C, 256)), dim3(256), 0, st, src, lds_, dst, ldd, R, C, acc, scale);
     }
     void colsum(const T* x, long long ld, int M, int N, float* out, float* out2 = nullptr, float scale = 1.f) {
+        if (ld == N && (N == 32 || N == 64) && M >= 4096) {          // conv bias grads: flat 16-byte streaming
+            const int nblk = 256;
+            hipLaunchKernelGGL((colsum_flat_kernel<T>), dim3(nblk), dim3(256), 0, st, x, (long long)M * N, N, cspart);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, cspart, nblk, N, out, out2, scale);
+            return;
+        }
         // two-stage, deterministic: <=256 row chunks of >=256 rows, then a 4-lane final per column
         const int nsplit = std::max(1, std::min(256, cdiv(M, 256)));
         const int rps = cdiv(M, nsplit);
@@ -298,12 +305,28 @@ struct Engine : IEngine {
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
-                hipLaunchKernelGGL(skinny_gemm_kernel, dim3(N / 16), dim3(256), 0, st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
+                launch_skinny(st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
                 return;
             }
         }
-        if (M >= 512 && N >= 128) launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
-        else launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
+        // largest tile that still yields >= 128 workgroups (small-N transformer / encoder GEMMs are latency-bound otherwise)
+        const long long w128 = (long long)cdiv(M, 128) * cdiv(N, 128), w64 = (long long)cdiv(M, 64) * cdiv(N, 64);
+        if (M >= 512 && N >= 128 && w128 >= 128) launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
+        else if (w64 >= 128 || (M <= 64 && N <= 64)) launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
+        else launch_gemm<T, 32, 32>(st, a, b, om, ep, M, N, K);
+    }
+    // dW[M][N] += A[M][K] B[N][K]^T with fp32 accumulate; few output tiles + long K -> split K across workgroups (atomics)
+    void gemm_wgrad(const DenseLoader<T>& a, const DenseLoader<T>& b, float* dW, long long lddw, int M, int N, int K) {
+        EpiP ep = epi(dW, true); ep.accumulate = 1;
+        const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128), t64 = (long long)cdiv(M, 64) * cdiv(N, 64);
+        const bool big = M >= 128 && N >= 128;
+        const long long tiles = big ? t128 : t64;
+        int nsplit = 1;
+        if (tiles < 128 && K >= 512) nsplit = (int)std::min<long long>(std::min<long long>(256 / tiles, K / 256), 32);
+        if (nsplit <= 1) { gemm(a, b, dense_out(lddw), ep, M, N, K); return; }
+        ep.atomic = 1;
+        if (big) launch_gemm<T, 128, 128>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
+        else launch_gemm<T, 64, 64>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
     }
     static EpiP epi(void* out, bool f32) { EpiP e; e.out = out; e.out_f32 = f32 ? 1 : 0; return e; }
 
@@ -317,8 +340,7 @@ struct Engine : IEngine {
         const int mp = ldpad(M);
         cast_tr<T, T>(dY, N, nullptr, 0, tA, mp, M, N);
         cast_tr<T, T>(X, ldx, nullptr, 0, tB, mp, M, K);
-        EpiP ep = epi(dW, true); ep.accumulate = 1;
-        gemm(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dense_out(lddw), ep, N, K, M);
+        gemm_wgrad(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dW, lddw, N, K, M);
         if (db) colsum(dY, N, M, N, db, db2);
     }
     // dX[M][K] = dY[M][N] W   (via the transposed copy Wt [K][N])
@@ -424,16 +446,26 @@ struct Engine : IEngine {
     void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {
         const int Kc = c.I * c.KH * c.KW;
         const long long npix = (long long)g.Nf * g.OH * g.OW;
-        int nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
-        nsplit = std::min(nsplit, 256);
-        EpiP ep = epi(part, true); ep.z_stride = (long long)c.O * Kc;
-        PixMajorLoaderT<T> la{}; la.p = dy; la.rows = c.O; la.ld = c.O;
-        if (conv1) {
-            Conv1LoaderT<T> lb{(const float*)xin, g};
-            launch_gemm<T, 32, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
-        } else {
-            ConvNHWCLoaderT<T> lb{(const T*)xin, g};
-            launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
+        int nsplit = 0;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
+            if (!conv1 && c.I == 64 && c.KH == 3)
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 256);
+            else if (!conv1 && c.I == 32 && c.KH == 4)
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 256);
+        }
+        if (nsplit == 0) {
+            nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
+            nsplit = std::min(nsplit, 256);
+            EpiP ep = epi(part, true); ep.z_stride = (long long)c.O * Kc;
+            PixMajorLoaderT<T> la{}; la.p = dy; la.rows = c.O; la.ld = c.O;
+            if (conv1) {
+                Conv1LoaderT<T> lb{(const float*)xin, g};
+                launch_gemm<T, 32, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
+            } else {
+                ConvNHWCLoaderT<T> lb{(const T*)xin, g};
+                launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
+            }
         }
         hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256)), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc, c.dW, c.O, c.I, c.KH,
                            c.KW, c.nhwc);

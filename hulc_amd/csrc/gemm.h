@@ -20,6 +20,7 @@ struct EpiP {
     void* out = nullptr;
     int out_f32 = 0;
     int accumulate = 0;
+    int atomic = 0;              // fp32 out += via atomicAdd (split-K over workgroups; order-nondeterministic at the ulp level)
     long long z_stride = 0;      // element offset between split-K partial slabs
     const float* bias = nullptr;
     const float* bias2 = nullptr;
@@ -220,7 +221,7 @@ struct ConvNHWCLoaderT {   // operand[r=(kh,kw,ci)][k=pixel] from NHWC activatio
 struct DenseOut {
     int R1;
     long long s0, s1;
-    DEVI long long offset(int r, int) const { return (long long)(r / R1) * s0 + (long long)(r % R1) * s1; }
+    DEVI long long offset(int r, int) const { const unsigned q = (unsigned)r / (unsigned)R1; return (long long)q * s0 + (long long)((unsigned)r - q * (unsigned)R1) * s1; }
 };
 static inline DenseOut dense_out(long long ld) { DenseOut o; o.R1 = 0x7fffffff; o.s0 = 0; o.s1 = ld; return o; }
 static inline DenseOut dense_out_map(int R1, long long s0, long long s1) { DenseOut o; o.R1 = R1; o.s0 = s0; o.s1 = s1; return o; }
@@ -258,7 +259,8 @@ DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) 
     if (ep.res_late) v += resv;
     if (ep.out_f32) {
         float* op = reinterpret_cast<float*>(ep.out) + o;
-        *op = ep.accumulate ? (*op + v) : v;
+        if (ep.atomic) unsafeAtomicAdd(op, v);
+        else *op = ep.accumulate ? (*op + v) : v;
     } else {
         T* op = reinterpret_cast<T*>(ep.out) + o;
         *op = from_f<T>(ep.accumulate ? (to_f<T>(*op) + v) : v);
@@ -310,6 +312,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     static_assert(TM >= 1 && TN >= 1, "tile too small");
     __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
+    __shared__ long long rowoff[BM];      // output row offsets: the (division-heavy) output map is evaluated once per row
     T* As = smem;
     T* Bs = smem + BM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -396,13 +399,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
     }
 
     // ---- epilogue: lane holds C[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
+    if (tid < BM) rowoff[tid] = (m0 + tid < M) ? om.offset(m0 + tid, zc) : 0;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
             if (row < M) {
-                const long long obase = om.offset(row, zc) + (long long)zs * ep.z_stride;
+                const long long obase = rowoff[row - m0] + (long long)zs * ep.z_stride;
                 const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -434,50 +439,81 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 //   (no LDS staging: nothing is reused across waves), then a 16 KB LDS tree combines the 4 K-partials.
 // Requirements: K % 128 == 0, N % 16 == 0, 16-B aligned rows.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) skinny_gemm_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
-                                                          long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
-    __shared__ float red[4][1024];
+template <int NW, int MT>
+__global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+                                                             long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
+    __shared__ float red[NW][MT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
-    const int kq = K >> 2, kb = wave * kq;
+    const int m0 = blockIdx.y * 64;                 // row block (grid.y > 1: small-N, large-K GEMMs with many rows)
+    const int kq = K / NW, kb = wave * kq;          // K % (NW*32) == 0
     const int g = lane >> 4, i = lane & 15;
     const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
-    const bf16_t* ap[4];
+    const bf16_t* ap[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) ap[mt] = A + (long long)min(mt * 16 + i, M - 1) * lda + kb + g * 8;
-    const int MT = (M + 15) >> 4;
-    f32x4 acc[4];
+    for (int mt = 0; mt < MT; ++mt) ap[mt] = A + (long long)min(m0 + mt * 16 + i, M - 1) * lda + kb + g * 8;
+    f32x4 acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = 0; k < kq; k += 32) {
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // batches of 4 k-steps: issue all (1+MT)*4 16-byte loads, then the MFMAs (memory-level parallelism per wave)
+    int k = 0;
+    for (; k + 128 <= kq; k += 128) {
+        bf16x8_t b[4], a[4][MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + u * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][mt], b[u], acc[mt], 0, 0, 0);
+    }
+    for (; k < kq; k += 32) {
         const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + k);
-        bf16x8_t a[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            if (mt < MT) a[mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            if (mt < MT) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(mt * 4 + r) * 64 + lane] = acc[mt][r];
     __syncthreads();
-    // thread (r = tid>>6, lane) finishes tile mt = j
+    for (int idx = tid; idx < MT * 256; idx += NW * 64) {
+        float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = j * 256 + tid;
-        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        const int row = j * 16 + (lane >> 4) * 4 + (tid >> 6);
-        const int col = n0 + (lane & 15);
+        for (int w = 0; w < NW; ++w) v += red[w][idx];
+        const int mt = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
+        const int row = m0 + mt * 16 + (l >> 4) * 4 + r;
+        const int col = n0 + (l & 15);
         if (row < M && col < N) {
             const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
             epi_store<bf16_t>(ep, v, rrow, col, om.offset(row, 0) + col);
         }
     }
 }
+template <int NW>
+static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+                                    const DenseOut& om, const EpiP& ep) {
+    const int MT = M >= 64 ? 4 : (M + 15) / 16;
+    dim3 grid(N / 16, (M + 63) / 64), block(NW * 64);
+    switch (MT) {
+        case 1: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 1>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
+        case 2: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 2>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
+        case 3: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 3>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
+        default: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 4>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
+    }
+}
+static inline void launch_skinny(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+                                 const DenseOut& om, const EpiP& ep) {
+    if (K % 512 == 0) launch_skinny_nw<8>(st, A, lda, W, ldw, M, N, K, om, ep);     // 8 waves x >=2 k-steps
+    else launch_skinny_nw<4>(st, A, lda, W, ldw, M, N, K, om, ep);
+}
 static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, const void* A, const void* W) {
-    return M <= 64 && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
+    const bool shape = M <= 64 || (N <= 256 && K >= 512 && (long long)((M + 63) / 64) * (N / 16) >= 64);
+    return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }

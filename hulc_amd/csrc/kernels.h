@@ -144,6 +144,32 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, lo
         else out[(long long)blockIdx.y * N + c] = s;
     }
 }
+// column sums of a contiguous [M][N] matrix with N in {32, 64}: every thread streams 8-element (16 B for bf16) chunks whose
+// column group is fixed (gridDim.x*256*8 % N == 0), partial[blockIdx.x][N] written deterministically
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_flat_kernel(const T* __restrict__ x, long long total, int N, float* __restrict__ part) {
+    __shared__ float red[256][9];
+    const long long nchunk = total >> 3;
+    const long long stride = (long long)gridDim.x * 256;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nchunk; c += stride) {
+        T v[8];
+        load8<T>(x + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += to_f<T>(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    // thread t's column group = (t*8) % N ; groups repeat every N/8 threads
+    const int G = N >> 3;
+    if (threadIdx.x < N) {
+        const int grp = threadIdx.x >> 3, e = threadIdx.x & 7;
+        float a = 0.f;
+        for (int t = grp; t < 256; t += G) a += red[t][e];
+        part[(long long)blockIdx.x * N + threadIdx.x] = a;
+    }
+}
 // out[c] (+out2[c]) += scale * sum_z part[z][c] : 64 columns x 4 partial-lanes per block
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nsplit, int N, float* __restrict__ out,
                                                            float* __restrict__ out2, float scale) {

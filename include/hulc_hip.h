@@ -103,6 +103,10 @@ int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* host_out, int64_t cap);
 /* Per-kernel test entry points (device pointers; dtype selects fp32 / bf16(uint16) storage of A, B). */
 int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, const float* bias, int32_t relu, void* hip_stream);
+/* conv weight-gradient kernel alone (bf16 NHWC activations): which = 2 (4x4 s2, 32->64) or 3 (3x3 s1, 64->64); square frames of
+ * side IH; out = fp32 [64][KH*KW*CI] in packed (kh,kw,ci) order, overwritten. Synchronises. */
+int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* hip_stream);
+int hulc_k_trread_probe(const int32_t* elem_index_per_lane /*64*/, uint16_t* out /*64x4*/, void* hip_stream);
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);
 
 #ifdef __cplusplus
