@@ -99,17 +99,36 @@ int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* str
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     float* part = nullptr;
-    const int KC = which == 3 ? 576 : 512;
+    const int KC = which == 3 ? 576 : (which == 2 ? 512 : 192);
+    const int CO = which == 1 ? 32 : 64;
     if (hipMalloc(&part, sizeof(float) * 512ll * 64 * KC) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
     int ns;
     if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
     else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
-    else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 2 or 3"); return 1; }
-    hipMemsetAsync(out, 0, sizeof(float) * 64 * KC, st);
-    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((64 * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)64 * KC, out, 64, KC, 1, 1, 0);
+    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, (const float*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
+    else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
+    hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
     hipError_t e = hipStreamSynchronize(st);
     hipFree(part);
     if (e != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+// raw-tile conv kernels alone (bf16 NHWC): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of (1)
+int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
+                     int32_t OUTH, int32_t relu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ConvTileP p{}; p.img = (const bf16_t*)img; p.IMH = p.IMW = IMH; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.OUTH = p.OUTW = OUTH;
+    p.bias = bias; p.mask = (const bf16_t*)mask; p.relu = relu; p.Nf = Nf;
+    bool ok = false;
+    if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
+    else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);
+    else if (mode == 2) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+    else if (mode == 3) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+    else if (mode == 4) { launch_conv1_fwd(st, (const float*)img, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH, OUTH, relu & ~1); ok = true; }
+    if (!ok) { hulc_set_error("hulc_k_conv_tile: unsupported mode/shape"); return 1; }
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_conv_tile: launch failed"); return 1; }
     return 0;
 }
 

@@ -1,0 +1,310 @@
+// hulc_amd/csrc/conv_tile.h — raw-tile convolution kernels for NHWC bf16 activations on gfx950 (forward and data-gradient).
+//
+// Instead of an implicit-GEMM gather (every input element re-fetched KH*KW/S^2 times through the loader), a persistent
+// workgroup (8 waves) keeps the whole packed weight matrix in LDS and streams *raw* row bands of the image through a second
+// LDS region: the (kh,kw) taps are plain address offsets into that band, so each activation byte is read from HBM once.
+// The next band is prefetched into registers while the current one is being multiplied.
+//
+//   forward  (REV=0): out[i][j][cn]            = act( sum_{ta,tb,ck} img[i*SI+ta][j*SI+tb][ck] * W[cn][(ta,tb,ck)] + bias[cn] )
+//   dgrad    (REV=1): out[i*OS+ph][j*OS+pw][cn] = mask * sum_{ta,tb,ck} img[i-ta][j-tb][ck] * W[(ph,pw)][cn][(ta,tb,ck)]
+//                     (img = dY with implicit zero border; (ph,pw) = stride-parity class of the input pixel, OS = conv stride)
+//
+// MFMA orientation: A = weight fragment (rows = cn), B = image fragment (cols = 16 flattened pixels of the band), so each lane
+// ends up with 4 consecutive output channels of one pixel -> 8-byte stores, 4-channel bias / mask loads.
+#pragma once
+#include "common.h"
+#include "conv_wgrad.h"   // lds_char, u32x4_t
+
+struct ConvTileP {
+    const bf16_t* img; int IMH, IMW;
+    const bf16_t* w;
+    bf16_t* out; int OUTH, OUTW;
+    const float* bias;
+    const bf16_t* mask;
+    int relu;
+    int Nf, RB, nbands, LW, LR;
+};
+
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
+struct ConvTileCfg {
+    static constexpr int XS = CK * 2 + 16;                     // LDS bytes per staged pixel (padded -> conflict-free b128 rows)
+    static constexpr int WS = TA * TB * CK * 2 + 16;           // LDS bytes per weight row
+    static constexpr int NCLS = OS * OS;
+    static constexpr int NT = CN / 16;
+    static constexpr int CH = CK / 8;                          // 16-byte chunks per pixel
+    static constexpr int PF = 10;                              // prefetch registers (uint4) per thread
+    static constexpr int MT = 2;                               // m-tiles (16 pixels) per wave pass
+    static size_t w_bytes() { return (size_t)NCLS * CN * WS; }
+    static size_t lds_bytes(int LR, int LW) { return w_bytes() + (size_t)(LR * LW + 16) * XS; }
+};
+
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
+__global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
+    using C = ConvTileCfg<CK, CN, TA, TB, SI, OS, REV>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* wl = (lds_char*)smem;
+    lds_char* xl = wl + C::NCLS * CN * C::WS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    // ---- weights -> LDS (once)
+    {
+        constexpr int ROWCH = TA * TB * CK / 8;                // 16-byte chunks per weight row
+        for (int i = tid; i < C::NCLS * CN * ROWCH; i += 512) {
+            const int r = i / ROWCH, c = i % ROWCH;
+            *(lds_u32x4*)(wl + r * C::WS + c * 16) = *reinterpret_cast<const u32x4_t*>(p.w + (long long)r * (TA * TB * CK) + c * 8);
+        }
+    }
+    const int nitems = p.Nf * p.nbands;
+    const int wchunks = p.LR * p.LW * C::CH;
+    u32x4_t pf[C::PF];
+    auto prefetch = [&](int item) {
+        const int f = item / p.nbands, b = item % p.nbands;
+        const int i0 = b * p.RB;
+        const int rlo = REV ? i0 - (TA - 1) : i0 * SI;
+        const int clo = REV ? -(TB - 1) : 0;
+        const bf16_t* base = p.img + (long long)f * p.IMH * p.IMW * CK;
+#pragma unroll
+        for (int k = 0; k < C::PF; ++k) {
+            const int q = tid + k * 512;
+            const int qc = min(q, wchunks - 1);
+            const int pix = qc / C::CH, c = qc % C::CH;
+            const int wr = pix / p.LW, wc = pix % p.LW;
+            const int ir = rlo + wr, ic = clo + wc;
+            const bool in = ir >= 0 && ir < p.IMH && ic >= 0 && ic < p.IMW;
+            const int irc = min(max(ir, 0), p.IMH - 1), icc = min(max(ic, 0), p.IMW - 1);
+            u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + ((long long)irc * p.IMW + icc) * CK + c * 8);   // always-valid address
+            if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+            pf[k] = v;
+        }
+    };
+    int item = blockIdx.x;
+    if (item < nitems) prefetch(item);
+    while (item < nitems) {
+        __syncthreads();                                        // previous band fully consumed (and weights visible)
+#pragma unroll
+        for (int k = 0; k < C::PF; ++k) {
+            const int q = tid + k * 512;
+            if (q < wchunks) *(lds_u32x4*)(xl + (q / C::CH) * C::XS + (q % C::CH) * 16) = pf[k];
+        }
+        __syncthreads();
+        const int cur = item;
+        item += gridDim.x;
+        if (item < nitems) prefetch(item);                      // in flight during the MFMAs below
+        const int f = cur / p.nbands, b = cur % p.nbands;
+        const int i0 = b * p.RB;
+#pragma unroll 1
+        for (int cls = 0; cls < C::NCLS; ++cls) {
+            const int ph = cls / OS, pw = cls % OS;
+            const int NI = (p.OUTH - ph + OS - 1) / OS, NJ = (p.OUTW - pw + OS - 1) / OS;
+            const int RBe = min(p.RB, NI - i0);
+            if (RBe <= 0) continue;
+            const int npix = RBe * NJ;
+            const int ntm = (npix + 15) >> 4;
+            for (int mt0 = wave * C::MT; mt0 < ntm; mt0 += 8 * C::MT) {
+                int xoff[C::MT];
+                int opix[C::MT];                                // output pixel offset (elements / CN) or -1
+#pragma unroll
+                for (int mm = 0; mm < C::MT; ++mm) {
+                    const int pi = (mt0 + mm) * 16 + li;
+                    const bool ok = pi < npix;
+                    const int pc = ok ? pi : npix - 1;
+                    const int ri = pc / NJ, j = pc % NJ;
+                    xoff[mm] = (REV ? ((ri + TA - 1) * p.LW + (j + TB - 1)) : (ri * SI * p.LW + j * SI)) * C::XS + g * 16;
+                    opix[mm] = ok ? (((i0 + ri) * OS + ph) * p.OUTW + j * OS + pw) : -1;
+                }
+                f32x4 acc[C::MT][C::NT];
+#pragma unroll
+                for (int mm = 0; mm < C::MT; ++mm)
+#pragma unroll
+                    for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lds_char* wrow = wl + (cls * CN + li) * C::WS + g * 16;
+#pragma unroll 1
+                for (int tap = 0; tap < TA * TB; ++tap) {     // not unrolled: keeps the weight fragments out of the loop-invariant set
+                    const int ta = tap / TB, tb = tap % TB;
+                    const int toff = (REV ? -(ta * p.LW + tb) : (ta * p.LW + tb)) * C::XS;
+#pragma unroll
+                    for (int ks = 0; ks < CK / 32; ++ks) {
+                        bf16x8_t xf[C::MT], wf[C::NT];
+#pragma unroll
+                        for (int mm = 0; mm < C::MT; ++mm) xf[mm] = *(__attribute__((address_space(3))) bf16x8_t*)(xl + xoff[mm] + toff + ks * 64);
+#pragma unroll
+                        for (int nn = 0; nn < C::NT; ++nn) wf[nn] = *(__attribute__((address_space(3))) bf16x8_t*)(wrow + nn * 16 * C::WS + (tap * CK + ks * 32) * 2);
+#pragma unroll
+                        for (int mm = 0; mm < C::MT; ++mm)
+#pragma unroll
+                            for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], xf[mm], acc[mm][nn], 0, 0, 0);
+                    }
+                }
+                // ---- epilogue: lane holds channels cn0..cn0+3 (cn0 = nn*16 + g*4) of pixel li of each m-tile
+#pragma unroll
+                for (int mm = 0; mm < C::MT; ++mm) {
+                    if (opix[mm] < 0) continue;
+                    const long long obase = ((long long)f * p.OUTH * p.OUTW + opix[mm]) * CN;
+#pragma unroll
+                    for (int nn = 0; nn < C::NT; ++nn) {
+                        const int cn0 = nn * 16 + g * 4;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[mm][nn][r];
+                        if (p.bias) {
+                            const float4 bb = *reinterpret_cast<const float4*>(p.bias + cn0);
+                            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        if (p.mask) {
+                            const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + obase + cn0);
+                            const bf16_t m0 = (bf16_t)(mk.x & 0xffff), m1 = (bf16_t)(mk.x >> 16), m2 = (bf16_t)(mk.y & 0xffff), m3 = (bf16_t)(mk.y >> 16);
+                            v[0] = bf2f(m0) > 0.f ? v[0] : 0.f; v[1] = bf2f(m1) > 0.f ? v[1] : 0.f;
+                            v[2] = bf2f(m2) > 0.f ? v[2] : 0.f; v[3] = bf2f(m3) > 0.f ? v[3] : 0.f;
+                        }
+                        uint2 o;
+                        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(p.out + obase + cn0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// host side: pick the band height, launch persistent workgroups. Returns false if the shape does not fit (caller falls back).
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
+static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
+    using C = ConvTileCfg<CK, CN, TA, TB, SI, OS, REV>;
+    const int NI = REV ? (p.OUTH + OS - 1) / OS : p.OUTH;          // class rows (class 0 is the largest)
+    const int NJ = REV ? (p.OUTW + OS - 1) / OS : p.OUTW;
+    p.LW = REV ? NJ + TB - 1 : p.IMW;
+    int RB = NI;
+    for (;; --RB) {
+        if (RB < 1) return false;
+        const int LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA;
+        if ((long long)LR * p.LW * C::CH <= 512ll * C::PF && C::lds_bytes(LR, p.LW) <= 160 * 1024) { p.LR = LR; break; }
+    }
+    // balance the bands
+    p.nbands = (NI + RB - 1) / RB;
+    RB = (NI + p.nbands - 1) / p.nbands;
+    p.RB = RB;
+    p.LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA;
+    const size_t lds = C::lds_bytes(p.LR, p.LW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int items = p.Nf * p.nbands;
+    const int grid = items < 256 ? items : 256;
+    hipLaunchKernelGGL((conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>), dim3(grid), dim3(512), lds, st, p);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 forward (8x8 stride 4, 3 -> 32, + bias + ReLU) straight from the fp32 NCHW boundary frames.
+// The band of input rows is converted to bf16 while staged ([c][row][iw] image, each input byte read from HBM once instead
+// of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
+// x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* ximg = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int XR = (R - 1) * 4 + 8;
+    const int XRS = IW * 2 + 16;
+    const int W4 = IW >> 2;
+    bf16x8_t wf[6][2];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(W + (ct * 16 + li) * 192 + ks * 32 + g * 8);
+    // (c, kh) row of this lane group for each k-step
+    int rowsel[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    const int nitems = Nf * nbands;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int f = item / nbands, b = item % nbands;
+        const int oh0 = b * R;
+        const int ih0 = oh0 * 4;
+        const int rows = min(XR, IH - ih0);
+        __syncthreads();
+        if (!(dbg & 4)) {
+            const int nrows = 3 * rows;
+            for (int t0 = wave * 8; t0 < nrows; t0 += 32) {               // 8 rows (one float4 per lane each) in flight per wave
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                               // unconditional (clamped) loads: no branch, no per-load wait
+                    const int t = min(t0 + u, nrows - 1), lc = min(lane, W4 - 1);
+                    const int c = t / rows, rr = t - c * rows;
+                    v[u] = *reinterpret_cast<const float4*>(X + (((long long)f * 3 + c) * IH + ih0 + rr) * IW + lc * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u;
+                    if (t < nrows && lane < W4) {
+                        const int c = t / rows, rr = t - c * rows;
+                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                        u32x2_t o;
+                        o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                        o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                        *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + lane * 8) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int RBe = min(R, OH - oh0);
+        const int npix = RBe * OW;
+        const int ntm = (dbg & 2) ? 0 : (npix + 15) >> 4;
+        for (int mt = wave; mt < ntm; mt += 4) {
+            const int pi = mt * 16 + li;
+            const bool ok = pi < npix;
+            const int pc = ok ? pi : npix - 1;
+            const int r = pc / OW, ow = pc - r * OW;
+            lds_char* xb = ximg + r * 4 * XRS + ow * 8;
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                typedef short s16x4v __attribute__((ext_vector_type(4)));
+                typedef short s16x8v __attribute__((ext_vector_type(8)));
+                const s16x4v lo = *(__attribute__((address_space(3))) s16x4v*)(xb + rowsel[ks]);
+                const s16x4v hi = *(__attribute__((address_space(3))) s16x4v*)(xb + rowsel[ks] + 8);
+                const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, (s16x8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf, acc[ct], 0, 0, 0);
+            }
+            if (ok) {
+                const long long obase = (((long long)f * OH + oh0 + r) * OW + ow) * 32;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int cn0 = ct * 16 + g * 4;
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + cn0);
+                    const float v0 = fmaxf(acc[ct][0] + bb.x, 0.f), v1 = fmaxf(acc[ct][1] + bb.y, 0.f);
+                    const float v2 = fmaxf(acc[ct][2] + bb.z, 0.f), v3 = fmaxf(acc[ct][3] + bb.w, 0.f);
+                    uint2 o;
+                    o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                    o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                    *reinterpret_cast<uint2*>(out + obase + cn0) = o;
+                }
+            }
+        }
+    }
+}
+static inline void launch_conv1_fwd(hipStream_t st, const float* X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0) {
+    auto lds_of = [&](int R) { return (size_t)3 * ((R - 1) * 4 + 8) * (IW * 2 + 16) + 64; };
+    int R = OH;
+    while (R > 1 && lds_of(R) > 78 * 1024) --R;
+    const int nbands = (OH + R - 1) / R;
+    R = (OH + nbands - 1) / nbands;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int items = Nf * nbands;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < 512 ? items : 512), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg);
+}

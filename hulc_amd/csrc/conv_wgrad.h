@@ -78,16 +78,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
     for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
         for (int oh0 = 0; oh0 < OH; oh0 += R) {
             __syncthreads();                         // previous band fully consumed
-            // ---- stage dY band [R][OWp][CO] (rows/pixels outside the frame -> zeros)
+            // ---- stage dY band [R][OWp][CO] (rows outside the frame -> zeros): one band row per wave pass, no per-chunk division
             {
                 constexpr int CH = CO / 8;           // 16-byte chunks per pixel
-                const int total = R * OW * CH;
-                for (int i = tid; i < total; i += 256) {
-                    const int c = i % CH, p = i / CH;
-                    const int r = p / OW, ow = p % OW;
-                    u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-                    if (oh0 + r < OH) v = *reinterpret_cast<const u32x4_t*>(dY + (((long long)f * OH + oh0 + r) * OW + ow) * CO + c * 8);
-                    *(lds_u32x4*)(dyimg + (r * OWp + ow) * C::DYS + c * 16) = v;
+                for (int r = wave; r < R; r += 4) {
+                    const bool in = oh0 + r < OH;
+                    const bf16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * CO;
+                    for (int i = lane; i < OW * CH; i += 64) {
+                        u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
+                        if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+                        *(lds_u32x4*)(dyimg + (r * OWp + i / CH) * C::DYS + (i % CH) * 16) = v;
+                    }
                 }
             }
             // ---- stage X band [XR][IW][CI] (rows below the frame keep stale finite data: they only meet zero dY rows)
@@ -97,9 +98,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                 const int rows = min(XR, IH - ih0);
                 const int total = rows * IW * CH;
                 const bf16_t* src = X + ((long long)f * IH + ih0) * IW * CI;
-                for (int i = tid; i < total; i += 256) {
-                    const int c = i % CH, p = i / CH;
-                    *(lds_u32x4*)(ximg + p * C::XS + c * 16) = *reinterpret_cast<const u32x4_t*>(src + (long long)p * CI + c * 8);
+                for (int i0 = tid; i0 < total; i0 += 256 * 8) {          // 8 independent 16-byte loads in flight per thread
+                    u32x4_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {                           // unconditional (clamped) loads: no branch, no per-load wait
+                        const int i = min(i0 + u * 256, total - 1);
+                        v[u] = *reinterpret_cast<const u32x4_t*>(src + (long long)(i / CH) * CI + (i % CH) * 8);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * 256;
+                        if (i < total) *(lds_u32x4*)(ximg + (i / CH) * C::XS + (i % CH) * 16) = v[u];
+                    }
                 }
             }
             __syncthreads();
@@ -154,4 +164,133 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf
     const int grid = Nf < max_blocks ? Nf : max_blocks;
     hipLaunchKernelGGL((conv_wgrad_tr_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(256), lds, st, X, dY, part, Nf, IH, IW, OH, OW, R);
     return grid;                                             // = number of partial slabs written
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 (8x8 stride 4, 3 -> 32 channels) weight gradient straight from the fp32 NCHW boundary frames.
+//   dW[co][(c,kh,kw)] = sum dY[n][oh][ow][co] * X[n][c][oh*4+kh][ow*4+kw]
+// The X band is converted to bf16 while it is staged ([c][row][iw] image), dY is staged as [pix][32]; an n-tile of 16 packed
+// columns = (c, two kernel rows kh, 8 kw): lane chunk q covers kh = kh_lo + q/2, kw = (q&1)*4..+3 -> 4 contiguous bf16 in a row.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Wgrad1Cfg {
+    static constexpr int CO = 32, KH = 8, KW = 8, S = 4, C = 3;
+    static constexpr int DYS = CO * 2 + 16;
+    static size_t lds_bytes(int R, int IW, int OW) {
+        const int OWp = (OW + 7) / 8 * 8;
+        const int XR = (R - 1) * S + KH;
+        return (size_t)C * XR * (IW * 2 + 16) + 512 + (size_t)(R * OWp + 8) * DYS;
+    }
+};
+
+__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+                                                                int Nf, int IH, int IW, int OH, int OW, int R) {
+    using C = Wgrad1Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * C::S + C::KH;
+    const int XRS = IW * 2 + 16;                                  // bytes per staged input row
+    const int xbytes = C::C * XR * XRS + 512;
+    const int dypix = R * OWp + 8;
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xbytes;
+    for (int i = tid * 16; i < xbytes + dypix * C::DYS; i += 256 * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2, q = a & 3;
+    const int ccolA = q * 8;
+    const int nt0 = wave * 3;
+    const int W4 = IW >> 2;                                       // float4 per input row (IW % 4 == 0)
+
+    for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
+        for (int oh0 = 0; oh0 < OH; oh0 += R) {
+            __syncthreads();
+            {   // dY band, one row per wave pass
+                for (int r = wave; r < R; r += 4) {
+                    const bool in = oh0 + r < OH;
+                    const bf16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * C::CO;
+                    for (int i = lane; i < OW * 4; i += 64) {
+                        u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
+                        if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+                        *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
+                    }
+                }
+            }
+            {   // X band: fp32 NCHW rows -> bf16 [c][row][iw], one (c,row) per wave pass
+                const int ih0 = oh0 * C::S;
+                const int rows = min(XR, IH - ih0);
+                const int nrows = C::C * rows;
+                for (int t0 = wave * 8; t0 < nrows; t0 += 32) {           // 8 rows (one float4 per lane each) in flight per wave
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {                           // unconditional (clamped) loads
+                        const int t = min(t0 + u, nrows - 1), lc = min(lane, W4 - 1);
+                        const int c = t / rows, rr = t - c * rows;
+                        v[u] = *reinterpret_cast<const float4*>(X + (((long long)f * C::C + c) * IH + ih0 + rr) * IW + lc * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < nrows && lane < W4) {
+                            const int c = t / rows, rr = t - c * rows;
+                            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                            u32x2_t o;
+                            o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                            o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                            *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + lane * 8) = o;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int units = R * U;
+            for (int u0 = 0; u0 < units; u0 += 4) {
+                const int u = u0 + g;
+                const bool valid = u < units;
+                const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
+                const int pixA = valid ? r * OWp + ow0 : R * OWp;
+                lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
+                bf16x8_t af[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int nt = nt0 + j;
+                    const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
+                    lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
+                    const bf16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = part + (long long)blockIdx.x * C::CO * 192;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * 192 + (nt0 + j) * 16 + a] = acc[j][c][r];
+}
+
+static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf16_t* dY, float* part, int Nf, int IH, int IW, int OH, int OW,
+                                        int max_blocks) {
+    int R = OH;
+    while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW) > 78 * 1024) --R;
+    const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv1_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = Nf < max_blocks ? Nf : max_blocks;
+    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, dY, part, Nf, IH, IW, OH, OW, R);
+    return grid;
 }

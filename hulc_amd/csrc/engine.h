@@ -11,6 +11,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "conv_wgrad.h"
+#include "conv_tile.h"
 
 struct IEngine {
     virtual ~IEngine() {}
@@ -415,20 +416,30 @@ struct Engine : IEngine {
     }
     void enc_fwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
-        {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            launch_conv1_fwd(st, x, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW);
+        } else {
             Conv1Loader<T> l{x, g1};
             EpiP ep = epi(a.a1, false); ep.bias = e.c1.b32; ep.relu = 1;
             launch_gemm<T, 128, 32>(st, l, dense<T>(e.c1.Wf, 32, 192), dense_out(32), ep, Nf * g1.OH * g1.OW, 32, 192);
         }
-        {
-            ConvNHWCLoader<T> l{a.a1, g2};
-            EpiP ep = epi(a.a2, false); ep.bias = e.c2.b32; ep.relu = 1;
-            launch_gemm<T, 128, 64>(st, l, dense<T>(e.c2.Wf, 64, 512), dense_out(64), ep, Nf * g2.OH * g2.OW, 64, 512);
+        bool tiled = false;
+        if constexpr (std::is_same<T, bf16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
+            ConvTileP p2{}; p2.img = a.a1; p2.IMH = p2.IMW = e.H1; p2.w = e.c2.Wf; p2.out = a.a2; p2.OUTH = p2.OUTW = e.H2; p2.bias = e.c2.b32; p2.relu = 1; p2.Nf = Nf;
+            ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
+            tiled = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2) && launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
         }
-        {
-            ConvNHWCLoader<T> l{a.a2, g3};
-            EpiP ep = epi(a.a3, false); ep.bias = e.c3.b32; ep.relu = 1;
-            launch_gemm<T, 128, 64>(st, l, dense<T>(e.c3.Wf, 64, 576), dense_out(64), ep, Nf * g3.OH * g3.OW, 64, 576);
+        if (!tiled) {
+            {
+                ConvNHWCLoader<T> l{a.a1, g2};
+                EpiP ep = epi(a.a2, false); ep.bias = e.c2.b32; ep.relu = 1;
+                launch_gemm<T, 128, 64>(st, l, dense<T>(e.c2.Wf, 64, 512), dense_out(64), ep, Nf * g2.OH * g2.OW, 64, 512);
+            }
+            {
+                ConvNHWCLoader<T> l{a.a2, g3};
+                EpiP ep = epi(a.a3, false); ep.bias = e.c3.b32; ep.relu = 1;
+                launch_gemm<T, 128, 64>(st, l, dense<T>(e.c3.Wf, 64, 576), dense_out(64), ep, Nf * g3.OH * g3.OW, 64, 576);
+            }
         }
         const T* fin; int fk;
         if (!e.gripper) {
@@ -449,10 +460,12 @@ struct Engine : IEngine {
         int nsplit = 0;
         if constexpr (std::is_same<T, bf16_t>::value) {
             // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
-            if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 256);
+            if (conv1)
+                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+            else if (!conv1 && c.I == 64 && c.KH == 3)
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 256);
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
         }
         if (nsplit == 0) {
             nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
@@ -467,11 +480,18 @@ struct Engine : IEngine {
                 launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
             }
         }
-        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256)), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc, c.dW, c.O, c.I, c.KH,
-                           c.KW, c.nhwc);
+        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256), nsplit >= 64 ? 8 : 1), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,
+                           c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
         colsum(dy, c.O, (int)npix, c.O, c.db);
     }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.Nf = g.Nf;
+            bool ok = false;
+            if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+            else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+            if (ok) return;
+        }
         ConvDgradLoader<T> l{dy, g, c.O};
         DgradOut om{g};
         EpiP ep = epi(dx, false); ep.mask = mask;

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
     __shared__ float red[NW][MT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
-    const int m0 = blockIdx.y * 64;                 // row block (grid.y > 1: small-N, large-K GEMMs with many rows)
+    const int m0 = blockIdx.y * (MT * 16);          // row block of MT*16 rows
     const int kq = K / NW, kb = wave * kq;          // K % (NW*32) == 0
     const int g = lane >> 4, i = lane & 15;
     const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
@@ -499,8 +499,11 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
 template <int NW>
 static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
                                     const DenseOut& om, const EpiP& ep) {
-    const int MT = M >= 64 ? 4 : (M + 15) / 16;
-    dim3 grid(N / 16, (M + 63) / 64), block(NW * 64);
+    // The kernel is bound by the per-CU load path (~10 B/clk/CU): every workgroup streams its A rows (M x K) and a 16-row W slice.
+    // With only N/16 workgroups (128 at N = 2048) half the CUs idle, so split the rows in two 32-row blocks when that fills the chip.
+    int MT = M >= 64 ? 4 : (M + 15) / 16;
+    if (M > 32 && (N / 16) * ((M + 63) / 64) <= 160) MT = 2;
+    dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16)), block(NW * 64);
     switch (MT) {
         case 1: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 1>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
         case 2: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 2>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;

@@ -58,16 +58,22 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
-// conv wgrad partial slabs [nsplit][O][Kc] (packed K order) -> summed, un-permuted, accumulated into torch-layout grad
+// conv wgrad partial slabs [nsplit][O][Kc] (packed K order) -> summed, un-permuted, accumulated into torch-layout grad.
+// grid.y splits the slab range; each part lands with one fp32 atomicAdd (<= gridDim.y adds per element).
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsplit, long long slab, float* __restrict__ grad,
                                          int O, int I, int KH, int KW, int nhwc_fwd) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // index in packed layout (coalesced slab reads)
     const int total = O * I * KH * KW;
     if (idx >= total) return;
-    float s0 = 0.f, s1 = 0.f;
-    int z = 0;
-    for (; z + 1 < nsplit; z += 2) { s0 += part[(long long)z * slab + idx]; s1 += part[(long long)(z + 1) * slab + idx]; }
-    if (z < nsplit) s0 += part[(long long)z * slab + idx];
+    const int per = (nsplit + gridDim.y - 1) / gridDim.y;
+    const int z0 = blockIdx.y * per, z1 = min(nsplit, z0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+        s0 += part[(long long)z * slab + idx]; s1 += part[(long long)(z + 1) * slab + idx];
+        s2 += part[(long long)(z + 2) * slab + idx]; s3 += part[(long long)(z + 3) * slab + idx];
+    }
+    for (; z < z1; ++z) s0 += part[(long long)z * slab + idx];
     int dst = idx;
     if (nhwc_fwd) {   // packed idx = o*(KH*KW*I) + (kh*KW+kw)*I + ci  ->  torch ((o*I+ci)*KH+kh)*KW+kw
         int ci = idx % I, t = idx / I;
@@ -75,7 +81,9 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsp
         int kh = t % KH, o = t / KH;
         dst = ((o * I + ci) * KH + kh) * KW + kw;
     }
-    grad[dst] += s0 + s1;
+    const float s = (s0 + s1) + (s2 + s3);
+    if (gridDim.y > 1) unsafeAtomicAdd(grad + dst, s);
+    else grad[dst] += s;
 }
 
 // dst[r][perm(c)] = src[r][c] with c = ch*P + p  ->  perm(c) = p*CH + ch   (torch Flatten(C,H,W) <-> NHWC flatten)

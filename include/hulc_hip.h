@@ -106,6 +106,11 @@ int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_
 /* conv weight-gradient kernel alone (bf16 NHWC activations): which = 2 (4x4 s2, 32->64) or 3 (3x3 s1, 64->64); square frames of
  * side IH; out = fp32 [64][KH*KW*CI] in packed (kh,kw,ci) order, overwritten. Synchronises. */
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* hip_stream);
+/* raw-tile conv kernels alone (bf16 NHWC, square frames): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of
+ * (1). img side IMH, out side OUTH; w = packed weights as produced by hulc_prepare_weights (fwd [co][(kh,kw,ci)], dgrad per-parity
+ * [class][ci][(a,b,co)]); bias fp32 / mask bf16 optional. Asynchronous on hip_stream. */
+int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
+                     int32_t OUTH, int32_t relu, void* hip_stream);
 int hulc_k_trread_probe(const int32_t* elem_index_per_lane /*64*/, uint16_t* out /*64x4*/, void* hip_stream);
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);
 

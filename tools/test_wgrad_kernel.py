@@ -25,6 +25,27 @@ for which, IH, CI, KH, S in ((3, 23, 64, 3, 1), (3, 9, 64, 3, 1), (2, 49, 32, 4,
         r = ref(X.float().cpu().numpy().astype(np.float64), dY.float().cpu().numpy().astype(np.float64), KH, S)
         err = np.abs(out.cpu().numpy() - r).max() / np.abs(r).max()
         print(f"conv{which} IH={IH} Nf={Nf}: rel err {err:.2e}", "OK" if err < 1e-4 else "FAIL")
+def ref1(X, dY):
+    n, c, ih, iw = X.shape; _, oh, ow, co = dY.shape
+    out = np.zeros((co, c, 8, 8))
+    for kh in range(8):
+        for kw in range(8):
+            xs = X[:, :, kh:kh + 4 * oh:4, kw:kw + 4 * ow:4]
+            out[:, :, kh, kw] = np.einsum("nhwd,nchw->dc", dY, xs)
+    return out.reshape(co, -1)
+
+for IH in (200, 84):
+    OH = (IH - 8) // 4 + 1
+    for Nf in (2, 19):
+        g = torch.Generator(device="cuda"); g.manual_seed(IH + Nf)
+        X = torch.randn(Nf, 3, IH, IH, device="cuda", generator=g).contiguous()
+        dY = (torch.randn(Nf, OH, OH, 32, device="cuda", generator=g) * (torch.arange(32, device="cuda") % 5 + 1)).to(torch.bfloat16).contiguous()
+        out = torch.zeros(32, 192, device="cuda")
+        L.check(lib.hulc_k_conv_wgrad(1, X.data_ptr(), dY.data_ptr(), out.data_ptr(), Nf, IH, None))
+        r = ref1(X.to(torch.bfloat16).float().cpu().numpy().astype(np.float64), dY.float().cpu().numpy().astype(np.float64))
+        err = np.abs(out.cpu().numpy() - r).max() / np.abs(r).max()
+        print(f"conv1 IH={IH} Nf={Nf}: rel err {err:.2e}", "OK" if err < 1e-4 else "FAIL")
+
 for which, IH, CI, KH, S in ((3, 23, 64, 3, 1), (2, 49, 32, 4, 2)):
     OH = (IH - KH) // S + 1; Nf = 2048
     X = torch.randn(Nf, IH, IH, CI, device="cuda").to(torch.bfloat16); dY = torch.randn(Nf, OH, OH, 64, device="cuda").to(torch.bfloat16)
