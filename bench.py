@@ -131,6 +131,15 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # survey pass (untimed): HIP events around every kernel class -> which class dominates the step
+    eng.timers_enable(True)
+    eng.timers_read(reset=True)
+    for i in range(2):
+        step(args.warmup + i)
+    survey = eng.timers_read(reset=True)
+    dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0] if survey else ""
+    # timed region: events only around the dominant class (on the engine's stream), so the timers do not perturb the step
+    eng.timers_enable(True, dominant)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -146,8 +155,38 @@ def main():
     wps = B * world / (dt / args.steps)
     loss = eng._loss_dev.cpu().numpy().tolist()
 
+    timers = eng.timers_read(reset=True)
+    eng.timers_enable(False)
+
+    def roofline(tm):
+        """Dominant kernel class by measured device time; achieved = algorithmic FLOPs (or bytes) / measured time."""
+        if not tm:
+            return None
+        name, t = max(tm.items(), key=lambda kv: kv[1]["ms"])
+        sec = t["ms"] * 1e-3
+        if t["bound"] == "mfma":
+            ach, peak, unit = t["flops"] / sec / 1e12, MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3, "TFLOP/s"
+        else:
+            ach, peak, unit = t["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(name)
+            except Exception:
+                traffic = None
+        return {"kernel": name, "bound": t["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                "traffic": traffic, "launches_per_step": t["launches"] / args.steps, "avg_launch_us": round(t["ms"] * 1e3 / max(1, t["launches"]), 2),
+                "ms_per_step": round(t["ms"] / args.steps, 4),
+                "per_launch": {"algorithmic_flops": t["flops"] / max(1, t["launches"]), "algorithmic_bytes": t["bytes"] / max(1, t["launches"])}}
+
     if rank == 0:
-        rl = eng.roofline_report() if hasattr(eng, "roofline_report") else None
+        rl = roofline(timers)
+        kernel_classes = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
+                              "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+                          for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["ms"])}
+        for v in kernel_classes.values():
+            v["ms_per_step"] = round(v["ms_per_step"] * args.steps / 2, 4); v["launches_per_step"] = v["launches_per_step"] * args.steps / 2
         out = {
             "metric": "trajectory-windows/sec (seq_len=%d, bs=%d/GPU)" % (S, B), "value": round(wps, 2), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -160,6 +199,7 @@ def main():
             "model_flops_per_window": FLOP_PER_WINDOW_S32 * S / 32.0,
             "step_tflops": round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
             "roofline": rl,
+            "kernel_classes": kernel_classes,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(S),
         }
         print(json.dumps(out))

@@ -70,6 +70,8 @@ int hulc_set_dropout(hulc_ctx* ctx, float p) {
     ctx->e->set_dropout(p);
     return 0;
 }
+int hulc_timers_enable(hulc_ctx* ctx, int32_t on, const char* only_class) { ctx->e->set_timing(on != 0, only_class); return 0; }
+int hulc_timers_read(hulc_ctx* ctx, char* json_out, int64_t cap, int32_t reset) { return ctx->e->timers_read(json_out, cap, reset != 0); }
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* out, int64_t cap, int64_t* n) { return ctx->e->get_tensor(name, out, cap, n); }
 int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* out, int64_t cap) { return ctx->e->get_plan_idx(out, cap); }
 

@@ -27,7 +27,47 @@ struct IEngine {
     virtual int64_t workspace_bytes() const = 0;
     virtual void set_kl_beta(float b) = 0;
     virtual void set_dropout(float p) = 0;
+    void set_timing(bool on, const char* filter) { timing = on; timing_filter = filter ? filter : ""; }
     hipStream_t st = nullptr;
+    // ---- per-kernel-class HIP-event timers (bench.py roofline leg): events are recorded on `st` around the launches of a class
+    struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };
+    std::map<std::string, KTimer> timers;
+    bool timing = false;
+    std::string timing_filter;      // empty = every class; else only this class (keeps event overhead out of the timed region)
+    int timer_depth = 0;            // a group scope (e.g. the S recurrent steps) suppresses the per-launch scopes inside it
+    struct TimerScope {
+        IEngine* e; IEngine::KTimer* t;
+        TimerScope(IEngine* e_, const char* name, const char* bound, double flops, double bytes, int nlaunch = 1) : e(e_), t(nullptr) {
+            if (!e->timing || e->timer_depth > 0) return;
+            if (!e->timing_filter.empty() && e->timing_filter != name) return;
+            e->timer_depth++;
+            t = &e->timers[name];
+            if (t->name.empty()) { t->name = name; t->bound = bound; }
+            if (t->used == t->ev.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); t->ev.emplace_back(a, b); }
+            t->flops += flops; t->bytes += bytes; t->launches += nlaunch;
+            hipEventRecord(t->ev[t->used].first, e->st);
+        }
+        ~TimerScope() { if (t) { hipEventRecord(t->ev[t->used].second, e->st); t->used++; e->timer_depth--; } }
+    };
+    int timers_read(char* out, int64_t cap, bool reset) {
+        hipStreamSynchronize(st);
+        std::string js = "{";
+        bool first = true;
+        for (auto& kv : timers) {
+            KTimer& t = kv.second;
+            double ms = 0;
+            for (size_t i = 0; i < t.used; ++i) { float x = 0; hipEventElapsedTime(&x, t.ev[i].first, t.ev[i].second); ms += x; }
+            char buf[512];
+            snprintf(buf, sizeof(buf), "%s\"%s\": {\"bound\": \"%s\", \"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                     t.name.c_str(), t.bound.c_str(), t.launches, ms, t.flops, t.bytes);
+            js += buf; first = false;
+            if (reset) { t.used = 0; t.flops = t.bytes = 0; t.launches = 0; }
+        }
+        js += "}";
+        if ((int64_t)js.size() + 1 > cap) { hulc_set_error("hulc_timers_read: buffer too small"); return 1; }
+        memcpy(out, js.c_str(), js.size() + 1);
+        return 0;
+    }
 };
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -304,21 +344,26 @@ struct Engine : IEngine {
     }
     // dense NT GEMM with tile selection
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+        const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
+                TimerScope ts(this, "skinny_gemm", "hbm", fl, by);
                 launch_skinny(st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
                 return;
             }
         }
         // largest tile that still yields >= 128 workgroups (small-N transformer / encoder GEMMs are latency-bound otherwise)
         const long long w128 = (long long)cdiv(M, 128) * cdiv(N, 128), w64 = (long long)cdiv(M, 64) * cdiv(N, 64);
-        if (M >= 512 && N >= 128 && w128 >= 128) launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
+        if (M >= 512 && N >= 128 && w128 >= 128) { TimerScope ts(this, "gemm_128x128", "mfma", fl, by); launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K); }
         else if (w64 >= 128 || (M <= 64 && N <= 64)) launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
         else launch_gemm<T, 32, 32>(st, a, b, om, ep, M, N, K);
     }
     // dW[M][N] += A[M][K] B[N][K]^T with fp32 accumulate; few output tiles + long K -> split K across workgroups (atomics)
     void gemm_wgrad(const DenseLoader<T>& a, const DenseLoader<T>& b, float* dW, long long lddw, int M, int N, int K) {
         EpiP ep = epi(dW, true); ep.accumulate = 1;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) { gemm(a, b, dense_out(lddw), ep, M, N, K); return; }
+        }
         const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128), t64 = (long long)cdiv(M, 64) * cdiv(N, 64);
         const bool big = M >= 128 && N >= 128;
         const long long tiles = big ? t128 : t64;
@@ -326,6 +371,7 @@ struct Engine : IEngine {
         if (tiles < 128 && K >= 512) nsplit = (int)std::min<long long>(std::min<long long>(256 / tiles, K / 256), 32);
         if (nsplit <= 1) { gemm(a, b, dense_out(lddw), ep, M, N, K); return; }
         ep.atomic = 1;
+        TimerScope ts(this, big ? "gemm_128x128" : "gemm_64x64_splitk", "mfma", 2.0 * M * N * K, ((double)M * K + (double)N * K) * sizeof(T) + 4.0 * M * N);
         if (big) launch_gemm<T, 128, 128>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
         else launch_gemm<T, 64, 64>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
     }
@@ -417,6 +463,8 @@ struct Engine : IEngine {
     void enc_fwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
         if constexpr (std::is_same<T, bf16_t>::value) {
+            const double px = (double)Nf * g1.OH * g1.OW;
+            TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)Nf * 3 * e.IH * e.IH * 4 + px * 32 * 2);
             launch_conv1_fwd(st, x, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW);
         } else {
             Conv1Loader<T> l{x, g1};
@@ -427,6 +475,8 @@ struct Engine : IEngine {
         if constexpr (std::is_same<T, bf16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
             ConvTileP p2{}; p2.img = a.a1; p2.IMH = p2.IMW = e.H1; p2.w = e.c2.Wf; p2.out = a.a2; p2.OUTH = p2.OUTW = e.H2; p2.bias = e.c2.b32; p2.relu = 1; p2.Nf = Nf;
             ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
+            const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
+            TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
             tiled = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2) && launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
         }
         if (!tiled) {
@@ -460,6 +510,8 @@ struct Engine : IEngine {
         int nsplit = 0;
         if constexpr (std::is_same<T, bf16_t>::value) {
             // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
+            TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
+                          conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * 4 + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
                 nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 64 && c.KH == 3)
@@ -488,6 +540,8 @@ struct Engine : IEngine {
         if constexpr (std::is_same<T, bf16_t>::value) {
             ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.Nf = g.Nf;
             bool ok = false;
+            const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
+            TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
             if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
             else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
             if (ok) return;
@@ -697,6 +751,7 @@ struct Engine : IEngine {
     void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S) {
         const long long BH = (long long)B * HID;
         hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
+        TimerScope ts(this, "skinny_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int t = 1; t < S; ++t) {
             EpiP ep = epi(H + t * BH, false); ep.res = Zx + t * BH; ep.res_ld = HID; ep.relu = 1;
             gemm(dense<T>(H + (t - 1) * BH, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
@@ -706,6 +761,7 @@ struct Engine : IEngine {
     void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S) {
         const long long BH = (long long)B * HID;
         hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH + (S - 1) * BH, H + (S - 1) * BH, dZ + (S - 1) * BH, BH);
+        TimerScope ts(this, "skinny_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int t = S - 2; t >= 0; --t) {
             EpiP ep = epi(dZ + t * BH, false); ep.res = dH + t * BH; ep.res_ld = HID; ep.mask = H + t * BH;
             gemm(dense<T>(dZ + (t + 1) * BH, B, HID), dense<T>(whh.Wt, HID, HID), dense_out(HID), ep, B, HID, HID);

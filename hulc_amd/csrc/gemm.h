@@ -267,6 +267,76 @@ DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) 
     }
 }
 
+// 4 consecutive output columns of one row (the MFMA is issued as D^T = B A^T, so a lane owns C[row][col..col+3]):
+// vector bias / residual / mask loads and one 16-byte (fp32) or 8-byte (T = bf16) store when aligned, else the scalar path.
+template <typename T>
+DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, int N, long long o) {
+    const bool vec = (col + 3 < N) && ((o & 3) == 0) && !ep.atomic && ep.drop_p == 0.f &&
+                     (!ep.res || (((long long)rrow * ep.res_ld + col) & 3) == 0);
+    if (!vec) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (col + r < N) epi_store<T>(ep, accv[r], rrow, col + r, o + r);
+        return;
+    }
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = accv[r] * ep.alpha;
+    if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    if (ep.bias2) { const float4 b = *reinterpret_cast<const float4*>(ep.bias2 + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.res) {
+        const long long ro = (long long)rrow * ep.res_ld + col;
+        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); rv[0] = x.x; rv[1] = x.y; rv[2] = x.z; rv[3] = x.w; }
+        else {
+            T t[4];
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.res) + ro);
+            else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.res) + ro);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = to_f<T>(t[r]);
+        }
+    }
+    if (!ep.res_late) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+    }
+    if (ep.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (ep.mask) {
+        T t[4];
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.mask) + o);
+        else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.mask) + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = to_f<T>(t[r]) > 0.f ? v[r] : 0.f;
+    }
+    if (ep.res_late) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+    }
+    if (ep.out_f32) {
+        float4* op = reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o);
+        float4 w = make_float4(v[0], v[1], v[2], v[3]);
+        if (ep.accumulate) { const float4 old = *op; w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w; }
+        *op = w;
+    } else {
+        T* op = reinterpret_cast<T*>(ep.out) + o;
+        if (ep.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f<T>(op[r]);
+        }
+        if constexpr (sizeof(T) == 2) {
+            uint2 w;
+            w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(op) = w;
+        } else {
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------
@@ -377,7 +447,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
         } else {
             const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4);
             const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4);
@@ -392,29 +462,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
+    // ---- epilogue: (operands swapped) lane holds C[row = lane&15][col = (lane>>4)*4 .. +3] of each 16x16 tile
     if (tid < BM) rowoff[tid] = (m0 + tid < M) ? om.offset(m0 + tid, zc) : 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WM + i * 16 + (lane & 15);
+        if (row < M) {
+            const long long obase = rowoff[row - m0] + (long long)zs * ep.z_stride;
+            const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-            if (row < M) {
-                const long long obase = rowoff[row - m0] + (long long)zs * ep.z_stride;
-                const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * WN + j * 16 + (lane & 15);
-                    if (col < N) {
-                        epi_store<T>(ep, acc[i][j][r], rrow, col, obase + col);
-                    }
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+                if (col < N) {
+                    const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    epi_store4<T>(ep, v4, rrow, col, N, obase + col);
                 }
             }
         }
@@ -517,6 +585,7 @@ static inline void launch_skinny(hipStream_t st, const bf16_t* A, long long lda,
     else launch_skinny_nw<4>(st, A, lda, W, ldw, M, N, K, om, ep);
 }
 static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, const void* A, const void* W) {
-    const bool shape = M <= 64 || (N <= 256 && K >= 512 && (long long)((M + 63) / 64) * (N / 16) >= 64);
+    // many-row use: every 64-row block of A is re-read by each of the N/16 column workgroups -> only when M*N is small
+    const bool shape = M <= 64 || (K >= 512 && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 32);
     return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }

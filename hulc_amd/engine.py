@@ -112,6 +112,15 @@ class StepEngine:
     def set_dropout(self, p: float):
         L.check(self.lib.hulc_set_dropout(self.ctx, float(p)))
 
+    def timers_enable(self, on: bool = True, only: str = ""):
+        L.check(self.lib.hulc_timers_enable(self.ctx, int(on), only.encode()))
+
+    def timers_read(self, reset: bool = True) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        L.check(self.lib.hulc_timers_read(self.ctx, buf, len(buf), int(reset)))
+        return json.loads(buf.value.decode())
+
     def backward(self):
         L.check(self.lib.hulc_backward(self.ctx))
 

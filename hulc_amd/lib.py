@@ -26,7 +26,7 @@ class HulcBatch(C.Structure):
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward",
-           "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile"]
+           "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile"]
 
 _lib = None
 
@@ -55,6 +55,8 @@ def load():
     lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]
     lib.hulc_set_kl_beta.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_set_dropout.argtypes = [C.c_void_p, C.c_float]
+    lib.hulc_timers_enable.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
+    lib.hulc_timers_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int32]
     lib.hulc_get_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.hulc_get_plan_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.hulc_k_gemm_nt.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

@@ -96,6 +96,12 @@ int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps,
 int hulc_set_kl_beta(hulc_ctx* ctx, float kl_beta);
 int hulc_set_dropout(hulc_ctx* ctx, float p);
 
+/* HIP-event timers around the launches of each kernel class, recorded on the context's stream (bench.py's roofline leg).
+ * hulc_timers_read synchronises and writes a JSON object {"class": {"bound","launches","ms","flops","bytes"}} (algorithmic
+ * FLOPs / bytes summed over the timed launches). */
+int hulc_timers_enable(hulc_ctx* ctx, int32_t on, const char* only_class /* NULL or "" = every class */);
+int hulc_timers_read(hulc_ctx* ctx, char* json_out, int64_t cap, int32_t reset);
+
 /* Inspection (tests): copy a named internal tensor to HOST fp32. Returns element count in *n (cap = capacity). */
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* host_out, int64_t cap, int64_t* n);
 int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* host_out, int64_t cap);
