@@ -101,13 +101,15 @@ int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* str
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     float* part = nullptr;
+    static float* bias_tmp = nullptr;
+    if (!bias_tmp && hipMalloc(&bias_tmp, sizeof(float) * 512 * 64) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
     const int KC = which == 3 ? 576 : (which == 2 ? 512 : 192);
     const int CO = which == 1 ? 32 : 64;
     if (hipMalloc(&part, sizeof(float) * 512ll * 64 * KC) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
     int ns;
-    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, (const float*)X, (const bf16_t*)dY, part, Nf, IH, IH, OH, OH, 512); }
+    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, (const float*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
     hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);
     hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
@@ -132,6 +134,21 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     if (!ok) { hulc_set_error("hulc_k_conv_tile: unsupported mode/shape"); return 1; }
     if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_conv_tile: launch failed"); return 1; }
     return 0;
+}
+
+// skinny GEMM alone (bf16): out[M][N] (bf16) = A[M][K] W[N][K]^T ; variant = NW*10 + MT (e.g. 82 = 8 waves, 32-row blocks)
+int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K, int32_t variant, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    EpiP ep; ep.out = out; ep.out_f32 = 0;
+    const int NW = variant / 10, MT = variant % 10;
+    dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
+    const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
+#define SK(nw, mt) hipLaunchKernelGGL((skinny_gemm_kernel<nw, mt>), grid, dim3(nw * 64), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep)
+    if (NW == 8 && MT == 2) SK(8, 2); else if (NW == 8 && MT == 4) SK(8, 4); else if (NW == 4 && MT == 2) SK(4, 2); else if (NW == 4 && MT == 4) SK(4, 4);
+    else if (NW == 8 && MT == 1) SK(8, 1); else if (NW == 4 && MT == 1) SK(4, 1);
+    else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
+#undef SK
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 // probe of ds_read_b64_tr_b16 semantics (tests/tools only): LDS image lds[i] = i (uint16), lane l reads at element index addr[l]

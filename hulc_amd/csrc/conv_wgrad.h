@@ -50,7 +50,7 @@ struct WgradCfg {
 
 template <int CI, int CO, int KH, int KW, int S>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
-                                                            int Nf, int IH, int IW, int OH, int OW, int R) {
+                                                            float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
     const int prow = a >> 2;                         // pixel (k-row) this lane addresses inside an 8-pixel run: prow, prow + 4
     const int ccol = (a & 3) * 8;                    // byte offset of this lane's 4-channel chunk inside a 16-channel group
     const int nt0 = wave * C::NTW;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias gradient: this lane's 8 channels (chunk lane % CH) of every dY pixel it stages
 
     for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
         for (int oh0 = 0; oh0 < OH; oh0 += R) {
@@ -87,6 +88,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                     for (int i = lane; i < OW * CH; i += 64) {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
                         if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
                         *(lds_u32x4*)(dyimg + (r * OWp + i / CH) * C::DYS + (i % CH) * 16) = v;
                     }
                 }
@@ -147,11 +150,24 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
         for (int c = 0; c < C::CT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+    // ---- bias-gradient slab: channel c = 8*(tid % CH) + e is spread over the threads with the same tid % CH
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < CO) {
+        constexpr int CH = CO / 8;
+        const int cgrp = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int t = cgrp; t < 256; t += CH) s += red[t * 8 + e];
+        bias_part[(long long)blockIdx.x * CO + tid] = s;
+    }
 }
 
 template <int CI, int CO, int KH, int KW, int S>
-static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, int Nf, int IH, int IW, int OH, int OW,
-                                       int max_blocks) {
+static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
+                                       int OW, int max_blocks) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     int R = OH;                                              // largest band that keeps two workgroups per CU (<= 78 KB)
     while (R > 1 && C::lds_bytes(R, IW, OW) > 78 * 1024) --R;
@@ -162,7 +178,7 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf
         attr_set = true;
     }
     const int grid = Nf < max_blocks ? Nf : max_blocks;
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(256), lds, st, X, dY, part, Nf, IH, IW, OH, OW, R);
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(256), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
     return grid;                                             // = number of partial slabs written
 }
 
@@ -183,7 +199,7 @@ struct Wgrad1Cfg {
 };
 
 __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
-                                                                int Nf, int IH, int IW, int OH, int OW, int R) {
+                                                                float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = Wgrad1Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
     const int ccolA = q * 8;
     const int nt0 = wave * 3;
     const int W4 = IW >> 2;                                       // float4 per input row (IW % 4 == 0)
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
         for (int oh0 = 0; oh0 < OH; oh0 += R) {
@@ -218,6 +235,8 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
                     for (int i = lane; i < OW * 4; i += 64) {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
                         if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
                         *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
                     }
                 }
@@ -278,10 +297,21 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * 192 + (nt0 + j) * 16 + a] = acc[j][c][r];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C::CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int t = cgrp; t < 256; t += 4) s += red[t * 8 + e];
+        bias_part[(long long)blockIdx.x * C::CO + tid] = s;
+    }
 }
 
-static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf16_t* dY, float* part, int Nf, int IH, int IW, int OH, int OW,
-                                        int max_blocks) {
+static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
+                                        int OW, int max_blocks) {
     int R = OH;
     while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW) > 78 * 1024) --R;
     const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW);
@@ -291,6 +321,80 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf
         attr_set = true;
     }
     const int grid = Nf < max_blocks ? Nf : max_blocks;
-    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, dY, part, Nf, IH, IW, OH, OW, R);
+    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
     return grid;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear-layer backward for M <= 64 rows (every M = B MLP layer): dW[N][K] += dY^T X and db[N] += colsum(dY) in ONE launch.
+// Both operands are reduction(M)-major in memory; their tiles are staged in LDS as they lie ([m][n] and [m][k]) and the MFMA
+// fragments come from transposing reads, so no transposed activation copies (and no separate column-sum launches) are needed.
+// Orientation: A = X fragment (rows k), B = dY fragment (cols n)  ->  a lane owns dW[n][k..k+3]: float4 read-modify-write.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __restrict__ dY, long long ldy, const bf16_t* __restrict__ X, long long ldx,
+                                                             int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
+                                                             float* __restrict__ db2) {
+    constexpr int TN = 64, TK = 128, YS = TN * 2 + 16, XS = TK * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char smem[64 * YS + 64 * XS];
+    lds_char* yimg = (lds_char*)smem;
+    lds_char* ximg = yimg + 64 * YS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+    // stage dY[0:64][n0:n0+64] and X[0:64][k0:k0+128] (rows >= M and columns past the edge -> zeros)
+    for (int i = tid; i < 64 * (TN / 8); i += 256) {
+        const int m = i / (TN / 8), c = i % (TN / 8);
+        bf16_t v[8];
+        if (m < M && n0 + c * 8 < N) load8_guard<bf16_t>(dY + (long long)m * ldy + n0 + c * 8, N - (n0 + c * 8), v);
+        else zero8<bf16_t>(v);
+        *(lds_u32x4*)(yimg + m * YS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+    }
+    for (int i = tid; i < 64 * (TK / 8); i += 256) {
+        const int m = i / (TK / 8), c = i % (TK / 8);
+        bf16_t v[8];
+        if (m < M && k0 + c * 8 < K) load8_guard<bf16_t>(X + (long long)m * ldx + k0 + c * 8, K - (k0 + c * 8), v);
+        else zero8<bf16_t>(v);
+        *(lds_u32x4*)(ximg + m * XS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+    }
+    __syncthreads();
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2, ccol = (a & 3) * 8;
+    // wave w: n-tile w (16 columns of dY) x 8 k-tiles
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {                        // reduction over m: 2 x 32
+        const int mrow = ms * 32 + g * 8 + prow;
+        lds_char* yb = yimg + mrow * YS + wave * 32 + ccol;
+        const bf16x8_t yf = tr_read8(yb, yb + 4 * YS);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lds_char* xb = ximg + mrow * XS + j * 32 + ccol;
+            const bf16x8_t xf = tr_read8(xb, xb + 4 * XS);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
+        }
+    }
+    const int n = n0 + wave * 16 + a;
+    if (n < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j * 16 + g * 4;
+            float* p = dW + (long long)n * lddw + k;
+            if (k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+                float4 o = *reinterpret_cast<float4*>(p);
+                o.x += acc[j][0]; o.y += acc[j][1]; o.z += acc[j][2]; o.w += acc[j][3];
+                *reinterpret_cast<float4*>(p) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k + r < K) p[r] += acc[j][r];
+            }
+        }
+    }
+    if (db && blockIdx.y == 0 && tid < TN && n0 + tid < N) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += bf2f(*(__attribute__((address_space(3))) bf16_t*)(yimg + m * YS + tid * 2));
+        db[n0 + tid] += s;
+        if (db2) db2[n0 + tid] += s;
+    }
 }

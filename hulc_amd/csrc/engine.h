@@ -199,7 +199,7 @@ struct Engine : IEngine {
         pidx = alloc<int>(B * NCAT, "plan_idx"); pidx_in = alloc<int>(B * NCAT);
         embg = alloc<T>(SB * 64); Cplan = alloc<float>(B * HID); Cb = alloc<T>(B * HID, "dec_cb");
         Zx0 = alloc<T>(SB * HID); Zx1 = alloc<T>(SB * HID); H0 = alloc<T>(SB * HID, "dec_h0"); H1 = alloc<T>(SB * HID, "dec_h1");
-        heads = alloc<float>(SB * NHEAD, "heads"); dheads = alloc<T>(SB * NHEAD, "dheads"); rowloss = alloc<float>(SB); a_tcp = alloc<float>(SB * 7, "a_tcp");
+        heads = alloc<float>(SB * NHEAD, "heads"); dheads = alloc<T>(SB * NHEAD, "dheads"); rowloss = alloc<float>(SB * 8); a_tcp = alloc<float>(SB * 7, "a_tcp");
         dH1 = alloc<T>(SB * HID); dZ1 = alloc<T>(SB * HID, "dec_dz1"); dH0 = alloc<T>(SB * HID); dZ0 = alloc<T>(SB * HID, "dec_dz0"); dC = alloc<T>(B * HID);
         demb = alloc<float>(N * EMB, "demb"); dgoal = alloc<float>(B * GOAL, "dgoal"); dseqf = alloc<float>(B * FCH, "dseq_feat");
         dplan = alloc<float>(B * PLAN, "dplan"); dprl = alloc<float>(B * PLAN, "dpr_logits"); dppx = alloc<float>(B * (EMB + GOAL));
@@ -384,6 +384,12 @@ struct Engine : IEngine {
     }
     // weight + bias grads of Y = X W^T: dW[N][K] += dY^T X ; db += colsum(dY).  dY [M][N] dense, X [M][K] (ldx)
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
+                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2);
+                return;
+            }
+        }
         const int mp = ldpad(M);
         cast_tr<T, T>(dY, N, nullptr, 0, tA, mp, M, N);
         cast_tr<T, T>(X, ldx, nullptr, 0, tB, mp, M, K);
@@ -513,11 +519,16 @@ struct Engine : IEngine {
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
                           conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * 4 + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
-                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+        }
+        bool bias_done = false;
+        if (nsplit > 0) {     // the tr kernels also produced per-workgroup bias-gradient slabs in cspart
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c.O, 64)), dim3(256), 0, st, cspart, nsplit, c.O, c.db, (float*)nullptr, 1.f);
+            bias_done = true;
         }
         if (nsplit == 0) {
             nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
@@ -534,7 +545,7 @@ struct Engine : IEngine {
         }
         hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256), nsplit >= 64 ? 8 : 1), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
-        colsum(dy, c.O, (int)npix, c.O, c.db);
+        if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask) {
         if constexpr (std::is_same<T, bf16_t>::value) {
@@ -714,9 +725,9 @@ struct Engine : IEngine {
             rnn_fwd(Zx1, H1, whh1, B, S);
             { EpiP ep = epi(heads, true); ep.bias = bheads;
               gemm(dense<T>(H1, SB, HID), dense<T>(wheads, NHEAD, HID), dense_out(NHEAD), ep, SB, NHEAD, HID); }
-            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, lw / (float)SB, rowloss, a_tcp, dheads);
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, 1.f / SB, losses + 0);
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
         STAGE("decoder_fwd");
         // ---- CLIP auxiliary loss (hulc.py:650-695), lang modality, masked rows

@@ -622,12 +622,16 @@ DEVI void euler_xyz(float a, float b, float c, float (&R)[9]) {
 DEVI float softplusf(float x) { return x > 20.f ? x : (x < -20.f ? __expf(x) : log1pf(__expf(x))); }
 DEVI float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// one thread per (row, slot): slots 0..NDIM-1 = mixture dimension d, slot NDIM = gripper cross entropy, last slot idle;
+// row_loss is [rows][8] (summed deterministically afterwards).  Each thread recomputes the row's tcp-frame action (cheap) so the
+// 7 partial losses of a row run in parallel instead of serially in one lane.
 template <typename T>
 __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
                                      const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
                                      float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
                                      float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;    // time-major row: r = t*B + b
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 3, slot = gid & 7;                  // time-major row: r = t*B + b
     if (r >= B * S) return;
     const int t = r / B, b = r % B;
     const float* act = actions + ((long long)b * S + t) * 7;
@@ -637,16 +641,11 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
         float R[9], Rn[9];
         euler_xyz(ro[3], ro[4], ro[5], R);
         euler_xyz(ro[3] + act[3] * 0.01f, ro[4] + act[4] * 0.01f, ro[5] + act[5] * 0.01f, Rn);
-        // pos_tcp = R^T act[0:3]
 #pragma unroll
         for (int i = 0; i < 3; ++i) at[i] = R[0 + i] * act[0] + R[3 + i] * act[1] + R[6 + i] * act[2];
-        // M = Rn^T R ; need M12, M22, M02, M01, M00
         auto Mij = [&](int i, int j) { return Rn[0 + i] * R[0 + j] + Rn[3 + i] * R[3 + j] + Rn[6 + i] * R[6 + j]; };
-        float o0 = atan2f(-Mij(1, 2), Mij(2, 2));
-        float o1 = asinf(fminf(1.f, fmaxf(-1.f, Mij(0, 2))));
-        float o2 = atan2f(-Mij(0, 1), Mij(0, 0));
+        float o[3] = {atan2f(-Mij(1, 2), Mij(2, 2)), asinf(fminf(1.f, fmaxf(-1.f, Mij(0, 2)))), atan2f(-Mij(0, 1), Mij(0, 0))};
         const float PI = 3.14159265358979323846f;
-        float o[3] = {o0, o1, o2};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (o[i] < -PI) o[i] += 2.f * PI;
@@ -658,18 +657,21 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
 #pragma unroll
         for (int i = 0; i < 7; ++i) at[i] = act[i];
     }
-    if (a_tcp_out)
+    if (a_tcp_out && slot == 7)
 #pragma unroll
         for (int i = 0; i < 7; ++i) a_tcp_out[((long long)b * S + t) * 7 + i] = at[i];
 
     const float* hr = heads + (long long)r * ldh;
     T* dr = dheads + (long long)r * ldh;
     const int NO = NMIX * NDIM;
-    const float hb = 1.f / (num_classes - 1);        // (max-min)/2/(nc-1) with bounds +-1 (conf/datamodule/default.yaml)
-    const float logc = __logf((num_classes - 1) * 0.5f);
     float loss = 0.f;
-    for (int d = 0; d < NDIM; ++d) {
-        const float a = at[d];
+    if (slot < NDIM) {
+        const int d = slot;
+        const float hb = 1.f / (num_classes - 1);    // (max-min)/2/(nc-1) with bounds +-1 (conf/datamodule/default.yaml)
+        const float logc = __logf((num_classes - 1) * 0.5f);
+        float a = at[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) a = (d == i) ? at[i] : a;
         float lp[16], dlogp_dmean[16], dlogp_dls[16];
         float mlog = -INFINITY;
         for (int k = 0; k < NMIX; ++k) mlog = fmaxf(mlog, hr[d * NMIX + k]);
@@ -699,7 +701,7 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
         float se = 0.f;
         for (int k = 0; k < NMIX; ++k) se += __expf(lp[k] - mx);
         const float lse = mx + __logf(se);
-        loss -= lse;
+        loss = -lse;
         for (int k = 0; k < NMIX; ++k) {
             const float w = __expf(lp[k] - lse);
             const float pi = __expf(hr[d * NMIX + k] - lz);
@@ -707,20 +709,20 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
             dr[NO + d * NMIX + k] = from_f<T>(-w * dlogp_dmean[k] * grad_scale);
             dr[2 * NO + d * NMIX + k] = from_f<T>(-w * dlogp_dls[k] * grad_scale);
         }
-    }
-    // gripper cross entropy: label -1 -> 0 else (long)value  (logistic_decoder_rnn.py:144-151)
-    {
+    } else if (slot == NDIM) {
+        // gripper cross entropy: label -1 -> 0 else (long)value  (logistic_decoder_rnn.py:144-151)
         const float g0 = hr[3 * NO], g1 = hr[3 * NO + 1];
         const int lab = (at[6] == -1.f) ? 0 : (int)at[6];
         const float m = fmaxf(g0, g1);
         const float lz = m + __logf(__expf(g0 - m) + __expf(g1 - m));
-        loss += gripper_alpha * (lz - (lab == 0 ? g0 : g1));
+        loss = gripper_alpha * (lz - (lab == 0 ? g0 : g1));
         const float p0 = __expf(g0 - lz), p1 = __expf(g1 - lz);
         dr[3 * NO] = from_f<T>(gripper_alpha * (p0 - (lab == 0 ? 1.f : 0.f)) * grad_scale);
         dr[3 * NO + 1] = from_f<T>(gripper_alpha * (p1 - (lab == 1 ? 1.f : 0.f)) * grad_scale);
+    } else {
+        for (int c = 3 * NO + 2; c < ldh; ++c) dr[c] = from_f<T>(0.f);
     }
-    for (int c = 3 * NO + 2; c < ldh; ++c) dr[c] = from_f<T>(0.f);
-    row_loss[r] = loss;
+    row_loss[gid] = loss;
 }
 
 // out[0] = scale * sum(x[0..n))   (single block, deterministic tree)

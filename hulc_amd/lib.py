@@ -26,7 +26,7 @@ class HulcBatch(C.Structure):
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward",
-           "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile"]
+           "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
 
 _lib = None
 
@@ -64,6 +64,7 @@ def load():
     lib.hulc_k_conv_wgrad.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.hulc_k_conv_tile.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]
+    lib.hulc_k_skinny.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.hulc_k_trread_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hulc_k_cast.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     _lib = lib
