@@ -17,7 +17,7 @@ struct IEngine {
     virtual ~IEngine() {}
     virtual int bind(float* p, float* g, float* m, float* v, int64_t numel, int n, const char* const* names, const int64_t* offs,
                      const int64_t* numels) = 0;
-    virtual int prepare_weights() = 0;
+    virtual int prepare_weights(bool shadow_fresh = false) = 0;
     virtual int zero_grads() = 0;
     virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
     virtual int backward() = 0;
@@ -129,6 +129,8 @@ struct Engine : IEngine {
     const float *head_w32[4], *head_b32[4]; float *head_dw[4], *head_db[4]; int head_rows[4] = {60, 60, 60, 2};
     float* dw7_tmp = nullptr;
     bool bound = false;
+    T* wshadow = nullptr;                 // bf16 mode: flat compute copy of all parameters (written by the Adam kernel)
+    std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0;
 
     // ---- workspace (per modality pass)
     struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; } aS, aG;
@@ -138,6 +140,7 @@ struct Engine : IEngine {
     int* pidx; int* pidx_in;
     T *xt[3], *qkv[2], *ao[2], *x1t[2], *hff[2];
     float *xf[3], *Pat[2], *y1[2], *st1[2], *x1f[2], *y2[2], *st2[2];
+    float* zero_arena = nullptr; int64_t zero_n = 0;
     float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
     T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
     T *tA, *tB; int64_t tcap;
@@ -201,7 +204,16 @@ struct Engine : IEngine {
         Zx0 = alloc<T>(SB * HID); Zx1 = alloc<T>(SB * HID); H0 = alloc<T>(SB * HID, "dec_h0"); H1 = alloc<T>(SB * HID, "dec_h1");
         heads = alloc<float>(SB * NHEAD, "heads"); dheads = alloc<T>(SB * NHEAD, "dheads"); rowloss = alloc<float>(SB * 8); a_tcp = alloc<float>(SB * 7, "a_tcp");
         dH1 = alloc<T>(SB * HID); dZ1 = alloc<T>(SB * HID, "dec_dz1"); dH0 = alloc<T>(SB * HID); dZ0 = alloc<T>(SB * HID, "dec_dz0"); dC = alloc<T>(B * HID);
-        demb = alloc<float>(N * EMB, "demb"); dgoal = alloc<float>(B * GOAL, "dgoal"); dseqf = alloc<float>(B * FCH, "dseq_feat");
+        // backward scratch that must start at zero lives in ONE arena -> a single memset per backward
+        {
+            auto r64 = [](int64_t n) { return (n + 63) / 64 * 64; };
+            zero_n = r64(N * EMB) + r64(B * GOAL) + r64(B * FCH) + r64((int64_t)NHEAD * HID) + r64(NHEAD) + r64(128 * 3136);
+            zero_arena = alloc<float>(zero_n);
+            float* q = zero_arena;
+            demb = q; q += r64(N * EMB); dgoal = q; q += r64(B * GOAL); dseqf = q; q += r64(B * FCH);
+            dwheads_tmp = q; q += r64((int64_t)NHEAD * HID); dbheads_tmp = q; q += r64(NHEAD); dw7_tmp = q;
+            named["demb"] = Named{demb, N * EMB, 0}; named["dgoal"] = Named{dgoal, B * GOAL, 0}; named["dseq_feat"] = Named{dseqf, B * FCH, 0};
+        }
         dplan = alloc<float>(B * PLAN, "dplan"); dprl = alloc<float>(B * PLAN, "dpr_logits"); dppx = alloc<float>(B * (EMB + GOAL));
         dxa = alloc<float>(N * EMB); dxb = alloc<float>(N * EMB); dy_f = alloc<float>(N * EMB); dxm = alloc<float>(B * EMB);
         dprl_t = alloc<T>(B * PLAN); dppl_t = alloc<T>(B * PLAN); dseq_t = alloc<T>(B * FCH);
@@ -214,7 +226,6 @@ struct Engine : IEngine {
         dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
         dim1 = alloc<T>(B * 128); dla1 = alloc<T>(B * 128); dsf_m = alloc<float>(B * FCH); dg_m = alloc<float>(B * GOAL);
         losses = alloc<float>(8);
-        dwheads_tmp = alloc<float>((int64_t)NHEAD * HID); dbheads_tmp = alloc<float>(NHEAD); dw7_tmp = alloc<float>(128 * 3136);
         bheads = alloc<float>(NHEAD); wheads = alloc<T>((int64_t)NHEAD * HID); wheadsT = alloc<T>((int64_t)HID * NHEAD);
         if (alloc_failed) { hulc_set_error("hipMalloc failed while sizing the workspace (B=%d S=%d)", maxB, maxS); return 1; }
         return 0;
@@ -228,9 +239,16 @@ struct Engine : IEngine {
         L.W32 = pw(name + (bias_suffix ? ".weight" : "")); L.dW = gw(name + (bias_suffix ? ".weight" : ""));
         if (bias_suffix) { L.b32 = pw(name + ".bias"); L.db = gw(name + ".bias"); }
         L.N = N; L.K = K;
-        if (std::is_same<T, float>::value) { L.W = (T*)L.W32; L.own_w = false; }
-        else if (!L.W) { L.W = alloc<T>((int64_t)N * K); L.own_w = true; }
+        if (std::is_same<T, float>::value) L.W = (T*)L.W32;
+        else L.W = wshadow + (L.W32 - P);
+        L.own_w = false;
         if (!L.Wt) L.Wt = alloc<T>((int64_t)N * K);
+        add_tr(L.W32, L.W, L.Wt, N, K);
+    }
+    void add_tr(const float* w32, const T* w, T* wt, int R, int C) {
+        TrDesc d; d.src = std::is_same<T, float>::value ? (const void*)w32 : (const void*)w; d.dst = wt; d.lds = C; d.ldt = R; d.R = R; d.C = C;
+        d.tiles_x = cdiv(C, 32); d.blk0 = tr_blocks; tr_blocks += d.tiles_x * cdiv(R, 32);
+        trdesc.push_back(d);
     }
     void bind_conv(ConvW& c, const std::string& name, int O, int I, int K, int S, int nhwc) {
         c.W32 = pw(name + ".weight"); c.b32 = pw(name + ".bias"); c.dW = gw(name + ".weight"); c.db = gw(name + ".bias");
@@ -257,7 +275,8 @@ struct Engine : IEngine {
     int bind(float* p, float* g, float* m, float* v, int64_t n_, int n, const char* const* names, const int64_t* offs,
              const int64_t* numels) override {
         P = p; G = g; AM = m; AV = v; numel = n_;
-        tab.clear();
+        tab.clear(); trdesc.clear(); tr_blocks = 0;
+        if (!std::is_same<T, float>::value && !wshadow) wshadow = alloc<T>(numel);
         for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
         try {
             bind_enc(encS, "perceptual_encoder.rgb_static_encoder.", false, 200);
@@ -280,8 +299,9 @@ struct Engine : IEngine {
                 tr_in[l].W32 = pw(L + "self_attn.in_proj_weight"); tr_in[l].dW = gw(L + "self_attn.in_proj_weight");
                 tr_in[l].b32 = pw(L + "self_attn.in_proj_bias"); tr_in[l].db = gw(L + "self_attn.in_proj_bias");
                 tr_in[l].N = 3 * EMB; tr_in[l].K = EMB;
-                if (std::is_same<T, float>::value) tr_in[l].W = (T*)tr_in[l].W32; else if (!tr_in[l].W) tr_in[l].W = alloc<T>(3 * EMB * EMB);
+                tr_in[l].W = std::is_same<T, float>::value ? (T*)tr_in[l].W32 : wshadow + (tr_in[l].W32 - P);
                 if (!tr_in[l].Wt) tr_in[l].Wt = alloc<T>(3 * EMB * EMB);
+                add_tr(tr_in[l].W32, tr_in[l].W, tr_in[l].Wt, 3 * EMB, EMB);
                 bind_lin(tr_out[l], L + "self_attn.out_proj", EMB, EMB);
                 bind_lin(tr_l1[l], L + "linear1", FF, EMB);
                 bind_lin(tr_l2[l], L + "linear2", EMB, FF);
@@ -294,8 +314,9 @@ struct Engine : IEngine {
             wih0_32 = pw(ad + "rnn.weight_ih_l0"); dwih0 = gw(ad + "rnn.weight_ih_l0");
             bih0 = pw(ad + "rnn.bias_ih_l0"); bhh0 = pw(ad + "rnn.bias_hh_l0"); bih1 = pw(ad + "rnn.bias_ih_l1"); bhh1 = pw(ad + "rnn.bias_hh_l1");
             dbih0 = gw(ad + "rnn.bias_ih_l0"); dbhh0 = gw(ad + "rnn.bias_hh_l0"); dbih1 = gw(ad + "rnn.bias_ih_l1"); dbhh1 = gw(ad + "rnn.bias_hh_l1");
-            if (std::is_same<T, float>::value) wih0 = (T*)wih0_32; else if (!wih0) wih0 = alloc<T>((int64_t)HID * KIN);
+            wih0 = std::is_same<T, float>::value ? (T*)wih0_32 : wshadow + (wih0_32 - P);
             if (!wih0T) wih0T = alloc<T>((int64_t)HID * KIN);
+            add_tr(wih0_32, wih0, wih0T, HID, KIN);
             bind_lin(whh0, ad + "rnn.weight_hh_l0", HID, HID, false);
             bind_lin(wih1, ad + "rnn.weight_ih_l1", HID, HID, false);
             bind_lin(whh1, ad + "rnn.weight_hh_l1", HID, HID, false);
@@ -313,6 +334,9 @@ struct Engine : IEngine {
             hulc_set_error("hulc_bind_params: a required parameter name is missing from the table");
             return 1;
         }
+        if (trdesc_dev) { hipFree(trdesc_dev); trdesc_dev = nullptr; }
+        if (hipMalloc((void**)&trdesc_dev, sizeof(TrDesc) * trdesc.size()) != hipSuccess) alloc_failed = true;
+        else hipMemcpy(trdesc_dev, trdesc.data(), sizeof(TrDesc) * trdesc.size(), hipMemcpyHostToDevice);
         if (alloc_failed) { hulc_set_error("hipMalloc failed while allocating weight copies"); return 1; }
         bound = true;
         return prepare_weights();
@@ -414,35 +438,28 @@ struct Engine : IEngine {
     }
 
     // ---------------------------------------------------------------- weight preparation
-    void prep_lin(LinW& L) {
-        if (!L.W32) return;
-        cast_tr<float, T>(L.W32, L.K, L.own_w ? L.W : nullptr, L.K, L.Wt, L.N, L.N, L.K);
-    }
     void prep_conv(ConvW& c) {
         const int total = c.O * c.I * c.KH * c.KW;
         hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, c.W32, c.Wf, c.nhwc ? c.Wd : (T*)nullptr, c.O, c.I, c.KH,
                            c.KW, c.S, c.nhwc);
     }
-    int prepare_weights() override {
+    // compute-precision copies: (bf16) flat shadow cast, ONE batched launch for every transposed Linear weight, conv packs, the
+    // NHWC-permuted gripper fc and the packed decoder heads
+    int prepare_weights(bool shadow_fresh = false) override {
         if (!bound) { hulc_set_error("hulc_prepare_weights before hulc_bind_params"); return 1; }
+        if constexpr (!std::is_same<T, float>::value) {
+            if (!shadow_fresh) hipLaunchKernelGGL((cast_kernel<float, T>), dim3(2048), dim3(256), 0, st, P, wshadow, (long long)numel);
+        }
+        if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        else hipLaunchKernelGGL((batched_transpose_kernel<T, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         for (EncW* e : {&encS, &encG}) {
             prep_conv(e->c1); prep_conv(e->c2); prep_conv(e->c3);
-            prep_lin(e->fc1); prep_lin(e->fc2);
             if (e->gripper) {
                 // W7p[o][p*64+c] = W7[o][c*49+p]; then transposed copy
                 hipLaunchKernelGGL((permute_cols_kernel<float, T>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, e->fc7.W32, e->fc7.W, 128, 64, 49, 0, 0);
                 cast_tr<T, T>(e->fc7.W, 3136, nullptr, 0, e->fc7.Wt, 128, 128, 3136);
             }
         }
-        for (auto& l : pp) prep_lin(l);
-        for (auto& l : vg) prep_lin(l);
-        for (auto& l : lg) prep_lin(l);
-        for (int l = 0; l < 2; ++l) {
-            cast_tr<float, T>(tr_in[l].W32, EMB, std::is_same<T, float>::value ? nullptr : tr_in[l].W, EMB, tr_in[l].Wt, 3 * EMB, 3 * EMB, EMB);
-            prep_lin(tr_out[l]); prep_lin(tr_l1[l]); prep_lin(tr_l2[l]);
-        }
-        prep_lin(pr_fc); prep_lin(pr_fs); prep_lin(whh0); prep_lin(wih1); prep_lin(whh1);
-        cast_tr<float, T>(wih0_32, KIN, std::is_same<T, float>::value ? nullptr : wih0, KIN, wih0T, HID, HID, KIN);
         // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
         int r0 = 0;
         for (int i = 0; i < 4; ++i) {
@@ -451,7 +468,6 @@ struct Engine : IEngine {
             r0 += head_rows[i];
         }
         cast_tr<T, T>(wheads, HID, nullptr, 0, wheadsT, NHEAD, NHEAD, HID);
-        if (cfg.use_clip) { prep_lin(cl_im0); prep_lin(cl_im2); prep_lin(cl_la0); prep_lin(cl_la2); }
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
         return 0;
@@ -603,7 +619,6 @@ struct Engine : IEngine {
             lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
             { EpiP ep = epi(dact3, false); ep.mask = a.a3; lin_dgrad(d_g0, Nf, e.fc7, ep, dense_out(3136)); }
             // dW7 in packed (NHWC) column order -> temp, then permute-accumulate into the torch-layout grad
-            HIP_CHECK_VOID(hipMemsetAsync(dw7_tmp, 0, sizeof(float) * 128 * 3136, st));
             lin_wgrad(d_g0, a.a3, 3136, Nf, 128, 3136, dw7_tmp, 3136, e.fc7.db);
             hipLaunchKernelGGL((permute_cols_kernel<float, float>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, dw7_tmp, e.fc7.dW, 128, 64, 49, 1, 1);
         }
@@ -787,9 +802,7 @@ struct Engine : IEngine {
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         const float dp = cfg.dropout_p;
         const long long BH = (long long)B * HID;
-        HIP_CHECK(hipMemsetAsync(demb, 0, sizeof(float) * N * EMB, st));
-        HIP_CHECK(hipMemsetAsync(dgoal, 0, sizeof(float) * B * GOAL, st));
-        HIP_CHECK(hipMemsetAsync(dseqf, 0, sizeof(float) * B * FCH, st));
+        HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries
         bool have_dseq = false;
         // ---- CLIP backward
         if (clip_n > 0) {
@@ -815,8 +828,6 @@ struct Engine : IEngine {
         {
             // heads
             { EpiP ep = epi(dH1, false); gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
-            HIP_CHECK(hipMemsetAsync(dwheads_tmp, 0, sizeof(float) * NHEAD * HID, st));
-            HIP_CHECK(hipMemsetAsync(dbheads_tmp, 0, sizeof(float) * NHEAD, st));
             lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
             int r0 = 0;
             for (int i = 0; i < 4; ++i) {
@@ -940,9 +951,10 @@ struct Engine : IEngine {
         const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
         const double bc1d = 1.0 - pow((double)b1, (double)step), bc2d = 1.0 - pow((double)b2, (double)step);
         (void)bc1; (void)bc2;
-        hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale);
+        hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale,
+                           std::is_same<T, float>::value ? (bf16_t*)nullptr : (bf16_t*)wshadow);
         if (hipGetLastError() != hipSuccess) { hulc_set_error("adam launch failed"); return 1; }
-        return prepare_weights();
+        return prepare_weights(true);
     }
 
     int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) override {

@@ -33,6 +33,32 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const TS* __restric
     }
 }
 
+// many transposes in one launch: block b belongs to descriptor d with blk0[d] <= b < blk0[d+1]; dstT[c][r] = src[r][c]
+struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, tiles_x; };
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __restrict__ desc, int ndesc) {
+    __shared__ float tile[32][33];
+    int d = 0;
+    while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
+    const TrDesc D = desc[d];
+    const int b = blockIdx.x - D.blk0;
+    const int c0 = (b % D.tiles_x) * 32, r0 = (b / D.tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const TS* src = reinterpret_cast<const TS*>(D.src);
+    TD* dst = reinterpret_cast<TD*>(D.dst);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        tile[ty + i * 8][tx] = (r < D.R && c < D.C) ? to_f<TS>(src[(long long)r * D.lds + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < D.R && c < D.C) dst[(long long)c * D.ldt + r] = from_f<TD>(tile[tx][ty + i * 8]);
+    }
+}
+
 // conv weights: torch (O, I, KH, KW) fp32 ->
 //   fwd pack  Wf[o][(kh,kw,ci)]                       (conv2/3; conv1 keeps torch's (c,kh,kw) order = plain cast)
 //   dgrad pack Wd[zc][ci][(a,b,co)] = W[co][ci][ph+S*a][pw+S*b],  zc = ph*S+pw
@@ -837,7 +863,7 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int
 // fused with the gradient scale (1/world for the DP mean) — one pass over p, g, m, v.
 // =========================================================================================================
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, bf16_t* __restrict__ shadow) {
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
@@ -852,6 +878,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             P[e] -= (lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
         }
         *reinterpret_cast<float4*>(p + i) = pp;
+        if (shadow) {      // bf16 compute copy of the parameters, refreshed in the same pass
+            uint2 o;
+            o.x = (unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16);
+            o.y = (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16);
+            *reinterpret_cast<uint2*>(shadow + i) = o;
+        }
         *reinterpret_cast<float4*>(m + i) = mm;
         *reinterpret_cast<float4*>(v + i) = vv;
     }
