@@ -25,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hulc_amd import spec  # noqa: E402
+from hulc_amd import parallel, spec  # noqa: E402
 from hulc_amd.engine import StepEngine  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -115,13 +115,13 @@ def main():
 
     def step(i):
         eng.zero_grads()
-        for name, mb in mods:
+        for k, (name, mb) in enumerate(mods):
             eng.forward_loss(mb, name == "lang", 1.0 / nmod, 3.0, step=i, sync_losses=False)
-            eng.backward()
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(eng.flat_grads)          # RCCL over xGMI, one flat 188 MB fp32 bucket
-        eng.adam_step(lr=2e-4, grad_scale=1.0 / world)
+            if world > 1 and k == nmod - 1:
+                parallel.backward_overlapped(eng)    # RCCL all-reduce of the flat gradient, overlapped with the encoder backward
+            else:
+                eng.backward()
+        eng.adam_step(lr=2e-4, grad_scale=1.0 / world)   # DP mean folded into the Adam kernel
 
     def barrier():
         if world > 1:

@@ -62,7 +62,11 @@ int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* b, float lw, float cw, fl
     if (!ctx || !b) { hulc_set_error("hulc_forward_loss: null argument"); return 1; }
     return ctx->e->forward(b, lw, cw, out, on_host);
 }
-int hulc_backward(hulc_ctx* ctx) { return ctx->e->backward(); }
+int hulc_backward(hulc_ctx* ctx) { return ctx->e->backward(-1); }
+int hulc_backward_part(hulc_ctx* ctx, int32_t part) {
+    if (part != 0 && part != 1) { hulc_set_error("hulc_backward_part: part must be 0 or 1"); return 1; }
+    return ctx->e->backward(part);
+}
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
 int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }
 int hulc_set_dropout(hulc_ctx* ctx, float p) {

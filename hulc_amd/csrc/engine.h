@@ -20,7 +20,7 @@ struct IEngine {
     virtual int prepare_weights(bool shadow_fresh = false) = 0;
     virtual int zero_grads() = 0;
     virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
-    virtual int backward() = 0;
+    virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
     virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
     virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
     virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
@@ -795,14 +795,19 @@ struct Engine : IEngine {
     }
 
     // ---------------------------------------------------------------- backward
-    int backward() override {
+    int bwd_stage = 0;    // 0: nothing pending; 1: part 0 done, encoders pending
+    int backward(int part = -1) override {
         if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
+        if (part == 1 && bwd_stage != 1) { hulc_set_error("hulc_backward_part(1) must follow hulc_backward_part(0)"); return 1; }
+        if (part != 1 && bwd_stage != 0) { hulc_set_error("hulc_backward: encoder part of the previous backward still pending"); return 1; }
         const hulc_batch* b = &cur;
         const int B = b->B, S = b->S, N = B * S, SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         const float dp = cfg.dropout_p;
         const long long BH = (long long)B * HID;
+        if (part == 1) goto encoders;
         HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries
+        {
         bool have_dseq = false;
         // ---- CLIP backward
         if (clip_n > 0) {
@@ -936,6 +941,13 @@ struct Engine : IEngine {
                         demb + (long long)(S - 1) * EMB, &om, 1);
             }
         }
+        }
+        if (part == 0) {
+            if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
+            bwd_stage = 1;
+            return 0;
+        }
+    encoders:
         // ---- encoders backward
         enc_bwd(encS, aS, b->rgb_static, N, 0);
         STAGE("enc_static_bwd");
@@ -943,6 +955,7 @@ struct Engine : IEngine {
         STAGE("enc_gripper_bwd");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;
+        bwd_stage = 0;
         return 0;
     }
 

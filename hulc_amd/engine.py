@@ -121,8 +121,17 @@ class StepEngine:
         L.check(self.lib.hulc_timers_read(self.ctx, buf, len(buf), int(reset)))
         return json.loads(buf.value.decode())
 
-    def backward(self):
-        L.check(self.lib.hulc_backward(self.ctx))
+    def backward(self, part: int = -1):
+        """part -1: whole backward; 0: everything but the perceptual encoders; 1: the encoders (must follow 0)."""
+        if part < 0:
+            L.check(self.lib.hulc_backward(self.ctx))
+        else:
+            L.check(self.lib.hulc_backward_part(self.ctx, part))
+
+    @property
+    def encoder_numel(self) -> int:
+        """Flat-buffer elements [0, encoder_numel) belong to perceptual_encoder.*; the rest is final after backward(part=0)."""
+        return min(off for n, (off, _) in self.layout.items() if not n.startswith("perceptual_encoder."))
 
     def adam_step(self, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
         self.adam_t += 1

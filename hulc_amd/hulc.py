@@ -49,7 +49,9 @@ class FusedAdam:
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         world = parallel.world_size()
-        parallel.allreduce_sum_(self.module.engine.flat_grads)
+        if not self.module._grads_reduced:               # training_step already overlapped the all-reduce with the encoder backward
+            parallel.allreduce_sum_(self.module.engine.flat_grads)
+        self.module._grads_reduced = False
         self.module.engine.adam_step(lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], grad_scale=1.0 / world)
         return loss
 
@@ -158,6 +160,7 @@ class Hulc(torch.nn.Module):
             self._params[n].grad = g
         self.reset_parameters(seed)
         self.logged: Dict[str, float] = {}
+        self._grads_reduced = False
         self.global_step = 0
         self.rollout_step_counter = 0
         self.latent_goal = None
@@ -268,11 +271,15 @@ class Hulc(torch.nn.Module):
         kl = act = tot = clip = 0.0
         total_bs = 0
         bs: Dict[str, int] = {}
-        for self.modality_scope, dataset_batch in batch.items():
+        for imod, (self.modality_scope, dataset_batch) in enumerate(batch.items()):
             is_lang = "lang" in self.modality_scope
             mb = self._modality_batch(dataset_batch, is_lang, eng.device)
             l = eng.forward_loss(mb, is_lang, 1.0 / nmod, self.clip_auxiliary_loss_beta, step=self.global_step)
-            eng.backward()
+            if imod == nmod - 1 and parallel.world_size() > 1:
+                parallel.backward_overlapped(eng)          # RCCL all-reduce of the finished 98 % under the encoder backward
+                self._grads_reduced = True
+            else:
+                eng.backward()
             b = mb["actions"].shape[0]
             bs[self.modality_scope] = b
             total_bs += b

@@ -25,7 +25,7 @@ class HulcBatch(C.Structure):
 
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
-           "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward",
+           "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward", "hulc_backward_part",
            "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
 
 _lib = None
@@ -52,6 +52,7 @@ def load():
     lib.hulc_zero_grads.argtypes = [C.c_void_p]
     lib.hulc_forward_loss.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
     lib.hulc_backward.argtypes = [C.c_void_p]
+    lib.hulc_backward_part.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]
     lib.hulc_set_kl_beta.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_set_dropout.argtypes = [C.c_void_p, C.c_float]

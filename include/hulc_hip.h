@@ -88,6 +88,10 @@ int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* batch, float loss_weight,
                       int32_t losses_on_host);
 /* Backward of the last hulc_forward_loss; ACCUMULATES into the bound gradient buffer. */
 int hulc_backward(hulc_ctx* ctx);
+/* The same in two halves, so the host can start the gradient all-reduce of the 98 % of the parameters that are finished first:
+ * part 0 = everything except the perceptual encoders (decoder, plan networks, goal encoders, CLIP head); part 1 = the encoders.
+ * After part 0 the gradients of every non-encoder tensor (flat offsets >= the first `plan_proposal.*` tensor) are final. */
+int hulc_backward_part(hulc_ctx* ctx, int32_t part);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
 

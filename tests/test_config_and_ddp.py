@@ -92,3 +92,45 @@ def test_data_parallel_mean_gradient_gloo():
     O.adam_step(P, {"w": ((g0 + g1) / 2).numpy()}, {}, 1)
     O.adam_step(Pa, {"w": (s0 * 0.5).numpy()}, {}, 1)
     assert np.array_equal(P["w"], Pa["w"])
+
+
+class _FakeEngine:
+    """CPU stand-in with the StepEngine surface backward_overlapped touches (flat_grads, encoder_numel, backward(part))."""
+
+    def __init__(self, rank):
+        self.flat_grads = torch.zeros(1000)
+        self.encoder_numel = 128
+        self.rank = rank
+        self.calls = []
+
+    def backward(self, part=-1):
+        self.calls.append(part)
+        if part in (-1, 0):
+            self.flat_grads[self.encoder_numel:] += float(self.rank + 1)
+        if part in (-1, 1):
+            self.flat_grads[: self.encoder_numel] += 10.0 * (self.rank + 1)
+
+
+def _overlap_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hulc_amd import parallel
+    parallel.init_from_env("gloo")
+    e = _FakeEngine(rank)
+    parallel.backward_overlapped(e)
+    out[rank] = (e.calls, float(e.flat_grads[0]), float(e.flat_grads[-1]))
+    dist.destroy_process_group()
+
+
+def test_backward_overlapped_allreduce_gloo():
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_overlap_worker, args=(2, 29700 + os.getpid() % 200, out), nprocs=2, join=True)
+    for r in (0, 1):
+        calls, enc, rest = out[r]
+        assert calls == [0, 1] and enc == 30.0 and rest == 3.0      # both slices hold the SUM over ranks
+    from hulc_amd import parallel
+    e = _FakeEngine(0)
+    parallel.backward_overlapped(e)                                   # world 1: plain whole backward
+    assert e.calls == [-1]

@@ -195,3 +195,28 @@ def test_error_paths():
     with pytest.raises(RuntimeError):
         eng.backward()                                   # no forward kept
     eng.close()
+
+
+def test_backward_in_two_parts_equals_whole():
+    """hulc_backward_part(0) + (1) == hulc_backward (the split exists so the all-reduce can overlap the encoder backward);
+    after part 0 every non-encoder gradient is already final."""
+    dims, P, batch, fx = load_case("hulc_tiny")
+    eng = _engine(dims, 2, 4, "fp32")
+    eng.load_numpy(P)
+    run_step(eng, batch)
+    whole = eng.flat_grads.clone()
+    eng.zero_grads()
+    nmod = len(batch)
+    n_enc = eng.encoder_numel
+    for k, (sc, mb) in enumerate(batch.items()):
+        eng.forward_loss(to_dev(mb), "lang" in sc, 1.0 / nmod, 3.0)
+        eng.backward(0)
+        if k == nmod - 1:
+            assert torch.equal(eng.flat_grads[n_enc:], whole[n_enc:])
+            with pytest.raises(RuntimeError):
+                eng.backward()                      # encoder part still pending
+        eng.backward(1)
+    assert torch.equal(eng.flat_grads, whole)
+    names_enc = [n for n, (off, _) in eng.layout.items() if off < n_enc]
+    assert names_enc and all(n.startswith("perceptual_encoder.") for n in names_enc)
+    eng.close()
