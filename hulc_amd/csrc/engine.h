@@ -378,7 +378,13 @@ struct Engine : IEngine {
         }
         // largest tile that still yields >= 128 workgroups (small-N transformer / encoder GEMMs are latency-bound otherwise)
         const long long w128 = (long long)cdiv(M, 128) * cdiv(N, 128), w64 = (long long)cdiv(M, 64) * cdiv(N, 64);
-        if (M >= 512 && N >= 128 && w128 >= 128) { TimerScope ts(this, "gemm_128x128", "mfma", fl, by); launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K); }
+        if (M >= 512 && N >= 128 && w128 >= 128) {
+            TimerScope ts(this, "gemm_128x128", "mfma", fl, by);
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (K >= 256) { launch_gemm<T, 128, 128, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K); return; }   // BK = 64: half the barriers per flop
+            }
+            launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
+        }
         else if (w64 >= 128 || (M <= 64 && N <= 64)) launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
         else launch_gemm<T, 32, 32>(st, a, b, om, ep, M, N, K);
     }

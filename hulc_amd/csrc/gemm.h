@@ -340,30 +340,30 @@ DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, 
 // ---------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------
-template <typename T> struct LdsLd;
-template <> struct LdsLd<bf16_t> { static constexpr int v = 40; };   // 80 B rows: 16-B aligned b128 reads
-template <> struct LdsLd<float> { static constexpr int v = 34; };    // 2*row + g distinct banks for b32 reads
+template <typename T, int BK> struct LdsLd;
+template <int BK> struct LdsLd<bf16_t, BK> { static constexpr int v = BK + 8; };   // 80 / 144 B rows: 16-B aligned, conflict-free b128 reads
+template <int BK> struct LdsLd<float, BK> { static constexpr int v = BK + 2; };    // 2*row + g distinct banks for b32 reads
 
 // piece numbering inside a [BR rows][32 k] operand tile:
 //   normal loader:      q -> row = q >> 2, k-piece = q & 3          (8 contiguous k per piece)
 //   transposed loader:  q -> row-group = q % (BR/8), kk = q / (BR/8) (8 consecutive rows at one k)
-template <typename T, int BR, typename L>
+template <typename T, int BR, typename L, int BK>
 DEVI void tile_fetch(const L& l, const typename L::Row& rc, int r0blk, int q, int k, int kend, T (&v)[8]) {
     if constexpr (L::TRANSPOSED) {
         l.fetchT(r0blk + (q % (BR / 8)) * 8, k + q / (BR / 8), kend, v);
     } else {
-        l.fetch(rc, k + (q & 3) * 8, kend, v);
+        l.fetch(rc, k + (q % (BK / 8)) * 8, kend, v);
     }
 }
-template <typename T, int BR, bool TRANSPOSED>
+template <typename T, int BR, bool TRANSPOSED, int BK>
 DEVI void tile_commit(T* S, const T (&v)[8], int q) {
-    constexpr int LD = LdsLd<T>::v;
+    constexpr int LD = LdsLd<T, BK>::v;
     if constexpr (TRANSPOSED) {
         const int rg = q % (BR / 8), kk = q / (BR / 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) S[(rg * 8 + e) * LD + kk] = v[e];
     } else {
-        T* d = S + (q >> 2) * LD + (q & 3) * 8;
+        T* d = S + (q / (BK / 8)) * LD + (q % (BK / 8)) * 8;
         if constexpr (sizeof(T) == 2) {
             *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(v);
         } else {
@@ -373,12 +373,12 @@ DEVI void tile_commit(T* S, const T (&v)[8], int q) {
     }
 }
 
-template <typename T, int BM, int BN, typename AL, typename BL, typename OM>
+template <typename T, int BM, int BN, typename AL, typename BL, typename OM, int BK = 32>
 __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep, int N, int K, int nsplit, int ksplit) {
-    constexpr int BK = 32;
-    constexpr int LD = LdsLd<T>::v;
-    constexpr int APT = (BM * 4 + 255) / 256;
-    constexpr int BPT = (BN * 4 + 255) / 256;
+    constexpr int LD = LdsLd<T, BK>::v;
+    constexpr int PPR = BK / 8;                                  // 8-element pieces per tile row
+    constexpr int APT = (BM * PPR + 255) / 256;
+    constexpr int BPT = (BN * PPR + 255) / 256;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     static_assert(TM >= 1 && TN >= 1, "tile too small");
     __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
@@ -396,21 +396,21 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
     typename AL::Row arow[APT];
     typename BL::Row brow[BPT];
 #pragma unroll
-    for (int i = 0; i < APT; ++i) arow[i] = al.row(m0 + ((tid + i * 256) >> 2), zc);
+    for (int i = 0; i < APT; ++i) arow[i] = al.row(m0 + (tid + i * 256) / PPR, zc);
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) brow[i] = bl.row(n0 + ((tid + i * 256) >> 2), zc);
+    for (int i = 0; i < BPT; ++i) brow[i] = bl.row(n0 + (tid + i * 256) / PPR, zc);
 
     T ra[APT][8], rb[BPT][8];
     auto fetch_all = [&](int k) {
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int q = tid + i * 256;
-            if (q < BM * 4) tile_fetch<T, BM, AL>(al, arow[i], m0, q, k, kend, ra[i]);
+            if (q < BM * PPR) tile_fetch<T, BM, AL, BK>(al, arow[i], m0, q, k, kend, ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const int q = tid + i * 256;
-            if (q < BN * 4) tile_fetch<T, BN, BL>(bl, brow[i], n0, q, k, kend, rb[i]);
+            if (q < BN * PPR) tile_fetch<T, BN, BL, BK>(bl, brow[i], n0, q, k, kend, rb[i]);
         }
     };
 
@@ -426,28 +426,31 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int q = tid + i * 256;
-            if (q < BM * 4) tile_commit<T, BM, AL::TRANSPOSED>(As, ra[i], q);
+            if (q < BM * PPR) tile_commit<T, BM, AL::TRANSPOSED, BK>(As, ra[i], q);
         }
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const int q = tid + i * 256;
-            if (q < BN * 4) tile_commit<T, BN, BL::TRANSPOSED>(Bs, rb[i], q);
+            if (q < BN * PPR) tile_commit<T, BN, BL::TRANSPOSED, BK>(Bs, rb[i], q);
         }
         __syncthreads();
         if (k + BK < kend) fetch_all(k + BK);
         if constexpr (sizeof(T) == 2) {
-            bf16x8_t a[TM], b[TN];
             const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4) * 8;
             const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4) * 8;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 16 * LD);
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8_t a[TM], b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 16 * LD);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 16 * LD + kk * 32);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 16 * LD + kk * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
+            }
         } else {
             const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4);
             const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4);
@@ -490,14 +493,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
 }
 
 // host launcher: grid.x over M tiles, grid.y over N tiles, grid.z = classes * nsplit
-template <typename T, int BM, int BN, typename AL, typename BL, typename OM>
+template <typename T, int BM, int BN, typename AL, typename BL, typename OM, int BK = 32>
 static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const OM& om, const EpiP& ep, int Mmax, int N,
                                int K, int nclass = 1, int nsplit = 1) {
     if (Mmax <= 0 || N <= 0) return;
     int ksplit = K;
-    if (nsplit > 1) ksplit = ((K + nsplit - 1) / nsplit + 31) / 32 * 32;   // empty slabs still write zeros
+    if (nsplit > 1) ksplit = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;   // empty slabs still write zeros
     dim3 grid((Mmax + BM - 1) / BM, (N + BN - 1) / BN, nclass * nsplit);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AL, BL, OM>), grid, dim3(256), 0, st, al, bl, om, ep, N, K, nsplit, ksplit);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, AL, BL, OM, BK>), grid, dim3(256), 0, st, al, bl, om, ep, N, K, nsplit, ksplit);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -586,6 +589,6 @@ static inline void launch_skinny(hipStream_t st, const bf16_t* A, long long lda,
 }
 static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, const void* A, const void* W) {
     // many-row use: every 64-row block of A is re-read by each of the N/16 column workgroups -> only when M*N is small
-    const bool shape = M <= 64 || (K >= 512 && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 32);
+    const bool shape = M <= 64 || (K >= 512 && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
     return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }
