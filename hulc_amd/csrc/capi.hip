@@ -150,6 +150,9 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
 #define SK(nw, mt) hipLaunchKernelGGL((skinny_gemm_kernel<nw, mt>), grid, dim3(nw * 64), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep)
     if (NW == 8 && MT == 2) SK(8, 2); else if (NW == 8 && MT == 4) SK(8, 4); else if (NW == 4 && MT == 2) SK(4, 2); else if (NW == 4 && MT == 4) SK(4, 4);
     else if (NW == 8 && MT == 1) SK(8, 1); else if (NW == 4 && MT == 1) SK(4, 1);
+    else if (NW == 16 && MT == 2) SK(16, 2); else if (NW == 16 && MT == 4) SK(16, 4);
+    else if (NW == 9 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<8, 2, 8>), grid, dim3(512), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
+    else if (NW == 17 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<16, 2, 4>), grid, dim3(1024), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
     else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;

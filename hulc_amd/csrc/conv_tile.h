@@ -33,7 +33,7 @@ struct ConvTileCfg {
     static constexpr int NT = CN / 16;
     static constexpr int CH = CK / 8;                          // 16-byte chunks per pixel
     static constexpr int PF = 10;                              // prefetch registers (uint4) per thread
-    static constexpr int MT = 2;                               // m-tiles (16 pixels) per wave pass
+    static constexpr int MT = (CN / 16 <= 2) ? 4 : 2;          // m-tiles (16 pixels) per wave pass: LDS reads per MFMA = (MT+NT)/(MT*NT)
     static size_t w_bytes() { return (size_t)NCLS * CN * WS; }
     static size_t lds_bytes(int LR, int LW) { return w_bytes() + (size_t)(LR * LW + 16) * XS; }
 };
@@ -92,15 +92,30 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         if (item < nitems) prefetch(item);                      // in flight during the MFMAs below
         const int f = cur / p.nbands, b = cur % p.nbands;
         const int i0 = b * p.RB;
+        // work items of this band = (parity class, group of MT m-tiles), dealt round-robin to the 8 waves
+        auto groups_of = [&](int cls) {
+            const int ph = cls / OS, pw = cls % OS;
+            const int NI = (p.OUTH - ph + OS - 1) / OS, NJ = (p.OUTW - pw + OS - 1) / OS;
+            const int RBe = max(0, min(p.RB, NI - i0));
+            return (((RBe * NJ + 15) >> 4) + C::MT - 1) / C::MT;
+        };
+        int total_groups = 0;
+#pragma unroll
+        for (int c = 0; c < C::NCLS; ++c) total_groups += groups_of(c);
 #pragma unroll 1
-        for (int cls = 0; cls < C::NCLS; ++cls) {
+        for (int wi = wave; wi < total_groups; wi += 8) {
+            int cls = 0, mybase = 0, base = 0;
+#pragma unroll
+            for (int c = 0; c < C::NCLS; ++c) {
+                if (wi >= base) { cls = c; mybase = base; }
+                base += groups_of(c);
+            }
             const int ph = cls / OS, pw = cls % OS;
             const int NI = (p.OUTH - ph + OS - 1) / OS, NJ = (p.OUTW - pw + OS - 1) / OS;
             const int RBe = min(p.RB, NI - i0);
-            if (RBe <= 0) continue;
             const int npix = RBe * NJ;
-            const int ntm = (npix + 15) >> 4;
-            for (int mt0 = wave * C::MT; mt0 < ntm; mt0 += 8 * C::MT) {
+            const int mt0 = (wi - mybase) * C::MT;
+            {
                 int xoff[C::MT];
                 int opix[C::MT];                                // output pixel offset (elements / CN) or -1
 #pragma unroll
@@ -225,6 +240,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
     int rowsel[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 4), *reinterpret_cast<const float4*>(bias + 16 + g * 4)};
     const int nitems = Nf * nbands;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int f = item / nbands, b = item % nbands;
@@ -233,25 +249,24 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         const int rows = min(XR, IH - ih0);
         __syncthreads();
         if (!(dbg & 4)) {
-            const int nrows = 3 * rows;
-            for (int t0 = wave * 8; t0 < nrows; t0 += 32) {               // 8 rows (one float4 per lane each) in flight per wave
-                float4 v[8];
+            const int plane = rows * W4;                                  // float4 per channel plane of this band (contiguous in HBM)
+            for (int c = 0; c < 3; ++c) {
+                const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
+                for (int q0 = tid; q0 < plane; q0 += 256 * 8) {          // 8 unconditional (clamped) 16-byte loads in flight per thread
+                    float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {                               // unconditional (clamped) loads: no branch, no per-load wait
-                    const int t = min(t0 + u, nrows - 1), lc = min(lane, W4 - 1);
-                    const int c = t / rows, rr = t - c * rows;
-                    v[u] = *reinterpret_cast<const float4*>(X + (((long long)f * 3 + c) * IH + ih0 + rr) * IW + lc * 4);
-                }
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)min(q0 + u * 256, plane - 1) * 4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = t0 + u;
-                    if (t < nrows && lane < W4) {
-                        const int c = t / rows, rr = t - c * rows;
-                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                        u32x2_t o;
-                        o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
-                        o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
-                        *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + lane * 8) = o;
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = q0 + u * 256;
+                        if (q < plane) {
+                            const int rr = q / W4, x4 = q - rr * W4;
+                            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                            u32x2_t o;
+                            o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                            o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                            *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + x4 * 8) = o;
+                        }
                     }
                 }
             }
@@ -260,31 +275,47 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         const int RBe = min(R, OH - oh0);
         const int npix = RBe * OW;
         const int ntm = (dbg & 2) ? 0 : (npix + 15) >> 4;
-        for (int mt = wave; mt < ntm; mt += 4) {
-            const int pi = mt * 16 + li;
-            const bool ok = pi < npix;
-            const int pc = ok ? pi : npix - 1;
-            const int r = pc / OW, ow = pc - r * OW;
-            lds_char* xb = ximg + r * 4 * XRS + ow * 8;
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int mt = wave * 2; mt < ntm; mt += 8) {                      // two m-tiles per pass: independent MFMA chains interleave
+            bool ok[2]; int rr[2], oww[2];
+            lds_char* xb[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int pi = (mt + mm) * 16 + li;
+                ok[mm] = pi < npix;
+                const int pc = ok[mm] ? pi : npix - 1;
+                rr[mm] = pc / OW; oww[mm] = pc - rr[mm] * OW;
+                xb[mm] = ximg + rr[mm] * 4 * XRS + oww[mm] * 8;
+            }
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[mm][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 typedef short s16x4v __attribute__((ext_vector_type(4)));
                 typedef short s16x8v __attribute__((ext_vector_type(8)));
-                const s16x4v lo = *(__attribute__((address_space(3))) s16x4v*)(xb + rowsel[ks]);
-                const s16x4v hi = *(__attribute__((address_space(3))) s16x4v*)(xb + rowsel[ks] + 8);
-                const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, (s16x8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                bf16x8_t xf[2];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf, acc[ct], 0, 0, 0);
+                for (int mm = 0; mm < 2; ++mm) {
+                    const s16x4v lo = *(__attribute__((address_space(3))) s16x4v*)(xb[mm] + rowsel[ks]);
+                    const s16x4v hi = *(__attribute__((address_space(3))) s16x4v*)(xb[mm] + rowsel[ks] + 8);
+                    xf[mm] = __builtin_bit_cast(bf16x8_t, (s16x8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc[mm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf[mm], acc[mm][ct], 0, 0, 0);
             }
-            if (ok) {
-                const long long obase = (((long long)f * OH + oh0 + r) * OW + ow) * 32;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                if (!ok[mm]) continue;
+                const long long obase = (((long long)f * OH + oh0 + rr[mm]) * OW + oww[mm]) * 32;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const int cn0 = ct * 16 + g * 4;
-                    const float4 bb = *reinterpret_cast<const float4*>(bias + cn0);
-                    const float v0 = fmaxf(acc[ct][0] + bb.x, 0.f), v1 = fmaxf(acc[ct][1] + bb.y, 0.f);
-                    const float v2 = fmaxf(acc[ct][2] + bb.z, 0.f), v3 = fmaxf(acc[ct][3] + bb.w, 0.f);
+                    const float v0 = fmaxf(acc[mm][ct][0] + bb[ct].x, 0.f), v1 = fmaxf(acc[mm][ct][1] + bb[ct].y, 0.f);
+                    const float v2 = fmaxf(acc[mm][ct][2] + bb[ct].z, 0.f), v3 = fmaxf(acc[mm][ct][3] + bb[ct].w, 0.f);
                     uint2 o;
                     o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
                     o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);

@@ -244,25 +244,24 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
             {   // X band: fp32 NCHW rows -> bf16 [c][row][iw], one (c,row) per wave pass
                 const int ih0 = oh0 * C::S;
                 const int rows = min(XR, IH - ih0);
-                const int nrows = C::C * rows;
-                for (int t0 = wave * 8; t0 < nrows; t0 += 32) {           // 8 rows (one float4 per lane each) in flight per wave
-                    float4 v[8];
+                const int plane = rows * W4;                                  // float4 per channel plane of this band (contiguous in HBM)
+                for (int c = 0; c < 3; ++c) {
+                    const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
+                    for (int q0 = tid; q0 < plane; q0 += 256 * 8) {          // 8 unconditional (clamped) 16-byte loads in flight per thread
+                        float4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {                           // unconditional (clamped) loads
-                        const int t = min(t0 + u, nrows - 1), lc = min(lane, W4 - 1);
-                        const int c = t / rows, rr = t - c * rows;
-                        v[u] = *reinterpret_cast<const float4*>(X + (((long long)f * C::C + c) * IH + ih0 + rr) * IW + lc * 4);
-                    }
+                        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)min(q0 + u * 256, plane - 1) * 4);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int t = t0 + u;
-                        if (t < nrows && lane < W4) {
-                            const int c = t / rows, rr = t - c * rows;
-                            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                            u32x2_t o;
-                            o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
-                            o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
-                            *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + lane * 8) = o;
+                        for (int u = 0; u < 8; ++u) {
+                            const int q = q0 + u * 256;
+                            if (q < plane) {
+                                const int rr = q / W4, x4 = q - rr * W4;
+                                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                                u32x2_t o;
+                                o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                                o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                                *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + x4 * 8) = o;
+                            }
                         }
                     }
                 }

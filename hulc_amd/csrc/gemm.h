@@ -510,7 +510,7 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 //   (no LDS staging: nothing is reused across waves), then a 16 KB LDS tree combines the 4 K-partials.
 // Requirements: K % 128 == 0, N % 16 == 0, 16-B aligned rows.
 // ---------------------------------------------------------------------------------------------------------
-template <int NW, int MT>
+template <int NW, int MT, int KS = 0>   // KS > 0: K == NW*32*KS exactly -> every load of the wave is issued up front (one latency exposure)
 __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
                                                              long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
     __shared__ float red[NW][MT * 256];
@@ -526,6 +526,19 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (KS > 0) {
+        bf16x8_t b[KS], a[KS][MT];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            b[u] = *reinterpret_cast<const bf16x8_t*>(wp + u * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][mt], b[u], acc[mt], 0, 0, 0);
+    } else {
     // batches of 4 k-steps: issue all (1+MT)*4 16-byte loads, then the MFMAs (memory-level parallelism per wave)
     int k = 0;
     for (; k + 128 <= kq; k += 128) {
@@ -548,6 +561,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
             const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k);
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
         }
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
