@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
         const int cgrp = tid >> 3, e = tid & 7;
         float s = 0.f;
         for (int t = cgrp; t < 256; t += CH) s += red[t * 8 + e];
-        bias_part[(long long)blockIdx.x * CO + tid] = s;
+        unsafeAtomicAdd(bias_part + tid, s);          // bias_part = the bias gradient itself (<= gridDim.x adds per channel)
     }
 }
 
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
         const int cgrp = tid >> 3, e = tid & 7;
         float s = 0.f;
         for (int t = cgrp; t < 256; t += 4) s += red[t * 8 + e];
-        bias_part[(long long)blockIdx.x * C::CO + tid] = s;
+        unsafeAtomicAdd(bias_part + tid, s);
     }
 }
 

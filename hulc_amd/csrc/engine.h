@@ -349,6 +349,14 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((cast_transpose_kernel<TS, TD>), grid, dim3(256), 0, st, src, lds_, dst, ldd, dstT, ldt, R, C);
     }
     static int ldpad(int m) { return (m + 7) / 8 * 8; }
+    // dstA[c][r] = srcA[r][c] and dstB likewise, one launch
+    void transpose_pair(const T* a, long long lda, T* at, int Ra, int Ca, const T* b, long long ldb, T* bt, int Rb, int Cb, long long ldt) {
+        TrPair p;
+        p.d[0].src = a; p.d[0].dst = at; p.d[0].lds = lda; p.d[0].ldt = ldt; p.d[0].R = Ra; p.d[0].C = Ca; p.d[0].tiles_x = cdiv(Ca, 32); p.d[0].blk0 = 0;
+        const int n0 = p.d[0].tiles_x * cdiv(Ra, 32);
+        p.d[1].src = b; p.d[1].dst = bt; p.d[1].lds = ldb; p.d[1].ldt = ldt; p.d[1].R = Rb; p.d[1].C = Cb; p.d[1].tiles_x = cdiv(Cb, 32); p.d[1].blk0 = n0;
+        hipLaunchKernelGGL((pair_transpose_kernel<T>), dim3(n0 + p.d[1].tiles_x * cdiv(Rb, 32)), dim3(256), 0, st, p);
+    }
     template <typename TS, typename TD>
     void copy2d(const TS* src, long long lds_, TD* dst, long long ldd, int R, int C, int acc, float scale = 1.f) {
         hipLaunchKernelGGL((copy2d_kernel<TS, TD>), dim3(cdiv((long long)R * C, 256)), dim3(256), 0, st, src, lds_, dst, ldd, R, C, acc, scale);
@@ -360,11 +368,16 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, cspart, nblk, N, out, out2, scale);
             return;
         }
-        // two-stage, deterministic: <=256 row chunks of >=256 rows, then a 4-lane final per column
         const int nsplit = std::max(1, std::min(256, cdiv(M, 256)));
         const int rps = cdiv(M, nsplit);
-        hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, cspart, rps, 0, 1.f);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, cspart, nsplit, N, out, out2, scale);
+        if constexpr (std::is_same<T, float>::value) {
+            // fp32 (parity) mode stays bit-reproducible: two-stage, deterministic
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, cspart, rps, 0, 1.f, (float*)nullptr);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, cspart, nsplit, N, out, out2, scale);
+        } else {
+            // bf16 (bench) mode: one launch, each row chunk adds its column sums with fp32 atomics
+            hipLaunchKernelGGL((colsum_kernel<T>), dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, ld, M, N, out, rps, 2, scale, out2);
+        }
     }
     // dense NT GEMM with tile selection
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
@@ -398,7 +411,7 @@ struct Engine : IEngine {
         const bool big = M >= 128 && N >= 128;
         const long long tiles = big ? t128 : t64;
         int nsplit = 1;
-        if (tiles < 128 && K >= 512) nsplit = (int)std::min<long long>(std::min<long long>(256 / tiles, K / 256), 32);
+        if (!std::is_same<T, float>::value && tiles < 128 && K >= 512) nsplit = (int)std::min<long long>(std::min<long long>(256 / tiles, K / 256), 32);
         if (nsplit <= 1) { gemm(a, b, dense_out(lddw), ep, M, N, K); return; }
         ep.atomic = 1;
         TimerScope ts(this, big ? "gemm_128x128" : "gemm_64x64_splitk", "mfma", 2.0 * M * N * K, ((double)M * K + (double)N * K) * sizeof(T) + 4.0 * M * N);
@@ -421,8 +434,7 @@ struct Engine : IEngine {
             }
         }
         const int mp = ldpad(M);
-        cast_tr<T, T>(dY, N, nullptr, 0, tA, mp, M, N);
-        cast_tr<T, T>(X, ldx, nullptr, 0, tB, mp, M, K);
+        transpose_pair(dY, N, tA, M, N, X, ldx, tB, M, K, mp);
         gemm_wgrad(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dW, lddw, N, K, M);
         if (db) colsum(dY, N, M, N, db, db2);
     }
@@ -541,17 +553,14 @@ struct Engine : IEngine {
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
                           conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * 4 + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
-                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, cspart, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
         }
         bool bias_done = false;
-        if (nsplit > 0) {     // the tr kernels also produced per-workgroup bias-gradient slabs in cspart
-            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c.O, 64)), dim3(256), 0, st, cspart, nsplit, c.O, c.db, (float*)nullptr, 1.f);
-            bias_done = true;
-        }
+        if (nsplit > 0) bias_done = true;     // the tr kernels added the bias gradient themselves (atomics)
         if (nsplit == 0) {
             nsplit = (int)std::min<long long>(std::max<long long>(1, npix / 2048), partcap / ((long long)c.O * Kc));
             nsplit = std::min(nsplit, 256);
@@ -850,8 +859,7 @@ struct Engine : IEngine {
             rnn_bwd(dH1, H1, dZ1, whh1, B, S);
             {
                 const int mp = ldpad(SB);
-                cast_tr<T, T>(dZ1, HID, nullptr, 0, tA, mp, SB, HID);
-                cast_tr<T, T>(H1, HID, nullptr, 0, tB, mp, SB, HID);
+                transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
@@ -863,8 +871,7 @@ struct Engine : IEngine {
             rnn_bwd(dH0, H0, dZ0, whh0, B, S);
             {
                 const int mp = ldpad(SB);
-                cast_tr<T, T>(dZ0, HID, nullptr, 0, tA, mp, SB, HID);
-                cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
+                transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, 64, nullptr, 0, tB, mp, SB, 64);
@@ -879,8 +886,7 @@ struct Engine : IEngine {
               gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + 64) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
             {
                 const int mp = ldpad(B);
-                cast_tr<T, T>(dC, HID, nullptr, 0, tA, mp, B, HID);
-                cast_tr<T, T>(goal_t, GOAL, nullptr, 0, tB, mp, B, GOAL);
+                transpose_pair(dC, HID, tA, B, HID, goal_t, GOAL, tB, B, GOAL, mp);
                 EpiP ep = epi(dwih0 + dec_plan + 64, true); ep.accumulate = 1;
                 gemm(dense<T>(tA, HID, mp), dense<T>(tB, GOAL, mp), dense_out(KIN), ep, HID, GOAL, B);
             }

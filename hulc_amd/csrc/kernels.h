@@ -59,6 +59,30 @@ __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __
     }
 }
 
+// two transposes in one launch (the dY / X pair of a large-M Linear weight gradient); descriptors by value
+struct TrPair { TrDesc d[2]; };
+template <typename T>
+__global__ void __launch_bounds__(256) pair_transpose_kernel(TrPair pr) {
+    __shared__ float tile[32][33];
+    const TrDesc D = ((int)blockIdx.x >= pr.d[1].blk0) ? pr.d[1] : pr.d[0];
+    const int b = blockIdx.x - D.blk0;
+    const int c0 = (b % D.tiles_x) * 32, r0 = (b / D.tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const T* src = reinterpret_cast<const T*>(D.src);
+    T* dst = reinterpret_cast<T*>(D.dst);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        tile[ty + i * 8][tx] = (r < D.R && c < D.C) ? to_f<T>(src[(long long)r * D.lds + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (r < D.R && c < D.C) dst[(long long)c * D.ldt + r] = from_f<T>(tile[tx][ty + i * 8]);
+    }
+}
+
 // conv weights: torch (O, I, KH, KW) fp32 ->
 //   fwd pack  Wf[o][(kh,kw,ci)]                       (conv2/3; conv1 keeps torch's (c,kh,kw) order = plain cast)
 //   dgrad pack Wd[zc][ci][(a,b,co)] = W[co][ci][ph+S*a][pw+S*b],  zc = ph*S+pw
@@ -155,7 +179,7 @@ __global__ void copy2d_kernel(const TS* __restrict__ src, long long lds_, TD* __
 // =========================================================================================================
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, long long ld, int M, int N, float* __restrict__ out,
-                                                     int rows_per_split, int direct_accumulate, float scale) {
+                                                     int rows_per_split, int direct_accumulate, float scale, float* __restrict__ out2 = nullptr) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
@@ -174,7 +198,8 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, lo
     __syncthreads();
     if (rl == 0 && c < N) {
         const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (direct_accumulate) out[c] += s * scale;
+        if (direct_accumulate == 2) { unsafeAtomicAdd(out + c, s * scale); if (out2) unsafeAtomicAdd(out2 + c, s * scale); }
+        else if (direct_accumulate) out[c] += s * scale;
         else out[(long long)blockIdx.y * N + c] = s;
     }
 }
