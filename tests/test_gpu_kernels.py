@@ -1,0 +1,151 @@
+"""GPU (-m gpu): the individual bench-mode (bf16) kernels through their C-ABI test entry points, against numpy on
+bf16-rounded operands (fp64 reference): raw-tile conv forward / dgrad, tr-read conv wgrad (incl. conv1 from fp32 NCHW),
+skinny GEMM, and the ds_read_b64_tr_b16 lane mapping the wgrad kernels are built on."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from hulc_amd import lib as L
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return L, L.load()
+
+
+def bf(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda().to(torch.bfloat16).contiguous()
+
+
+def f64(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+def conv_fwd_ref(X, W, b, S):          # X (n,h,w,ci) ; W (co,ci,kh,kw)
+    n, ih, iw, ci = X.shape
+    co, _, kh, kw = W.shape
+    oh, ow = (ih - kh) // S + 1, (iw - kw) // S + 1
+    out = np.zeros((n, oh, ow, co))
+    for a in range(kh):
+        for c in range(kw):
+            out += np.einsum("nhwc,dc->nhwd", X[:, a:a + S * oh:S, c:c + S * ow:S, :], W[:, :, a, c])
+    return np.maximum(out + b, 0)
+
+
+def conv_dgrad_ref(dY, W, S, IH):
+    n, oh, ow, co = dY.shape
+    _, ci, kh, kw = W.shape
+    dX = np.zeros((n, IH, IH, ci))
+    for a in range(kh):
+        for c in range(kw):
+            dX[:, a:a + S * oh:S, c:c + S * ow:S, :] += np.einsum("nhwd,dc->nhwc", dY, W[:, :, a, c])
+    return dX
+
+
+def conv_wgrad_ref(X, dY, KH, S):
+    n, ih, iw, ci = X.shape
+    _, oh, ow, co = dY.shape
+    out = np.zeros((co, KH, KH, ci))
+    for kh in range(KH):
+        for kw in range(KH):
+            out[:, kh, kw, :] = np.einsum("nhwc,nhwd->cd", dY, X[:, kh:kh + S * oh:S, kw:kw + S * ow:S, :])
+    return out.reshape(co, -1)
+
+
+@pytest.mark.parametrize("IH,CI,KH,S,fmode,dmode", [(23, 64, 3, 1, 0, 2), (9, 64, 3, 1, 0, 2), (49, 32, 4, 2, 1, 3), (20, 32, 4, 2, 1, 3)])
+@pytest.mark.parametrize("Nf", [1, 7])
+def test_conv_tile_fwd_and_dgrad(IH, CI, KH, S, fmode, dmode, Nf):
+    L, lib = _lib()
+    rng = np.random.default_rng(IH * 10 + Nf)
+    OH = (IH - KH) // S + 1
+    Wb = f64(bf(rng.standard_normal((64, CI, KH, KH)) * 0.1))
+    X = bf(rng.standard_normal((Nf, IH, IH, CI)))
+    b = rng.standard_normal(64).astype(np.float32)
+    wf = bf(Wb.transpose(0, 2, 3, 1).reshape(64, -1))
+    out = torch.zeros(Nf, OH, OH, 64, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_conv_tile(fmode, X.data_ptr(), wf.data_ptr(), torch.from_numpy(b).cuda().data_ptr(), None, out.data_ptr(), Nf, IH, OH, 1, None))
+    torch.cuda.synchronize()
+    ref = conv_fwd_ref(f64(X), Wb, b, S)
+    assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3          # bf16 output rounding
+    # dgrad with ReLU mask; parity-class weight pack [class][ci][(a,b,co)]
+    dY = bf(rng.standard_normal((Nf, OH, OH, 64)) * (np.arange(64) % 5 + 1))
+    TA = KH // S
+    wd = np.zeros((S * S, CI, TA, TA, 64))
+    for kh in range(KH):
+        for kw in range(KH):
+            wd[(kh % S) * S + kw % S, :, kh // S, kw // S, :] = Wb[:, :, kh, kw].T
+    mask = bf(rng.standard_normal((Nf, IH, IH, CI)))
+    dx = torch.full((Nf, IH, IH, CI), 7.0, device="cuda", dtype=torch.bfloat16)      # every pixel must be overwritten
+    L.check(lib.hulc_k_conv_tile(dmode, dY.data_ptr(), bf(wd.reshape(S * S * CI, -1)).data_ptr(), None, mask.data_ptr(), dx.data_ptr(), Nf, OH, IH, 0, None))
+    torch.cuda.synchronize()
+    ref = conv_dgrad_ref(f64(dY), Wb, S, IH) * (f64(mask) > 0)
+    assert np.abs(f64(dx) - ref).max() / np.abs(ref).max() < 6e-3
+
+
+@pytest.mark.parametrize("IH", [200, 84])
+def test_conv1_fwd_and_wgrad_from_fp32_nchw(IH):
+    L, lib = _lib()
+    rng = np.random.default_rng(IH)
+    OH = (IH - 8) // 4 + 1
+    Nf = 3
+    Wb = f64(bf(rng.standard_normal((32, 3, 8, 8)) * 0.1))
+    X = torch.from_numpy(rng.standard_normal((Nf, 3, IH, IH)).astype(np.float32)).cuda()
+    b = rng.standard_normal(32).astype(np.float32)
+    out = torch.zeros(Nf, OH, OH, 32, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_conv_tile(4, X.data_ptr(), bf(Wb.reshape(32, -1)).data_ptr(), torch.from_numpy(b).cuda().data_ptr(), None, out.data_ptr(), Nf, IH, OH, 1, None))
+    torch.cuda.synchronize()
+    Xb = f64(X.to(torch.bfloat16)).transpose(0, 2, 3, 1)
+    ref = conv_fwd_ref(Xb, Wb, b, 4)
+    assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3
+    dY = bf(rng.standard_normal((Nf, OH, OH, 32)) * (np.arange(32) % 5 + 1))
+    g = torch.zeros(32, 192, device="cuda")
+    L.check(lib.hulc_k_conv_wgrad(1, X.data_ptr(), dY.data_ptr(), g.data_ptr(), Nf, IH, None))
+    refw = np.zeros((32, 3, 8, 8))
+    Xn = f64(X.to(torch.bfloat16))
+    for kh in range(8):
+        for kw in range(8):
+            refw[:, :, kh, kw] = np.einsum("nhwd,nchw->dc", f64(dY), Xn[:, :, kh:kh + 4 * OH:4, kw:kw + 4 * OH:4])
+    assert np.abs(g.cpu().numpy() - refw.reshape(32, -1)).max() / np.abs(refw).max() < 1e-4      # fp32 accumulate: tight
+
+
+@pytest.mark.parametrize("which,IH,CI,KH,S", [(3, 23, 64, 3, 1), (3, 9, 64, 3, 1), (2, 49, 32, 4, 2), (2, 20, 32, 4, 2)])
+def test_conv_wgrad_tr(which, IH, CI, KH, S):
+    L, lib = _lib()
+    rng = np.random.default_rng(which * 100 + IH)
+    OH = (IH - KH) // S + 1
+    for Nf in (3, 37):
+        X = bf(rng.standard_normal((Nf, IH, IH, CI)))
+        dY = bf(rng.standard_normal((Nf, OH, OH, 64)) * (np.arange(64) % 7 + 1))
+        out = torch.zeros(64, KH * KH * CI, device="cuda")
+        L.check(lib.hulc_k_conv_wgrad(which, X.data_ptr(), dY.data_ptr(), out.data_ptr(), Nf, IH, None))
+        ref = conv_wgrad_ref(f64(X), f64(dY), KH, S)
+        assert np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(64, 2048, 2048, 82), (64, 2048, 2048, 84), (37, 256, 512, 82), (5, 32, 128, 41), (16, 1024, 4096, 81)])
+def test_skinny_gemm(M, N, K, variant):
+    L, lib = _lib()
+    rng = np.random.default_rng(M + N)
+    A = bf(rng.standard_normal((M, K)))
+    W = bf(rng.standard_normal((N, K)) * 0.05 + np.arange(N)[:, None] * 1e-4)      # asymmetric: a transposed result would show
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_skinny(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, variant, None))
+    torch.cuda.synchronize()
+    ref = f64(A) @ f64(W).T
+    assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3
+
+
+def test_tr_read_lane_mapping():
+    """ds_read_b64_tr_b16: lane i of a 16-lane group receives element (i & 3) of the chunks addressed by lanes j*4 + (i >> 2)."""
+    L, lib = _lib()
+    lane = np.arange(64)
+    addr = torch.from_numpy(((lane >> 4) * 2048 + (lane & 15) * 64).astype(np.int32)).cuda()
+    out = torch.zeros(256, dtype=torch.int16, device="cuda")
+    L.check(lib.hulc_k_trread_probe(addr.data_ptr(), out.data_ptr(), None))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().astype(np.int64).reshape(64, 4) & 0xFFFF
+    for l in range(64):
+        for j in range(4):
+            assert o[l, j] == (l >> 4) * 2048 + (j * 4 + (l & 15) // 4) * 64 + (l & 15) % 4
