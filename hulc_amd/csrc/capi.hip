@@ -128,7 +128,7 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
                      int32_t OUTH, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvTileP p{}; p.img = (const bf16_t*)img; p.IMH = p.IMW = IMH; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.OUTH = p.OUTW = OUTH;
-    p.bias = bias; p.mask = (const bf16_t*)mask; p.relu = relu; p.Nf = Nf;
+    p.bias = bias; p.mask = (const bf16_t*)mask; p.relu = relu & 1; p.dbg = relu & ~1; p.Nf = Nf;
     bool ok = false;
     if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);

@@ -11,10 +11,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define DEVI __device__ __forceinline__
 
 DEVI float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+// fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction)
 DEVI bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even (NaN payloads are not preserved; inputs are finite)
-    return (bf16_t)(u >> 16);
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+DEVI unsigned pack2bf(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t b = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return *reinterpret_cast<unsigned*>(&b);
 }
 template <typename T> DEVI float to_f(T x);
 template <> DEVI float to_f<float>(float x) { return x; }

@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
                                 const int rr = q / W4, x4 = q - rr * W4;
                                 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
                                 u32x2_t o;
-                                o[0] = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
-                                o[1] = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                                o[0] = pack2bf(v[u].x, v[u].y);
+                                o[1] = pack2bf(v[u].z, v[u].w);
                                 *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + x4 * 8) = o;
                             }
                         }

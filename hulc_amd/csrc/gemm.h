@@ -328,8 +328,8 @@ DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, 
         }
         if constexpr (sizeof(T) == 2) {
             uint2 w;
-            w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            w.x = pack2bf(v[0], v[1]);
+            w.y = pack2bf(v[2], v[3]);
             *reinterpret_cast<uint2*>(op) = w;
         } else {
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);

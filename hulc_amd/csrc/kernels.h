@@ -905,8 +905,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         *reinterpret_cast<float4*>(p + i) = pp;
         if (shadow) {      // bf16 compute copy of the parameters, refreshed in the same pass
             uint2 o;
-            o.x = (unsigned)f2bf(pp.x) | ((unsigned)f2bf(pp.y) << 16);
-            o.y = (unsigned)f2bf(pp.z) | ((unsigned)f2bf(pp.w) << 16);
+            o.x = pack2bf(pp.x, pp.y);
+            o.y = pack2bf(pp.z, pp.w);
             *reinterpret_cast<uint2*>(shadow + i) = o;
         }
         *reinterpret_cast<float4*>(m + i) = mm;
