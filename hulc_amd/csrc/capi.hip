@@ -153,6 +153,7 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
     else if (NW == 16 && MT == 2) SK(16, 2); else if (NW == 16 && MT == 4) SK(16, 4);
     else if (NW == 9 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<8, 2, 8>), grid, dim3(512), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
     else if (NW == 17 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<16, 2, 4>), grid, dim3(1024), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
+    else if (NW == 20) { if (!launch_skinny_lds(st, a, (long long)K, w, (long long)K, M, N, K, MT, dense_out(N), ep)) { hulc_set_error("hulc_k_skinny: shape not covered by the LDS kernel"); return 1; } }
     else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;

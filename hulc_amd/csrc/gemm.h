@@ -269,11 +269,45 @@ DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) 
 
 // 4 consecutive output columns of one row (the MFMA is issued as D^T = B A^T, so a lane owns C[row][col..col+3]):
 // vector bias / residual / mask loads and one 16-byte (fp32) or 8-byte (T = bf16) store when aligned, else the scalar path.
+// The vector path is split in two so that a kernel can issue the operand loads early (skinny_lds_kernel: before it waits for
+// its A/W stream) and apply them after the reduction.
+struct EpiPre4 {
+    bool vec;
+    float b[4], rv[4], mk[4];
+};
 template <typename T>
-DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, int N, long long o) {
-    const bool vec = (col + 3 < N) && ((o & 3) == 0) && !ep.atomic && ep.drop_p == 0.f &&
-                     (!ep.res || (((long long)rrow * ep.res_ld + col) & 3) == 0);
-    if (!vec) {
+DEVI EpiPre4 epi_prefetch4(const EpiP& ep, int rrow, int col, int N, long long o) {
+    EpiPre4 p;
+    p.vec = (col + 3 < N) && ((o & 3) == 0) && !ep.atomic && ep.drop_p == 0.f &&
+            (!ep.res || (((long long)rrow * ep.res_ld + col) & 3) == 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p.b[r] = 0.f; p.rv[r] = 0.f; p.mk[r] = 1.f; }
+    if (!p.vec) return p;
+    if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); p.b[0] += b.x; p.b[1] += b.y; p.b[2] += b.z; p.b[3] += b.w; }
+    if (ep.bias2) { const float4 b = *reinterpret_cast<const float4*>(ep.bias2 + col); p.b[0] += b.x; p.b[1] += b.y; p.b[2] += b.z; p.b[3] += b.w; }
+    if (ep.res) {
+        const long long ro = (long long)rrow * ep.res_ld + col;
+        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); p.rv[0] = x.x; p.rv[1] = x.y; p.rv[2] = x.z; p.rv[3] = x.w; }
+        else {
+            T t[4];
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.res) + ro);
+            else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.res) + ro);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.rv[r] = to_f<T>(t[r]);
+        }
+    }
+    if (ep.mask) {
+        T t[4];
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.mask) + o);
+        else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.mask) + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.mk[r] = to_f<T>(t[r]);
+    }
+    return p;
+}
+template <typename T>
+DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], int rrow, int col, int N, long long o) {
+    if (!p.vec) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (col + r < N) epi_store<T>(ep, accv[r], rrow, col + r, o + r);
@@ -281,39 +315,22 @@ DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, 
     }
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = accv[r] * ep.alpha;
-    if (ep.bias) { const float4 b = *reinterpret_cast<const float4*>(ep.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-    if (ep.bias2) { const float4 b = *reinterpret_cast<const float4*>(ep.bias2 + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ep.res) {
-        const long long ro = (long long)rrow * ep.res_ld + col;
-        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); rv[0] = x.x; rv[1] = x.y; rv[2] = x.z; rv[3] = x.w; }
-        else {
-            T t[4];
-            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.res) + ro);
-            else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.res) + ro);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = to_f<T>(t[r]);
-        }
-    }
+    for (int r = 0; r < 4; ++r) v[r] = accv[r] * ep.alpha + p.b[r];
     if (!ep.res_late) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        for (int r = 0; r < 4; ++r) v[r] += p.rv[r];
     }
     if (ep.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
     if (ep.mask) {
-        T t[4];
-        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(ep.mask) + o);
-        else *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(ep.mask) + o);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = to_f<T>(t[r]) > 0.f ? v[r] : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = p.mk[r] > 0.f ? v[r] : 0.f;
     }
     if (ep.res_late) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        for (int r = 0; r < 4; ++r) v[r] += p.rv[r];
     }
     if (ep.out_f32) {
         float4* op = reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o);
@@ -336,12 +353,17 @@ DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, 
         }
     }
 }
+template <typename T>
+DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, int N, long long o) {
+    const EpiPre4 p = epi_prefetch4<T>(ep, rrow, col, N, o);
+    epi_apply4<T>(ep, p, accv, rrow, col, N, o);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BK> struct LdsLd;
-template <int BK> struct LdsLd<bf16_t, BK> { static constexpr int v = BK + 8; };   // 80 / 144 B rows: 16-B aligned, conflict-free b128 reads
+template <int BK> struct LdsLd<bf16_t, BK> { static constexpr int v = BK + 16; };  // 96 / 160 B rows: pitch = 2 (mod 4) 16-B slots -> conflict-free ds_read_b128 (MI355X_MICROARCH.md §LDS)
 template <int BK> struct LdsLd<float, BK> { static constexpr int v = BK + 2; };    // 2*row + g distinct banks for b32 reads
 
 // piece numbering inside a [BR rows][32 k] operand tile:
@@ -581,6 +603,114 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
         }
     }
 }
+#ifdef HULC_KERNEL_STAMPS   // tools/skinny_stamps.hip: cycle stamps of the phases of one launch (never defined in the library build)
+__device__ unsigned long long g_stamps[512 * 64];
+#define KSTAMP(n) do { if (lane == 0) g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 64 + wave * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(n)
+#endif
+static bool skinny_use_lds = true;   // tests / tools can force the register-fragment kernel
+// skinny GEMM, A through LDS (K % 512 == 0, MT*16 rows x K bf16 <= 128 KB): the A rows — 2/3 of the bytes a workgroup pulls, and
+// re-read by every column workgroup — arrive as full 128-byte lines by LDS-DMA (global_load_lds_dwordx4: one wave instruction =
+// 8 rows x 128 B, XOR-swizzled on the SOURCE address so the later ds_read_b128 fragments are conflict-free) instead of
+// fragment-shaped 16 x 64 B loads, which the texture-address path serves at ~2/3 of the full-line rate (tools/loadbench.hip:
+// 192 KB/CU in 4.3 us vs 7.4 us).  Each wave DMAs exactly the k-range it multiplies, so no barrier sits between load and MFMA.
+template <int MT, int KQ32>   // KQ32 = k-steps (of 32) per wave = K / 256
+__global__ void __launch_bounds__(512) skinny_lds_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+                                                         long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
+    constexpr int NW = 8, PCW = KQ32 / 2;               // 128-byte pieces (64 k) per row per wave
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    typedef __attribute__((address_space(3))) char lchar;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * (MT * 16);
+    const int kq = KQ32 * 32, kb = wave * kq;
+    const int g = lane >> 4, i = lane & 15;
+    lchar* wbase = (lchar*)sk_smem + wave * (MT * 2 * PCW * 1024);
+    KSTAMP(0);
+    // ---- A: MT*2 row groups (8 rows) x PCW pieces, lane = (row l>>3, LDS slot l&7), source chunk = slot ^ (row & 6)
+    {
+        const int r = lane >> 3, c = (lane & 7) ^ (r & 6);
+#pragma unroll
+        for (int rg = 0; rg < MT * 2; ++rg) {
+            const bf16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
+#pragma unroll
+            for (int pc = 0; pc < PCW; ++pc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
+                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+        }
+    }
+    // ---- W: fragments straight to registers (one third of the bytes)
+    const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    bf16x8_t b[KQ32];
+#pragma unroll
+    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + u * 32);
+    // ---- epilogue operands of this thread's 4 outputs (threads < MT*64), fetched under the operand stream
+    const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
+    const bool ethread = tid < MT * 64 && erow < M;
+    const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
+    const long long eo = ethread ? om.offset(erow, 0) + ecol : 0;
+    EpiPre4 pre;
+    if (ethread) pre = epi_prefetch4<bf16_t>(ep, errow, ecol, N, eo);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    KSTAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's own DMA has landed (no other wave reads it)
+    KSTAMP(2);
+    {
+        const int r = i & 7;
+        lchar* fb = wbase + (i >> 3) * (PCW * 1024) + r * 128;
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u) {
+            const int chunk = ((u & 1) * 4 + g) ^ (r & 6);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8_t a = *(__attribute__((address_space(3))) bf16x8_t*)(fb + (mt * 2 * PCW + (u >> 1)) * 1024 + chunk * 16);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a, acc[mt], 0, 0, 0);   // D^T: lane (row i, g) owns columns g*4..g*4+3
+            }
+        }
+    }
+    KSTAMP(3);
+    __syncthreads();                                     // every wave is done with its A region: reuse LDS for the K-partials
+    KSTAMP(4);
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);      // [NW][MT][64 lanes]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    if (ethread) {
+        f32x4 v = red[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w * MT * 64 + tid];
+        const float v4[4] = {v[0], v[1], v[2], v[3]};
+        epi_apply4<bf16_t>(ep, pre, v4, errow, ecol, N, eo);
+    }
+    KSTAMP(5);
+}
+template <int MT, int KQ32>
+static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+                                       const DenseOut& om, const EpiP& ep) {
+    const size_t lds = (size_t)8 * MT * 2 * (KQ32 / 2) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)skinny_lds_kernel<MT, KQ32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((skinny_lds_kernel<MT, KQ32>), grid, dim3(512), lds, st, A, lda, W, ldw, M, N, K, om, ep);
+}
+// returns false when the shape is not covered (caller uses the register-fragment kernel)
+static inline bool launch_skinny_lds(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K, int MT,
+                                     const DenseOut& om, const EpiP& ep) {
+    if (K % 512 != 0 || K > 2048 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0) return false;
+    if ((size_t)MT * 16 * K * 2 > 128 * 1024 || (MT != 2 && MT != 4)) return false;
+    dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
+    const int kq32 = K / 256;
+#define SKL(mt, kq) launch_skinny_lds_t<mt, kq>(st, grid, A, lda, W, ldw, M, N, K, om, ep)
+    if (MT == 2) { if (kq32 == 8) SKL(2, 8); else if (kq32 == 4) SKL(2, 4); else if (kq32 == 2) SKL(2, 2); else return false; }
+    else { if (kq32 == 4) SKL(4, 4); else if (kq32 == 2) SKL(4, 2); else return false; }
+#undef SKL
+    return true;
+}
 template <int NW>
 static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
                                     const DenseOut& om, const EpiP& ep) {
@@ -588,6 +718,7 @@ static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long l
     // With only N/16 workgroups (128 at N = 2048) half the CUs idle, so split the rows in two 32-row blocks when that fills the chip.
     int MT = M >= 64 ? 4 : (M + 15) / 16;
     if (M > 32 && (N / 16) * ((M + 63) / 64) <= 160) MT = 2;
+    if (NW == 8 && skinny_use_lds && launch_skinny_lds(st, A, lda, W, ldw, M, N, K, MT, om, ep)) return;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16)), block(NW * 64);
     switch (MT) {
         case 1: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 1>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;

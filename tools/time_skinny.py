@@ -7,7 +7,7 @@ M, N, K = 64, 2048, 2048
 W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
 H = [torch.randn(M, K, device="cuda").to(torch.bfloat16) for _ in range(33)]
 ref = (H[0].float() @ W.float().T)
-for var in (82, 162, 164, 92, 172):
+for var in (82, 202, 92):
     L.check(lib.hulc_k_skinny(H[0].data_ptr(), W.data_ptr(), H[1].data_ptr(), M, N, K, var, None)); torch.cuda.synchronize()
     err = (H[1].float() - ref).abs().max().item() / ref.abs().max().item()
     # dependent chain like the RNN: H[t+1] = f(H[t])
