@@ -82,7 +82,15 @@ int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* out, int64_t cap) { return ctx->e-
 int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    const float* bias, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    EpiP ep; ep.out = C; ep.out_f32 = 1; ep.bias = bias; ep.relu = relu;
+    EpiP ep; ep.out = C; ep.out_f32 = 1; ep.bias = bias; ep.relu = relu & 1;     // relu bit 2 (value 4): force the register-staged kernel
+    if (dtype != HULC_DTYPE_F32 && !(relu & 4) && M >= 512 && N >= 128) {
+        const DenseLoader<bf16_t> a = dense<bf16_t>((const bf16_t*)A, M, lda), b = dense<bf16_t>((const bf16_t*)B, N, ldb);
+        if (gemm_glds_ok(a, b, ep, M, N, K)) {
+            launch_gemm_glds(st, a, b, dense_out(ldc), ep, M, N, K);
+            if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
+            return 0;
+        }
+    }
     if (dtype == HULC_DTYPE_F32) {
         if (M >= 512 && N >= 128) launch_gemm<float, 128, 128>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
         else launch_gemm<float, 64, 64>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);

@@ -394,6 +394,7 @@ struct Engine : IEngine {
         if (M >= 512 && N >= 128 && w128 >= 128) {
             TimerScope ts(this, "gemm_128x128", "mfma", fl, by);
             if constexpr (std::is_same<T, bf16_t>::value) {
+                if (gemm_use_glds && gemm_glds_ok(a, b, ep, M, N, K)) { launch_gemm_glds(st, a, b, om, ep, M, N, K); return; }
                 if (K >= 256) { launch_gemm<T, 128, 128, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K); return; }   // BK = 64: half the barriers per flop
             }
             launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);

@@ -526,6 +526,121 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Dense bf16 NT GEMM, 128x128 tile, operands by LDS-DMA (global_load_lds_dwordx4) into a 3-stage LDS ring.
+//   The 2048-square RNN GEMMs give exactly one 128x128 tile per CU (4 waves): with a single LDS buffer + register prefetch the
+//   L2 latency of every k-step is exposed (64 us at K = 2048 against a 20 us per-CU load floor).  Here two k-steps (BK = 64) are
+//   in flight while a third is multiplied; one raw s_barrier per k-step, counted vmcnt (8 DMA instructions per wave per stage).
+//   A stage = 16 + 16 pieces of 8 rows x 128 B; piece-local swizzle on the SOURCE address (chunk = slot ^ (row & 6)) makes the
+//   ds_read_b128 fragment reads conflict-free (see skinny_lds_kernel).  K % 32 == 0 (a trailing half step multiplies only 32 k).
+//   Workgroup -> tile order is XCD-aware: block b runs on XCD b % 8, which gets a contiguous run of tiles in 4-row groups, so
+//   each XCD's L2 sees 4 A panels x 8 B panels instead of the whole of B.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemm_glds_kernel(DenseLoader<bf16_t> al, DenseLoader<bf16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
+                                                        int tiles_m, int tiles_n) {
+    constexpr int NST = 3, STAGE = 32 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char gg_smem[];
+    typedef __attribute__((address_space(3))) char lchar;
+    lchar* lds = (lchar*)gg_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    int tm, tn;
+    {
+        const int nt = tiles_m * tiles_n, per = nt / 8, rem = nt % 8;
+        const int x = blockIdx.x % 8, q = blockIdx.x / 8;
+        const int tile = x * per + min(x, rem) + q;
+        constexpr int GM = 4;
+        const int gsz = GM * tiles_n, grp = tile / gsz, first_m = grp * GM, gm = min(GM, tiles_m - first_m);
+        tm = first_m + (tile % gsz) % gm;
+        tn = (tile % gsz) / gm;
+    }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int r = lane >> 3, cs = (lane & 7) ^ (r & 6);
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asrc[j] = al.row(min(m0 + (wave * 4 + j) * 8 + r, M - 1), 0).base + cs * 8;
+        bsrc[j] = bl.row(min(n0 + (wave * 4 + j) * 8 + r, N - 1), 0).base + cs * 8;
+    }
+    const int nk = (K + 63) >> 6;
+    const bool khalf = (K & 63) != 0;
+    auto issue = [&](int kt, int buf) {
+        lchar* st = lds + buf * STAGE + wave * 4096;
+        long long ko = (long long)kt * 64;
+        if (khalf && kt == nk - 1 && cs >= 4) ko -= 32;         // chunk beyond K: fetch a valid one instead (never multiplied)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + ko), (__attribute__((address_space(3))) void*)(st + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + ko), (__attribute__((address_space(3))) void*)(st + 16384 + j * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wm = wave >> 1, wn = wave & 1;
+    const int foff = (li >> 3) * 1024 + (li & 7) * 128;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int buf = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt of THIS wave has landed (stage kt+1 may still be in flight); the barrier makes that true for every wave and
+        // also says every wave has finished multiplying stage kt-1, whose buffer the next DMA overwrites
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+        lchar* sa = lds + buf * STAGE + wm * 8192 + foff;
+        lchar* sb = lds + buf * STAGE + 16384 + wn * 8192 + foff;
+        const int nkk = (khalf && kt == nk - 1) ? 1 : 2;
+#pragma unroll 1
+        for (int kk = 0; kk < nkk; ++kk) {
+            const int chunk = (((kk << 2) + g) ^ (li & 6)) << 4;
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(__attribute__((address_space(3))) bf16x8_t*)(sa + i * 2048 + chunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) bf16x8_t*)(sb + j * 2048 + chunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + li;
+        if (row < M) {
+            const long long obase = om.offset(row, 0);
+            const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + g * 4;
+                if (col < N) {
+                    const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    epi_store4<bf16_t>(ep, v4, rrow, col, N, obase + col);
+                }
+            }
+        }
+    }
+}
+static inline bool gemm_glds_ok(const DenseLoader<bf16_t>& a, const DenseLoader<bf16_t>& b, const EpiP& ep, int M, int N, int K) {
+    auto row_ok = [](const DenseLoader<bf16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0; };
+    return K >= 128 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
+}
+static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<bf16_t>& a, const DenseLoader<bf16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles_m * tiles_n), dim3(256), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // skinny GEMM (bf16): M <= 64 rows (the per-timestep recurrent GEMMs and every M = B MLP layer).
 //   out[M][N] = epi(A[M][K] W[N][K]^T), weight-bandwidth bound: one workgroup per 16 output columns (N/16 WGs fill
 //   the chip at N = 2048), its 4 waves split K and stream W / A fragments straight from L2 into MFMA operands
@@ -609,7 +724,8 @@ __device__ unsigned long long g_stamps[512 * 64];
 #else
 #define KSTAMP(n)
 #endif
-static bool skinny_use_lds = true;   // tests / tools can force the register-fragment kernel
+static bool skinny_use_lds = true;
+static bool gemm_use_glds = true;   // tests / tools can force the register-fragment kernel
 // skinny GEMM, A through LDS (K % 512 == 0, MT*16 rows x K bf16 <= 128 KB): the A rows — 2/3 of the bytes a workgroup pulls, and
 // re-read by every column workgroup — arrive as full 128-byte lines by LDS-DMA (global_load_lds_dwordx4: one wave instruction =
 // 8 rows x 128 B, XOR-swizzled on the SOURCE address so the later ds_read_b128 fragments are conflict-free) instead of

@@ -149,3 +149,23 @@ def test_tr_read_lane_mapping():
     for l in range(64):
         for j in range(4):
             assert o[l, j] == (l >> 4) * 2048 + (j * 4 + (l & 15) // 4) * 64 + (l & 15) % 4
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 2048), (2048, 1120, 2048), (2048, 2048, 1120), (1000, 200, 160), (520, 136, 128)])
+def test_gemm_glds_matches_fp64(M, N, K):
+    """3-stage LDS-DMA GEMM (gemm_glds_kernel, the RNN input/weight-gradient GEMMs): ragged tiles, K % 64 == 32 tail, bias + ReLU
+    epilogue, against an fp64 product of the same bf16-rounded operands; also equal to the register-staged kernel."""
+    from hulc_amd import lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) + torch.arange(M, device="cuda")[:, None] * 1e-3).to(torch.bfloat16).contiguous()
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.5 + torch.arange(N, device="cuda")[:, None] * 1e-3).to(torch.bfloat16).contiguous()
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = torch.relu(a.double() @ b.double().T + bias.double())
+    c = torch.zeros(M, N, device="cuda"); c_old = torch.zeros(M, N, device="cuda")
+    L.check(lib.hulc_k_gemm_nt(L.DTYPE["bf16"], a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, bias.data_ptr(), 1, None))
+    L.check(lib.hulc_k_gemm_nt(L.DTYPE["bf16"], a.data_ptr(), b.data_ptr(), c_old.data_ptr(), M, N, K, K, K, N, bias.data_ptr(), 5, None))
+    torch.cuda.synchronize()
+    err = ((c.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err                       # fp32 accumulation of exact bf16 products
+    assert (c - c_old).abs().max().item() <= 2e-5 * ref.abs().max().item()
