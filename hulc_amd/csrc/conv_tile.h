@@ -394,8 +394,10 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
 }
 static inline void launch_conv1_fwd(hipStream_t st, const float* X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0) {
     auto lds_of = [&](int R) { return (size_t)3 * ((R - 1) * 4 + 8) * (IW * 2 + 16) + 64; };
+    static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
+    static const int max_wg = getenv("HULC_C1_WG") ? atoi(getenv("HULC_C1_WG")) : 1024;
     int R = OH;
-    while (R > 1 && lds_of(R) > 78 * 1024) --R;
+    while (R > 1 && lds_of(R) > (size_t)lds_kb * 1024) --R;
     const int nbands = (OH + R - 1) / R;
     R = (OH + nbands - 1) / nbands;
     static bool attr_set = false;
@@ -404,5 +406,5 @@ static inline void launch_conv1_fwd(hipStream_t st, const float* X, const bf16_t
         attr_set = true;
     }
     const int items = Nf * nbands;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < 512 ? items : 512), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg);
 }

@@ -34,8 +34,11 @@ DEVI bf16x8_t tr_read8(lds_char* p0, lds_char* p1) {
 
 template <int CI, int CO, int KH, int KW, int S>
 struct WgradCfg {
-    static constexpr int XS = CI * 2 + 16;          // bytes per input pixel row in LDS (padded: spreads tr-read banks)
-    static constexpr int DYS = CO * 2 + 16;         // bytes per dY pixel row in LDS
+    // LDS bytes per pixel.  A ds_read_b64_tr_b16 is served in two 32-lane halves; with the k <-> pixel assignment of the v2 kernel
+    // a half reads 8 pixels (stride S) x 32 B, which tiles the 64 banks exactly iff pitch * S = 32 * odd bytes
+    // (SQ_LDS_BANK_CONFLICT: 45 % of the LDS cycles with the old +16 pitch at S = 1, 0 with this one)
+    static constexpr int XS = (S == 1) ? ((CI * 2 / 32) | 1) * 32 : CI * 2 + 16;
+    static constexpr int DYS = ((CO * 2 / 32) | 1) * 32;
     static constexpr int CGN = CI / 16;             // channel groups per tap
     static constexpr int NT = KH * KW * CGN;        // n-tiles (16 columns of the packed K dimension each)
     static constexpr int NTW = NT / 4;              // n-tiles per wave
@@ -165,12 +168,191 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 of the kernel above: ONE 8-wave workgroup per CU instead of two 4-wave ones.
+//   * wave = (n-quarter q, co-half h): 2 co-tiles x NT/4 n-tiles of accumulators (72 VGPRs at conv3 instead of 144), which
+//     leaves room for
+//   * a register prefetch of the NEXT band (dY rows + X rows, 16 x 16 B per thread) that is in flight during the MFMAs of the
+//     current one — the two-workgroup version had nothing in flight while it multiplied and nothing multiplying while it staged;
+//   * whole-frame bands where the frame fits (conv3: 152 KB of LDS), balanced bands otherwise (no 1-row tail band).
+// Chunk k of a thread is (dY or X, LDS offset, global offset) packed in one register; loads are unconditional (clamped).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CI, int CO, int KH, int KW, int S, int NWV>
+__global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+                                                            float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg) {
+    using C = WgradCfg<CI, CO, KH, KW, S>;
+    constexpr int NTH = NWV * 64, PF = 8192 / NTH, CTH = C::CT / (NWV / 4), CHY = CO / 8, CHX = CI / 8;   // NWV = 8 or 16 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * S + KH;
+    const int xpix = XR * IW + 8 * S + KW;
+    const int dypix = R * OWp + 8;
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xpix * C::XS;
+    for (int i = tid * 16; i < xpix * C::XS + dypix * C::DYS; i += NTH * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+
+    // ---- this thread's chunks: index ci = tid + k*512 over [dY band chunks | X band chunks]
+    const int ndy = R * OW * CHY, nx = XR * IW * CHX, nch = ndy + nx;
+    unsigned pk[PF];                               // bit 31: X chunk; bits 17..30: LDS offset / 16; bits 0..16: global element offset / 8
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int ci = min(tid + k * NTH, nch - 1);
+        if (ci < ndy) {
+            const int pix = ci / CHY, c = ci % CHY;
+            const int r = pix / OW, ow = pix % OW;
+            pk[k] = ((unsigned)((xpix * C::XS + (r * OWp + ow) * C::DYS + c * 16) >> 4) << 17) | (unsigned)ci;
+        } else {
+            const int cx = ci - ndy;
+            const int pix = cx / CHX, c = cx % CHX;
+            pk[k] = 0x80000000u | ((unsigned)((pix * C::XS + c * 16) >> 4) << 17) | (unsigned)cx;
+        }
+    }
+    const int q = wave & 3, h = wave >> 2;
+    f32x4 acc[C::NTW][CTH];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < CTH; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2;
+    const int ccol = (a & 3) * 8;
+    const int nt0 = q * C::NTW;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    u32x4_t pf[PF];
+    const int nitems = Nf * nbands;
+    unsigned zmask = 0, zmask_cur = 0;
+    auto prefetch = [&](int item) {
+        zmask = 0;
+        if (dbg & 2) return;
+        const int f = item / nbands, oh0 = (item % nbands) * R;
+        const bf16_t* ybase = dY + ((long long)f * OH + oh0) * OW * CO;
+        const bf16_t* xbase = X + ((long long)f * IH + oh0 * S) * IW * CI;
+        const int ylim = (min(R, OH - oh0) * OW * CHY - 1), xlim = (min(XR, IH - oh0 * S) * IW * CHX - 1);   // last in-frame chunk
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const bool isx = (pk[k] >> 31) != 0;
+            const int go = (int)(pk[k] & 0x1ffffu);
+            const bf16_t* src = isx ? xbase + (long long)min(go, xlim) * 8 : ybase + (long long)min(go, ylim) * 8;
+            pf[k] = *reinterpret_cast<const u32x4_t*>(src);           // value untouched here: no wait at the issue point
+            if (!isx && go > ylim) zmask |= 1u << k;                  // dY rows below the frame become zeros at the LDS write
+        }
+    };
+    int item = blockIdx.x;
+    if (item < nitems) prefetch(item);
+    while (item < nitems) {
+        __syncthreads();                               // previous band fully consumed (first pass: zero fill visible)
+        zmask_cur = zmask;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            if (tid + k * NTH < nch) {
+                const u32x4_t v = ((zmask_cur >> k) & 1u) ? u32x4_t{0u, 0u, 0u, 0u} : pf[k];
+                if (!(pk[k] >> 31)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+                }
+                *(lds_u32x4*)((lds_char*)smem + (((pk[k] >> 17) & 0x3fffu) << 4)) = v;
+            }
+        }
+        __syncthreads();
+        item += gridDim.x;
+        if (item < nitems) prefetch(item);             // in flight during the MFMAs below
+        const int units = (dbg & 1) ? 0 : R * U;
+        // k <-> pixel assignment of a 32-pixel step (4 runs of 8): k = g*8 + e; e < 4 (first tr-read): run g>>1, pixel (g&1)*4 + e;
+        // e >= 4 (second tr-read): run 2 + (g>>1), pixel (g&1)*4 + e - 4.  A 32-lane half of one read then covers 8 consecutive
+        // pixels of ONE run -> conflict-free with the pitches of WgradCfg.
+        const int px = (g & 1) * 4 + prow;
+#pragma unroll 1
+        for (int u0 = 0; u0 < units; u0 += 4) {
+            lds_char* ab[2];
+            int pb[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int u = u0 + hh * 2 + (g >> 1);
+                const bool valid = u < units;
+                const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
+                const int pixA = valid ? r * OWp + ow0 : R * OWp;      // idle runs read the permanent zero pixels
+                ab[hh] = dyimg + (pixA + px) * C::DYS + ccol + h * CTH * 32;
+                pb[hh] = ((r * S) * IW + (ow0 + px) * S) * C::XS + ccol;
+            }
+            auto bfrag = [&](int j) {
+                const int nt = nt0 + j;
+                const int tap = nt / C::CGN, cg = nt % C::CGN;
+                const int kh = tap / KW, kw = tap % KW;
+                const int toff = (kh * IW + kw) * C::XS + cg * 32;
+                return tr_read8(ximg + pb[0] + toff, ximg + pb[1] + toff);
+            };
+            // B fragments run D n-tiles ahead of their MFMAs; A fragments first
+            constexpr int D = 3;
+            bf16x8_t ring[D];
+            bf16x8_t af[CTH];
+#pragma unroll
+            for (int c = 0; c < CTH; ++c) af[c] = tr_read8(ab[0] + c * 32, ab[1] + c * 32);
+#pragma unroll
+            for (int j = 0; j < D && j < C::NTW; ++j) ring[j] = bfrag(j);
+            __builtin_amdgcn_sched_barrier(0);          // keep the reads this far ahead: the scheduler otherwise sinks them next to their use
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j) {
+                const bf16x8_t bf = ring[j % D];
+#pragma unroll
+                for (int c = 0; c < CTH; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                if (j + D < C::NTW) ring[j % D] = bfrag(j + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    constexpr int KC = KH * KW * CI;
+    float* out = part + (long long)blockIdx.x * CO * KC;
+    if (!(dbg & 4) || acc[0][0][0] == 12345.678f)
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < CTH; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int t = cgrp; t < NTH; t += CHY) s += red[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, s);
+    }
+}
+
 template <int CI, int CO, int KH, int KW, int S>
 static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                        int OW, int max_blocks) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
+    static const bool v1 = getenv("HULC_WGRAD_V1") != nullptr;
+    constexpr int NWV = 8;                                   // 16 waves (one co-tile each, 4 waves per SIMD) measured slower: 0.43 vs 0.40 ms/step
+    if (!v1) {
+        // fewest balanced bands whose chunks fit the 16 x 512 prefetch slots and whose images fit in 160 KB (16 KB kept for the bias reduction)
+        for (int nb = 1; nb <= OH; ++nb) {
+            const int R = (OH + nb - 1) / nb, XR = (R - 1) * S + KH;
+            const long long chunks = (long long)R * OW * (CO / 8) + (long long)XR * IW * (CI / 8);
+            const size_t lds = std::max<size_t>(C::lds_bytes(R, IW, OW), NWV * 64 * 8 * sizeof(float));
+            if (chunks > 16 * 512 || lds > 160 * 1024 || (long long)XR * IW * CI >= (1 << 20)) continue;
+            static bool attr8 = false;
+            if (!attr8) {
+                hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr8 = true;
+            }
+            const int items = Nf * nb;
+            const int grid = std::min(std::min(items, 256), max_blocks);
+            static const int dbg = getenv("HULC_WGRAD_DBG") ? atoi(getenv("HULC_WGRAD_DBG")) : 0;   // bench ablation only
+            hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg);
+            return grid;
+        }
+    }
     int R = OH;                                              // largest band that keeps two workgroups per CU (<= 78 KB)
     while (R > 1 && C::lds_bytes(R, IW, OW) > 78 * 1024) --R;
+    const int nbands = (OH + R - 1) / R;
+    R = (OH + nbands - 1) / nbands;                          // balanced (no short tail band)
     const size_t lds = C::lds_bytes(R, IW, OW);
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,8 +493,11 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
 
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks) {
+    static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
+    static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
+    if (env_wg > 0) max_blocks = env_wg;
     int R = OH;
-    while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW) > 78 * 1024) --R;
+    while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW) > (size_t)lds_kb * 1024) --R;
     const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW);
     static bool attr_set = false;
     if (!attr_set) {

@@ -381,6 +381,8 @@ struct Engine : IEngine {
     }
     // dense NT GEMM with tile selection
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+        static const bool trace = getenv("HULC_TRACE_GEMM") != nullptr;
+        if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%lld ldb=%lld f32out=%d acc=%d atomic=%d\n", M, N, K, a.s1, b.s1, ep.out_f32, ep.accumulate, ep.atomic);
         const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
@@ -554,7 +556,7 @@ struct Engine : IEngine {
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
                           conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * 4 + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
-                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024);
             else if (!conv1 && c.I == 64 && c.KH == 3)
                 nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 32 && c.KH == 4)
