@@ -245,9 +245,10 @@ struct Engine : IEngine {
         if (!L.Wt) L.Wt = alloc<T>((int64_t)N * K);
         add_tr(L.W32, L.W, L.Wt, N, K);
     }
+    static constexpr int TRT = std::is_same<T, float>::value ? 32 : 64;     // transpose tile (bf16: 64x64, 16-byte accesses)
     void add_tr(const float* w32, const T* w, T* wt, int R, int C) {
         TrDesc d; d.src = std::is_same<T, float>::value ? (const void*)w32 : (const void*)w; d.dst = wt; d.lds = C; d.ldt = R; d.R = R; d.C = C;
-        d.tiles_x = cdiv(C, 32); d.blk0 = tr_blocks; tr_blocks += d.tiles_x * cdiv(R, 32);
+        d.tiles_x = cdiv(C, TRT); d.blk0 = tr_blocks; tr_blocks += d.tiles_x * cdiv(R, TRT);
         trdesc.push_back(d);
     }
     void bind_conv(ConvW& c, const std::string& name, int O, int I, int K, int S, int nhwc) {
@@ -352,10 +353,12 @@ struct Engine : IEngine {
     // dstA[c][r] = srcA[r][c] and dstB likewise, one launch
     void transpose_pair(const T* a, long long lda, T* at, int Ra, int Ca, const T* b, long long ldb, T* bt, int Rb, int Cb, long long ldt) {
         TrPair p;
-        p.d[0].src = a; p.d[0].dst = at; p.d[0].lds = lda; p.d[0].ldt = ldt; p.d[0].R = Ra; p.d[0].C = Ca; p.d[0].tiles_x = cdiv(Ca, 32); p.d[0].blk0 = 0;
-        const int n0 = p.d[0].tiles_x * cdiv(Ra, 32);
-        p.d[1].src = b; p.d[1].dst = bt; p.d[1].lds = ldb; p.d[1].ldt = ldt; p.d[1].R = Rb; p.d[1].C = Cb; p.d[1].tiles_x = cdiv(Cb, 32); p.d[1].blk0 = n0;
-        hipLaunchKernelGGL((pair_transpose_kernel<T>), dim3(n0 + p.d[1].tiles_x * cdiv(Rb, 32)), dim3(256), 0, st, p);
+        p.d[0].src = a; p.d[0].dst = at; p.d[0].lds = lda; p.d[0].ldt = ldt; p.d[0].R = Ra; p.d[0].C = Ca; p.d[0].tiles_x = cdiv(Ca, TRT); p.d[0].blk0 = 0;
+        const int n0 = p.d[0].tiles_x * cdiv(Ra, TRT);
+        p.d[1].src = b; p.d[1].dst = bt; p.d[1].lds = ldb; p.d[1].ldt = ldt; p.d[1].R = Rb; p.d[1].C = Cb; p.d[1].tiles_x = cdiv(Cb, TRT); p.d[1].blk0 = n0;
+        const dim3 grid(n0 + p.d[1].tiles_x * cdiv(Rb, TRT));
+        if constexpr (std::is_same<T, float>::value) hipLaunchKernelGGL((pair_transpose_kernel<T>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(pair_transpose64_kernel, grid, dim3(256), 0, st, p);
     }
     template <typename TS, typename TD>
     void copy2d(const TS* src, long long lds_, TD* dst, long long ldd, int R, int C, int acc, float scale = 1.f) {
@@ -472,7 +475,7 @@ struct Engine : IEngine {
             if (!shadow_fresh) hipLaunchKernelGGL((cast_kernel<float, T>), dim3(2048), dim3(256), 0, st, P, wshadow, (long long)numel);
         }
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
-        else hipLaunchKernelGGL((batched_transpose_kernel<T, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         for (EncW* e : {&encS, &encG}) {
             prep_conv(e->c1); prep_conv(e->c2); prep_conv(e->c3);
             if (e->gripper) {
