@@ -351,8 +351,10 @@ struct Engine : IEngine {
     }
     static int ldpad(int m) { return (m + 7) / 8 * 8; }
     // dstA[c][r] = srcA[r][c] and dstB likewise, one launch
-    void transpose_pair(const T* a, long long lda, T* at, int Ra, int Ca, const T* b, long long ldb, T* bt, int Rb, int Cb, long long ldt) {
+    void transpose_pair(const T* a, long long lda, T* at, int Ra, int Ca, const T* b, long long ldb, T* bt, int Rb, int Cb, long long ldt,
+                        float* cs = nullptr, float* cs2 = nullptr) {
         TrPair p;
+        p.d[0].cs = cs; p.d[0].cs2 = cs2;
         p.d[0].src = a; p.d[0].dst = at; p.d[0].lds = lda; p.d[0].ldt = ldt; p.d[0].R = Ra; p.d[0].C = Ca; p.d[0].tiles_x = cdiv(Ca, TRT); p.d[0].blk0 = 0;
         const int n0 = p.d[0].tiles_x * cdiv(Ra, TRT);
         p.d[1].src = b; p.d[1].dst = bt; p.d[1].lds = ldb; p.d[1].ldt = ldt; p.d[1].R = Rb; p.d[1].C = Cb; p.d[1].tiles_x = cdiv(Cb, TRT); p.d[1].blk0 = n0;
@@ -440,9 +442,10 @@ struct Engine : IEngine {
             }
         }
         const int mp = ldpad(M);
-        transpose_pair(dY, N, tA, M, N, X, ldx, tB, M, K, mp);
+        constexpr bool fuse_cs = std::is_same<T, bf16_t>::value;     // bf16 (bench) mode: the dY transpose also adds its column sums into db (atomics)
+        transpose_pair(dY, N, tA, M, N, X, ldx, tB, M, K, mp, fuse_cs ? db : nullptr, fuse_cs ? db2 : nullptr);
         gemm_wgrad(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dW, lddw, N, K, M);
-        if (db) colsum(dY, N, M, N, db, db2);
+        if (db && !fuse_cs) colsum(dY, N, M, N, db, db2);
     }
     // dX[M][K] = dY[M][N] W   (via the transposed copy Wt [K][N])
     void lin_dgrad(const T* dY, int M, const LinW& L, EpiP ep, const DenseOut& om) {
@@ -539,7 +542,8 @@ struct Engine : IEngine {
         }
         const T* fin; int fk;
         if (!e.gripper) {
-            hipLaunchKernelGGL((spatial_softmax_fwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, 64, a.ss, (float*)nullptr, a.ssstats);
+            if constexpr (std::is_same<T, bf16_t>::value) hipLaunchKernelGGL(spatial_softmax_fwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, a.ss, a.ssstats);
+            else hipLaunchKernelGGL((spatial_softmax_fwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, 64, a.ss, (float*)nullptr, a.ssstats);
             fin = a.ss; fk = 128;
         } else {
             EpiP ep = epi(a.g0, false); ep.relu = 1;
@@ -634,7 +638,8 @@ struct Engine : IEngine {
         if (!e.gripper) {
             { EpiP ep = epi(d_ss, true); lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
             lin_wgrad(d_f1, a.ss, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
-            hipLaunchKernelGGL((spatial_softmax_bwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, 64, dact3);
+            if constexpr (std::is_same<T, bf16_t>::value) hipLaunchKernelGGL(spatial_softmax_bwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, dact3);
+            else hipLaunchKernelGGL((spatial_softmax_bwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, 64, dact3);
         } else {
             { EpiP ep = epi(d_g0, false); ep.mask = a.g0; lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
             lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);

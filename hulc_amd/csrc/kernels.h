@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const TS* __restric
 }
 
 // many transposes in one launch: block b belongs to descriptor d with blk0[d] <= b < blk0[d+1]; dstT[c][r] = src[r][c]
-struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, tiles_x; };
+struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, tiles_x; float* cs = nullptr; float* cs2 = nullptr; };   // cs: optional column sums of src (bias gradient), bf16 64x64 path only, atomics
 template <typename TS, typename TD>
 __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __restrict__ desc, int ndesc) {
     __shared__ float tile[32][33];
@@ -81,6 +81,13 @@ DEVI void transpose_tile64_bf16(const TrDesc& D, int b, unsigned short (*tile)[6
         for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(&tile[row][cc + 2 * e]) = (unsigned)v[2 * e] | ((unsigned)v[2 * e + 1] << 16);
     }
     __syncthreads();
+    if (D.cs && threadIdx.x < 64 && c0 + (int)threadIdx.x < D.C) {      // fused bias gradient: column sums of this tile (pad rows are zeros)
+        float sum = 0.f;
+#pragma unroll 16
+        for (int rr = 0; rr < 64; ++rr) sum += bf2f(tile[rr][threadIdx.x]);
+        unsafeAtomicAdd(D.cs + c0 + threadIdx.x, sum);
+        if (D.cs2) unsafeAtomicAdd(D.cs2 + c0 + threadIdx.x, sum);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = threadIdx.x + i * 256, orow = q >> 3, oc = (q & 7) * 8;
@@ -363,6 +370,103 @@ __global__ void __launch_bounds__(256) spatial_softmax_bwd_kernel(const T* __res
         const float p = __expf(v - M) * inv;
         const float g = (v > 0.f) ? p * (dex * (lx - ex) + dey * (ly - ey)) : 0.f;
         df[base + (long long)q * C] = from_f<T>(g);
+    }
+}
+
+// bf16, C = 64 versions: a thread owns 8 channels (one 16-byte load per pixel) of every 32nd pixel, so a frame is 14 wide
+// iterations instead of 110 two-byte ones; the forward keeps 8 online-softmax states per thread and merges the 32 pixel groups in LDS.
+__global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const bf16_t* __restrict__ f, int H, int W, bf16_t* __restrict__ out,
+                                                                    float* __restrict__ stats /*[N][64][4]*/) {
+    __shared__ float sm[32][65], ss[32][65], sx[32][65], sy[32][65];
+    const int n = blockIdx.x, cg = threadIdx.x & 7, pg = threadIdx.x >> 3;
+    const int HW = H * W;
+    const bf16_t* p = f + (long long)n * HW * 64 + cg * 8;
+    float m[8], s[8], ax[8], ay[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; s[e] = 0.f; ax[e] = 0.f; ay[e] = 0.f; }
+    const float sh = 2.f / (H - 1), sw = 2.f / (W - 1);
+    for (int q0 = pg; q0 < HW; q0 += 64) {
+        uint4 raw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) raw[u] = *reinterpret_cast<const uint4*>(p + (long long)min(q0 + u * 32, HW - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * 32;
+            if (q >= HW) break;
+            const int h = q / W, w = q - h * W;
+            const float lx = -1.f + sh * h, ly = -1.f + sw * w;
+            const unsigned wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = __uint_as_float((e & 1) ? (wd[e >> 1] & 0xffff0000u) : (wd[e >> 1] << 16));
+                if (v > m[e]) {
+                    const float sc = __expf(m[e] - v);
+                    s[e] *= sc; ax[e] *= sc; ay[e] *= sc;
+                    m[e] = v;
+                }
+                const float ex = __expf(v - m[e]);
+                s[e] += ex; ax[e] += ex * lx; ay[e] += ex * ly;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[pg][cg * 8 + e] = m[e]; ss[pg][cg * 8 + e] = s[e]; sx[pg][cg * 8 + e] = ax[e]; sy[pg][cg * 8 + e] = ay[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        float M = -INFINITY;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) M = fmaxf(M, sm[k][c]);
+        float S = 0.f, X = 0.f, Y = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float sc = (sm[k][c] == -INFINITY) ? 0.f : __expf(sm[k][c] - M);
+            S += ss[k][c] * sc; X += sx[k][c] * sc; Y += sy[k][c] * sc;
+        }
+        const float inv = 1.f / S;
+        const float ex = X * inv, ey = Y * inv;
+        const long long o = (long long)n * 128 + 2 * c;
+        out[o] = f2bf(ex); out[o + 1] = f2bf(ey);
+        float* st = stats + ((long long)n * 64 + c) * 4;
+        st[0] = M; st[1] = inv; st[2] = ex; st[3] = ey;
+    }
+}
+__global__ void __launch_bounds__(256) spatial_softmax_bwd64_kernel(const bf16_t* __restrict__ f, const float* __restrict__ stats,
+                                                                    const float* __restrict__ dout /*[N][128] fp32*/, int H, int W, bf16_t* __restrict__ df) {
+    const int n = blockIdx.x, cg = threadIdx.x & 7, pg = threadIdx.x >> 3;
+    const int HW = H * W;
+    float M[8], inv[8], ex[8], ey[8], dex[8], dey[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float4 st = *reinterpret_cast<const float4*>(stats + ((long long)n * 64 + cg * 8 + e) * 4);
+        M[e] = st.x; inv[e] = st.y; ex[e] = st.z; ey[e] = st.w;
+        const float2 d = *reinterpret_cast<const float2*>(dout + (long long)n * 128 + 2 * (cg * 8 + e));
+        dex[e] = d.x; dey[e] = d.y;
+    }
+    const float sh = 2.f / (H - 1), sw = 2.f / (W - 1);
+    const long long base = (long long)n * HW * 64 + cg * 8;
+    for (int q0 = pg; q0 < HW; q0 += 64) {
+        uint4 raw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) raw[u] = *reinterpret_cast<const uint4*>(f + base + (long long)min(q0 + u * 32, HW - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * 32;
+            if (q >= HW) break;
+            const int h = q / W, w = q - h * W;
+            const float lx = -1.f + sh * h, ly = -1.f + sw * w;
+            const unsigned wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = __uint_as_float((e & 1) ? (wd[e >> 1] & 0xffff0000u) : (wd[e >> 1] << 16));
+                const float pr = __expf(v - M[e]) * inv[e];
+                g[e] = (v > 0.f) ? pr * (dex[e] * (lx - ex[e]) + dey[e] * (ly - ey[e])) : 0.f;
+            }
+            uint4 o;
+            o.x = pack2bf(g[0], g[1]); o.y = pack2bf(g[2], g[3]); o.z = pack2bf(g[4], g[5]); o.w = pack2bf(g[6], g[7]);
+            *reinterpret_cast<uint4*>(df + base + (long long)q * 64) = o;
+        }
     }
 }
 
