@@ -343,6 +343,11 @@ struct Engine : IEngine {
         return prepare_weights();
     }
 
+    HeadPack head_pack() const {
+        HeadPack hp;
+        for (int i = 0; i < 4; ++i) { hp.w[i] = head_w32[i]; hp.b[i] = head_b32[i]; hp.dw[i] = head_dw[i]; hp.db[i] = head_db[i]; hp.rows[i] = head_rows[i]; }
+        return hp;
+    }
     // ---------------------------------------------------------------- small launch helpers
     template <typename TS, typename TD>
     void cast_tr(const TS* src, long long lds_, TD* dst, long long ldd, TD* dstT, long long ldt, int R, int C) {
@@ -459,7 +464,11 @@ struct Engine : IEngine {
                 long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db) {
         hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt);
         const int nsplit = std::max(1, std::min(64, cdiv(rows, 64)));
-        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64), nsplit), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, cdiv(rows, nsplit), cspart);
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64), nsplit), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, cdiv(rows, nsplit), cspart, dg, db);
+            return;
+        }
+        hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64), nsplit), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, cdiv(rows, nsplit), cspart, (float*)nullptr, (float*)nullptr);
         hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, cspart, nsplit, n, dg, (float*)nullptr, 1.f);
         hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, cspart + (long long)nsplit * n, nsplit, n, db, (float*)nullptr, 1.f);
     }
@@ -488,11 +497,10 @@ struct Engine : IEngine {
             }
         }
         // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
-        int r0 = 0;
-        for (int i = 0; i < 4; ++i) {
-            copy2d<float, T>(head_w32[i], HID, wheads + (int64_t)r0 * HID, HID, head_rows[i], HID, 0);
-            copy2d<float, float>(head_b32[i], 1, bheads + r0, 1, head_rows[i], 1, 0);
-            r0 += head_rows[i];
+        {
+            const HeadPack hp = head_pack();
+            const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
+            hipLaunchKernelGGL((pack_heads_kernel<T>), dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, wheads, bheads, HID);
         }
         cast_tr<T, T>(wheads, HID, nullptr, 0, wheadsT, NHEAD, NHEAD, HID);
         STAGE("prepare_weights");
@@ -860,11 +868,10 @@ struct Engine : IEngine {
             // heads
             { EpiP ep = epi(dH1, false); gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
             lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
-            int r0 = 0;
-            for (int i = 0; i < 4; ++i) {
-                copy2d<float, float>(dwheads_tmp + (int64_t)r0 * HID, HID, head_dw[i], HID, head_rows[i], HID, 1);
-                copy2d<float, float>(dbheads_tmp + r0, 1, head_db[i], 1, head_rows[i], 1, 1);
-                r0 += head_rows[i];
+            {
+                const HeadPack hp = head_pack();
+                const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
+                hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, dwheads_tmp, dbheads_tmp, HID);
             }
             // layer 1 BPTT
             rnn_bwd(dH1, H1, dZ1, whh1, B, S);

@@ -470,6 +470,33 @@ __global__ void __launch_bounds__(256) spatial_softmax_bwd64_kernel(const bf16_t
     }
 }
 
+// the four decoder heads (prob | mean | log_scale | gripper) as one packed [NHEAD][HID] GEMM operand: ONE launch packs weights
+// + biases, ONE launch adds the packed gradient back into the four parameter gradients (was 8 + 8 copy2d launches per step)
+struct HeadPack { const float* w[4]; const float* b[4]; float* dw[4]; float* db[4]; int rows[4]; };
+template <typename T>
+__global__ void pack_heads_kernel(HeadPack hp, T* __restrict__ wheads, float* __restrict__ bheads, int HID) {
+    const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)total_rows * HID) return;
+    int r = (int)(idx / HID);
+    const int k = (int)(idx % HID);
+    int i = 0;
+    while (i < 3 && r >= hp.rows[i]) { r -= hp.rows[i]; ++i; }
+    wheads[idx] = from_f<T>(hp.w[i][(long long)r * HID + k]);
+    if (k == 0) bheads[idx / HID] = hp.b[i][r];
+}
+__global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ dw, const float* __restrict__ db, int HID) {
+    const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)total_rows * HID) return;
+    int r = (int)(idx / HID);
+    const int k = (int)(idx % HID);
+    int i = 0;
+    while (i < 3 && r >= hp.rows[i]) { r -= hp.rows[i]; ++i; }
+    hp.dw[i][(long long)r * HID + k] += dw[idx];
+    if (k == 0) hp.db[i][r] += db[idx / HID];
+}
+
 // =========================================================================================================
 // LayerNorm over the last dim n (32/64/128), one wave per row; biased variance, eps 1e-5
 // =========================================================================================================
@@ -528,7 +555,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 // partial sums for dgamma[c] = sum_r dy*xhat and dbeta[c] = sum_r dy over a row chunk (grid.y); part = [2][nsplit][n]
 __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                                    long long ldx, const float* __restrict__ stats, int rows, int n,
-                                                                   int rows_per_split, float* __restrict__ part) {
+                                                                   int rows_per_split, float* __restrict__ part,
+                                                                   float* __restrict__ dg_atomic = nullptr, float* __restrict__ db_atomic = nullptr) {
     __shared__ float r1[4][64], r2[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int rbeg = blockIdx.y * rows_per_split, rend = min(rows, rbeg + rows_per_split);
@@ -543,8 +571,13 @@ __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* 
     __syncthreads();
     if (rl == 0 && c < n) {
         const int t = threadIdx.x;
-        part[(long long)blockIdx.y * n + c] = (r1[0][t] + r1[1][t]) + (r1[2][t] + r1[3][t]);
-        part[((long long)gridDim.y + blockIdx.y) * n + c] = (r2[0][t] + r2[1][t]) + (r2[2][t] + r2[3][t]);
+        const float sa = (r1[0][t] + r1[1][t]) + (r1[2][t] + r1[3][t]), sb = (r2[0][t] + r2[1][t]) + (r2[2][t] + r2[3][t]);
+        if (dg_atomic) {                                            // bf16 (bench) mode: no second stage
+            unsafeAtomicAdd(dg_atomic + c, sa); unsafeAtomicAdd(db_atomic + c, sb);
+        } else {
+            part[(long long)blockIdx.y * n + c] = sa;
+            part[((long long)gridDim.y + blockIdx.y) * n + c] = sb;
+        }
     }
 }
 
