@@ -850,6 +850,9 @@ static inline void launch_skinny(hipStream_t st, const bf16_t* A, long long lda,
 }
 static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, const void* A, const void* W) {
     // many-row use: every 64-row block of A is re-read by each of the N/16 column workgroups -> only when M*N is small
-    const bool shape = M <= 64 || (K >= 512 && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
+    // (short K: the skinny kernel is shorter per launch at M = 2048, N = 128, K = 128..512 (5 vs 12 us in rocprof) but the step got
+    //  0.03 ms SLOWER in an A/B on one box — kept off)
+    static const bool shortk = getenv("HULC_SKINNY_SHORTK") ? atoi(getenv("HULC_SKINNY_SHORTK")) != 0 : false;
+    const bool shape = M <= 64 || ((shortk || K >= 512) && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
     return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }
