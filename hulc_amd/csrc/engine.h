@@ -811,7 +811,7 @@ struct Engine : IEngine {
     void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S) {
         const long long BH = (long long)B * HID;
         hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
-        TimerScope ts(this, "skinny_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
+        TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int t = 1; t < S; ++t) {
             EpiP ep = epi(H + t * BH, false); ep.res = Zx + t * BH; ep.res_ld = HID; ep.relu = 1;
             gemm(dense<T>(H + (t - 1) * BH, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
@@ -821,7 +821,7 @@ struct Engine : IEngine {
     void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S) {
         const long long BH = (long long)B * HID;
         hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH + (S - 1) * BH, H + (S - 1) * BH, dZ + (S - 1) * BH, BH);
-        TimerScope ts(this, "skinny_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
+        TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int t = S - 2; t >= 0; --t) {
             EpiP ep = epi(dZ + t * BH, false); ep.res = dH + t * BH; ep.res_ld = HID; ep.mask = H + t * BH;
             gemm(dense<T>(dZ + (t + 1) * BH, B, HID), dense<T>(whh.Wt, HID, HID), dense_out(HID), ep, B, HID, HID);

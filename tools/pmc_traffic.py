@@ -1,0 +1,38 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as MI355X_MICROARCH.md §HBM prescribes:
+bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950 FETCH_SIZE reports half of a wide coalesced read; both
+counters are in KiB).  Writes <dir>/pmc_hbm_per_kernel.csv and <dir>/pmc_traffic.json (class -> bytes per launch)."""
+import collections, csv, glob, json, sys
+
+d = sys.argv[1]
+CLASSES = [("rnn_step_gemm", ("skinny_lds_kernel<2, 8>",)), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
+           ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
+           ("conv_tile_fwd", ("1, 1, false>(ConvTileP)", "2, 1, false>(ConvTileP)")), ("conv_tile_dgrad", ("true>(ConvTileP)",)), ("adam", ("adam_kernel",))]
+per = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"{d}/pmc_{name}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != name:
+            continue
+        k = r["Kernel_Name"]
+        agg[k][0] += float(r["Counter_Value"]); agg[k][1].add(r["Dispatch_Id"])
+    per[name] = {k: (v[0], len(v[1])) for k, v in agg.items()}
+rows = []
+for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+    f, nf = per["FETCH_SIZE"].get(k, (0.0, 1)); w, nw = per["WRITE_SIZE"].get(k, (0.0, 1))
+    rows.append((k, nf, f / max(nf, 1), w / max(nw, 1), (2 * f / max(nf, 1) + w / max(nw, 1)) * 1024))
+with open(f"{d}/pmc_hbm_per_kernel.csv", "w") as fo:
+    wr = csv.writer(fo); wr.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_per_dispatch", "WRITE_SIZE_KiB_per_dispatch", "hbm_bytes_per_dispatch_corrected"])
+    for r in sorted(rows, key=lambda r: -r[4] * r[1]):
+        wr.writerow([r[0][:160], r[1], round(r[2], 1), round(r[3], 1), int(r[4])])
+traffic = {}
+for cls, pats in CLASSES:
+    tot = 0.0; n = 0
+    for r in rows:
+        if any(p in r[0] for p in pats):
+            tot += r[4] * r[1]; n += r[1]
+    if n:
+        traffic[cls] = int(tot / n)
+json.dump(traffic, open(f"{d}/pmc_traffic.json", "w"), indent=1)
+for k, v in traffic.items():
+    print(f"{k:18s} {v / 1e6:10.2f} MB per launch")
