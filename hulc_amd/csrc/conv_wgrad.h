@@ -517,54 +517,69 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __restrict__ dY, long long ldy, const bf16_t* __restrict__ X, long long ldx,
                                                              int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
-                                                             float* __restrict__ db2) {
+                                                             float* __restrict__ db2, int mchunk) {
+    // Large M (token-major transformer / encoder layers): blockIdx.z owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
+    // time and adds its partial with fp32 atomics — replaces "transpose dY, transpose X, split-K NT GEMM, column-sum" (4 launches).
     constexpr int TN = 64, TK = 128, YS = TN * 2 + 16, XS = TK * 2 + 16;
     __shared__ __attribute__((aligned(16))) char smem[64 * YS + 64 * XS];
     lds_char* yimg = (lds_char*)smem;
     lds_char* ximg = yimg + 64 * YS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
-    // stage dY[0:64][n0:n0+64] and X[0:64][k0:k0+128] (rows >= M and columns past the edge -> zeros)
-    for (int i = tid; i < 64 * (TN / 8); i += 256) {
-        const int m = i / (TN / 8), c = i % (TN / 8);
-        bf16_t v[8];
-        if (m < M && n0 + c * 8 < N) load8_guard<bf16_t>(dY + (long long)m * ldy + n0 + c * 8, N - (n0 + c * 8), v);
-        else zero8<bf16_t>(v);
-        *(lds_u32x4*)(yimg + m * YS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
-    }
-    for (int i = tid; i < 64 * (TK / 8); i += 256) {
-        const int m = i / (TK / 8), c = i % (TK / 8);
-        bf16_t v[8];
-        if (m < M && k0 + c * 8 < K) load8_guard<bf16_t>(X + (long long)m * ldx + k0 + c * 8, K - (k0 + c * 8), v);
-        else zero8<bf16_t>(v);
-        *(lds_u32x4*)(ximg + m * XS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
-    }
-    __syncthreads();
+    const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
     const int g = lane >> 4, a = lane & 15;
     const int prow = a >> 2, ccol = (a & 3) * 8;
     // wave w: n-tile w (16 columns of dY) x 8 k-tiles
     f32x4 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int m0 = mbeg; m0 < mend; m0 += 64) {
+        if (m0 > mbeg) __syncthreads();
+        // stage dY[m0:m0+64][n0:n0+64] and X[m0:m0+64][k0:k0+128] (rows >= mend and columns past the edge -> zeros)
+        for (int i = tid; i < 64 * (TN / 8); i += 256) {
+            const int m = i / (TN / 8), c = i % (TN / 8);
+            bf16_t v[8];
+            if (m0 + m < mend && n0 + c * 8 < N) load8_guard<bf16_t>(dY + (long long)(m0 + m) * ldy + n0 + c * 8, N - (n0 + c * 8), v);
+            else zero8<bf16_t>(v);
+            *(lds_u32x4*)(yimg + m * YS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+        }
+        for (int i = tid; i < 64 * (TK / 8); i += 256) {
+            const int m = i / (TK / 8), c = i % (TK / 8);
+            bf16_t v[8];
+            if (m0 + m < mend && k0 + c * 8 < K) load8_guard<bf16_t>(X + (long long)(m0 + m) * ldx + k0 + c * 8, K - (k0 + c * 8), v);
+            else zero8<bf16_t>(v);
+            *(lds_u32x4*)(ximg + m * XS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {                        // reduction over m: 2 x 32
-        const int mrow = ms * 32 + g * 8 + prow;
-        lds_char* yb = yimg + mrow * YS + wave * 32 + ccol;
-        const bf16x8_t yf = tr_read8(yb, yb + 4 * YS);
+        for (int ms = 0; ms < 2; ++ms) {                        // reduction over m: 2 x 32
+            const int mrow = ms * 32 + g * 8 + prow;
+            lds_char* yb = yimg + mrow * YS + wave * 32 + ccol;
+            const bf16x8_t yf = tr_read8(yb, yb + 4 * YS);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            lds_char* xb = ximg + mrow * XS + j * 32 + ccol;
-            const bf16x8_t xf = tr_read8(xb, xb + 4 * XS);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
+            for (int j = 0; j < 8; ++j) {
+                lds_char* xb = ximg + mrow * XS + j * 32 + ccol;
+                const bf16x8_t xf = tr_read8(xb, xb + 4 * XS);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
+            }
+        }
+        if (db && blockIdx.y == 0 && tid < TN) {
+            for (int m = 0; m < 64; ++m) bsum += bf2f(*(__attribute__((address_space(3))) bf16_t*)(yimg + m * YS + tid * 2));
         }
     }
+    const bool atomic = gridDim.z > 1;
     const int n = n0 + wave * 16 + a;
     if (n < N) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + j * 16 + g * 4;
             float* p = dW + (long long)n * lddw + k;
-            if (k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+            if (atomic) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k + r < K) unsafeAtomicAdd(p + r, acc[j][r]);
+            } else if (k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
                 float4 o = *reinterpret_cast<float4*>(p);
                 o.x += acc[j][0]; o.y += acc[j][1]; o.z += acc[j][2]; o.w += acc[j][3];
                 *reinterpret_cast<float4*>(p) = o;
@@ -576,9 +591,7 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
         }
     }
     if (db && blockIdx.y == 0 && tid < TN && n0 + tid < N) {
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s += bf2f(*(__attribute__((address_space(3))) bf16_t*)(yimg + m * YS + tid * 2));
-        db[n0 + tid] += s;
-        if (db2) db2[n0 + tid] += s;
+        if (atomic) { unsafeAtomicAdd(db + n0 + tid, bsum); if (db2) unsafeAtomicAdd(db2 + n0 + tid, bsum); }
+        else { db[n0 + tid] += bsum; if (db2) db2[n0 + tid] += bsum; }
     }
 }

@@ -442,7 +442,17 @@ struct Engine : IEngine {
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
         if constexpr (std::is_same<T, bf16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
-                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2);
+                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
+                return;
+            }
+            static const bool fused_largem = getenv("HULC_LINBWD_LARGEM") ? atoi(getenv("HULC_LINBWD_LARGEM")) != 0 : false;   // measured 0.25 ms/step SLOWER than transposes + NT GEMM (A/B, same box): off
+            if (fused_largem && (long long)N * K <= 2048ll * 512) {
+                // token-major layers (M = B*S): the same kernel, rows split over blockIdx.z (~256 workgroups), partials by atomics
+                const int tiles = cdiv(N, 64) * cdiv(K, 128);
+                const int z = std::max(1, std::min(cdiv(M, 64), cdiv(256, tiles)));
+                const int mchunk = cdiv(cdiv(M, z), 64) * 64;
+                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128), cdiv(M, mchunk)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw,
+                                   db, db2, mchunk);
                 return;
             }
         }
