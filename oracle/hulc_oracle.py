@@ -378,22 +378,26 @@ def world_to_tcp_frame(action, robot_obs):
     return np.concatenate([pos, orn, act[..., -1:]], -1).astype(F32)
 
 
-def rnn_fwd(P, pre, x):
-    """utils/rnn.py:5-14 : 2-layer ReLU nn.RNN, batch_first, h0 = 0."""
+def rnn_fwd(P, pre, x, h0=None):
+    """utils/rnn.py:5-14 : 2-layer ReLU nn.RNN, batch_first; h0 = 0 unless given as (2, B, H) (stateful rollout,
+    logistic_decoder_rnn.py:107-111).  The cache carries the final hidden state as c["h_n"]."""
     B, S, _ = x.shape
     c = {"x": x}
     inp = x
+    hn = []
     for l in range(2):
         wih, whh = P[f"{pre}weight_ih_l{l}"], P[f"{pre}weight_hh_l{l}"]
         b = P[f"{pre}bias_ih_l{l}"] + P[f"{pre}bias_hh_l{l}"]
         zx = (inp.reshape(B * S, -1) @ wih.T + b).reshape(B, S, -1)
         H = np.zeros((B, S, whh.shape[0]), F32)
-        h = np.zeros((B, whh.shape[0]), F32)
+        h = np.zeros((B, whh.shape[0]), F32) if h0 is None else h0[l].astype(F32)
         for t in range(S):
             h = relu(zx[:, t] + h @ whh.T).astype(F32)
             H[:, t] = h
         c[f"H{l}"] = H
+        hn.append(h)
         inp = H
+    c["h_n"] = np.stack(hn, 0)
     return inp, c
 
 
@@ -519,6 +523,145 @@ def decoder_loss_bwd(P, G, c, dims, scale):
 # ----------------------------------------------------------------------------------------------------
 # KL (hulc.py:539-561), straight-through sample (distributions.py:23-27), CLIP aux (hulc.py:650-695)
 # ----------------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# validation / rollout forward: forward-only, stochastic draws injected
+# ----------------------------------------------------------------------------------------------------
+def tcp_to_world_frame(action, robot_obs):
+    """gripper_control.py:39-63 (fp32); inverse(R(e)) == R(e)^T; the NaN fallback branch (:52-56) is not restated."""
+    act = action.astype(F32)
+    e = robot_obs[..., 3:6].astype(F32)
+    R = euler_xyz_to_matrix(e)
+    pos = (R @ act[..., :3, None])[..., 0]
+    Rrel = euler_xyz_to_matrix(act[..., 3:6] * F32(0.01))
+    M = R @ np.swapaxes(Rrel, -1, -2)
+    o0 = np.arctan2(-M[..., 1, 2], M[..., 2, 2])
+    o1 = np.arcsin(M[..., 0, 2])
+    o2 = np.arctan2(-M[..., 0, 1], M[..., 0, 0])
+    orn = np.stack([o0, o1, o2], -1).astype(F32) - e
+    orn = np.where(orn < -np.pi, orn + 2 * np.pi, orn)
+    orn = np.where(orn > np.pi, orn - 2 * np.pi, orn)
+    orn = (orn * 100).astype(F32)
+    return np.concatenate([pos, orn, act[..., -1:]], -1).astype(F32)
+
+
+def logistic_sample(logit_probs, log_scales_raw, means, gripper_logits, u_mix, u_act, log_scale_min=-7.0):
+    """logistic_decoder_rnn.py:234-258 (_sample).  u_mix (B,S,D,K) and u_act (B,S,D) are the two torch.rand draws in [0,1)
+    BEFORE the affine map to [1e-5, 1-1e-5] (:238-239, :250); gripper command = bounds[argmax] with bounds (-1, 1) (:59)."""
+    r1, r2 = F32(1e-5), F32(1.0 - 1e-5)
+    ls = np.maximum(log_scales_raw, F32(log_scale_min))           # forward() clamps before _sample sees them (:279)
+    t = ((r1 - r2) * u_mix.astype(F32) + r2).astype(F32)
+    g = logit_probs - np.log(-np.log(t))
+    k = g.argmax(-1)
+    sel_ls = np.take_along_axis(ls, k[..., None], -1)[..., 0]
+    sel_mu = np.take_along_axis(means, k[..., None], -1)[..., 0]
+    u = ((r1 - r2) * u_act.astype(F32) + r2).astype(F32)
+    act = (sel_mu + np.exp(sel_ls) * (np.log(u) - np.log(1.0 - u))).astype(F32)
+    grip = np.where(gripper_logits.argmax(-1) == 0, F32(-1.0), F32(1.0))
+    return np.concatenate([act, grip[..., None]], -1).astype(F32)
+
+
+def decoder_heads(P, plan, emb, goal, dims, h0=None):
+    """LogisticDecoderRNN.forward :260-287 -> (logit_probs, log_scales_raw, means, gripper_logits, h_n)."""
+    ad = "action_decoder."
+    B, S, _ = emb.shape
+    parts = []
+    if plan is not None and plan.shape[-1] > 0:
+        parts.append(np.repeat(plan[:, None, :], S, 1))
+    parts += [emb[..., 64:128], np.repeat(goal[:, None, :], S, 1)]
+    x = np.concatenate(parts, -1).astype(F32)
+    H1, rc = rnn_fwd(P, ad + "rnn.", x, h0)
+    h2 = H1.reshape(B * S, -1)
+    K, Dd = dims.n_mix, dims.act_dims
+    probs = linear(h2, P[ad + "prob_fc.weight"], P[ad + "prob_fc.bias"]).reshape(B, S, Dd, K)
+    means = linear(h2, P[ad + "mean_fc.weight"], P[ad + "mean_fc.bias"]).reshape(B, S, Dd, K)
+    lsr = linear(h2, P[ad + "log_scale_fc.weight"], P[ad + "log_scale_fc.bias"]).reshape(B, S, Dd, K)
+    grip = linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
+    return probs, lsr, means, grip, rc["h_n"]
+
+
+def encode(P, rgb_static, rgb_gripper):
+    """ConcatEncoders.forward (concat_encoders.py:59-109) on (B,S,3,H,W) frames -> (B,S,128)."""
+    B, S = rgb_static.shape[:2]
+    es, _ = static_encoder_fwd(P, "perceptual_encoder.rgb_static_encoder.", rgb_static.reshape((B * S,) + rgb_static.shape[2:]).astype(F32))
+    eg, _ = gripper_encoder_fwd(P, "perceptual_encoder.rgb_gripper_encoder.", rgb_gripper.reshape((B * S,) + rgb_gripper.shape[2:]).astype(F32))
+    return np.concatenate([es.reshape(B, S, -1), eg.reshape(B, S, -1)], -1).astype(F32)
+
+
+def goal_encode(P, emb_last_or_lang, is_lang):
+    names, ln = (LG_NAMES, "language_goal.ln") if is_lang else (VG_NAMES, "visual_goal.ln")
+    gpre, _ = mlp_fwd(P, names, emb_last_or_lang.astype(F32), False)
+    goal, _ = layer_norm(gpre, P[ln + ".weight"], P[ln + ".bias"])
+    return goal
+
+
+def onehot_plan(idx, dims):
+    B = idx.shape[0]
+    oh = np.zeros((B, dims.n_cat, dims.n_cls), F32)
+    np.put_along_axis(oh, idx[..., None].astype(np.int64), 1.0, -1)
+    return oh.reshape(B, -1)
+
+
+def validation_forward(P, dims, mb, is_lang, noise):
+    """Hulc.validation_step body for one modality (hulc.py:770-797) -> lmp_val (:301-388) + the logged reductions (:816-833).
+
+    noise: plan_idx_pp / plan_idx_pr (B, n_cat) — the categorical samples (distributions.py:37-41), u_mix_pp/u_act_pp and
+    u_mix_pr/u_act_pr — the torch.rand draws of the two _sample calls."""
+    B, S = mb["actions"].shape[:2]
+    emb = encode(P, mb["rgb_static"], mb["rgb_gripper"])
+    goal = goal_encode(P, mb["lang"] if is_lang else emb[:, -1], is_lang)
+    pp_logits, _ = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)
+    pr_logits, seq_feat, _ = plan_recognition_fwd(P, emb, dims.heads)
+    a_tcp = world_to_tcp_frame(mb["actions"], mb["robot_obs"])
+    out = {"seq_feat": seq_feat, "pp_logits": pp_logits, "pr_logits": pr_logits}
+    for tag in ("pp", "pr"):
+        plan = onehot_plan(noise[f"plan_idx_{tag}"], dims)
+        probs, lsr, means, grip, _ = decoder_heads(P, plan, emb, goal, dims)
+        loss, _ = logistic_loss(probs, lsr, means, grip, a_tcp, num_classes=dims.num_classes)
+        pred = logistic_sample(probs, lsr, means, grip, noise[f"u_mix_{tag}"], noise[f"u_act_{tag}"])
+        pred_w = tcp_to_world_frame(pred, mb["robot_obs"])
+        mae = np.abs(pred_w[..., :-1] - mb["actions"][..., :-1]).mean(1)          # (B, 6)  hulc.py:347-350
+        sr = F32((np.where(pred_w[..., -1] > 0, 1.0, -1.0) == mb["actions"][..., -1]).mean())
+        out.update({f"action_loss_{tag}": loss, f"mae_{tag}": mae.astype(F32), f"gripper_sr_{tag}": sr, f"pred_{tag}": pred_w})
+    out["kl_loss"], _, _ = kl_loss(pp_logits, pr_logits, dims)
+    return out
+
+
+class Rollout:
+    """Hulc.reset / step / get_pp_plan_vision / get_pp_plan_lang / predict_with_plan (hulc.py:843-957) + the stateful
+    LogisticDecoderRNN.act (logistic_decoder_rnn.py:102-116).  Draws are injected per call."""
+
+    def __init__(self, P, dims, replan_freq=30):
+        self.P, self.dims, self.replan_freq = P, dims, replan_freq
+        self.reset()
+
+    def reset(self):
+        self.plan = None
+        self.goal = None
+        self.h = None
+        self.counter = 0
+
+    def step(self, obs, goal, noise):
+        """obs: rgb_static (1,1,3,200,200), rgb_gripper (1,1,3,84,84), robot_obs_raw (1,1,15); goal: same two images (vision)
+        or a (1,384) language embedding; noise: plan_idx (1,n_cat) on replan steps, u_mix (1,1,6,10), u_act (1,1,6)."""
+        P, dims = self.P, self.dims
+        if self.counter % self.replan_freq == 0:
+            if isinstance(goal, dict):
+                emb = encode(P, np.concatenate([obs["rgb_static"], goal["rgb_static"]], 1), np.concatenate([obs["rgb_gripper"], goal["rgb_gripper"]], 1))
+                self.goal = goal_encode(P, emb[:, -1], False)
+            else:
+                emb = encode(P, obs["rgb_static"], obs["rgb_gripper"])
+                self.goal = goal_encode(P, goal, True)
+            pp_logits, _ = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], self.goal], -1), False)
+            self.pp_logits = pp_logits
+            self.plan = onehot_plan(noise["plan_idx"], dims)
+            self.h = None                                          # clear_hidden_state (hulc.py:925 / :946)
+        emb = encode(P, obs["rgb_static"], obs["rgb_gripper"])
+        probs, lsr, means, grip, self.h = decoder_heads(P, self.plan, emb, self.goal, dims, self.h)
+        pred = logistic_sample(probs, lsr, means, grip, noise["u_mix"], noise["u_act"])
+        self.counter += 1
+        return tcp_to_world_frame(pred, obs["robot_obs_raw"])
+
+
 def kl_loss(pp_logits, pr_logits, dims, beta=0.01, alpha=0.8):
     B = pp_logits.shape[0]
     a = log_softmax(pr_logits.reshape(B, dims.n_cat, dims.n_cls), -1)

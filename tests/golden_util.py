@@ -82,3 +82,27 @@ def adam_close(got, ref, g, lr=2e-4, steps=1):
         return bool((err <= 2 * steps * lr * 1.05 + 1e-6).all()) and float(np.median(err)) < 1e-5
     big = np.abs(g) > 1e-5
     return bool((err[big] <= 4e-6 + 2e-3 * lr).all()) and bool((err[~big] <= 2 * lr * 1.05 + 1e-6).all())
+
+
+# ---- validation / rollout fixtures (tools/gen_golden_val.py = the reference's lmp_val / step)
+VAL_CASES = {"val_hulc_tiny": (2, 2, 4, True, 11), "val_hulc_s16": (3, 0, 16, False, 12)}   # name: (Bv, Bl, S, use_clip, seed)
+VAL_NOISE_KEYS = ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")
+
+
+def load_val_case(name):
+    Bv, Bl, S, use_clip, seed = VAL_CASES[name]
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=use_clip)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    noise = {sc: {k: fx[f"{k}_{sc}"] for k in VAL_NOISE_KEYS} for sc in batch}
+    return dims, P, batch, noise, fx
+
+
+def load_rollout_case(name="rollout_hulc"):
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    nsteps, replan_freq, seed = (int(v) for v in fx["meta"])
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=True)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    frames = synthetic.make_batch(1, 1, nsteps + 1, seed=seed, edge_frac=0.0, aux_mask="all")
+    return dims, P, frames, nsteps, replan_freq, fx

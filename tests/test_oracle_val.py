@@ -1,0 +1,51 @@
+"""CPU: the oracle's validation forward (lmp_val) and stateful rollout (reset/step) against fixtures produced by the
+unmodified reference (tools/gen_golden_val.py).  The reference's stochastic draws are inputs of the fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import hulc_oracle as O  # noqa: E402
+from golden_util import VAL_CASES, load_rollout_case, load_val_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(VAL_CASES))
+def test_validation_forward_matches_reference(name):
+    dims, P, batch, noise, fx = load_val_case(name)
+    for sc, mb in batch.items():
+        o = O.validation_forward(P, dims, mb, "lang" in sc, noise[sc])
+        for k in ("action_loss_pp", "action_loss_pr", "kl_loss"):
+            assert abs(float(o[k]) - float(fx[f"{k}_{sc}"])) <= 2e-5 * abs(float(fx[f"{k}_{sc}"])) + 1e-7, (sc, k)
+        for k in ("mae_pp", "mae_pr"):
+            assert np.abs(o[k] - fx[f"{k}_{sc}"]).max() <= 5e-5, (sc, k)
+        for k in ("gripper_sr_pp", "gripper_sr_pr"):
+            assert float(o[k]) == float(fx[f"{k}_{sc}"]), (sc, k)
+        assert np.abs(o["seq_feat"] - fx[f"seq_feat_{sc}"]).max() <= 2e-5 * np.abs(fx[f"seq_feat_{sc}"]).max()
+
+
+def test_rollout_matches_reference_step():
+    dims, P, frames, nsteps, replan_freq, fx = load_rollout_case()
+    for mode in ("vis", "lang"):
+        mb = frames[mode]
+        ro = O.Rollout(P, dims, replan_freq)
+        goal = dict(rgb_static=mb["rgb_static"][:, nsteps:nsteps + 1], rgb_gripper=mb["rgb_gripper"][:, nsteps:nsteps + 1]) if mode == "vis" \
+            else frames["lang"]["lang"][0:1]
+        for t in range(nsteps):
+            obs = dict(rgb_static=mb["rgb_static"][:, t:t + 1], rgb_gripper=mb["rgb_gripper"][:, t:t + 1], robot_obs_raw=mb["robot_obs"][:, t:t + 1])
+            a = ro.step(obs, goal, dict(plan_idx=fx[f"plan_idx_{mode}"][t], u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
+            assert np.abs(a - fx[f"actions_{mode}"][:, t:t + 1]).max() <= 1e-4, (mode, t)
+
+
+def test_tcp_world_round_trip():
+    """tcp_to_world_frame(world_to_tcp_frame(a)) == a (gripper_control.py:16-63) on random actions / poses."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, (3, 5, 7)).astype(np.float32)
+    a[..., 6] = np.where(a[..., 6] > 0, 1.0, -1.0)
+    ro = rng.normal(0, 0.5, (3, 5, 15)).astype(np.float32)
+    back = O.tcp_to_world_frame(O.world_to_tcp_frame(a, ro), ro)
+    assert np.abs(back - a).max() < 2e-3

@@ -1,0 +1,153 @@
+"""Generate tests/golden/val_*.npz and rollout_*.npz by running the UNMODIFIED reference (/root/reference) on CPU:
+validation forward (Hulc.validation_step body -> lmp_val, hulc/models/hulc.py:770-797, :301-388) and the stateful rollout
+(reset / step, :843-957).  The stochastic draws the reference makes are RECORDED (torch.rand wrapper for the two draws of
+LogisticDecoderRNN._sample; the categorical plan samples are outputs) and stored as inputs of the fixture.
+
+Run in the build container only:  python tools/gen_golden_val.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+warnings.filterwarnings("ignore")
+
+from hulc_amd import spec  # noqa: E402
+from hulc_amd.utils import portable_rng as prng  # noqa: E402
+from hulc_amd.utils import synthetic  # noqa: E402
+import ref_harness  # noqa: E402
+from gen_golden import to_ref_batch  # noqa: E402
+
+VAL_CASES = {
+    # name: (Bv, Bl, S, use_clip, seed)
+    "val_hulc_tiny": (2, 2, 4, True, 11),
+    "val_hulc_s16": (3, 0, 16, False, 12),
+}
+
+
+class RandRecorder:
+    """Wraps torch.rand: the reference's own generator draws, we only keep a copy of what it drew."""
+
+    def __init__(self):
+        self.draws = []
+        self.orig = torch.rand
+
+    def __enter__(self):
+        def rand(*a, **k):
+            t = self.orig(*a, **k)
+            self.draws.append(t.detach().cpu().numpy().copy())
+            return t
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self.orig
+
+
+def load_params(model, P):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(P[n]).reshape(p.shape))
+
+
+def run_val(name, case, outdir):
+    Bv, Bl, S, use_clip, seed = case
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=use_clip)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
+    model = ref_harness.build_reference("hulc", max_window=32, use_clip=use_clip)
+    model.eval()
+    load_params(model, P)
+    rb = to_ref_batch(batch)
+    fx = {"meta": np.array([Bv, Bl, S, int(use_clip), seed], np.int64)}
+    torch.manual_seed(4321 + seed)
+    with torch.no_grad():
+        for sc, db in rb.items():                      # the body of validation_step (hulc.py:770-797) for one modality
+            emb = model.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
+            goal = model.language_goal(db["lang"]) if "lang" in sc else model.visual_goal(emb[:, -1])
+            with RandRecorder() as rr:
+                (plan_pp, loss_pp, plan_pr, loss_pr, kl, mae_pp, mae_pr, sr_pp, sr_pr, seq_feat) = model.lmp_val(
+                    emb, goal, db["actions"], db["state_info"]["robot_obs"])
+            assert len(rr.draws) == 4, len(rr.draws)
+            B = emb.shape[0]
+            fx[f"plan_idx_pp_{sc}"] = plan_pp.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
+            fx[f"plan_idx_pr_{sc}"] = plan_pr.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
+            fx[f"u_mix_pp_{sc}"], fx[f"u_act_pp_{sc}"], fx[f"u_mix_pr_{sc}"], fx[f"u_act_pr_{sc}"] = rr.draws
+            for k, v in (("action_loss_pp", loss_pp), ("action_loss_pr", loss_pr), ("kl_loss", kl), ("gripper_sr_pp", sr_pp), ("gripper_sr_pr", sr_pr)):
+                fx[f"{k}_{sc}"] = np.float32(v.item())
+            fx[f"mae_pp_{sc}"] = mae_pp.numpy()
+            fx[f"mae_pr_{sc}"] = mae_pr.numpy()
+            fx[f"seq_feat_{sc}"] = seq_feat.numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
+    # sanity: oracle vs reference (report only; the committed test does the check)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hulc_oracle as O
+    for sc, mb in batch.items():
+        noise = {k: fx[f"{k}_{sc}"] for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")}
+        o = O.validation_forward(P, dims, mb, "lang" in sc, noise)
+        print(f"[{name}/{sc}] loss_pp ref {fx[f'action_loss_pp_{sc}']:.6f} oracle {o['action_loss_pp']:.6f} | kl {fx[f'kl_loss_{sc}']:.6f} {o['kl_loss']:.6f} | "
+              f"mae_pp err {np.abs(o['mae_pp'] - fx[f'mae_pp_{sc}']).max():.2e} mae_pr err {np.abs(o['mae_pr'] - fx[f'mae_pr_{sc}']).max():.2e} "
+              f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f} {fx[f'gripper_sr_pr_{sc}']:.3f}/{o['gripper_sr_pr']:.3f}")
+
+
+def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2):
+    """Two rollouts with the same weights: vision goal (nsteps steps, replan every replan_freq) then language goal."""
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=True)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    model = ref_harness.build_reference("hulc", max_window=32, use_clip=True)
+    model.eval()
+    load_params(model, P)
+    model.replan_freq = replan_freq
+    frames = synthetic.make_batch(1, 1, nsteps + 1, seed=seed, edge_frac=0.0, aux_mask="all")
+    vis, lang = frames["vis"], frames["lang"]
+    fx = {"meta": np.array([nsteps, replan_freq, seed], np.int64)}
+    model.lang_embeddings = {"do the task": lang["lang"][0:1].reshape(1, 1, 384)}
+    torch.manual_seed(99 + seed)
+    for mode, mb in (("vis", vis), ("lang", lang)):
+        model.reset()
+        goal = None
+        if mode == "vis":
+            goal = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, nsteps:nsteps + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, nsteps:nsteps + 1])),
+                        depth_obs={}, robot_obs=torch.zeros(1, 1, 8))
+        else:
+            goal = "do the task"
+        acts, plans, umix, uact = [], [], [], []
+        for t in range(nsteps):
+            obs = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, t:t + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, t:t + 1])),
+                       depth_obs={}, robot_obs=torch.zeros(1, 1, 8), robot_obs_raw=torch.from_numpy(mb["robot_obs"][:, t:t + 1]))
+            with RandRecorder() as rr:
+                a = model.step(obs, goal)
+            assert len(rr.draws) == 2
+            umix.append(rr.draws[0]); uact.append(rr.draws[1])
+            plans.append(model.plan.reshape(1, 32, 32).argmax(-1).numpy().astype(np.int32))
+            acts.append(a.detach().numpy().copy())
+        fx[f"actions_{mode}"] = np.concatenate(acts, 1)          # (1, nsteps, 7)
+        fx[f"plan_idx_{mode}"] = np.stack(plans, 0)               # (nsteps, 1, 32): the plan in force at each step
+        fx[f"u_mix_{mode}"] = np.stack(umix, 0)
+        fx[f"u_act_{mode}"] = np.stack(uact, 0)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hulc_oracle as O
+    for mode, mb in (("vis", vis), ("lang", lang)):
+        ro = O.Rollout(P, dims, replan_freq)
+        goal = dict(rgb_static=mb["rgb_static"][:, nsteps:nsteps + 1], rgb_gripper=mb["rgb_gripper"][:, nsteps:nsteps + 1]) if mode == "vis" else lang["lang"][0:1]
+        worst = 0.0
+        for t in range(nsteps):
+            obs = dict(rgb_static=mb["rgb_static"][:, t:t + 1], rgb_gripper=mb["rgb_gripper"][:, t:t + 1], robot_obs_raw=mb["robot_obs"][:, t:t + 1])
+            a = ro.step(obs, goal, dict(plan_idx=fx[f"plan_idx_{mode}"][t], u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
+            worst = max(worst, np.abs(a - fx[f"actions_{mode}"][:, t:t + 1]).max())
+        print(f"[{name}/{mode}] rollout oracle-vs-reference max |action diff| {worst:.2e}")
+
+
+if __name__ == "__main__":
+    out = os.path.join(ROOT, "tests", "golden")
+    for name, case in VAL_CASES.items():
+        run_val(name, case, out)
+    run_rollout("rollout_hulc", out)
