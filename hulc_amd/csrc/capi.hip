@@ -67,6 +67,21 @@ int hulc_backward_part(hulc_ctx* ctx, int32_t part) {
     if (part != 0 && part != 1) { hulc_set_error("hulc_backward_part: part must be 0 or 1"); return 1; }
     return ctx->e->backward(part);
 }
+int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* noise, float* out_host, int32_t* plan_idx_pp_out, int32_t* plan_idx_pr_out,
+                  float* pred_pp_out, float* pred_pr_out) {
+    if (!batch) { hulc_set_error("hulc_validate: null batch"); return 1; }
+    return ctx->e->validate(batch, noise, out_host, plan_idx_pp_out, plan_idx_pr_out, pred_pp_out, pred_pr_out);
+}
+int hulc_rollout_reset(hulc_ctx* ctx) { return ctx->e->rollout_reset(); }
+int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* goal_rgb_static, const float* goal_rgb_gripper, const float* goal_lang,
+                      const int32_t* plan_idx_inject, int32_t* plan_idx_out) {
+    if (!obs || !obs->rgb_static || !obs->rgb_gripper) { hulc_set_error("hulc_rollout_plan: null observation"); return 1; }
+    return ctx->e->rollout_plan(obs, goal_rgb_static, goal_rgb_gripper, goal_lang, plan_idx_inject, plan_idx_out);
+}
+int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out_host) {
+    if (!obs || !obs->rgb_static || !obs->rgb_gripper || !obs->robot_obs_raw || !action_out_host) { hulc_set_error("hulc_rollout_act: null argument"); return 1; }
+    return ctx->e->rollout_act(obs, u_mix, u_act, action_out_host);
+}
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
 int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }
 int hulc_set_dropout(hulc_ctx* ctx, float p) {

@@ -21,6 +21,12 @@ struct IEngine {
     virtual int zero_grads() = 0;
     virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
     virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
+    virtual int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
+                         float* pred_pr_out) = 0;
+    virtual int rollout_reset() = 0;
+    virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
+                             const int32_t* plan_inject, int32_t* plan_out) = 0;
+    virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
     virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
     virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
     virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
@@ -705,19 +711,12 @@ struct Engine : IEngine {
         }
     }
 
-    // ---------------------------------------------------------------- forward
-    int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) override {
-        if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
-        if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
-            hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
-            return 1;
-        }
-        if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
-        cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false;
-        const int B = b->B, S = b->S, N = B * S, SB = S * B;
+    // ---------------------------------------------------------------- forward pieces (shared by training, validation and rollout)
+    // perceptual encoders + goal encoder + plan proposal MLP
+    void trunk_fwd(const hulc_batch* b, float dp) {
+        const int B = b->B, S = b->S, N = B * S;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
-        const float dp = cfg.dropout_p;
-        HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
+        (void)dp;
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
         enc_fwd(encS, aS, b->rgb_static, N, 0);
         STAGE("enc_static_fwd");
@@ -741,6 +740,10 @@ struct Engine : IEngine {
             mlp_fwd(ppx, EMB + GOAL, B, pp, 5, ppa, pp_logits, nullptr);
         }
         STAGE("goal+pp_fwd");
+    }
+    // plan recognition transformer -> seq_feat, pr_logits
+    void pr_fwd(int B, int S, float dp) {
+        const int N = B * S;
         // ---- plan recognition transformer (plan_recognition_net.py:94-117)
         hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0));
         for (int l = 0; l < 2; ++l) {
@@ -760,6 +763,42 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, seqf, seqf_t, (long long)B * FCH);
         { EpiP ep = epi(pr_logits, true); lin_fwd(seqf_t, FCH, B, pr_fs, ep, PLAN); }
         STAGE("plan_recognition_fwd");
+    }
+    // action decoder up to the packed heads [S*B][NHEAD] (logistic_decoder_rnn.py:260-287); plan/goal terms hoisted out of the time loop.
+    // h0_0 / h0_1: previous hidden states [B][HID] of the two layers (stateful rollout, :107-111) or null (h0 = 0).
+    void dec_fwd(const int* plan_idx, int B, int S, const T* h0_0, const T* h0_1) {
+        const int SB = S * B;
+        const bool hulc = cfg.kind == HULC_KIND_HULC;
+            // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
+            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * 64, 256)), dim3(256), 0, st, emb, embg, B, S);
+            hipLaunchKernelGGL(plan_gather_kernel, dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0_32, KIN, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
+            { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
+              gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + 64, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
+            { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
+              gemm(dense<T>(embg, SB, 64), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, 64); }
+            rnn_fwd(Zx0, H0, whh0, B, S, h0_0);
+            { EpiP ep = epi(Zx1, false); ep.bias = bih1; ep.bias2 = bhh1;
+              gemm(dense<T>(H0, SB, HID), dense<T>(wih1.W, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            rnn_fwd(Zx1, H1, whh1, B, S, h0_1);
+            { EpiP ep = epi(heads, true); ep.bias = bheads;
+              gemm(dense<T>(H1, SB, HID), dense<T>(wheads, NHEAD, HID), dense_out(NHEAD), ep, SB, NHEAD, HID); }
+    }
+
+    // ---------------------------------------------------------------- forward
+    int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) override {
+        if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
+        if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
+            hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
+            return 1;
+        }
+        if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
+        cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false;
+        const int B = b->B, S = b->S, N = B * S, SB = S * B;
+        const bool hulc = cfg.kind == HULC_KIND_HULC;
+        const float dp = cfg.dropout_p;
+        HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
+        trunk_fwd(b, dp);
+        pr_fwd(B, S, dp);
         // ---- sample + KL (hulc.py:289-296, 539-561)
         if (hulc) {
             const int* idx_in = nullptr;
@@ -771,19 +810,7 @@ struct Engine : IEngine {
         }
         // ---- action decoder (logistic_decoder_rnn.py:260-287): plan/goal terms hoisted out of the time loop
         {
-            // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
-            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * 64, 256)), dim3(256), 0, st, emb, embg, B, S);
-            hipLaunchKernelGGL(plan_gather_kernel, dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0_32, KIN, pidx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
-            { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
-              gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + 64, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
-            { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
-              gemm(dense<T>(embg, SB, 64), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, 64); }
-            rnn_fwd(Zx0, H0, whh0, B, S);
-            { EpiP ep = epi(Zx1, false); ep.bias = bih1; ep.bias2 = bhh1;
-              gemm(dense<T>(H0, SB, HID), dense<T>(wih1.W, HID, HID), dense_out(HID), ep, SB, HID, HID); }
-            rnn_fwd(Zx1, H1, whh1, B, S);
-            { EpiP ep = epi(heads, true); ep.bias = bheads;
-              gemm(dense<T>(H1, SB, HID), dense<T>(wheads, NHEAD, HID), dense_out(NHEAD), ep, SB, NHEAD, HID); }
+            dec_fwd(pidx, B, S, nullptr, nullptr);
             hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, lw / (float)SB, rowloss, a_tcp, dheads);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
@@ -817,10 +844,153 @@ struct Engine : IEngine {
     }
     int clip_n = 0;
 
+    // ---------------------------------------------------------------- validation forward (hulc.py:301-388, 770-797)
+    float* valm = nullptr;            // [32]: 0 loss_pp, 1 loss_pr, 2 kl; 8..14 pp (mae[6], sr); 16..22 pr
+    float *pred_pp = nullptr, *pred_pr = nullptr, *nz_mix = nullptr, *nz_act = nullptr;
+    int* pidx_pp = nullptr;
+    void val_alloc() {
+        if (valm) return;
+        valm = alloc<float>(32); pred_pp = alloc<float>((int64_t)maxB * maxS * 7); pred_pr = alloc<float>((int64_t)maxB * maxS * 7);
+        nz_mix = alloc<float>((int64_t)maxB * maxS * NDIM * NMIX); nz_act = alloc<float>((int64_t)maxB * maxS * NDIM);
+        pidx_pp = alloc<int>((int64_t)maxB * NCAT);
+    }
+    int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
+                 float* pred_pr_out) override {
+        if (!bound) { hulc_set_error("hulc_validate before hulc_bind_params"); return 1; }
+        if (cfg.kind != HULC_KIND_HULC) { hulc_set_error("hulc_validate: only the HULC model kind has a plan proposal / recognition pair"); return 1; }
+        if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
+            hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
+            return 1;
+        }
+        if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
+        val_alloc();
+        if (alloc_failed) { hulc_set_error("hulc_validate: workspace allocation failed"); return 1; }
+        static const hulc_val_noise none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (!nz) nz = &none;
+        cur = *b; have_fwd = false;
+        const int B = b->B, S = b->S, SB = S * B;
+        HIP_CHECK(hipMemsetAsync(valm, 0, 32 * sizeof(float), st));
+        trunk_fwd(b, 0.f);
+        pr_fwd(B, S, 0.f);
+        // KL (beta-scaled) + recognition sample, then the proposal sample (no KL terms: second logits pointer null)
+        const int* in_pr = nullptr;
+        if (nz->plan_idx_pr) { HIP_CHECK(hipMemcpyAsync(pidx_in, nz->plan_idx_pr, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); in_pr = pidx_in; }
+        hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, in_pr, pidx, probs, klcat, dpp_kl, dpr_kl, 0.f,
+                           0.f, site_seed(40));
+        hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, B * NCAT, cfg.kl_beta / B, valm + 2);
+        const int* in_pp = nullptr;
+        if (nz->plan_idx_pp) { HIP_CHECK(hipMemcpyAsync(pidx_in, nz->plan_idx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); in_pp = pidx_in; }
+        hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, B, NCAT, NCLS, in_pp, pidx_pp, probs, klcat,
+                           dpp_kl, dpr_kl, 0.f, 0.f, site_seed(41));
+        for (int pass = 0; pass < 2; ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
+            dec_fwd(pass == 0 ? pidx_pp : pidx, B, S, nullptr, nullptr);
+            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, 0.f, rowloss, a_tcp, dheads);
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, valm + pass);
+            const float* um = pass == 0 ? nz->u_mix_pp : nz->u_mix_pr;
+            const float* ua = pass == 0 ? nz->u_act_pp : nz->u_act_pr;
+            if (um) { HIP_CHECK(hipMemcpyAsync(nz_mix, um, sizeof(float) * SB * NDIM * NMIX, hipMemcpyDefault, st)); um = nz_mix; }
+            if (ua) { HIP_CHECK(hipMemcpyAsync(nz_act, ua, sizeof(float) * SB * NDIM, hipMemcpyDefault, st)); ua = nz_act; }
+            hipLaunchKernelGGL(logistic_sample_kernel, dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->robot_obs, b->actions, um, ua, B, S, NMIX, NDIM,
+                               cfg.log_scale_min, 1, site_seed(42 + pass), pass == 0 ? pred_pp : pred_pr, valm + 8 + 8 * pass);
+        }
+        STAGE("validate");
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in validate"); return 1; }
+        if (plan_pp_out) HIP_CHECK(hipMemcpyAsync(plan_pp_out, pidx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
+        if (plan_pr_out) HIP_CHECK(hipMemcpyAsync(plan_pr_out, pidx, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
+        if (pred_pp_out) HIP_CHECK(hipMemcpyAsync(pred_pp_out, pred_pp, sizeof(float) * SB * 7, hipMemcpyDefault, st));
+        if (pred_pr_out) HIP_CHECK(hipMemcpyAsync(pred_pr_out, pred_pr, sizeof(float) * SB * 7, hipMemcpyDefault, st));
+        float h[32];
+        HIP_CHECK(hipMemcpyAsync(h, valm, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (out17) {
+            out17[0] = h[0]; out17[1] = h[1]; out17[2] = h[2]; out17[3] = h[14]; out17[4] = h[22];
+            for (int i = 0; i < 6; ++i) { out17[5 + i] = h[8 + i]; out17[11 + i] = h[16 + i]; }
+        }
+        return 0;
+    }
+
+    // ---------------------------------------------------------------- rollout (hulc.py:843-957), B = 1
+    int* roll_plan = nullptr; T *roll_goal = nullptr, *roll_h0 = nullptr, *roll_h1 = nullptr;
+    float *roll_fs = nullptr, *roll_fg = nullptr, *roll_ro = nullptr, *roll_pred = nullptr;
+    bool roll_has_h = false, roll_has_plan = false;
+    uint64_t roll_counter = 0;
+    void roll_alloc() {
+        if (roll_plan) return;
+        val_alloc();
+        roll_plan = alloc<int>(NCAT); roll_goal = alloc<T>(GOAL); roll_h0 = alloc<T>(HID); roll_h1 = alloc<T>(HID);
+        roll_fs = alloc<float>(2ll * 3 * encS.IH * encS.IH); roll_fg = alloc<float>(2ll * 3 * encG.IH * encG.IH);
+        roll_ro = alloc<float>(16); roll_pred = alloc<float>(8);
+    }
+    int rollout_reset() override { roll_has_h = false; roll_has_plan = false; roll_counter = 0; return 0; }
+    int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang, const int32_t* plan_inject,
+                     int32_t* plan_out) override {
+        if (!bound) { hulc_set_error("hulc_rollout_plan before hulc_bind_params"); return 1; }
+        if (cfg.kind != HULC_KIND_HULC) { hulc_set_error("hulc_rollout_plan: HULC model kind only"); return 1; }
+        if ((goal_lang != nullptr) == (goal_static != nullptr && goal_gripper != nullptr)) {
+            hulc_set_error("hulc_rollout_plan: give either the two goal images or the language embedding");
+            return 1;
+        }
+        if (maxS < 2 && !goal_lang) { hulc_set_error("hulc_rollout_plan: a visual goal needs max_seq >= 2 (obs + goal frame form one window, hulc.py:917-919)"); return 1; }
+        roll_alloc();
+        if (alloc_failed) { hulc_set_error("hulc_rollout_plan: workspace allocation failed"); return 1; }
+        have_fwd = false;
+        hulc_batch bb; memset(&bb, 0, sizeof(bb));
+        bb.B = 1; bb.step = roll_counter;
+        if (goal_lang) {
+            bb.S = 1; bb.is_lang = 1; bb.rgb_static = obs->rgb_static; bb.rgb_gripper = obs->rgb_gripper; bb.lang = goal_lang;
+        } else {
+            const size_t ns = sizeof(float) * 3 * encS.IH * encS.IH, ng = sizeof(float) * 3 * encG.IH * encG.IH;
+            HIP_CHECK(hipMemcpyAsync(roll_fs, obs->rgb_static, ns, hipMemcpyDefault, st));
+            HIP_CHECK(hipMemcpyAsync((char*)roll_fs + ns, goal_static, ns, hipMemcpyDefault, st));
+            HIP_CHECK(hipMemcpyAsync(roll_fg, obs->rgb_gripper, ng, hipMemcpyDefault, st));
+            HIP_CHECK(hipMemcpyAsync((char*)roll_fg + ng, goal_gripper, ng, hipMemcpyDefault, st));
+            bb.S = 2; bb.is_lang = 0; bb.rgb_static = roll_fs; bb.rgb_gripper = roll_fg;
+        }
+        cur = bb;
+        trunk_fwd(&bb, 0.f);
+        const int* inj = nullptr;
+        if (plan_inject) { HIP_CHECK(hipMemcpyAsync(pidx_in, plan_inject, sizeof(int) * NCAT, hipMemcpyDefault, st)); inj = pidx_in; }
+        hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, 1, NCAT, NCLS, inj, roll_plan, probs, klcat, dpp_kl,
+                           dpr_kl, 0.f, 0.f, site_seed(50));
+        HIP_CHECK(hipMemcpyAsync(roll_goal, goal_t, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
+        roll_has_h = false; roll_has_plan = true;      // action_decoder.clear_hidden_state() (hulc.py:925 / :946)
+        if (plan_out) HIP_CHECK(hipMemcpyAsync(plan_out, roll_plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_plan"); return 1; }
+        return 0;
+    }
+    int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) override {
+        if (!roll_has_plan) { hulc_set_error("hulc_rollout_act before hulc_rollout_plan (Hulc.step replans at rollout_step_counter %% replan_freq == 0)"); return 1; }
+        have_fwd = false;
+        hulc_batch bb; memset(&bb, 0, sizeof(bb));
+        bb.B = 1; bb.S = 1; bb.step = roll_counter++;
+        cur = bb;
+        enc_fwd(encS, aS, obs->rgb_static, 1, 0);
+        enc_fwd(encG, aG, obs->rgb_gripper, 1, 64);
+        HIP_CHECK(hipMemcpyAsync(goal_t, roll_goal, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
+        dec_fwd(roll_plan, 1, 1, roll_has_h ? roll_h0 : nullptr, roll_has_h ? roll_h1 : nullptr);
+        HIP_CHECK(hipMemcpyAsync(roll_h0, H0, sizeof(T) * HID, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(roll_h1, H1, sizeof(T) * HID, hipMemcpyDeviceToDevice, st));
+        roll_has_h = true;
+        HIP_CHECK(hipMemcpyAsync(roll_ro, obs->robot_obs_raw, sizeof(float) * 15, hipMemcpyDefault, st));
+        if (u_mix) { HIP_CHECK(hipMemcpyAsync(nz_mix, u_mix, sizeof(float) * NDIM * NMIX, hipMemcpyDefault, st)); u_mix = nz_mix; }
+        if (u_act) { HIP_CHECK(hipMemcpyAsync(nz_act, u_act, sizeof(float) * NDIM, hipMemcpyDefault, st)); u_act = nz_act; }
+        hipLaunchKernelGGL(logistic_sample_kernel, dim3(1), dim3(64), 0, st, heads, NHEAD, roll_ro, (const float*)nullptr, u_mix, u_act, 1, 1, NMIX, NDIM,
+                           cfg.log_scale_min, 1, site_seed(51), roll_pred, (float*)nullptr);
+        HIP_CHECK(hipMemcpyAsync(action_out, roll_pred, sizeof(float) * 7, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_act"); return 1; }
+        return 0;
+    }
+
     // H[t] = relu(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID]
-    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S) {
+    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S, const T* h0 = nullptr) {
         const long long BH = (long long)B * HID;
-        hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
+        if (h0) {
+            EpiP ep = epi(H, false); ep.res = Zx; ep.res_ld = HID; ep.relu = 1;
+            gemm(dense<T>(h0, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
+        } else hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int t = 1; t < S; ++t) {
             EpiP ep = epi(H + t * BH, false); ep.res = Zx + t * BH; ep.res_ld = HID; ep.relu = 1;

@@ -861,6 +861,76 @@ DEVI void euler_xyz(float a, float b, float c, float (&R)[9]) {
 DEVI float softplusf(float x) { return x > 20.f ? x : (x < -20.f ? __expf(x) : log1pf(__expf(x))); }
 DEVI float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// =========================================================================================================
+// validation / rollout: sample an action from the logistic mixture heads (logistic_decoder_rnn.py:234-258),
+// map it from the tcp frame back to the world frame (gripper_control.py:39-63) and, when ground truth is given, accumulate the
+// metrics lmp_val reports (hulc.py:347-358): per-dimension mean |error| and the binary gripper success rate.
+// One thread per time-major row r = t*B + b.  u_mix [B][S][6][NMIX] / u_act [B][S][6] are the two uniform draws in [0,1)
+// (injected for parity, else the counter RNG).  metrics[0..5] += |err_d| / (B*S), metrics[6] += match / (B*S).
+// =========================================================================================================
+__global__ void logistic_sample_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ robot_obs /*[B][S][15]*/,
+                                       const float* __restrict__ actions_gt /*[B][S][7] or null*/, const float* __restrict__ u_mix,
+                                       const float* __restrict__ u_act, int B, int S, int NMIX, int NDIM, float log_scale_min, int gripper_control,
+                                       unsigned long long seed, float* __restrict__ pred_out /*[B][S][7]*/, float* __restrict__ metrics) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B * S) return;
+    const int t = r / B, b = r % B;
+    const long long bs = (long long)b * S + t;
+    const float* hr = heads + (long long)r * ldh;
+    const int NO = NMIX * NDIM;
+    const float r1 = 1e-5f, r2 = 1.f - 1e-5f;
+    float a[7];
+    for (int d = 0; d < NDIM; ++d) {
+        int ksel = 0;
+        float best = -INFINITY;
+        for (int k = 0; k < NMIX; ++k) {
+            const float u = u_mix ? u_mix[(bs * NDIM + d) * NMIX + k] : hash_uniform(seed, (unsigned long long)((bs * NDIM + d) * NMIX + k));
+            const float tt = (r1 - r2) * u + r2;
+            const float g = hr[d * NMIX + k] - __logf(-__logf(tt));
+            if (g > best) { best = g; ksel = k; }                     // first maximum, like torch.argmax
+        }
+        const float mu = hr[NO + d * NMIX + ksel];
+        const float ls = fmaxf(hr[2 * NO + d * NMIX + ksel], log_scale_min);
+        const float uu = u_act ? u_act[bs * NDIM + d] : hash_uniform(seed ^ 0x9e3779b97f4a7c15ull, (unsigned long long)(bs * NDIM + d));
+        const float u = (r1 - r2) * uu + r2;
+        a[d] = mu + __expf(ls) * (__logf(u) - __logf(1.f - u));
+    }
+    a[6] = (hr[3 * NO + 1] > hr[3 * NO]) ? 1.f : -1.f;               // gripper_bounds[argmax]
+    float w[7];
+    if (gripper_control) {
+        const float* ro = robot_obs + bs * 15;
+        float R[9], Rr[9];
+        euler_xyz(ro[3], ro[4], ro[5], R);
+        euler_xyz(a[3] * 0.01f, a[4] * 0.01f, a[5] * 0.01f, Rr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = R[3 * i] * a[0] + R[3 * i + 1] * a[1] + R[3 * i + 2] * a[2];
+        auto Mij = [&](int i, int j) { return R[3 * i] * Rr[3 * j] + R[3 * i + 1] * Rr[3 * j + 1] + R[3 * i + 2] * Rr[3 * j + 2]; };   // R * Rr^T
+        float o[3] = {atan2f(-Mij(1, 2), Mij(2, 2)), asinf(fminf(1.f, fmaxf(-1.f, Mij(0, 2)))), atan2f(-Mij(0, 1), Mij(0, 0))};
+        const float PI = 3.14159265358979323846f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            o[i] -= ro[3 + i];
+            if (o[i] < -PI) o[i] += 2.f * PI;
+            if (o[i] > PI) o[i] -= 2.f * PI;
+            w[3 + i] = o[i] * 100.f;
+        }
+        w[6] = a[6];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) w[i] = a[i];
+    }
+    if (pred_out)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pred_out[bs * 7 + i] = w[i];
+    if (metrics && actions_gt) {
+        const float inv = 1.f / (float)(B * S);
+        const float* gt = actions_gt + bs * 7;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(metrics + i, fabsf(w[i] - gt[i]) * inv);
+        atomicAdd(metrics + 6, (((w[6] > 0.f) ? 1.f : -1.f) == gt[6]) ? inv : 0.f);
+    }
+}
+
 // one thread per (row, slot): slots 0..NDIM-1 = mixture dimension d, slot NDIM = gripper cross entropy, last slot idle;
 // row_loss is [rows][8] (summed deterministically afterwards).  Each thread recomputes the row's tcp-frame action (cheap) so the
 // 7 partial losses of a row run in parallel instead of serially in one lane.

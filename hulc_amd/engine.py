@@ -5,7 +5,7 @@ torch is plumbing here (device memory, streams, torch.distributed); every FLOP o
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -105,6 +105,85 @@ class StepEngine:
             self._loss_dev = torch.zeros(4, dtype=torch.float32, device=self.device)
         L.check(self.lib.hulc_forward_loss(self.ctx, C.byref(b), loss_weight, clip_weight, self._loss_dev.data_ptr(), 0))
         return self._loss_dev
+
+    # ------------------------------------------------------------------ validation / rollout (forward only)
+    @staticmethod
+    def _dev_or_host_ptr(x, keep, dtype):
+        """Noise arrays may be torch (device/host) tensors or numpy arrays; returns a raw pointer and keeps the buffer alive."""
+        if x is None:
+            return None
+        if torch.is_tensor(x):
+            t = x.to(dtype=torch.int32 if dtype == np.int32 else torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        a = np.ascontiguousarray(x, dtype)
+        keep.append(a)
+        return a.ctypes.data
+
+    def validate(self, mb: Dict, is_lang: bool, noise: Optional[Dict] = None, want_pred: bool = False) -> Dict:
+        """One modality of Hulc.validation_step (hulc.py:770-797 -> lmp_val :301-388), eval mode.  noise (optional, parity):
+        plan_idx_pp / plan_idx_pr (B,32) int, u_mix_pp / u_mix_pr (B,S,6,10), u_act_pp / u_act_pr (B,S,6) uniform [0,1) draws."""
+        B, S = mb["actions"].shape[:2]
+        keep = []
+
+        def ptr(t):
+            t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        b = L.HulcBatch(B=B, S=S, is_lang=int(is_lang), rgb_static=ptr(mb["rgb_static"]), rgb_gripper=ptr(mb["rgb_gripper"]),
+                        actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
+                        plan_idx=None, aux_rows=None, n_aux=0, step=int(mb.get("step", 0)))
+        noise = noise or {}
+        nz = L.HulcValNoise(**{k: self._dev_or_host_ptr(noise.get(k), keep, np.int32 if k.startswith("plan") else np.float32)
+                               for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")})
+        out = (C.c_float * 17)()
+        ppp = torch.zeros(B, 32, dtype=torch.int32, device=self.device)
+        ppr = torch.zeros(B, 32, dtype=torch.int32, device=self.device)
+        pred_pp = torch.zeros(B, S, 7, device=self.device) if want_pred else None
+        pred_pr = torch.zeros(B, S, 7, device=self.device) if want_pred else None
+        L.check(self.lib.hulc_validate(self.ctx, C.byref(b), C.byref(nz), out, ppp.data_ptr(), ppr.data_ptr(),
+                                       pred_pp.data_ptr() if want_pred else None, pred_pr.data_ptr() if want_pred else None))
+        o = list(out)
+        res = dict(action_loss_pp=o[0], action_loss_pr=o[1], kl_loss=o[2], gripper_sr_pp=o[3], gripper_sr_pr=o[4],
+                   mae_pp=np.array(o[5:11], np.float32), mae_pr=np.array(o[11:17], np.float32), sampled_plan_idx_pp=ppp, sampled_plan_idx_pr=ppr)
+        if want_pred:
+            res.update(pred_pp=pred_pp, pred_pr=pred_pr)
+        return res
+
+    def rollout_reset(self):
+        L.check(self.lib.hulc_rollout_reset(self.ctx))
+
+    def _obs(self, obs, keep):
+        def ptr(t):
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        return L.HulcRolloutObs(rgb_static=ptr(obs["rgb_static"]), rgb_gripper=ptr(obs["rgb_gripper"]),
+                                robot_obs_raw=ptr(obs["robot_obs_raw"]) if obs.get("robot_obs_raw") is not None else None)
+
+    def rollout_plan(self, obs: Dict, goal, plan_idx=None):
+        """goal: dict(rgb_static, rgb_gripper) (1,1,3,H,W) for a visual goal or a (384,) language embedding tensor.  Returns the plan (32,) int32."""
+        keep = []
+        o = self._obs(obs, keep)
+        gs = gg = gl = None
+        if isinstance(goal, dict):
+            gs = goal["rgb_static"].to(device=self.device, dtype=torch.float32).contiguous(); keep.append(gs)
+            gg = goal["rgb_gripper"].to(device=self.device, dtype=torch.float32).contiguous(); keep.append(gg)
+        else:
+            gl = torch.as_tensor(goal).to(device=self.device, dtype=torch.float32).reshape(-1).contiguous(); keep.append(gl)
+        out = torch.zeros(32, dtype=torch.int32, device=self.device)
+        L.check(self.lib.hulc_rollout_plan(self.ctx, C.byref(o), gs.data_ptr() if gs is not None else None, gg.data_ptr() if gg is not None else None,
+                                           gl.data_ptr() if gl is not None else None, self._dev_or_host_ptr(plan_idx, keep, np.int32), out.data_ptr()))
+        return out
+
+    def rollout_act(self, obs: Dict, u_mix=None, u_act=None) -> np.ndarray:
+        keep = []
+        o = self._obs(obs, keep)
+        out = (C.c_float * 7)()
+        L.check(self.lib.hulc_rollout_act(self.ctx, C.byref(o), self._dev_or_host_ptr(u_mix, keep, np.float32),
+                                          self._dev_or_host_ptr(u_act, keep, np.float32), out))
+        return np.array(list(out), np.float32)
 
     def set_kl_beta(self, kl_beta: float):
         L.check(self.lib.hulc_set_kl_beta(self.ctx, float(kl_beta)))

@@ -24,9 +24,18 @@ class HulcBatch(C.Structure):
                 ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64)]
 
 
+class HulcValNoise(C.Structure):
+    _fields_ = [("plan_idx_pp", C.c_void_p), ("plan_idx_pr", C.c_void_p), ("u_mix_pp", C.c_void_p), ("u_act_pp", C.c_void_p),
+                ("u_mix_pr", C.c_void_p), ("u_act_pr", C.c_void_p)]
+
+
+class HulcRolloutObs(C.Structure):
+    _fields_ = [("rgb_static", C.c_void_p), ("rgb_gripper", C.c_void_p), ("robot_obs_raw", C.c_void_p)]
+
+
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward", "hulc_backward_part",
-           "hulc_adam_step", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
+           "hulc_adam_step", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
 
 _lib = None
 
@@ -54,6 +63,10 @@ def load():
     lib.hulc_backward.argtypes = [C.c_void_p]
     lib.hulc_backward_part.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]
+    lib.hulc_validate.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.POINTER(HulcValNoise), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hulc_rollout_reset.argtypes = [C.c_void_p]
+    lib.hulc_rollout_plan.argtypes = [C.c_void_p, C.POINTER(HulcRolloutObs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hulc_rollout_act.argtypes = [C.c_void_p, C.POINTER(HulcRolloutObs), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hulc_set_kl_beta.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_set_dropout.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_timers_enable.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]

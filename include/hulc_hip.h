@@ -95,6 +95,44 @@ int hulc_backward_part(hulc_ctx* ctx, int32_t part);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
 
+/* ---- Validation forward: one modality of Hulc.validation_step (hulc/models/hulc.py:770-797) = lmp_val
+ * (:301-388): plan proposal and plan recognition each sample a plan (distributions.py:37-41), the decoder is run with both
+ * (LogisticDecoderRNN.loss_and_act, logistic_decoder_rnn.py:85-100): NLL loss, a sampled action (_sample :234-258) mapped back to
+ * the world frame (tcp_to_world_frame, gripper_control.py:39-63), its mean absolute error and the gripper success rate.
+ * Eval-mode: dropout off.  Forward only — it invalidates the state hulc_backward needs.
+ * Every pointer of hulc_val_noise is optional (device or host memory); NULL = draw on the device with the counter RNG. */
+typedef struct hulc_val_noise {
+    const int32_t* plan_idx_pp;  /* (B,32) categorical sample of the plan-proposal distribution */
+    const int32_t* plan_idx_pr;  /* (B,32) ... of the plan-recognition distribution */
+    const float* u_mix_pp;       /* (B,S,6,10) torch.rand draw selecting the mixture component (Gumbel argmax), pp pass */
+    const float* u_act_pp;       /* (B,S,6)    torch.rand draw of the logistic inversion sampling, pp pass */
+    const float* u_mix_pr;
+    const float* u_act_pr;
+} hulc_val_noise;
+/* out_host[17] = {action_loss_pp, action_loss_pr, kl_loss (beta-scaled, hulc.py:539-561), gripper_sr_pp, gripper_sr_pr,
+ *                 mae_pp[6], mae_pr[6]}  (per-dimension means over B and S: everything validation_step logs, :816-833).
+ * plan_idx_*_out (B,32) int32 and pred_*_out (B,S,7) world-frame sampled actions: optional, device or host. */
+#define HULC_N_VAL 17
+int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* noise, float* out_host, int32_t* plan_idx_pp_out,
+                  int32_t* plan_idx_pr_out, float* pred_pp_out, float* pred_pr_out);
+
+/* ---- Rollout (Hulc.reset / step, hulc/models/hulc.py:843-957; stateful LogisticDecoderRNN.act, logistic_decoder_rnn.py:102-116).
+ * hulc_rollout_plan  = get_pp_plan_vision (:905-927: obs and goal frame encoded as one 2-frame window) or get_pp_plan_lang
+ *                      (:929-948): latent goal + a plan sampled from the plan proposal; clears the decoder's hidden state.
+ * hulc_rollout_act   = predict_with_plan (:881-903): encode the current frame, one recurrent step, sample, tcp -> world.
+ * The replan_freq counter lives in the host wrapper (hulc_amd.hulc.Hulc.step).  B = 1. */
+typedef struct hulc_rollout_obs {
+    const float* rgb_static;     /* (1,1,3,200,200) device */
+    const float* rgb_gripper;    /* (1,1,3,84,84)   device */
+    const float* robot_obs_raw;  /* (15) device or host: raw proprioception, euler angles in [3:6] */
+} hulc_rollout_obs;
+int hulc_rollout_reset(hulc_ctx* ctx);
+int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* goal_rgb_static, const float* goal_rgb_gripper,
+                      const float* goal_lang /* (384) device; exactly one of goal images / goal_lang */,
+                      const int32_t* plan_idx_inject /* (32) or NULL */, int32_t* plan_idx_out /* (32) host or device, optional */);
+int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix /* (6,10) or NULL */,
+                     const float* u_act /* (6) or NULL */, float* action_out_host /* (7) */);
+
 /* Runtime knobs: kl_beta (Hulc.set_kl_beta, hulc/models/hulc.py:563-565; called by hulc/utils/kl_callbacks.py:19-22) and the
  * transformer dropout probability (module.train()/eval(): 0 in eval mode). Take effect from the next hulc_forward_loss. */
 int hulc_set_kl_beta(hulc_ctx* ctx, float kl_beta);

@@ -1,0 +1,88 @@
+"""GPU, through the C-ABI: validation forward (hulc_validate) and the stateful rollout (hulc_rollout_plan / hulc_rollout_act)
+against fixtures produced by the unmodified reference (tools/gen_golden_val.py) with the reference's own draws injected."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from golden_util import VAL_CASES, load_rollout_case, load_val_case  # noqa: E402
+from hulc_amd.engine import StepEngine  # noqa: E402
+
+
+def _dev(mb):
+    out = {}
+    for k, v in mb.items():
+        if k in ("rgb_static", "rgb_gripper", "actions", "robot_obs", "lang"):
+            out[k] = torch.from_numpy(np.ascontiguousarray(v, np.float32)).cuda()
+    return out
+
+
+@pytest.mark.parametrize("name", list(VAL_CASES))
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 6e-2)])
+def test_validate_matches_reference(name, dtype, tol):
+    dims, P, batch, noise, fx = load_val_case(name)
+    for sc, mb in batch.items():
+        B, S = mb["actions"].shape[:2]
+        eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.1, seed=5)
+        eng.load_numpy(P)
+        o = eng.validate(_dev(mb), "lang" in sc, noise[sc], want_pred=True)
+        eng.close()
+        for k in ("action_loss_pp", "action_loss_pr", "kl_loss"):
+            ref = float(fx[f"{k}_{sc}"])
+            assert abs(o[k] - ref) <= tol * abs(ref) + 1e-6, (sc, k, o[k], ref)
+        assert np.array_equal(o["sampled_plan_idx_pp"].cpu().numpy(), noise[sc]["plan_idx_pp"])
+        assert np.array_equal(o["sampled_plan_idx_pr"].cpu().numpy(), noise[sc]["plan_idx_pr"])
+        if dtype == "fp32":             # the sampled action is a discontinuous function of the logits (argmax): exact draws only in fp32
+            for k in ("mae_pp", "mae_pr"):
+                assert np.abs(o[k] - fx[f"{k}_{sc}"].mean(0)).max() <= 2e-3, (sc, k, o[k], fx[f"{k}_{sc}"].mean(0))
+            for k in ("gripper_sr_pp", "gripper_sr_pr"):
+                assert abs(o[k] - float(fx[f"{k}_{sc}"])) <= 1e-6, (sc, k)
+        assert np.isfinite(o["pred_pp"].cpu().numpy()).all()
+
+
+def test_validate_device_draws_are_valid_and_reproducible():
+    dims, P, batch, noise, fx = load_val_case("val_hulc_tiny")
+    mb = batch["vis"]
+    B, S = mb["actions"].shape[:2]
+    eng = StepEngine(dims, B, S, dtype="fp32", device="cuda:0", seed=9)
+    eng.load_numpy(P)
+    d = _dev(mb)
+    a = eng.validate(d, False, None, want_pred=True)
+    b = eng.validate(d, False, None, want_pred=True)
+    eng.close()
+    idx = a["sampled_plan_idx_pp"].cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 32
+    assert torch.equal(a["pred_pp"], b["pred_pp"]) and a["action_loss_pp"] == b["action_loss_pp"]      # counter RNG: same step -> same draws
+    assert 0.0 <= a["gripper_sr_pp"] <= 1.0 and np.isfinite(a["mae_pr"]).all()
+
+
+def test_rollout_matches_reference_step():
+    dims, P, frames, nsteps, replan_freq, fx = load_rollout_case()
+    eng = StepEngine(dims, 1, 2, dtype="fp32", device="cuda:0", seed=3)
+    eng.load_numpy(P)
+    for mode in ("vis", "lang"):
+        mb = frames[mode]
+        t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+        goal = dict(rgb_static=t_(mb["rgb_static"][:, nsteps:nsteps + 1]), rgb_gripper=t_(mb["rgb_gripper"][:, nsteps:nsteps + 1])) if mode == "vis" \
+            else t_(frames["lang"]["lang"][0])
+        eng.rollout_reset()
+        for t in range(nsteps):
+            obs = dict(rgb_static=t_(mb["rgb_static"][:, t:t + 1]), rgb_gripper=t_(mb["rgb_gripper"][:, t:t + 1]), robot_obs_raw=t_(mb["robot_obs"][0, t]))
+            if t % replan_freq == 0:
+                plan = eng.rollout_plan(obs, goal, plan_idx=fx[f"plan_idx_{mode}"][t][0])
+                assert np.array_equal(plan.cpu().numpy(), fx[f"plan_idx_{mode}"][t][0])
+            a = eng.rollout_act(obs, u_mix=fx[f"u_mix_{mode}"][t][0, 0], u_act=fx[f"u_act_{mode}"][t][0, 0])
+            ref = fx[f"actions_{mode}"][0, t]
+            assert np.abs(a - ref).max() <= 2e-3, (mode, t, a, ref)
+    # error paths
+    eng.rollout_reset()
+    with pytest.raises(RuntimeError):
+        eng.rollout_act(obs)
+    eng.close()
