@@ -302,10 +302,78 @@ class Hulc(torch.nn.Module):
         self.global_step += 1
         return torch.tensor(total, dtype=torch.float32, device=eng.device)
 
-    def validation_step(self, batch, batch_idx):
-        raise NotImplementedError("validation / rollout forward (lmp_val, act, step) is SURVEY §8(f) row 2 — not built yet")
+    def validation_step(self, batch: Dict[str, Dict], batch_idx: int, noise: Optional[Dict[str, Dict]] = None) -> Dict[str, torch.Tensor]:
+        """hulc.py:739-841: per modality lmp_val (:301-388) + the logged reductions; eval-mode forward, no gradients.
+        `noise` (optional, tests): {scope: {plan_idx_pp, plan_idx_pr, u_mix_pp, u_act_pp, u_mix_pr, u_act_pr}} injected draws."""
+        if self.KIND != "hulc":
+            raise NotImplementedError("GCBC validation (gcbc.py:183-270) is not built")
+        eng = self.engine
+        output: Dict[str, torch.Tensor] = {}
+        val_total_act_loss_pp = 0.0
+        nmod = len(batch)
+        for self.modality_scope, dataset_batch in batch.items():
+            sc = self.modality_scope
+            is_lang = "lang" in sc
+            mb = self._modality_batch(dataset_batch, is_lang, eng.device)
+            mb["step"] = self.global_step * 131 + batch_idx
+            r = eng.validate(mb, is_lang, (noise or {}).get(sc))
+            val_total_act_loss_pp += r["action_loss_pp"]
+            mae_pp, mae_pr = r["mae_pp"], r["mae_pr"]
+            self.log(f"val_total_mae/{sc}_total_mae_pr", float(mae_pr.mean()), sync_dist=True)
+            self.log(f"val_total_mae/{sc}_total_mae_pp", float(mae_pp.mean()), sync_dist=True)
+            self.log(f"val_pos_mae/{sc}_pos_mae_pr", float(mae_pr[:3].mean()), sync_dist=True)
+            self.log(f"val_pos_mae/{sc}_pos_mae_pp", float(mae_pp[:3].mean()), sync_dist=True)
+            self.log(f"val_orn_mae/{sc}_orn_mae_pr", float(mae_pr[3:6].mean()), sync_dist=True)
+            self.log(f"val_orn_mae/{sc}_orn_mae_pp", float(mae_pp[3:6].mean()), sync_dist=True)
+            self.log(f"val_kl/{sc}_kl_loss", r["kl_loss"], sync_dist=True)
+            self.log(f"val_act/{sc}_act_loss_pp", r["action_loss_pp"], sync_dist=True)
+            self.log(f"val_act/{sc}_act_loss_pr", r["action_loss_pr"], sync_dist=True)
+            self.log(f"val_grip/{sc}_grip_sr_pr", r["gripper_sr_pr"], sync_dist=True)
+            self.log(f"val_grip/{sc}_grip_sr_pp", r["gripper_sr_pp"], sync_dist=True)
+            self.log("val_act/action_loss_pp", val_total_act_loss_pp / nmod, sync_dist=True)
+            one_hot = lambda idx: torch.nn.functional.one_hot(idx.long(), 32).to(torch.float32).reshape(idx.shape[0], -1)
+            output[f"sampled_plan_pp_{sc}"] = one_hot(r["sampled_plan_idx_pp"])     # (B, 1024) like distributions.py:37-41
+            output[f"sampled_plan_pr_{sc}"] = one_hot(r["sampled_plan_idx_pr"])
+            output[f"idx_{sc}"] = dataset_batch.get("idx")
+        return output
 
-    step = reset = load_lang_embeddings = validation_step
+    # ---- rollout (hulc.py:843-957) ---------------------------------------------------------------------------------
+    def reset(self):
+        """Call this at the beginning of a new rollout when doing inference (hulc.py:843-849)."""
+        self.plan = None
+        self.latent_goal = None
+        self.rollout_step_counter = 0
+        self.engine.rollout_reset()
+
+    def load_lang_embeddings(self, embeddings_path):
+        """hulc.py:871-879: <dataset>/validation/embeddings.npy -> {annotation sentence: 384-d embedding}."""
+        import numpy as np
+        embeddings = np.load(embeddings_path, allow_pickle=True).item()
+        self.lang_embeddings = {v["ann"][0]: v["emb"] for k, v in embeddings.items()}
+
+    @staticmethod
+    def _rollout_obs(obs: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+        return dict(rgb_static=obs["rgb_obs"]["rgb_static"], rgb_gripper=obs["rgb_obs"]["rgb_gripper"], robot_obs_raw=obs.get("robot_obs_raw"))
+
+    def step(self, obs, goal, noise: Optional[Dict] = None):
+        """One step of inference (hulc.py:851-869): replan every replan_freq steps from the plan proposal, then act.
+        obs: rgb_obs {rgb_static (1,1,3,200,200), rgb_gripper (1,1,3,84,84)}, robot_obs_raw (1,1,15); goal: a sentence (key of
+        load_lang_embeddings) or a dict with rgb_obs goal images.  Returns the (1,1,7) world-frame action."""
+        import numpy as np
+        noise = noise or {}
+        o = self._rollout_obs(obs)
+        if self.rollout_step_counter % self.replan_freq == 0:
+            if isinstance(goal, str):
+                if self.lang_embeddings is None:
+                    raise RuntimeError("call load_lang_embeddings() before stepping with a language goal (hulc.py:871)")
+                g = torch.from_numpy(np.asarray(self.lang_embeddings[goal], np.float32)).reshape(-1)
+            else:
+                g = dict(rgb_static=goal["rgb_obs"]["rgb_static"], rgb_gripper=goal["rgb_obs"]["rgb_gripper"])
+            self.plan = self.engine.rollout_plan(o, g, plan_idx=noise.get("plan_idx"))
+            self.latent_goal = True
+        action = self.engine.rollout_act(o, u_mix=noise.get("u_mix"), u_act=noise.get("u_act"))
+        self.rollout_step_counter += 1
+        return torch.from_numpy(action).reshape(1, 1, 7)
 
 
 class GCBC(Hulc):

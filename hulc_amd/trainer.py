@@ -55,6 +55,15 @@ class SyntheticDataModule:
             g.manual_seed(self.seed + 1000 * rank + i)
             yield {m: self._modality("lang" in m, g) for m in self.modalities}
 
+    val_batches = 1
+
+    def val_dataloader(self, rank: int = 0):
+        """Validation batches (validation_step, hulc.py:739-841): same shapes, a fixed seed disjoint from the training ones."""
+        g = torch.Generator(device=self.device)
+        for i in range(self.val_batches):
+            g.manual_seed(self.seed * 7919 + 17 + 1000 * rank + i)
+            yield {m: self._modality("lang" in m, g) for m in self.modalities}
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 class KLConstantSchedule:
@@ -117,8 +126,10 @@ def get_last_checkpoint(log_dir: str) -> Optional[str]:
 # ---------------------------------------------------------------------------------------------------------------------
 class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_dir: str = "./runs", callbacks: Optional[List] = None,
-                 log_every: int = 10, **_unused):
+                 log_every: int = 10, limit_val_batches: Optional[int] = None, check_val_every_n_epoch: int = 1, **_unused):
         self.max_epochs, self.max_steps, self.log_dir = int(max_epochs), int(max_steps), log_dir
+        self.limit_val_batches, self.check_val_every_n_epoch = limit_val_batches, max(1, int(check_val_every_n_epoch or 1))
+        self.val_history: List[Dict[str, float]] = []
         self.callbacks = callbacks or []
         self.log_every = log_every
         self.current_epoch = 0
@@ -126,6 +137,26 @@ class Trainer:
         self.rank, self.world, self.local = 0, 1, 0
         self.optimizer = None
         self.history: List[Dict[str, float]] = []
+
+    def validate(self, module, datamodule) -> Dict[str, float]:
+        """Lightning's validation loop for this module: eval mode, validation_step over the val batches, mean of every `val*` metric."""
+        if not hasattr(datamodule, "val_dataloader") or getattr(module, "KIND", "hulc") != "hulc":
+            return {}
+        module.eval()
+        sums: Dict[str, float] = {}
+        n = 0
+        for bi, batch in enumerate(datamodule.val_dataloader(self.rank)):
+            if self.limit_val_batches is not None and bi >= self.limit_val_batches:
+                break
+            module.validation_step(batch, bi)
+            for k, v in module.logged.items():
+                if k.startswith("val"):
+                    sums[k] = sums.get(k, 0.0) + float(v)
+            n += 1
+        module.train()
+        out = {k: parallel.mean_scalar(v / max(n, 1), device=module.device) for k, v in sums.items()}
+        self.val_history.append(out)
+        return out
 
     def fit(self, module, datamodule, ckpt_path: Optional[str] = None):
         self.rank, self.world, self.local = parallel.init_from_env()
@@ -158,6 +189,8 @@ class Trainer:
                 if 0 < self.max_steps <= self.global_step:
                     done = True
                     break
+            if (self.current_epoch + 1) % self.check_val_every_n_epoch == 0 and self.limit_val_batches != 0 and not done:
+                self.validate(module, datamodule)                             # Lightning: validation loop at the end of the epoch
             for cb in self.callbacks:
                 if hasattr(cb, "on_train_epoch_end"):
                     cb.on_train_epoch_end(self, module)
