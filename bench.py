@@ -33,10 +33,12 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_WINDOW_S32 = 13.02e9   # fwd+bwd algorithmic FLOPs per window at S=32
 
 
-def synth_batch(B, S, dev, seed, lang=False):
+def synth_batch(B, S, dev, seed, lang=False, ingest="fp32"):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     def u8img(h):
+        if ingest == "u8":      # dataset layout: uint8 (B,S,H,W,C); scale / normalise / RandomShiftsAug run inside conv1's load path
+            return torch.randint(0, 256, (B, S, h, h, 3), device=dev, generator=g, dtype=torch.int32).to(torch.uint8).contiguous()
         u = torch.randint(0, 256, (B, S, 3, h, h), device=dev, generator=g, dtype=torch.int32).float()
         return ((u / 255.0 - 0.5) / 0.5).contiguous()
     act = torch.rand(B, S, 7, device=dev, generator=g) * 2 - 1
@@ -46,6 +48,9 @@ def synth_batch(B, S, dev, seed, lang=False):
     ro = torch.randn(B, S, 15, device=dev, generator=g) * 0.3
     ro[..., 3:6] = torch.rand(B, S, 3, device=dev, generator=g) * 2 - 1
     mb = dict(rgb_static=u8img(200), rgb_gripper=u8img(84), actions=act.contiguous(), robot_obs=ro.contiguous())
+    if ingest == "u8":
+        mb.update(shift_static=torch.randint(0, 21, (B * S, 2), device=dev, generator=g, dtype=torch.int32), pad_static=10,
+                  shift_gripper=torch.randint(0, 9, (B * S, 2), device=dev, generator=g, dtype=torch.int32), pad_gripper=4)
     if lang:
         l = torch.randn(B, 384, device=dev, generator=g)
         mb["lang"] = (l / l.norm(dim=-1, keepdim=True)).contiguous()
@@ -89,6 +94,9 @@ def main():
     ap.add_argument("--seq", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--lang", type=int, default=0, help="1: 32 vis + 32 lang per GPU with CLIP aux loss (config 3)")
+    ap.add_argument("--ingest", default="fp32", choices=["fp32", "u8"],
+                    help="fp32: the reference's boundary (transformed fp32 NCHW frames, the headline); u8: uint8 HWC dataset frames, "
+                         "scale/normalise/RandomShiftsAug fused into conv1 (SURVEY §8(f) row 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,9 +116,9 @@ def main():
     Bmod = B // 2 if args.lang else B
     eng = StepEngine(dims, Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.1, seed=42)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
-    mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False))]
+    mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest))]
     if args.lang:
-        mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True)))
+        mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest)))
     nmod = len(mods)
 
     def step(i):
@@ -191,9 +199,10 @@ def main():
             "metric": "trajectory-windows/sec (seq_len=%d, bs=%d/GPU)" % (S, B), "value": round(wps, 2), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "HULC training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper fp32 NCHW frames, "
+            "config": {"workload": "HULC training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper %s frames, "
                                    "fwd+loss+bwd+%sAdam, dropout 0.1" % ("32 vis + 32 lang + CLIP aux" if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
-                                                                        B, S, "RCCL all-reduce+" if world > 1 else ""),
+                                                                        B, S, "uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" if args.ingest == "u8" else "fp32 NCHW",
+                                                                        "RCCL all-reduce+" if world > 1 else ""),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "last_losses": {"total_mod": loss[0], "kl": loss[1], "action": loss[2], "clip": loss[3]},
             "model_flops_per_window": FLOP_PER_WINDOW_S32 * S / 32.0,

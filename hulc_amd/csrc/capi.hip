@@ -136,7 +136,7 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     int ns;
     if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, (const float*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, Conv1Src{X, nullptr, 0, 0}, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
     hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);
     hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
@@ -157,7 +157,12 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);
     else if (mode == 2) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
     else if (mode == 3) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
-    else if (mode == 4) { launch_conv1_fwd(st, (const float*)img, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH, OUTH, relu & ~1); ok = true; }
+    else if (mode == 4) { launch_conv1_fwd(st, Conv1Src{img, nullptr, 0, 0}, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH, OUTH, relu & ~1); ok = true; }
+    else if (mode == 5 || mode == 6) {      // conv1 forward from uint8 NHWC frames; mode 6: `mask` = (Nf,2) int32 RandomShiftsAug shifts, pad 10 (IMH >= 100) or 4
+        launch_conv1_fwd(st, Conv1Src{img, mode == 6 ? (const int*)mask : nullptr, 1, IMH >= 100 ? 10 : 4}, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH,
+                         OUTH, relu & ~1);
+        ok = true;
+    }
     if (!ok) { hulc_set_error("hulc_k_conv_tile: unsupported mode/shape"); return 1; }
     if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_conv_tile: launch failed"); return 1; }
     return 0;

@@ -289,7 +289,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 // of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
 // x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(Conv1Src X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* ximg = (lds_char*)smem;
@@ -315,29 +315,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         const int ih0 = oh0 * 4;
         const int rows = min(XR, IH - ih0);
         __syncthreads();
-        if (!(dbg & 4)) {
-            const int plane = rows * W4;                                  // float4 per channel plane of this band (contiguous in HBM)
-            for (int c = 0; c < 3; ++c) {
-                const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
-                for (int q0 = tid; q0 < plane; q0 += 256 * 8) {          // 8 unconditional (clamped) 16-byte loads in flight per thread
-                    float4 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)min(q0 + u * 256, plane - 1) * 4);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int q = q0 + u * 256;
-                        if (q < plane) {
-                            const int rr = q / W4, x4 = q - rr * W4;
-                            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                            u32x2_t o;
-                            o[0] = pack2bf(v[u].x, v[u].y);
-                            o[1] = pack2bf(v[u].z, v[u].w);
-                            *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + x4 * 8) = o;
-                        }
-                    }
-                }
-            }
-        }
+        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
         __syncthreads();
         const int RBe = min(R, OH - oh0);
         const int npix = RBe * OW;
@@ -392,8 +370,8 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         }
     }
 }
-static inline void launch_conv1_fwd(hipStream_t st, const float* X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0) {
-    auto lds_of = [&](int R) { return (size_t)3 * ((R - 1) * 4 + 8) * (IW * 2 + 16) + 64; };
+static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0) {
+    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = getenv("HULC_C1_WG") ? atoi(getenv("HULC_C1_WG")) : 1024;
     int R = OH;

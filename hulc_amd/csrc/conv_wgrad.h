@@ -365,6 +365,156 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv1 input band staging, shared by conv1_fwd_kernel and conv1_wgrad_tr_kernel: rows [ih0, ih0+rows) of frame f as a bf16
+// [c][row][iw] LDS image.  Two boundary formats:
+//   * fp32 NCHW frames already transformed by the reference's dataloader (hulc.py:395-414) — the reference boundary;
+//   * uint8 (.., H, W, C) frames straight from the dataset: ScaleImageTensor (x/255), Normalize(0.5, 0.5)
+//     and RandomShiftsAug (hulc/utils/transforms.py:8-29: replicate-pad by `pad`, one integer shift per frame; the bilinear
+//     grid_sample lands on pixel centres, i.e. out[y][x] = in[clamp(y + sy - pad)][clamp(x + sx - pad)]) are fused into this load —
+//     4x fewer input bytes and no fp32 copy of the frames ever exists.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CONV1_RAW_MARGIN 16          // replicated edge pixels each side of a raw uint8 row (>= the largest RandomShiftsAug pad; 48 bytes)
+static inline __host__ __device__ int conv1_raw_pitch(int IW) { return ((IW + 2 * CONV1_RAW_MARGIN) * 3 + 8 + 7) & ~7; }   // bytes per raw row (+8: the 16-byte read window)
+struct Conv1Src {
+    const void* X;         // fp32 NCHW (u8 == 0) or uint8 NHWC (u8 == 1)
+    const int* shift;      // u8 only: [Nf][2] = (sx, sy) in [0, 2*pad], or null (no augmentation)
+    int u8, pad;
+};
+DEVI float u8_to_unit(unsigned char b) { return ((float)b / 255.f - 0.5f) / 0.5f; }    // ScaleImageTensor then Normalize(mean .5, std .5)
+// element e = tid + m*256 of a [rows][n] grid, m = 0, 1, ...: (row, col) advanced incrementally — a runtime integer division per
+// element (~35 VALU instructions) made the staging VALU-bound (one division per load AND per store, 3 channels, every band)
+struct RowCol { int r, c; };
+struct Step256 {
+    int n, dq, dr;
+    DEVI explicit Step256(int n_) : n(n_), dq(256 / n_), dr(256 % n_) {}
+    DEVI void adv(RowCol& p) const { p.c += dr; p.r += dq; if (p.c >= n) { p.c -= n; ++p.r; } }
+};
+DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const int W4 = IW >> 2;                                           // 4-pixel groups per row
+    const Step256 sq(W4);
+    const RowCol q0{tid / W4, tid % W4};
+    if (!s.u8) {
+        const float* X = reinterpret_cast<const float*>(s.X);
+        for (int c = 0; c < 3; ++c) {
+            const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
+            lds_char* dst = ximg + c * XR * XRS;
+            RowCol p = q0;
+            while (p.r < rows) {                                      // 8 unconditional (clamped) 16-byte loads in flight per thread
+                RowCol e[8];
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    e[u] = p; sq.adv(p);
+                    const bool in = e[u].r < rows;
+                    v[u] = *reinterpret_cast<const float4*>(src + ((long long)(in ? e[u].r : rows - 1) * W4 + (in ? e[u].c : W4 - 1)) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (e[u].r < rows) {
+                        u32x2_t o;
+                        o[0] = pack2bf(v[u].x, v[u].y);
+                        o[1] = pack2bf(v[u].z, v[u].w);
+                        *(__attribute__((address_space(3))) u32x2_t*)(dst + e[u].r * XRS + e[u].c * 8) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // uint8: (A) the band's source rows (row clamp of the replicate pad applied) are copied with 8- or 4-byte loads into `raw`, each
+    // row behind a margin of CONV1_RAW_MARGIN replicated edge pixels — byte-wide global loads cost a full wave instruction per
+    // 64 bytes and made a first version as slow as the 4x larger fp32 path; (B) a 4-pixel group is 12 contiguous bytes of a raw row
+    // at a (shift-dependent) unaligned offset: four aligned LDS dwords, v_alignbyte, v_cvt_f32_ubyteN, one FMA per value
+    // (b * 2/255 - 1: within one fp32 ulp of the reference's (b/255 - .5)/.5, which the fp32-mode ingest_u8_kernel keeps exactly).
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(s.X) + (long long)f * IH * IW * 3;
+    int dx = 0, dy = 0;
+    if (s.shift) { dx = s.shift[2 * f] - s.pad; dy = s.shift[2 * f + 1] - s.pad; }
+    const int RB = IW * 3;                                            // bytes per source row (multiple of 4: IW % 4 == 0)
+    const int RP = conv1_raw_pitch(IW);
+    constexpr int LM = CONV1_RAW_MARGIN * 3;                          // byte offset of pixel 0 in a raw row (multiple of 8)
+    if ((RB & 7) == 0 && ((uintptr_t)base & 7) == 0) {
+        typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+        constexpr int NU = 10;                                        // the whole band in one round of loads per thread
+        const int n8 = RB >> 3;
+        const Step256 s8(n8);
+        RowCol p{tid / n8, tid % n8};
+        while (p.r < rows) {
+            RowCol e[NU];
+            u32x2v v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                e[u] = p; s8.adv(p);
+                const bool in = e[u].r < rows;
+                v[u] = *reinterpret_cast<const u32x2v*>(base + (long long)min(max(ih0 + (in ? e[u].r : rows - 1) + dy, 0), IH - 1) * RB + (in ? e[u].c : 0) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (e[u].r < rows) *(__attribute__((address_space(3))) u32x2v*)(raw + e[u].r * RP + LM + e[u].c * 8) = v[u];
+        }
+    } else {
+        constexpr int NU = 8;
+        const int n4 = RB >> 2;
+        const Step256 s4(n4);
+        RowCol p{tid / n4, tid % n4};
+        while (p.r < rows) {
+            RowCol e[NU];
+            unsigned v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                e[u] = p; s4.adv(p);
+                const bool in = e[u].r < rows;
+                v[u] = *reinterpret_cast<const unsigned*>(base + (long long)min(max(ih0 + (in ? e[u].r : rows - 1) + dy, 0), IH - 1) * RB + (in ? e[u].c : 0) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (e[u].r < rows) *(__attribute__((address_space(3))) unsigned*)(raw + e[u].r * RP + LM + e[u].c * 4) = v[u];
+        }
+    }
+    if (dx != 0) {                                                    // replicate margins (F.pad(..., "replicate")): one thread per (row, side)
+        for (int i = tid; i < rows * 2; i += 256) {
+            const int rr = i >> 1, side = i & 1;
+            const unsigned char* rp = base + (long long)min(max(ih0 + rr + dy, 0), IH - 1) * RB;
+            const unsigned w = *reinterpret_cast<const unsigned*>(rp + (side ? RB - 4 : 0));
+            const unsigned px = side ? (w >> 8) : (w & 0xffffffu);    // the edge pixel's 3 bytes
+            lds_char* dst = raw + rr * RP + (side ? LM + RB : 0);
+            for (int k = 0; k < CONV1_RAW_MARGIN; ++k) {
+                dst[k * 3 + 0] = (char)(px & 0xff); dst[k * 3 + 1] = (char)((px >> 8) & 0xff); dst[k * 3 + 2] = (char)((px >> 16) & 0xff);
+            }
+        }
+    }
+    __syncthreads();
+    const float sc = 2.f / 255.f;
+    for (RowCol p = q0; p.r < rows; sq.adv(p)) {
+        const int o = p.r * RP + LM + (p.c * 4 + dx) * 3;             // |dx| <= pad <= CONV1_RAW_MARGIN: stays inside the margins
+        const int sh = o & 3;
+        const __attribute__((address_space(3))) unsigned* wp = (const __attribute__((address_space(3))) unsigned*)(raw + (o & ~3));
+        const unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+        const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u32x2_t ov;
+            ov[0] = pack2bf(v[c], v[3 + c]);
+            ov[1] = pack2bf(v[6 + c], v[9 + c]);
+            *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + p.r) * XRS + p.c * 8) = ov;
+        }
+    }
+}
+// the same transform materialised as fp32 NCHW frames (fp32 parity mode, tests): out[f][c][y][x]
+__global__ void ingest_u8_kernel(const unsigned char* __restrict__ in, const int* __restrict__ shift, int pad, int Nf, int IH, int IW, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Nf * 3 * IH * IW) return;
+    const int x = (int)(idx % IW), y = (int)((idx / IW) % IH), c = (int)((idx / ((long long)IW * IH)) % 3), f = (int)(idx / ((long long)3 * IW * IH));
+    int dx = 0, dy = 0;
+    if (shift) { dx = shift[2 * f] - pad; dy = shift[2 * f + 1] - pad; }
+    const int sy = min(max(y + dy, 0), IH - 1), sx = min(max(x + dx, 0), IW - 1);
+    out[idx] = u8_to_unit(in[(((long long)f * IH + sy) * IW + sx) * 3 + c]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // conv1 (8x8 stride 4, 3 -> 32 channels) weight gradient straight from the fp32 NCHW boundary frames.
 //   dW[co][(c,kh,kw)] = sum dY[n][oh][ow][co] * X[n][c][oh*4+kh][ow*4+kw]
 // The X band is converted to bf16 while it is staged ([c][row][iw] image), dY is staged as [pix][32]; an n-tile of 16 packed
@@ -373,14 +523,14 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf
 struct Wgrad1Cfg {
     static constexpr int CO = 32, KH = 8, KW = 8, S = 4, C = 3;
     static constexpr int DYS = CO * 2 + 16;
-    static size_t lds_bytes(int R, int IW, int OW) {
+    static size_t lds_bytes(int R, int IW, int OW, bool u8 = false) {
         const int OWp = (OW + 7) / 8 * 8;
         const int XR = (R - 1) * S + KH;
-        return (size_t)C * XR * (IW * 2 + 16) + 512 + (size_t)(R * OWp + 8) * DYS;
+        return (size_t)C * XR * (IW * 2 + 16) + 512 + (size_t)(R * OWp + 8) * DYS + (u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0);   // + raw uint8 rows
     }
 };
 
-__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, const bf16_t* __restrict__ dY, float* __restrict__ part,
                                                                 float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = Wgrad1Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -423,30 +573,9 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
                     }
                 }
             }
-            {   // X band: fp32 NCHW rows -> bf16 [c][row][iw], one (c,row) per wave pass
+            {   // X band -> bf16 [c][row][iw]
                 const int ih0 = oh0 * C::S;
-                const int rows = min(XR, IH - ih0);
-                const int plane = rows * W4;                                  // float4 per channel plane of this band (contiguous in HBM)
-                for (int c = 0; c < 3; ++c) {
-                    const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
-                    for (int q0 = tid; q0 < plane; q0 += 256 * 8) {          // 8 unconditional (clamped) 16-byte loads in flight per thread
-                        float4 v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)min(q0 + u * 256, plane - 1) * 4);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int q = q0 + u * 256;
-                            if (q < plane) {
-                                const int rr = q / W4, x4 = q - rr * W4;
-                                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                                u32x2_t o;
-                                o[0] = pack2bf(v[u].x, v[u].y);
-                                o[1] = pack2bf(v[u].z, v[u].w);
-                                *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + rr) * XRS + x4 * 8) = o;
-                            }
-                        }
-                    }
-                }
+                conv1_stage_band(X, f, ih0, min(XR, IH - ih0), IH, IW, ximg, XR, XRS, tid, dyimg + dypix * C::DYS);
             }
             __syncthreads();
             const int units = R * U;
@@ -491,14 +620,14 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(const float* __r
     }
 }
 
-static inline int launch_conv1_wgrad_tr(hipStream_t st, const float* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
+static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks) {
     static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
     static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
     if (env_wg > 0) max_blocks = env_wg;
     int R = OH;
-    while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW) > (size_t)lds_kb * 1024) --R;
-    const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW);
+    while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW, X.u8) > (size_t)lds_kb * 1024) --R;
+    const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW, X.u8);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv1_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

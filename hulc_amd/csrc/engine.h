@@ -533,13 +533,33 @@ struct Engine : IEngine {
     ConvGeom geom(int Nf, int IH, int C, int K, int S) const {
         ConvGeom g; g.Nf = Nf; g.IH = g.IW = IH; g.C = C; g.KH = g.KW = K; g.S = S; g.OH = g.OW = (IH - K) / S + 1; return g;
     }
-    void enc_fwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
+    // conv1 input of the current batch: the reference's fp32 NCHW frames, or uint8 NHWC frames + the fused dataloader transforms
+    Conv1Src conv1_src(const hulc_batch& b, bool gripper) const {
+        Conv1Src s;
+        s.X = gripper ? b.rgb_gripper : b.rgb_static;
+        s.u8 = b.frames_u8 != 0;
+        s.shift = s.u8 ? (gripper ? b.shift_gripper : b.shift_static) : nullptr;
+        s.pad = gripper ? b.pad_gripper : b.pad_static;
+        return s;
+    }
+    float* x32[2] = {nullptr, nullptr};       // fp32 (parity) mode + uint8 ingest: the transformed frames are materialised once per step
+    const float* conv1_f32(const Conv1Src& src, bool gripper, int Nf, int IH) {
+        if (!src.u8) return reinterpret_cast<const float*>(src.X);
+        float*& buf = x32[gripper ? 1 : 0];
+        if (!buf) buf = alloc<float>((int64_t)maxN * 3 * IH * IH);
+        const long long n = (long long)Nf * 3 * IH * IH;
+        hipLaunchKernelGGL(ingest_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(src.X), src.shift, src.pad, Nf, IH, IH, buf);
+        return buf;
+    }
+    void enc_fwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0) {
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
+        const float* x = nullptr;
         if constexpr (std::is_same<T, bf16_t>::value) {
             const double px = (double)Nf * g1.OH * g1.OW;
-            TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)Nf * 3 * e.IH * e.IH * 4 + px * 32 * 2);
-            launch_conv1_fwd(st, x, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW);
+            TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)Nf * 3 * e.IH * e.IH * (src.u8 ? 1 : 4) + px * 32 * 2);
+            launch_conv1_fwd(st, src, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW);
         } else {
+            x = conv1_f32(src, e.gripper, Nf, e.IH);
             Conv1Loader<T> l{x, g1};
             EpiP ep = epi(a.a1, false); ep.bias = e.c1.b32; ep.relu = 1;
             launch_gemm<T, 128, 32>(st, l, dense<T>(e.c1.Wf, 32, 192), dense_out(32), ep, Nf * g1.OH * g1.OW, 32, 192);
@@ -578,6 +598,7 @@ struct Engine : IEngine {
         { EpiP ep = epi(a.f2, true); lin_fwd(a.f1, 512, Nf, e.fc2, ep, 64); }
         ln_fwd(a.f2, 64, Nf, 64, e.lng, e.lnb, emb + col0, EMB, nullptr, 0, a.lnst);
     }
+    Conv1Src wgrad_src;                       // conv1 only: set by enc_bwd before conv_wgrad(e.c1, ...)
     void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {
         const int Kc = c.I * c.KH * c.KW;
         const long long npix = (long long)g.Nf * g.OH * g.OW;
@@ -585,9 +606,9 @@ struct Engine : IEngine {
         if constexpr (std::is_same<T, bf16_t>::value) {
             // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
-                          conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * 4 + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
+                          conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * (wgrad_src.u8 ? 1 : 4) + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
-                nsplit = launch_conv1_wgrad_tr(st, (const float*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024);
+                nsplit = launch_conv1_wgrad_tr(st, wgrad_src, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024);
             else if (!conv1 && c.I == 64 && c.KH == 3)
                 nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
             else if (!conv1 && c.I == 32 && c.KH == 4)
@@ -651,7 +672,10 @@ struct Engine : IEngine {
         O o; int zc;
         DEVI long long offset(int r, int) const { return o.offset(r, zc); }
     };
-    void enc_bwd(const EncW& e, EncA& a, const float* x, int Nf, int col0) {
+    void enc_bwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0) {
+        wgrad_src = src;
+        const float* x = nullptr;
+        if constexpr (std::is_same<T, float>::value) x = src.u8 ? x32[e.gripper ? 1 : 0] : reinterpret_cast<const float*>(src.X);   // materialised by the forward
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
         // LN bwd on demb[:, col0:col0+64]
         ln_bwd(demb + col0, EMB, a.f2, 64, a.lnst, e.lng, Nf, 64, nullptr, 0, 0, d_f2t, 64, e.dlng, e.dlnb);
@@ -718,9 +742,9 @@ struct Engine : IEngine {
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         (void)dp;
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
-        enc_fwd(encS, aS, b->rgb_static, N, 0);
+        enc_fwd(encS, aS, conv1_src(*b, false), N, 0);
         STAGE("enc_static_fwd");
-        enc_fwd(encG, aG, b->rgb_gripper, N, 64);
+        enc_fwd(encG, aG, conv1_src(*b, true), N, 64);
         STAGE("enc_gripper_fwd");
         // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
         {
@@ -966,8 +990,8 @@ struct Engine : IEngine {
         hulc_batch bb; memset(&bb, 0, sizeof(bb));
         bb.B = 1; bb.S = 1; bb.step = roll_counter++;
         cur = bb;
-        enc_fwd(encS, aS, obs->rgb_static, 1, 0);
-        enc_fwd(encG, aG, obs->rgb_gripper, 1, 64);
+        enc_fwd(encS, aS, Conv1Src{obs->rgb_static, nullptr, 0, 0}, 1, 0);
+        enc_fwd(encG, aG, Conv1Src{obs->rgb_gripper, nullptr, 0, 0}, 1, 64);
         HIP_CHECK(hipMemcpyAsync(goal_t, roll_goal, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
         dec_fwd(roll_plan, 1, 1, roll_has_h ? roll_h0 : nullptr, roll_has_h ? roll_h1 : nullptr);
         HIP_CHECK(hipMemcpyAsync(roll_h0, H0, sizeof(T) * HID, hipMemcpyDeviceToDevice, st));
@@ -1159,9 +1183,9 @@ struct Engine : IEngine {
         }
     encoders:
         // ---- encoders backward
-        enc_bwd(encS, aS, b->rgb_static, N, 0);
+        enc_bwd(encS, aS, conv1_src(*b, false), N, 0);
         STAGE("enc_static_bwd");
-        enc_bwd(encG, aG, b->rgb_gripper, N, 64);
+        enc_bwd(encG, aG, conv1_src(*b, true), N, 64);
         STAGE("enc_gripper_bwd");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;

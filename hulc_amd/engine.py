@@ -76,6 +76,20 @@ class StepEngine:
         L.check(self.lib.hulc_zero_grads(self.ctx))
 
     # ---- step pieces ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ingest_fields(mb: Dict, ptr) -> Dict:
+        """uint8 (B,S,H,W,C) frames select the fused ingest path (include/hulc_hip.h: frames_u8); optional per-frame RandomShiftsAug
+        shifts `shift_static` / `shift_gripper` (B*S,2) int32 in [0, 2*pad] with pads `pad_static` (10) / `pad_gripper` (4)."""
+        if mb["rgb_static"].dtype != torch.uint8:
+            return {}
+        if mb["rgb_gripper"].dtype != torch.uint8 or mb["rgb_static"].shape[-1] != 3 or mb["rgb_gripper"].shape[-1] != 3:
+            raise ValueError("uint8 ingest expects both cameras as uint8 (B,S,H,W,3) tensors")
+        f = dict(frames_u8=1, pad_static=int(mb.get("pad_static", 10)), pad_gripper=int(mb.get("pad_gripper", 4)))
+        for k in ("shift_static", "shift_gripper"):
+            if mb.get(k) is not None:
+                f[k] = ptr(mb[k].to(torch.int32))
+        return f
+
     def forward_loss(self, mb: Dict, is_lang: bool, loss_weight: float, clip_weight: float, step: int = 0,
                      sync_losses: bool = True):
         """mb: device tensors rgb_static (B,S,3,200,200) f32, rgb_gripper, actions, robot_obs(15), [lang], [plan_idx int32],
@@ -90,7 +104,8 @@ class StepEngine:
 
         b = L.HulcBatch(B=B, S=S, is_lang=int(is_lang), rgb_static=ptr(mb["rgb_static"]), rgb_gripper=ptr(mb["rgb_gripper"]),
                         actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
-                        plan_idx=ptr(mb["plan_idx"]) if mb.get("plan_idx") is not None else None, aux_rows=None, n_aux=0, step=step)
+                        plan_idx=ptr(mb["plan_idx"]) if mb.get("plan_idx") is not None else None, aux_rows=None, n_aux=0, step=step,
+                        **self._ingest_fields(mb, ptr))
         if is_lang and mb.get("aux_rows") is not None and len(mb["aux_rows"]) > 0:
             rows = np.ascontiguousarray(mb["aux_rows"], np.int32)
             keep.append(rows)
@@ -133,7 +148,7 @@ class StepEngine:
 
         b = L.HulcBatch(B=B, S=S, is_lang=int(is_lang), rgb_static=ptr(mb["rgb_static"]), rgb_gripper=ptr(mb["rgb_gripper"]),
                         actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
-                        plan_idx=None, aux_rows=None, n_aux=0, step=int(mb.get("step", 0)))
+                        plan_idx=None, aux_rows=None, n_aux=0, step=int(mb.get("step", 0)), **self._ingest_fields(mb, ptr))
         noise = noise or {}
         nz = L.HulcValNoise(**{k: self._dev_or_host_ptr(noise.get(k), keep, np.int32 if k.startswith("plan") else np.float32)
                                for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")})

@@ -21,7 +21,9 @@ class HulcConfig(C.Structure):
 class HulcBatch(C.Structure):
     _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("is_lang", C.c_int32), ("rgb_static", C.c_void_p),
                 ("rgb_gripper", C.c_void_p), ("actions", C.c_void_p), ("robot_obs", C.c_void_p), ("lang", C.c_void_p),
-                ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64)]
+                ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64),
+                ("frames_u8", C.c_int32), ("pad_static", C.c_int32), ("pad_gripper", C.c_int32), ("shift_static", C.c_void_p),
+                ("shift_gripper", C.c_void_p)]
 
 
 class HulcValNoise(C.Structure):

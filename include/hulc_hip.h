@@ -53,8 +53,8 @@ typedef struct hulc_config {
 typedef struct hulc_batch {
     int32_t B, S;                /* windows, window length */
     int32_t is_lang;             /* 0: 'vis' modality (visual goal = emb[:, -1]); 1: 'lang' modality */
-    const float* rgb_static;     /* (B,S,3,200,200) fp32 NCHW in [-1,1]   hulc.py:398 */
-    const float* rgb_gripper;    /* (B,S,3,84,84)   fp32 NCHW */
+    const void* rgb_static;      /* (B,S,3,200,200) fp32 NCHW in [-1,1]   hulc.py:398   (or uint8 (B,S,200,200,3), see frames_u8) */
+    const void* rgb_gripper;     /* (B,S,3,84,84)   fp32 NCHW                           (or uint8 (B,S,84,84,3)) */
     const float* actions;        /* (B,S,7) relative actions, last = +-1 gripper */
     const float* robot_obs;      /* (B,S,15) state_info.robot_obs (raw; euler angles in [3:6]) */
     const float* lang;           /* (B,384) language embedding, lang modality only */
@@ -62,6 +62,15 @@ typedef struct hulc_batch {
     const int32_t* aux_rows;     /* HOST: indices b with use_for_aux_lang_loss[b] != 0 (lang modality, clip loss) */
     int32_t n_aux;
     uint64_t step;               /* optimizer step index, mixed into the dropout / sampling seeds */
+    /* ---- uint8 ingest (zero-initialise for the reference's fp32 boundary) ------------------------------
+     * frames_u8 != 0: rgb_static / rgb_gripper point to uint8 (B,S,H,W,C) frames as stored in the dataset; the dataloader transforms of
+     * conf/datamodule/transforms/rand_shift.yaml — ScaleImageTensor (x/255), Normalize(0.5, 0.5) and RandomShiftsAug
+     * (hulc/utils/transforms.py:8-29; pad 10 / 4) — are applied inside conv1's load path (bf16 mode) instead of on the CPU.
+     * shift_*: (B*S,2) int32 (sx, sy) in [0, 2*pad] per frame, device memory; NULL = no augmentation (the validation transforms). */
+    int32_t frames_u8;
+    int32_t pad_static, pad_gripper;
+    const int32_t* shift_static;
+    const int32_t* shift_gripper;
 } hulc_batch;
 
 /* out_losses (device or host pointer, see `losses_on_host`): [total_mod, kl_scaled, action, clip] of this modality,

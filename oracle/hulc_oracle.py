@@ -524,6 +524,35 @@ def decoder_loss_bwd(P, G, c, dims, scale):
 # KL (hulc.py:539-561), straight-through sample (distributions.py:23-27), CLIP aux (hulc.py:650-695)
 # ----------------------------------------------------------------------------------------------------
 # ----------------------------------------------------------------------------------------------------
+# dataloader image transforms: uint8 HWC frames -> the fp32 NCHW tensors the step consumes
+# ----------------------------------------------------------------------------------------------------
+def random_shifts_aug(x, shift, pad):
+    """hulc/utils/transforms.py:8-29 (RandomShiftsAug.forward) for given integer draws.  x (n,c,h,w) float, shift (n,2) = the
+    torch.randint(0, 2*pad+1) draws (column 0 shifts x / width, column 1 shifts y / height).  The replicate-padded image is sampled
+    by grid_sample on a grid that lands on pixel centres, so out[y][x] = padded[y + sy][x + sx] = in[clamp(y+sy-pad)][clamp(x+sx-pad)]."""
+    n, c, h, w = x.shape
+    out = np.empty_like(x)
+    ys, xs = np.arange(h), np.arange(w)
+    for i in range(n):
+        sy = np.clip(ys + int(shift[i, 1]) - pad, 0, h - 1)
+        sx = np.clip(xs + int(shift[i, 0]) - pad, 0, w - 1)
+        out[i] = x[i][:, sy][:, :, sx]
+    return out
+
+
+def ingest_u8(frames, shift=None, pad=0):
+    """conf/datamodule/transforms/rand_shift.yaml (train: rgb_static / rgb_gripper): uint8 (B,S,H,W,C) ->
+    RandomShiftsAug(pad) [skipped when shift is None: the `val` transforms] -> ScaleImageTensor (x/255) -> Normalize(0.5, 0.5);
+    returns fp32 (B,S,C,H,W) in [-1,1]."""
+    B, S, H, W, C = frames.shape
+    x = np.transpose(frames.reshape(B * S, H, W, C), (0, 3, 1, 2)).astype(F32)
+    if shift is not None:
+        x = random_shifts_aug(x, np.asarray(shift).reshape(B * S, 2), pad)
+    x = ((x / F32(255.0) - F32(0.5)) / F32(0.5)).astype(F32)
+    return x.reshape(B, S, C, H, W)
+
+
+# ----------------------------------------------------------------------------------------------------
 # validation / rollout forward (SURVEY.md §8 row a20): forward-only, stochastic draws injected
 # ----------------------------------------------------------------------------------------------------
 def tcp_to_world_frame(action, robot_obs):

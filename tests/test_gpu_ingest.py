@@ -1,0 +1,71 @@
+"""GPU, through the C-ABI: the uint8 (B,S,H,W,C) ingest path (SURVEY.md §8(f) row 1 — ScaleImageTensor + Normalize + RandomShiftsAug
+fused into conv1's load) gives the same training step as the reference boundary fed with the transformed fp32 NCHW frames."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import hulc_oracle as O  # noqa: E402
+from golden_util import load_case  # noqa: E402
+from hulc_amd.engine import StepEngine  # noqa: E402
+
+
+def _inputs(B, S, seed):
+    rng = np.random.default_rng(seed)
+    fs = rng.integers(0, 256, (B, S, 200, 200, 3), dtype=np.uint8)
+    fg = rng.integers(0, 256, (B, S, 84, 84, 3), dtype=np.uint8)
+    sh_s = rng.integers(0, 21, (B * S, 2)).astype(np.int32)
+    sh_g = rng.integers(0, 9, (B * S, 2)).astype(np.int32)
+    sh_s[0] = (0, 20); sh_g[0] = (8, 0)                      # extreme shifts: the replicate clamp on both sides
+    return fs, fg, sh_s, sh_g
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-6, 2e-5), ("bf16", 2e-4, 3e-3)])
+def test_u8_ingest_step_equals_fp32_boundary(dtype, tol_loss, tol_grad):
+    dims, P, batch, fx = load_case("hulc_tiny")
+    mb0 = batch["vis"]
+    B, S = mb0["actions"].shape[:2]
+    fs, fg, sh_s, sh_g = _inputs(B, S, 5)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).cuda() if dt is None else torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+    common = dict(actions=t(mb0["actions"], np.float32), robot_obs=t(mb0["robot_obs"], np.float32), plan_idx=t(mb0["plan_idx"], np.int32))
+    ref = dict(common, rgb_static=t(O.ingest_u8(fs, sh_s, 10)), rgb_gripper=t(O.ingest_u8(fg, sh_g, 4)))
+    u8 = dict(common, rgb_static=t(fs), rgb_gripper=t(fg), shift_static=t(sh_s), shift_gripper=t(sh_g), pad_static=10, pad_gripper=4)
+    out = []
+    for mb in (ref, u8):
+        eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=1)
+        eng.load_numpy(P)
+        eng.zero_grads()
+        l = eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append((l, eng.flat_grads.clone()))
+        eng.close()
+    (l0, g0), (l1, g1) = out
+    assert abs(l0["total_mod"] - l1["total_mod"]) <= tol_loss * abs(l0["total_mod"]), (l0, l1)
+    rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
+    assert rel <= tol_grad, rel
+
+
+def test_u8_ingest_validation_without_augmentation():
+    """`val` transforms (no RandomShiftsAug): hulc_validate on uint8 frames == on their scaled / normalised fp32 version."""
+    dims, P, batch, fx = load_case("hulc_tiny")
+    mb0 = batch["vis"]
+    B, S = mb0["actions"].shape[:2]
+    fs, fg, _, _ = _inputs(B, S, 9)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).cuda() if dt is None else torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+    common = dict(actions=t(mb0["actions"], np.float32), robot_obs=t(mb0["robot_obs"], np.float32))
+    eng = StepEngine(dims, B, S, dtype="bf16", device="cuda:0", seed=2)
+    eng.load_numpy(P)
+    a = eng.validate(dict(common, rgb_static=t(O.ingest_u8(fs)), rgb_gripper=t(O.ingest_u8(fg))), False, None)
+    b = eng.validate(dict(common, rgb_static=t(fs), rgb_gripper=t(fg)), False, None)
+    eng.close()
+    assert abs(a["action_loss_pp"] - b["action_loss_pp"]) <= 2e-4 * abs(a["action_loss_pp"])
+    assert torch.equal(a["sampled_plan_idx_pp"], b["sampled_plan_idx_pp"])

@@ -49,3 +49,18 @@ def test_tcp_world_round_trip():
     ro = rng.normal(0, 0.5, (3, 5, 15)).astype(np.float32)
     back = O.tcp_to_world_frame(O.world_to_tcp_frame(a, ro), ro)
     assert np.abs(back - a).max() < 2e-3
+
+
+def test_random_shifts_aug_matches_reference_fixture():
+    """oracle.random_shifts_aug (integer crop of the replicate-padded frame) vs the reference's grid_sample implementation
+    (hulc/utils/transforms.py:8-29) with its recorded draws: equal up to the bilinear round-off (<= 5e-3 on 0..255 values)."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ingest_shift.npz"))
+    for name in ("gripper", "small"):
+        o = O.random_shifts_aug(fx[f"in_{name}"].astype(np.float32), fx[f"shift_{name}"], int(fx[f"pad_{name}"]))
+        assert np.abs(o - fx[f"out_{name}"]).max() <= 5e-3, name
+    # full ingest: no shift = scale + normalise only; shift == pad is the identity crop
+    fr = np.random.default_rng(0).integers(0, 256, (2, 3, 20, 20, 3), dtype=np.uint8)
+    a = O.ingest_u8(fr)
+    assert a.shape == (2, 3, 3, 20, 20) and a.min() >= -1 and a.max() <= 1
+    assert np.array_equal(a[0, 0, :, 5, 7], (fr[0, 0, 5, 7].astype(np.float32) / 255 - 0.5) / 0.5)
+    assert np.array_equal(O.ingest_u8(fr, np.full((6, 2), 4), 4), a)

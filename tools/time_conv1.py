@@ -13,6 +13,16 @@ for name, dbg in (("full", 1), ("no-compute", 3), ("no-staging", 5), ("neither",
     for _ in range(5): L.check(lib.hulc_k_conv_tile(4, X.data_ptr(), W.data_ptr(), b.data_ptr(), None, out.data_ptr(), Nf, IH, OH, dbg, None))
     e1.record(); torch.cuda.synchronize()
     print(f"conv1 fwd static {name}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")
+Xu = torch.randint(0, 256, (Nf, IH, IH, 3), device="cuda", dtype=torch.int32).to(torch.uint8)
+sh = torch.randint(0, 21, (Nf, 2), device="cuda", dtype=torch.int32)
+for mode, mname, msk in ((5, "u8", None), (6, "u8+shift", sh)):
+    for name, dbg in (("full", 1), ("no-compute", 3), ("no-staging", 5)):
+        for _ in range(2): L.check(lib.hulc_k_conv_tile(mode, Xu.data_ptr(), W.data_ptr(), b.data_ptr(), msk.data_ptr() if msk is not None else None, out.data_ptr(), Nf, IH, OH, dbg, None))
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): L.check(lib.hulc_k_conv_tile(mode, Xu.data_ptr(), W.data_ptr(), b.data_ptr(), msk.data_ptr() if msk is not None else None, out.data_ptr(), Nf, IH, OH, dbg, None))
+        e1.record(); torch.cuda.synchronize()
+        print(f"conv1 fwd static {mname} {name}: {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")
 # reference: plain copy bandwidth
 y = torch.empty_like(X)
 for _ in range(2): y.copy_(X)
