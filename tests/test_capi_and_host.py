@@ -27,12 +27,27 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.EXPORTS)
 
 
-def test_ctypes_struct_layout_matches_header():
+def test_ctypes_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors in hulc_amd/lib.py against the C compiler's view of include/hulc_hip.h (sizeof / offsetof)."""
+    import subprocess
     from hulc_amd import lib
     assert ctypes.sizeof(lib.HulcConfig) == 56
     assert lib.HulcConfig.seed.offset == 48
-    assert ctypes.sizeof(lib.HulcBatch) == 88
-    assert lib.HulcBatch.rgb_static.offset == 16 and lib.HulcBatch.step.offset == 80
+    src = tmp_path / "layout.c"
+    fields = {"hulc_batch": [f[0] for f in lib.HulcBatch._fields_], "hulc_val_noise": [f[0] for f in lib.HulcValNoise._fields_],
+              "hulc_rollout_obs": [f[0] for f in lib.HulcRolloutObs._fields_], "hulc_config": [f[0] for f in lib.HulcConfig._fields_]}
+    body = "".join(f'printf("{st} %zu\\n", sizeof({st}));' + "".join(f'printf("{st}.{fl} %zu\\n", offsetof({st}, {fl}));' for fl in fls)
+                   for st, fls in fields.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hulc_hip.h"\nint main(void) {' + body + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    mirrors = {"hulc_batch": lib.HulcBatch, "hulc_val_noise": lib.HulcValNoise, "hulc_rollout_obs": lib.HulcRolloutObs, "hulc_config": lib.HulcConfig}
+    for st, cls in mirrors.items():
+        assert ctypes.sizeof(cls) == int(out[st]), st
+        for fl in fields[st]:
+            assert getattr(cls, fl).offset == int(out[f"{st}.{fl}"]), (st, fl)
+    assert lib.HulcBatch.rgb_static.offset == 16 and lib.HulcBatch.step.offset == 80 and lib.HulcBatch.frames_u8.offset == 88
 
 
 def test_ctx_create_fails_loudly_without_gpu():
