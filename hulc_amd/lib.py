@@ -50,6 +50,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"hulc_amd: {LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
                            "there is no CPU fallback for the product path")
+    # torch ships its own libamdhip64; it must be the HIP runtime of the process.  Loading this library first would pull in
+    # /opt/rocm's copy and a later `import torch` then sees no device ("hulc_ctx_create: no HIP device visible").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.hulc_last_error.restype = C.c_char_p
     lib.hulc_workspace_bytes.restype = C.c_int64
