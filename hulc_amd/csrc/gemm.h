@@ -535,9 +535,13 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 //   Workgroup -> tile order is XCD-aware: block b runs on XCD b % 8, which gets a contiguous run of tiles in 4-row groups, so
 //   each XCD's L2 sees 4 A panels x 8 B panels instead of the whole of B.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gemm_glds_kernel(DenseLoader<bf16_t> al, DenseLoader<bf16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
-                                                        int tiles_m, int tiles_n) {
-    constexpr int NST = 3, STAGE = 32 * 1024;
+template <int NST, int NW>      // NW = 4 (wave tile 64x64) or 8 waves (wave tile 32x64: two waves per SIMD hide each other's DMA issue / LDS latency)
+__global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<bf16_t> al, DenseLoader<bf16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
+                                                           int tiles_m, int tiles_n) {
+    constexpr int STAGE = 32 * 1024;
+    constexpr int PW = 16 / NW;                  // 8-row pieces of each operand a wave DMAs per stage
+    constexpr int TM = 8 / NW * 2 * 2 / 2;       // m-tiles per wave: 4 (NW = 4) or 2 (NW = 8)
+    constexpr int WROWS = TM * 16;               // rows of the tile a wave multiplies
     extern __shared__ __attribute__((aligned(16))) char gg_smem[];
     typedef __attribute__((address_space(3))) char lchar;
     lchar* lds = (lchar*)gg_smem;
@@ -555,63 +559,72 @@ __global__ void __launch_bounds__(256) gemm_glds_kernel(DenseLoader<bf16_t> al, 
     }
     const int m0 = tm * 128, n0 = tn * 128;
     const int r = lane >> 3, cs = (lane & 7) ^ (r & 6);
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
+    const bf16_t* asrc[PW];
+    const bf16_t* bsrc[PW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        asrc[j] = al.row(min(m0 + (wave * 4 + j) * 8 + r, M - 1), 0).base + cs * 8;
-        bsrc[j] = bl.row(min(n0 + (wave * 4 + j) * 8 + r, N - 1), 0).base + cs * 8;
+    for (int j = 0; j < PW; ++j) {
+        asrc[j] = al.row(min(m0 + (wave * PW + j) * 8 + r, M - 1), 0).base + cs * 8;
+        bsrc[j] = bl.row(min(n0 + (wave * PW + j) * 8 + r, N - 1), 0).base + cs * 8;
     }
     const int nk = (K + 63) >> 6;
     const bool khalf = (K & 63) != 0;
     auto issue = [&](int kt, int buf) {
-        lchar* st = lds + buf * STAGE + wave * 4096;
+        lchar* st = lds + buf * STAGE + wave * PW * 1024;
         long long ko = (long long)kt * 64;
         if (khalf && kt == nk - 1 && cs >= 4) ko -= 32;         // chunk beyond K: fetch a valid one instead (never multiplied)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PW; ++j) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + ko), (__attribute__((address_space(3))) void*)(st + j * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + ko), (__attribute__((address_space(3))) void*)(st + 16384 + j * 1024), 16, 0, 0);
         }
     };
-    f32x4 acc[4][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wm = wave >> 1, wn = wave & 1;
     const int foff = (li >> 3) * 1024 + (li & 7) * 128;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+        if (j < nk) issue(j, j);
     int buf = 0;
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt of THIS wave has landed (stage kt+1 may still be in flight); the barrier makes that true for every wave and
-        // also says every wave has finished multiplying stage kt-1, whose buffer the next DMA overwrites
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2, buf == 0 ? 2 : buf - 1);
-        lchar* sa = lds + buf * STAGE + wm * 8192 + foff;
+        // stage kt of THIS wave has landed (later stages may still be in flight: 2*PW DMA instructions each); the barrier makes that
+        // true for every wave and also says every wave has finished multiplying stage kt-1, whose buffer the next DMA overwrites
+        const int ahead = min(NST - 2, nk - 1 - kt);
+        if constexpr (PW == 4) {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (kt + NST - 1 < nk) issue(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+        lchar* sa = lds + buf * STAGE + wm * (WROWS / 8) * 1024 + foff;
         lchar* sb = lds + buf * STAGE + 16384 + wn * 8192 + foff;
         const int nkk = (khalf && kt == nk - 1) ? 1 : 2;
 #pragma unroll 1
         for (int kk = 0; kk < nkk; ++kk) {
             const int chunk = (((kk << 2) + g) ^ (li & 6)) << 4;
-            bf16x8_t a[4], b[4];
+            bf16x8_t a[TM], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(__attribute__((address_space(3))) bf16x8_t*)(sa + i * 2048 + chunk);
+            for (int i = 0; i < TM; ++i) a[i] = *(__attribute__((address_space(3))) bf16x8_t*)(sa + i * 2048 + chunk);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) bf16x8_t*)(sb + j * 2048 + chunk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NST - 1 ? 0 : buf + 1;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + li;
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WROWS + i * 16 + li;
         if (row < M) {
             const long long obase = om.offset(row, 0);
             const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
@@ -631,13 +644,16 @@ static inline bool gemm_glds_ok(const DenseLoader<bf16_t>& a, const DenseLoader<
     return K >= 128 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
 }
 static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<bf16_t>& a, const DenseLoader<bf16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+    static const int nw = getenv("HULC_GLDS_NW") ? atoi(getenv("HULC_GLDS_NW")) : 8;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_glds_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
-    hipLaunchKernelGGL(gemm_glds_kernel, dim3(tiles_m * tiles_n), dim3(256), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
+    if (nw == 4) hipLaunchKernelGGL((gemm_glds_kernel<3, 4>), dim3(tiles_m * tiles_n), dim3(256), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_glds_kernel<3, 8>), dim3(tiles_m * tiles_n), dim3(512), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------
