@@ -747,10 +747,10 @@ static bool gemm_use_glds = true;   // tests / tools can force the register-frag
 // 8 rows x 128 B, XOR-swizzled on the SOURCE address so the later ds_read_b128 fragments are conflict-free) instead of
 // fragment-shaped 16 x 64 B loads, which the texture-address path serves at ~2/3 of the full-line rate (tools/loadbench.hip:
 // 192 KB/CU in 4.3 us vs 7.4 us).  Each wave DMAs exactly the k-range it multiplies, so no barrier sits between load and MFMA.
-template <int MT, int KQ32>   // KQ32 = k-steps (of 32) per wave = K / 256
-__global__ void __launch_bounds__(512) skinny_lds_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+template <int MT, int KQ32, int NW = 8>   // KQ32 = k-steps (of 32) per wave = K / (NW * 32)
+__global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
                                                          long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
-    constexpr int NW = 8, PCW = KQ32 / 2;               // 128-byte pieces (64 k) per row per wave
+    constexpr int PCW = KQ32 / 2;               // 128-byte pieces (64 k) per row per wave
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     typedef __attribute__((address_space(3))) char lchar;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -838,6 +838,13 @@ static inline bool launch_skinny_lds(hipStream_t st, const bf16_t* A, long long 
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
     const int kq32 = K / 256;
 #define SKL(mt, kq) launch_skinny_lds_t<mt, kq>(st, grid, A, lda, W, ldw, M, N, K, om, ep)
+    static const int nw16 = getenv("HULC_SKINNY_NW16") ? atoi(getenv("HULC_SKINNY_NW16")) : 1;   // A/B: -0.6 % of the step
+    if (nw16 && MT == 2 && kq32 == 8) {            // K = 2048 (the recurrent step): 16 waves x 4 k-steps, 4 waves per SIMD overlap DMA issue and MFMAs
+        static bool attr16 = false;
+        if (!attr16) { hipFuncSetAttribute((const void*)skinny_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
+        hipLaunchKernelGGL((skinny_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep);
+        return true;
+    }
     if (MT == 2) { if (kq32 == 8) SKL(2, 8); else if (kq32 == 4) SKL(2, 4); else if (kq32 == 2) SKL(2, 2); else return false; }
     else { if (kq32 == 4) SKL(4, 4); else if (kq32 == 2) SKL(4, 2); else return false; }
 #undef SKL
