@@ -21,6 +21,7 @@ struct ConvTileP {
     bf16_t* out; int OUTH, OUTW;
     const float* bias;
     const bf16_t* mask;
+    const unsigned* maskbits; // CN <= 32 only: one word per output pixel, bit c = (layer input channel c > 0) — 16x fewer mask bytes than `mask`
     int relu;
     int dbg;                 // bench ablation: bit 1 = skip the MFMA/epilogue phase, bit 2 = skip the global prefetch loads
     int Nf, RB, nbands, LW, LR;
@@ -164,7 +165,11 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             // mask (dgrad: ReLU mask of the layer input) fetched now, consumed in the epilogue -> its HBM latency hides behind the MFMAs
             constexpr int EW = C::NT / 2;                       // 16-byte words per pixel per lane (lane owns 4*NT consecutive channels)
             u32x4_t mk[C::MT][EW];
-            if (p.mask) {
+            unsigned mkw[C::MT];
+            if (p.maskbits) {
+#pragma unroll
+                for (int mm = 0; mm < C::MT; ++mm) mkw[mm] = p.maskbits[(long long)f * p.OUTH * p.OUTW + max(opix[mm], 0)];
+            } else if (p.mask) {
 #pragma unroll
                 for (int mm = 0; mm < C::MT; ++mm) {
                     const long long ob = ((long long)f * p.OUTH * p.OUTW + max(opix[mm], 0)) * CN + g * 4 * C::NT;
@@ -221,7 +226,10 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    if (p.mask) {
+                    if (p.maskbits) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = ((mkw[mm] >> ((g * 4 * C::NT + e * 8 + r) & 31)) & 1u) ? v[r] : 0.f;
+                    } else if (p.mask) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
                             const unsigned wd = mk[mm][e][r >> 1];
@@ -290,7 +298,8 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 // x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(Conv1Src X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                           bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg) {
+                                                           bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
+                                                           unsigned* __restrict__ maskbits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* ximg = (lds_char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -355,7 +364,9 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(Conv1Src X, const bf1
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 if (!ok[mm]) continue;
-                const long long obase = (((long long)f * OH + oh0 + rr[mm]) * OW + oww[mm]) * 32;
+                const long long opix = ((long long)f * OH + oh0 + rr[mm]) * OW + oww[mm];
+                const long long obase = opix * 32;
+                unsigned bits = 0;                                       // ReLU mask of this lane's 8 channels (what conv2's dgrad needs of a1)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const int cn0 = ct * 16 + g * 4;
@@ -365,12 +376,20 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(Conv1Src X, const bf1
                     o.x = pack2bf(v0, v1);
                     o.y = pack2bf(v2, v3);
                     *reinterpret_cast<uint2*>(out + obase + cn0) = o;
+                    const unsigned nz = ((o.x & 0xffffu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xffffu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
+                    bits |= nz << cn0;
+                }
+                if (maskbits) {                                          // the four lanes of a pixel (g = 0..3) are all active here: OR their bytes
+                    bits |= __shfl_xor(bits, 16);
+                    bits |= __shfl_xor(bits, 32);
+                    if (g == 0) maskbits[opix] = bits;
                 }
             }
         }
     }
 }
-static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0) {
+static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
+                                    unsigned* maskbits = nullptr) {
     auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = getenv("HULC_C1_WG") ? atoi(getenv("HULC_C1_WG")) : 1024;
@@ -384,5 +403,5 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf1
         attr_set = true;
     }
     const int items = Nf * nbands;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
 }

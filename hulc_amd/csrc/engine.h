@@ -139,7 +139,7 @@ struct Engine : IEngine {
     std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0;
 
     // ---- workspace (per modality pass)
-    struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; } aS, aG;
+    struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; } aS, aG;
     T *dact1, *dact2, *dact3, *d_g0, *d_f1, *d_f2t; float* d_ss;
     T *emb, *lang_t, *gl1, *gl2, *goal_t, *ppx, *ppa[4], *xm, *seqf_t, *embg, *Cb, *Zx0, *Zx1, *H0, *H1, *dheads, *dH1, *dZ1, *dH0, *dZ0, *dC;
     float *gl3, *goal_st, *pp_logits, *seqf, *pr_logits, *probs, *klcat, *dpp_kl, *dpr_kl, *Cplan, *heads, *rowloss, *a_tcp;
@@ -178,6 +178,8 @@ struct Engine : IEngine {
         const int H1 = (IH - 8) / 4 + 1, H2 = (H1 - 4) / 2 + 1, H3 = H2 - 2;
         std::string s(pre);
         a.a1 = alloc<T>((int64_t)maxN * H1 * H1 * 32, (s + "a1").c_str());
+        static const bool use_bits = getenv("HULC_MASKBITS") ? atoi(getenv("HULC_MASKBITS")) != 0 : true;
+        a.m1bits = (use_bits && std::is_same<T, bf16_t>::value) ? alloc<unsigned>((int64_t)maxN * H1 * H1) : nullptr;   // ReLU bitmask of a1 (conv2 dgrad)
         a.a2 = alloc<T>((int64_t)maxN * H2 * H2 * 64, (s + "a2").c_str());
         a.a3 = alloc<T>((int64_t)maxN * H3 * H3 * 64, (s + "a3").c_str());
         a.ss = gripper ? nullptr : alloc<T>((int64_t)maxN * 128, (s + "ss").c_str());
@@ -557,7 +559,7 @@ struct Engine : IEngine {
         if constexpr (std::is_same<T, bf16_t>::value) {
             const double px = (double)Nf * g1.OH * g1.OW;
             TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)Nf * 3 * e.IH * e.IH * (src.u8 ? 1 : 4) + px * 32 * 2);
-            launch_conv1_fwd(st, src, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW);
+            launch_conv1_fwd(st, src, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits);
         } else {
             x = conv1_f32(src, e.gripper, Nf, e.IH);
             Conv1Loader<T> l{x, g1};
@@ -633,9 +635,9 @@ struct Engine : IEngine {
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
-    void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask) {
+    void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
         if constexpr (std::is_same<T, bf16_t>::value) {
-            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.Nf = g.Nf;
+            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.maskbits = (c.I <= 32) ? maskbits : nullptr; p.Nf = g.Nf;
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
@@ -699,7 +701,7 @@ struct Engine : IEngine {
         conv_wgrad(e.c3, dact3, a.a2, g3, false);
         conv_dgrad(e.c3, dact3, g3, dact2, a.a2);
         conv_wgrad(e.c2, dact2, a.a1, g2, false);
-        conv_dgrad(e.c2, dact2, g2, dact1, a.a1);
+        conv_dgrad(e.c2, dact2, g2, dact1, a.a1, a.m1bits);
         conv_wgrad(e.c1, dact1, x, g1, true);
     }
 
