@@ -883,7 +883,7 @@ struct Engine : IEngine {
     int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
                  float* pred_pr_out) override {
         if (!bound) { hulc_set_error("hulc_validate before hulc_bind_params"); return 1; }
-        if (cfg.kind != HULC_KIND_HULC) { hulc_set_error("hulc_validate: only the HULC model kind has a plan proposal / recognition pair"); return 1; }
+        const bool hulc = cfg.kind == HULC_KIND_HULC;     // GCBC (gcbc.py:214-246): one decoder pass without a plan, reported in the "pp" slots
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
             return 1;
@@ -900,6 +900,7 @@ struct Engine : IEngine {
         pr_fwd(B, S, 0.f);
         // KL (beta-scaled) + recognition sample, then the proposal sample (no KL terms: second logits pointer null)
         const int* in_pr = nullptr;
+        if (hulc) {
         if (nz->plan_idx_pr) { HIP_CHECK(hipMemcpyAsync(pidx_in, nz->plan_idx_pr, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); in_pr = pidx_in; }
         hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, in_pr, pidx, probs, klcat, dpp_kl, dpr_kl, 0.f,
                            0.f, site_seed(40));
@@ -908,7 +909,8 @@ struct Engine : IEngine {
         if (nz->plan_idx_pp) { HIP_CHECK(hipMemcpyAsync(pidx_in, nz->plan_idx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); in_pp = pidx_in; }
         hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, B, NCAT, NCLS, in_pp, pidx_pp, probs, klcat,
                            dpp_kl, dpr_kl, 0.f, 0.f, site_seed(41));
-        for (int pass = 0; pass < 2; ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
+        }
+        for (int pass = 0; pass < (hulc ? 2 : 1); ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
             dec_fwd(pass == 0 ? pidx_pp : pidx, B, S, nullptr, nullptr);
             hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, 0.f, rowloss, a_tcp, dheads);
@@ -922,10 +924,10 @@ struct Engine : IEngine {
         }
         STAGE("validate");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in validate"); return 1; }
-        if (plan_pp_out) HIP_CHECK(hipMemcpyAsync(plan_pp_out, pidx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
-        if (plan_pr_out) HIP_CHECK(hipMemcpyAsync(plan_pr_out, pidx, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
+        if (plan_pp_out && hulc) HIP_CHECK(hipMemcpyAsync(plan_pp_out, pidx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
+        if (plan_pr_out && hulc) HIP_CHECK(hipMemcpyAsync(plan_pr_out, pidx, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
         if (pred_pp_out) HIP_CHECK(hipMemcpyAsync(pred_pp_out, pred_pp, sizeof(float) * SB * 7, hipMemcpyDefault, st));
-        if (pred_pr_out) HIP_CHECK(hipMemcpyAsync(pred_pr_out, pred_pr, sizeof(float) * SB * 7, hipMemcpyDefault, st));
+        if (pred_pr_out && hulc) HIP_CHECK(hipMemcpyAsync(pred_pr_out, pred_pr, sizeof(float) * SB * 7, hipMemcpyDefault, st));
         float h[32];
         HIP_CHECK(hipMemcpyAsync(h, valm, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

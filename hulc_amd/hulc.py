@@ -306,7 +306,7 @@ class Hulc(torch.nn.Module):
         """hulc.py:739-841: per modality lmp_val (:301-388) + the logged reductions; eval-mode forward, no gradients.
         `noise` (optional, tests): {scope: {plan_idx_pp, plan_idx_pr, u_mix_pp, u_act_pp, u_mix_pr, u_act_pr}} injected draws."""
         if self.KIND != "hulc":
-            raise NotImplementedError("GCBC validation (gcbc.py:183-270) is not built")
+            return self._validation_step_gcbc(batch, batch_idx, noise)
         eng = self.engine
         output: Dict[str, torch.Tensor] = {}
         val_total_act_loss_pp = 0.0
@@ -334,6 +334,29 @@ class Hulc(torch.nn.Module):
             one_hot = lambda idx: torch.nn.functional.one_hot(idx.long(), 32).to(torch.float32).reshape(idx.shape[0], -1)
             output[f"sampled_plan_pp_{sc}"] = one_hot(r["sampled_plan_idx_pp"])     # (B, 1024) like distributions.py:37-41
             output[f"sampled_plan_pr_{sc}"] = one_hot(r["sampled_plan_idx_pr"])
+            output[f"idx_{sc}"] = dataset_batch.get("idx")
+        return output
+
+    def _validation_step_gcbc(self, batch, batch_idx, noise=None):
+        """gcbc.py:183-270: one decoder pass without a plan (loss_and_act), mae / gripper success rate, the reference's metric names."""
+        eng = self.engine
+        val_total = 0.0
+        nmod = len(batch)
+        output: Dict[str, torch.Tensor] = {}
+        for self.modality_scope, dataset_batch in batch.items():
+            sc = self.modality_scope
+            is_lang = "lang" in sc
+            mb = self._modality_batch(dataset_batch, is_lang, eng.device)
+            mb["step"] = self.global_step * 131 + batch_idx
+            r = eng.validate(mb, is_lang, (noise or {}).get(sc))
+            mae = r["mae_pp"]
+            val_total += r["action_loss_pp"]
+            self.log(f"val_total_mae/{sc}_total_mae", float(mae.mean()), sync_dist=True)
+            self.log(f"val_pos_mae/{sc}_pos_mae", float(mae[:3].mean()), sync_dist=True)
+            self.log(f"val_orn_mae/{sc}_orn_mae", float(mae[3:6].mean()), sync_dist=True)
+            self.log(f"val_act/{sc}_act_loss", r["action_loss_pp"], sync_dist=True)
+            self.log(f"val_grip/{sc}_grip_sr", r["gripper_sr_pp"], sync_dist=True)
+            self.log("val_act/action_loss", val_total / nmod, sync_dist=True)
             output[f"idx_{sc}"] = dataset_batch.get("idx")
         return output
 

@@ -140,7 +140,7 @@ class Trainer:
 
     def validate(self, module, datamodule) -> Dict[str, float]:
         """Lightning's validation loop for this module: eval mode, validation_step over the val batches, mean of every `val*` metric."""
-        if not hasattr(datamodule, "val_dataloader") or getattr(module, "KIND", "hulc") != "hulc":
+        if not hasattr(datamodule, "val_dataloader"):
             return {}
         module.eval()
         sums: Dict[str, float] = {}

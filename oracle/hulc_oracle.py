@@ -638,12 +638,12 @@ def validation_forward(P, dims, mb, is_lang, noise):
     B, S = mb["actions"].shape[:2]
     emb = encode(P, mb["rgb_static"], mb["rgb_gripper"])
     goal = goal_encode(P, mb["lang"] if is_lang else emb[:, -1], is_lang)
-    pp_logits, _ = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)
+    pp_logits = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)[0] if dims.kind == "hulc" else None
     pr_logits, seq_feat, _ = plan_recognition_fwd(P, emb, dims.heads)
     a_tcp = world_to_tcp_frame(mb["actions"], mb["robot_obs"])
     out = {"seq_feat": seq_feat, "pp_logits": pp_logits, "pr_logits": pr_logits}
-    for tag in ("pp", "pr"):
-        plan = onehot_plan(noise[f"plan_idx_{tag}"], dims)
+    for tag in (("pp", "pr") if dims.kind == "hulc" else ("pp",)):     # GCBC (gcbc.py:214-246): one pass, no plan — reported under "pp"
+        plan = onehot_plan(noise[f"plan_idx_{tag}"], dims) if dims.kind == "hulc" else None
         probs, lsr, means, grip, _ = decoder_heads(P, plan, emb, goal, dims)
         loss, _ = logistic_loss(probs, lsr, means, grip, a_tcp, num_classes=dims.num_classes)
         pred = logistic_sample(probs, lsr, means, grip, noise[f"u_mix_{tag}"], noise[f"u_act_{tag}"])
@@ -651,6 +651,8 @@ def validation_forward(P, dims, mb, is_lang, noise):
         mae = np.abs(pred_w[..., :-1] - mb["actions"][..., :-1]).mean(1)          # (B, 6)  hulc.py:347-350
         sr = F32((np.where(pred_w[..., -1] > 0, 1.0, -1.0) == mb["actions"][..., -1]).mean())
         out.update({f"action_loss_{tag}": loss, f"mae_{tag}": mae.astype(F32), f"gripper_sr_{tag}": sr, f"pred_{tag}": pred_w})
+    if dims.kind != "hulc":
+        return out
     out["kl_loss"], _, _ = kl_loss(pp_logits, pr_logits, dims)
     return out
 

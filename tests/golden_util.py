@@ -85,17 +85,18 @@ def adam_close(got, ref, g, lr=2e-4, steps=1):
 
 
 # ---- validation / rollout fixtures (tools/gen_golden_val.py = the reference's lmp_val / step)
-VAL_CASES = {"val_hulc_tiny": (2, 2, 4, True, 11), "val_hulc_s16": (3, 0, 16, False, 12)}   # name: (Bv, Bl, S, use_clip, seed)
+VAL_CASES = {"val_hulc_tiny": (2, 2, 4, True, 11), "val_hulc_s16": (3, 0, 16, False, 12), "val_gcbc_s8": (2, 2, 8, True, 13, "gcbc")}   # (Bv, Bl, S, use_clip, seed[, kind])
 VAL_NOISE_KEYS = ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")
 
 
 def load_val_case(name):
-    Bv, Bl, S, use_clip, seed = VAL_CASES[name]
-    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=use_clip)
+    Bv, Bl, S, use_clip, seed = VAL_CASES[name][:5]
+    kind = VAL_CASES[name][5] if len(VAL_CASES[name]) > 5 else "hulc"
+    dims = spec.ModelDims(kind=kind, max_window=32, use_clip=use_clip)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
     fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
-    noise = {sc: {k: fx[f"{k}_{sc}"] for k in VAL_NOISE_KEYS} for sc in batch}
+    noise = {sc: {k: fx[f"{k}_{sc}"] for k in VAL_NOISE_KEYS if f"{k}_{sc}" in fx.files} for sc in batch}
     return dims, P, batch, noise, fx
 
 

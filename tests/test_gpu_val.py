@@ -34,6 +34,12 @@ def test_validate_matches_reference(name, dtype, tol):
         eng.load_numpy(P)
         o = eng.validate(_dev(mb), "lang" in sc, noise[sc], want_pred=True)
         eng.close()
+        if dims.kind == "gcbc":
+            ref = float(fx[f"action_loss_pp_{sc}"])
+            assert abs(o["action_loss_pp"] - ref) <= tol * abs(ref), (sc, o["action_loss_pp"], ref)
+            if dtype == "fp32":
+                assert np.abs(o["mae_pp"] - fx[f"mae_pp_{sc}"].mean(0)).max() <= 2e-3 and abs(o["gripper_sr_pp"] - float(fx[f"gripper_sr_pp_{sc}"])) <= 1e-6
+            continue
         for k in ("action_loss_pp", "action_loss_pr", "kl_loss"):
             ref = float(fx[f"{k}_{sc}"])
             assert abs(o[k] - ref) <= tol * abs(ref) + 1e-6, (sc, k, o[k], ref)

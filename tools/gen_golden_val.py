@@ -26,9 +26,10 @@ import ref_harness  # noqa: E402
 from gen_golden import to_ref_batch  # noqa: E402
 
 VAL_CASES = {
-    # name: (Bv, Bl, S, use_clip, seed)
+    # name: (Bv, Bl, S, use_clip, seed[, kind])
     "val_hulc_tiny": (2, 2, 4, True, 11),
     "val_hulc_s16": (3, 0, 16, False, 12),
+    "val_gcbc_s8": (2, 2, 8, True, 13, "gcbc"),
 }
 
 
@@ -58,11 +59,12 @@ def load_params(model, P):
 
 
 def run_val(name, case, outdir):
-    Bv, Bl, S, use_clip, seed = case
-    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=use_clip)
+    Bv, Bl, S, use_clip, seed = case[:5]
+    kind = case[5] if len(case) > 5 else "hulc"
+    dims = spec.ModelDims(kind=kind, max_window=32, use_clip=use_clip)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
-    model = ref_harness.build_reference("hulc", max_window=32, use_clip=use_clip)
+    model = ref_harness.build_reference(kind, max_window=32, use_clip=use_clip)
     model.eval()
     load_params(model, P)
     rb = to_ref_batch(batch)
@@ -72,6 +74,21 @@ def run_val(name, case, outdir):
         for sc, db in rb.items():                      # the body of validation_step (hulc.py:770-797) for one modality
             emb = model.perceptual_encoder(db["rgb_obs"], db["depth_obs"], db["robot_obs"])
             goal = model.language_goal(db["lang"]) if "lang" in sc else model.visual_goal(emb[:, -1])
+            if kind == "gcbc":                          # gcbc.py:226-246 (validation_step body)
+                empty_plan = torch.empty((db["actions"].shape[0]), 0)
+                with RandRecorder() as rr:
+                    loss, sample_act = model.action_decoder.loss_and_act(empty_plan, emb, goal, db["actions"], db["state_info"]["robot_obs"])
+                assert len(rr.draws) == 2
+                mae = torch.nn.functional.l1_loss(sample_act[..., :-1], db["actions"][..., :-1], reduction="none").mean(1)
+                gd = sample_act[..., -1]
+                m = gd > 0
+                gd[m] = 1
+                gd[~m] = -1
+                fx[f"u_mix_pp_{sc}"], fx[f"u_act_pp_{sc}"] = rr.draws
+                fx[f"action_loss_pp_{sc}"] = np.float32(loss.item())
+                fx[f"mae_pp_{sc}"] = mae.numpy()
+                fx[f"gripper_sr_pp_{sc}"] = np.float32(torch.mean((db["actions"][..., -1] == gd).float()).item())
+                continue
             with RandRecorder() as rr:
                 (plan_pp, loss_pp, plan_pr, loss_pr, kl, mae_pp, mae_pr, sr_pp, sr_pr, seq_feat) = model.lmp_val(
                     emb, goal, db["actions"], db["state_info"]["robot_obs"])
@@ -90,8 +107,12 @@ def run_val(name, case, outdir):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hulc_oracle as O
     for sc, mb in batch.items():
-        noise = {k: fx[f"{k}_{sc}"] for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")}
+        noise = {k: fx[f"{k}_{sc}"] for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr") if f"{k}_{sc}" in fx}
         o = O.validation_forward(P, dims, mb, "lang" in sc, noise)
+        if kind == "gcbc":
+            print(f"[{name}/{sc}] loss ref {fx[f'action_loss_pp_{sc}']:.6f} oracle {o['action_loss_pp']:.6f} mae err {np.abs(o['mae_pp'] - fx[f'mae_pp_{sc}']).max():.2e} "
+                  f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f}")
+            continue
         print(f"[{name}/{sc}] loss_pp ref {fx[f'action_loss_pp_{sc}']:.6f} oracle {o['action_loss_pp']:.6f} | kl {fx[f'kl_loss_{sc}']:.6f} {o['kl_loss']:.6f} | "
               f"mae_pp err {np.abs(o['mae_pp'] - fx[f'mae_pp_{sc}']).max():.2e} mae_pr err {np.abs(o['mae_pr'] - fx[f'mae_pr_{sc}']).max():.2e} "
               f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f} {fx[f'gripper_sr_pr_{sc}']:.3f}/{o['gripper_sr_pr']:.3f}")
@@ -148,6 +169,9 @@ def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2):
 
 if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
+    only = sys.argv[1:]
     for name, case in VAL_CASES.items():
-        run_val(name, case, out)
-    run_rollout("rollout_hulc", out)
+        if not only or name in only:
+            run_val(name, case, out)
+    if not only or "rollout_hulc" in only:
+        run_rollout("rollout_hulc", out)
