@@ -26,6 +26,9 @@ struct ConvTileP {
     int dbg;                 // bench ablation: bit 1 = skip the MFMA/epilogue phase, bit 2 = skip the global prefetch loads
     int Nf, RB, nbands, LW, LR;
     int LP;                  // LDS row pitch of the staged band in pixels (>= LW; a multiple of the input stride)
+    int* work_ctr;           // optional zero-initialised device counter: items beyond the first round are CLAIMED (atomicAdd) instead of strided,
+                             // so a workgroup that starts late (CUs held by an overlapped RCCL collective) takes less work instead of
+                             // doubling the kernel's time
 };
 
 // ds_read_b128 is serviced in four fixed 16-lane groups, each mixing lanes of two k-chunk groups g (MI355X_MICROARCH.md §LDS):
@@ -108,16 +111,19 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         const int wr = pix / p.LW, wc = pix % p.LW;
         soff[k] = (((wr % SI) * PLR + wr / SI) * p.LP + wc) * C::XS + c * 16;
     }
-    int item = blockIdx.x;
+    __shared__ int s_next[2];
+    int item = blockIdx.x, iter = 0;
     if (item < nitems) prefetch(item);
     while (item < nitems) {
+        if (p.work_ctr && tid == 0) s_next[iter & 1] = (int)gridDim.x + atomicAdd(p.work_ctr, 1);   // claimed early: its latency hides under the LDS write
         __syncthreads();                                        // previous band fully consumed (and weights visible)
 #pragma unroll
         for (int k = 0; k < C::PF; ++k)
             if (tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = pf[k];
         __syncthreads();
         const int cur = item;
-        item += gridDim.x;
+        item = p.work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
+        ++iter;
         if (item < nitems) prefetch(item);                      // in flight during the MFMAs below
         const int f = cur / p.nbands, b = cur % p.nbands;
         const int i0 = b * p.RB;
@@ -261,7 +267,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     for (int nb = 1; nb <= NI; ++nb) {
         const int RB = (NI + nb - 1) / nb;
         const int LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA;
-        if ((long long)LR * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LR, p.LP) > 160 * 1024) continue;
+        if ((long long)LR * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LR, p.LP) > 160 * 1024 - 64) continue;   // 64 B left for the kernel's static __shared__ (work-claim slots)
         double cost = 0.25 * nb;                                   // per-band barrier / staging overhead, in units of one wave round
         for (int b = 0; b < nb; ++b) {
             int groups = 0;
@@ -282,7 +288,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.LR, p.LP);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
     const int items = p.Nf * p.nbands;

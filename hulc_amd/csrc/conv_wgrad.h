@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CI, int CO, int KH, int KW, int S, int NWV>
 __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
-                                                            float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg) {
+                                                            float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
+                                                            int* __restrict__ work_ctr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     constexpr int NTH = NWV * 64, PF = 8192 / NTH, CTH = C::CT / (NWV / 4), CHY = CO / 8, CHX = CI / 8;   // NWV = 8 or 16 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -239,9 +240,11 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
             if (!isx && go > ylim) zmask |= 1u << k;                  // dY rows below the frame become zeros at the LDS write
         }
     };
-    int item = blockIdx.x;
+    __shared__ int s_next[2];
+    int item = blockIdx.x, iter = 0;
     if (item < nitems) prefetch(item);
     while (item < nitems) {
+        if (work_ctr && tid == 0) s_next[iter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);   // dynamic claim (see ConvTileP::work_ctr)
         __syncthreads();                               // previous band fully consumed (first pass: zero fill visible)
         zmask_cur = zmask;
 #pragma unroll
@@ -256,7 +259,8 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
             }
         }
         __syncthreads();
-        item += gridDim.x;
+        item = work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
+        ++iter;
         if (item < nitems) prefetch(item);             // in flight during the MFMAs below
         const int units = (dbg & 1) ? 0 : R * U;
         // k <-> pixel assignment of a 32-pixel step (4 runs of 8): k = g*8 + e; e < 4 (first tr-read): run g>>1, pixel (g&1)*4 + e;
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
 
 template <int CI, int CO, int KH, int KW, int S>
 static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
-                                       int OW, int max_blocks) {
+                                       int OW, int max_blocks, int* work_ctr = nullptr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     static const bool v1 = getenv("HULC_WGRAD_V1") != nullptr;
     constexpr int NWV = 8;                                   // 16 waves (one co-tile each, 4 waves per SIMD) measured slower: 0.43 vs 0.40 ms/step
@@ -336,16 +340,16 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf
             const int R = (OH + nb - 1) / nb, XR = (R - 1) * S + KH;
             const long long chunks = (long long)R * OW * (CO / 8) + (long long)XR * IW * (CI / 8);
             const size_t lds = std::max<size_t>(C::lds_bytes(R, IW, OW), NWV * 64 * 8 * sizeof(float));
-            if (chunks > 16 * 512 || lds > 160 * 1024 || (long long)XR * IW * CI >= (1 << 20)) continue;
+            if (chunks > 16 * 512 || lds > 160 * 1024 - 64 || (long long)XR * IW * CI >= (1 << 20)) continue;
             static bool attr8 = false;
             if (!attr8) {
-                hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
                 attr8 = true;
             }
             const int items = Nf * nb;
             const int grid = std::min(std::min(items, 256), max_blocks);
             static const int dbg = getenv("HULC_WGRAD_DBG") ? atoi(getenv("HULC_WGRAD_DBG")) : 0;   // bench ablation only
-            hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg);
+            hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr);
             return grid;
         }
     }
@@ -530,7 +534,7 @@ struct Wgrad1Cfg {
     }
 };
 
-__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int* __restrict__ work_ctr, const bf16_t* __restrict__ dY, float* __restrict__ part,
                                                                 float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = Wgrad1Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -557,7 +561,10 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, cons
     const int W4 = IW >> 2;                                       // float4 per input row (IW % 4 == 0)
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    for (int f = blockIdx.x; f < Nf; f += gridDim.x) {
+    __shared__ int s_nextf[2];
+    int fiter = 0;
+    for (int f = blockIdx.x; f < Nf;) {
+        if (work_ctr && tid == 0) s_nextf[fiter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);   // next frame claimed dynamically (see ConvTileP::work_ctr)
         for (int oh0 = 0; oh0 < OH; oh0 += R) {
             __syncthreads();
             {   // dY band, one row per wave pass
@@ -599,6 +606,8 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, cons
                 }
             }
         }
+        f = work_ctr ? s_nextf[fiter & 1] : f + (int)gridDim.x;   // written >= 2 barriers ago; the other slot is the one tid 0 writes next
+        ++fiter;
     }
     float* out = part + (long long)blockIdx.x * C::CO * 192;
 #pragma unroll
@@ -621,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, cons
 }
 
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
-                                        int OW, int max_blocks) {
+                                        int OW, int max_blocks, int* work_ctr = nullptr) {
     static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
     static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
     if (env_wg > 0) max_blocks = env_wg;
@@ -630,11 +639,11 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
     const size_t lds = Wgrad1Cfg::lds_bytes(R, IW, OW, X.u8);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv1_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv1_wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
     const int grid = Nf < max_blocks ? Nf : max_blocks;
-    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
+    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
     return grid;
 }
 

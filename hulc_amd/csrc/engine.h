@@ -147,6 +147,8 @@ struct Engine : IEngine {
     T *xt[3], *qkv[2], *ao[2], *x1t[2], *hff[2];
     float *xf[3], *Pat[2], *y1[2], *st1[2], *x1f[2], *y2[2], *st2[2];
     float* zero_arena = nullptr; int64_t zero_n = 0;
+    int* work_ctrs = nullptr; int work_ctr_next = 0;
+    int* next_ctr() { return work_ctrs ? work_ctrs + (work_ctr_next++ & 63) : nullptr; }
     float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
     T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
     T *tA, *tB; int64_t tcap;
@@ -215,11 +217,12 @@ struct Engine : IEngine {
         // backward scratch that must start at zero lives in ONE arena -> a single memset per backward
         {
             auto r64 = [](int64_t n) { return (n + 63) / 64 * 64; };
-            zero_n = r64(N * EMB) + r64(B * GOAL) + r64(B * FCH) + r64((int64_t)NHEAD * HID) + r64(NHEAD) + r64(128 * 3136);
+            zero_n = r64(N * EMB) + r64(B * GOAL) + r64(B * FCH) + r64((int64_t)NHEAD * HID) + r64(NHEAD) + r64(128 * 3136) + 64;
             zero_arena = alloc<float>(zero_n);
             float* q = zero_arena;
             demb = q; q += r64(N * EMB); dgoal = q; q += r64(B * GOAL); dseqf = q; q += r64(B * FCH);
-            dwheads_tmp = q; q += r64((int64_t)NHEAD * HID); dbheads_tmp = q; q += r64(NHEAD); dw7_tmp = q;
+            dwheads_tmp = q; q += r64((int64_t)NHEAD * HID); dbheads_tmp = q; q += r64(NHEAD); dw7_tmp = q; q += r64(128 * 3136);
+            work_ctrs = reinterpret_cast<int*>(q);      // 64 zeroed counters per backward: dynamic work claiming of the persistent encoder-backward kernels
             named["demb"] = Named{demb, N * EMB, 0}; named["dgoal"] = Named{dgoal, B * GOAL, 0}; named["dseq_feat"] = Named{dseqf, B * FCH, 0};
         }
         dplan = alloc<float>(B * PLAN, "dplan"); dprl = alloc<float>(B * PLAN, "dpr_logits"); dppx = alloc<float>(B * (EMB + GOAL));
@@ -610,11 +613,11 @@ struct Engine : IEngine {
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
                           conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * (wgrad_src.u8 ? 1 : 4) + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
-                nsplit = launch_conv1_wgrad_tr(st, wgrad_src, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024);
+                nsplit = launch_conv1_wgrad_tr(st, wgrad_src, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024, next_ctr());
             else if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512);
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
         }
         bool bias_done = false;
         if (nsplit > 0) bias_done = true;     // the tr kernels added the bias gradient themselves (atomics)
@@ -637,7 +640,7 @@ struct Engine : IEngine {
     }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
         if constexpr (std::is_same<T, bf16_t>::value) {
-            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.maskbits = (c.I <= 32) ? maskbits : nullptr; p.Nf = g.Nf;
+            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.maskbits = (c.I <= 32) ? maskbits : nullptr; p.Nf = g.Nf; p.work_ctr = next_ctr();
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
@@ -1048,7 +1051,8 @@ struct Engine : IEngine {
         const float dp = cfg.dropout_p;
         const long long BH = (long long)B * HID;
         if (part == 1) goto encoders;
-        HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries
+        HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
+        work_ctr_next = 0;
         {
         bool have_dseq = false;
         // ---- CLIP backward
