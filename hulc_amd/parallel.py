@@ -81,6 +81,10 @@ def backward_overlapped(engine) -> None:
     if world_size() == 1:
         engine.backward()
         return
+    if os.environ.get("HULC_DP_OVERLAP", "1") == "0":        # experiment knob: plain backward, then one all-reduce
+        engine.backward()
+        dist.all_reduce(engine.flat_grads, op=dist.ReduceOp.SUM)
+        return
     n_enc = engine.encoder_numel
     engine.backward(0)
     work = dist.all_reduce(engine.flat_grads[n_enc:], op=dist.ReduceOp.SUM, async_op=True)

@@ -4,7 +4,7 @@ counters are in KiB).  Writes <dir>/pmc_hbm_per_kernel.csv and <dir>/pmc_traffic
 import collections, csv, glob, json, sys
 
 d = sys.argv[1]
-CLASSES = [("rnn_step_gemm", ("skinny_lds_kernel<2, 8>",)), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
+CLASSES = [("rnn_step_gemm", ("skinny_lds_kernel<2, 4, 16>", "skinny_lds_kernel<2, 8>")), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
            ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
            ("conv_tile_fwd", ("1, 1, false>(ConvTileP)", "2, 1, false>(ConvTileP)")), ("conv_tile_dgrad", ("true>(ConvTileP)",)), ("adam", ("adam_kernel",))]
 per = {}
