@@ -24,6 +24,7 @@ TARGET_MAP = {
     "hulc.models.hulc.Hulc": "hulc_amd.hulc.Hulc",
     "hulc.models.gcbc.GCBC": "hulc_amd.hulc.GCBC",
     "torch.optim.Adam": "hulc_amd.hulc.FusedAdam",
+    "hulc.models.encoders.language_network.SBert": "hulc_amd.sbert.SBert",
 }
 MISSING = "???"
 

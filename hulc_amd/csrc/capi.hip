@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "engine.h"
+#include "sbert.h"
 
 static thread_local char g_err[1024] = "";
 void hulc_set_error(const char* fmt, ...) {
@@ -81,6 +82,53 @@ int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* g
 int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out_host) {
     if (!obs || !obs->rgb_static || !obs->rgb_gripper || !obs->robot_obs_raw || !action_out_host) { hulc_set_error("hulc_rollout_act: null argument"); return 1; }
     return ctx->e->rollout_act(obs, u_mix, u_act, action_out_host);
+}
+int hulc_sbert_create(const hulc_sbert_config* cfg, hulc_sbert** out) {
+    if (!cfg || !out) { hulc_set_error("hulc_sbert_create: null argument"); return 1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { hulc_set_error("hulc_sbert_create: no HIP device visible"); return 1; }
+    if (cfg->hidden % 64 != 0 || cfg->hidden > 1024 || cfg->hidden % cfg->heads != 0 || cfg->hidden / cfg->heads > 64 || cfg->max_tokens > 128 || cfg->layers < 1) {
+        hulc_set_error("hulc_sbert_create: unsupported shape (hidden %% 64 == 0, <= 1024; head dim <= 64; <= 128 tokens)");
+        return 1;
+    }
+    hulc_sbert* c = new hulc_sbert();
+    c->cfg = *cfg;
+    if (!c->init()) { delete c; hulc_set_error("hulc_sbert_create: workspace allocation failed"); return 1; }
+    *out = c;
+    return 0;
+}
+int hulc_sbert_destroy(hulc_sbert* ctx) { delete ctx; return 0; }
+int hulc_sbert_set_stream(hulc_sbert* ctx, void* s) { ctx->st = (hipStream_t)s; return 0; }
+int hulc_sbert_bind(hulc_sbert* ctx, const float* flat, int64_t numel, int32_t n, const char* const* names, const int64_t* offs, const int64_t* numels) {
+    if (!ctx || !flat || !names || !offs || !numels) { hulc_set_error("hulc_sbert_bind: null argument"); return 1; }
+    ctx->w.clear();
+    for (int i = 0; i < n; ++i) {
+        if (offs[i] < 0 || offs[i] + numels[i] > numel) { hulc_set_error("hulc_sbert_bind: tensor %s out of range", names[i]); return 1; }
+        ctx->w[names[i]] = flat + offs[i];
+    }
+    const long long H = ctx->cfg.hidden, I = ctx->cfg.intermediate;
+    auto need = [&](const std::string& nm, long long cnt) {
+        for (int i = 0; i < n; ++i)
+            if (nm == names[i]) return numels[i] == cnt;
+        return false;
+    };
+    bool ok = need("embeddings.word_embeddings.weight", (long long)ctx->cfg.vocab * H) && need("embeddings.position_embeddings.weight", (long long)ctx->cfg.max_position * H) &&
+              need("embeddings.LayerNorm.weight", H) && need("embeddings.LayerNorm.bias", H);
+    for (int l = 0; l < ctx->cfg.layers && ok; ++l) {
+        const std::string p = "encoder.layer." + std::to_string(l) + ".";
+        ok = need(p + "attention.self.query.weight", H * H) && need(p + "attention.self.key.weight", H * H) && need(p + "attention.self.value.weight", H * H) &&
+             need(p + "attention.self.query.bias", H) && need(p + "attention.self.key.bias", H) && need(p + "attention.self.value.bias", H) &&
+             need(p + "attention.output.dense.weight", H * H) && need(p + "attention.output.dense.bias", H) && need(p + "attention.output.LayerNorm.weight", H) &&
+             need(p + "attention.output.LayerNorm.bias", H) && need(p + "intermediate.dense.weight", I * H) && need(p + "intermediate.dense.bias", I) &&
+             need(p + "output.dense.weight", H * I) && need(p + "output.dense.bias", H) && need(p + "output.LayerNorm.weight", H) && need(p + "output.LayerNorm.bias", H);
+    }
+    if (!ok || !ctx->get("embeddings.token_type_embeddings.weight")) { hulc_set_error("hulc_sbert_bind: a BertModel tensor is missing or has the wrong size"); return 1; }
+    ctx->bound = true;
+    return 0;
+}
+int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* ids, const int32_t* mask, int32_t B, int32_t L, float* out) {
+    if (!ctx || !ids || !mask || !out) { hulc_set_error("hulc_sbert_encode: null argument"); return 1; }
+    return ctx->encode(ids, mask, B, L, out);
 }
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
 int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }

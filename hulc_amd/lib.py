@@ -35,9 +35,14 @@ class HulcRolloutObs(C.Structure):
     _fields_ = [("rgb_static", C.c_void_p), ("rgb_gripper", C.c_void_p), ("robot_obs_raw", C.c_void_p)]
 
 
+class HulcSbertConfig(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("intermediate", C.c_int32), ("vocab", C.c_int32),
+                ("max_position", C.c_int32), ("max_sentences", C.c_int32), ("max_tokens", C.c_int32), ("normalize", C.c_int32), ("ln_eps", C.c_float)]
+
+
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward", "hulc_backward_part",
-           "hulc_adam_step", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
+           "hulc_adam_step", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
 
 _lib = None
 
@@ -72,6 +77,11 @@ def load():
     lib.hulc_rollout_reset.argtypes = [C.c_void_p]
     lib.hulc_rollout_plan.argtypes = [C.c_void_p, C.POINTER(HulcRolloutObs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hulc_rollout_act.argtypes = [C.c_void_p, C.POINTER(HulcRolloutObs), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hulc_sbert_create.argtypes = [C.POINTER(HulcSbertConfig), C.POINTER(C.c_void_p)]
+    lib.hulc_sbert_destroy.argtypes = [C.c_void_p]
+    lib.hulc_sbert_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hulc_sbert_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.hulc_sbert_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.hulc_set_kl_beta.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_set_dropout.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_timers_enable.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]

@@ -142,6 +142,27 @@ int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* g
 int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix /* (6,10) or NULL */,
                      const float* u_act /* (6) or NULL */, float* action_out_host /* (7) */);
 
+/* ---- MiniLM sentence encoder: the reference's SBert (hulc/models/encoders/language_network.py:8-17) =
+ * sentence_transformers "all-MiniLM-L6-v2" (conf/model/sbert.yaml:2) = BERT encoder + masked mean pooling + L2 normalisation.
+ * Forward only, fp32.  Weights: one flat fp32 device buffer + Hugging Face BertModel state_dict names (e.g.
+ * "encoder.layer.0.attention.self.query.weight") with element offsets, like hulc_bind_params.  Token ids come from the host-side
+ * WordPiece tokenizer (hulc_amd/sbert.py).  Defaults of all-MiniLM-L6-v2: layers 6, hidden 384, heads 12, intermediate 1536,
+ * vocab 30522, max_position 512, ln_eps 1e-12, normalize 1. */
+typedef struct hulc_sbert_config {
+    int32_t layers, hidden, heads, intermediate, vocab, max_position;
+    int32_t max_sentences, max_tokens;     /* workspace: sentences per call, tokens per sentence (<= 128) */
+    int32_t normalize;                     /* 1: L2-normalise the pooled embedding */
+    float ln_eps;
+} hulc_sbert_config;
+typedef struct hulc_sbert hulc_sbert;
+int hulc_sbert_create(const hulc_sbert_config* cfg, hulc_sbert** out);
+int hulc_sbert_destroy(hulc_sbert* ctx);
+int hulc_sbert_set_stream(hulc_sbert* ctx, void* hip_stream);
+int hulc_sbert_bind(hulc_sbert* ctx, const float* flat_params, int64_t numel, int32_t n_tensors, const char* const* names,
+                    const int64_t* offsets, const int64_t* numels);
+/* token_ids / attention_mask: (B,L) int32, device or host; out: (B,hidden) fp32, device or host.  Synchronises the stream. */
+int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* token_ids, const int32_t* attention_mask, int32_t B, int32_t L, float* out);
+
 /* Runtime knobs: kl_beta (Hulc.set_kl_beta, hulc/models/hulc.py:563-565; called by hulc/utils/kl_callbacks.py:19-22) and the
  * transformer dropout probability (module.train()/eval(): 0 in eval mode). Take effect from the next hulc_forward_loss. */
 int hulc_set_kl_beta(hulc_ctx* ctx, float kl_beta);

@@ -884,3 +884,45 @@ def adam_step(P, G, state, step, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8):
         v[...] = b2 * v + (1 - b2) * g * g
         denom = np.sqrt(v) / math.sqrt(bc2) + eps
         P[n] = (P[n] - (lr / bc1) * m / denom).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------------
+# MiniLM sentence encoder: sentence_transformers "all-MiniLM-L6-v2" = transformers BertModel (pinned version in
+# this image: transformers 5.x, models/bert/modeling_bert.py: BertEmbeddings, BertSelfAttention, BertSelfOutput, BertIntermediate,
+# BertOutput) -> Pooling(mean, attention-mask weighted, clamp(min=1e-9)) -> Normalize (F.normalize p=2, eps 1e-12).
+# The library is a third-party dependency absent from /root/reference; parity is pinned on transformers.BertModel run in the build
+# container with seeded weights (tools/gen_golden_sbert.py -> tests/golden/sbert_minilm.npz).
+# ----------------------------------------------------------------------------------------------------
+def _erf(x):
+    # Abramowitz-Stegun 7.1.26 is too coarse (1.5e-7 abs) for a 2e-5 parity bar on 6 layers -> use math.erf elementwise
+    return np.vectorize(math.erf, otypes=[np.float64])(x)
+
+
+def sbert_forward(W, ids, mask, heads=12, eps=1e-12, normalize=True):
+    """W: BertModel state_dict (numpy); ids, mask: (B,L) ints.  Returns (sentence_embeddings (B,H), last_hidden_state (B,L,H))."""
+    B, Ln = ids.shape
+    H = W["embeddings.word_embeddings.weight"].shape[1]
+    x = (W["embeddings.word_embeddings.weight"][ids] + W["embeddings.position_embeddings.weight"][None, :Ln]
+         + W["embeddings.token_type_embeddings.weight"][0][None, None]).astype(F32)
+    x = layer_norm(x.reshape(B * Ln, H), W["embeddings.LayerNorm.weight"], W["embeddings.LayerNorm.bias"], eps)[0].reshape(B, Ln, H)
+    D = H // heads
+    bias = np.where(mask[:, None, None, :] != 0, 0.0, -np.inf).astype(F32)           # extended attention mask
+    nl = 1 + max(int(k.split(".")[2]) for k in W if k.startswith("encoder.layer."))
+    for l in range(nl):
+        p = f"encoder.layer.{l}."
+        x2 = x.reshape(B * Ln, H)
+        q, k, v = (linear(x2, W[p + f"attention.self.{n}.weight"], W[p + f"attention.self.{n}.bias"]).reshape(B, Ln, heads, D).transpose(0, 2, 1, 3)
+                   for n in ("query", "key", "value"))
+        sc = (q @ k.transpose(0, 1, 3, 2)) / F32(math.sqrt(D)) + bias
+        ctx = (softmax(sc, -1).astype(F32) @ v).transpose(0, 2, 1, 3).reshape(B * Ln, H)
+        y = linear(ctx, W[p + "attention.output.dense.weight"], W[p + "attention.output.dense.bias"]) + x2
+        x1 = layer_norm(y, W[p + "attention.output.LayerNorm.weight"], W[p + "attention.output.LayerNorm.bias"], eps)[0]
+        h = linear(x1, W[p + "intermediate.dense.weight"], W[p + "intermediate.dense.bias"])
+        h = (0.5 * h * (1.0 + _erf(h.astype(np.float64) / math.sqrt(2.0)))).astype(F32)
+        y2 = linear(h, W[p + "output.dense.weight"], W[p + "output.dense.bias"]) + x1
+        x = layer_norm(y2, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], eps)[0].reshape(B, Ln, H)
+    m = (mask != 0).astype(F32)[..., None]
+    emb = (x * m).sum(1) / np.maximum(m.sum(1), 1e-9)
+    if normalize:
+        emb = emb / np.maximum(np.linalg.norm(emb, axis=-1, keepdims=True), 1e-12)
+    return emb.astype(F32), x
