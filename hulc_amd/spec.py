@@ -18,7 +18,7 @@ from .utils import portable_rng as prng
 
 @dataclass(frozen=True)
 class ModelDims:
-    kind: str = "hulc"            # "hulc" | "gcbc"
+    kind: str = "hulc"            # "hulc" | "gcbc" | "mcil" (conf/model/mcil.yaml: BiRNN plan encoder, continuous latent; use_clip must be False)
     max_window: int = 32          # rows of plan_recognition.position_embeddings
     use_clip: bool = True         # use_clip_auxiliary_loss (creates proj_vis_lang + logit_scale)
     emb: int = 128                # perceptual latent size (64 static + 64 gripper)
@@ -35,17 +35,35 @@ class ModelDims:
     act_dims: int = 6             # out_features - 1 (discrete gripper)
     num_classes: int = 10
 
+    cont_plan: int = 256          # mcil: distribution.plan_features (conf/model/distribution/continuous.yaml)
+
     @property
     def plan(self) -> int:
-        return self.n_cat * self.n_cls
+        return self.cont_plan if self.kind == "mcil" else self.n_cat * self.n_cls
+
+    @property
+    def state(self) -> int:       # width of the fc_state outputs: logits (discrete) or mean | var (continuous, distributions.py:55-59)
+        return 2 * self.cont_plan if self.kind == "mcil" else self.n_cat * self.n_cls
 
     @property
     def dec_plan(self) -> int:    # plan features seen by the decoder (gcbc.py:44 sets 0)
         return 0 if self.kind == "gcbc" else self.plan
 
     @property
-    def dec_in(self) -> int:      # logistic_decoder_rnn.py:56-59 with perceptual_emb_slice [64,128]
-        return self.dec_plan + 64 + self.goal
+    def dec_emb(self) -> int:     # perceptual features seen by the decoder: perceptual_emb_slice [64,128] (hulc_default.yaml:15); all 128 for mcil
+        return self.emb if self.kind == "mcil" else 64
+
+    @property
+    def dec_in(self) -> int:      # logistic_decoder_rnn.py:56-59
+        return self.dec_plan + self.dec_emb + self.goal
+
+    @property
+    def mix_dims(self) -> int:    # dimensions modelled by the logistic mixture: 6 + discrete gripper head, or all 7 (mcil_default.yaml)
+        return 7 if self.kind == "mcil" else self.act_dims
+
+    @property
+    def mix_classes(self) -> int:
+        return 256 if self.kind == "mcil" else self.num_classes
 
 
 # (name, shape, init) ; init = ("u", fan_in) uniform(+-1/sqrt(fan_in)) | ("n",) N(0,1) | ("xav", fi, fo)
@@ -88,11 +106,20 @@ def param_table(d: ModelDims) -> List[Tuple[str, Tuple[int, ...], tuple]]:
     lin("plan_proposal.fc_model.2", H, H)
     lin("plan_proposal.fc_model.4", H, H)
     lin("plan_proposal.fc_model.6", H, H)
-    lin("plan_proposal.fc_state.0", d.plan, H)
+    lin("plan_proposal.fc_state.0", d.state, H)
 
     pr = "plan_recognition."
-    t.append((pr + "position_embeddings.weight", (d.max_window, d.emb), ("n",)))
-    for l in range(2):
+    if d.kind == "mcil":          # PlanRecognitionBiRNNNetwork (plan_recognition_net.py:12-42): nn.RNN(tanh), 2 layers, bidirectional
+        for l, kin in ((0, d.emb), (1, 2 * H)):
+            for sfx in ("", "_reverse"):
+                t.append((f"{pr}birnn_model.weight_ih_l{l}{sfx}", (H, kin), ("u", H)))
+                t.append((f"{pr}birnn_model.weight_hh_l{l}{sfx}", (H, H), ("u", H)))
+                t.append((f"{pr}birnn_model.bias_ih_l{l}{sfx}", (H,), ("u", H)))
+                t.append((f"{pr}birnn_model.bias_hh_l{l}{sfx}", (H,), ("u", H)))
+        lin(pr + "fc_state.0", d.state, 2 * H)
+    else:
+        t.append((pr + "position_embeddings.weight", (d.max_window, d.emb), ("n",)))
+    for l in range(0 if d.kind == "mcil" else 2):
         L = f"{pr}transformer_encoder.layers.{l}."
         t.append((L + "self_attn.in_proj_weight", (3 * d.emb, d.emb), ("xav", d.emb, 3 * d.emb)))
         t.append((L + "self_attn.in_proj_bias", (3 * d.emb,), ("zero",)))
@@ -102,8 +129,9 @@ def param_table(d: ModelDims) -> List[Tuple[str, Tuple[int, ...], tuple]]:
         lin(L + "linear2", d.emb, d.ff)
         ln(L + "norm1", d.emb)
         ln(L + "norm2", d.emb)
-    lin(pr + "fc", d.fc_hidden, d.emb)
-    lin(pr + "fc_state.0", d.plan, d.fc_hidden)
+    if d.kind != "mcil":
+        lin(pr + "fc", d.fc_hidden, d.emb)
+        lin(pr + "fc_state.0", d.plan, d.fc_hidden)
 
     lin("visual_goal.mlp.0", H, d.emb)
     lin("visual_goal.mlp.2", H, H)
@@ -120,11 +148,12 @@ def param_table(d: ModelDims) -> List[Tuple[str, Tuple[int, ...], tuple]]:
         t.append((f"{ad}rnn.weight_hh_l{l}", (H, H), ("u", H)))
         t.append((f"{ad}rnn.bias_ih_l{l}", (H,), ("u", H)))
         t.append((f"{ad}rnn.bias_hh_l{l}", (H,), ("u", H)))
-    no = d.act_dims * d.n_mix
+    no = d.mix_dims * d.n_mix
     lin(ad + "mean_fc", no, H)
     lin(ad + "log_scale_fc", no, H)
     lin(ad + "prob_fc", no, H)
-    lin(ad + "gripper_fc", 2, H)
+    if d.kind != "mcil":
+        lin(ad + "gripper_fc", 2, H)
 
     if d.use_clip:
         lin("proj_vis_lang.mlp_im.0", 128, d.fc_hidden)

@@ -453,12 +453,15 @@ def logistic_loss(logit_probs, log_scales_raw, means, gripper_logits, actions_tc
     m = lp.max(-1, keepdims=True)
     lse = m[..., 0] + np.log(np.exp(lp - m).sum(-1))
     logistics = -(lse.sum(-1)).mean()
-    # gripper cross entropy (:144-151) ; labels: -1 -> 0, else long(value)
-    g = actions_tcp[..., -1]
-    lab = np.where(g == -1, 0, g).astype(np.int64)
-    glsm = log_softmax(gripper_logits, -1)
-    ce = -np.take_along_axis(glsm, lab[..., None], -1)[..., 0].mean()
-    loss = F32(logistics + gripper_alpha * ce)
+    # gripper cross entropy (:144-151) ; labels: -1 -> 0, else long(value).  discrete_gripper=False (mcil_default.yaml): no head, :152
+    if gripper_logits is not None:
+        g = actions_tcp[..., -1]
+        lab = np.where(g == -1, 0, g).astype(np.int64)
+        glsm = log_softmax(gripper_logits, -1)
+        ce = -np.take_along_axis(glsm, lab[..., None], -1)[..., 0].mean()
+        loss = F32(logistics + gripper_alpha * ce)
+    else:
+        loss = F32(logistics)
     # ---- backward
     n = B * S
     wk = np.exp(lp - lse[..., None])
@@ -471,6 +474,8 @@ def logistic_loss(logit_probs, log_scales_raw, means, gripper_logits, actions_tc
     dmean = dlogp * (-inv) * (g_plus + g_minus + g_mid)
     dls = dlogp * (-(g_plus * plus + g_minus * minus + g_mid * mid) - np.where(caseD, 1.0, 0.0))
     dls_raw = np.where(log_scales_raw >= log_scale_min, dls, 0.0)
+    if gripper_logits is None:
+        return loss, (dlogit.astype(F32), dls_raw.astype(F32), dmean.astype(F32), None)
     dgl = np.exp(glsm)
     np.put_along_axis(dgl, lab[..., None], np.take_along_axis(dgl, lab[..., None], -1) - 1.0, -1)
     dgl = gripper_alpha * dgl / n
@@ -481,7 +486,8 @@ def decoder_loss_fwd(P, plan, emb, goal, actions, robot_obs, dims):
     """LogisticDecoderRNN.loss :121-134 -> forward :260-287."""
     ad = "action_decoder."
     B, S, _ = emb.shape
-    pe = emb[..., 64:128]
+    mcil = dims.kind == "mcil"
+    pe = emb[..., dims.emb - dims.dec_emb:dims.emb]               # perceptual_emb_slice [64,128]; mcil: no slice (mcil_default.yaml)
     parts = []
     if plan is not None and plan.shape[-1] > 0:
         parts.append(np.repeat(plan[:, None, :], S, 1))
@@ -489,13 +495,13 @@ def decoder_loss_fwd(P, plan, emb, goal, actions, robot_obs, dims):
     x = np.concatenate(parts, -1).astype(F32)
     H1, rc = rnn_fwd(P, ad + "rnn.", x)
     h2 = H1.reshape(B * S, -1)
-    K, Dd = dims.n_mix, dims.act_dims
+    K, Dd = dims.n_mix, dims.mix_dims
     probs = linear(h2, P[ad + "prob_fc.weight"], P[ad + "prob_fc.bias"]).reshape(B, S, Dd, K)
     means = linear(h2, P[ad + "mean_fc.weight"], P[ad + "mean_fc.bias"]).reshape(B, S, Dd, K)
     lsr = linear(h2, P[ad + "log_scale_fc.weight"], P[ad + "log_scale_fc.bias"]).reshape(B, S, Dd, K)
-    grip = linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
-    a_tcp = world_to_tcp_frame(actions, robot_obs)
-    loss, grads = logistic_loss(probs, lsr, means, grip, a_tcp, num_classes=dims.num_classes)
+    grip = None if mcil else linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
+    a_tcp = actions.astype(F32) if mcil else world_to_tcp_frame(actions, robot_obs)      # gripper_control: false (logistic_decoder_rnn.py:133-134)
+    loss, grads = logistic_loss(probs, lsr, means, grip, a_tcp, num_classes=dims.mix_classes)
     c = dict(rc=rc, x=x, H1=H1, probs=probs, means=means, log_scales=lsr, gripper=grip, a_tcp=a_tcp, grads=grads)
     return loss, c
 
@@ -505,9 +511,11 @@ def decoder_loss_bwd(P, G, c, dims, scale):
     H1 = c["H1"]
     B, S, Hn = H1.shape
     h2 = H1.reshape(B * S, Hn)
-    dlogit, dls, dmean, dgl = [g * F32(scale) for g in c["grads"]]
+    dlogit, dls, dmean, dgl = [None if g is None else g * F32(scale) for g in c["grads"]]
     dH = np.zeros((B * S, Hn), F32)
     for nm, d in (("prob_fc", dlogit), ("mean_fc", dmean), ("log_scale_fc", dls), ("gripper_fc", dgl)):
+        if d is None:
+            continue
         dx, dw, db = linear_bwd(h2, P[f"{ad}{nm}.weight"], d.reshape(B * S, -1))
         _acc(G, f"{ad}{nm}.weight", dw)
         _acc(G, f"{ad}{nm}.bias", db)
@@ -515,14 +523,107 @@ def decoder_loss_bwd(P, G, c, dims, scale):
     dx = rnn_bwd(P, G, ad + "rnn.", c["rc"], dH.reshape(B, S, Hn))
     np_ = dims.dec_plan
     dplan = dx[..., :np_].sum(1) if np_ > 0 else None
-    dpe = dx[..., np_:np_ + 64]
-    dgoal = dx[..., np_ + 64:].sum(1)
+    dpe = dx[..., np_:np_ + dims.dec_emb]
+    dgoal = dx[..., np_ + dims.dec_emb:].sum(1)
     return dplan, dpe, dgoal
 
 
 # ----------------------------------------------------------------------------------------------------
 # KL (hulc.py:539-561), straight-through sample (distributions.py:23-27), CLIP aux (hulc.py:650-695)
 # ----------------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# mcil variant (conf/model/mcil.yaml): bidirectional tanh-RNN plan recognition, continuous latent plan
+# ----------------------------------------------------------------------------------------------------
+def birnn_fwd(P, emb):
+    """PlanRecognitionBiRNNNetwork.forward (plan_recognition_net.py:37-42): nn.RNN(tanh, 2 layers, bidirectional, batch_first);
+    x = output[:, -1] = [forward hidden after the last step | reverse hidden at the last position (= its FIRST step)]."""
+    pre = "plan_recognition.birnn_model."
+    B, S, _ = emb.shape
+    c = {"inp0": emb}
+    inp = emb
+    for l in range(2):
+        outs = []
+        for sfx, order in (("", range(S)), ("_reverse", range(S - 1, -1, -1))):
+            wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
+            b = P[f"{pre}bias_ih_l{l}{sfx}"] + P[f"{pre}bias_hh_l{l}{sfx}"]
+            zx = (inp.reshape(B * S, -1) @ wih.T + b).reshape(B, S, -1)
+            Hs = np.zeros((B, S, whh.shape[0]), F32)
+            h = np.zeros((B, whh.shape[0]), F32)
+            for t in order:
+                h = np.tanh(zx[:, t] + h @ whh.T).astype(F32)
+                Hs[:, t] = h
+            c[f"H{l}{sfx}"] = Hs
+            outs.append(Hs)
+        inp = np.concatenate(outs, -1)
+        c[f"out{l}"] = inp
+    x = inp[:, -1]
+    c["x"] = x
+    state = linear(x, P["plan_recognition.fc_state.0.weight"], P["plan_recognition.fc_state.0.bias"])
+    return state, x, c
+
+
+def birnn_bwd(P, G, c, dstate):
+    pre = "plan_recognition.birnn_model."
+    dx, dw, db = linear_bwd(c["x"], P["plan_recognition.fc_state.0.weight"], dstate)
+    _acc(G, "plan_recognition.fc_state.0.weight", dw)
+    _acc(G, "plan_recognition.fc_state.0.bias", db)
+    emb = c["inp0"]
+    B, S, _ = emb.shape
+    Hn = c["H0"].shape[-1]
+    dout = np.zeros((B, S, 2 * Hn), F32)
+    dout[:, -1] = dx
+    for l in (1, 0):
+        inp = c["out0"] if l == 1 else emb
+        dinp = np.zeros_like(inp)
+        for k, (sfx, order) in enumerate((("", list(range(S))), ("_reverse", list(range(S - 1, -1, -1))))):
+            wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
+            Hs = c[f"H{l}{sfx}"]
+            dH = dout[..., k * Hn:(k + 1) * Hn]
+            dZ = np.zeros((B, S, Hn), F32)
+            carry = np.zeros((B, Hn), F32)
+            Hprev = np.zeros((B, S, Hn), F32)
+            for i in reversed(range(S)):                     # reverse of the processing order
+                t = order[i]
+                dz = (dH[:, t] + carry) * (1.0 - Hs[:, t] ** 2)
+                dZ[:, t] = dz
+                carry = dz @ whh
+                if i > 0:
+                    Hprev[:, t] = Hs[:, order[i - 1]]
+            dz2 = dZ.reshape(B * S, Hn)
+            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dz2.T @ Hprev.reshape(B * S, Hn))
+            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dz2.T @ inp.reshape(B * S, -1))
+            _acc(G, f"{pre}bias_ih_l{l}{sfx}", dz2.sum(0))
+            _acc(G, f"{pre}bias_hh_l{l}{sfx}", dz2.sum(0))
+            dinp += (dz2 @ wih).reshape(B, S, -1)
+        dout = dinp.astype(F32)
+    return dout              # grad w.r.t. perceptual_emb (B,S,128)
+
+
+def cont_state(state):
+    """Distribution.forward_dist, continuous (distributions.py:55-59): mean, std = softplus(var) + 1e-4."""
+    n = state.shape[-1] // 2
+    mean, var = state[..., :n], state[..., n:]
+    return mean.astype(F32), (softplus(var) + F32(1e-4)).astype(F32), var
+
+
+def kl_normal_balanced(pp_state, pr_state, beta=0.01, alpha=0.8):
+    """Hulc.compute_kl_loss (hulc.py:539-561) for Independent(Normal): KL(pr || pp) summed over the plan dims, mean over the batch,
+    balanced with stop-gradients.  Returns loss and the gradients w.r.t. the two fc_state outputs (mean | var)."""
+    B = pp_state.shape[0]
+    m2, s2, v2 = cont_state(pp_state)
+    m1, s1, v1 = cont_state(pr_state)
+    kl = (np.log(s2 / s1) + (s1 ** 2 + (m1 - m2) ** 2) / (2 * s2 ** 2) - 0.5).sum(-1).mean()
+    loss = F32(beta * (alpha * kl + (1 - alpha) * kl))
+    # lhs: gradient to the prior (pp); rhs: gradient to the posterior (pr)
+    dm2 = -(m1 - m2) / s2 ** 2
+    ds2 = 1.0 / s2 - (s1 ** 2 + (m1 - m2) ** 2) / s2 ** 3
+    dm1 = (m1 - m2) / s2 ** 2
+    ds1 = -1.0 / s1 + s1 / s2 ** 2
+    dpp = np.concatenate([dm2, ds2 * sigmoid(v2)], -1) * (beta * alpha / B)
+    dpr = np.concatenate([dm1, ds1 * sigmoid(v1)], -1) * (beta * (1 - alpha) / B)
+    return loss, dpp.astype(F32), dpr.astype(F32)
+
+
 # ----------------------------------------------------------------------------------------------------
 # dataloader image transforms (SURVEY.md §8(f) row 1): uint8 HWC frames -> the fp32 NCHW tensors the step consumes
 # ----------------------------------------------------------------------------------------------------
@@ -775,6 +876,16 @@ def modality_fwd(P, dims, mb, is_lang):
         gpre, c["goal_acts"] = mlp_fwd(P, VG_NAMES, emb[:, -1], False)
         goal, c["goal_ln"] = layer_norm(gpre, P["visual_goal.ln.weight"], P["visual_goal.ln.bias"])
     c["goal"] = goal
+    if dims.kind == "mcil":
+        pr_state, seq_feat, c["pr"] = birnn_fwd(P, emb)
+        pp_state, c["pp_acts"] = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)
+        mean, std, _ = cont_state(pr_state)
+        plan = (mean + std * mb["plan_eps"].astype(F32)).astype(F32)          # pr_dist.rsample() (hulc.py:289) with the injected N(0,1) draw
+        c.update(pr_logits=pr_state, pp_logits=pp_state, seq_feat=seq_feat, plan=plan, pr_std=std)
+        act, c["dec"] = decoder_loss_fwd(P, plan, emb, goal, mb["actions"], mb["robot_obs"], dims)
+        kl, c["dpp_kl"], c["dpr_kl"] = kl_normal_balanced(pp_state, pr_state)
+        c["clip"] = None
+        return dict(kl=kl, action=act, total=F32(act + kl), clip=F32(0)), c
     pr_logits, seq_feat, c["pr"] = plan_recognition_fwd(P, emb, dims.heads)
     c["pr_logits"], c["seq_feat"] = pr_logits, seq_feat
     out = {}
@@ -808,8 +919,17 @@ def modality_bwd(P, G, dims, c, is_lang, w_mod, w_clip):
     B, S, _ = emb.shape
     demb = np.zeros_like(emb)
     dplan, dpe, dgoal = decoder_loss_bwd(P, G, c["dec"], dims, w_mod)
-    demb[..., 64:128] += dpe
+    demb[..., dims.emb - dims.dec_emb:] += dpe
     dsf = None
+    if dims.kind == "mcil":
+        n = dims.plan
+        _, _, var = cont_state(c["pr_logits"])
+        # plan = mean + std * eps -> d mean = dplan, d var = dplan * eps * sigmoid(var)
+        dpr = np.concatenate([dplan, dplan * ((c["plan"] - c["pr_logits"][:, :n]) / c["pr_std"]) * sigmoid(var)], -1) + c["dpr_kl"] * F32(w_mod)
+        demb += birnn_bwd(P, G, c["pr"], dpr.astype(F32))
+        dppx = mlp_bwd(P, G, PP_NAMES, c["pp_acts"], (c["dpp_kl"] * F32(w_mod)).astype(F32), False)
+        demb[:, 0] += dppx[:, :dims.emb]
+        dgoal = dgoal + dppx[:, dims.emb:]
     if c["clip"] is not None:
         dsf, dg_clip = clip_loss_bwd(P, G, c["clip"], w_clip, B)
         dgoal = dgoal + dg_clip
@@ -823,7 +943,7 @@ def modality_bwd(P, G, dims, c, is_lang, w_mod, w_clip):
         dppx = mlp_bwd(P, G, PP_NAMES, c["pp_acts"], dpp, False)
         demb[:, 0] += dppx[:, :dims.emb]
         dgoal = dgoal + dppx[:, dims.emb:]
-    if dpr_logits is not None or dsf is not None:
+    if dims.kind != "mcil" and (dpr_logits is not None or dsf is not None):
         demb += plan_recognition_bwd(P, G, c["pr"], dpr_logits, dsf, dims.heads,
                                      fc_state_used=dims.kind == "hulc")
     lnn = "language_goal.ln" if is_lang else "visual_goal.ln"

@@ -107,3 +107,18 @@ def load_rollout_case(name="rollout_hulc"):
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     frames = synthetic.make_batch(1, 1, nsteps + 1, seed=seed, edge_frac=0.0, aux_mask="all")
     return dims, P, frames, nsteps, replan_freq, fx
+
+
+# ---- mcil variant (tools/gen_golden_mcil.py)
+MCIL_CASES = {"mcil_s6": (2, 2, 6, 41), "mcil_s12": (3, 0, 12, 32)}       # name: (Bv, Bl, S, seed)
+
+
+def load_mcil_case(name):
+    Bv, Bl, S, seed = MCIL_CASES[name]
+    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    for sc in batch:
+        batch[sc]["plan_eps"] = fx[f"plan_eps_{sc}"]
+    return dims, P, batch, fx
