@@ -86,8 +86,13 @@ template <typename T>
 struct Engine : IEngine {
     hulc_config cfg;
     // ---- model dims
-    static constexpr int EMB = 128, VF = 64, GOAL = 32, LANG = 384, HID = 2048, NCAT = 32, NCLS = 32, PLAN = 1024, NH = 8, FF = 2048,
-                         FCH = 4096, NMIX = 10, NDIM = 6, NHEAD = 192, NO = 60;
+    static constexpr int EMB = 128, VF = 64, GOAL = 32, LANG = 384, HID = 2048, NCAT = 32, NCLS = 32, NH = 8, FF = 2048,
+                         FCH = 4096, NMIX = 10;
+    // per model kind: PLAN = width of the two fc_state outputs (32x32 logits; mcil: mean|var of a 256-d Normal), NDIM = mixture
+    // dimensions (6 + discrete gripper head; mcil: 7, no gripper head), NHEAD = packed head columns (16-aligned), DE = decoder's slice
+    // of the perceptual embedding (perceptual_emb_slice [64,128]; mcil: all 128)
+    int PLAN, NDIM, NHEAD, NO, DE;
+    bool mcil;
     int dec_plan, KIN;
     int maxB, maxS, maxN;
     // ---- bound flat buffers
@@ -125,6 +130,11 @@ struct Engine : IEngine {
     struct EncW { ConvW c1, c2, c3; LinW fc7, fc1, fc2; const float *lng = nullptr, *lnb = nullptr; float *dlng = nullptr, *dlnb = nullptr; bool gripper = false; int IH = 0; int H1 = 0, H2 = 0, H3 = 0; };
     EncW encS, encG;
     LinW pp[5], vg[3], lg[3], tr_in[2], tr_out[2], tr_l1[2], tr_l2[2], pr_fc, pr_fs, whh0, wih1, whh1, cl_im0, cl_im2, cl_la0, cl_la2;
+    // mcil plan recognition (plan_recognition_net.py:14-42): 2-layer bidirectional tanh RNN; [layer][direction]
+    LinW bw_ih[2][2], bw_hh[2][2];
+    const float *bb_ih[2][2], *bb_hh[2][2]; float *dbb_ih[2][2], *dbb_hh[2][2];
+    T *bZ0[2] = {nullptr, nullptr}, *bH0[2], *bZ1, *bH1, *bh1b, *bxcat, *bdx, *bdH0[2], *bdZ0[2], *bdZ1, *bdz1b, *plan_t;
+    float *plan_f, *plan_eps, *plan_eps_in, *klel;
     const float *ln_vg_g, *ln_vg_b, *ln_lg_g, *ln_lg_b, *tr_n1g[2], *tr_n1b[2], *tr_n2g[2], *tr_n2b[2], *pos32, *logit_scale;
     float *d_ln_vg_g, *d_ln_vg_b, *d_ln_lg_g, *d_ln_lg_b, *d_tr_n1g[2], *d_tr_n1b[2], *d_tr_n2g[2], *d_tr_n2b[2], *dpos, *dlogit_scale;
     // decoder input weights W_ih0 [HID][KIN] (sub-blocked) + packed heads
@@ -161,8 +171,11 @@ struct Engine : IEngine {
 
     // =====================================================================================================
     Engine(const hulc_config& c) : cfg(c) {
-        dec_plan = cfg.kind == HULC_KIND_GCBC ? 0 : PLAN;
-        KIN = dec_plan + 64 + GOAL;
+        mcil = cfg.kind == HULC_KIND_MCIL;
+        PLAN = mcil ? 512 : 1024; NDIM = mcil ? 7 : 6; NO = NMIX * NDIM; NHEAD = mcil ? 224 : 192; DE = mcil ? EMB : 64;
+        if (mcil) { head_rows[0] = head_rows[1] = head_rows[2] = NO; head_rows[3] = 0; }
+        dec_plan = cfg.kind == HULC_KIND_GCBC ? 0 : (mcil ? PLAN / 2 : PLAN);
+        KIN = dec_plan + DE + GOAL;
         maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
     }
     ~Engine() override { for (void* p : allocs) hipFree(p); }
@@ -210,7 +223,7 @@ struct Engine : IEngine {
         xm = alloc<T>(B * EMB); seqf = alloc<float>(B * FCH, "seq_feat"); seqf_t = alloc<T>(B * FCH); pr_logits = alloc<float>(B * PLAN, "pr_logits");
         probs = alloc<float>(B * PLAN, "pr_probs"); klcat = alloc<float>(B * NCAT); dpp_kl = alloc<float>(B * PLAN); dpr_kl = alloc<float>(B * PLAN);
         pidx = alloc<int>(B * NCAT, "plan_idx"); pidx_in = alloc<int>(B * NCAT);
-        embg = alloc<T>(SB * 64); Cplan = alloc<float>(B * HID); Cb = alloc<T>(B * HID, "dec_cb");
+        embg = alloc<T>(SB * DE); Cplan = alloc<float>(B * HID); Cb = alloc<T>(B * HID, "dec_cb");
         Zx0 = alloc<T>(SB * HID); Zx1 = alloc<T>(SB * HID); H0 = alloc<T>(SB * HID, "dec_h0"); H1 = alloc<T>(SB * HID, "dec_h1");
         heads = alloc<float>(SB * NHEAD, "heads"); dheads = alloc<T>(SB * NHEAD, "dheads"); rowloss = alloc<float>(SB * 8); a_tcp = alloc<float>(SB * 7, "a_tcp");
         dH1 = alloc<T>(SB * HID); dZ1 = alloc<T>(SB * HID, "dec_dz1"); dH0 = alloc<T>(SB * HID); dZ0 = alloc<T>(SB * HID, "dec_dz0"); dC = alloc<T>(B * HID);
@@ -237,6 +250,13 @@ struct Engine : IEngine {
         dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
         dim1 = alloc<T>(B * 128); dla1 = alloc<T>(B * 128); dsf_m = alloc<float>(B * FCH); dg_m = alloc<float>(B * GOAL);
         losses = alloc<float>(8);
+        if (mcil) {
+            for (int d = 0; d < 2; ++d) { bZ0[d] = alloc<T>(SB * HID); bH0[d] = alloc<T>(SB * HID, d ? "birnn_h0_rev" : "birnn_h0"); bdH0[d] = alloc<T>(SB * HID); bdZ0[d] = alloc<T>(SB * HID); }
+            bZ1 = alloc<T>(SB * HID); bH1 = alloc<T>(SB * HID, "birnn_h1"); bh1b = alloc<T>(B * HID); bxcat = alloc<T>(B * 2 * HID, "birnn_x"); bdx = alloc<T>(B * 2 * HID);
+            bdZ1 = alloc<T>(SB * HID); bdz1b = alloc<T>(B * HID);
+            plan_t = alloc<T>(B * PLAN / 2); plan_f = alloc<float>(B * PLAN / 2, "plan"); plan_eps = alloc<float>(B * PLAN / 2); plan_eps_in = alloc<float>(B * PLAN / 2);
+            klel = alloc<float>(B * PLAN / 2);
+        }
         bheads = alloc<float>(NHEAD); wheads = alloc<T>((int64_t)NHEAD * HID); wheadsT = alloc<T>((int64_t)HID * NHEAD);
         if (alloc_failed) { hulc_set_error("hipMalloc failed while sizing the workspace (B=%d S=%d)", maxB, maxS); return 1; }
         return 0;
@@ -305,6 +325,17 @@ struct Engine : IEngine {
             ln_vg_g = pw("visual_goal.ln.weight"); ln_vg_b = pw("visual_goal.ln.bias"); d_ln_vg_g = gw("visual_goal.ln.weight"); d_ln_vg_b = gw("visual_goal.ln.bias");
             ln_lg_g = pw("language_goal.ln.weight"); ln_lg_b = pw("language_goal.ln.bias"); d_ln_lg_g = gw("language_goal.ln.weight"); d_ln_lg_b = gw("language_goal.ln.bias");
             const std::string pr = "plan_recognition.";
+            if (mcil) {
+                for (int l = 0; l < 2; ++l)
+                    for (int d = 0; d < 2; ++d) {
+                        const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+                        const std::string bp = pr + "birnn_model.";
+                        bind_lin(bw_ih[l][d], bp + "weight_ih" + sfx, HID, l ? 2 * HID : EMB, false);
+                        bind_lin(bw_hh[l][d], bp + "weight_hh" + sfx, HID, HID, false);
+                        bb_ih[l][d] = pw(bp + "bias_ih" + sfx); bb_hh[l][d] = pw(bp + "bias_hh" + sfx);
+                        dbb_ih[l][d] = gw(bp + "bias_ih" + sfx); dbb_hh[l][d] = gw(bp + "bias_hh" + sfx);
+                    }
+            } else {
             pos32 = pw(pr + "position_embeddings.weight"); dpos = gw(pr + "position_embeddings.weight");
             for (int l = 0; l < 2; ++l) {
                 const std::string L = pr + "transformer_encoder.layers." + std::to_string(l) + ".";
@@ -321,6 +352,7 @@ struct Engine : IEngine {
                 tr_n2g[l] = pw(L + "norm2.weight"); tr_n2b[l] = pw(L + "norm2.bias"); d_tr_n2g[l] = gw(L + "norm2.weight"); d_tr_n2b[l] = gw(L + "norm2.bias");
             }
             bind_lin(pr_fc, pr + "fc", FCH, EMB);
+            }
             bind_lin(pr_fs, pr + "fc_state.0", PLAN, FCH);
             const std::string ad = "action_decoder.";
             wih0_32 = pw(ad + "rnn.weight_ih_l0"); dwih0 = gw(ad + "rnn.weight_ih_l0");
@@ -333,7 +365,8 @@ struct Engine : IEngine {
             bind_lin(wih1, ad + "rnn.weight_ih_l1", HID, HID, false);
             bind_lin(whh1, ad + "rnn.weight_hh_l1", HID, HID, false);
             const char* hn[4] = {"prob_fc", "mean_fc", "log_scale_fc", "gripper_fc"};
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) { head_w32[i] = head_b32[i] = nullptr; head_dw[i] = head_db[i] = nullptr; }
+            for (int i = 0; i < (mcil ? 3 : 4); ++i) {
                 head_w32[i] = pw(ad + hn[i] + ".weight"); head_b32[i] = pw(ad + hn[i] + ".bias");
                 head_dw[i] = gw(ad + hn[i] + ".weight"); head_db[i] = gw(ad + hn[i] + ".bias");
             }
@@ -764,7 +797,7 @@ struct Engine : IEngine {
             }
         }
         // ---- plan proposal (plan_proposal_net.py:42-47)
-        if (hulc) {
+        if (hulc || mcil) {
             hipLaunchKernelGGL((concat_pp_kernel<T>), dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, emb, (long long)S * EMB, EMB, goal_t, GOAL, B, ppx);
             mlp_fwd(ppx, EMB + GOAL, B, pp, 5, ppa, pp_logits, nullptr);
         }
@@ -799,12 +832,16 @@ struct Engine : IEngine {
         const int SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
             // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
-            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * 64, 256)), dim3(256), 0, st, emb, embg, B, S);
+            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * DE, 256)), dim3(256), 0, st, emb, embg, B, S, DE);
+            if (mcil) {      // continuous plan (B,256): a GEMM against the plan columns of W_ih0 instead of the one-hot column gather
+                EpiP ep = epi(Cplan, true); ep.bias = bih0; ep.bias2 = bhh0;
+                gemm(dense<T>(plan_t, B, dec_plan), dense<T>(wih0, HID, KIN), dense_out(HID), ep, B, HID, dec_plan);
+            } else
             hipLaunchKernelGGL(plan_gather_kernel, dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0_32, KIN, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
             { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
-              gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + 64, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
+              gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + DE, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
             { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
-              gemm(dense<T>(embg, SB, 64), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, 64); }
+              gemm(dense<T>(embg, SB, DE), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, DE); }
             rnn_fwd(Zx0, H0, whh0, B, S, h0_0);
             { EpiP ep = epi(Zx1, false); ep.bias = bih1; ep.bias2 = bhh1;
               gemm(dense<T>(H0, SB, HID), dense<T>(wih1.W, HID, HID), dense_out(HID), ep, SB, HID, HID); }
@@ -827,7 +864,16 @@ struct Engine : IEngine {
         const float dp = cfg.dropout_p;
         HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
         trunk_fwd(b, dp);
-        pr_fwd(B, S, dp);
+        if (mcil) {
+            birnn_fwd(B, S);
+            const int n = PLAN / 2;
+            const float* eps = nullptr;
+            if (b->plan_eps) { HIP_CHECK(hipMemcpyAsync(plan_eps_in, b->plan_eps, sizeof(float) * B * n, hipMemcpyDefault, st)); eps = plan_eps_in; }
+            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / B, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / B;
+            hipLaunchKernelGGL((normal_kl_sample_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, pr_logits, pp_logits, B, n, eps, plan_eps, plan_f, plan_t, klel,
+                               dpp_kl, dpr_kl, wpp, wpr, site_seed(20));
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, B * n, cfg.kl_beta / B, losses + 1);
+        } else pr_fwd(B, S, dp);
         // ---- sample + KL (hulc.py:289-296, 539-561)
         if (hulc) {
             const int* idx_in = nullptr;
@@ -840,8 +886,9 @@ struct Engine : IEngine {
         // ---- action decoder (logistic_decoder_rnn.py:260-287): plan/goal terms hoisted out of the time loop
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
+            // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
             hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
-                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, lw / (float)SB, rowloss, a_tcp, dheads);
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)SB, rowloss, a_tcp, dheads, mcil ? 0 : 1);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
         STAGE("decoder_fwd");
@@ -887,6 +934,7 @@ struct Engine : IEngine {
                  float* pred_pr_out) override {
         if (!bound) { hulc_set_error("hulc_validate before hulc_bind_params"); return 1; }
         const bool hulc = cfg.kind == HULC_KIND_HULC;     // GCBC (gcbc.py:214-246): one decoder pass without a plan, reported in the "pp" slots
+        if (mcil) { hulc_set_error("hulc_validate: not implemented for the mcil model kind (training step only)"); return 1; }
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
             return 1;
@@ -1015,28 +1063,106 @@ struct Engine : IEngine {
         return 0;
     }
 
-    // H[t] = relu(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID]
-    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S, const T* h0 = nullptr) {
+    // H[t] = act(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID].  act 1: ReLU (action decoder), 2: tanh (mcil BiRNN); rev: the
+    // recurrence runs from t = S-1 down to 0 (nn.RNN's reverse direction, outputs stay at their own positions)
+    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S, const T* h0 = nullptr, int act = 1, bool rev = false) {
         const long long BH = (long long)B * HID;
+        auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i) * BH; };
         if (h0) {
-            EpiP ep = epi(H, false); ep.res = Zx; ep.res_ld = HID; ep.relu = 1;
+            EpiP ep = epi(H + at(0), false); ep.res = Zx + at(0); ep.res_ld = HID; ep.relu = act;
             gemm(dense<T>(h0, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
-        } else hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx, H, BH);
+        } else hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx + at(0), H + at(0), BH, act);
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
-        for (int t = 1; t < S; ++t) {
-            EpiP ep = epi(H + t * BH, false); ep.res = Zx + t * BH; ep.res_ld = HID; ep.relu = 1;
-            gemm(dense<T>(H + (t - 1) * BH, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
+        for (int i = 1; i < S; ++i) {
+            EpiP ep = epi(H + at(i), false); ep.res = Zx + at(i); ep.res_ld = HID; ep.relu = act;
+            gemm(dense<T>(H + at(i - 1), B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
         }
     }
-    // dZ[t] = (dH[t] + dZ[t+1] Whh) * (H[t] > 0)
-    void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S) {
+    // dZ[t] = (dH[t] + dZ[t+1] Whh) * act'(H[t]).  dH_last_only: dH is [B][HID], the gradient of the LAST processed state alone.
+    void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S, int act = 1, bool rev = false, bool dH_last_only = false) {
         const long long BH = (long long)B * HID;
-        hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH + (S - 1) * BH, H + (S - 1) * BH, dZ + (S - 1) * BH, BH);
+        auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i) * BH; };
+        hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH_last_only ? dH : dH + at(S - 1), H + at(S - 1), dZ + at(S - 1), BH, act);
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
-        for (int t = S - 2; t >= 0; --t) {
-            EpiP ep = epi(dZ + t * BH, false); ep.res = dH + t * BH; ep.res_ld = HID; ep.mask = H + t * BH;
-            gemm(dense<T>(dZ + (t + 1) * BH, B, HID), dense<T>(whh.Wt, HID, HID), dense_out(HID), ep, B, HID, HID);
+        for (int i = S - 2; i >= 0; --i) {
+            EpiP ep = epi(dZ + at(i), false); ep.mask = H + at(i); ep.mask_tanh = act == 2;
+            if (!dH_last_only) { ep.res = dH + at(i); ep.res_ld = HID; }
+            gemm(dense<T>(dZ + at(i + 1), B, HID), dense<T>(whh.Wt, HID, HID), dense_out(HID), ep, B, HID, HID);
         }
+    }
+
+    // ---------------------------------------------------------------- mcil plan recognition (plan_recognition_net.py:14-42)
+    // nn.RNN(tanh, 2 layers, bidirectional) over the time-major embedding; x = output[:, -1] = [fwd state after the last step |
+    // reverse state at the last position (its FIRST step, so the layer-1 reverse recurrence never runs)]; pr_state = fc_state(x).
+    void birnn_fwd(int B, int S) {
+        const int SB = S * B;
+        const long long BH = (long long)B * HID;
+        hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * EMB, 256)), dim3(256), 0, st, emb, embg, B, S, EMB);
+        for (int d = 0; d < 2; ++d) {
+            { EpiP ep = epi(bZ0[d], false); ep.bias = bb_ih[0][d]; ep.bias2 = bb_hh[0][d];
+              gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, HID, EMB), dense_out(HID), ep, SB, HID, EMB); }
+            rnn_fwd(bZ0[d], bH0[d], bw_hh[0][d], B, S, nullptr, 2, d == 1);
+        }
+        // layer 1 forward direction: input [H0f | H0b] -> two K = 2048 GEMMs against the column halves of W_ih_l1
+        { EpiP ep = epi(bZ1, false); ep.bias = bb_ih[1][0]; ep.bias2 = bb_hh[1][0];
+          gemm(dense<T>(bH0[0], SB, HID), dense<T>(bw_ih[1][0].W, HID, 2 * HID), dense_out(HID), ep, SB, HID, HID); }
+        { EpiP ep = epi(bZ1, false); ep.res = bZ1; ep.res_ld = HID;
+          gemm(dense<T>(bH0[1], SB, HID), dense<T>(bw_ih[1][0].W + HID, HID, 2 * HID), dense_out(HID), ep, SB, HID, HID); }
+        rnn_fwd(bZ1, bH1, bw_hh[1][0], B, S, nullptr, 2, false);
+        // layer 1 reverse direction at position S-1 only (h_prev = 0): tanh(W_ih [H0f|H0b][S-1] + b)
+        { EpiP ep = epi(bh1b, false); ep.bias = bb_ih[1][1]; ep.bias2 = bb_hh[1][1];
+          gemm(dense<T>(bH0[0] + (S - 1) * BH, B, HID), dense<T>(bw_ih[1][1].W, HID, 2 * HID), dense_out(HID), ep, B, HID, HID); }
+        { EpiP ep = epi(bh1b, false); ep.res = bh1b; ep.res_ld = HID; ep.relu = 2;
+          gemm(dense<T>(bH0[1] + (S - 1) * BH, B, HID), dense<T>(bw_ih[1][1].W + HID, HID, 2 * HID), dense_out(HID), ep, B, HID, HID); }
+        copy2d<T, T>(bH1 + (S - 1) * BH, HID, bxcat, 2 * HID, B, HID, 0);
+        copy2d<T, T>(bh1b, HID, bxcat + HID, 2 * HID, B, HID, 0);
+        { EpiP ep = epi(pr_logits, true); lin_fwd(bxcat, 2 * HID, B, pr_fs, ep, PLAN); }
+        STAGE("birnn_fwd");
+    }
+    // dpr: d pr_state (T, [B][PLAN]).  Accumulates the BiRNN / fc_state parameter gradients and adds d emb into demb (B,S,128).
+    void birnn_bwd(const T* dpr, int B, int S) {
+        const int SB = S * B, mp = ldpad(SB);
+        const long long BH = (long long)B * HID;
+        lin_wgrad(dpr, bxcat, 2 * HID, B, PLAN, 2 * HID, pr_fs.dW, 2 * HID, pr_fs.db);
+        { EpiP ep = epi(bdx, false); lin_dgrad(dpr, B, pr_fs, ep, dense_out(2 * HID)); }
+        // ---- layer 1, reverse direction: one step, no recurrence (weight_hh_l1_reverse receives no gradient)
+        copy2d<T, T>(bdx + HID, 2 * HID, dt_a + BH, HID, B, HID, 0);
+        hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dt_a + BH, bh1b, bdz1b, BH, 2);
+        lin_wgrad(bdz1b, bH0[0] + (S - 1) * BH, HID, B, HID, HID, bw_ih[1][1].dW, 2 * HID, dbb_ih[1][1], dbb_hh[1][1]);
+        lin_wgrad(bdz1b, bH0[1] + (S - 1) * BH, HID, B, HID, HID, bw_ih[1][1].dW + HID, 2 * HID, nullptr);
+        // ---- layer 1, forward direction: BPTT from the last state
+        copy2d<T, T>(bdx, 2 * HID, dt_a, HID, B, HID, 0);       // its only consumer is x = output[:, -1]: dH = bdx[:, 0:HID] at t = S-1, zero elsewhere
+        rnn_bwd(dt_a, bH1, bdZ1, bw_hh[1][0], B, S, 2, false, true);
+        // d (layer-0 outputs) = dZ1 W_ih_l1 (+ the reverse direction's single step at t = S-1)
+        for (int d = 0; d < 2; ++d) {
+            { EpiP ep = epi(bdH0[d], false);
+              gemm(dense<T>(bdZ1, SB, HID), dense<T>(bw_ih[1][0].Wt + (long long)d * HID * HID, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            { EpiP ep = epi(bdH0[d] + (S - 1) * BH, false); ep.res = bdH0[d] + (S - 1) * BH; ep.res_ld = HID;
+              gemm(dense<T>(bdz1b, B, HID), dense<T>(bw_ih[1][1].Wt + (long long)d * HID * HID, HID, HID), dense_out(HID), ep, B, HID, HID); }
+        }
+        // layer-1 forward weights
+        transpose_pair(bdZ1, HID, tA, SB, HID, bH1, HID, tB, SB, HID, mp);
+        if (S > 1) { EpiP ep = epi(bw_hh[1][0].dW, true); ep.accumulate = 1;
+          gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
+        for (int d = 0; d < 2; ++d) {
+            cast_tr<T, T>(bH0[d], HID, nullptr, 0, tB, mp, SB, HID);
+            EpiP ep = epi(bw_ih[1][0].dW + d * HID, true); ep.accumulate = 1;
+            gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(2 * HID), ep, HID, HID, SB);
+        }
+        colsum(bdZ1, HID, SB, HID, dbb_ih[1][0], dbb_hh[1][0]);
+        // ---- layer 0, both directions
+        for (int d = 0; d < 2; ++d) {
+            rnn_bwd(bdH0[d], bH0[d], bdZ0[d], bw_hh[0][d], B, S, 2, d == 1, false);
+            transpose_pair(bdZ0[d], HID, tA, SB, HID, bH0[d], HID, tB, SB, HID, mp);
+            if (S > 1) { EpiP ep = epi(bw_hh[0][d].dW, true); ep.accumulate = 1;     // forward: dZ[t] x H[t-1]; reverse: dZ[t] x H[t+1]
+              gemm(dense<T>(tA + (d ? 0 : B), HID, mp), dense<T>(tB + (d ? B : 0), HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
+            cast_tr<T, T>(embg, EMB, nullptr, 0, tB, mp, SB, EMB);
+            { EpiP ep = epi(bw_ih[0][d].dW, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, EMB, mp), dense_out(EMB), ep, HID, EMB, SB); }
+            colsum(bdZ0[d], HID, SB, HID, dbb_ih[0][d], dbb_hh[0][d]);
+            { EpiP ep = epi(demb, true); ep.accumulate = 1;
+              gemm(dense<T>(bdZ0[d], SB, HID), dense<T>(bw_ih[0][d].Wt, EMB, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, EMB, HID); }
+        }
+        STAGE("birnn_bwd");
     }
 
     // ---------------------------------------------------------------- backward
@@ -1104,25 +1230,29 @@ struct Engine : IEngine {
                 transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
-                cast_tr<T, T>(embg, 64, nullptr, 0, tB, mp, SB, 64);
-                { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, 64, mp), dense_out(KIN), ep, HID, 64, SB); }
+                cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
+                { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
             }
             // d emb (gripper half), scattered back to (B,S,128)[..., 64:128]
-            { EpiP ep = epi(demb + 64, true); ep.accumulate = 1;
-              gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, 64, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, 64, HID); }
+            { EpiP ep = epi(demb + (EMB - DE), true); ep.accumulate = 1;
+              gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, DE, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, DE, HID); }
             hipLaunchKernelGGL((sum_over_t_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dZ0, S, BH, dC);
             colsum(dC, HID, B, HID, dbih0, dbhh0);
             { EpiP ep = epi(dgoal, true); ep.accumulate = 1;
-              gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + 64) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
+              gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + DE) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
             {
                 const int mp = ldpad(B);
                 transpose_pair(dC, HID, tA, B, HID, goal_t, GOAL, tB, B, GOAL, mp);
-                EpiP ep = epi(dwih0 + dec_plan + 64, true); ep.accumulate = 1;
+                EpiP ep = epi(dwih0 + dec_plan + DE, true); ep.accumulate = 1;
                 gemm(dense<T>(tA, HID, mp), dense<T>(tB, GOAL, mp), dense_out(KIN), ep, HID, GOAL, B);
             }
             if (hulc) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, PLAN, HID), dense_out(PLAN), ep, B, PLAN, HID); }
                 hipLaunchKernelGGL((plan_scatter_grad_kernel<T>), dim3(cdiv(HID * NCAT, 256)), dim3(256), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
+            }
+            if (mcil) {
+                { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, dec_plan, HID), dense_out(dec_plan), ep, B, dec_plan, HID); }
+                lin_wgrad(dC, plan_t, dec_plan, B, HID, dec_plan, dwih0, KIN, nullptr);
             }
         }
         STAGE("decoder_bwd");
@@ -1139,6 +1269,17 @@ struct Engine : IEngine {
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
             { EpiP ep = epi(dseqf, true); ep.accumulate = 1; lin_dgrad(dprl_t, B, pr_fs, ep, dense_out(FCH)); }
             have_dseq = true;
+        }
+        // ---- mcil: reparametrised sample + KL -> fc_state grads; plan proposal and BiRNN backward
+        if (mcil) {
+            const int n = PLAN / 2;
+            hipLaunchKernelGGL((normal_rsample_bwd_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, dplan, plan_eps, pr_logits, dpr_kl, B, n, dprl_t);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dpp_kl, dppl_t, (long long)B * PLAN);
+            DenseOut om = dense_out(EMB + GOAL);
+            mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
+            copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
+            copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            birnn_bwd(dprl_t, B, S);
         }
         // ---- plan recognition backward
         if (have_dseq) {

@@ -29,8 +29,9 @@ struct EpiP {
     long long res_ld = 0;
     int res_rowmod = 0;          // >0: residual row = r % res_rowmod (broadcast over time)
     int res_late = 0;            // 0: residual added before relu/mask (RNN); 1: after dropout (transformer x + drop(f(x)))
-    const void* mask = nullptr;  // T*, same element offsets as out: v *= (mask > 0)
-    int relu = 0;
+    const void* mask = nullptr;  // T*, same element offsets as out: v *= (mask > 0)   [mask_tanh: v *= 1 - mask^2]
+    int mask_tanh = 0;
+    int relu = 0;                // 1: ReLU, 2: tanh
     float alpha = 1.f;
     float drop_p = 0.f;          // inverted dropout applied after relu/mask (seeded by element offset)
     unsigned long long drop_seed = 0;
@@ -250,8 +251,11 @@ DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) 
         resv = ep.res_f32 ? reinterpret_cast<const float*>(ep.res)[ro] : to_f<T>(reinterpret_cast<const T*>(ep.res)[ro]);
     }
     if (!ep.res_late) v += resv;
-    if (ep.relu) v = fmaxf(v, 0.f);
-    if (ep.mask) v = (to_f<T>(reinterpret_cast<const T*>(ep.mask)[o]) > 0.f) ? v : 0.f;
+    if (ep.relu) v = ep.relu == 2 ? tanhf(v) : fmaxf(v, 0.f);
+    if (ep.mask) {
+        const float m = to_f<T>(reinterpret_cast<const T*>(ep.mask)[o]);
+        v = ep.mask_tanh ? v * (1.f - m * m) : (m > 0.f ? v : 0.f);
+    }
     if (ep.drop_p > 0.f) {
         const float u = hash_uniform(ep.drop_seed, (unsigned long long)o);
         v = (u < ep.drop_p) ? 0.f : v * (1.f / (1.f - ep.drop_p));
@@ -320,13 +324,21 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p.rv[r];
     }
-    if (ep.relu) {
+    if (ep.relu == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+    } else if (ep.relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
     if (ep.mask) {
+        if (ep.mask_tanh) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = p.mk[r] > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 4; ++r) v[r] *= 1.f - p.mk[r] * p.mk[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = p.mk[r] > 0.f ? v[r] : 0.f;
+        }
     }
     if (ep.res_late) {
 #pragma unroll

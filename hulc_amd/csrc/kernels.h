@@ -779,6 +779,53 @@ __global__ void __launch_bounds__(64) plan_kl_sample_kernel(const float* __restr
     }
     if (lane == 0) idx_out[bc] = sel;
 }
+// mcil: continuous latent plan.  state = [mean | var] (B, 2n), std = softplus(var) + 1e-4 (distributions.py:55-59);
+// KL(N(m1,s1) || N(m2,s2)) per element with the balancing weights (hulc.py:539-561), reparametrised sample plan = m1 + s1 * eps
+// (hulc.py:289) with an injected or Box-Muller draw.  One thread per (b, j).
+DEVI float softplus_k(float x) { return x > 20.f ? x : (x < -20.f ? __expf(x) : log1pf(__expf(x))); }
+template <typename T>
+__global__ void normal_kl_sample_kernel(const float* __restrict__ pr_state, const float* __restrict__ pp_state, int B, int n,
+                                        const float* __restrict__ eps_in, float* __restrict__ eps_out, float* __restrict__ plan_f,
+                                        T* __restrict__ plan_t, float* __restrict__ kl_elem, float* __restrict__ dpp, float* __restrict__ dpr,
+                                        float w_pp, float w_pr, unsigned long long seed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
+    const int b = idx / n, j = idx % n;
+    const long long o = (long long)b * 2 * n + j;
+    const float m1 = pr_state[o], v1 = pr_state[o + n], s1 = softplus_k(v1) + 1e-4f;
+    float e;
+    if (eps_in) e = eps_in[idx];
+    else {
+        const float u1 = fmaxf(hash_uniform(seed, 2ull * idx), 1e-12f), u2 = hash_uniform(seed, 2ull * idx + 1);
+        e = sqrtf(-2.f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+    }
+    eps_out[idx] = e;
+    const float pl = m1 + s1 * e;
+    plan_f[idx] = pl;
+    plan_t[idx] = from_f<T>(pl);
+    if (pp_state) {
+        const float m2 = pp_state[o], v2 = pp_state[o + n], s2 = softplus_k(v2) + 1e-4f;
+        const float dm = m1 - m2, i2 = 1.f / (s2 * s2);
+        kl_elem[idx] = __logf(s2 / s1) + (s1 * s1 + dm * dm) * 0.5f * i2 - 0.5f;
+        const float sg1 = 1.f / (1.f + __expf(-v1)), sg2 = 1.f / (1.f + __expf(-v2));
+        dpp[o] = w_pp * (-dm * i2);
+        dpp[o + n] = w_pp * (1.f / s2 - (s1 * s1 + dm * dm) * i2 / s2) * sg2;
+        dpr[o] = w_pr * (dm * i2);
+        dpr[o + n] = w_pr * (-1.f / s1 + s1 * i2) * sg1;
+    }
+}
+// d pr_state = [dplan | dplan * eps * sigmoid(var)] + dpr_kl
+template <typename T>
+__global__ void normal_rsample_bwd_kernel(const float* __restrict__ dplan, const float* __restrict__ eps, const float* __restrict__ pr_state,
+                                          const float* __restrict__ dpr_kl, int B, int n, T* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
+    const int b = idx / n, j = idx % n;
+    const long long o = (long long)b * 2 * n + j;
+    const float g = dplan[idx], v1 = pr_state[o + n];
+    out[o] = from_f<T>(g + dpr_kl[o]);
+    out[o + n] = from_f<T>(g * eps[idx] / (1.f + __expf(-v1)) + dpr_kl[o + n]);
+}
 // dpr_logits[b][cat][:] = probs * (dplan - sum(probs*dplan)) + dpr_kl
 __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dplan,
                                                             const float* __restrict__ dpr_kl, int NCLS, float* __restrict__ out) {
@@ -815,17 +862,19 @@ __global__ void plan_scatter_grad_kernel(const T* __restrict__ dC, const int* __
     float* row = dw + (long long)i * KIN + c * NCLS;
     for (int b = 0; b < B; ++b) row[idx[b * NCAT + c]] += to_f<T>(dC[(long long)b * H + i]);
 }
-// out[r][c] = relu(x[r][c])
+// out[r][c] = relu(x[r][c])   (act 2: tanh)
 template <typename T>
-__global__ void relu_copy_kernel(const T* __restrict__ x, T* __restrict__ out, long long n) {
+__global__ void relu_copy_kernel(const T* __restrict__ x, T* __restrict__ out, long long n, int act = 1) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = from_f<T>(fmaxf(to_f<T>(x[i]), 0.f));
+    if (i < n) { const float v = to_f<T>(x[i]); out[i] = from_f<T>(act == 2 ? tanhf(v) : fmaxf(v, 0.f)); }
 }
-// out = g * (h > 0)
+// out = g * (h > 0)   (act 2: g * (1 - h^2))
 template <typename T>
-__global__ void mask_mul_kernel(const T* __restrict__ g, const T* __restrict__ h, T* __restrict__ out, long long n) {
+__global__ void mask_mul_kernel(const T* __restrict__ g, const T* __restrict__ h, T* __restrict__ out, long long n, int act = 1) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = to_f<T>(h[i]) > 0.f ? g[i] : from_f<T>(0.f);
+    if (i >= n) return;
+    if (act == 2) { const float hv = to_f<T>(h[i]); out[i] = from_f<T>(to_f<T>(g[i]) * (1.f - hv * hv)); }
+    else out[i] = to_f<T>(h[i]) > 0.f ? g[i] : from_f<T>(0.f);
 }
 // out[b][c] = sum_t x[t][b][c]   (time-major), fp32 accumulate
 template <typename T>
@@ -871,7 +920,8 @@ DEVI float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 __global__ void logistic_sample_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ robot_obs /*[B][S][15]*/,
                                        const float* __restrict__ actions_gt /*[B][S][7] or null*/, const float* __restrict__ u_mix,
                                        const float* __restrict__ u_act, int B, int S, int NMIX, int NDIM, float log_scale_min, int gripper_control,
-                                       unsigned long long seed, float* __restrict__ pred_out /*[B][S][7]*/, float* __restrict__ metrics) {
+                                       unsigned long long seed, float* __restrict__ pred_out /*[B][S][7]*/, float* __restrict__ metrics,
+                                       int discrete_gripper = 1) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= B * S) return;
     const int t = r / B, b = r % B;
@@ -895,7 +945,7 @@ __global__ void logistic_sample_kernel(const float* __restrict__ heads, int ldh,
         const float u = (r1 - r2) * uu + r2;
         a[d] = mu + __expf(ls) * (__logf(u) - __logf(1.f - u));
     }
-    a[6] = (hr[3 * NO + 1] > hr[3 * NO]) ? 1.f : -1.f;               // gripper_bounds[argmax]
+    if (discrete_gripper) a[6] = (hr[3 * NO + 1] > hr[3 * NO]) ? 1.f : -1.f;               // gripper_bounds[argmax]
     float w[7];
     if (gripper_control) {
         const float* ro = robot_obs + bs * 15;
@@ -938,7 +988,8 @@ template <typename T>
 __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
                                      const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
                                      float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
-                                     float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads) {
+                                     float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads,
+                                     int discrete_gripper = 1) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = gid >> 3, slot = gid & 7;                  // time-major row: r = t*B + b
     if (r >= B * S) return;
@@ -980,7 +1031,7 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
         const float logc = __logf((num_classes - 1) * 0.5f);
         float a = at[0];
 #pragma unroll
-        for (int i = 1; i < 6; ++i) a = (d == i) ? at[i] : a;
+        for (int i = 1; i < 7; ++i) a = (d == i) ? at[i] : a;
         float lp[16], dlogp_dmean[16], dlogp_dls[16];
         float mlog = -INFINITY;
         for (int k = 0; k < NMIX; ++k) mlog = fmaxf(mlog, hr[d * NMIX + k]);
@@ -1018,7 +1069,7 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
             dr[NO + d * NMIX + k] = from_f<T>(-w * dlogp_dmean[k] * grad_scale);
             dr[2 * NO + d * NMIX + k] = from_f<T>(-w * dlogp_dls[k] * grad_scale);
         }
-    } else if (slot == NDIM) {
+    } else if (slot == NDIM && discrete_gripper) {
         // gripper cross entropy: label -1 -> 0 else (long)value  (logistic_decoder_rnn.py:144-151)
         const float g0 = hr[3 * NO], g1 = hr[3 * NO + 1];
         const int lab = (at[6] == -1.f) ? 0 : (int)at[6];
@@ -1028,9 +1079,9 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
         const float p0 = __expf(g0 - lz), p1 = __expf(g1 - lz);
         dr[3 * NO] = from_f<T>(gripper_alpha * (p0 - (lab == 0 ? 1.f : 0.f)) * grad_scale);
         dr[3 * NO + 1] = from_f<T>(gripper_alpha * (p1 - (lab == 1 ? 1.f : 0.f)) * grad_scale);
-    } else {
-        for (int c = 3 * NO + 2; c < ldh; ++c) dr[c] = from_f<T>(0.f);
     }
+    if (slot == 7)
+        for (int c = 3 * NO + (discrete_gripper ? 2 : 0); c < ldh; ++c) dr[c] = from_f<T>(0.f);
     row_loss[gid] = loss;
 }
 
@@ -1172,14 +1223,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-// embg[(t*B+b)*64 + c] = emb[(b*S+t)*128 + 64 + c]   (time-major copy of the gripper half, perceptual_emb_slice [64,128])
+// embg[(t*B+b)*W + c] = emb[(b*S+t)*128 + (128-W) + c]   (time-major copy of the last W columns: W = 64 is the gripper half,
+// perceptual_emb_slice [64,128]; W = 128 the whole embedding, mcil)
 template <typename T>
-__global__ void gather_embg_kernel(const T* __restrict__ emb, T* __restrict__ out, int B, int S) {
+__global__ void gather_embg_kernel(const T* __restrict__ emb, T* __restrict__ out, int B, int S, int W = 64) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * B * 64) return;
-    const int c = idx & 63, r = idx >> 6;
+    if (idx >= S * B * W) return;
+    const int c = idx % W, r = idx / W;
     const int t = r / B, b = r % B;
-    out[idx] = emb[((long long)b * S + t) * 128 + 64 + c];
+    out[idx] = emb[((long long)b * S + t) * 128 + (128 - W) + c];
 }
 // losses[4..7] = [action + kl, kl, action, clip]
 __global__ void pack_losses_kernel(float* __restrict__ l) {

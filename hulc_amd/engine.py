@@ -106,6 +106,8 @@ class StepEngine:
                         actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
                         plan_idx=ptr(mb["plan_idx"]) if mb.get("plan_idx") is not None else None, aux_rows=None, n_aux=0, step=step,
                         **self._ingest_fields(mb, ptr))
+        if mb.get("plan_eps") is not None:          # mcil: injected N(0,1) draw of the reparametrised plan sample
+            b.plan_eps = ptr(mb["plan_eps"].to(torch.float32))
         if is_lang and mb.get("aux_rows") is not None and len(mb["aux_rows"]) > 0:
             rows = np.ascontiguousarray(mb["aux_rows"], np.int32)
             keep.append(rows)

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhulc_hip.so")
 
-KIND = {"hulc": 0, "gcbc": 1}
+KIND = {"hulc": 0, "gcbc": 1, "mcil": 2}
 DTYPE = {"fp32": 0, "bf16": 1}
 
 
@@ -23,7 +23,7 @@ class HulcBatch(C.Structure):
                 ("rgb_gripper", C.c_void_p), ("actions", C.c_void_p), ("robot_obs", C.c_void_p), ("lang", C.c_void_p),
                 ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64),
                 ("frames_u8", C.c_int32), ("pad_static", C.c_int32), ("pad_gripper", C.c_int32), ("shift_static", C.c_void_p),
-                ("shift_gripper", C.c_void_p)]
+                ("shift_gripper", C.c_void_p), ("plan_eps", C.c_void_p)]
 
 
 class HulcValNoise(C.Structure):

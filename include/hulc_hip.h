@@ -31,11 +31,11 @@ extern "C" {
 
 typedef struct hulc_ctx hulc_ctx;
 
-enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1 };
+enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1, HULC_KIND_MCIL = 2 };
 enum { HULC_DTYPE_F32 = 0, HULC_DTYPE_BF16 = 1 };
 
 typedef struct hulc_config {
-    int32_t kind;            /* HULC_KIND_*  (conf/model/hulc.yaml:16, gcbc.yaml:16) */
+    int32_t kind;            /* HULC_KIND_*  (conf/model/hulc.yaml:16, gcbc.yaml:16, mcil.yaml:16) */
     int32_t dtype;           /* HULC_DTYPE_* : storage/MFMA operand type; accumulation is always fp32 */
     int32_t max_batch;       /* largest per-modality batch B the workspace is sized for */
     int32_t max_seq;         /* largest window length S (<= 64) */
@@ -71,6 +71,9 @@ typedef struct hulc_batch {
     int32_t pad_static, pad_gripper;
     const int32_t* shift_static;
     const int32_t* shift_gripper;
+    /* ---- HULC_KIND_MCIL (conf/model/mcil.yaml): optional (B,256) fp32 injected N(0,1) draw of pr_dist.rsample() (hulc.py:289),
+     * device or host; NULL = drawn on device */
+    const float* plan_eps;
 } hulc_batch;
 
 /* out_losses (device or host pointer, see `losses_on_host`): [total_mod, kl_scaled, action, clip] of this modality,

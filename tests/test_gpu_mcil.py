@@ -1,0 +1,76 @@
+"""GPU (-m gpu): the mcil variant of the HIP training step (bidirectional tanh-RNN plan recognition, continuous
+latent plan with balanced Normal KL, 7-dimension logistic mixture without gripper head) through the C-ABI, against the numpy
+oracle and fixtures of the unmodified reference in its conf/model/mcil.yaml configuration (tools/gen_golden_mcil.py)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import hulc_oracle as O  # noqa: E402
+from golden_util import MCIL_CASES, check_grads, load_mcil_case, rel_l2  # noqa: E402
+from test_gpu_parity import _engine, grads_np, run_step  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(MCIL_CASES))
+def test_mcil_fp32_step_matches_oracle_and_reference(name):
+    dims, P, batch, fx = load_mcil_case(name)
+    Bmax = max(mb["actions"].shape[0] for mb in batch.values())
+    S = next(iter(batch.values()))["actions"].shape[1]
+    eng = _engine(dims, Bmax, S, "fp32", num_classes=dims.mix_classes)
+    eng.load_numpy(P)
+    losses_o, G, caches = O.training_step(P, dims, batch, keep_cache=True)
+    tot, per = run_step(eng, batch)
+    ref = float(fx["loss_total"])
+    assert abs(tot - ref) <= 1e-3 * abs(ref), (tot, ref)                 # north_star tolerance vs the REFERENCE
+    assert abs(tot - float(losses_o["total"])) <= 2e-5 * abs(ref)
+    for sc in batch:
+        assert abs(per[sc]["kl"] - float(losses_o[f"kl_{sc}"])) <= 1e-5 * max(1.0, abs(float(losses_o[f"kl_{sc}"])))
+    sc = list(batch)[-1]
+    B = batch[sc]["actions"].shape[0]
+    assert rel_l2(eng.get_tensor("emb", B * S * 128).reshape(B, S, 128), fx[f"emb_{sc}"]) < 1e-4
+    assert np.abs(eng.get_tensor("plan", B * 256).reshape(B, 256) - fx[f"plan_{sc}"]).max() < 1e-4
+    assert np.abs(eng.get_tensor("birnn_x", B * 4096).reshape(B, 4096) - fx[f"seq_feat_{sc}"]).max() < 1e-4
+    Gg = grads_np(eng)
+    rels = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    worst = max(rels, key=rels.get)
+    assert rels[worst] < 1e-2, (worst, rels[worst])
+    assert np.median(list(rels.values())) < 2e-4
+    bad = check_grads(Gg, fx, tol_l2=1e-2, tol_norm=5e-3, label=name)
+    assert not bad, bad[:6]
+    # weight_hh_l1_reverse never runs a recurrence step that reaches the output (x = output[:, -1]): exactly zero gradient
+    assert not np.any(Gg["plan_recognition.birnn_model.weight_hh_l1_reverse"])
+    eng.close()
+
+
+def test_mcil_bf16_step_close_to_oracle():
+    dims, P, batch, fx = load_mcil_case("mcil_s12")
+    eng = _engine(dims, 3, 12, "bf16", num_classes=dims.mix_classes)
+    eng.load_numpy(P)
+    losses_o, G = O.training_step(P, dims, batch)
+    tot, _ = run_step(eng, batch)
+    assert abs(tot - float(losses_o["total"])) <= 5e-3 * abs(float(losses_o["total"])), (tot, losses_o["total"])
+    Gg = grads_np(eng)
+    a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
+    b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert cos > 0.99, cos
+    assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.05
+    eng.close()
+
+
+def test_mcil_device_sampling_and_adam_run():
+    """Train-mode path without an injected draw: the Box-Muller sample is finite and the step updates the parameters."""
+    dims, P, batch, fx = load_mcil_case("mcil_s6")
+    for mb in batch.values():
+        mb.pop("plan_eps")
+    eng = _engine(dims, 2, 6, "bf16", num_classes=dims.mix_classes)
+    eng.load_numpy(P)
+    tot, _ = run_step(eng, batch)
+    assert np.isfinite(tot)
+    plan = eng.get_tensor("plan", 2 * 256)
+    assert np.all(np.isfinite(plan)) and plan.std() > 0
+    before = eng.flat_params.clone()
+    eng.adam_step()
+    assert torch.isfinite(eng.flat_params).all() and not torch.equal(before, eng.flat_params)
+    eng.close()
