@@ -121,21 +121,38 @@ class Hulc(torch.nn.Module):
         # ---- options outside the hot path are rejected loudly instead of silently ignored (SURVEY §2.1 OUT OF SCOPE rows)
         if state_recons or use_bc_z_auxiliary_loss or use_mia_auxiliary_loss or bc_z_lang_decoder or mia_lang_discriminator:
             raise NotImplementedError("state_recons / bc_z / mia auxiliary losses are disabled in every BASELINE config and not built")
-        if _get(distribution, "dist", "discrete") != "discrete":
-            raise NotImplementedError("continuous plan distribution (mcil) is a later scope row (SURVEY §8 a19)")
         pr = plan_recognition
-        if pr is not None and "Transformers" not in str(_get(pr, "_target_", "Transformers")):
-            raise NotImplementedError("only the transformer plan recognition network is built (birnn = mcil, later row)")
         ad = action_decoder
-        chk = [(_get(ad, "n_mixtures", 10), 10), (_get(ad, "hidden_size", 2048), 2048), (_get(ad, "num_layers", 2), 2),
-               (_get(ad, "rnn_model", "rnn_decoder"), "rnn_decoder"), (_get(ad, "gripper_control", True), True),
-               (_get(ad, "discrete_gripper", True), True), (_get(ad, "policy_rnn_dropout_p", 0.0), 0.0),
-               (_get(pr, "num_heads", 8), 8), (_get(pr, "num_layers", 2), 2), (_get(pr, "encoder_hidden_size", 2048), 2048),
-               (_get(pr, "fc_hidden_size", 4096), 4096), (_get(distribution, "category_size", 32), 32),
-               (_get(distribution, "class_size", 32), 32), (_get(visual_goal, "latent_goal_features", 32), 32)]
+        self.kind = self.KIND
+        # conf/model/mcil.yaml: the same Hulc class with a BiRNN plan recognition net, a continuous plan distribution
+        # and the mcil decoder options; the three go together (any other mix has no built engine path)
+        mcil_flags = [_get(distribution, "dist", "discrete") == "continuous", "BiRNN" in str(_get(pr, "_target_", "Transformers")),
+                      not _get(ad, "gripper_control", True), not _get(ad, "discrete_gripper", True)]
+        if any(mcil_flags):
+            if not all(mcil_flags) or self.KIND != "hulc" or _get(ad, "perceptual_emb_slice", None) is not None:
+                raise NotImplementedError("continuous distribution, BiRNN plan recognition and the mcil decoder options (gripper_control / "
+                                          "discrete_gripper false, no perceptual_emb_slice) are only built together (conf/model/mcil.yaml)")
+            if use_clip_auxiliary_loss:
+                raise NotImplementedError("conf/model/mcil.yaml trains without the CLIP auxiliary loss (proj_vis_lang: none)")
+            chk = [(str(_get(pr, "rnn_type", "nn.RNN")), "nn.RNN"), (_get(pr, "plan_features", 256), 256), (_get(pr, "birnn_dropout_p", 0.0), 0.0),
+                   (_get(distribution, "plan_features", 256), 256)]
+            of = _get(ad, "out_features", 7)
+            if not isinstance(of, str) and int(of) != 7:
+                raise NotImplementedError(f"action_decoder.out_features {of!r}: the built mixture has 7 dimensions")
+            self.kind = "mcil"
+        else:
+            if pr is not None and "Transformers" not in str(_get(pr, "_target_", "Transformers")):
+                raise NotImplementedError("plan recognition: the transformer (hulc / gcbc) and the BiRNN of conf/model/mcil.yaml are built")
+            chk = [(_get(ad, "gripper_control", True), True), (_get(ad, "discrete_gripper", True), True),
+                   (_get(pr, "num_heads", 8), 8), (_get(pr, "num_layers", 2), 2), (_get(pr, "encoder_hidden_size", 2048), 2048),
+                   (_get(pr, "fc_hidden_size", 4096), 4096), (_get(distribution, "category_size", 32), 32),
+                   (_get(distribution, "class_size", 32), 32)]
+        chk += [(_get(ad, "n_mixtures", 10), 10), (_get(ad, "hidden_size", 2048), 2048), (_get(ad, "num_layers", 2), 2),
+                (_get(ad, "rnn_model", "rnn_decoder"), "rnn_decoder"), (_get(ad, "policy_rnn_dropout_p", 0.0), 0.0),
+                (_get(visual_goal, "latent_goal_features", 32), 32)]
         for got, want in chk:
             if got != want:
-                raise NotImplementedError(f"configuration value {got!r} differs from the built HULC architecture ({want!r})")
+                raise NotImplementedError(f"configuration value {got!r} differs from the built architecture ({want!r})")
         self.use_clip_auxiliary_loss = bool(use_clip_auxiliary_loss)
         self.clip_auxiliary_loss_beta = float(clip_auxiliary_loss_beta)
         self.kl_beta = float(kl_beta)
@@ -146,12 +163,12 @@ class Hulc(torch.nn.Module):
         self.lr_scheduler = lr_scheduler
         mw = _get(pr, "max_position_embeddings", 32) or 32
         max_window = 32 if isinstance(mw, str) else int(mw)      # a dangling ${...} (vision_only datasets) falls back to 32
-        self.dims = spec.ModelDims(kind=self.KIND, max_window=max_window, use_clip=self.use_clip_auxiliary_loss)
+        self.dims = spec.ModelDims(kind=self.kind, max_window=max_window, use_clip=self.use_clip_auxiliary_loss)
         self.precision = {"16": "bf16", "bf16": "bf16", "32": "fp32", "fp32": "fp32"}[str(precision)]
-        self.dropout_p = float(_get(pr, "dropout_p", 0.1))
+        self.dropout_p = 0.0 if self.kind == "mcil" else float(_get(pr, "dropout_p", 0.1))
         self._engine_kw = dict(max_batch=int(max_batch_size), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,
                                kl_beta=self.kl_beta, kl_balancing_mix=self.kl_balancing_mix,
-                               num_classes=int(_get(ad, "num_classes", 10)), gripper_alpha=float(_get(ad, "gripper_alpha", 1.0)),
+                               num_classes=int(_get(ad, "num_classes", 256 if self.kind == "mcil" else 10)), gripper_alpha=float(_get(ad, "gripper_alpha", 1.0)),
                                log_scale_min=float(_get(ad, "log_scale_min", -7.0)), seed=int(seed))
         self.engine = StepEngine(self.dims, dropout_p=self.dropout_p, **self._engine_kw)
         self._train_mode = True
@@ -185,10 +202,13 @@ class Hulc(torch.nn.Module):
         lin = torch.linspace(-1.0, 1.0, 21)
         ad = "action_decoder."
         ss = "perceptual_encoder.rgb_static_encoder.spatial_softmax."
-        return {ss + "x_map": lin.repeat_interleave(21), ss + "y_map": lin.repeat(21), ss + "temperature": torch.ones(1),
-                ad + "one_hot_embedding_eye": torch.eye(10), ad + "ones": torch.ones(1, 1, 10),
-                ad + "gripper_bounds": torch.tensor([-1.0, 1.0]), ad + "action_max_bound": torch.ones(1, 1, 6, 10),
-                ad + "action_min_bound": -torch.ones(1, 1, 6, 10)}
+        nd = self.dims.mix_dims                       # logistic_decoder_rnn.py:61: out_features - 1 with the discrete gripper head
+        buf = {ss + "x_map": lin.repeat_interleave(21), ss + "y_map": lin.repeat(21), ss + "temperature": torch.ones(1),
+               ad + "one_hot_embedding_eye": torch.eye(10), ad + "ones": torch.ones(1, 1, 10),
+               ad + "action_max_bound": torch.ones(1, 1, nd, 10), ad + "action_min_bound": -torch.ones(1, 1, nd, 10)}
+        if self.kind != "mcil":
+            buf[ad + "gripper_bounds"] = torch.tensor([-1.0, 1.0])     # :169-170, discrete_gripper only
+        return buf
 
     def state_dict(self, *args, **kwargs):  # type: ignore[override]
         sd = {n: p.detach().clone() for n, p in self._params.items()}
@@ -259,6 +279,8 @@ class Hulc(torch.nn.Module):
             mb["aux_rows"] = torch.nonzero(m.reshape(-1)).reshape(-1).to("cpu", torch.int32).numpy()
         if "plan_idx" in dataset_batch and dataset_batch["plan_idx"] is not None:
             mb["plan_idx"] = dataset_batch["plan_idx"].to(device=device, dtype=torch.int32)
+        if dataset_batch.get("plan_eps") is not None:         # mcil: injected N(0,1) draw (parity tests)
+            mb["plan_eps"] = dataset_batch["plan_eps"].to(device=device, dtype=torch.float32)
         return mb
 
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
@@ -283,10 +305,10 @@ class Hulc(torch.nn.Module):
             b = mb["actions"].shape[0]
             bs[self.modality_scope] = b
             total_bs += b
-            if self.KIND == "hulc":
+            if self.kind != "gcbc":
                 self.log(f"train/kl_loss_scaled_{self.modality_scope}", l["kl"], on_step=False, on_epoch=True, batch_size=b)
             self.log(f"train/action_loss_{self.modality_scope}", l["action"], on_step=False, on_epoch=True, batch_size=b)
-            if self.KIND == "hulc":
+            if self.kind != "gcbc":
                 self.log(f"train/total_loss_{self.modality_scope}", l["total_mod"], on_step=False, on_epoch=True, batch_size=b)
             kl += l["kl"]; act += l["action"]; tot += l["total_mod"]
             if is_lang and self.use_clip_auxiliary_loss:
@@ -295,7 +317,7 @@ class Hulc(torch.nn.Module):
         if self.use_clip_auxiliary_loss:
             total = total + self.clip_auxiliary_loss_beta * clip
             self.log("train/lang_clip_loss", parallel.mean_scalar(self.clip_auxiliary_loss_beta * clip), on_step=False, on_epoch=True, sync_dist=True)
-        if self.KIND == "hulc":
+        if self.kind != "gcbc":
             self.log("train/kl_loss", kl / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
         self.log("train/action_loss", act / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
         self.log("train/total_loss", total, on_step=False, on_epoch=True, batch_size=total_bs)
@@ -305,7 +327,9 @@ class Hulc(torch.nn.Module):
     def validation_step(self, batch: Dict[str, Dict], batch_idx: int, noise: Optional[Dict[str, Dict]] = None) -> Dict[str, torch.Tensor]:
         """hulc.py:739-841: per modality lmp_val (:301-388) + the logged reductions; eval-mode forward, no gradients.
         `noise` (optional, tests): {scope: {plan_idx_pp, plan_idx_pr, u_mix_pp, u_act_pp, u_mix_pr, u_act_pr}} injected draws."""
-        if self.KIND != "hulc":
+        if self.kind == "mcil":
+            raise NotImplementedError("validation / rollout of the mcil variant: only its training step is built (SURVEY §8 a19)")
+        if self.kind != "hulc":
             return self._validation_step_gcbc(batch, batch_idx, noise)
         eng = self.engine
         output: Dict[str, torch.Tensor] = {}
