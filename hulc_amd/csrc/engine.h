@@ -580,6 +580,14 @@ struct Engine : IEngine {
         s.pad = gripper ? b.pad_gripper : b.pad_static;
         return s;
     }
+    // actions of the current batch: the reference's relative actions, or absolute targets + RelativeActions applied here
+    float* act_rel = nullptr;
+    const float* actions_of(const hulc_batch& b) {
+        if (!b.actions_absolute) return b.actions;
+        if (!act_rel) act_rel = alloc<float>((int64_t)maxN * 7);
+        hipLaunchKernelGGL(relative_actions_kernel, dim3(cdiv(b.B * b.S, 256)), dim3(256), 0, st, b.actions, b.robot_obs, b.B * b.S, b.max_rel_pos, b.max_rel_orn, act_rel);
+        return act_rel;
+    }
     float* x32[2] = {nullptr, nullptr};       // fp32 (parity) mode + uint8 ingest: the transformed frames are materialised once per step
     const float* conv1_f32(const Conv1Src& src, bool gripper, int Nf, int IH) {
         if (!src.u8) return reinterpret_cast<const float*>(src.X);
@@ -858,6 +866,7 @@ struct Engine : IEngine {
             return 1;
         }
         if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
+        if (b->actions_absolute && !(b->max_rel_pos > 0.f && b->max_rel_orn > 0.f)) { hulc_set_error("actions_absolute needs max_rel_pos > 0 and max_rel_orn > 0 (RelativeActions, transforms.py:35-37)"); return 1; }
         cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false;
         const int B = b->B, S = b->S, N = B * S, SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
@@ -887,7 +896,7 @@ struct Engine : IEngine {
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
-            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)SB, rowloss, a_tcp, dheads, mcil ? 0 : 1);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
@@ -940,6 +949,7 @@ struct Engine : IEngine {
             return 1;
         }
         if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
+        if (b->actions_absolute && !(b->max_rel_pos > 0.f && b->max_rel_orn > 0.f)) { hulc_set_error("actions_absolute needs max_rel_pos > 0 and max_rel_orn > 0 (RelativeActions, transforms.py:35-37)"); return 1; }
         val_alloc();
         if (alloc_failed) { hulc_set_error("hulc_validate: workspace allocation failed"); return 1; }
         static const hulc_val_noise none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -961,16 +971,17 @@ struct Engine : IEngine {
         hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, B, NCAT, NCLS, in_pp, pidx_pp, probs, klcat,
                            dpp_kl, dpr_kl, 0.f, 0.f, site_seed(41));
         }
+        const float* acts = actions_of(*b);
         for (int pass = 0; pass < (hulc ? 2 : 1); ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
             dec_fwd(pass == 0 ? pidx_pp : pidx, B, S, nullptr, nullptr);
-            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, b->actions, b->robot_obs, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, acts, b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, 0.f, rowloss, a_tcp, dheads);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, valm + pass);
             const float* um = pass == 0 ? nz->u_mix_pp : nz->u_mix_pr;
             const float* ua = pass == 0 ? nz->u_act_pp : nz->u_act_pr;
             if (um) { HIP_CHECK(hipMemcpyAsync(nz_mix, um, sizeof(float) * SB * NDIM * NMIX, hipMemcpyDefault, st)); um = nz_mix; }
             if (ua) { HIP_CHECK(hipMemcpyAsync(nz_act, ua, sizeof(float) * SB * NDIM, hipMemcpyDefault, st)); ua = nz_act; }
-            hipLaunchKernelGGL(logistic_sample_kernel, dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->robot_obs, b->actions, um, ua, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL(logistic_sample_kernel, dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->robot_obs, acts, um, ua, B, S, NMIX, NDIM,
                                cfg.log_scale_min, 1, site_seed(42 + pass), pass == 0 ? pred_pp : pred_pr, valm + 8 + 8 * pass);
         }
         STAGE("validate");

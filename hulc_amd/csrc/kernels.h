@@ -981,6 +981,27 @@ __global__ void logistic_sample_kernel(const float* __restrict__ heads, int ldh,
     }
 }
 
+// RelativeActions (hulc/utils/transforms.py:32-56): absolute tcp targets -> the relative, clipped and scaled actions the policy is
+// trained on.  One thread per (window, step) row; robot_obs is the raw 15-d state (position 0:3, euler orientation 3:6).
+__global__ void relative_actions_kernel(const float* __restrict__ actions_abs, const float* __restrict__ robot_obs, int rows, float max_pos,
+                                        float max_orn, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* a = actions_abs + (long long)r * 7;
+    const float* ro = robot_obs + (long long)r * 15;
+    float* o = out + (long long)r * 7;
+    const float PI = 3.14159265358979323846f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = fminf(fmaxf(a[i] - ro[i], -max_pos), max_pos) / max_pos;
+#pragma unroll
+    for (int i = 3; i < 6; ++i) {
+        float x = (a[i] - ro[i]) + PI;                       // batch_angle_between: (diff + pi) mod 2pi - pi, Python's non-negative modulo
+        x -= 2.f * PI * floorf(x / (2.f * PI));
+        o[i] = fminf(fmaxf(x - PI, -max_orn), max_orn) / max_orn;
+    }
+    o[6] = a[6];
+}
+
 // one thread per (row, slot): slots 0..NDIM-1 = mixture dimension d, slot NDIM = gripper cross entropy, last slot idle;
 // row_loss is [rows][8] (summed deterministically afterwards).  Each thread recomputes the row's tcp-frame action (cheap) so the
 // 7 partial losses of a row run in parallel instead of serially in one lane.

@@ -80,11 +80,14 @@ class StepEngine:
     def _ingest_fields(mb: Dict, ptr) -> Dict:
         """uint8 (B,S,H,W,C) frames select the fused ingest path (include/hulc_hip.h: frames_u8); optional per-frame RandomShiftsAug
         shifts `shift_static` / `shift_gripper` (B*S,2) int32 in [0, 2*pad] with pads `pad_static` (10) / `pad_gripper` (4)."""
+        rel = {}
+        if mb.get("actions_absolute"):        # RelativeActions (transforms.py:32-56) applied on the device
+            rel = dict(actions_absolute=1, max_rel_pos=float(mb.get("max_rel_pos", 0.02)), max_rel_orn=float(mb.get("max_rel_orn", 0.05)))
         if mb["rgb_static"].dtype != torch.uint8:
-            return {}
+            return rel
         if mb["rgb_gripper"].dtype != torch.uint8 or mb["rgb_static"].shape[-1] != 3 or mb["rgb_gripper"].shape[-1] != 3:
             raise ValueError("uint8 ingest expects both cameras as uint8 (B,S,H,W,3) tensors")
-        f = dict(frames_u8=1, pad_static=int(mb.get("pad_static", 10)), pad_gripper=int(mb.get("pad_gripper", 4)))
+        f = dict(rel, frames_u8=1, pad_static=int(mb.get("pad_static", 10)), pad_gripper=int(mb.get("pad_gripper", 4)))
         for k in ("shift_static", "shift_gripper"):
             if mb.get(k) is not None:
                 f[k] = ptr(mb[k].to(torch.int32))

@@ -74,6 +74,12 @@ typedef struct hulc_batch {
     /* ---- HULC_KIND_MCIL (conf/model/mcil.yaml): optional (B,256) fp32 injected N(0,1) draw of pr_dist.rsample() (hulc.py:289),
      * device or host; NULL = drawn on device */
     const float* plan_eps;
+    /* ---- absolute-action ingest (SURVEY.md §2 "next (f)" data-side row): actions_absolute != 0 -> `actions` holds ABSOLUTE tcp targets
+     * (x,y,z, euler x,y,z, gripper) and the dataloader transform RelativeActions (hulc/utils/transforms.py:32-56) is applied on the
+     * device against robot_obs[..., 0:6]: clip(pos - obs, +-max_rel_pos) / max_rel_pos, wrapped angle difference clipped to
+     * +-max_rel_orn and scaled, gripper unchanged.  0 = the reference's boundary (relative actions already in `actions`). */
+    int32_t actions_absolute;
+    float max_rel_pos, max_rel_orn;
 } hulc_batch;
 
 /* out_losses (device or host pointer, see `losses_on_host`): [total_mod, kl_scaled, action, clip] of this modality,

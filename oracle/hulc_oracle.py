@@ -641,6 +641,18 @@ def random_shifts_aug(x, shift, pad):
     return out
 
 
+def relative_actions(actions_abs, robot_obs, max_pos, max_orn):
+    """hulc/utils/transforms.py:32-56 (RelativeActions.__call__), batched over leading dims: absolute tcp targets (..., 7) and the raw
+    robot state (..., >= 6) -> clipped / scaled relative position and wrapped orientation differences, gripper action unchanged."""
+    a = np.asarray(actions_abs)
+    ro = np.asarray(robot_obs)
+    rel_pos = np.clip(a[..., :3] - ro[..., :3], -max_pos, max_pos) / max_pos
+    diff = a[..., 3:6] - ro[..., 3:6]
+    rel_orn = (diff + np.pi) % (2 * np.pi) - np.pi                              # batch_angle_between(robot_obs, actions) :41-44
+    rel_orn = np.clip(rel_orn, -max_orn, max_orn) / max_orn
+    return np.concatenate([rel_pos, rel_orn, a[..., 6:7]], -1)
+
+
 def ingest_u8(frames, shift=None, pad=0):
     """conf/datamodule/transforms/rand_shift.yaml (train: rgb_static / rgb_gripper): uint8 (B,S,H,W,C) ->
     RandomShiftsAug(pad) [skipped when shift is None: the `val` transforms] -> ScaleImageTensor (x/255) -> Normalize(0.5, 0.5);

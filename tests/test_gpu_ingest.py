@@ -69,3 +69,34 @@ def test_u8_ingest_validation_without_augmentation():
     eng.close()
     assert abs(a["action_loss_pp"] - b["action_loss_pp"]) <= 2e-4 * abs(a["action_loss_pp"])
     assert torch.equal(a["sampled_plan_idx_pp"], b["sampled_plan_idx_pp"])
+
+
+def test_absolute_action_ingest_equals_relative_boundary():
+    """hulc_batch.actions_absolute: RelativeActions (transforms.py:32-56) applied on the device == the step fed with the reference's
+    transformed actions (the committed reference fixture), training step and validation."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ingest_shift.npz"))
+    dims, P, batch, _ = load_case("hulc_tiny")
+    mb0 = batch["vis"]
+    B, S = mb0["actions"].shape[:2]
+    n = B * S
+    t = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+    ro, act_abs, act_rel = (fx[k][:n].reshape(B, S, -1) for k in ("rel_robot_obs", "rel_actions_abs", "rel_out"))
+    mp, mo = (float(v) for v in fx["rel_max"])
+    common = dict(rgb_static=t(mb0["rgb_static"]), rgb_gripper=t(mb0["rgb_gripper"]), robot_obs=t(ro), plan_idx=t(mb0["plan_idx"], np.int32))
+    eng = StepEngine(dims, B, S, dtype="fp32", device="cuda:0", dropout_p=0.0, seed=1)
+    eng.load_numpy(P)
+    res = []
+    for mb in (dict(common, actions=t(act_rel)), dict(common, actions=t(act_abs), actions_absolute=True, max_rel_pos=mp, max_rel_orn=mo)):
+        eng.zero_grads()
+        l = eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+        eng.backward()
+        torch.cuda.synchronize()
+        v = eng.validate(dict(mb, step=3), False, None)
+        res.append((l, eng.flat_grads.clone(), v))
+    (l0, g0, v0), (l1, g1, v1) = res
+    assert abs(l0["action"] - l1["action"]) <= 2e-6 * abs(l0["action"]), (l0, l1)
+    assert ((g0 - g1).double().norm() / g0.double().norm()).item() <= 2e-5
+    assert abs(v0["action_loss_pp"] - v1["action_loss_pp"]) <= 1e-5 * abs(v0["action_loss_pp"]) and np.allclose(v0["mae_pp"], v1["mae_pp"], atol=1e-5)
+    with pytest.raises(RuntimeError):
+        eng.forward_loss(dict(common, actions=t(act_abs), actions_absolute=True, max_rel_pos=0.0), False, 1.0, 3.0)
+    eng.close()

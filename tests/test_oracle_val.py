@@ -68,3 +68,17 @@ def test_random_shifts_aug_matches_reference_fixture():
     assert a.shape == (2, 3, 3, 20, 20) and a.min() >= -1 and a.max() <= 1
     assert np.array_equal(a[0, 0, :, 5, 7], (fr[0, 0, 5, 7].astype(np.float32) / 255 - 0.5) / 0.5)
     assert np.array_equal(O.ingest_u8(fr, np.full((6, 2), 4), 4), a)
+
+
+def test_relative_actions_matches_reference_fixture():
+    """oracle.relative_actions vs the reference's RelativeActions (hulc/utils/transforms.py:32-56) on absolute targets that include
+    clipped entries and orientation differences wrapping through +-pi (tools/gen_golden_ingest.py)."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ingest_shift.npz"))
+    mp, mo = (float(v) for v in fx["rel_max"])
+    got = O.relative_actions(fx["rel_actions_abs"], fx["rel_robot_obs"], mp, mo)
+    assert np.abs(got - fx["rel_out"]).max() <= 1e-6
+    assert np.abs(fx["rel_out"][:, :6]).max() <= 1.0 + 1e-6 and (np.abs(fx["rel_out"][:, :6]) == 1.0).any()     # the clip is exercised
+    assert np.abs(fx["rel_out"][:8, 3:6]).max() <= 1.0 + 1e-6       # rows 0..7 hold the +-2pi aliases: still small after wrapping
+    # batched leading dims (B, S, ...) are handled like the per-episode (n, ...) arrays of the dataloader
+    a = fx["rel_actions_abs"].reshape(4, 16, 7); ro = fx["rel_robot_obs"].reshape(4, 16, 15)
+    assert np.array_equal(O.relative_actions(a, ro, mp, mo).reshape(64, 7), got)
