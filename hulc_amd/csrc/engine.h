@@ -939,11 +939,21 @@ struct Engine : IEngine {
         nz_mix = alloc<float>((int64_t)maxB * maxS * NDIM * NMIX); nz_act = alloc<float>((int64_t)maxB * maxS * NDIM);
         pidx_pp = alloc<int>((int64_t)maxB * NCAT);
     }
+    // mcil: plan ~ N(mean, std) of `state` (B, PLAN) into plan_f / plan_t, or the injected (B, PLAN/2) draw; with kl_with the per-element
+    // KL(state || kl_with) lands in klel (no gradient weights)
+    void sample_cont(const float* state, const float* kl_with, const float* inject, int B, uint64_t seed) {
+        const int n = PLAN / 2;
+        hipLaunchKernelGGL((normal_kl_sample_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, state, kl_with, B, n, (const float*)nullptr, plan_eps, plan_f, plan_t, klel,
+                           dpp_kl, dpr_kl, 0.f, 0.f, seed);
+        if (inject) {
+            hipMemcpyAsync(plan_f, inject, sizeof(float) * B * n, hipMemcpyDefault, st);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, plan_f, plan_t, (long long)B * n);
+        }
+    }
     int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
                  float* pred_pr_out) override {
         if (!bound) { hulc_set_error("hulc_validate before hulc_bind_params"); return 1; }
         const bool hulc = cfg.kind == HULC_KIND_HULC;     // GCBC (gcbc.py:214-246): one decoder pass without a plan, reported in the "pp" slots
-        if (mcil) { hulc_set_error("hulc_validate: not implemented for the mcil model kind (training step only)"); return 1; }
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
             return 1;
@@ -958,7 +968,7 @@ struct Engine : IEngine {
         const int B = b->B, S = b->S, SB = S * B;
         HIP_CHECK(hipMemsetAsync(valm, 0, 32 * sizeof(float), st));
         trunk_fwd(b, 0.f);
-        pr_fwd(B, S, 0.f);
+        if (mcil) birnn_fwd(B, S); else pr_fwd(B, S, 0.f);
         // KL (beta-scaled) + recognition sample, then the proposal sample (no KL terms: second logits pointer null)
         const int* in_pr = nullptr;
         if (hulc) {
@@ -972,24 +982,31 @@ struct Engine : IEngine {
                            dpp_kl, dpr_kl, 0.f, 0.f, site_seed(41));
         }
         const float* acts = actions_of(*b);
-        for (int pass = 0; pass < (hulc ? 2 : 1); ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
+        for (int pass = 0; pass < ((hulc || mcil) ? 2 : 1); ++pass) {          // 0: plan proposal, 1: plan recognition (loss_and_act, logistic_decoder_rnn.py:85-100)
+            if (mcil) {      // continuous plan: Independent(Normal).sample() (distributions.py:37-38) or the injected draw (B,256) fp32
+                sample_cont(pass == 0 ? pp_logits : pr_logits, pass == 0 ? nullptr : pp_logits, reinterpret_cast<const float*>(pass == 0 ? nz->plan_idx_pp : nz->plan_idx_pr),
+                            B, site_seed(41 - pass));
+                if (pass == 1) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, B * (PLAN / 2), cfg.kl_beta / B, valm + 2);
+                int32_t* po = pass == 0 ? plan_pp_out : plan_pr_out;
+                if (po) HIP_CHECK(hipMemcpyAsync(po, plan_f, sizeof(float) * B * (PLAN / 2), hipMemcpyDefault, st));
+            }
             dec_fwd(pass == 0 ? pidx_pp : pidx, B, S, nullptr, nullptr);
             hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, acts, b->robot_obs, B, S, NMIX, NDIM,
-                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, 1, 0.f, rowloss, a_tcp, dheads);
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, 0.f, rowloss, a_tcp, dheads, mcil ? 0 : 1);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, valm + pass);
             const float* um = pass == 0 ? nz->u_mix_pp : nz->u_mix_pr;
             const float* ua = pass == 0 ? nz->u_act_pp : nz->u_act_pr;
             if (um) { HIP_CHECK(hipMemcpyAsync(nz_mix, um, sizeof(float) * SB * NDIM * NMIX, hipMemcpyDefault, st)); um = nz_mix; }
             if (ua) { HIP_CHECK(hipMemcpyAsync(nz_act, ua, sizeof(float) * SB * NDIM, hipMemcpyDefault, st)); ua = nz_act; }
             hipLaunchKernelGGL(logistic_sample_kernel, dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->robot_obs, acts, um, ua, B, S, NMIX, NDIM,
-                               cfg.log_scale_min, 1, site_seed(42 + pass), pass == 0 ? pred_pp : pred_pr, valm + 8 + 8 * pass);
+                               cfg.log_scale_min, mcil ? 0 : 1, site_seed(42 + pass), pass == 0 ? pred_pp : pred_pr, valm + 8 + 8 * pass, mcil ? 0 : 1);
         }
         STAGE("validate");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in validate"); return 1; }
         if (plan_pp_out && hulc) HIP_CHECK(hipMemcpyAsync(plan_pp_out, pidx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
         if (plan_pr_out && hulc) HIP_CHECK(hipMemcpyAsync(plan_pr_out, pidx, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
         if (pred_pp_out) HIP_CHECK(hipMemcpyAsync(pred_pp_out, pred_pp, sizeof(float) * SB * 7, hipMemcpyDefault, st));
-        if (pred_pr_out && hulc) HIP_CHECK(hipMemcpyAsync(pred_pr_out, pred_pr, sizeof(float) * SB * 7, hipMemcpyDefault, st));
+        if (pred_pr_out && (hulc || mcil)) HIP_CHECK(hipMemcpyAsync(pred_pr_out, pred_pr, sizeof(float) * SB * 7, hipMemcpyDefault, st));
         float h[32];
         HIP_CHECK(hipMemcpyAsync(h, valm, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1001,14 +1018,14 @@ struct Engine : IEngine {
     }
 
     // ---------------------------------------------------------------- rollout (hulc.py:843-957), B = 1
-    int* roll_plan = nullptr; T *roll_goal = nullptr, *roll_h0 = nullptr, *roll_h1 = nullptr;
+    int* roll_plan = nullptr; T* roll_plan_c = nullptr; T *roll_goal = nullptr, *roll_h0 = nullptr, *roll_h1 = nullptr;
     float *roll_fs = nullptr, *roll_fg = nullptr, *roll_ro = nullptr, *roll_pred = nullptr;
     bool roll_has_h = false, roll_has_plan = false;
     uint64_t roll_counter = 0;
     void roll_alloc() {
         if (roll_plan) return;
         val_alloc();
-        roll_plan = alloc<int>(NCAT); roll_goal = alloc<T>(GOAL); roll_h0 = alloc<T>(HID); roll_h1 = alloc<T>(HID);
+        roll_plan = alloc<int>(NCAT); roll_plan_c = alloc<T>(PLAN); roll_goal = alloc<T>(GOAL); roll_h0 = alloc<T>(HID); roll_h1 = alloc<T>(HID);
         roll_fs = alloc<float>(2ll * 3 * encS.IH * encS.IH); roll_fg = alloc<float>(2ll * 3 * encG.IH * encG.IH);
         roll_ro = alloc<float>(16); roll_pred = alloc<float>(8);
     }
@@ -1016,7 +1033,7 @@ struct Engine : IEngine {
     int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang, const int32_t* plan_inject,
                      int32_t* plan_out) override {
         if (!bound) { hulc_set_error("hulc_rollout_plan before hulc_bind_params"); return 1; }
-        if (cfg.kind != HULC_KIND_HULC) { hulc_set_error("hulc_rollout_plan: HULC model kind only"); return 1; }
+        if (cfg.kind == HULC_KIND_GCBC) { hulc_set_error("hulc_rollout_plan: the GCBC model kind has no latent plan"); return 1; }
         if ((goal_lang != nullptr) == (goal_static != nullptr && goal_gripper != nullptr)) {
             hulc_set_error("hulc_rollout_plan: give either the two goal images or the language embedding");
             return 1;
@@ -1040,12 +1057,18 @@ struct Engine : IEngine {
         cur = bb;
         trunk_fwd(&bb, 0.f);
         const int* inj = nullptr;
+        if (mcil) {     // continuous plan (256) fp32: sampled from the proposal Normal or injected; kept in roll_plan_c for the following act() calls
+            sample_cont(pp_logits, nullptr, reinterpret_cast<const float*>(plan_inject), 1, site_seed(50));
+            HIP_CHECK(hipMemcpyAsync(roll_plan_c, plan_t, sizeof(T) * (PLAN / 2), hipMemcpyDeviceToDevice, st));
+            if (plan_out) HIP_CHECK(hipMemcpyAsync(plan_out, plan_f, sizeof(float) * (PLAN / 2), hipMemcpyDefault, st));
+        } else {
         if (plan_inject) { HIP_CHECK(hipMemcpyAsync(pidx_in, plan_inject, sizeof(int) * NCAT, hipMemcpyDefault, st)); inj = pidx_in; }
         hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, 1, NCAT, NCLS, inj, roll_plan, probs, klcat, dpp_kl,
                            dpr_kl, 0.f, 0.f, site_seed(50));
+        }
         HIP_CHECK(hipMemcpyAsync(roll_goal, goal_t, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
         roll_has_h = false; roll_has_plan = true;      // action_decoder.clear_hidden_state() (hulc.py:925 / :946)
-        if (plan_out) HIP_CHECK(hipMemcpyAsync(plan_out, roll_plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+        if (plan_out && !mcil) HIP_CHECK(hipMemcpyAsync(plan_out, roll_plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_plan"); return 1; }
         return 0;
@@ -1059,6 +1082,7 @@ struct Engine : IEngine {
         enc_fwd(encS, aS, Conv1Src{obs->rgb_static, nullptr, 0, 0}, 1, 0);
         enc_fwd(encG, aG, Conv1Src{obs->rgb_gripper, nullptr, 0, 0}, 1, 64);
         HIP_CHECK(hipMemcpyAsync(goal_t, roll_goal, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
+        if (mcil) HIP_CHECK(hipMemcpyAsync(plan_t, roll_plan_c, sizeof(T) * (PLAN / 2), hipMemcpyDeviceToDevice, st));
         dec_fwd(roll_plan, 1, 1, roll_has_h ? roll_h0 : nullptr, roll_has_h ? roll_h1 : nullptr);
         HIP_CHECK(hipMemcpyAsync(roll_h0, H0, sizeof(T) * HID, hipMemcpyDeviceToDevice, st));
         HIP_CHECK(hipMemcpyAsync(roll_h1, H1, sizeof(T) * HID, hipMemcpyDeviceToDevice, st));
@@ -1067,7 +1091,7 @@ struct Engine : IEngine {
         if (u_mix) { HIP_CHECK(hipMemcpyAsync(nz_mix, u_mix, sizeof(float) * NDIM * NMIX, hipMemcpyDefault, st)); u_mix = nz_mix; }
         if (u_act) { HIP_CHECK(hipMemcpyAsync(nz_act, u_act, sizeof(float) * NDIM, hipMemcpyDefault, st)); u_act = nz_act; }
         hipLaunchKernelGGL(logistic_sample_kernel, dim3(1), dim3(64), 0, st, heads, NHEAD, roll_ro, (const float*)nullptr, u_mix, u_act, 1, 1, NMIX, NDIM,
-                           cfg.log_scale_min, 1, site_seed(51), roll_pred, (float*)nullptr);
+                           cfg.log_scale_min, mcil ? 0 : 1, site_seed(51), roll_pred, (float*)nullptr, mcil ? 0 : 1);
         HIP_CHECK(hipMemcpyAsync(action_out, roll_pred, sizeof(float) * 7, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_act"); return 1; }

@@ -154,12 +154,15 @@ class StepEngine:
         b = L.HulcBatch(B=B, S=S, is_lang=int(is_lang), rgb_static=ptr(mb["rgb_static"]), rgb_gripper=ptr(mb["rgb_gripper"]),
                         actions=ptr(mb["actions"]), robot_obs=ptr(mb["robot_obs"]), lang=ptr(mb["lang"]) if is_lang else None,
                         plan_idx=None, aux_rows=None, n_aux=0, step=int(mb.get("step", 0)), **self._ingest_fields(mb, ptr))
-        noise = noise or {}
-        nz = L.HulcValNoise(**{k: self._dev_or_host_ptr(noise.get(k), keep, np.int32 if k.startswith("plan") else np.float32)
+        noise = dict(noise or {})
+        mcil = self.dims.kind == "mcil"
+        if mcil:       # continuous plans travel as (B,256) fp32 in the plan slots (include/hulc_hip.h: hulc_val_noise)
+            noise["plan_idx_pp"], noise["plan_idx_pr"] = noise.get("plan_pp"), noise.get("plan_pr")
+        nz = L.HulcValNoise(**{k: self._dev_or_host_ptr(noise.get(k), keep, np.int32 if (k.startswith("plan") and not mcil) else np.float32)
                                for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")})
         out = (C.c_float * 17)()
-        ppp = torch.zeros(B, 32, dtype=torch.int32, device=self.device)
-        ppr = torch.zeros(B, 32, dtype=torch.int32, device=self.device)
+        ppp = torch.zeros(B, 256 if mcil else 32, dtype=torch.float32 if mcil else torch.int32, device=self.device)
+        ppr = torch.zeros(B, 256 if mcil else 32, dtype=torch.float32 if mcil else torch.int32, device=self.device)
         pred_pp = torch.zeros(B, S, 7, device=self.device) if want_pred else None
         pred_pr = torch.zeros(B, S, 7, device=self.device) if want_pred else None
         L.check(self.lib.hulc_validate(self.ctx, C.byref(b), C.byref(nz), out, ppp.data_ptr(), ppr.data_ptr(),
@@ -167,6 +170,8 @@ class StepEngine:
         o = list(out)
         res = dict(action_loss_pp=o[0], action_loss_pr=o[1], kl_loss=o[2], gripper_sr_pp=o[3], gripper_sr_pr=o[4],
                    mae_pp=np.array(o[5:11], np.float32), mae_pr=np.array(o[11:17], np.float32), sampled_plan_idx_pp=ppp, sampled_plan_idx_pr=ppr)
+        if mcil:
+            res.update(sampled_plan_pp=ppp, sampled_plan_pr=ppr)
         if want_pred:
             res.update(pred_pp=pred_pp, pred_pr=pred_pr)
         return res
@@ -192,9 +197,10 @@ class StepEngine:
             gg = goal["rgb_gripper"].to(device=self.device, dtype=torch.float32).contiguous(); keep.append(gg)
         else:
             gl = torch.as_tensor(goal).to(device=self.device, dtype=torch.float32).reshape(-1).contiguous(); keep.append(gl)
-        out = torch.zeros(32, dtype=torch.int32, device=self.device)
+        mcil = self.dims.kind == "mcil"      # continuous (256,) fp32 plan instead of (32,) int32 category indices
+        out = torch.zeros(256 if mcil else 32, dtype=torch.float32 if mcil else torch.int32, device=self.device)
         L.check(self.lib.hulc_rollout_plan(self.ctx, C.byref(o), gs.data_ptr() if gs is not None else None, gg.data_ptr() if gg is not None else None,
-                                           gl.data_ptr() if gl is not None else None, self._dev_or_host_ptr(plan_idx, keep, np.int32), out.data_ptr()))
+                                           gl.data_ptr() if gl is not None else None, self._dev_or_host_ptr(plan_idx, keep, np.float32 if mcil else np.int32), out.data_ptr()))
         return out
 
     def rollout_act(self, obs: Dict, u_mix=None, u_act=None) -> np.ndarray:

@@ -327,9 +327,7 @@ class Hulc(torch.nn.Module):
     def validation_step(self, batch: Dict[str, Dict], batch_idx: int, noise: Optional[Dict[str, Dict]] = None) -> Dict[str, torch.Tensor]:
         """hulc.py:739-841: per modality lmp_val (:301-388) + the logged reductions; eval-mode forward, no gradients.
         `noise` (optional, tests): {scope: {plan_idx_pp, plan_idx_pr, u_mix_pp, u_act_pp, u_mix_pr, u_act_pr}} injected draws."""
-        if self.kind == "mcil":
-            raise NotImplementedError("validation / rollout of the mcil variant: only its training step is built (SURVEY §8 a19)")
-        if self.kind != "hulc":
+        if self.kind == "gcbc":
             return self._validation_step_gcbc(batch, batch_idx, noise)
         eng = self.engine
         output: Dict[str, torch.Tensor] = {}
@@ -355,9 +353,12 @@ class Hulc(torch.nn.Module):
             self.log(f"val_grip/{sc}_grip_sr_pr", r["gripper_sr_pr"], sync_dist=True)
             self.log(f"val_grip/{sc}_grip_sr_pp", r["gripper_sr_pp"], sync_dist=True)
             self.log("val_act/action_loss_pp", val_total_act_loss_pp / nmod, sync_dist=True)
-            one_hot = lambda idx: torch.nn.functional.one_hot(idx.long(), 32).to(torch.float32).reshape(idx.shape[0], -1)
-            output[f"sampled_plan_pp_{sc}"] = one_hot(r["sampled_plan_idx_pp"])     # (B, 1024) like distributions.py:37-41
-            output[f"sampled_plan_pr_{sc}"] = one_hot(r["sampled_plan_idx_pr"])
+            if self.kind == "mcil":       # continuous plans (B, 256) as drawn
+                output[f"sampled_plan_pp_{sc}"], output[f"sampled_plan_pr_{sc}"] = r["sampled_plan_pp"], r["sampled_plan_pr"]
+            else:
+                one_hot = lambda idx: torch.nn.functional.one_hot(idx.long(), 32).to(torch.float32).reshape(idx.shape[0], -1)
+                output[f"sampled_plan_pp_{sc}"] = one_hot(r["sampled_plan_idx_pp"])     # (B, 1024) like distributions.py:37-41
+                output[f"sampled_plan_pr_{sc}"] = one_hot(r["sampled_plan_idx_pr"])
             output[f"idx_{sc}"] = dataset_batch.get("idx")
         return output
 
@@ -416,7 +417,7 @@ class Hulc(torch.nn.Module):
                 g = torch.from_numpy(np.asarray(self.lang_embeddings[goal], np.float32)).reshape(-1)
             else:
                 g = dict(rgb_static=goal["rgb_obs"]["rgb_static"], rgb_gripper=goal["rgb_obs"]["rgb_gripper"])
-            self.plan = self.engine.rollout_plan(o, g, plan_idx=noise.get("plan_idx"))
+            self.plan = self.engine.rollout_plan(o, g, plan_idx=noise.get("plan") if self.kind == "mcil" else noise.get("plan_idx"))
             self.latent_goal = True
         action = self.engine.rollout_act(o, u_mix=noise.get("u_mix"), u_act=noise.get("u_act"))
         self.rollout_step_counter += 1

@@ -119,6 +119,9 @@ int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps,
  * the world frame (tcp_to_world_frame, gripper_control.py:39-63), its mean absolute error and the gripper success rate.
  * Eval-mode: dropout off.  Forward only — it invalidates the state hulc_backward needs.
  * Every pointer of hulc_val_noise is optional (device or host memory); NULL = draw on the device with the counter RNG. */
+/* HULC_KIND_MCIL: the plans are continuous — plan_idx_pp / plan_idx_pr (here, in hulc_validate's plan_idx_*_out and in
+ * hulc_rollout_plan's plan_inject / plan_out) then point to (B,256) fp32 sampled plans instead of (B,32) int32 category indices,
+ * u_mix_* is (B,S,7,10) and u_act_* (B,S,7) (7 mixture dimensions, no gripper head). */
 typedef struct hulc_val_noise {
     const int32_t* plan_idx_pp;  /* (B,32) categorical sample of the plan-proposal distribution */
     const int32_t* plan_idx_pr;  /* (B,32) ... of the plan-recognition distribution */

@@ -698,6 +698,8 @@ def logistic_sample(logit_probs, log_scales_raw, means, gripper_logits, u_mix, u
     sel_mu = np.take_along_axis(means, k[..., None], -1)[..., 0]
     u = ((r1 - r2) * u_act.astype(F32) + r2).astype(F32)
     act = (sel_mu + np.exp(sel_ls) * (np.log(u) - np.log(1.0 - u))).astype(F32)
+    if gripper_logits is None:                                     # discrete_gripper false (mcil_default.yaml): :257-258, all 7 dims sampled
+        return act
     grip = np.where(gripper_logits.argmax(-1) == 0, F32(-1.0), F32(1.0))
     return np.concatenate([act, grip[..., None]], -1).astype(F32)
 
@@ -709,15 +711,15 @@ def decoder_heads(P, plan, emb, goal, dims, h0=None):
     parts = []
     if plan is not None and plan.shape[-1] > 0:
         parts.append(np.repeat(plan[:, None, :], S, 1))
-    parts += [emb[..., 64:128], np.repeat(goal[:, None, :], S, 1)]
+    parts += [emb[..., dims.emb - dims.dec_emb:dims.emb], np.repeat(goal[:, None, :], S, 1)]
     x = np.concatenate(parts, -1).astype(F32)
     H1, rc = rnn_fwd(P, ad + "rnn.", x, h0)
     h2 = H1.reshape(B * S, -1)
-    K, Dd = dims.n_mix, dims.act_dims
+    K, Dd = dims.n_mix, dims.mix_dims
     probs = linear(h2, P[ad + "prob_fc.weight"], P[ad + "prob_fc.bias"]).reshape(B, S, Dd, K)
     means = linear(h2, P[ad + "mean_fc.weight"], P[ad + "mean_fc.bias"]).reshape(B, S, Dd, K)
     lsr = linear(h2, P[ad + "log_scale_fc.weight"], P[ad + "log_scale_fc.bias"]).reshape(B, S, Dd, K)
-    grip = linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
+    grip = None if dims.kind == "mcil" else linear(h2, P[ad + "gripper_fc.weight"], P[ad + "gripper_fc.bias"]).reshape(B, S, 2)
     return probs, lsr, means, grip, rc["h_n"]
 
 
@@ -751,6 +753,21 @@ def validation_forward(P, dims, mb, is_lang, noise):
     B, S = mb["actions"].shape[:2]
     emb = encode(P, mb["rgb_static"], mb["rgb_gripper"])
     goal = goal_encode(P, mb["lang"] if is_lang else emb[:, -1], is_lang)
+    if dims.kind == "mcil":
+        # continuous plans: noise["plan_pp"] / ["plan_pr"] (B,256) are the draws of Independent(Normal).sample() (distributions.py:37-38);
+        # gripper_control false: loss and sample stay in the world frame (logistic_decoder_rnn.py:99-100)
+        pp_state = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)[0]
+        pr_state, seq_feat, _ = birnn_fwd(P, emb)
+        out = {"seq_feat": seq_feat, "pp_logits": pp_state, "pr_logits": pr_state}
+        for tag in ("pp", "pr"):
+            probs, lsr, means, _, _ = decoder_heads(P, noise[f"plan_{tag}"].astype(F32), emb, goal, dims)
+            loss, _ = logistic_loss(probs, lsr, means, None, mb["actions"].astype(F32), num_classes=dims.mix_classes)
+            pred = logistic_sample(probs, lsr, means, None, noise[f"u_mix_{tag}"], noise[f"u_act_{tag}"])
+            mae = np.abs(pred[..., :-1] - mb["actions"][..., :-1]).mean(1)
+            sr = F32((np.where(pred[..., -1] > 0, 1.0, -1.0) == mb["actions"][..., -1]).mean())
+            out.update({f"action_loss_{tag}": loss, f"mae_{tag}": mae.astype(F32), f"gripper_sr_{tag}": sr, f"pred_{tag}": pred})
+        out["kl_loss"], _, _ = kl_normal_balanced(pp_state, pr_state)
+        return out
     pp_logits = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)[0] if dims.kind == "hulc" else None
     pr_logits, seq_feat, _ = plan_recognition_fwd(P, emb, dims.heads)
     a_tcp = world_to_tcp_frame(mb["actions"], mb["robot_obs"])
@@ -797,13 +814,13 @@ class Rollout:
                 self.goal = goal_encode(P, goal, True)
             pp_logits, _ = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], self.goal], -1), False)
             self.pp_logits = pp_logits
-            self.plan = onehot_plan(noise["plan_idx"], dims)
+            self.plan = noise["plan"].astype(F32) if dims.kind == "mcil" else onehot_plan(noise["plan_idx"], dims)
             self.h = None                                          # clear_hidden_state (hulc.py:925 / :946)
         emb = encode(P, obs["rgb_static"], obs["rgb_gripper"])
         probs, lsr, means, grip, self.h = decoder_heads(P, self.plan, emb, self.goal, dims, self.h)
         pred = logistic_sample(probs, lsr, means, grip, noise["u_mix"], noise["u_act"])
         self.counter += 1
-        return tcp_to_world_frame(pred, obs["robot_obs_raw"])
+        return pred if dims.kind == "mcil" else tcp_to_world_frame(pred, obs["robot_obs_raw"])
 
 
 def kl_loss(pp_logits, pr_logits, dims, beta=0.01, alpha=0.8):

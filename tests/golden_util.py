@@ -85,8 +85,9 @@ def adam_close(got, ref, g, lr=2e-4, steps=1):
 
 
 # ---- validation / rollout fixtures (tools/gen_golden_val.py = the reference's lmp_val / step)
-VAL_CASES = {"val_hulc_tiny": (2, 2, 4, True, 11), "val_hulc_s16": (3, 0, 16, False, 12), "val_gcbc_s8": (2, 2, 8, True, 13, "gcbc")}   # (Bv, Bl, S, use_clip, seed[, kind])
-VAL_NOISE_KEYS = ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")
+VAL_CASES = {"val_hulc_tiny": (2, 2, 4, True, 11), "val_hulc_s16": (3, 0, 16, False, 12), "val_gcbc_s8": (2, 2, 8, True, 13, "gcbc"),
+             "val_mcil_s8": (2, 2, 8, False, 14, "mcil")}   # (Bv, Bl, S, use_clip, seed[, kind])
+VAL_NOISE_KEYS = ("plan_idx_pp", "plan_idx_pr", "plan_pp", "plan_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")
 
 
 def load_val_case(name):
@@ -103,7 +104,8 @@ def load_val_case(name):
 def load_rollout_case(name="rollout_hulc"):
     fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     nsteps, replan_freq, seed = (int(v) for v in fx["meta"])
-    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=True)
+    mcil = name.endswith("mcil")
+    dims = spec.ModelDims(kind="mcil" if mcil else "hulc", max_window=32, use_clip=not mcil)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     frames = synthetic.make_batch(1, 1, nsteps + 1, seed=seed, edge_frac=0.0, aux_mask="all")
     return dims, P, frames, nsteps, replan_freq, fx

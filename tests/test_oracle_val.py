@@ -32,8 +32,9 @@ def test_validation_forward_matches_reference(name):
         assert np.abs(o["seq_feat"] - fx[f"seq_feat_{sc}"]).max() <= 2e-5 * np.abs(fx[f"seq_feat_{sc}"]).max()
 
 
-def test_rollout_matches_reference_step():
-    dims, P, frames, nsteps, replan_freq, fx = load_rollout_case()
+@pytest.mark.parametrize("case", ["rollout_hulc", "rollout_mcil"])
+def test_rollout_matches_reference_step(case):
+    dims, P, frames, nsteps, replan_freq, fx = load_rollout_case(case)
     for mode in ("vis", "lang"):
         mb = frames[mode]
         ro = O.Rollout(P, dims, replan_freq)
@@ -41,7 +42,8 @@ def test_rollout_matches_reference_step():
             else frames["lang"]["lang"][0:1]
         for t in range(nsteps):
             obs = dict(rgb_static=mb["rgb_static"][:, t:t + 1], rgb_gripper=mb["rgb_gripper"][:, t:t + 1], robot_obs_raw=mb["robot_obs"][:, t:t + 1])
-            a = ro.step(obs, goal, dict(plan_idx=fx[f"plan_idx_{mode}"][t], u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
+            pk = dict(plan=fx[f"plan_{mode}"][t]) if dims.kind == "mcil" else dict(plan_idx=fx[f"plan_idx_{mode}"][t])
+            a = ro.step(obs, goal, dict(pk, u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
             assert np.abs(a - fx[f"actions_{mode}"][:, t:t + 1]).max() <= 1e-4, (mode, t)
 
 

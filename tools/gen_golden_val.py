@@ -30,6 +30,7 @@ VAL_CASES = {
     "val_hulc_tiny": (2, 2, 4, True, 11),
     "val_hulc_s16": (3, 0, 16, False, 12),
     "val_gcbc_s8": (2, 2, 8, True, 13, "gcbc"),
+    "val_mcil_s8": (2, 2, 8, False, 14, "mcil"),      # conf/model/mcil.yaml: continuous plans are stored as drawn (B,256)
 }
 
 
@@ -94,8 +95,12 @@ def run_val(name, case, outdir):
                     emb, goal, db["actions"], db["state_info"]["robot_obs"])
             assert len(rr.draws) == 4, len(rr.draws)
             B = emb.shape[0]
-            fx[f"plan_idx_pp_{sc}"] = plan_pp.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
-            fx[f"plan_idx_pr_{sc}"] = plan_pr.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
+            if kind == "mcil":
+                fx[f"plan_pp_{sc}"] = plan_pp.numpy().astype(np.float32)
+                fx[f"plan_pr_{sc}"] = plan_pr.numpy().astype(np.float32)
+            else:
+                fx[f"plan_idx_pp_{sc}"] = plan_pp.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
+                fx[f"plan_idx_pr_{sc}"] = plan_pr.reshape(B, 32, 32).argmax(-1).numpy().astype(np.int32)
             fx[f"u_mix_pp_{sc}"], fx[f"u_act_pp_{sc}"], fx[f"u_mix_pr_{sc}"], fx[f"u_act_pr_{sc}"] = rr.draws
             for k, v in (("action_loss_pp", loss_pp), ("action_loss_pr", loss_pr), ("kl_loss", kl), ("gripper_sr_pp", sr_pp), ("gripper_sr_pr", sr_pr)):
                 fx[f"{k}_{sc}"] = np.float32(v.item())
@@ -107,7 +112,7 @@ def run_val(name, case, outdir):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hulc_oracle as O
     for sc, mb in batch.items():
-        noise = {k: fx[f"{k}_{sc}"] for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr") if f"{k}_{sc}" in fx}
+        noise = {k: fx[f"{k}_{sc}"] for k in ("plan_idx_pp", "plan_idx_pr", "plan_pp", "plan_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr") if f"{k}_{sc}" in fx}
         o = O.validation_forward(P, dims, mb, "lang" in sc, noise)
         if kind == "gcbc":
             print(f"[{name}/{sc}] loss ref {fx[f'action_loss_pp_{sc}']:.6f} oracle {o['action_loss_pp']:.6f} mae err {np.abs(o['mae_pp'] - fx[f'mae_pp_{sc}']).max():.2e} "
@@ -118,11 +123,12 @@ def run_val(name, case, outdir):
               f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f} {fx[f'gripper_sr_pr_{sc}']:.3f}/{o['gripper_sr_pr']:.3f}")
 
 
-def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2):
+def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2, kind="hulc"):
     """Two rollouts with the same weights: vision goal (nsteps steps, replan every replan_freq) then language goal."""
-    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=True)
+    mcil = kind == "mcil"
+    dims = spec.ModelDims(kind=kind, max_window=32, use_clip=not mcil)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
-    model = ref_harness.build_reference("hulc", max_window=32, use_clip=True)
+    model = ref_harness.build_reference(kind, max_window=32, use_clip=not mcil)
     model.eval()
     load_params(model, P)
     model.replan_freq = replan_freq
@@ -147,10 +153,10 @@ def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2):
                 a = model.step(obs, goal)
             assert len(rr.draws) == 2
             umix.append(rr.draws[0]); uact.append(rr.draws[1])
-            plans.append(model.plan.reshape(1, 32, 32).argmax(-1).numpy().astype(np.int32))
+            plans.append(model.plan.numpy().astype(np.float32).copy() if mcil else model.plan.reshape(1, 32, 32).argmax(-1).numpy().astype(np.int32))
             acts.append(a.detach().numpy().copy())
         fx[f"actions_{mode}"] = np.concatenate(acts, 1)          # (1, nsteps, 7)
-        fx[f"plan_idx_{mode}"] = np.stack(plans, 0)               # (nsteps, 1, 32): the plan in force at each step
+        fx[f"plan_{mode}" if mcil else f"plan_idx_{mode}"] = np.stack(plans, 0)   # (nsteps, 1, 32 | 256): the plan in force at each step
         fx[f"u_mix_{mode}"] = np.stack(umix, 0)
         fx[f"u_act_{mode}"] = np.stack(uact, 0)
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
@@ -162,7 +168,8 @@ def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2):
         worst = 0.0
         for t in range(nsteps):
             obs = dict(rgb_static=mb["rgb_static"][:, t:t + 1], rgb_gripper=mb["rgb_gripper"][:, t:t + 1], robot_obs_raw=mb["robot_obs"][:, t:t + 1])
-            a = ro.step(obs, goal, dict(plan_idx=fx[f"plan_idx_{mode}"][t], u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
+            pk = dict(plan=fx[f"plan_{mode}"][t]) if mcil else dict(plan_idx=fx[f"plan_idx_{mode}"][t])
+            a = ro.step(obs, goal, dict(pk, u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
             worst = max(worst, np.abs(a - fx[f"actions_{mode}"][:, t:t + 1]).max())
         print(f"[{name}/{mode}] rollout oracle-vs-reference max |action diff| {worst:.2e}")
 
@@ -175,3 +182,5 @@ if __name__ == "__main__":
             run_val(name, case, out)
     if not only or "rollout_hulc" in only:
         run_rollout("rollout_hulc", out)
+    if not only or "rollout_mcil" in only:
+        run_rollout("rollout_mcil", out, seed=22, kind="mcil")
