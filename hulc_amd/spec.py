@@ -36,6 +36,7 @@ class ModelDims:
     num_classes: int = 10
 
     cont_plan: int = 256          # mcil: distribution.plan_features (conf/model/distribution/continuous.yaml)
+    rnn_type: str = "rnn"         # mcil: plan_recognition.rnn_type — "rnn" = nn.RNN (tanh; birnn.yaml default), "gru" = nn.GRU (BASELINE config 4)
 
     @property
     def plan(self) -> int:
@@ -110,12 +111,13 @@ def param_table(d: ModelDims) -> List[Tuple[str, Tuple[int, ...], tuple]]:
 
     pr = "plan_recognition."
     if d.kind == "mcil":          # PlanRecognitionBiRNNNetwork (plan_recognition_net.py:12-42): nn.RNN(tanh), 2 layers, bidirectional
+        ng = 3 if d.rnn_type == "gru" else 1      # nn.GRU stacks the reset | update | new gate blocks along dim 0
         for l, kin in ((0, d.emb), (1, 2 * H)):
             for sfx in ("", "_reverse"):
-                t.append((f"{pr}birnn_model.weight_ih_l{l}{sfx}", (H, kin), ("u", H)))
-                t.append((f"{pr}birnn_model.weight_hh_l{l}{sfx}", (H, H), ("u", H)))
-                t.append((f"{pr}birnn_model.bias_ih_l{l}{sfx}", (H,), ("u", H)))
-                t.append((f"{pr}birnn_model.bias_hh_l{l}{sfx}", (H,), ("u", H)))
+                t.append((f"{pr}birnn_model.weight_ih_l{l}{sfx}", (ng * H, kin), ("u", H)))
+                t.append((f"{pr}birnn_model.weight_hh_l{l}{sfx}", (ng * H, H), ("u", H)))
+                t.append((f"{pr}birnn_model.bias_ih_l{l}{sfx}", (ng * H,), ("u", H)))
+                t.append((f"{pr}birnn_model.bias_hh_l{l}{sfx}", (ng * H,), ("u", H)))
         lin(pr + "fc_state.0", d.state, 2 * H)
     else:
         t.append((pr + "position_embeddings.weight", (d.max_window, d.emb), ("n",)))

@@ -534,6 +534,80 @@ def decoder_loss_bwd(P, G, c, dims, scale):
 # ----------------------------------------------------------------------------------------------------
 # mcil variant (conf/model/mcil.yaml): bidirectional tanh-RNN plan recognition, continuous latent plan
 # ----------------------------------------------------------------------------------------------------
+def bigru_fwd(P, emb):
+    """PlanRecognitionBiRNNNetwork.forward with rnn_type nn.GRU (plan_recognition_net.py:27-42; torch.nn.GRU cell equations):
+    r = sig(W_ir x + b_ir + W_hr h + b_hr), z = sig(W_iz x + b_iz + W_hz h + b_hz), n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
+    h' = (1 - z) * n + z * h; gate blocks stacked r | z | n along dim 0 of weight_ih / weight_hh."""
+    pre = "plan_recognition.birnn_model."
+    B, S, _ = emb.shape
+    c = {"inp0": emb}
+    inp = emb
+    for l in range(2):
+        outs = []
+        for sfx, order in (("", range(S)), ("_reverse", range(S - 1, -1, -1))):
+            wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
+            bih, bhh = P[f"{pre}bias_ih_l{l}{sfx}"], P[f"{pre}bias_hh_l{l}{sfx}"]
+            Hn = whh.shape[1]
+            zx = (inp.reshape(B * S, -1) @ wih.T + bih).reshape(B, S, 3 * Hn)
+            Hs, R, Z, N, GN, HP = (np.zeros((B, S, Hn), F32) for _ in range(6))
+            h = np.zeros((B, Hn), F32)
+            for t in order:
+                g = (h @ whh.T + bhh).astype(F32)
+                r = sigmoid(zx[:, t, :Hn] + g[:, :Hn]).astype(F32)
+                z = sigmoid(zx[:, t, Hn:2 * Hn] + g[:, Hn:2 * Hn]).astype(F32)
+                n = np.tanh(zx[:, t, 2 * Hn:] + r * g[:, 2 * Hn:]).astype(F32)
+                HP[:, t] = h
+                h = ((1.0 - z) * n + z * h).astype(F32)
+                Hs[:, t], R[:, t], Z[:, t], N[:, t], GN[:, t] = h, r, z, n, g[:, 2 * Hn:]
+            c[f"g{l}{sfx}"] = (Hs, R, Z, N, GN, HP)
+            outs.append(Hs)
+        inp = np.concatenate(outs, -1)
+        c[f"out{l}"] = inp
+    x = inp[:, -1]
+    c["x"] = x
+    state = linear(x, P["plan_recognition.fc_state.0.weight"], P["plan_recognition.fc_state.0.bias"])
+    return state, x, c
+
+
+def bigru_bwd(P, G, c, dstate):
+    pre = "plan_recognition.birnn_model."
+    dx, dw, db = linear_bwd(c["x"], P["plan_recognition.fc_state.0.weight"], dstate)
+    _acc(G, "plan_recognition.fc_state.0.weight", dw)
+    _acc(G, "plan_recognition.fc_state.0.bias", db)
+    emb = c["inp0"]
+    B, S, _ = emb.shape
+    Hn = c["g0"][0].shape[-1]
+    dout = np.zeros((B, S, 2 * Hn), F32)
+    dout[:, -1] = dx
+    for l in (1, 0):
+        inp = c["out0"] if l == 1 else emb
+        dinp = np.zeros_like(inp)
+        for k, (sfx, order) in enumerate((("", list(range(S))), ("_reverse", list(range(S - 1, -1, -1))))):
+            wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
+            Hs, R, Z, N, GN, HP = c[f"g{l}{sfx}"]
+            dH = dout[..., k * Hn:(k + 1) * Hn]
+            dZx = np.zeros((B, S, 3 * Hn), F32)          # grads of the input-side pre-activations (r | z | n)
+            dGh = np.zeros((B, S, 3 * Hn), F32)          # grads of the hidden-side pre-activations (n block scaled by r)
+            carry = np.zeros((B, Hn), F32)
+            for i in reversed(range(S)):
+                t = order[i]
+                dh = dH[:, t] + carry
+                r, z, n, gn, hp = R[:, t], Z[:, t], N[:, t], GN[:, t], HP[:, t]
+                dn = dh * (1.0 - z) * (1.0 - n * n)
+                dz = dh * (hp - n) * z * (1.0 - z)
+                dr = dn * gn * r * (1.0 - r)
+                dZx[:, t] = np.concatenate([dr, dz, dn], -1)
+                dGh[:, t] = np.concatenate([dr, dz, dn * r], -1)
+                carry = dh * z + dGh[:, t] @ whh
+            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dGh.reshape(B * S, -1).T @ HP.reshape(B * S, Hn))
+            _acc(G, f"{pre}bias_hh_l{l}{sfx}", dGh.reshape(B * S, -1).sum(0))
+            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dZx.reshape(B * S, -1).T @ inp.reshape(B * S, -1))
+            _acc(G, f"{pre}bias_ih_l{l}{sfx}", dZx.reshape(B * S, -1).sum(0))
+            dinp += (dZx.reshape(B * S, -1) @ wih).reshape(B, S, -1)
+        dout = dinp.astype(F32)
+    return dout
+
+
 def birnn_fwd(P, emb):
     """PlanRecognitionBiRNNNetwork.forward (plan_recognition_net.py:37-42): nn.RNN(tanh, 2 layers, bidirectional, batch_first);
     x = output[:, -1] = [forward hidden after the last step | reverse hidden at the last position (= its FIRST step)]."""
@@ -757,7 +831,7 @@ def validation_forward(P, dims, mb, is_lang, noise):
         # continuous plans: noise["plan_pp"] / ["plan_pr"] (B,256) are the draws of Independent(Normal).sample() (distributions.py:37-38);
         # gripper_control false: loss and sample stay in the world frame (logistic_decoder_rnn.py:99-100)
         pp_state = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)[0]
-        pr_state, seq_feat, _ = birnn_fwd(P, emb)
+        pr_state, seq_feat, _ = (bigru_fwd if dims.rnn_type == "gru" else birnn_fwd)(P, emb)
         out = {"seq_feat": seq_feat, "pp_logits": pp_state, "pr_logits": pr_state}
         for tag in ("pp", "pr"):
             probs, lsr, means, _, _ = decoder_heads(P, noise[f"plan_{tag}"].astype(F32), emb, goal, dims)
@@ -906,7 +980,7 @@ def modality_fwd(P, dims, mb, is_lang):
         goal, c["goal_ln"] = layer_norm(gpre, P["visual_goal.ln.weight"], P["visual_goal.ln.bias"])
     c["goal"] = goal
     if dims.kind == "mcil":
-        pr_state, seq_feat, c["pr"] = birnn_fwd(P, emb)
+        pr_state, seq_feat, c["pr"] = (bigru_fwd if dims.rnn_type == "gru" else birnn_fwd)(P, emb)
         pp_state, c["pp_acts"] = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)
         mean, std, _ = cont_state(pr_state)
         plan = (mean + std * mb["plan_eps"].astype(F32)).astype(F32)          # pr_dist.rsample() (hulc.py:289) with the injected N(0,1) draw
@@ -955,7 +1029,7 @@ def modality_bwd(P, G, dims, c, is_lang, w_mod, w_clip):
         _, _, var = cont_state(c["pr_logits"])
         # plan = mean + std * eps -> d mean = dplan, d var = dplan * eps * sigmoid(var)
         dpr = np.concatenate([dplan, dplan * ((c["plan"] - c["pr_logits"][:, :n]) / c["pr_std"]) * sigmoid(var)], -1) + c["dpr_kl"] * F32(w_mod)
-        demb += birnn_bwd(P, G, c["pr"], dpr.astype(F32))
+        demb += (bigru_bwd if dims.rnn_type == "gru" else birnn_bwd)(P, G, c["pr"], dpr.astype(F32))
         dppx = mlp_bwd(P, G, PP_NAMES, c["pp_acts"], (c["dpp_kl"] * F32(w_mod)).astype(F32), False)
         demb[:, 0] += dppx[:, :dims.emb]
         dgoal = dgoal + dppx[:, dims.emb:]

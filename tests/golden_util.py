@@ -112,12 +112,12 @@ def load_rollout_case(name="rollout_hulc"):
 
 
 # ---- mcil variant (tools/gen_golden_mcil.py)
-MCIL_CASES = {"mcil_s6": (2, 2, 6, 41), "mcil_s12": (3, 0, 12, 32)}       # name: (Bv, Bl, S, seed)
+MCIL_CASES = {"mcil_s6": (2, 2, 6, 41), "mcil_s12": (3, 0, 12, 32), "mcil_gru_s6": (2, 2, 6, 43, "gru")}       # name: (Bv, Bl, S, seed[, rnn_type])
 
 
 def load_mcil_case(name):
-    Bv, Bl, S, seed = MCIL_CASES[name]
-    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False)
+    Bv, Bl, S, seed = MCIL_CASES[name][:4]
+    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False, rnn_type=MCIL_CASES[name][4] if len(MCIL_CASES[name]) > 4 else "rnn")
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
     fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))

@@ -21,15 +21,18 @@ from hulc_amd.utils import synthetic  # noqa: E402
 import ref_harness  # noqa: E402
 from gen_golden import FULL_MAX, sample_idx, to_ref_batch  # noqa: E402
 
-CASES = {"mcil_s6": (2, 2, 6, 41), "mcil_s12": (3, 0, 12, 32)}       # name: (Bv, Bl, S, seed)
+CASES = {"mcil_s6": (2, 2, 6, 41), "mcil_s12": (3, 0, 12, 32),       # name: (Bv, Bl, S, seed[, rnn_type])
+         "mcil_gru_s6": (2, 2, 6, 43, "gru")}                           # plan_recognition.rnn_type=nn.GRU (BASELINE config 4)
 
 
 def run_case(name, case, outdir):
-    Bv, Bl, S, seed = case
-    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False)
+    Bv, Bl, S, seed = case[:4]
+    rnn_type = case[4] if len(case) > 4 else "rnn"
+    refkind = "mcil_gru" if rnn_type == "gru" else "mcil"
+    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False, rnn_type=rnn_type)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=0.05, aux_mask="all")
-    model = ref_harness.build_reference("mcil", max_window=32)
+    model = ref_harness.build_reference(refkind, max_window=32)
     model.eval()
     names = [n for n, _ in model.named_parameters()]
     assert set(names) == set(P.keys()), set(names) ^ set(P.keys())
@@ -75,7 +78,7 @@ def run_case(name, case, outdir):
     # conv / MLP gradients deviate up to 1.6 % (rel-L2) from it on some tensors (ReLU sign flips of near-zero pre-activations), which is
     # noise of the reference, not signal (the oracle is 1.6e-5 from the fp64 evaluation).
     import torch.distributions as D
-    model64 = ref_harness.build_reference("mcil", max_window=32).eval().double()
+    model64 = ref_harness.build_reference(refkind, max_window=32).eval().double()
     with torch.no_grad():
         for n, p in model64.named_parameters():
             p.copy_(torch.from_numpy(P[n]).reshape(p.shape).double())

@@ -173,10 +173,10 @@ def model_cfg(kind="hulc", max_window=32, use_clip=True, dropout_p=0.1):
     return to_cfg(cfg)
 
 
-def mcil_cfg(cfg):
+def mcil_cfg(cfg, rnn_type="nn.RNN"):
     """conf/model/mcil.yaml: plan_recognition birnn, distribution continuous, action_decoder mcil_default, no CLIP loss."""
     cfg["plan_recognition"] = to_cfg(dict(_target_="hulc.models.plan_encoders.plan_recognition_net.PlanRecognitionBiRNNNetwork", in_features=None,
-                                          plan_features=256, action_space=7, birnn_dropout_p=0.0, rnn_type="nn.RNN"))
+                                          plan_features=256, action_space=7, birnn_dropout_p=0.0, rnn_type=rnn_type))
     cfg["distribution"] = to_cfg(dict(_target_="hulc.utils.distributions.Distribution", dist="continuous", plan_features=256))
     ad = dict(cfg["action_decoder"])
     ad.update(num_classes=256, gripper_control=False, discrete_gripper=False)
@@ -189,9 +189,9 @@ def mcil_cfg(cfg):
 
 def build_reference(kind="hulc", **kw):
     install_stubs()
-    if kind == "mcil":
+    if kind in ("mcil", "mcil_gru"):
         kw = dict(kw); kw["use_clip"] = False
-        cfg = mcil_cfg(model_cfg("hulc", **kw))
+        cfg = mcil_cfg(model_cfg("hulc", **kw), "nn.GRU" if kind == "mcil_gru" else "nn.RNN")
         from hulc.models.hulc import Hulc
         return Hulc(**cfg)
     cfg = model_cfg(kind, **kw)
