@@ -58,12 +58,12 @@ def synth_batch(B, S, dev, seed, lang=False, ingest="fp32"):
     return mb
 
 
-def cpu_baseline(S, budget_s=20.0, kind="hulc"):
+def cpu_baseline(S, budget_s=20.0, kind="hulc", rnn_type="rnn"):
     """Oracle (numpy port of the reference step) timed on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hulc_oracle as O
     from hulc_amd.utils import synthetic
-    dims = spec.ModelDims(kind=kind, max_window=max(32, S), use_clip=False)
+    dims = spec.ModelDims(kind=kind, max_window=max(32, S), use_clip=False, rnn_type=rnn_type)
     P = spec.init_all(dims, seed=0)
     Bc = 4
     batch = synthetic.make_batch(Bc, 0, S, seed=0)
@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--ingest", default="fp32", choices=["fp32", "u8"],
                     help="fp32: the reference's boundary (transformed fp32 NCHW frames, the headline); u8: uint8 HWC dataset frames, "
                          "scale/normalise/RandomShiftsAug fused into conv1 (SURVEY §8(f) row 1)")
-    ap.add_argument("--model", default="hulc", choices=["hulc", "mcil"],
-                    help="hulc: the headline configuration; mcil: conf/model/mcil.yaml (BASELINE config 4: BiRNN plan recognition, continuous plan, no CLIP loss)")
+    ap.add_argument("--model", default="hulc", choices=["hulc", "mcil", "mcil_gru"],
+                    help="hulc: the headline configuration; mcil: conf/model/mcil.yaml (BiRNN plan recognition, continuous plan, no CLIP loss); "
+                         "mcil_gru: the same with plan_recognition.rnn_type=nn.GRU (BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,9 +117,9 @@ def main():
     torch.cuda.set_device(dev)
 
     B, S = args.batch, args.seq
-    mcil = args.model == "mcil"
+    mcil = args.model in ("mcil", "mcil_gru")
     use_clip = bool(args.lang) and not mcil
-    dims = spec.ModelDims(kind=args.model, max_window=max(32, S), use_clip=use_clip)
+    dims = spec.ModelDims(kind="mcil" if mcil else args.model, max_window=max(32, S), use_clip=use_clip, rnn_type="gru" if args.model == "mcil_gru" else "rnn")
     Bmod = B // 2 if args.lang else B
     eng = StepEngine(dims, Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
@@ -206,7 +207,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper %s frames, "
-                                   "fwd+loss+bwd+%sAdam, dropout %s" % ("HULC (model=mcil: BiRNN plan recognition, continuous plan)" if mcil else "HULC",
+                                   "fwd+loss+bwd+%sAdam, dropout %s" % (("HULC (model=mcil: Bi%s plan recognition, continuous plan)" % ("GRU" if args.model == "mcil_gru" else "RNN")) if mcil else "HULC",
                                                                         ("32 vis + 32 lang" + ("" if mcil else " + CLIP aux")) if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
                                                                         B, S, "uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" if args.ingest == "u8" else "fp32 NCHW",
                                                                         "RCCL all-reduce+" if world > 1 else "", "0.0" if mcil else "0.1"),
@@ -216,7 +217,7 @@ def main():
             "step_tflops": None if mcil else round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
             "roofline": rl,
             "kernel_classes": kernel_classes,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(S, kind=args.model),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(S, kind=dims.kind, rnn_type=dims.rnn_type),
         }
         print(json.dumps(out))
     if world > 1:

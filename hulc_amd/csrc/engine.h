@@ -92,7 +92,7 @@ struct Engine : IEngine {
     // dimensions (6 + discrete gripper head; mcil: 7, no gripper head), NHEAD = packed head columns (16-aligned), DE = decoder's slice
     // of the perceptual embedding (perceptual_emb_slice [64,128]; mcil: all 128)
     int PLAN, NDIM, NHEAD, NO, DE;
-    bool mcil;
+    bool mcil, gru = false;       // gru: mcil with plan_recognition.rnn_type = nn.GRU (3 gate blocks per BiRNN weight)
     int dec_plan, KIN;
     int maxB, maxS, maxN;
     // ---- bound flat buffers
@@ -135,6 +135,9 @@ struct Engine : IEngine {
     const float *bb_ih[2][2], *bb_hh[2][2]; float *dbb_ih[2][2], *dbb_hh[2][2];
     T *bZ0[2] = {nullptr, nullptr}, *bH0[2], *bZ1, *bH1, *bh1b, *bxcat, *bdx, *bdH0[2], *bdZ0[2], *bdZ1, *bdz1b, *plan_t;
     float *plan_f, *plan_eps, *plan_eps_in, *klel;
+    // GRU variant: per recurrence c (0: layer 0 fwd, 1: layer 0 reverse, 2: layer 1 fwd; 3: the single evaluated step of layer 1 reverse)
+    struct GruBuf { T *Zx, *H, *R, *Z, *N, *GN, *dZx, *dG; } gb[4];
+    float* gGf = nullptr; T *gcarA = nullptr, *gcarB = nullptr;
     const float *ln_vg_g, *ln_vg_b, *ln_lg_g, *ln_lg_b, *tr_n1g[2], *tr_n1b[2], *tr_n2g[2], *tr_n2b[2], *pos32, *logit_scale;
     float *d_ln_vg_g, *d_ln_vg_b, *d_ln_lg_g, *d_ln_lg_b, *d_tr_n1g[2], *d_tr_n1b[2], *d_tr_n2g[2], *d_tr_n2b[2], *dpos, *dlogit_scale;
     // decoder input weights W_ih0 [HID][KIN] (sub-blocked) + packed heads
@@ -171,7 +174,8 @@ struct Engine : IEngine {
 
     // =====================================================================================================
     Engine(const hulc_config& c) : cfg(c) {
-        mcil = cfg.kind == HULC_KIND_MCIL;
+        mcil = cfg.kind == HULC_KIND_MCIL || cfg.kind == HULC_KIND_MCIL_GRU;
+        gru = cfg.kind == HULC_KIND_MCIL_GRU;
         PLAN = mcil ? 512 : 1024; NDIM = mcil ? 7 : 6; NO = NMIX * NDIM; NHEAD = mcil ? 224 : 192; DE = mcil ? EMB : 64;
         if (mcil) { head_rows[0] = head_rows[1] = head_rows[2] = NO; head_rows[3] = 0; }
         dec_plan = cfg.kind == HULC_KIND_GCBC ? 0 : (mcil ? PLAN / 2 : PLAN);
@@ -242,7 +246,7 @@ struct Engine : IEngine {
         dxa = alloc<float>(N * EMB); dxb = alloc<float>(N * EMB); dy_f = alloc<float>(N * EMB); dxm = alloc<float>(B * EMB);
         dprl_t = alloc<T>(B * PLAN); dppl_t = alloc<T>(B * PLAN); dseq_t = alloc<T>(B * FCH);
         dt_a = alloc<T>(std::max<int64_t>(N * FF, 2 * B * HID)); dt_b = alloc<T>(N * 3 * EMB); dt_c = alloc<T>(N * EMB); dgl3_t = alloc<T>(B * GOAL);
-        tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>(HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
+        tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>((gru ? 3 : 1) * HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
         tA = alloc<T>(tcap); tB = alloc<T>(tcap);
         partcap = 1024ll * 64 * 576; part = alloc<float>(partcap); cspart = alloc<float>(1024 * 2048);
         auxrows = alloc<int>(B); sf_m = alloc<T>(B * FCH); im1 = alloc<T>(B * 128); g_m = alloc<T>(B * GOAL); la1 = alloc<T>(B * 128);
@@ -250,6 +254,14 @@ struct Engine : IEngine {
         dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
         dim1 = alloc<T>(B * 128); dla1 = alloc<T>(B * 128); dsf_m = alloc<float>(B * FCH); dg_m = alloc<float>(B * GOAL);
         losses = alloc<float>(8);
+        if (gru) {
+            for (int c = 0; c < 4; ++c) {
+                const int64_t rows = c < 3 ? SB : B;
+                gb[c].Zx = alloc<T>(rows * 3 * HID); gb[c].R = alloc<T>(rows * HID); gb[c].Z = alloc<T>(rows * HID); gb[c].N = alloc<T>(rows * HID);
+                gb[c].GN = alloc<T>(rows * HID); gb[c].dZx = alloc<T>(rows * 3 * HID); gb[c].dG = alloc<T>(rows * 3 * HID);
+            }
+            gGf = alloc<float>(B * 3 * HID); gcarA = alloc<T>(B * HID); gcarB = alloc<T>(B * HID);
+        }
         if (mcil) {
             for (int d = 0; d < 2; ++d) { bZ0[d] = alloc<T>(SB * HID); bH0[d] = alloc<T>(SB * HID, d ? "birnn_h0_rev" : "birnn_h0"); bdH0[d] = alloc<T>(SB * HID); bdZ0[d] = alloc<T>(SB * HID); }
             bZ1 = alloc<T>(SB * HID); bH1 = alloc<T>(SB * HID, "birnn_h1"); bh1b = alloc<T>(B * HID); bxcat = alloc<T>(B * 2 * HID, "birnn_x"); bdx = alloc<T>(B * 2 * HID);
@@ -330,8 +342,8 @@ struct Engine : IEngine {
                     for (int d = 0; d < 2; ++d) {
                         const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
                         const std::string bp = pr + "birnn_model.";
-                        bind_lin(bw_ih[l][d], bp + "weight_ih" + sfx, HID, l ? 2 * HID : EMB, false);
-                        bind_lin(bw_hh[l][d], bp + "weight_hh" + sfx, HID, HID, false);
+                        bind_lin(bw_ih[l][d], bp + "weight_ih" + sfx, (gru ? 3 : 1) * HID, l ? 2 * HID : EMB, false);
+                        bind_lin(bw_hh[l][d], bp + "weight_hh" + sfx, (gru ? 3 : 1) * HID, HID, false);
                         bb_ih[l][d] = pw(bp + "bias_ih" + sfx); bb_hh[l][d] = pw(bp + "bias_hh" + sfx);
                         dbb_ih[l][d] = gw(bp + "bias_ih" + sfx); dbb_hh[l][d] = gw(bp + "bias_hh" + sfx);
                     }
@@ -874,7 +886,7 @@ struct Engine : IEngine {
         HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
         trunk_fwd(b, dp);
         if (mcil) {
-            birnn_fwd(B, S);
+            if (gru) bigru_fwd(B, S); else birnn_fwd(B, S);
             const int n = PLAN / 2;
             const float* eps = nullptr;
             if (b->plan_eps) { HIP_CHECK(hipMemcpyAsync(plan_eps_in, b->plan_eps, sizeof(float) * B * n, hipMemcpyDefault, st)); eps = plan_eps_in; }
@@ -968,7 +980,7 @@ struct Engine : IEngine {
         const int B = b->B, S = b->S, SB = S * B;
         HIP_CHECK(hipMemsetAsync(valm, 0, 32 * sizeof(float), st));
         trunk_fwd(b, 0.f);
-        if (mcil) birnn_fwd(B, S); else pr_fwd(B, S, 0.f);
+        if (gru) bigru_fwd(B, S); else if (mcil) birnn_fwd(B, S); else pr_fwd(B, S, 0.f);
         // KL (beta-scaled) + recognition sample, then the proposal sample (no KL terms: second logits pointer null)
         const int* in_pr = nullptr;
         if (hulc) {
@@ -1154,6 +1166,104 @@ struct Engine : IEngine {
         { EpiP ep = epi(pr_logits, true); lin_fwd(bxcat, 2 * HID, B, pr_fs, ep, PLAN); }
         STAGE("birnn_fwd");
     }
+    // ---------------------------------------------------------------- the same with rnn_type = nn.GRU (BASELINE config 4)
+    // one direction of one layer: Zx (incl. b_ih) [S][B][3H] -> H [S][B][H]; per step one M = B GEMM against W_hh (N = 3H) + the gate kernel
+    void gru_recur_fwd(GruBuf& g, const LinW& whh, const float* bhh, int B, int S, bool rev) {
+        const long long BH = (long long)B * HID;
+        auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i); };
+        for (int i = 0; i < S; ++i) {
+            const long long t = at(i);
+            const T* hp = i ? g.H + at(i - 1) * BH : nullptr;
+            if (i) { EpiP ep = epi(gGf, true); ep.bias = bhh; gemm(dense<T>(hp, B, HID), dense<T>(whh.W, 3 * HID, HID), dense_out(3 * HID), ep, B, 3 * HID, HID); }
+            hipLaunchKernelGGL((gru_gate_fwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, g.Zx + t * 3 * BH, i ? gGf : (const float*)nullptr, bhh, hp, B, HID,
+                               g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH);
+        }
+    }
+    // BPTT of it: dH [S][B][H] (or, dH_last_only, the gradient [B][H] of the last processed state) -> g.dZx, g.dG
+    void gru_recur_bwd(GruBuf& g, const T* dH, const LinW& whh, int B, int S, bool rev, bool dH_last_only) {
+        const long long BH = (long long)B * HID;
+        auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i); };
+        for (int i = S - 1; i >= 0; --i) {
+            const long long t = at(i);
+            const T* dh = dH_last_only ? (i == S - 1 ? dH : nullptr) : dH + t * BH;
+            hipLaunchKernelGGL((gru_gate_bwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dh, i == S - 1 ? (const T*)nullptr : gcarA, g.R + t * BH, g.Z + t * BH,
+                               g.N + t * BH, g.GN + t * BH, i ? g.H + at(i - 1) * BH : (const T*)nullptr, B, HID, g.dZx + t * 3 * BH, g.dG + t * 3 * BH, gcarB);
+            if (i) { EpiP ep = epi(gcarA, false); ep.res = gcarB; ep.res_ld = HID;
+                     gemm(dense<T>(g.dG + t * 3 * BH, B, 3 * HID), dense<T>(whh.Wt, HID, 3 * HID), dense_out(HID), ep, B, HID, 3 * HID); }
+        }
+    }
+    // weight / bias gradients of one recurrence from dZx, dG, its states H and its input X [S][B][K] (ldx), into dW_ih (+ column offset, lddw)
+    void gru_param_grads(GruBuf& g, const LinW& wih, const LinW& whh, float* dbih, float* dbhh, int B, int S, bool rev) {
+        const int SB = S * B, mp = ldpad(SB), H3 = 3 * HID;
+        transpose_pair(g.dG, H3, tA, SB, H3, g.H, HID, tB, SB, HID, mp);
+        if (S > 1) { EpiP ep = epi(whh.dW, true); ep.accumulate = 1;      // forward: dG[t] x H[t-1]; reverse: dG[t] x H[t+1]
+          gemm(dense<T>(tA + (rev ? 0 : B), H3, mp), dense<T>(tB + (rev ? B : 0), HID, mp), dense_out(HID), ep, H3, HID, (S - 1) * B); }
+        colsum(g.dG, H3, SB, H3, dbhh);
+        colsum(g.dZx, H3, SB, H3, dbih);
+        (void)wih;
+    }
+    void bigru_fwd(int B, int S) {
+        const int SB = S * B, H3 = 3 * HID;
+        const long long BH = (long long)B * HID;
+        gb[0].H = bH0[0]; gb[1].H = bH0[1]; gb[2].H = bH1; gb[3].H = bh1b;
+        hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * EMB, 256)), dim3(256), 0, st, emb, embg, B, S, EMB);
+        for (int d = 0; d < 2; ++d) {
+            { EpiP ep = epi(gb[d].Zx, false); ep.bias = bb_ih[0][d];
+              gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, H3, EMB), dense_out(H3), ep, SB, H3, EMB); }
+            gru_recur_fwd(gb[d], bw_hh[0][d], bb_hh[0][d], B, S, d == 1);
+        }
+        for (int d = 0; d < 2; ++d) {      // layer 1 input [H0f | H0b]: two K = 2048 GEMMs against the column halves of W_ih_l1; d = 1: reverse direction, t = S-1 only
+            const int M = d ? B : SB;
+            const long long off = d ? (S - 1) * BH : 0;
+            GruBuf& g = gb[2 + d];
+            { EpiP ep = epi(g.Zx, false); ep.bias = bb_ih[1][d];
+              gemm(dense<T>(bH0[0] + off, M, HID), dense<T>(bw_ih[1][d].W, H3, 2 * HID), dense_out(H3), ep, M, H3, HID); }
+            { EpiP ep = epi(g.Zx, false); ep.res = g.Zx; ep.res_ld = H3;
+              gemm(dense<T>(bH0[1] + off, M, HID), dense<T>(bw_ih[1][d].W + HID, H3, 2 * HID), dense_out(H3), ep, M, H3, HID); }
+            gru_recur_fwd(g, bw_hh[1][d], bb_hh[1][d], B, d ? 1 : S, false);
+        }
+        copy2d<T, T>(bH1 + (S - 1) * BH, HID, bxcat, 2 * HID, B, HID, 0);
+        copy2d<T, T>(bh1b, HID, bxcat + HID, 2 * HID, B, HID, 0);
+        { EpiP ep = epi(pr_logits, true); lin_fwd(bxcat, 2 * HID, B, pr_fs, ep, PLAN); }
+        STAGE("bigru_fwd");
+    }
+    void bigru_bwd(const T* dpr, int B, int S) {
+        const int SB = S * B, mp = ldpad(SB), H3 = 3 * HID;
+        const long long BH = (long long)B * HID;
+        lin_wgrad(dpr, bxcat, 2 * HID, B, PLAN, 2 * HID, pr_fs.dW, 2 * HID, pr_fs.db);
+        { EpiP ep = epi(bdx, false); lin_dgrad(dpr, B, pr_fs, ep, dense_out(2 * HID)); }
+        // ---- layer 1: reverse direction (its one evaluated step, h_prev = 0: weight_hh_l1_reverse gets no gradient, its bias does) and forward BPTT
+        copy2d<T, T>(bdx + HID, 2 * HID, dt_a + BH, HID, B, HID, 0);
+        gru_recur_bwd(gb[3], dt_a + BH, bw_hh[1][1], B, 1, false, true);
+        lin_wgrad(gb[3].dZx, bH0[0] + (S - 1) * BH, HID, B, H3, HID, bw_ih[1][1].dW, 2 * HID, dbb_ih[1][1]);
+        lin_wgrad(gb[3].dZx, bH0[1] + (S - 1) * BH, HID, B, H3, HID, bw_ih[1][1].dW + HID, 2 * HID, nullptr);
+        colsum(gb[3].dG, H3, B, H3, dbb_hh[1][1]);
+        copy2d<T, T>(bdx, 2 * HID, dt_a, HID, B, HID, 0);
+        gru_recur_bwd(gb[2], dt_a, bw_hh[1][0], B, S, false, true);
+        for (int d = 0; d < 2; ++d) {      // d (layer-0 outputs) = dZx1 W_ih_l1 (+ the reverse direction's step at t = S-1)
+            { EpiP ep = epi(bdH0[d], false);
+              gemm(dense<T>(gb[2].dZx, SB, H3), dense<T>(bw_ih[1][0].Wt + (long long)d * HID * H3, HID, H3), dense_out(HID), ep, SB, HID, H3); }
+            { EpiP ep = epi(bdH0[d] + (S - 1) * BH, false); ep.res = bdH0[d] + (S - 1) * BH; ep.res_ld = HID;
+              gemm(dense<T>(gb[3].dZx, B, H3), dense<T>(bw_ih[1][1].Wt + (long long)d * HID * H3, HID, H3), dense_out(HID), ep, B, HID, H3); }
+        }
+        gru_param_grads(gb[2], bw_ih[1][0], bw_hh[1][0], dbb_ih[1][0], dbb_hh[1][0], B, S, false);
+        cast_tr<T, T>(gb[2].dZx, H3, nullptr, 0, tA, mp, SB, H3);
+        for (int d = 0; d < 2; ++d) {
+            cast_tr<T, T>(bH0[d], HID, nullptr, 0, tB, mp, SB, HID);
+            EpiP ep = epi(bw_ih[1][0].dW + d * HID, true); ep.accumulate = 1;
+            gemm(dense<T>(tA, H3, mp), dense<T>(tB, HID, mp), dense_out(2 * HID), ep, H3, HID, SB);
+        }
+        // ---- layer 0, both directions
+        for (int d = 0; d < 2; ++d) {
+            gru_recur_bwd(gb[d], bdH0[d], bw_hh[0][d], B, S, d == 1, false);
+            gru_param_grads(gb[d], bw_ih[0][d], bw_hh[0][d], dbb_ih[0][d], dbb_hh[0][d], B, S, d == 1);
+            transpose_pair(gb[d].dZx, H3, tA, SB, H3, embg, EMB, tB, SB, EMB, mp);
+            { EpiP ep = epi(bw_ih[0][d].dW, true); ep.accumulate = 1; gemm(dense<T>(tA, H3, mp), dense<T>(tB, EMB, mp), dense_out(EMB), ep, H3, EMB, SB); }
+            { EpiP ep = epi(demb, true); ep.accumulate = 1;
+              gemm(dense<T>(gb[d].dZx, SB, H3), dense<T>(bw_ih[0][d].Wt, EMB, H3), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, EMB, H3); }
+        }
+        STAGE("bigru_bwd");
+    }
     // dpr: d pr_state (T, [B][PLAN]).  Accumulates the BiRNN / fc_state parameter gradients and adds d emb into demb (B,S,128).
     void birnn_bwd(const T* dpr, int B, int S) {
         const int SB = S * B, mp = ldpad(SB);
@@ -1314,7 +1424,7 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
-            birnn_bwd(dprl_t, B, S);
+            if (gru) bigru_bwd(dprl_t, B, S); else birnn_bwd(dprl_t, B, S);
         }
         // ---- plan recognition backward
         if (have_dseq) {

@@ -826,6 +826,46 @@ __global__ void normal_rsample_bwd_kernel(const float* __restrict__ dplan, const
     out[o] = from_f<T>(g + dpr_kl[o]);
     out[o + n] = from_f<T>(g * eps[idx] / (1.f + __expf(-v1)) + dpr_kl[o + n]);
 }
+// mcil with plan_recognition.rnn_type = nn.GRU (torch.nn.GRU cell): one time step of one direction, elementwise part.
+// zx (B,3H) = W_i x + b_i (gate blocks r | z | n), g (B,3H) fp32 = W_h h + b_h or null (h = 0: g = b_h), hprev (B,H) or null.
+//   r = sig(zx_r + g_r), z = sig(zx_z + g_z), n = tanh(zx_n + r * g_n), h' = (1 - z) n + z h
+// r, z, n and g_n are kept for the backward.
+template <typename T>
+__global__ void gru_gate_fwd_kernel(const T* __restrict__ zx, const float* __restrict__ g, const float* __restrict__ bhh, const T* __restrict__ hprev,
+                                    int B, int H, T* __restrict__ h_out, T* __restrict__ r_out, T* __restrict__ z_out, T* __restrict__ n_out,
+                                    T* __restrict__ gn_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx % H;
+    const long long o3 = (long long)b * 3 * H + j;
+    const float gr = g ? g[o3] : bhh[j], gz = g ? g[o3 + H] : bhh[H + j], gn = g ? g[o3 + 2 * H] : bhh[2 * H + j];
+    const float r = 1.f / (1.f + __expf(-(to_f<T>(zx[o3]) + gr)));
+    const float z = 1.f / (1.f + __expf(-(to_f<T>(zx[o3 + H]) + gz)));
+    const float n = tanhf(to_f<T>(zx[o3 + 2 * H]) + r * gn);
+    const float hp = hprev ? to_f<T>(hprev[idx]) : 0.f;
+    h_out[idx] = from_f<T>((1.f - z) * n + z * hp);
+    r_out[idx] = from_f<T>(r); z_out[idx] = from_f<T>(z); n_out[idx] = from_f<T>(n); gn_out[idx] = from_f<T>(gn);
+}
+// backward of the same step: dh = dH (or 0) + carry (or 0) -> gradients of the input-side pre-activations dzx = (dr, dz, dn), of the
+// hidden-side ones dg = (dr, dz, dn * r), and the direct path dh * z to the previous state (the caller adds dg W_h)
+template <typename T>
+__global__ void gru_gate_bwd_kernel(const T* __restrict__ dH, const T* __restrict__ carry, const T* __restrict__ r_, const T* __restrict__ z_,
+                                    const T* __restrict__ n_, const T* __restrict__ gn_, const T* __restrict__ hprev, int B, int H,
+                                    T* __restrict__ dzx, T* __restrict__ dg, T* __restrict__ direct) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx % H;
+    const long long o3 = (long long)b * 3 * H + j;
+    const float dh = (dH ? to_f<T>(dH[idx]) : 0.f) + (carry ? to_f<T>(carry[idx]) : 0.f);
+    const float r = to_f<T>(r_[idx]), z = to_f<T>(z_[idx]), n = to_f<T>(n_[idx]), gn = to_f<T>(gn_[idx]);
+    const float hp = hprev ? to_f<T>(hprev[idx]) : 0.f;
+    const float dn = dh * (1.f - z) * (1.f - n * n);
+    const float dz = dh * (hp - n) * z * (1.f - z);
+    const float dr = dn * gn * r * (1.f - r);
+    dzx[o3] = from_f<T>(dr); dzx[o3 + H] = from_f<T>(dz); dzx[o3 + 2 * H] = from_f<T>(dn);
+    dg[o3] = from_f<T>(dr); dg[o3 + H] = from_f<T>(dz); dg[o3 + 2 * H] = from_f<T>(dn * r);
+    direct[idx] = from_f<T>(dh * z);
+}
 // dpr_logits[b][cat][:] = probs * (dplan - sum(probs*dplan)) + dpr_kl
 __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dplan,
                                                             const float* __restrict__ dpr_kl, int NCLS, float* __restrict__ out) {

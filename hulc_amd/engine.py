@@ -31,7 +31,7 @@ class StepEngine:
         self.flat_grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        cfg = L.HulcConfig(kind=L.KIND[dims.kind], dtype=L.DTYPE[dtype], max_batch=max_batch, max_seq=max_seq,
+        cfg = L.HulcConfig(kind=L.KIND["mcil_gru" if (dims.kind == "mcil" and dims.rnn_type == "gru") else dims.kind], dtype=L.DTYPE[dtype], max_batch=max_batch, max_seq=max_seq,
                            max_window=dims.max_window, use_clip=int(dims.use_clip), kl_beta=kl_beta,
                            kl_balancing_mix=kl_balancing_mix, dropout_p=dropout_p, num_classes=num_classes,
                            gripper_alpha=gripper_alpha, log_scale_min=log_scale_min, seed=seed)

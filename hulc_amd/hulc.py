@@ -124,6 +124,7 @@ class Hulc(torch.nn.Module):
         pr = plan_recognition
         ad = action_decoder
         self.kind = self.KIND
+        rnn_type = "nn.RNN"
         # conf/model/mcil.yaml: the same Hulc class with a BiRNN plan recognition net, a continuous plan distribution
         # and the mcil decoder options; the three go together (any other mix has no built engine path)
         mcil_flags = [_get(distribution, "dist", "discrete") == "continuous", "BiRNN" in str(_get(pr, "_target_", "Transformers")),
@@ -134,7 +135,10 @@ class Hulc(torch.nn.Module):
                                           "discrete_gripper false, no perceptual_emb_slice) are only built together (conf/model/mcil.yaml)")
             if use_clip_auxiliary_loss:
                 raise NotImplementedError("conf/model/mcil.yaml trains without the CLIP auxiliary loss (proj_vis_lang: none)")
-            chk = [(str(_get(pr, "rnn_type", "nn.RNN")), "nn.RNN"), (_get(pr, "plan_features", 256), 256), (_get(pr, "birnn_dropout_p", 0.0), 0.0),
+            rnn_type = str(_get(pr, "rnn_type", "nn.RNN"))
+            if rnn_type not in ("nn.RNN", "nn.GRU"):
+                raise NotImplementedError(f"plan_recognition.rnn_type {rnn_type!r}: nn.RNN (birnn.yaml default) and nn.GRU are built")
+            chk = [(_get(pr, "plan_features", 256), 256), (_get(pr, "birnn_dropout_p", 0.0), 0.0),
                    (_get(distribution, "plan_features", 256), 256)]
             of = _get(ad, "out_features", 7)
             if not isinstance(of, str) and int(of) != 7:
@@ -163,7 +167,8 @@ class Hulc(torch.nn.Module):
         self.lr_scheduler = lr_scheduler
         mw = _get(pr, "max_position_embeddings", 32) or 32
         max_window = 32 if isinstance(mw, str) else int(mw)      # a dangling ${...} (vision_only datasets) falls back to 32
-        self.dims = spec.ModelDims(kind=self.kind, max_window=max_window, use_clip=self.use_clip_auxiliary_loss)
+        self.dims = spec.ModelDims(kind=self.kind, max_window=max_window, use_clip=self.use_clip_auxiliary_loss,
+                                   rnn_type="gru" if (self.kind == "mcil" and rnn_type == "nn.GRU") else "rnn")
         self.precision = {"16": "bf16", "bf16": "bf16", "32": "fp32", "fp32": "fp32"}[str(precision)]
         self.dropout_p = 0.0 if self.kind == "mcil" else float(_get(pr, "dropout_p", 0.1))
         self._engine_kw = dict(max_batch=int(max_batch_size), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,

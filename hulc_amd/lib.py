@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhulc_hip.so")
 
-KIND = {"hulc": 0, "gcbc": 1, "mcil": 2}
+KIND = {"hulc": 0, "gcbc": 1, "mcil": 2, "mcil_gru": 3}
 DTYPE = {"fp32": 0, "bf16": 1}
 
 

@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct hulc_ctx hulc_ctx;
 
-enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1, HULC_KIND_MCIL = 2 };
+enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1, HULC_KIND_MCIL = 2, HULC_KIND_MCIL_GRU = 3 };   /* MCIL_GRU: conf/model/mcil.yaml with plan_recognition.rnn_type=nn.GRU */
 enum { HULC_DTYPE_F32 = 0, HULC_DTYPE_BF16 = 1 };
 
 typedef struct hulc_config {

@@ -40,12 +40,15 @@ def test_mcil_fp32_step_matches_oracle_and_reference(name):
     assert not bad, bad[:6]
     # weight_hh_l1_reverse never runs a recurrence step that reaches the output (x = output[:, -1]): exactly zero gradient
     assert not np.any(Gg["plan_recognition.birnn_model.weight_hh_l1_reverse"])
+    if dims.rnn_type == "gru":      # ... while its bias does get one (h_prev = 0, but b_hn sits inside r * (.))
+        assert np.any(Gg["plan_recognition.birnn_model.bias_hh_l1_reverse"])
     eng.close()
 
 
-def test_mcil_bf16_step_close_to_oracle():
-    dims, P, batch, fx = load_mcil_case("mcil_s12")
-    eng = _engine(dims, 3, 12, "bf16", num_classes=dims.mix_classes)
+@pytest.mark.parametrize("name,B,S", [("mcil_s12", 3, 12), ("mcil_gru_s6", 2, 6)])
+def test_mcil_bf16_step_close_to_oracle(name, B, S):
+    dims, P, batch, fx = load_mcil_case(name)
+    eng = _engine(dims, B, S, "bf16", num_classes=dims.mix_classes)
     eng.load_numpy(P)
     losses_o, G = O.training_step(P, dims, batch)
     tot, _ = run_step(eng, batch)
@@ -103,7 +106,11 @@ def test_mcil_module_from_conf_matches_reference_fixture():
     for k in ("train/kl_loss", "train/action_loss", "train/total_loss", "train/kl_loss_scaled_vis", "train/action_loss_lang"):
         assert abs(model.logged[k] - float(fx["log/" + k])) <= 1e-3 * max(1.0, abs(float(fx["log/" + k]))), k
     with pytest.raises(NotImplementedError):
-        config.instantiate(config.compose(os.path.join(root, "conf"), "config", ["model=mcil", "model.plan_recognition.rnn_type=nn.GRU"]).model, device="cuda:0")
+        config.instantiate(config.compose(os.path.join(root, "conf"), "config", ["model=mcil", "model.plan_recognition.rnn_type=nn.LSTM"]).model, device="cuda:0")
+    gm = config.instantiate(config.compose(os.path.join(root, "conf"), "config", ["model=mcil", "model.plan_recognition.rnn_type=nn.GRU", "datamodule.batch_size=2"]).model,
+                            device="cuda:0", max_seq_len=8)
+    assert gm.dims.rnn_type == "gru" and dict(gm.named_parameters())["plan_recognition.birnn_model.weight_hh_l1_reverse"].shape == (6144, 2048)
+    gm.engine.close()
     with pytest.raises(NotImplementedError):
         config.instantiate(config.compose(os.path.join(root, "conf"), "config", ["model=hulc", "model/distribution=continuous"]).model, device="cuda:0")
     model.engine.close()
