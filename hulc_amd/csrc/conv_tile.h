@@ -303,7 +303,8 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 // of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
 // x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(Conv1Src X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                            bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                            unsigned* __restrict__ maskbits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -403,11 +404,14 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf1
     while (R > 1 && lds_of(R) > (size_t)lds_kb * 1024) --R;
     const int nbands = (OH + R - 1) / R;
     R = (OH + nbands - 1) / nbands;
+    static const int occ = getenv("HULC_C1_OCC") ? atoi(getenv("HULC_C1_OCC")) : 4;      // min waves per SIMD the register allocation targets: 128 VGPRs (5 spilled) lets all 4 workgroups of a CU be resident (133 -> only 3); A/B on one box: -0.8 % of the step
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv1_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv1_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv1_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int items = Nf * nbands;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
+    if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
+    else hipLaunchKernelGGL(conv1_fwd_kernel<2>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
 }

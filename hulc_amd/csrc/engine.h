@@ -857,7 +857,7 @@ struct Engine : IEngine {
                 EpiP ep = epi(Cplan, true); ep.bias = bih0; ep.bias2 = bhh0;
                 gemm(dense<T>(plan_t, B, dec_plan), dense<T>(wih0, HID, KIN), dense_out(HID), ep, B, HID, dec_plan);
             } else
-            hipLaunchKernelGGL(plan_gather_kernel, dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0_32, KIN, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
+            hipLaunchKernelGGL((plan_gather_t_kernel<T>), dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0T, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
             { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
               gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + DE, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
             { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
@@ -1393,7 +1393,7 @@ struct Engine : IEngine {
             }
             if (hulc) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, PLAN, HID), dense_out(PLAN), ep, B, PLAN, HID); }
-                hipLaunchKernelGGL((plan_scatter_grad_kernel<T>), dim3(cdiv(HID * NCAT, 256)), dim3(256), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
+                hipLaunchKernelGGL((plan_scatter_grad_lds_kernel<T>), dim3(NCAT, cdiv(HID, 64)), dim3(64), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
             }
             if (mcil) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, dec_plan, HID), dense_out(dec_plan), ep, B, dec_plan, HID); }

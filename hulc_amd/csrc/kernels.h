@@ -892,6 +892,32 @@ __global__ void plan_gather_kernel(const float* __restrict__ w_ih /*[H][KIN] mas
     for (int c = 0; c < NCAT; ++c) s += wr[c * NCLS + idx[b * NCAT + c]];
     out[gid] = s;
 }
+// the same from the transposed compute copy WihT [KIN][H]: consecutive threads read consecutive i (coalesced), same summation order
+template <typename T>
+__global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
+                                     const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * H) return;
+    const int b = gid / H, i = gid % H;
+    float s = b1[i] + b2[i];
+    for (int c = 0; c < NCAT; ++c) s += to_f<T>(w_t[(long long)(c * NCLS + idx[b * NCAT + c]) * H + i]);
+    out[gid] = s;
+}
+// dW_ih[i][cat*NCLS + cls] += sum_{b: idx[b][cat] == cls} dC[b][i], b-ordered.  Block (cat, 64-wide i tile): the [NCLS][64] tile is
+// accumulated in LDS with coalesced dC reads, then added to dW with NCLS consecutive floats per row (128-byte segments).
+template <typename T>
+__global__ void __launch_bounds__(64) plan_scatter_grad_lds_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
+                                                                   int KIN, float* __restrict__ dw) {
+    __shared__ float tile[32][65];
+    const int c = blockIdx.x, i0 = blockIdx.y * 64, t = threadIdx.x;
+    for (int k = 0; k < 32; ++k) tile[k][t] = 0.f;
+    if (i0 + t < H)
+        for (int b = 0; b < B; ++b) tile[idx[b * NCAT + c]][t] += to_f<T>(dC[(long long)b * H + i0 + t]);
+    __syncthreads();
+    const int cls = t & 31, half = t >> 5;
+    for (int r = half; r < 64; r += 2)
+        if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] += tile[cls][r];
+}
 // dW_ih[i][cat*NCLS + idx[b][cat]] += dC[b][i]  — thread (i, cat) owns its NCLS columns: race-free, b-ordered
 template <typename T>
 __global__ void plan_scatter_grad_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H, int KIN,
