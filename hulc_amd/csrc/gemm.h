@@ -869,7 +869,10 @@ static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long l
     // With only N/16 workgroups (128 at N = 2048) half the CUs idle, so split the rows in two 32-row blocks when that fills the chip.
     int MT = M >= 64 ? 4 : (M + 15) / 16;
     if (M > 32 && (N / 16) * ((M + 63) / 64) <= 160) MT = 2;
-    if (M > 32 && M <= 64 && K == 2048 && N >= 4096) MT = 2;     // GRU recurrent step (N = 3 x 2048): 32-row blocks keep the LDS-DMA kernel eligible
+    static const bool mt2k = getenv("HULC_SKINNY_MT2K") ? atoi(getenv("HULC_SKINNY_MT2K")) != 0 : true;
+    // K = 2048 (GRU recurrent step with N = 3 x 2048; the many-row weight-gradient / small-N GEMMs over 2048 tokens): 32-row blocks keep the
+    // LDS-DMA kernel eligible (64 rows x 2048 would not fit LDS) and double the workgroup count of the small-M cases
+    if (mt2k && M > 32 && K == 2048 && NW == 8) MT = 2;
     if (NW == 8 && skinny_use_lds && launch_skinny_lds(st, A, lda, W, ldw, M, N, K, MT, om, ep)) return;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16)), block(NW * 64);
     switch (MT) {
