@@ -609,13 +609,14 @@ __global__ void dropout_apply_kernel(const float* __restrict__ src, float* __res
     if (dstt) dstt[idx] = from_f<T>(v);
 }
 
-// attention for tiny S (<=64), head_dim 16: one block (64 threads) per (b, head); qkv [B*S][3D] T, row = b*S+t
+// attention for tiny S (<= SMAX = 32 or 64), head_dim 16: one block (64 threads) per (b, head); the key loops are fully unrolled over SMAX
+// (predicated on j < S) so the per-row score arrays stay in registers; qkv [B*S][3D] T, row = b*S+t
 // P saved as fp32 [B][H][S][S] (post-softmax, pre-dropout); out ao [B*S][D] T
-template <typename T>
+template <typename T, int SMAX>
 __global__ void __launch_bounds__(64) attention_fwd_kernel(const T* __restrict__ qkv, int B, int S, int D, int NH, float* __restrict__ P,
                                                            T* __restrict__ ao, float drop_p, unsigned long long seed) {
     constexpr int HD = 16;
-    __shared__ float q[64][HD + 1], k[64][HD + 1], v[64][HD + 1];
+    __shared__ float q[SMAX][HD + 1], k[SMAX][HD + 1], v[SMAX][HD + 1];
     const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x;
     if (i < S) {
         const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
@@ -624,23 +625,27 @@ __global__ void __launch_bounds__(64) attention_fwd_kernel(const T* __restrict__
     }
     __syncthreads();
     if (i >= S) return;
-    float sc[64];
+    float sc[SMAX];
     float m = -INFINITY;
-    for (int j = 0; j < S; ++j) {
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) {
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s += q[i][d] * k[j][d];
-        sc[j] = s;
-        m = fmaxf(m, s);
+        for (int d = 0; d < HD; ++d) s += q[i][d] * k[j < S ? j : 0][d];
+        sc[j] = j < S ? s : -INFINITY;
+        m = fmaxf(m, sc[j]);
     }
     float den = 0.f;
-    for (int j = 0; j < S; ++j) { sc[j] = __expf(sc[j] - m); den += sc[j]; }
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) { sc[j] = j < S ? __expf(sc[j] - m) : 0.f; den += sc[j]; }
     const float inv = 1.f / den;
     float o[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
     float* Pr = P + (((long long)b * NH + h) * S + i) * S;
-    for (int j = 0; j < S; ++j) {
+#pragma unroll
+    for (int j = 0; j < SMAX; ++j) {
+        if (j >= S) break;
         float p = sc[j] * inv;
         Pr[j] = p;
         if (drop_p > 0.f) p = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : p / (1.f - drop_p);
@@ -652,14 +657,14 @@ __global__ void __launch_bounds__(64) attention_fwd_kernel(const T* __restrict__
     for (int d = 0; d < HD; ++d) orow[d] = from_f<T>(o[d]);
 }
 // backward: dao [B*S][D] (T) -> dqkv [B*S][3D] (T)
-template <typename T>
+template <typename T, int SMAX>
 __global__ void __launch_bounds__(64) attention_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ P, const T* __restrict__ dao,
                                                            int B, int S, int D, int NH, T* __restrict__ dqkv, float drop_p,
                                                            unsigned long long seed) {
     constexpr int HD = 16;
-    __shared__ float q[64][HD + 1], k[64][HD + 1], v[64][HD + 1], dO[64][HD + 1];
-    __shared__ float dS[64][65];    // dS[i][j]
-    __shared__ float Pd[64][65];    // dropped P[i][j] (for dV)
+    __shared__ float q[SMAX][HD + 1], k[SMAX][HD + 1], v[SMAX][HD + 1], dO[SMAX][HD + 1];
+    __shared__ float dS[SMAX][SMAX + 1];    // dS[i][j]
+    __shared__ float Pd[SMAX][SMAX + 1];    // dropped P[i][j] (for dV)
     const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x;
     if (i < S) {
         const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
@@ -674,8 +679,10 @@ __global__ void __launch_bounds__(64) attention_bwd_kernel(const T* __restrict__
     if (i < S) {
         const float* Pr = P + (((long long)b * NH + h) * S + i) * S;
         float dot = 0.f;
-        float dp[64];
-        for (int j = 0; j < S; ++j) {
+        float dp[SMAX];
+#pragma unroll
+        for (int j = 0; j < SMAX; ++j) {
+            if (j >= S) break;
             float dpj = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) dpj += dO[i][d] * v[j][d];
@@ -687,7 +694,8 @@ __global__ void __launch_bounds__(64) attention_bwd_kernel(const T* __restrict__
             dp[j] = dpj;
             dot += dpj * p;
         }
-        for (int j = 0; j < S; ++j) dS[i][j] = Pr[j] * (dp[j] - dot);
+#pragma unroll
+        for (int j = 0; j < SMAX; ++j) if (j < S) dS[i][j] = Pr[j] * (dp[j] - dot);
     }
     __syncthreads();
     if (i >= S) return;
