@@ -909,7 +909,7 @@ struct Engine : IEngine {
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
-            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)SB, rowloss, a_tcp, dheads, mcil ? 0 : 1);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
@@ -1004,7 +1004,7 @@ struct Engine : IEngine {
                 if (po) HIP_CHECK(hipMemcpyAsync(po, plan_f, sizeof(float) * B * (PLAN / 2), hipMemcpyDefault, st));
             }
             dec_fwd(pass == 0 ? pidx_pp : pidx, B, S, nullptr, nullptr);
-            hipLaunchKernelGGL((logistic_loss_kernel<T>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, acts, b->robot_obs, B, S, NMIX, NDIM,
+            hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, acts, b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, 0.f, rowloss, a_tcp, dheads, mcil ? 0 : 1);
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, valm + pass);
             const float* um = pass == 0 ? nz->u_mix_pp : nz->u_mix_pr;

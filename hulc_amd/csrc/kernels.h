@@ -1079,7 +1079,7 @@ __global__ void relative_actions_kernel(const float* __restrict__ actions_abs, c
 // one thread per (row, slot): slots 0..NDIM-1 = mixture dimension d, slot NDIM = gripper cross entropy, last slot idle;
 // row_loss is [rows][8] (summed deterministically afterwards).  Each thread recomputes the row's tcp-frame action (cheap) so the
 // 7 partial losses of a row run in parallel instead of serially in one lane.
-template <typename T>
+template <typename T, int NMIXC>      // NMIXC = n_mixtures at compile time: the per-mixture arrays stay in registers (NMIX must equal it)
 __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
                                      const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
                                      float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
@@ -1127,14 +1127,14 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
         float a = at[0];
 #pragma unroll
         for (int i = 1; i < 7; ++i) a = (d == i) ? at[i] : a;
-        float lp[16], dlogp_dmean[16], dlogp_dls[16];
+        float lp[NMIXC], dlogp_dmean[NMIXC], dlogp_dls[NMIXC];
         float mlog = -INFINITY;
-        for (int k = 0; k < NMIX; ++k) mlog = fmaxf(mlog, hr[d * NMIX + k]);
+        _Pragma("unroll") for (int k = 0; k < NMIXC; ++k) mlog = fmaxf(mlog, hr[d * NMIX + k]);
         float slog = 0.f;
-        for (int k = 0; k < NMIX; ++k) slog += __expf(hr[d * NMIX + k] - mlog);
+        _Pragma("unroll") for (int k = 0; k < NMIXC; ++k) slog += __expf(hr[d * NMIX + k] - mlog);
         const float lz = mlog + __logf(slog);
         float mx = -INFINITY;
-        for (int k = 0; k < NMIX; ++k) {
+        _Pragma("unroll") for (int k = 0; k < NMIXC; ++k) {
             const float mu = hr[NO + d * NMIX + k];
             const float lsr = hr[2 * NO + d * NMIX + k];
             const float ls = fmaxf(lsr, log_scale_min);
@@ -1154,10 +1154,10 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
             mx = fmaxf(mx, lp[k]);
         }
         float se = 0.f;
-        for (int k = 0; k < NMIX; ++k) se += __expf(lp[k] - mx);
+        _Pragma("unroll") for (int k = 0; k < NMIXC; ++k) se += __expf(lp[k] - mx);
         const float lse = mx + __logf(se);
         loss = -lse;
-        for (int k = 0; k < NMIX; ++k) {
+        _Pragma("unroll") for (int k = 0; k < NMIXC; ++k) {
             const float w = __expf(lp[k] - lse);
             const float pi = __expf(hr[d * NMIX + k] - lz);
             dr[d * NMIX + k] = from_f<T>(-(w - pi) * grad_scale);
@@ -1184,7 +1184,19 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
 __global__ void __launch_bounds__(256) sum_reduce_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
     __shared__ float red[256];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    if ((n & 3) == 0 && (reinterpret_cast<unsigned long long>(x) & 15) == 0) {      // 16-byte loads, 4 independent chains in flight
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int n4 = n >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = threadIdx.x;
+        for (; i + 768 < n4; i += 1024) {
+            const float4 a = x4[i], b = x4[i + 256], c = x4[i + 512], d = x4[i + 768];
+            s0 += (a.x + a.y) + (a.z + a.w); s1 += (b.x + b.y) + (b.z + b.w); s2 += (c.x + c.y) + (c.z + c.w); s3 += (d.x + d.y) + (d.z + d.w);
+        }
+        for (; i < n4; i += 256) { const float4 a = x4[i]; s0 += (a.x + a.y) + (a.z + a.w); }
+        s = (s0 + s1) + (s2 + s3);
+    } else
+        for (int i = threadIdx.x; i < n; i += 256) s += x[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
