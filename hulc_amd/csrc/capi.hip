@@ -187,7 +187,7 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, Conv1Src{X, nullptr, 0, 0}, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
     hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);
-    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 255) / 256), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 1023) / 1024), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
     hipError_t e = hipStreamSynchronize(st);
     hipFree(part);
     if (e != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: %s", hipGetErrorString(e)); return 1; }

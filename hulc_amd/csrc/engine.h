@@ -687,7 +687,7 @@ struct Engine : IEngine {
                 launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
             }
         }
-        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 256), (!std::is_same<T, float>::value && nsplit >= 64) ? 8 : 1), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
+        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 1024), (!std::is_same<T, float>::value && nsplit >= 64) ? 16 : 1), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }

@@ -170,28 +170,33 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ 
 // grid.y splits the slab range; each part lands with one fp32 atomicAdd (<= gridDim.y adds per element).
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsplit, long long slab, float* __restrict__ grad,
                                          int O, int I, int KH, int KW, int nhwc_fwd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // index in packed layout (coalesced slab reads)
-    const int total = O * I * KH * KW;
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // 4 consecutive elements of the packed layout (16-byte coalesced slab reads)
+    const int total = O * I * KH * KW;                              // a multiple of 4 for every conv of the model
     if (idx >= total) return;
     const int per = (nsplit + gridDim.y - 1) / gridDim.y;
     const int z0 = blockIdx.y * per, z1 = min(nsplit, z0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     int z = z0;
     for (; z + 3 < z1; z += 4) {
-        s0 += part[(long long)z * slab + idx]; s1 += part[(long long)(z + 1) * slab + idx];
-        s2 += part[(long long)(z + 2) * slab + idx]; s3 += part[(long long)(z + 3) * slab + idx];
+        const float4 a = *reinterpret_cast<const float4*>(part + (long long)z * slab + idx), b = *reinterpret_cast<const float4*>(part + (long long)(z + 1) * slab + idx);
+        const float4 c = *reinterpret_cast<const float4*>(part + (long long)(z + 2) * slab + idx), d = *reinterpret_cast<const float4*>(part + (long long)(z + 3) * slab + idx);
+        add4(s0, a); add4(s1, b); add4(s2, c); add4(s3, d);
     }
-    for (; z < z1; ++z) s0 += part[(long long)z * slab + idx];
-    int dst = idx;
-    if (nhwc_fwd) {   // packed idx = o*(KH*KW*I) + (kh*KW+kw)*I + ci  ->  torch ((o*I+ci)*KH+kh)*KW+kw
-        int ci = idx % I, t = idx / I;
-        int kw = t % KW; t /= KW;
-        int kh = t % KH, o = t / KH;
-        dst = ((o * I + ci) * KH + kh) * KW + kw;
+    for (; z < z1; ++z) add4(s0, *reinterpret_cast<const float4*>(part + (long long)z * slab + idx));
+    const float v[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int dst = idx + e;
+        if (nhwc_fwd) {   // packed idx = o*(KH*KW*I) + (kh*KW+kw)*I + ci  ->  torch ((o*I+ci)*KH+kh)*KW+kw
+            int ci = dst % I, t = dst / I;
+            int kw = t % KW; t /= KW;
+            int kh = t % KH, o = t / KH;
+            dst = ((o * I + ci) * KH + kh) * KW + kw;
+        }
+        if (gridDim.y > 1) unsafeAtomicAdd(grad + dst, v[e]);
+        else grad[dst] += v[e];
     }
-    const float s = (s0 + s1) + (s2 + s3);
-    if (gridDim.y > 1) unsafeAtomicAdd(grad + dst, s);
-    else grad[dst] += s;
 }
 
 // dst[r][perm(c)] = src[r][c] with c = ch*P + p  ->  perm(c) = p*CH + ch   (torch Flatten(C,H,W) <-> NHWC flatten)
@@ -904,11 +909,22 @@ __global__ void plan_gather_kernel(const float* __restrict__ w_ih /*[H][KIN] mas
 template <typename T>
 __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
                                      const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out) {
+    // H % blockDim == 0: a block lies within one b, so its NCAT row indices are fetched once and the NCAT weight loads are independent
+    __shared__ int sidx[64];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (blockIdx.x * blockDim.x) / H, i = gid % H;
+    if ((int)threadIdx.x < NCAT) sidx[threadIdx.x] = idx[b * NCAT + threadIdx.x];
+    __syncthreads();
     if (gid >= B * H) return;
-    const int b = gid / H, i = gid % H;
     float s = b1[i] + b2[i];
-    for (int c = 0; c < NCAT; ++c) s += to_f<T>(w_t[(long long)(c * NCLS + idx[b * NCAT + c]) * H + i]);
+    if (NCAT == 32) {
+        float w[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) w[c] = to_f<T>(w_t[(long long)(c * NCLS + sidx[c]) * H + i]);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) s += w[c];
+    } else
+        for (int c = 0; c < NCAT; ++c) s += to_f<T>(w_t[(long long)(c * NCLS + sidx[c]) * H + i]);
     out[gid] = s;
 }
 // dW_ih[i][cat*NCLS + cls] += sum_{b: idx[b][cat] == cls} dC[b][i], b-ordered.  Block (cat, 64-wide i tile): the [NCLS][64] tile is
@@ -917,10 +933,19 @@ template <typename T>
 __global__ void __launch_bounds__(64) plan_scatter_grad_lds_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
                                                                    int KIN, float* __restrict__ dw) {
     __shared__ float tile[32][65];
+    __shared__ int sidx[64];
     const int c = blockIdx.x, i0 = blockIdx.y * 64, t = threadIdx.x;
     for (int k = 0; k < 32; ++k) tile[k][t] = 0.f;
-    if (i0 + t < H)
-        for (int b = 0; b < B; ++b) tile[idx[b * NCAT + c]][t] += to_f<T>(dC[(long long)b * H + i0 + t]);
+    for (int b0 = 0; b0 < B; b0 += 64) {          // 64 windows at a time: indices once per block, the 64 dC loads of a lane issued together
+        __syncthreads();
+        sidx[t] = b0 + t < B ? idx[(b0 + t) * NCAT + c] : 0;
+        float v[64];
+#pragma unroll
+        for (int b = 0; b < 64; ++b) v[b] = (b0 + b < B && i0 + t < H) ? to_f<T>(dC[(long long)(b0 + b) * H + i0 + t]) : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 64; ++b) tile[sidx[b]][t] += v[b];
+    }
     __syncthreads();
     const int cls = t & 31, half = t >> 5;
     for (int r = half; r < 64; r += 2)
