@@ -4,7 +4,9 @@ counters are in KiB).  Writes <dir>/pmc_hbm_per_kernel.csv and <dir>/pmc_traffic
 import collections, csv, glob, json, sys
 
 d = sys.argv[1]
-CLASSES = [("rnn_step_gemm", ("skinny_lds_kernel<2, 4, 16>", "skinny_lds_kernel<2, 8>")), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
+# the recurrent step is the M=64, N=K=2048 launch of the skinny kernel: grid (128, 2) x 1024 threads (the same kernel also serves
+# many-row GEMMs with other grids; dispatches are keyed by kernel name + grid size so those stay out of the class)
+CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
            ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
            ("conv_tile_fwd", ("1, 1, false>(ConvTileP)", "2, 1, false>(ConvTileP)")), ("conv_tile_dgrad", ("true>(ConvTileP)",)), ("adam", ("adam_kernel",))]
 per = {}
@@ -15,6 +17,8 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != name:
             continue
         k = r["Kernel_Name"]
+        if "skinny_lds_kernel" in k:
+            k += f" [grid={r['Grid_Size']}]"
         agg[k][0] += float(r["Counter_Value"]); agg[k][1].add(r["Dispatch_Id"])
     per[name] = {k: (v[0], len(v[1])) for k, v in agg.items()}
 rows = []
@@ -24,12 +28,12 @@ for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
 with open(f"{d}/pmc_hbm_per_kernel.csv", "w") as fo:
     wr = csv.writer(fo); wr.writerow(["kernel", "dispatches", "FETCH_SIZE_KiB_per_dispatch", "WRITE_SIZE_KiB_per_dispatch", "hbm_bytes_per_dispatch_corrected"])
     for r in sorted(rows, key=lambda r: -r[4] * r[1]):
-        wr.writerow([r[0][:160], r[1], round(r[2], 1), round(r[3], 1), int(r[4])])
+        wr.writerow([r[0] if len(r[0]) <= 160 else r[0][:160] + (r[0][r[0].rfind(' [grid='):] if ' [grid=' in r[0] else ''), r[1], round(r[2], 1), round(r[3], 1), int(r[4])])
 traffic = {}
 for cls, pats in CLASSES:
     tot = 0.0; n = 0
     for r in rows:
-        if any(p in r[0] for p in pats):
+        if any((all(q in r[0] for q in p) if isinstance(p, tuple) else p in r[0]) for p in pats):
             tot += r[4] * r[1]; n += r[1]
     if n:
         traffic[cls] = int(tot / n)
