@@ -1014,6 +1014,19 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(logistic_sample_kernel, dim3(cdiv(SB, 64)), dim3(64), 0, st, heads, NHEAD, b->robot_obs, acts, um, ua, B, S, NMIX, NDIM,
                                cfg.log_scale_min, mcil ? 0 : 1, site_seed(42 + pass), pass == 0 ? pred_pp : pred_pr, valm + 8 + 8 * pass, mcil ? 0 : 1);
         }
+        // val/val_pred_clip_loss (hulc.py:804-808): the CLIP auxiliary loss of the lang modality on the masked rows, forward only
+        if (b->is_lang && cfg.use_clip && b->n_aux > 0) {
+            const int n = b->n_aux;
+            if (n > 64 || n > B) { hulc_set_error("clip aux rows n=%d unsupported (max 64, <= B)", n); return 1; }
+            HIP_CHECK(hipMemcpyAsync(auxrows, b->aux_rows, sizeof(int) * n, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((gather_rows_kernel<T, T>), dim3(cdiv(n * FCH, 256)), dim3(256), 0, st, seqf_t, (long long)FCH, auxrows, n, FCH, sf_m);
+            hipLaunchKernelGGL((gather_rows_kernel<T, T>), dim3(cdiv(n * GOAL, 256)), dim3(256), 0, st, goal_t, (long long)GOAL, auxrows, n, GOAL, g_m);
+            { EpiP ep = epi(im1, false); ep.relu = 1; lin_fwd(sf_m, FCH, n, cl_im0, ep, 128); }
+            { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
+            { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
+            { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
+            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, 0.f, valm + 3, dimg, dtxt, valm + 31);
+        }
         STAGE("validate");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in validate"); return 1; }
         if (plan_pp_out && hulc) HIP_CHECK(hipMemcpyAsync(plan_pp_out, pidx_pp, sizeof(int) * B * NCAT, hipMemcpyDefault, st));
@@ -1026,6 +1039,7 @@ struct Engine : IEngine {
         if (out17) {
             out17[0] = h[0]; out17[1] = h[1]; out17[2] = h[2]; out17[3] = h[14]; out17[4] = h[22];
             for (int i = 0; i < 6; ++i) { out17[5 + i] = h[8 + i]; out17[11 + i] = h[16 + i]; }
+            out17[17] = h[3];
         }
         return 0;
     }

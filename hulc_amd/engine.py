@@ -160,7 +160,12 @@ class StepEngine:
             noise["plan_idx_pp"], noise["plan_idx_pr"] = noise.get("plan_pp"), noise.get("plan_pr")
         nz = L.HulcValNoise(**{k: self._dev_or_host_ptr(noise.get(k), keep, np.int32 if (k.startswith("plan") and not mcil) else np.float32)
                                for k in ("plan_idx_pp", "plan_idx_pr", "u_mix_pp", "u_act_pp", "u_mix_pr", "u_act_pr")})
-        out = (C.c_float * 17)()
+        if is_lang and mb.get("aux_rows") is not None and len(mb["aux_rows"]) > 0:      # rows of the CLIP validation loss (hulc.py:804-808)
+            rows = np.ascontiguousarray(mb["aux_rows"], np.int32)
+            keep.append(rows)
+            b.aux_rows = rows.ctypes.data
+            b.n_aux = len(rows)
+        out = (C.c_float * 18)()
         ppp = torch.zeros(B, 256 if mcil else 32, dtype=torch.float32 if mcil else torch.int32, device=self.device)
         ppr = torch.zeros(B, 256 if mcil else 32, dtype=torch.float32 if mcil else torch.int32, device=self.device)
         pred_pp = torch.zeros(B, S, 7, device=self.device) if want_pred else None
@@ -169,7 +174,7 @@ class StepEngine:
                                        pred_pp.data_ptr() if want_pred else None, pred_pr.data_ptr() if want_pred else None))
         o = list(out)
         res = dict(action_loss_pp=o[0], action_loss_pr=o[1], kl_loss=o[2], gripper_sr_pp=o[3], gripper_sr_pr=o[4],
-                   mae_pp=np.array(o[5:11], np.float32), mae_pr=np.array(o[11:17], np.float32), sampled_plan_idx_pp=ppp, sampled_plan_idx_pr=ppr)
+                   mae_pp=np.array(o[5:11], np.float32), mae_pr=np.array(o[11:17], np.float32), sampled_plan_idx_pp=ppp, sampled_plan_idx_pr=ppr, val_pred_clip_loss=o[17])
         if mcil:
             res.update(sampled_plan_pp=ppp, sampled_plan_pr=ppr)
         if want_pred:

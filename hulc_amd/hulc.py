@@ -352,6 +352,8 @@ class Hulc(torch.nn.Module):
             self.log(f"val_pos_mae/{sc}_pos_mae_pp", float(mae_pp[:3].mean()), sync_dist=True)
             self.log(f"val_orn_mae/{sc}_orn_mae_pr", float(mae_pr[3:6].mean()), sync_dist=True)
             self.log(f"val_orn_mae/{sc}_orn_mae_pp", float(mae_pp[3:6].mean()), sync_dist=True)
+            if is_lang and self.use_clip_auxiliary_loss:
+                self.log("val/val_pred_clip_loss", r["val_pred_clip_loss"], sync_dist=True)       # hulc.py:804-808
             self.log(f"val_kl/{sc}_kl_loss", r["kl_loss"], sync_dist=True)
             self.log(f"val_act/{sc}_act_loss_pp", r["action_loss_pp"], sync_dist=True)
             self.log(f"val_act/{sc}_act_loss_pr", r["action_loss_pr"], sync_dist=True)

@@ -130,10 +130,11 @@ typedef struct hulc_val_noise {
     const float* u_mix_pr;
     const float* u_act_pr;
 } hulc_val_noise;
-/* out_host[17] = {action_loss_pp, action_loss_pr, kl_loss (beta-scaled, hulc.py:539-561), gripper_sr_pp, gripper_sr_pr,
- *                 mae_pp[6], mae_pr[6]}  (per-dimension means over B and S: everything validation_step logs, :816-833).
+/* out_host[18] = {action_loss_pp, action_loss_pr, kl_loss (beta-scaled, hulc.py:539-561), gripper_sr_pp, gripper_sr_pr,
+ *                 mae_pp[6], mae_pr[6], val_pred_clip_loss}  (per-dimension means over B and S: everything validation_step logs,
+ *                 :798-833; the CLIP loss (:804-808) only for a lang batch with use_clip and batch->n_aux > 0, else 0).
  * plan_idx_*_out (B,32) int32 and pred_*_out (B,S,7) world-frame sampled actions: optional, device or host. */
-#define HULC_N_VAL 17
+#define HULC_N_VAL 18
 int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* noise, float* out_host, int32_t* plan_idx_pp_out,
                   int32_t* plan_idx_pr_out, float* pred_pp_out, float* pred_pr_out);
 

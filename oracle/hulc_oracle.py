@@ -855,6 +855,8 @@ def validation_forward(P, dims, mb, is_lang, noise):
         mae = np.abs(pred_w[..., :-1] - mb["actions"][..., :-1]).mean(1)          # (B, 6)  hulc.py:347-350
         sr = F32((np.where(pred_w[..., -1] > 0, 1.0, -1.0) == mb["actions"][..., -1]).mean())
         out.update({f"action_loss_{tag}": loss, f"mae_{tag}": mae.astype(F32), f"gripper_sr_{tag}": sr, f"pred_{tag}": pred_w})
+    if is_lang and dims.use_clip and mb.get("use_for_aux") is not None:      # val/val_pred_clip_loss (hulc.py:804-808)
+        out["val_pred_clip_loss"] = clip_loss(P, seq_feat, goal, mb["use_for_aux"].astype(bool))[0]
     if dims.kind != "hulc":
         return out
     out["kl_loss"], _, _ = kl_loss(pp_logits, pr_logits, dims)

@@ -32,7 +32,10 @@ def test_validate_matches_reference(name, dtype, tol):
         B, S = mb["actions"].shape[:2]
         eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.1, seed=5, num_classes=dims.mix_classes)
         eng.load_numpy(P)
-        o = eng.validate(_dev(mb), "lang" in sc, noise[sc], want_pred=True)
+        d = _dev(mb)
+        if "use_for_aux" in mb:
+            d["aux_rows"] = np.nonzero(mb["use_for_aux"])[0].astype(np.int32)
+        o = eng.validate(d, "lang" in sc, noise[sc], want_pred=True)
         eng.close()
         if dims.kind == "gcbc":
             ref = float(fx[f"action_loss_pp_{sc}"])
@@ -43,6 +46,9 @@ def test_validate_matches_reference(name, dtype, tol):
         for k in ("action_loss_pp", "action_loss_pr", "kl_loss"):
             ref = float(fx[f"{k}_{sc}"])
             assert abs(o[k] - ref) <= tol * abs(ref) + 1e-6, (sc, k, o[k], ref)
+        if f"val_pred_clip_loss_{sc}" in fx.files:          # hulc.py:804-808, lang modality with the CLIP auxiliary loss
+            ref = float(fx[f"val_pred_clip_loss_{sc}"])
+            assert abs(o["val_pred_clip_loss"] - ref) <= tol * abs(ref), (sc, o["val_pred_clip_loss"], ref)
         if dims.kind == "mcil":         # continuous plans: the injected draws come back as the sampled plans
             assert np.array_equal(o["sampled_plan_pp"].cpu().numpy(), noise[sc]["plan_pp"]) and np.array_equal(o["sampled_plan_pr"].cpu().numpy(), noise[sc]["plan_pr"])
         else:

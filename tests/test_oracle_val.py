@@ -30,6 +30,8 @@ def test_validation_forward_matches_reference(name):
         for k in ("gripper_sr_pp", "gripper_sr_pr"):
             assert float(o[k]) == float(fx[f"{k}_{sc}"]), (sc, k)
         assert np.abs(o["seq_feat"] - fx[f"seq_feat_{sc}"]).max() <= 2e-5 * np.abs(fx[f"seq_feat_{sc}"]).max()
+        if f"val_pred_clip_loss_{sc}" in fx.files:
+            assert abs(float(o["val_pred_clip_loss"]) - float(fx[f"val_pred_clip_loss_{sc}"])) <= 2e-5 * abs(float(fx[f"val_pred_clip_loss_{sc}"]))
 
 
 @pytest.mark.parametrize("case", ["rollout_hulc", "rollout_mcil"])

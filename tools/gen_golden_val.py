@@ -107,6 +107,8 @@ def run_val(name, case, outdir):
             fx[f"mae_pp_{sc}"] = mae_pp.numpy()
             fx[f"mae_pr_{sc}"] = mae_pr.numpy()
             fx[f"seq_feat_{sc}"] = seq_feat.numpy()
+            if "lang" in sc and use_clip:               # hulc.py:804-808
+                fx[f"val_pred_clip_loss_{sc}"] = np.float32(model.clip_auxiliary_loss(seq_feat, goal, db["use_for_aux_lang_loss"]).item())
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
     # sanity: oracle vs reference (report only; the committed test does the check)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -120,7 +122,8 @@ def run_val(name, case, outdir):
             continue
         print(f"[{name}/{sc}] loss_pp ref {fx[f'action_loss_pp_{sc}']:.6f} oracle {o['action_loss_pp']:.6f} | kl {fx[f'kl_loss_{sc}']:.6f} {o['kl_loss']:.6f} | "
               f"mae_pp err {np.abs(o['mae_pp'] - fx[f'mae_pp_{sc}']).max():.2e} mae_pr err {np.abs(o['mae_pr'] - fx[f'mae_pr_{sc}']).max():.2e} "
-              f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f} {fx[f'gripper_sr_pr_{sc}']:.3f}/{o['gripper_sr_pr']:.3f}")
+              f"sr {fx[f'gripper_sr_pp_{sc}']:.3f}/{o['gripper_sr_pp']:.3f} {fx[f'gripper_sr_pr_{sc}']:.3f}/{o['gripper_sr_pr']:.3f}"
+              + (f" | clip {fx[f'val_pred_clip_loss_{sc}']:.6f} {float(o['val_pred_clip_loss']):.6f}" if f"val_pred_clip_loss_{sc}" in fx else ""))
 
 
 def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2, kind="hulc"):
