@@ -846,11 +846,17 @@ static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const bf16_t* 
 static inline bool launch_skinny_lds(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K, int MT,
                                      const DenseOut& om, const EpiP& ep) {
     if (K % 512 != 0 || K > 2048 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0) return false;
-    if ((size_t)MT * 16 * K * 2 > 128 * 1024 || (MT != 2 && MT != 4)) return false;
+    if ((size_t)MT * 16 * K * 2 > 128 * 1024 || (MT != 2 && MT != 4 && !(MT == 1 && K == 2048))) return false;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
     const int kq32 = K / 256;
 #define SKL(mt, kq) launch_skinny_lds_t<mt, kq>(st, grid, A, lda, W, ldw, M, N, K, om, ep)
     static const int nw16 = getenv("HULC_SKINNY_NW16") ? atoi(getenv("HULC_SKINNY_NW16")) : 1;   // A/B: -0.6 % of the step
+    if (MT == 1) {                                  // M <= 32 recurrent step (32 + 32 windows per GPU): 16-row blocks so that 2 x 128 workgroups fill the chip
+        static bool attr1 = false;
+        if (!attr1) { hipFuncSetAttribute((const void*)skinny_lds_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+        hipLaunchKernelGGL((skinny_lds_kernel<1, 4, 16>), grid, dim3(1024), (size_t)16 * 1 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep);
+        return true;
+    }
     if (nw16 && MT == 2 && kq32 == 8) {            // K = 2048 (the recurrent step): 16 waves x 4 k-steps, 4 waves per SIMD overlap DMA issue and MFMAs
         static bool attr16 = false;
         if (!attr16) { hipFuncSetAttribute((const void*)skinny_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
@@ -873,6 +879,8 @@ static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long l
     // K = 2048 (GRU recurrent step with N = 3 x 2048; the many-row weight-gradient / small-N GEMMs over 2048 tokens): 32-row blocks keep the
     // LDS-DMA kernel eligible (64 rows x 2048 would not fit LDS) and double the workgroup count of the small-M cases
     if (mt2k && M > 32 && K == 2048 && NW == 8) MT = 2;
+    static const bool mt1 = getenv("HULC_SKINNY_MT1") ? atoi(getenv("HULC_SKINNY_MT1")) != 0 : true;
+    if (mt1 && M > 16 && M <= 32 && K == 2048 && NW == 8 && (N / 16) * 2 <= 320) MT = 1;     // 16-row blocks: twice the workgroups, 128 KB instead of 192 KB each
     if (NW == 8 && skinny_use_lds && launch_skinny_lds(st, A, lda, W, ldw, M, N, K, MT, om, ep)) return;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16)), block(NW * 64);
     switch (MT) {

@@ -124,7 +124,10 @@ def test_conv_wgrad_tr(which, IH, CI, KH, S):
         assert np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(64, 2048, 2048, 82), (64, 2048, 2048, 84), (37, 256, 512, 82), (5, 32, 128, 41), (16, 1024, 4096, 81)])
+# variants 20x: the LDS-DMA kernel with MT = x row tiles per workgroup (201: the 16-row blocks of the M <= 32 recurrent step; 202 with a
+# ragged last block and many rows: the K = 2048 many-row routing)
+@pytest.mark.parametrize("M,N,K,variant", [(64, 2048, 2048, 82), (64, 2048, 2048, 84), (37, 256, 512, 82), (5, 32, 128, 41), (16, 1024, 4096, 81),
+                                           (64, 2048, 2048, 202), (32, 2048, 2048, 201), (27, 2048, 2048, 201), (500, 128, 2048, 202), (64, 6144, 2048, 202)])
 def test_skinny_gemm(M, N, K, variant):
     L, lib = _lib()
     rng = np.random.default_rng(M + N)
