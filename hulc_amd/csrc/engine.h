@@ -463,12 +463,29 @@ struct Engine : IEngine {
             TimerScope ts(this, "gemm_128x128", "mfma", fl, by);
             if constexpr (std::is_same<T, bf16_t>::value) {
                 if (gemm_use_glds && gemm_glds_ok(a, b, ep, M, N, K)) { launch_gemm_glds(st, a, b, om, ep, M, N, K); return; }
-                if (K >= 256) { launch_gemm<T, 128, 128, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K); return; }   // BK = 64: half the barriers per flop
+                if (K >= 128) { launch_gemm<T, 128, 128, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K); return; }   // BK = 64: half the barriers per flop
             }
             launch_gemm<T, 128, 128>(st, a, b, om, ep, M, N, K);
         }
-        else if (w64 >= 128 || (M <= 64 && N <= 64)) launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
-        else launch_gemm<T, 32, 32>(st, a, b, om, ep, M, N, K);
+        else {
+            // small-N / short-K GEMMs (transformer, encoder heads) are bound by the exposed L2 latency of each k-step: a deeper BK means fewer of them
+            static const int small_bk = getenv("HULC_SMALL_BK") ? atoi(getenv("HULC_SMALL_BK")) : 128;     // A/B on one box: 4.764 (32) / 4.739 (64) / 4.728 ms per step (128)
+            const bool t64 = w64 >= 128 || (M <= 64 && N <= 64);
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                if (small_bk == 128 && K >= 128) {
+                    if (t64) launch_gemm<T, 64, 64, DenseLoader<T>, DenseLoader<T>, DenseOut, 128>(st, a, b, om, ep, M, N, K);
+                    else launch_gemm<T, 32, 32, DenseLoader<T>, DenseLoader<T>, DenseOut, 128>(st, a, b, om, ep, M, N, K);
+                    return;
+                }
+                if (small_bk == 64 && K >= 64) {
+                    if (t64) launch_gemm<T, 64, 64, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K);
+                    else launch_gemm<T, 32, 32, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K);
+                    return;
+                }
+            }
+            if (t64) launch_gemm<T, 64, 64>(st, a, b, om, ep, M, N, K);
+            else launch_gemm<T, 32, 32>(st, a, b, om, ep, M, N, K);
+        }
     }
     // dW[M][N] += A[M][K] B[N][K]^T with fp32 accumulate; few output tiles + long K -> split K across workgroups (atomics)
     void gemm_wgrad(const DenseLoader<T>& a, const DenseLoader<T>& b, float* dW, long long lddw, int M, int N, int K) {
