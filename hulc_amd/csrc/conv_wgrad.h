@@ -672,6 +672,16 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
+    // the 8 dW quads this lane accumulates into are fetched NOW (single launch over M: plain read-modify-write), so their latency hides
+    // under the staging / MFMA phase instead of serialising as 8 dependent load-add-store rounds at the end
+    const bool atomic = gridDim.z > 1;
+    const int n = n0 + wave * 16 + a;
+    const bool vec_ok = !atomic && n < N && (lddw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) && k0 + TK <= K;
+    float4 oldw[8];
+    if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oldw[j] = *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4);
+    }
     for (int m0 = mbeg; m0 < mend; m0 += 64) {
         if (m0 > mbeg) __syncthreads();
         // stage dY[m0:m0+64][n0:n0+64] and X[m0:m0+64][k0:k0+128] (rows >= mend and columns past the edge -> zeros)
@@ -706,9 +716,14 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
             for (int m = 0; m < 64; ++m) bsum += bf2f(*(__attribute__((address_space(3))) bf16_t*)(yimg + m * YS + tid * 2));
         }
     }
-    const bool atomic = gridDim.z > 1;
-    const int n = n0 + wave * 16 + a;
-    if (n < N) {
+    if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 o = oldw[j];
+            o.x += acc[j][0]; o.y += acc[j][1]; o.z += acc[j][2]; o.w += acc[j][3];
+            *reinterpret_cast<float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4) = o;
+        }
+    } else if (n < N) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + j * 16 + g * 4;

@@ -948,8 +948,17 @@ __global__ void __launch_bounds__(64) plan_scatter_grad_lds_kernel(const T* __re
     }
     __syncthreads();
     const int cls = t & 31, half = t >> 5;
-    for (int r = half; r < 64; r += 2)
-        if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] += tile[cls][r];
+    float old[32];                                    // the 32 read-modify-writes of a lane: all loads first (one latency, not 32)
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int r = half + 2 * k;
+        old[k] = (i0 + r < H && cls < NCLS) ? dw[(long long)(i0 + r) * KIN + c * NCLS + cls] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int r = half + 2 * k;
+        if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] = old[k] + tile[cls][r];
+    }
 }
 // dW_ih[i][cat*NCLS + idx[b][cat]] += dC[b][i]  — thread (i, cat) owns its NCLS columns: race-free, b-ordered
 template <typename T>
