@@ -571,8 +571,18 @@ struct Engine : IEngine {
         }
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        {      // the six conv weight packs: one launch
+            ConvPackBatch d;
+            int k = 0, blk = 0;
+            for (EncW* e : {&encS, &encG})
+                for (ConvW* c : {&e->c1, &e->c2, &e->c3}) {
+                    d.w[k] = c->W32; d.wf[k] = c->Wf; d.wd[k] = c->nhwc ? c->Wd : nullptr; d.O[k] = c->O; d.I[k] = c->I; d.K[k] = c->KH; d.S[k] = c->S; d.nhwc[k] = c->nhwc;
+                    d.blk0[k] = blk; blk += cdiv(c->O * c->I * c->KH * c->KW, 256); ++k;
+                }
+            d.blk0[6] = blk;
+            hipLaunchKernelGGL((pack_conv_w_batched_kernel<T>), dim3(blk), dim3(256), 0, st, d);
+        }
         for (EncW* e : {&encS, &encG}) {
-            prep_conv(e->c1); prep_conv(e->c2); prep_conv(e->c3);
             if (e->gripper) {
                 // W7p[o][p*64+c] = W7[o][c*49+p]; then transposed copy
                 hipLaunchKernelGGL((permute_cols_kernel<float, T>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, e->fc7.W32, e->fc7.W, 128, 64, 49, 0, 0);

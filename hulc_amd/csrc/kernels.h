@@ -166,6 +166,33 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// the six conv layers of the two encoders in ONE launch (after every optimizer step): block b belongs to the conv whose block range holds it
+struct ConvPackBatch { const float* w[6]; void* wf[6]; void* wd[6]; int O[6], I[6], K[6], S[6], nhwc[6], blk0[7]; };
+template <typename T>
+__global__ void pack_conv_w_batched_kernel(ConvPackBatch d) {
+    int c = 0;
+    while (c < 5 && (int)blockIdx.x >= d.blk0[c + 1]) ++c;
+    const int idx = (blockIdx.x - d.blk0[c]) * blockDim.x + threadIdx.x;
+    const int O = d.O[c], I = d.I[c], KH = d.K[c], KW = d.K[c], S = d.S[c];
+    if (idx >= O * I * KH * KW) return;
+    int kw = idx % KW, t = idx / KW;
+    int kh = t % KH; t /= KH;
+    int ci = t % I, o = t / I;
+    const float v = d.w[c][idx];
+    T* wf = reinterpret_cast<T*>(d.wf[c]);
+    T* wd = reinterpret_cast<T*>(d.wd[c]);
+    if (wf) {
+        if (d.nhwc[c]) wf[(long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci] = from_f<T>(v);
+        else wf[idx] = from_f<T>(v);
+    }
+    if (wd) {
+        const int ph = kh % S, a = kh / S, pw = kw % S, b = kw / S;
+        const int TA = KH / S, TB = KW / S;
+        const int zc = ph * S + pw;
+        wd[((long long)zc * I + ci) * (TA * TB * O) + (a * TB + b) * O + o] = from_f<T>(v);
+    }
+}
+
 // conv wgrad partial slabs [nsplit][O][Kc] (packed K order) -> summed, un-permuted, accumulated into torch-layout grad.
 // grid.y splits the slab range; each part lands with one fp32 atomicAdd (<= gridDim.y adds per element).
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsplit, long long slab, float* __restrict__ grad,
