@@ -557,11 +557,6 @@ struct Engine : IEngine {
     }
 
     // ---------------------------------------------------------------- weight preparation
-    void prep_conv(ConvW& c) {
-        const int total = c.O * c.I * c.KH * c.KW;
-        hipLaunchKernelGGL((pack_conv_w_kernel<T>), dim3(cdiv(total, 256)), dim3(256), 0, st, c.W32, c.Wf, c.nhwc ? c.Wd : (T*)nullptr, c.O, c.I, c.KH,
-                           c.KW, c.S, c.nhwc);
-    }
     // compute-precision copies: (bf16) flat shadow cast, ONE batched launch for every transposed Linear weight, conv packs, the
     // NHWC-permuted gripper fc and the packed decoder heads
     int prepare_weights(bool shadow_fresh = false) override {

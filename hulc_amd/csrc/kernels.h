@@ -144,28 +144,6 @@ __global__ void __launch_bounds__(256) pair_transpose_kernel(TrPair pr) {
 // conv weights: torch (O, I, KH, KW) fp32 ->
 //   fwd pack  Wf[o][(kh,kw,ci)]                       (conv2/3; conv1 keeps torch's (c,kh,kw) order = plain cast)
 //   dgrad pack Wd[zc][ci][(a,b,co)] = W[co][ci][ph+S*a][pw+S*b],  zc = ph*S+pw
-template <typename T>
-__global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int O, int I, int KH,
-                                   int KW, int S, int nhwc_fwd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = O * I * KH * KW;
-    if (idx >= total) return;
-    int kw = idx % KW, t = idx / KW;
-    int kh = t % KH; t /= KH;
-    int ci = t % I, o = t / I;
-    const float v = w[idx];
-    if (wf) {
-        if (nhwc_fwd) wf[(long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci] = from_f<T>(v);
-        else wf[idx] = from_f<T>(v);
-    }
-    if (wd) {
-        const int ph = kh % S, a = kh / S, pw = kw % S, b = kw / S;
-        const int TA = KH / S, TB = KW / S;
-        const int zc = ph * S + pw;
-        wd[((long long)zc * I + ci) * (TA * TB * O) + (a * TB + b) * O + o] = from_f<T>(v);
-    }
-}
-
 // the six conv layers of the two encoders in ONE launch (after every optimizer step): block b belongs to the conv whose block range holds it
 struct ConvPackBatch { const float* w[6]; void* wf[6]; void* wd[6]; int O[6], I[6], K[6], S[6], nhwc[6], blk0[7]; };
 template <typename T>
@@ -921,18 +899,7 @@ __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restr
 // decoder glue (logistic_decoder_rnn.py:260-287 with the plan/goal terms hoisted out of the time loop)
 // =========================================================================================================
 // Cplan[b][i] = b_ih[i] + b_hh[i] + sum_cat WihT[cat*NCLS + idx[b][cat]][i]     (one-hot plan x W_ih[:, plan]^T)
-__global__ void plan_gather_kernel(const float* __restrict__ w_ih /*[H][KIN] master fp32*/, int KIN, const int* __restrict__ idx, int B,
-                                   int NCAT, int NCLS, int H, const float* __restrict__ b1, const float* __restrict__ b2,
-                                   float* __restrict__ out) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * H) return;
-    const int b = gid / H, i = gid % H;
-    float s = b1[i] + b2[i];
-    const float* wr = w_ih + (long long)i * KIN;
-    for (int c = 0; c < NCAT; ++c) s += wr[c * NCLS + idx[b * NCAT + c]];
-    out[gid] = s;
-}
-// the same from the transposed compute copy WihT [KIN][H]: consecutive threads read consecutive i (coalesced), same summation order
+// read from the transposed compute copy WihT [KIN][H]: consecutive threads read consecutive i (coalesced)
 template <typename T>
 __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
                                      const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out) {
@@ -986,16 +953,6 @@ __global__ void __launch_bounds__(64) plan_scatter_grad_lds_kernel(const T* __re
         const int r = half + 2 * k;
         if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] = old[k] + tile[cls][r];
     }
-}
-// dW_ih[i][cat*NCLS + idx[b][cat]] += dC[b][i]  — thread (i, cat) owns its NCLS columns: race-free, b-ordered
-template <typename T>
-__global__ void plan_scatter_grad_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H, int KIN,
-                                         float* __restrict__ dw) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= H * NCAT) return;
-    const int i = gid / NCAT, c = gid % NCAT;
-    float* row = dw + (long long)i * KIN + c * NCLS;
-    for (int b = 0; b < B; ++b) row[idx[b * NCAT + c]] += to_f<T>(dC[(long long)b * H + i]);
 }
 // out[r][c] = relu(x[r][c])   (act 2: tanh)
 template <typename T>
