@@ -91,8 +91,8 @@ def cpu_baseline(S, budget_s=20.0, kind="hulc", rnn_type="rnn"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)    # ~0.5 s of timed steps: one host-side stall of a few ms no longer moves the mean
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
     ap.add_argument("--seq", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--model", default="hulc", choices=["hulc", "mcil", "mcil_gru"],
                     help="hulc: the headline configuration; mcil: conf/model/mcil.yaml (BiRNN plan recognition, continuous plan, no CLIP loss); "
                          "mcil_gru: the same with plan_recognition.rnn_type=nn.GRU (BASELINE config 4)")
+    ap.add_argument("--preroll", type=int, default=300, help="untimed steps before the warm-up (≈1.5 s: clock ramp of an idle GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,6 +145,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # pre-roll (untimed, before the W warm-up steps): a GPU that has just been idle needs a few hundred ms of load before its clocks
+    # settle — the first bench process on a fresh box measured 4.89 ms/step against 4.61 for every later one with warm-up alone
+    for i in range(args.preroll):           # a fixed count, identical on every rank (the steps contain collectives)
+        step(i)
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     # survey pass (untimed): HIP events around every kernel class -> which class dominates the step

@@ -8,9 +8,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r01
 mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --preroll 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1 </dev/null
 done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1 </dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline > $O/stats.log 2>&1 </dev/null
 cd $R
 python tools/pmc_traffic.py $O > $O/pmc_traffic.log
 cp $O/pmc_traffic.json $R/profiles/r01_pmc_traffic.json

@@ -15,7 +15,7 @@ s = s[:i0] + f"""| file | what | command |
 | `r01_bench_n1_mcil.json` | `model=mcil` (BiRNN plan recognition, continuous plan; SURVEY §8 a19): {v['_mcil']['value']:.0f} windows/s, {v['_mcil']['ms_per_step']} ms/step | `python bench.py --model mcil --no-cpu-baseline` |
 | `r01_bench_n1_mcil_gru.json` | the same with `rnn_type=nn.GRU` (BASELINE config 4's GRU plan encoder): {v['_mcil_gru']['value']:.0f} windows/s, {v['_mcil_gru']['ms_per_step']} ms/step | `python bench.py --model mcil_gru --no-cpu-baseline` |
 | `r01_bench_n1_s64.json` | HULC at seq_len 64, 32 windows/GPU (BASELINE config 5's shape, bf16): {v['_s64']['value']:.0f} windows/s, {v['_s64']['ms_per_step']} ms/step | `python bench.py --seq 64 --batch 32 --no-cpu-baseline` |
-| `r01_kernel_stats.csv` | rocprofv3 per-kernel stats (9 steps: 2 warm-up + 2 survey + 5 timed) | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline` |
+| `r01_kernel_stats.csv` | rocprofv3 per-kernel stats (9 steps: 2 warm-up + 2 survey + 5 timed) | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline` |
 | `r01_kernel_stats_summary.txt` | the same, top 45 kernels, per-step | `python tools/prof_summary.py profiles/r01_kernel_stats.csv 9 45` |
 | `r01_pmc_hbm_per_kernel.csv` | FETCH_SIZE / WRITE_SIZE per dispatch per kernel (two separate `--pmc` passes; the skinny GEMM kernels are keyed by name + grid size) | `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` and `… --pmc WRITE_SIZE …`, `python tools/pmc_traffic.py <dir>` |
 | `r01_pmc_traffic.json` | per-launch HBM bytes of the big kernel classes, corrected as MI355X_MICROARCH.md §HBM prescribes: `(2 x FETCH_SIZE + WRITE_SIZE) x 1024` (gfx950 FETCH_SIZE reports half of a wide coalesced read); `bench.py` copies the dominant class's value into `roofline.traffic` | `tools/pmc_traffic.py` |
