@@ -104,6 +104,7 @@ def main():
                     help="hulc: the headline configuration; mcil: conf/model/mcil.yaml (BiRNN plan recognition, continuous plan, no CLIP loss); "
                          "mcil_gru: the same with plan_recognition.rnn_type=nn.GRU (BASELINE config 4)")
     ap.add_argument("--preroll", type=int, default=300, help="untimed steps before the warm-up (≈1.5 s: clock ramp of an idle GPU)")
+    ap.add_argument("--pair", type=int, default=1, help="with --lang 1: both modalities as ONE 2B-window pass (hulc_forward_loss_pair); 0 = one pass per modality like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,7 +123,8 @@ def main():
     use_clip = bool(args.lang) and not mcil
     dims = spec.ModelDims(kind="mcil" if mcil else args.model, max_window=max(32, S), use_clip=use_clip, rnn_type="gru" if args.model == "mcil_gru" else "rnn")
     Bmod = B // 2 if args.lang else B
-    eng = StepEngine(dims, Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
+    paired = bool(args.lang) and bool(args.pair)
+    eng = StepEngine(dims, B if paired else Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
     mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest))]
     if args.lang:
@@ -131,6 +133,14 @@ def main():
 
     def step(i):
         eng.zero_grads()
+        if paired:
+            eng.forward_loss_pair(mods[0][1], mods[1][1], 0.5, 3.0, step=i, sync_losses=False)
+            if world > 1:
+                parallel.backward_overlapped(eng)
+            else:
+                eng.backward()
+            eng.adam_step(lr=2e-4, grad_scale=1.0 / world)
+            return
         for k, (name, mb) in enumerate(mods):
             eng.forward_loss(mb, name == "lang", 1.0 / nmod, 3.0, step=i, sync_losses=False)
             if world > 1 and k == nmod - 1:
@@ -214,7 +224,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper %s frames, "
                                    "fwd+loss+bwd+%sAdam, dropout %s" % (("HULC (model=mcil: Bi%s plan recognition, continuous plan)" % ("GRU" if args.model == "mcil_gru" else "RNN")) if mcil else "HULC",
-                                                                        ("32 vis + 32 lang" + ("" if mcil else " + CLIP aux")) if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
+                                                                        ("32 vis + 32 lang" + ("" if mcil else " + CLIP aux") + (" as one paired pass" if paired else ", one pass per modality")) if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
                                                                         B, S, "uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" if args.ingest == "u8" else "fp32 NCHW",
                                                                         "RCCL all-reduce+" if world > 1 else "", "0.0" if mcil else "0.1"),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},

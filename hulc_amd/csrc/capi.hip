@@ -63,6 +63,10 @@ int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* b, float lw, float cw, fl
     if (!ctx || !b) { hulc_set_error("hulc_forward_loss: null argument"); return 1; }
     return ctx->e->forward(b, lw, cw, out, on_host);
 }
+int hulc_forward_loss_pair(hulc_ctx* ctx, const hulc_batch* v, const hulc_batch* l, float lw, float cw, float* out, int32_t on_host) {
+    if (!ctx || !v || !l) { hulc_set_error("hulc_forward_loss_pair: null argument"); return 1; }
+    return ctx->e->forward_pair(v, l, lw, cw, out, on_host);
+}
 int hulc_backward(hulc_ctx* ctx) { return ctx->e->backward(-1); }
 int hulc_backward_part(hulc_ctx* ctx, int32_t part) {
     if (part != 0 && part != 1) { hulc_set_error("hulc_backward_part: part must be 0 or 1"); return 1; }

@@ -20,6 +20,7 @@ struct IEngine {
     virtual int prepare_weights(bool shadow_fresh = false) = 0;
     virtual int zero_grads() = 0;
     virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
+    virtual int forward_pair(const hulc_batch* vis, const hulc_batch* lang, float lw, float cw, float* out8, int on_host) = 0;
     virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
     virtual int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
                          float* pred_pr_out) = 0;
@@ -174,6 +175,7 @@ struct Engine : IEngine {
 
     // =====================================================================================================
     Engine(const hulc_config& c) : cfg(c) {
+        memset(&cur2, 0, sizeof(cur2));
         mcil = cfg.kind == HULC_KIND_MCIL || cfg.kind == HULC_KIND_MCIL_GRU;
         gru = cfg.kind == HULC_KIND_MCIL_GRU;
         PLAN = mcil ? 512 : 1024; NDIM = mcil ? 7 : 6; NO = NMIX * NDIM; NHEAD = mcil ? 224 : 192; DE = mcil ? EMB : 64;
@@ -623,26 +625,37 @@ struct Engine : IEngine {
         return act_rel;
     }
     float* x32[2] = {nullptr, nullptr};       // fp32 (parity) mode + uint8 ingest: the transformed frames are materialised once per step
-    const float* conv1_f32(const Conv1Src& src, bool gripper, int Nf, int IH) {
+    const float* conv1_f32(const Conv1Src& src, bool gripper, int Nf, int IH, long long frame_off = 0) {
         if (!src.u8) return reinterpret_cast<const float*>(src.X);
         float*& buf = x32[gripper ? 1 : 0];
         if (!buf) buf = alloc<float>((int64_t)maxN * 3 * IH * IH);
         const long long n = (long long)Nf * 3 * IH * IH;
-        hipLaunchKernelGGL(ingest_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(src.X), src.shift, src.pad, Nf, IH, IH, buf);
-        return buf;
+        float* dst = buf + frame_off * 3 * IH * IH;
+        hipLaunchKernelGGL(ingest_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(src.X), src.shift, src.pad, Nf, IH, IH, dst);
+        return dst;
     }
-    void enc_fwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0) {
+    // ---- paired pass (vis + lang windows of one step as ONE 2B-window pass, hulc_forward_loss_pair): rows [0, pairBv) are the vis
+    // windows, the rest the lang windows; frames (and their shifts) stay in the two batches' own buffers, everything else is joint
+    bool pair = false; int pairBv = 0; hulc_batch cur2;
+    float *act_j = nullptr, *ro_j = nullptr, *eps_j = nullptr, *losses2 = nullptr; int* aux_j = nullptr;
+    // src2 (paired pass): frames [0, Nf/2) come from src, [Nf/2, Nf) from src2 — conv1 runs once per source, the rest on all Nf frames
+    void enc_fwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr) {
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
-        const float* x = nullptr;
-        if constexpr (std::is_same<T, bf16_t>::value) {
-            const double px = (double)Nf * g1.OH * g1.OW;
-            TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)Nf * 3 * e.IH * e.IH * (src.u8 ? 1 : 4) + px * 32 * 2);
-            launch_conv1_fwd(st, src, e.c1.Wf, e.c1.b32, a.a1, Nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits);
-        } else {
-            x = conv1_f32(src, e.gripper, Nf, e.IH);
-            Conv1Loader<T> l{x, g1};
-            EpiP ep = epi(a.a1, false); ep.bias = e.c1.b32; ep.relu = 1;
-            launch_gemm<T, 128, 32>(st, l, dense<T>(e.c1.Wf, 32, 192), dense_out(32), ep, Nf * g1.OH * g1.OW, 32, 192);
+        for (int h = 0; h < (src2 ? 2 : 1); ++h) {
+            const Conv1Src& sh = h ? *src2 : src;
+            const int nf = src2 ? Nf / 2 : Nf;
+            const long long foff = h ? Nf / 2 : 0, poff = foff * g1.OH * g1.OW;
+            ConvGeom gh = geom(nf, e.IH, 3, 8, 4);
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                const double px = (double)nf * g1.OH * g1.OW;
+                TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)nf * 3 * e.IH * e.IH * (sh.u8 ? 1 : 4) + px * 32 * 2);
+                launch_conv1_fwd(st, sh, e.c1.Wf, e.c1.b32, a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr);
+            } else {
+                const float* x = conv1_f32(sh, e.gripper, nf, e.IH, foff);
+                Conv1Loader<T> l{x, gh};
+                EpiP ep = epi(a.a1 + poff * 32, false); ep.bias = e.c1.b32; ep.relu = 1;
+                launch_gemm<T, 128, 32>(st, l, dense<T>(e.c1.Wf, 32, 192), dense_out(32), ep, nf * g1.OH * g1.OW, 32, 192);
+            }
         }
         bool tiled = false;
         if constexpr (std::is_same<T, bf16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
@@ -752,7 +765,7 @@ struct Engine : IEngine {
         O o; int zc;
         DEVI long long offset(int r, int) const { return o.offset(r, zc); }
     };
-    void enc_bwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0) {
+    void enc_bwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr) {
         wgrad_src = src;
         const float* x = nullptr;
         if constexpr (std::is_same<T, float>::value) x = src.u8 ? x32[e.gripper ? 1 : 0] : reinterpret_cast<const float*>(src.X);   // materialised by the forward
@@ -780,7 +793,15 @@ struct Engine : IEngine {
         conv_dgrad(e.c3, dact3, g3, dact2, a.a2);
         conv_wgrad(e.c2, dact2, a.a1, g2, false);
         conv_dgrad(e.c2, dact2, g2, dact1, a.a1, a.m1bits);
-        conv_wgrad(e.c1, dact1, x, g1, true);
+        if (!src2) { conv_wgrad(e.c1, dact1, x, g1, true); return; }
+        for (int h = 0; h < 2; ++h) {          // paired pass: the weight gradient of conv1 once per frame source
+            const Conv1Src& sh = h ? *src2 : src;
+            const long long foff = h ? Nf / 2 : 0;
+            wgrad_src = sh;
+            const float* xh = nullptr;
+            if constexpr (std::is_same<T, float>::value) xh = sh.u8 ? x32[e.gripper ? 1 : 0] + foff * 3 * e.IH * e.IH : reinterpret_cast<const float*>(sh.X);
+            conv_wgrad(e.c1, dact1 + foff * g1.OH * g1.OW * 32, xh, geom(Nf / 2, e.IH, 3, 8, 4), true);
+        }
     }
 
     // ---------------------------------------------------------------- MLP helper (ReLU between layers, none after last)
@@ -822,12 +843,24 @@ struct Engine : IEngine {
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         (void)dp;
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
-        enc_fwd(encS, aS, conv1_src(*b, false), N, 0);
-        STAGE("enc_static_fwd");
-        enc_fwd(encG, aG, conv1_src(*b, true), N, 64);
-        STAGE("enc_gripper_fwd");
-        // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
         {
+            const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
+            enc_fwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr);
+            STAGE("enc_static_fwd");
+            enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
+            STAGE("enc_gripper_fwd");
+        }
+        // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
+        if (pair) {       // rows [0, Bv): visual goal = emb[:, -1]; rows [Bv, B): language goal
+            const int Bv = pairBv, Bl = B - pairBv;
+            T* av[2] = {gl1, gl2};
+            T* al[2] = {gl1 + (long long)Bv * HID, gl2 + (long long)Bv * HID};
+            mlp_fwd(emb + (long long)(S - 1) * EMB, (long long)S * EMB, Bv, vg, 3, av, gl3, nullptr);
+            ln_fwd(gl3, GOAL, Bv, GOAL, ln_vg_g, ln_vg_b, goal_t, GOAL, nullptr, 0, goal_st);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(Bl * LANG, 256)), dim3(256), 0, st, b->lang, lang_t, (long long)Bl * LANG);
+            mlp_fwd(lang_t, LANG, Bl, lg, 3, al, gl3 + Bv * GOAL, nullptr);
+            ln_fwd(gl3 + Bv * GOAL, GOAL, Bl, GOAL, ln_lg_g, ln_lg_b, goal_t + Bv * GOAL, GOAL, nullptr, 0, goal_st + 2 * Bv);
+        } else {
             T* acts[2] = {gl1, gl2};
             if (b->is_lang) {
                 hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * LANG, 256)), dim3(256), 0, st, b->lang, lang_t, (long long)B * LANG);
@@ -895,6 +928,52 @@ struct Engine : IEngine {
 
     // ---------------------------------------------------------------- forward
     int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) override {
+        pair = false;
+        return forward_impl(b, lw, cw, out, on_host);
+    }
+    // vis + lang windows of one step as ONE pass over Bv + Bl windows (hulc.py:433-469 runs them one after the other): the encoders, plan
+    // networks and the decoder are shared, only the goal encoder (rows [0,Bv): visual, [Bv,B): language) and the CLIP rows differ.  The
+    // latency-bound part of the step (recurrent steps, M <= 64 GEMMs, transformer) then runs once at 2B rows instead of twice at B.
+    // Needs Bv == Bl (the per-modality means then share one gradient scale).  out: [total, kl, action, clip] of vis, then of lang.
+    std::vector<int> aux_host;
+    int* pidx_j = nullptr;
+    int forward_pair(const hulc_batch* vb, const hulc_batch* lb, float lw, float cw, float* out, int on_host) override {
+        if (!bound) { hulc_set_error("hulc_forward_loss_pair before hulc_bind_params"); return 1; }
+        if (vb->is_lang || !lb->is_lang || !lb->lang) { hulc_set_error("hulc_forward_loss_pair: first batch must be the vis modality, second the lang modality with embeddings"); return 1; }
+        if (vb->B != lb->B || vb->S != lb->S) { hulc_set_error("hulc_forward_loss_pair: both modalities need the same B and S (got %dx%d and %dx%d)", vb->B, vb->S, lb->B, lb->S); return 1; }
+        if (vb->frames_u8 != lb->frames_u8 || vb->actions_absolute != lb->actions_absolute || vb->max_rel_pos != lb->max_rel_pos || vb->max_rel_orn != lb->max_rel_orn) {
+            hulc_set_error("hulc_forward_loss_pair: both modalities must use the same ingest options"); return 1; }
+        if ((vb->plan_idx != nullptr) != (lb->plan_idx != nullptr) || (vb->plan_eps != nullptr) != (lb->plan_eps != nullptr)) {
+            hulc_set_error("hulc_forward_loss_pair: inject the plan draw for both modalities or for neither"); return 1; }
+        const int Bv = vb->B, B = 2 * Bv, S = vb->S;
+        if (B > maxB) { hulc_set_error("hulc_forward_loss_pair: %d + %d windows exceed max_batch=%d", Bv, Bv, maxB); return 1; }
+        if (!act_j) {
+            act_j = alloc<float>((int64_t)maxN * 7); ro_j = alloc<float>((int64_t)maxN * 15); eps_j = alloc<float>((int64_t)maxB * 256);
+            pidx_j = alloc<int>((int64_t)maxB * NCAT); losses2 = alloc<float>(8);
+            if (alloc_failed) { hulc_set_error("hulc_forward_loss_pair: workspace allocation failed"); return 1; }
+        }
+        const size_t na = sizeof(float) * Bv * S * 7, nr = sizeof(float) * Bv * S * 15;
+        HIP_CHECK(hipMemcpyAsync(act_j, vb->actions, na, hipMemcpyDefault, st)); HIP_CHECK(hipMemcpyAsync((char*)act_j + na, lb->actions, na, hipMemcpyDefault, st));
+        HIP_CHECK(hipMemcpyAsync(ro_j, vb->robot_obs, nr, hipMemcpyDefault, st)); HIP_CHECK(hipMemcpyAsync((char*)ro_j + nr, lb->robot_obs, nr, hipMemcpyDefault, st));
+        hulc_batch jb = *vb;
+        jb.B = B; jb.actions = act_j; jb.robot_obs = ro_j; jb.lang = lb->lang; jb.is_lang = 0;
+        if (vb->plan_idx) {
+            HIP_CHECK(hipMemcpyAsync(pidx_j, vb->plan_idx, sizeof(int) * Bv * NCAT, hipMemcpyDefault, st));
+            HIP_CHECK(hipMemcpyAsync(pidx_j + Bv * NCAT, lb->plan_idx, sizeof(int) * Bv * NCAT, hipMemcpyDefault, st));
+            jb.plan_idx = pidx_j;
+        }
+        if (vb->plan_eps) {
+            const size_t ne = sizeof(float) * Bv * (PLAN / 2);
+            HIP_CHECK(hipMemcpyAsync(eps_j, vb->plan_eps, ne, hipMemcpyDefault, st)); HIP_CHECK(hipMemcpyAsync((char*)eps_j + ne, lb->plan_eps, ne, hipMemcpyDefault, st));
+            jb.plan_eps = eps_j;
+        }
+        aux_host.assign(lb->aux_rows ? lb->aux_rows : nullptr, lb->aux_rows ? lb->aux_rows + lb->n_aux : nullptr);
+        for (int& r : aux_host) r += Bv;
+        jb.aux_rows = aux_host.data(); jb.n_aux = lb->aux_rows ? lb->n_aux : 0;
+        pair = true; pairBv = Bv; cur2 = *lb;
+        return forward_impl(&jb, lw, cw, out, on_host);
+    }
+    int forward_impl(const hulc_batch* b, float lw, float cw, float* out, int on_host) {
         if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
@@ -906,39 +985,44 @@ struct Engine : IEngine {
         const int B = b->B, S = b->S, N = B * S, SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         const float dp = cfg.dropout_p;
+        const int Bm = pair ? pairBv : B;                    // windows per modality: the reference's means (and so the gradient scales) are per modality
         HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
+        if (pair) HIP_CHECK(hipMemsetAsync(losses2, 0, 8 * sizeof(float), st));
         trunk_fwd(b, dp);
         if (mcil) {
             if (gru) bigru_fwd(B, S); else birnn_fwd(B, S);
             const int n = PLAN / 2;
             const float* eps = nullptr;
             if (b->plan_eps) { HIP_CHECK(hipMemcpyAsync(plan_eps_in, b->plan_eps, sizeof(float) * B * n, hipMemcpyDefault, st)); eps = plan_eps_in; }
-            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / B, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / B;
+            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL((normal_kl_sample_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, pr_logits, pp_logits, B, n, eps, plan_eps, plan_f, plan_t, klel,
                                dpp_kl, dpr_kl, wpp, wpr, site_seed(20));
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, B * n, cfg.kl_beta / B, losses + 1);
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, Bm * n, cfg.kl_beta / Bm, losses + 1);
+            if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel + (long long)Bm * n, Bm * n, cfg.kl_beta / Bm, losses2 + 1);
         } else pr_fwd(B, S, dp);
         // ---- sample + KL (hulc.py:289-296, 539-561)
         if (hulc) {
             const int* idx_in = nullptr;
             if (b->plan_idx) { HIP_CHECK(hipMemcpyAsync(pidx_in, b->plan_idx, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); idx_in = pidx_in; }
-            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / B, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / B;
+            const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, idx_in, pidx, probs, klcat, dpp_kl,
                                dpr_kl, wpp, wpr, site_seed(20));
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, B * NCAT, cfg.kl_beta / B, losses + 1);
+            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, Bm * NCAT, cfg.kl_beta / Bm, losses + 1);
+            if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat + Bm * NCAT, Bm * NCAT, cfg.kl_beta / Bm, losses2 + 1);
         }
         // ---- action decoder (logistic_decoder_rnn.py:260-287): plan/goal terms hoisted out of the time loop
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
             hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
-                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)SB, rowloss, a_tcp, dheads, mcil ? 0 : 1);
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1);
+            if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);
+            else hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
         STAGE("decoder_fwd");
         // ---- CLIP auxiliary loss (hulc.py:650-695), lang modality, masked rows
         clip_n = 0;
-        if (b->is_lang && cfg.use_clip && b->n_aux > 0) {
+        if ((b->is_lang || pair) && cfg.use_clip && b->n_aux > 0) {
             const int n = b->n_aux;
             if (n > 64 || n > B) { hulc_set_error("clip aux rows n=%d unsupported (max 64, <= B)", n); return 1; }
             clip_n = n;
@@ -949,7 +1033,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
             { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
             { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
-            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, losses + 2, dimg, dtxt, dlogit_scale);
+            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale);
         }
         STAGE("clip_fwd");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in forward"); return 1; }
@@ -957,8 +1041,11 @@ struct Engine : IEngine {
         if (out) {
             // [total_mod, kl, action, clip]
             hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses);
-            if (on_host) { HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st)); }
-            else HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (pair) hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses2);
+            const hipMemcpyKind kind = on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+            HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), kind, st));
+            if (pair) HIP_CHECK(hipMemcpyAsync(out + 4, losses2 + 4, 4 * sizeof(float), kind, st));
+            if (on_host) HIP_CHECK(hipStreamSynchronize(st));
         }
         return 0;
     }
@@ -999,7 +1086,7 @@ struct Engine : IEngine {
         if (alloc_failed) { hulc_set_error("hulc_validate: workspace allocation failed"); return 1; }
         static const hulc_val_noise none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (!nz) nz = &none;
-        cur = *b; have_fwd = false;
+        cur = *b; have_fwd = false; pair = false;
         const int B = b->B, S = b->S, SB = S * B;
         HIP_CHECK(hipMemsetAsync(valm, 0, 32 * sizeof(float), st));
         trunk_fwd(b, 0.f);
@@ -1090,7 +1177,7 @@ struct Engine : IEngine {
         if (maxS < 2 && !goal_lang) { hulc_set_error("hulc_rollout_plan: a visual goal needs max_seq >= 2 (obs + goal frame form one window, hulc.py:917-919)"); return 1; }
         roll_alloc();
         if (alloc_failed) { hulc_set_error("hulc_rollout_plan: workspace allocation failed"); return 1; }
-        have_fwd = false;
+        have_fwd = false; pair = false;
         hulc_batch bb; memset(&bb, 0, sizeof(bb));
         bb.B = 1; bb.step = roll_counter;
         if (goal_lang) {
@@ -1495,7 +1582,16 @@ struct Engine : IEngine {
         }
         STAGE("plan_recognition_bwd");
         // ---- goal encoder backward
-        {
+        if (pair) {
+            const int Bv = pairBv, Bl = B - pairBv;
+            T* av[2] = {gl1, gl2};
+            T* al[2] = {gl1 + (long long)Bv * HID, gl2 + (long long)Bv * HID};
+            ln_bwd(dgoal, GOAL, gl3, GOAL, goal_st, ln_vg_g, Bv, GOAL, nullptr, 0, 0, dgl3_t, GOAL, d_ln_vg_g, d_ln_vg_b);
+            DenseOut om = dense_out((long long)S * EMB);
+            mlp_bwd(dgl3_t, emb + (long long)(S - 1) * EMB, (long long)S * EMB, Bv, vg, 3, av, dt_a, dt_a + (long long)B * HID, demb + (long long)(S - 1) * EMB, &om, 1);
+            ln_bwd(dgoal + Bv * GOAL, GOAL, gl3 + Bv * GOAL, GOAL, goal_st + 2 * Bv, ln_lg_g, Bl, GOAL, nullptr, 0, 0, dgl3_t + Bv * GOAL, GOAL, d_ln_lg_g, d_ln_lg_b);
+            mlp_bwd(dgl3_t + Bv * GOAL, lang_t, LANG, Bl, lg, 3, al, dt_a, dt_a + (long long)B * HID, nullptr, nullptr, 0);
+        } else {
             T* acts[2] = {gl1, gl2};
             if (b->is_lang) {
                 ln_bwd(dgoal, GOAL, gl3, GOAL, goal_st, ln_lg_g, B, GOAL, nullptr, 0, 0, dgl3_t, GOAL, d_ln_lg_g, d_ln_lg_b);
@@ -1515,10 +1611,13 @@ struct Engine : IEngine {
         }
     encoders:
         // ---- encoders backward
-        enc_bwd(encS, aS, conv1_src(*b, false), N, 0);
-        STAGE("enc_static_bwd");
-        enc_bwd(encG, aG, conv1_src(*b, true), N, 64);
-        STAGE("enc_gripper_bwd");
+        {
+            const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
+            enc_bwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr);
+            STAGE("enc_static_bwd");
+            enc_bwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
+            STAGE("enc_gripper_bwd");
+        }
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;
         bwd_stage = 0;

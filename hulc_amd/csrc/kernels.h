@@ -1224,6 +1224,24 @@ __global__ void __launch_bounds__(256) sum_reduce_kernel(const float* __restrict
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// paired pass: the per-row loss partials [S*B][8] (time-major rows t*B + b) summed separately for the windows b < Bv and b >= Bv
+__global__ void __launch_bounds__(256) sum_rows_pair_kernel(const float* __restrict__ x, int rows, int B, int Bv, float scale, float* __restrict__ out_v,
+                                                            float* __restrict__ out_l) {
+    __shared__ float red[2][256];
+    float sv = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < rows * 8; i += 256) {
+        const float v = x[i];
+        if ((i >> 3) % B < Bv) sv += v; else sl += v;
+    }
+    red[0][threadIdx.x] = sv; red[1][threadIdx.x] = sl;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_v[0] = red[0][0] * scale; out_l[0] = red[1][0] * scale; }
+}
+
 // =========================================================================================================
 // CLIP-style auxiliary loss (hulc.py:679-695) on n <= 64 rows of 32-d projections; single block of 64 threads
 // writes loss, d img, d txt (already times `w`), d logit_scale (accumulated)

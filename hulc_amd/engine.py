@@ -93,12 +93,8 @@ class StepEngine:
                 f[k] = ptr(mb[k].to(torch.int32))
         return f
 
-    def forward_loss(self, mb: Dict, is_lang: bool, loss_weight: float, clip_weight: float, step: int = 0,
-                     sync_losses: bool = True):
-        """mb: device tensors rgb_static (B,S,3,200,200) f32, rgb_gripper, actions, robot_obs(15), [lang], [plan_idx int32],
-        [aux_rows: host int32 numpy]."""
+    def _batch_struct(self, mb: Dict, is_lang: bool, step: int, keep: list):
         B, S = mb["actions"].shape[:2]
-        keep = []
 
         def ptr(t):
             t = t.contiguous()
@@ -116,6 +112,31 @@ class StepEngine:
             keep.append(rows)
             b.aux_rows = rows.ctypes.data
             b.n_aux = len(rows)
+        return b
+
+    def forward_loss_pair(self, mb_vis: Dict, mb_lang: Dict, loss_weight: float, clip_weight: float, step: int = 0, sync_losses: bool = True):
+        """Both modalities of a step as ONE pass over 2B windows (hulc_forward_loss_pair; needs equal B and S).  Returns the two loss
+        dicts (vis, lang), or the (8,) device tensor [vis x4, lang x4] with sync_losses=False.  One backward() follows for the pair."""
+        keep = []
+        bv = self._batch_struct(mb_vis, False, step, keep)
+        bl = self._batch_struct(mb_lang, True, step, keep)
+        self._keep = keep
+        if sync_losses:
+            out = (C.c_float * 8)()
+            L.check(self.lib.hulc_forward_loss_pair(self.ctx, C.byref(bv), C.byref(bl), loss_weight, clip_weight, out, 1))
+            return (dict(total_mod=out[0], kl=out[1], action=out[2], clip=out[3]), dict(total_mod=out[4], kl=out[5], action=out[6], clip=out[7]))
+        if not hasattr(self, "_loss_dev8"):
+            self._loss_dev8 = torch.zeros(8, dtype=torch.float32, device=self.device)
+        L.check(self.lib.hulc_forward_loss_pair(self.ctx, C.byref(bv), C.byref(bl), loss_weight, clip_weight, self._loss_dev8.data_ptr(), 0))
+        self._loss_dev = self._loss_dev8[4:]
+        return self._loss_dev8
+
+    def forward_loss(self, mb: Dict, is_lang: bool, loss_weight: float, clip_weight: float, step: int = 0,
+                     sync_losses: bool = True):
+        """mb: device tensors rgb_static (B,S,3,200,200) f32, rgb_gripper, actions, robot_obs(15), [lang], [plan_idx int32],
+        [aux_rows: host int32 numpy]."""
+        keep = []
+        b = self._batch_struct(mb, is_lang, step, keep)
         self._keep = keep
         if sync_losses:
             out = (C.c_float * 4)()

@@ -16,6 +16,7 @@ There is no torch/CPU fallback: constructing the module without the HIP library 
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Dict, Iterator, Optional, Tuple
 
 import numpy as np
@@ -171,7 +172,8 @@ class Hulc(torch.nn.Module):
                                    rnn_type="gru" if (self.kind == "mcil" and rnn_type == "nn.GRU") else "rnn")
         self.precision = {"16": "bf16", "bf16": "bf16", "32": "fp32", "fp32": "fp32"}[str(precision)]
         self.dropout_p = 0.0 if self.kind == "mcil" else float(_get(pr, "dropout_p", 0.1))
-        self._engine_kw = dict(max_batch=int(max_batch_size), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,
+        self.pair_modalities = os.environ.get("HULC_PAIR", "1") != "0"      # vis + lang of a step as one paired pass (see training_step)
+        self._engine_kw = dict(max_batch=int(max_batch_size) * (2 if self.pair_modalities else 1), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,
                                kl_beta=self.kl_beta, kl_balancing_mix=self.kl_balancing_mix,
                                num_classes=int(_get(ad, "num_classes", 256 if self.kind == "mcil" else 10)), gripper_alpha=float(_get(ad, "gripper_alpha", 1.0)),
                                log_scale_min=float(_get(ad, "log_scale_min", -7.0)), seed=int(seed))
@@ -298,15 +300,32 @@ class Hulc(torch.nn.Module):
         kl = act = tot = clip = 0.0
         total_bs = 0
         bs: Dict[str, int] = {}
-        for imod, (self.modality_scope, dataset_batch) in enumerate(batch.items()):
-            is_lang = "lang" in self.modality_scope
-            mb = self._modality_batch(dataset_batch, is_lang, eng.device)
-            l = eng.forward_loss(mb, is_lang, 1.0 / nmod, self.clip_auxiliary_loss_beta, step=self.global_step)
-            if imod == nmod - 1 and parallel.world_size() > 1:
-                parallel.backward_overlapped(eng)          # RCCL all-reduce of the finished 98 % under the encoder backward
+        scopes = list(batch)
+        # the reference's usual batch {"vis": ..., "lang": ...} with equal window counts runs as ONE paired pass (hulc_forward_loss_pair):
+        # same losses and gradients as one pass per modality, the latency-bound part of the step only once
+        paired = None
+        if (self.pair_modalities and nmod == 2 and "lang" not in scopes[0] and "lang" in scopes[1]
+                and batch[scopes[0]]["actions"].shape[:2] == batch[scopes[1]]["actions"].shape[:2]
+                and 2 * batch[scopes[0]]["actions"].shape[0] <= self._engine_kw["max_batch"]):
+            mbs = [self._modality_batch(batch[sc], "lang" in sc, eng.device) for sc in scopes]
+            paired = eng.forward_loss_pair(mbs[0], mbs[1], 0.5, self.clip_auxiliary_loss_beta, step=self.global_step)
+            if parallel.world_size() > 1:
+                parallel.backward_overlapped(eng)
                 self._grads_reduced = True
             else:
                 eng.backward()
+        for imod, (self.modality_scope, dataset_batch) in enumerate(batch.items()):
+            is_lang = "lang" in self.modality_scope
+            if paired is not None:
+                mb, l = mbs[imod], paired[imod]
+            else:
+                mb = self._modality_batch(dataset_batch, is_lang, eng.device)
+                l = eng.forward_loss(mb, is_lang, 1.0 / nmod, self.clip_auxiliary_loss_beta, step=self.global_step)
+                if imod == nmod - 1 and parallel.world_size() > 1:
+                    parallel.backward_overlapped(eng)          # RCCL all-reduce of the finished 98 % under the encoder backward
+                    self._grads_reduced = True
+                else:
+                    eng.backward()
             b = mb["actions"].shape[0]
             bs[self.modality_scope] = b
             total_bs += b

@@ -42,7 +42,7 @@ class HulcSbertConfig(C.Structure):
 
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
-           "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_backward", "hulc_backward_part",
+           "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_forward_loss_pair", "hulc_backward", "hulc_backward_part",
            "hulc_adam_step", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny"]
 
 _lib = None
@@ -71,6 +71,7 @@ def load():
     lib.hulc_prepare_weights.argtypes = [C.c_void_p]
     lib.hulc_zero_grads.argtypes = [C.c_void_p]
     lib.hulc_forward_loss.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
+    lib.hulc_forward_loss_pair.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
     lib.hulc_backward.argtypes = [C.c_void_p]
     lib.hulc_backward_part.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]

@@ -104,6 +104,14 @@ int hulc_zero_grads(hulc_ctx* ctx);
  * clip_weight = clip_auxiliary_loss_beta (hulc.py:525) — used to scale the gradients in hulc_backward. */
 int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* batch, float loss_weight, float clip_weight, float* out_losses,
                       int32_t losses_on_host);
+/* Both modalities of one step (Hulc.training_step iterates 'vis' then 'lang', hulc.py:433-469) as ONE pass over vis->B + lang->B windows:
+ * the perceptual encoders, plan networks and the action decoder are shared, only the goal encoder and the CLIP rows differ, so the
+ * latency-bound part of the step runs once at twice the batch instead of twice.  Requires vis->B == lang->B, equal S and ingest options;
+ * loss_weight is the per-modality weight (1/2).  out_losses[8] = [total_mod, kl_scaled, action, clip] of vis, then of lang.  The result
+ * (losses and accumulated gradients) equals hulc_forward_loss + hulc_backward on vis followed by the same on lang, up to summation
+ * order; hulc_backward / hulc_backward_part then run once for the pair. */
+int hulc_forward_loss_pair(hulc_ctx* ctx, const hulc_batch* vis, const hulc_batch* lang, float loss_weight, float clip_weight, float* out_losses,
+                           int32_t losses_on_host);
 /* Backward of the last hulc_forward_loss; ACCUMULATES into the bound gradient buffer. */
 int hulc_backward(hulc_ctx* ctx);
 /* The same in two halves, so the host can start the gradient all-reduce of the 98 % of the parameters that are finished first:

@@ -220,3 +220,49 @@ def test_backward_in_two_parts_equals_whole():
     names_enc = [n for n, (off, _) in eng.layout.items() if off < n_enc]
     assert names_enc and all(n.startswith("perceptual_encoder.") for n in names_enc)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["hulc_tiny", "gcbc_s16", "mcil_s6"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_paired_pass_equals_two_modality_passes(name, dtype):
+    """hulc_forward_loss_pair (vis + lang windows as ONE 2B-window pass) == the reference's order, one pass per modality: per-modality
+    losses, every gradient tensor, and the reference fixture's total loss."""
+    if name.startswith("mcil"):
+        from golden_util import load_mcil_case
+        dims, P, batch, fx = load_mcil_case(name)
+    else:
+        dims, P, batch, fx = load_case(name)
+    if set(batch) != {"vis", "lang"} or batch["vis"]["actions"].shape[0] != batch["lang"]["actions"].shape[0]:
+        pytest.skip("needs both modalities with the same number of windows")
+    B, S = batch["vis"]["actions"].shape[:2]
+    kw = dict(num_classes=dims.mix_classes)
+    eng = _engine(dims, B, S, dtype, **kw)
+    eng.load_numpy(P)
+    tot, per = run_step(eng, batch)
+    g_seq = eng.flat_grads.clone()
+    eng.close()
+    eng = _engine(dims, 2 * B, S, dtype, **kw)
+    eng.load_numpy(P)
+    eng.zero_grads()
+    lv, ll = eng.forward_loss_pair(to_dev(batch["vis"]), to_dev(batch["lang"]), 0.5, 3.0, step=0)
+    eng.backward()
+    torch.cuda.synchronize()
+    tol = 2e-6 if dtype == "fp32" else 2e-3
+    for got, sc in ((lv, "vis"), (ll, "lang")):
+        for k in ("total_mod", "kl", "action", "clip"):
+            assert abs(got[k] - per[sc][k]) <= tol * max(1.0, abs(per[sc][k])), (sc, k, got[k], per[sc][k])
+    tot_pair = (lv["total_mod"] + ll["total_mod"]) / 2 + (3.0 * ll["clip"] if dims.use_clip else 0.0)
+    ref = float(fx["loss_total"])
+    assert abs(tot_pair - ref) <= (1e-3 if dtype == "fp32" else 5e-3) * abs(ref)
+    g_pair = eng.flat_grads
+    if dtype == "fp32":
+        views_a, views_b = eng.views(g_seq), eng.views(g_pair)
+        worst = max(rel_l2(views_b[n].cpu().numpy(), views_a[n].cpu().numpy()) for n in views_a if float(views_a[n].abs().max()) > 1e-7)
+        assert worst < 2e-5, worst
+    else:
+        cos = float((g_seq.double() @ g_pair.double()) / (g_seq.double().norm() * g_pair.double().norm()))
+        assert cos > 0.999, cos
+    # the pair is followed by ONE backward; a second one has nothing to run on
+    with pytest.raises(RuntimeError):
+        eng.backward()
+    eng.close()
