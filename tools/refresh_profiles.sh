@@ -19,6 +19,7 @@ test -n "$f" && cp $f $O/kernel_stats.csv && python tools/prof_summary.py $O/ker
 timeout 600 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err </dev/null
 timeout 300 python $R/bench.py --ingest u8 --no-cpu-baseline > $O/bench_n1_u8.json 2>/dev/null </dev/null
 timeout 300 python $R/bench.py --lang 1 --no-cpu-baseline > $O/bench_n1_vislang.json 2>/dev/null </dev/null
+timeout 300 python $R/bench.py --lang 1 --pair 0 --no-cpu-baseline > $O/bench_n1_vislang_seq.json 2>/dev/null </dev/null
 timeout 300 python $R/bench.py --model mcil --no-cpu-baseline > $O/bench_n1_mcil.json 2>/dev/null </dev/null
 timeout 300 python $R/bench.py --model mcil_gru --no-cpu-baseline > $O/bench_n1_mcil_gru.json 2>/dev/null </dev/null
 timeout 300 python $R/bench.py --seq 64 --batch 32 --no-cpu-baseline > $O/bench_n1_s64.json 2>/dev/null </dev/null

@@ -4,14 +4,15 @@ import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda f: os.path.join(ROOT, "profiles", f)
 d = json.load(open(P("r01_bench_n1.json"))); t = json.load(open(P("r01_pmc_traffic.json")))
-v = {k: json.load(open(P(f"r01_bench_n1{k}.json"))) for k in ("_u8", "_vislang", "_mcil", "_mcil_gru", "_s64")}
+v = {k: json.load(open(P(f"r01_bench_n1{k}.json"))) for k in ("_u8", "_vislang", "_vislang_seq", "_mcil", "_mcil_gru", "_s64")}
 s = open(P("README.md")).read()
 i0 = s.index("| file | what | command |"); i1 = s.index("## Dominant kernel (round 1)")
 s = s[:i0] + f"""| file | what | command |
 |---|---|---|
 | `r01_bench_n1.json` | the bench line (N=1): **{d['value']:.0f} windows/s, {d['ms_per_step']} ms/step**, roofline + cpu_baseline objects | `python bench.py` |
 | `r01_bench_n1_u8.json` | same step fed uint8 (B,S,H,W,C) frames, transforms fused into conv1 (SURVEY §8(f) row 1): {v['_u8']['value']:.0f} windows/s | `python bench.py --ingest u8 --no-cpu-baseline` |
-| `r01_bench_n1_vislang.json` | 32 vis + 32 lang windows + CLIP auxiliary loss (BASELINE config 3 per GPU): {v['_vislang']['value']:.0f} windows/s, {v['_vislang']['ms_per_step']} ms/step | `python bench.py --lang 1 --no-cpu-baseline` |
+| `r01_bench_n1_vislang.json` | 32 vis + 32 lang windows + CLIP auxiliary loss (BASELINE config 3 per GPU) as one paired pass (`hulc_forward_loss_pair`): {v['_vislang']['value']:.0f} windows/s, {v['_vislang']['ms_per_step']} ms/step | `python bench.py --lang 1 --no-cpu-baseline` |
+| `r01_bench_n1_vislang_seq.json` | the same with one pass per modality, the reference's order: {v['_vislang_seq']['value']:.0f} windows/s, {v['_vislang_seq']['ms_per_step']} ms/step | `python bench.py --lang 1 --pair 0 --no-cpu-baseline` |
 | `r01_bench_n1_mcil.json` | `model=mcil` (BiRNN plan recognition, continuous plan; SURVEY §8 a19): {v['_mcil']['value']:.0f} windows/s, {v['_mcil']['ms_per_step']} ms/step | `python bench.py --model mcil --no-cpu-baseline` |
 | `r01_bench_n1_mcil_gru.json` | the same with `rnn_type=nn.GRU` (BASELINE config 4's GRU plan encoder): {v['_mcil_gru']['value']:.0f} windows/s, {v['_mcil_gru']['ms_per_step']} ms/step | `python bench.py --model mcil_gru --no-cpu-baseline` |
 | `r01_bench_n1_s64.json` | HULC at seq_len 64, 32 windows/GPU (BASELINE config 5's shape, bf16): {v['_s64']['value']:.0f} windows/s, {v['_s64']['ms_per_step']} ms/step | `python bench.py --seq 64 --batch 32 --no-cpu-baseline` |
