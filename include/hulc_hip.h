@@ -15,6 +15,7 @@
  *                         + LogisticDecoderRNN.loss               decoders/logistic_decoder_rnn.py:121-134
  *                         + Hulc.compute_kl_loss                  hulc/models/hulc.py:539-561
  *                         + Hulc.clip_auxiliary_loss              hulc/models/hulc.py:650-695
+ *   hulc_forward_loss_pair <- the same for the 'vis' and the 'lang' modality of one step in a single pass (hulc.py:433-469 loops over them)
  *   hulc_backward      <- autograd backward of the above (Lightning: loss.backward())
  *   hulc_adam_step     <- torch.optim.Adam.step                   hulc/models/hulc.py:239-252, conf/model/optimizer/adam.yaml
  *   hulc_zero_grads    <- optimizer.zero_grad()
