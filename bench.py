@@ -95,7 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
     ap.add_argument("--seq", type=int, default=32)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16: the headline (BASELINE configs[1]); fp16: the reference's `precision: 16` with the on-device dynamic loss scaler (config 5)")
     ap.add_argument("--lang", type=int, default=0, help="1: 32 vis + 32 lang per GPU with CLIP aux loss (config 3)")
     ap.add_argument("--ingest", default="fp32", choices=["fp32", "u8"],
                     help="fp32: the reference's boundary (transformed fp32 NCHW frames, the headline); u8: uint8 HWC dataset frames, "
@@ -171,6 +172,7 @@ def main():
     dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0] if survey else ""
     # timed region: events only around the dominant class (on the engine's stream), so the timers do not perturb the step
     eng.timers_enable(True, dominant)
+    sc0 = eng.scaler_state() if args.dtype == "fp16" else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -196,7 +198,7 @@ def main():
         name, t = max(tm.items(), key=lambda kv: kv[1]["ms"])
         sec = t["ms"] * 1e-3
         if t["bound"] == "mfma":
-            ach, peak, unit = t["flops"] / sec / 1e12, MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3, "TFLOP/s"
+            ach, peak, unit = t["flops"] / sec / 1e12, MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "fp16") else 157.3, "TFLOP/s"
         else:
             ach, peak, unit = t["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         traffic = None
@@ -233,6 +235,8 @@ def main():
             "step_tflops": None if mcil else round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
             "roofline": rl,
             "kernel_classes": kernel_classes,
+            # fp16: GradScaler state after the timed steps; skipped_in_timed_region counts optimizer steps the scaler skipped (inf/nan) inside it
+            "loss_scaler": None if sc0 is None else dict(eng.scaler_state(), skipped_in_timed_region=eng.scaler_state()["skipped_steps"] - sc0["skipped_steps"]),
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(S, kind=dims.kind, rnn_type=dims.rnn_type),
         }
         print(json.dumps(out))

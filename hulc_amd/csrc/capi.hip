@@ -10,6 +10,8 @@
 #include "engine.h"
 #include "sbert.h"
 
+using namespace hulc_bf16;      // this translation unit: fp32 (parity) + bf16 engines and the per-kernel test entry points; fp16: engine_f16.hip
+
 static thread_local char g_err[1024] = "";
 void hulc_set_error(const char* fmt, ...) {
     va_list ap;
@@ -35,9 +37,9 @@ int hulc_ctx_create(const hulc_config* cfg, hulc_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hulc_set_error("hulc_ctx_create: no HIP device visible"); return 1; }
     hulc_ctx* c = new hulc_ctx();
-    int rc;
-    if (cfg->dtype == HULC_DTYPE_F32) { auto* e = new Engine<float>(*cfg); rc = e->alloc_all(); c->e = e; }
-    else if (cfg->dtype == HULC_DTYPE_BF16) { auto* e = new Engine<bf16_t>(*cfg); rc = e->alloc_all(); c->e = e; }
+    int rc = 1;
+    if (cfg->dtype == HULC_DTYPE_F32 || cfg->dtype == HULC_DTYPE_BF16) c->e = hulc_bf16::make_engine(*cfg, &rc);
+    else if (cfg->dtype == HULC_DTYPE_F16) c->e = hulc_f16::make_engine(*cfg, &rc);
     else { hulc_set_error("hulc_ctx_create: unknown dtype %d", cfg->dtype); delete c; return 1; }
     if (rc) { delete c->e; delete c; return rc; }
     *out = c;
@@ -135,6 +137,18 @@ int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* ids, const int32_t* mask, 
     return ctx->encode(ids, mask, B, L, out);
 }
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
+int hulc_scaler_enable(hulc_ctx* ctx, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval) {
+    if (!ctx) { hulc_set_error("hulc_scaler_enable: null context"); return 1; }
+    return ctx->e->scaler_enable(init_scale, growth_factor, backoff_factor, growth_interval);
+}
+int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf) {
+    if (!ctx) { hulc_set_error("hulc_scaler_get: null context"); return 1; }
+    return ctx->e->scaler_get(scale, growth_tracker, skipped_steps, last_found_inf);
+}
+int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker) {
+    if (!ctx) { hulc_set_error("hulc_scaler_set: null context"); return 1; }
+    return ctx->e->scaler_set(scale, growth_tracker);
+}
 int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }
 int hulc_set_dropout(hulc_ctx* ctx, float p) {
     if (p < 0.f || p >= 1.f) { hulc_set_error("hulc_set_dropout: p must be in [0,1)"); return 1; }
@@ -148,30 +162,13 @@ int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* out, int64_t cap) { return ctx->e-
 
 int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    const float* bias, int32_t relu, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    EpiP ep; ep.out = C; ep.out_f32 = 1; ep.bias = bias; ep.relu = relu & 1;     // relu bit 2 (value 4): force the register-staged kernel
-    if (dtype != HULC_DTYPE_F32 && !(relu & 4) && M >= 512 && N >= 128) {
-        const DenseLoader<bf16_t> a = dense<bf16_t>((const bf16_t*)A, M, lda), b = dense<bf16_t>((const bf16_t*)B, N, ldb);
-        if (gemm_glds_ok(a, b, ep, M, N, K)) {
-            launch_gemm_glds(st, a, b, dense_out(ldc), ep, M, N, K);
-            if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
-            return 0;
-        }
-    }
-    if (dtype == HULC_DTYPE_F32) {
-        if (M >= 512 && N >= 128) launch_gemm<float, 128, 128>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
-        else launch_gemm<float, 64, 64>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
-    } else {
-        if (M >= 512 && N >= 128) launch_gemm<bf16_t, 128, 128>(st, dense<bf16_t>((const bf16_t*)A, M, lda), dense<bf16_t>((const bf16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
-        else launch_gemm<bf16_t, 64, 64>(st, dense<bf16_t>((const bf16_t*)A, M, lda), dense<bf16_t>((const bf16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
-    }
-    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
-    return 0;
+    if (dtype == HULC_DTYPE_F16) return hulc_f16::k_gemm_nt(0, A, B, C, M, N, K, lda, ldb, ldc, bias, relu, stream);
+    return hulc_bf16::k_gemm_nt(dtype == HULC_DTYPE_F32, A, B, C, M, N, K, lda, ldb, ldc, bias, relu, stream);
 }
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HULC_DTYPE_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(1024), dim3(256), 0, st, src, (float*)dst, (long long)n);
-    else hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(1024), dim3(256), 0, st, src, (bf16_t*)dst, (long long)n);
+    else hipLaunchKernelGGL((cast_kernel<float, h16_t>), dim3(1024), dim3(256), 0, st, src, (h16_t*)dst, (long long)n);
     if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_cast: launch failed"); return 1; }
     return 0;
 }
@@ -186,9 +183,9 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     const int CO = which == 1 ? 32 : 64;
     if (hipMalloc(&part, sizeof(float) * 512ll * 64 * KC) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
     int ns;
-    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)X, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, Conv1Src{X, nullptr, 0, 0}, (const bf16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, Conv1Src{X, nullptr, 0, 0}, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
     hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);
     hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((CO * KC + 1023) / 1024), dim3(256), 0, st, part, ns, (long long)CO * KC, out, CO, KC, 1, 1, 0);
@@ -202,16 +199,16 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
 int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
                      int32_t OUTH, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    ConvTileP p{}; p.img = (const bf16_t*)img; p.IMH = p.IMW = IMH; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.OUTH = p.OUTW = OUTH;
-    p.bias = bias; p.mask = (const bf16_t*)mask; p.relu = relu & 1; p.dbg = relu & ~1; p.Nf = Nf;
+    ConvTileP p{}; p.img = (const h16_t*)img; p.IMH = p.IMW = IMH; p.w = (const h16_t*)w; p.out = (h16_t*)out; p.OUTH = p.OUTW = OUTH;
+    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & ~1; p.Nf = Nf;
     bool ok = false;
     if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);
     else if (mode == 2) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
     else if (mode == 3) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
-    else if (mode == 4) { launch_conv1_fwd(st, Conv1Src{img, nullptr, 0, 0}, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH, OUTH, relu & ~1); ok = true; }
+    else if (mode == 4) { launch_conv1_fwd(st, Conv1Src{img, nullptr, 0, 0}, (const h16_t*)w, bias, (h16_t*)out, Nf, IMH, IMH, OUTH, OUTH, relu & ~1); ok = true; }
     else if (mode == 5 || mode == 6) {      // conv1 forward from uint8 NHWC frames; mode 6: `mask` = (Nf,2) int32 RandomShiftsAug shifts, pad 10 (IMH >= 100) or 4
-        launch_conv1_fwd(st, Conv1Src{img, mode == 6 ? (const int*)mask : nullptr, 1, IMH >= 100 ? 10 : 4}, (const bf16_t*)w, bias, (bf16_t*)out, Nf, IMH, IMH, OUTH,
+        launch_conv1_fwd(st, Conv1Src{img, mode == 6 ? (const int*)mask : nullptr, 1, IMH >= 100 ? 10 : 4}, (const h16_t*)w, bias, (h16_t*)out, Nf, IMH, IMH, OUTH,
                          OUTH, relu & ~1);
         ok = true;
     }
@@ -226,7 +223,7 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
     EpiP ep; ep.out = out; ep.out_f32 = 0;
     const int NW = variant / 10, MT = variant % 10;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
-    const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
+    const h16_t* a = (const h16_t*)A; const h16_t* w = (const h16_t*)W;
 #define SK(nw, mt) hipLaunchKernelGGL((skinny_gemm_kernel<nw, mt>), grid, dim3(nw * 64), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep)
     if (NW == 8 && MT == 2) SK(8, 2); else if (NW == 8 && MT == 4) SK(8, 4); else if (NW == 4 && MT == 2) SK(4, 2); else if (NW == 4 && MT == 4) SK(4, 4);
     else if (NW == 8 && MT == 1) SK(8, 1); else if (NW == 4 && MT == 1) SK(4, 1);

@@ -1,39 +1,87 @@
 // hulc_amd/csrc/common.h — shared device helpers for the gfx950 (MI355X) HULC training-step kernels.
-// Wave = 64 lanes everywhere; bf16 is stored as raw uint16 and converted with bit ops (RNE).
+// Wave = 64 lanes everywhere.  The 16-bit compute type of the half-precision engines is selected PER TRANSLATION UNIT:
+//   capi.hip         (no macro)          -> bf16  (namespace hulc_bf16; also holds the fp32 parity engine)
+//   engine_f16.hip   (-DHULC_HALF_F16)   -> IEEE fp16 (namespace hulc_f16; the reference's `precision: 16`,
+//                                           conf/trainer/play_trainer.yaml:3, run with dynamic loss scaling)
+// Both store the type as raw uint16 (h16_t); only the conversions and the MFMA opcode differ
+// (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x32_f16 share one fragment layout), so every kernel is written once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+void hulc_set_error(const char* fmt, ...);
+
+#define HIP_CHECK(x)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) {                                                                          \
+            hulc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));            \
+            return 1;                                                                                    \
+        }                                                                                                \
+    } while (0)
 
 #define DEVI __device__ __forceinline__
 
-DEVI float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
-// fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction)
-DEVI bf16_t f2bf(float f) {
-    __bf16 b = (__bf16)f;
-    return *reinterpret_cast<bf16_t*>(&b);
+#ifdef HULC_HALF_F16
+#define HULC_NS hulc_f16
+#define HULC_HALF_NAME "fp16"
+#else
+#define HULC_NS hulc_bf16
+#define HULC_HALF_NAME "bf16"
+#endif
+
+namespace HULC_NS {
+
+typedef uint16_t h16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+#ifdef HULC_HALF_F16
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+#define MFMA_16x16x32_H __builtin_amdgcn_mfma_f32_16x16x32_f16
+DEVI float h2f(h16_t x) { return (float)*reinterpret_cast<const _Float16*>(&x); }
+// fp32 -> fp16, round to nearest even; overflow -> inf (caught by the loss scaler's non-finite check)
+DEVI h16_t f2h(float f) {
+    _Float16 b = (_Float16)f;
+    return *reinterpret_cast<h16_t*>(&b);
 }
-DEVI unsigned pack2bf(float lo, float hi) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    bf16x2_t b = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+#else
+typedef __bf16 h16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 h16x2_t __attribute__((ext_vector_type(2)));
+#define MFMA_16x16x32_H __builtin_amdgcn_mfma_f32_16x16x32_bf16
+DEVI float h2f(h16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+// fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction)
+DEVI h16_t f2h(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<h16_t*>(&b);
+}
+#endif
+DEVI unsigned pack2h(float lo, float hi) {
+    h16x2_t b = __builtin_convertvector(f32x2_t{lo, hi}, h16x2_t);
     return *reinterpret_cast<unsigned*>(&b);
+}
+// the two halves of a packed pair (low = first element)
+DEVI float h2f_lo(unsigned w) { return h2f((h16_t)(w & 0xffffu)); }
+DEVI float h2f_hi(unsigned w) {
+#ifdef HULC_HALF_F16
+    return h2f((h16_t)(w >> 16));
+#else
+    return __uint_as_float(w & 0xffff0000u);
+#endif
 }
 template <typename T> DEVI float to_f(T x);
 template <> DEVI float to_f<float>(float x) { return x; }
-template <> DEVI float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <> DEVI float to_f<h16_t>(h16_t x) { return h2f(x); }
 template <typename T> DEVI T from_f(float x);
 template <> DEVI float from_f<float>(float x) { return x; }
-template <> DEVI bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
+template <> DEVI h16_t from_f<h16_t>(float x) { return f2h(x); }
 
 // 8 contiguous elements of T (16 B for bf16, 32 B for fp32)
 template <typename T> struct Vec8 { T v[8]; };
 
 template <typename T> DEVI void load8(const T* p, T (&v)[8]);
-template <> DEVI void load8<bf16_t>(const bf16_t* p, bf16_t (&v)[8]) {
+template <> DEVI void load8<h16_t>(const h16_t* p, h16_t (&v)[8]) {
     if ((((uintptr_t)p) & 15) == 0) {
         uint4 u = *reinterpret_cast<const uint4*>(p);
         *reinterpret_cast<uint4*>(v) = u;
@@ -86,13 +134,4 @@ DEVI float hash_uniform(uint64_t seed, uint64_t idx) {
     return ((hash_u32(seed, idx) >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
-#define HIP_CHECK(x)                                                                                     \
-    do {                                                                                                 \
-        hipError_t e_ = (x);                                                                             \
-        if (e_ != hipSuccess) {                                                                          \
-            hulc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));            \
-            return 1;                                                                                    \
-        }                                                                                                \
-    } while (0)
-
-void hulc_set_error(const char* fmt, ...);
+}  // namespace HULC_NS

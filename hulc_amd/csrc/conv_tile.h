@@ -15,12 +15,14 @@
 #include "common.h"
 #include "conv_wgrad.h"   // lds_char, u32x4_t
 
+namespace HULC_NS {
+
 struct ConvTileP {
-    const bf16_t* img; int IMH, IMW;
-    const bf16_t* w;
-    bf16_t* out; int OUTH, OUTW;
+    const h16_t* img; int IMH, IMW;
+    const h16_t* w;
+    h16_t* out; int OUTH, OUTW;
     const float* bias;
-    const bf16_t* mask;
+    const h16_t* mask;
     const unsigned* maskbits; // CN <= 32 only: one word per output pixel, bit c = (layer input channel c > 0) — 16x fewer mask bytes than `mask`
     int relu;
     int dbg;                 // bench ablation: bit 1 = skip the MFMA/epilogue phase, bit 2 = skip the global prefetch loads
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         const int i0 = b * p.RB;
         const int rlo = REV ? i0 - (TA - 1) : i0 * SI;
         const int clo = REV ? -(TB - 1) : 0;
-        const bf16_t* base = p.img + (long long)f * p.IMH * p.IMW * CK;
+        const h16_t* base = p.img + (long long)f * p.IMH * p.IMW * CK;
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             const int q = tid + k * 512;
@@ -186,21 +188,21 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             lds_char* wrow = wl + (cls * CN + li) * C::WS + g * 16;
             constexpr int KS = CK / 32, NS = TA * TB * KS;      // k-steps of 32; NS is even for every instantiation
             static_assert(NS % 2 == 0, "pipelined loop handles k-steps in pairs");
-            bf16x8_t xf0[C::MT], wf0[C::NT], xf1[C::MT], wf1[C::NT];
-            auto frag_load = [&](bf16x8_t (&xf)[C::MT], bf16x8_t (&wf)[C::NT], int s) {
+            h16x8_t xf0[C::MT], wf0[C::NT], xf1[C::MT], wf1[C::NT];
+            auto frag_load = [&](h16x8_t (&xf)[C::MT], h16x8_t (&wf)[C::NT], int s) {
                 const int tap = s / KS, ks = s % KS;
                 const int ta = tap / TB, tb = tap % TB;
                 const int toff = (REV ? -(ta * p.LP + tb) : (((ta % SI) * PLR + ta / SI) * p.LP + tb)) * C::XS + ks * 64;
 #pragma unroll
-                for (int mm = 0; mm < C::MT; ++mm) xf[mm] = *(__attribute__((address_space(3))) bf16x8_t*)(xl + xoff[mm] + toff);
+                for (int mm = 0; mm < C::MT; ++mm) xf[mm] = *(__attribute__((address_space(3))) h16x8_t*)(xl + xoff[mm] + toff);
 #pragma unroll
-                for (int nn = 0; nn < C::NT; ++nn) wf[nn] = *(__attribute__((address_space(3))) bf16x8_t*)(wrow + nn * 16 * C::WS + s * 64);
+                for (int nn = 0; nn < C::NT; ++nn) wf[nn] = *(__attribute__((address_space(3))) h16x8_t*)(wrow + nn * 16 * C::WS + s * 64);
             };
-            auto frag_mma = [&](bf16x8_t (&xf)[C::MT], bf16x8_t (&wf)[C::NT]) {
+            auto frag_mma = [&](h16x8_t (&xf)[C::MT], h16x8_t (&wf)[C::NT]) {
 #pragma unroll
                 for (int mm = 0; mm < C::MT; ++mm)
 #pragma unroll
-                    for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nn], xf[mm], acc[mm][nn], 0, 0, 0);
+                    for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = MFMA_16x16x32_H(wf[nn], xf[mm], acc[mm][nn], 0, 0, 0);
             };
             // software pipeline: the LDS reads of k-step s+1 are in flight while the MFMAs of k-step s issue
             frag_load(xf0, wf0, 0);
@@ -239,13 +241,13 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
                             const unsigned wd = mk[mm][e][r >> 1];
-                            const bf16_t mb = (bf16_t)((r & 1) ? (wd >> 16) : (wd & 0xffff));
-                            v[r] = bf2f(mb) > 0.f ? v[r] : 0.f;
+                            const h16_t mb = (h16_t)((r & 1) ? (wd >> 16) : (wd & 0xffff));
+                            v[r] = h2f(mb) > 0.f ? v[r] : 0.f;
                         }
                     }
                     u32x4_t o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = pack2bf(v[2 * r], v[2 * r + 1]);
+                    for (int r = 0; r < 4; ++r) o[r] = pack2h(v[2 * r], v[2 * r + 1]);
                     *reinterpret_cast<u32x4_t*>(p.out + obase + e * 8) = o;
                 }
             }
@@ -304,8 +306,8 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 // x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MINW>
-__global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                           bf16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
+__global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           h16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                            unsigned* __restrict__ maskbits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* ximg = (lds_char*)smem;
@@ -314,11 +316,11 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
     const int XR = (R - 1) * 4 + 8;
     const int XRS = IW * 2 + 16;
     const int W4 = IW >> 2;
-    bf16x8_t wf[6][2];
+    h16x8_t wf[6][2];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const bf16x8_t*>(W + (ct * 16 + li) * 192 + ks * 32 + g * 8);
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + (ct * 16 + li) * 192 + ks * 32 + g * 8);
     // (c, kh) row of this lane group for each k-step
     int rowsel[6];
 #pragma unroll
@@ -356,17 +358,17 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
             for (int ks = 0; ks < 6; ++ks) {
                 typedef short s16x4v __attribute__((ext_vector_type(4)));
                 typedef short s16x8v __attribute__((ext_vector_type(8)));
-                bf16x8_t xf[2];
+                h16x8_t xf[2];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     const s16x4v lo = *(__attribute__((address_space(3))) s16x4v*)(xb[mm] + rowsel[ks]);
                     const s16x4v hi = *(__attribute__((address_space(3))) s16x4v*)(xb[mm] + rowsel[ks] + 8);
-                    xf[mm] = __builtin_bit_cast(bf16x8_t, (s16x8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    xf[mm] = __builtin_bit_cast(h16x8_t, (s16x8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) acc[mm][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ct], xf[mm], acc[mm][ct], 0, 0, 0);
+                    for (int ct = 0; ct < 2; ++ct) acc[mm][ct] = MFMA_16x16x32_H(wf[ks][ct], xf[mm], acc[mm][ct], 0, 0, 0);
             }
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
@@ -380,8 +382,8 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
                     const float v0 = fmaxf(acc[mm][ct][0] + bb[ct].x, 0.f), v1 = fmaxf(acc[mm][ct][1] + bb[ct].y, 0.f);
                     const float v2 = fmaxf(acc[mm][ct][2] + bb[ct].z, 0.f), v3 = fmaxf(acc[mm][ct][3] + bb[ct].w, 0.f);
                     uint2 o;
-                    o.x = pack2bf(v0, v1);
-                    o.y = pack2bf(v2, v3);
+                    o.x = pack2h(v0, v1);
+                    o.y = pack2h(v2, v3);
                     *reinterpret_cast<uint2*>(out + obase + cn0) = o;
                     const unsigned nz = ((o.x & 0xffffu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xffffu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
                     bits |= nz << cn0;
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
         }
     }
 }
-static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf16_t* W, const float* bias, bf16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
+static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16_t* W, const float* bias, h16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
                                     unsigned* maskbits = nullptr) {
     auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
@@ -415,3 +417,5 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const bf1
     if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
     else hipLaunchKernelGGL(conv1_fwd_kernel<2>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
 }
+
+}  // namespace HULC_NS

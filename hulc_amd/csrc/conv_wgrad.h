@@ -19,17 +19,19 @@
 #pragma once
 #include "common.h"
 
+namespace HULC_NS {
+
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 
 typedef __attribute__((address_space(3))) char lds_char;      // 32-bit LDS pointers: half the address registers of generic ones
-DEVI bf16x8_t tr_read8(lds_char* p0, lds_char* p1) {
+DEVI h16x8_t tr_read8(lds_char* p0, lds_char* p1) {
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
 
 template <int CI, int CO, int KH, int KW, int S>
@@ -52,7 +54,7 @@ struct WgradCfg {
 };
 
 template <int CI, int CO, int KH, int KW, int S>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+__global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                             float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,12 +89,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                 constexpr int CH = CO / 8;           // 16-byte chunks per pixel
                 for (int r = wave; r < R; r += 4) {
                     const bool in = oh0 + r < OH;
-                    const bf16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * CO;
+                    const h16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * CO;
                     for (int i = lane; i < OW * CH; i += 64) {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
                         if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
                         *(lds_u32x4*)(dyimg + (r * OWp + i / CH) * C::DYS + (i % CH) * 16) = v;
                     }
                 }
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                 const int ih0 = oh0 * S;
                 const int rows = min(XR, IH - ih0);
                 const int total = rows * IW * CH;
-                const bf16_t* src = X + ((long long)f * IH + ih0) * IW * CI;
+                const h16_t* src = X + ((long long)f * IH + ih0) * IW * CI;
                 for (int i0 = tid; i0 < total; i0 += 256 * 8) {          // 8 independent 16-byte loads in flight per thread
                     u32x4_t v[8];
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                 const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
                 const int pixA = valid ? r * OWp + ow0 : R * OWp;      // idle groups read the permanent zero pixels
                 lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccol;
-                bf16x8_t af[C::CT];
+                h16x8_t af[C::CT];
 #pragma unroll
                 for (int c = 0; c < C::CT; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
                 const int pixB0 = (r * S) * IW + ow0 * S;
@@ -137,9 +139,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
                     const int tap = nt / C::CGN, cg = nt % C::CGN;
                     const int kh = tap / KW, kw = tap % KW;
                     lds_char* bbase = ximg + (pixB0 + kh * IW + kw + prow * S) * C::XS + cg * 32 + ccol;
-                    const bf16x8_t bf = tr_read8(bbase, bbase + 4 * S * C::XS);
+                    const h16x8_t bf = tr_read8(bbase, bbase + 4 * S * C::XS);
 #pragma unroll
-                    for (int c = 0; c < C::CT; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                    for (int c = 0; c < C::CT; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
                 }
             }
         }
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const bf16_t* __r
 // Chunk k of a thread is (dY or X, LDS offset, global offset) packed in one register; loads are unconditional (clamped).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CI, int CO, int KH, int KW, int S, int NWV>
-__global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ dY, float* __restrict__ part,
+__global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                             float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                             int* __restrict__ work_ctr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
@@ -228,14 +230,14 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
         zmask = 0;
         if (dbg & 2) return;
         const int f = item / nbands, oh0 = (item % nbands) * R;
-        const bf16_t* ybase = dY + ((long long)f * OH + oh0) * OW * CO;
-        const bf16_t* xbase = X + ((long long)f * IH + oh0 * S) * IW * CI;
+        const h16_t* ybase = dY + ((long long)f * OH + oh0) * OW * CO;
+        const h16_t* xbase = X + ((long long)f * IH + oh0 * S) * IW * CI;
         const int ylim = (min(R, OH - oh0) * OW * CHY - 1), xlim = (min(XR, IH - oh0 * S) * IW * CHX - 1);   // last in-frame chunk
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const bool isx = (pk[k] >> 31) != 0;
             const int go = (int)(pk[k] & 0x1ffffu);
-            const bf16_t* src = isx ? xbase + (long long)min(go, xlim) * 8 : ybase + (long long)min(go, ylim) * 8;
+            const h16_t* src = isx ? xbase + (long long)min(go, xlim) * 8 : ybase + (long long)min(go, ylim) * 8;
             pf[k] = *reinterpret_cast<const u32x4_t*>(src);           // value untouched here: no wait at the issue point
             if (!isx && go > ylim) zmask |= 1u << k;                  // dY rows below the frame become zeros at the LDS write
         }
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
                 const u32x4_t v = ((zmask_cur >> k) & 1u) ? u32x4_t{0u, 0u, 0u, 0u} : pf[k];
                 if (!(pk[k] >> 31)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+                    for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
                 }
                 *(lds_u32x4*)((lds_char*)smem + (((pk[k] >> 17) & 0x3fffu) << 4)) = v;
             }
@@ -289,8 +291,8 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
             };
             // B fragments run D n-tiles ahead of their MFMAs; A fragments first
             constexpr int D = 3;
-            bf16x8_t ring[D];
-            bf16x8_t af[CTH];
+            h16x8_t ring[D];
+            h16x8_t af[CTH];
 #pragma unroll
             for (int c = 0; c < CTH; ++c) af[c] = tr_read8(ab[0] + c * 32, ab[1] + c * 32);
 #pragma unroll
@@ -298,9 +300,9 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
             __builtin_amdgcn_sched_barrier(0);          // keep the reads this far ahead: the scheduler otherwise sinks them next to their use
 #pragma unroll
             for (int j = 0; j < C::NTW; ++j) {
-                const bf16x8_t bf = ring[j % D];
+                const h16x8_t bf = ring[j % D];
 #pragma unroll
-                for (int c = 0; c < CTH; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                for (int c = 0; c < CTH; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
                 if (j + D < C::NTW) ring[j % D] = bfrag(j + D);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const bf16_t* 
 }
 
 template <int CI, int CO, int KH, int KW, int S>
-static inline int launch_conv_wgrad_tr(hipStream_t st, const bf16_t* X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
+static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                        int OW, int max_blocks, int* work_ctr = nullptr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     static const bool v1 = getenv("HULC_WGRAD_V1") != nullptr;
@@ -417,8 +419,8 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
                 for (int u = 0; u < 8; ++u) {
                     if (e[u].r < rows) {
                         u32x2_t o;
-                        o[0] = pack2bf(v[u].x, v[u].y);
-                        o[1] = pack2bf(v[u].z, v[u].w);
+                        o[0] = pack2h(v[u].x, v[u].y);
+                        o[1] = pack2h(v[u].z, v[u].w);
                         *(__attribute__((address_space(3))) u32x2_t*)(dst + e[u].r * XRS + e[u].c * 8) = o;
                     }
                 }
@@ -501,8 +503,8 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             u32x2_t ov;
-            ov[0] = pack2bf(v[c], v[3 + c]);
-            ov[1] = pack2bf(v[6 + c], v[9 + c]);
+            ov[0] = pack2h(v[c], v[3 + c]);
+            ov[1] = pack2h(v[6 + c], v[9 + c]);
             *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + p.r) * XRS + p.c * 8) = ov;
         }
     }
@@ -534,7 +536,7 @@ struct Wgrad1Cfg {
     }
 };
 
-__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int* __restrict__ work_ctr, const bf16_t* __restrict__ dY, float* __restrict__ part,
+__global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int* __restrict__ work_ctr, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                                 float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R) {
     using C = Wgrad1Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -570,12 +572,12 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
             {   // dY band, one row per wave pass
                 for (int r = wave; r < R; r += 4) {
                     const bool in = oh0 + r < OH;
-                    const bf16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * C::CO;
+                    const h16_t* src = dY + ((long long)f * OH + min(oh0 + r, OH - 1)) * OW * C::CO;
                     for (int i = lane; i < OW * 4; i += 64) {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + i * 8);
                         if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(v[e] << 16); bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+                        for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
                         *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
                     }
                 }
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
                 const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
                 const int pixA = valid ? r * OWp + ow0 : R * OWp;
                 lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
-                bf16x8_t af[2];
+                h16x8_t af[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
 #pragma unroll
@@ -600,9 +602,9 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
                     const int nt = nt0 + j;
                     const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
                     lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
-                    const bf16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
+                    const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[j][c], 0, 0, 0);
+                    for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
                 }
             }
         }
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
     }
 }
 
-static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const bf16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
+static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
     static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
     static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
@@ -653,7 +655,7 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
 // fragments come from transposing reads, so no transposed activation copies (and no separate column-sum launches) are needed.
 // Orientation: A = X fragment (rows k), B = dY fragment (cols n)  ->  a lane owns dW[n][k..k+3]: float4 read-modify-write.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __restrict__ dY, long long ldy, const bf16_t* __restrict__ X, long long ldx,
+__global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
                                                              int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
                                                              float* __restrict__ db2, int mchunk) {
     // Large M (token-major transformer / encoder layers): blockIdx.z owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
@@ -687,16 +689,16 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
         // stage dY[m0:m0+64][n0:n0+64] and X[m0:m0+64][k0:k0+128] (rows >= mend and columns past the edge -> zeros)
         for (int i = tid; i < 64 * (TN / 8); i += 256) {
             const int m = i / (TN / 8), c = i % (TN / 8);
-            bf16_t v[8];
-            if (m0 + m < mend && n0 + c * 8 < N) load8_guard<bf16_t>(dY + (long long)(m0 + m) * ldy + n0 + c * 8, N - (n0 + c * 8), v);
-            else zero8<bf16_t>(v);
+            h16_t v[8];
+            if (m0 + m < mend && n0 + c * 8 < N) load8_guard<h16_t>(dY + (long long)(m0 + m) * ldy + n0 + c * 8, N - (n0 + c * 8), v);
+            else zero8<h16_t>(v);
             *(lds_u32x4*)(yimg + m * YS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
         }
         for (int i = tid; i < 64 * (TK / 8); i += 256) {
             const int m = i / (TK / 8), c = i % (TK / 8);
-            bf16_t v[8];
-            if (m0 + m < mend && k0 + c * 8 < K) load8_guard<bf16_t>(X + (long long)(m0 + m) * ldx + k0 + c * 8, K - (k0 + c * 8), v);
-            else zero8<bf16_t>(v);
+            h16_t v[8];
+            if (m0 + m < mend && k0 + c * 8 < K) load8_guard<h16_t>(X + (long long)(m0 + m) * ldx + k0 + c * 8, K - (k0 + c * 8), v);
+            else zero8<h16_t>(v);
             *(lds_u32x4*)(ximg + m * XS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
         }
         __syncthreads();
@@ -704,16 +706,16 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
         for (int ms = 0; ms < 2; ++ms) {                        // reduction over m: 2 x 32
             const int mrow = ms * 32 + g * 8 + prow;
             lds_char* yb = yimg + mrow * YS + wave * 32 + ccol;
-            const bf16x8_t yf = tr_read8(yb, yb + 4 * YS);
+            const h16x8_t yf = tr_read8(yb, yb + 4 * YS);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 lds_char* xb = ximg + mrow * XS + j * 32 + ccol;
-                const bf16x8_t xf = tr_read8(xb, xb + 4 * XS);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
+                const h16x8_t xf = tr_read8(xb, xb + 4 * XS);
+                acc[j] = MFMA_16x16x32_H(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
             }
         }
         if (db && blockIdx.y == 0 && tid < TN) {
-            for (int m = 0; m < 64; ++m) bsum += bf2f(*(__attribute__((address_space(3))) bf16_t*)(yimg + m * YS + tid * 2));
+            for (int m = 0; m < 64; ++m) bsum += h2f(*(__attribute__((address_space(3))) h16_t*)(yimg + m * YS + tid * 2));
         }
     }
     if (vec_ok) {
@@ -748,3 +750,5 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const bf16_t* __res
         else { db[n0 + tid] += bsum; if (db2) db2[n0 + tid] += bsum; }
     }
 }
+
+}  // namespace HULC_NS

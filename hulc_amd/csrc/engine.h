@@ -1,81 +1,19 @@
 // hulc_amd/csrc/engine.h — host-side orchestration of one HULC / GCBC training step on one MI355X.
 // Engine<T> owns the workspace (saved activations, packed/transposed weight copies) and enqueues the kernels of
-// forward+loss, backward and Adam on one HIP stream.  T = float (parity mode) or bf16_t (bench mode).
+// forward+loss, backward and Adam on one HIP stream.  T = float (parity mode) or h16_t (bench mode).
 // Reference call stack restated here: SURVEY.md §3.2 (hulc/models/hulc.py:390-537).
 #pragma once
 #include <map>
 #include <string>
 #include <vector>
 
-#include "../../include/hulc_hip.h"
+#include "iengine.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "conv_wgrad.h"
 #include "conv_tile.h"
 
-struct IEngine {
-    virtual ~IEngine() {}
-    virtual int bind(float* p, float* g, float* m, float* v, int64_t numel, int n, const char* const* names, const int64_t* offs,
-                     const int64_t* numels) = 0;
-    virtual int prepare_weights(bool shadow_fresh = false) = 0;
-    virtual int zero_grads() = 0;
-    virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
-    virtual int forward_pair(const hulc_batch* vis, const hulc_batch* lang, float lw, float cw, float* out8, int on_host) = 0;
-    virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
-    virtual int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
-                         float* pred_pr_out) = 0;
-    virtual int rollout_reset() = 0;
-    virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
-                             const int32_t* plan_inject, int32_t* plan_out) = 0;
-    virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
-    virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
-    virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
-    virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
-    virtual int64_t workspace_bytes() const = 0;
-    virtual void set_kl_beta(float b) = 0;
-    virtual void set_dropout(float p) = 0;
-    void set_timing(bool on, const char* filter) { timing = on; timing_filter = filter ? filter : ""; }
-    hipStream_t st = nullptr;
-    // ---- per-kernel-class HIP-event timers (bench.py roofline leg): events are recorded on `st` around the launches of a class
-    struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };
-    std::map<std::string, KTimer> timers;
-    bool timing = false;
-    std::string timing_filter;      // empty = every class; else only this class (keeps event overhead out of the timed region)
-    int timer_depth = 0;            // a group scope (e.g. the S recurrent steps) suppresses the per-launch scopes inside it
-    struct TimerScope {
-        IEngine* e; IEngine::KTimer* t;
-        TimerScope(IEngine* e_, const char* name, const char* bound, double flops, double bytes, int nlaunch = 1) : e(e_), t(nullptr) {
-            if (!e->timing || e->timer_depth > 0) return;
-            if (!e->timing_filter.empty() && e->timing_filter != name) return;
-            e->timer_depth++;
-            t = &e->timers[name];
-            if (t->name.empty()) { t->name = name; t->bound = bound; }
-            if (t->used == t->ev.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); t->ev.emplace_back(a, b); }
-            t->flops += flops; t->bytes += bytes; t->launches += nlaunch;
-            hipEventRecord(t->ev[t->used].first, e->st);
-        }
-        ~TimerScope() { if (t) { hipEventRecord(t->ev[t->used].second, e->st); t->used++; e->timer_depth--; } }
-    };
-    int timers_read(char* out, int64_t cap, bool reset) {
-        hipStreamSynchronize(st);
-        std::string js = "{";
-        bool first = true;
-        for (auto& kv : timers) {
-            KTimer& t = kv.second;
-            double ms = 0;
-            for (size_t i = 0; i < t.used; ++i) { float x = 0; hipEventElapsedTime(&x, t.ev[i].first, t.ev[i].second); ms += x; }
-            char buf[512];
-            snprintf(buf, sizeof(buf), "%s\"%s\": {\"bound\": \"%s\", \"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
-                     t.name.c_str(), t.bound.c_str(), t.launches, ms, t.flops, t.bytes);
-            js += buf; first = false;
-            if (reset) { t.used = 0; t.flops = t.bytes = 0; t.launches = 0; }
-        }
-        js += "}";
-        if ((int64_t)js.size() + 1 > cap) { hulc_set_error("hulc_timers_read: buffer too small"); return 1; }
-        memcpy(out, js.c_str(), js.size() + 1);
-        return 0;
-    }
-};
+namespace HULC_NS {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // HULC_DEBUG_SYNC=1: synchronise after every stage and trace its name to stderr (bring-up / fault localisation)
@@ -200,7 +138,7 @@ struct Engine : IEngine {
         std::string s(pre);
         a.a1 = alloc<T>((int64_t)maxN * H1 * H1 * 32, (s + "a1").c_str());
         static const bool use_bits = getenv("HULC_MASKBITS") ? atoi(getenv("HULC_MASKBITS")) != 0 : true;
-        a.m1bits = (use_bits && std::is_same<T, bf16_t>::value) ? alloc<unsigned>((int64_t)maxN * H1 * H1) : nullptr;   // ReLU bitmask of a1 (conv2 dgrad)
+        a.m1bits = (use_bits && std::is_same<T, h16_t>::value) ? alloc<unsigned>((int64_t)maxN * H1 * H1) : nullptr;   // ReLU bitmask of a1 (conv2 dgrad)
         a.a2 = alloc<T>((int64_t)maxN * H2 * H2 * 64, (s + "a2").c_str());
         a.a3 = alloc<T>((int64_t)maxN * H3 * H3 * 64, (s + "a3").c_str());
         a.ss = gripper ? nullptr : alloc<T>((int64_t)maxN * 128, (s + "ss").c_str());
@@ -273,6 +211,9 @@ struct Engine : IEngine {
         }
         bheads = alloc<float>(NHEAD); wheads = alloc<T>((int64_t)NHEAD * HID); wheadsT = alloc<T>((int64_t)HID * NHEAD);
         if (alloc_failed) { hulc_set_error("hipMalloc failed while sizing the workspace (B=%d S=%d)", maxB, maxS); return 1; }
+#ifdef HULC_HALF_F16
+        if (!std::is_same<T, float>::value) return scaler_enable(65536.f, 2.f, 0.5f, 2000);      // torch.cuda.amp.GradScaler() defaults
+#endif
         return 0;
     }
 
@@ -452,7 +393,7 @@ struct Engine : IEngine {
         static const bool trace = getenv("HULC_TRACE_GEMM") != nullptr;
         if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%lld ldb=%lld f32out=%d acc=%d atomic=%d\n", M, N, K, a.s1, b.s1, ep.out_f32, ep.accumulate, ep.atomic);
         const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
                 TimerScope ts(this, "skinny_gemm", "hbm", fl, by);
                 launch_skinny(st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
@@ -463,7 +404,7 @@ struct Engine : IEngine {
         const long long w128 = (long long)cdiv(M, 128) * cdiv(N, 128), w64 = (long long)cdiv(M, 64) * cdiv(N, 64);
         if (M >= 512 && N >= 128 && w128 >= 128) {
             TimerScope ts(this, "gemm_128x128", "mfma", fl, by);
-            if constexpr (std::is_same<T, bf16_t>::value) {
+            if constexpr (std::is_same<T, h16_t>::value) {
                 if (gemm_use_glds && gemm_glds_ok(a, b, ep, M, N, K)) { launch_gemm_glds(st, a, b, om, ep, M, N, K); return; }
                 if (K >= 128) { launch_gemm<T, 128, 128, DenseLoader<T>, DenseLoader<T>, DenseOut, 64>(st, a, b, om, ep, M, N, K); return; }   // BK = 64: half the barriers per flop
             }
@@ -473,7 +414,7 @@ struct Engine : IEngine {
             // small-N / short-K GEMMs (transformer, encoder heads) are bound by the exposed L2 latency of each k-step: a deeper BK means fewer of them
             static const int small_bk = getenv("HULC_SMALL_BK") ? atoi(getenv("HULC_SMALL_BK")) : 128;     // A/B on one box: 4.764 (32) / 4.739 (64) / 4.728 ms per step (128)
             const bool t64 = w64 >= 128 || (M <= 64 && N <= 64);
-            if constexpr (std::is_same<T, bf16_t>::value) {
+            if constexpr (std::is_same<T, h16_t>::value) {
                 if (small_bk == 128 && K >= 128) {
                     if (t64) launch_gemm<T, 64, 64, DenseLoader<T>, DenseLoader<T>, DenseOut, 128>(st, a, b, om, ep, M, N, K);
                     else launch_gemm<T, 32, 32, DenseLoader<T>, DenseLoader<T>, DenseOut, 128>(st, a, b, om, ep, M, N, K);
@@ -492,7 +433,7 @@ struct Engine : IEngine {
     // dW[M][N] += A[M][K] B[N][K]^T with fp32 accumulate; few output tiles + long K -> split K across workgroups (atomics)
     void gemm_wgrad(const DenseLoader<T>& a, const DenseLoader<T>& b, float* dW, long long lddw, int M, int N, int K) {
         EpiP ep = epi(dW, true); ep.accumulate = 1;
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) { gemm(a, b, dense_out(lddw), ep, M, N, K); return; }
         }
         const long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128), t64 = (long long)cdiv(M, 64) * cdiv(N, 64);
@@ -515,7 +456,7 @@ struct Engine : IEngine {
     }
     // weight + bias grads of Y = X W^T: dW[N][K] += dY^T X ; db += colsum(dY).  dY [M][N] dense, X [M][K] (ldx)
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
                 hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
                 return;
@@ -532,7 +473,7 @@ struct Engine : IEngine {
             }
         }
         const int mp = ldpad(M);
-        constexpr bool fuse_cs = std::is_same<T, bf16_t>::value;     // bf16 (bench) mode: the dY transpose also adds its column sums into db (atomics)
+        constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // bf16 (bench) mode: the dY transpose also adds its column sums into db (atomics)
         transpose_pair(dY, N, tA, M, N, X, ldx, tB, M, K, mp, fuse_cs ? db : nullptr, fuse_cs ? db2 : nullptr);
         gemm_wgrad(dense<T>(tA, N, mp), dense<T>(tB, K, mp), dW, lddw, N, K, M);
         if (db && !fuse_cs) colsum(dY, N, M, N, db, db2);
@@ -549,7 +490,7 @@ struct Engine : IEngine {
                 long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db) {
         hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt);
         const int nsplit = std::max(1, std::min(64, cdiv(rows, 64)));
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(cdiv(n, 64), nsplit), dim3(256), 0, st, dy, lddy, x, ldx, stats, rows, n, cdiv(rows, nsplit), cspart, dg, db);
             return;
         }
@@ -646,7 +587,7 @@ struct Engine : IEngine {
             const int nf = src2 ? Nf / 2 : Nf;
             const long long foff = h ? Nf / 2 : 0, poff = foff * g1.OH * g1.OW;
             ConvGeom gh = geom(nf, e.IH, 3, 8, 4);
-            if constexpr (std::is_same<T, bf16_t>::value) {
+            if constexpr (std::is_same<T, h16_t>::value) {
                 const double px = (double)nf * g1.OH * g1.OW;
                 TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)nf * 3 * e.IH * e.IH * (sh.u8 ? 1 : 4) + px * 32 * 2);
                 launch_conv1_fwd(st, sh, e.c1.Wf, e.c1.b32, a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr);
@@ -658,7 +599,7 @@ struct Engine : IEngine {
             }
         }
         bool tiled = false;
-        if constexpr (std::is_same<T, bf16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
+        if constexpr (std::is_same<T, h16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
             ConvTileP p2{}; p2.img = a.a1; p2.IMH = p2.IMW = e.H1; p2.w = e.c2.Wf; p2.out = a.a2; p2.OUTH = p2.OUTW = e.H2; p2.bias = e.c2.b32; p2.relu = 1; p2.Nf = Nf;
             ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
             const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
@@ -679,7 +620,7 @@ struct Engine : IEngine {
         }
         const T* fin; int fk;
         if (!e.gripper) {
-            if constexpr (std::is_same<T, bf16_t>::value) hipLaunchKernelGGL(spatial_softmax_fwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, a.ss, a.ssstats);
+            if constexpr (std::is_same<T, h16_t>::value) hipLaunchKernelGGL(spatial_softmax_fwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, a.ss, a.ssstats);
             else hipLaunchKernelGGL((spatial_softmax_fwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, e.H3, e.H3, 64, a.ss, (float*)nullptr, a.ssstats);
             fin = a.ss; fk = 128;
         } else {
@@ -696,16 +637,16 @@ struct Engine : IEngine {
         const int Kc = c.I * c.KH * c.KW;
         const long long npix = (long long)g.Nf * g.OH * g.OW;
         int nsplit = 0;
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
                           conv1 ? ((double)g.Nf * 3 * g.IH * g.IW * (wgrad_src.u8 ? 1 : 4) + npix * c.O * 2) : ((double)g.Nf * g.IH * g.IW * c.I * 2 + npix * c.O * 2));
             if (conv1)
                 nsplit = launch_conv1_wgrad_tr(st, wgrad_src, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024, next_ctr());
             else if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const bf16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
         }
         bool bias_done = false;
         if (nsplit > 0) bias_done = true;     // the tr kernels added the bias gradient themselves (atomics)
@@ -727,7 +668,7 @@ struct Engine : IEngine {
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (std::is_same<T, h16_t>::value) {
             ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.maskbits = (c.I <= 32) ? maskbits : nullptr; p.Nf = g.Nf; p.work_ctr = next_ctr();
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
@@ -779,7 +720,7 @@ struct Engine : IEngine {
         if (!e.gripper) {
             { EpiP ep = epi(d_ss, true); lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
             lin_wgrad(d_f1, a.ss, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
-            if constexpr (std::is_same<T, bf16_t>::value) hipLaunchKernelGGL(spatial_softmax_bwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, dact3);
+            if constexpr (std::is_same<T, h16_t>::value) hipLaunchKernelGGL(spatial_softmax_bwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, dact3);
             else hipLaunchKernelGGL((spatial_softmax_bwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, 64, dact3);
         } else {
             { EpiP ep = epi(d_g0, false); ep.mask = a.g0; lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
@@ -996,7 +937,7 @@ struct Engine : IEngine {
             if (b->plan_eps) { HIP_CHECK(hipMemcpyAsync(plan_eps_in, b->plan_eps, sizeof(float) * B * n, hipMemcpyDefault, st)); eps = plan_eps_in; }
             const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL((normal_kl_sample_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, pr_logits, pp_logits, B, n, eps, plan_eps, plan_f, plan_t, klel,
-                               dpp_kl, dpr_kl, wpp, wpr, site_seed(20));
+                               dpp_kl, dpr_kl, wpp, wpr, site_seed(20), lscale());
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, Bm * n, cfg.kl_beta / Bm, losses + 1);
             if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel + (long long)Bm * n, Bm * n, cfg.kl_beta / Bm, losses2 + 1);
         } else pr_fwd(B, S, dp);
@@ -1006,7 +947,7 @@ struct Engine : IEngine {
             if (b->plan_idx) { HIP_CHECK(hipMemcpyAsync(pidx_in, b->plan_idx, sizeof(int) * B * NCAT, hipMemcpyDefault, st)); idx_in = pidx_in; }
             const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, idx_in, pidx, probs, klcat, dpp_kl,
-                               dpr_kl, wpp, wpr, site_seed(20));
+                               dpr_kl, wpp, wpr, site_seed(20), lscale());
             hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, Bm * NCAT, cfg.kl_beta / Bm, losses + 1);
             if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat + Bm * NCAT, Bm * NCAT, cfg.kl_beta / Bm, losses2 + 1);
         }
@@ -1015,7 +956,7 @@ struct Engine : IEngine {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
             hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
-                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1);
+                               cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
             if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);
             else hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
         }
@@ -1033,7 +974,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
             { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
             { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
-            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale);
+            hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale, lscale());
         }
         STAGE("clip_fwd");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in forward"); return 1; }
@@ -1624,13 +1565,50 @@ struct Engine : IEngine {
         return 0;
     }
 
+    // ---------------------------------------------------------------- dynamic loss scaling (kernels.h: ScalerState)
+    ScalerState* scaler = nullptr;          // device; null = off (fp32 / bf16 default)
+    const float* lscale() const { return scaler ? &scaler->scale : nullptr; }
+    int scaler_enable(float init_scale, float growth, float backoff, int interval) override {
+        if (!(init_scale > 0.f)) { scaler = nullptr; return 0; }          // <= 0: off
+        if (!(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) || interval < 1) { hulc_set_error("hulc_scaler_enable: need growth >= 1, 0 < backoff <= 1, interval >= 1"); return 1; }
+        if (!scaler_mem) { scaler_mem = alloc<ScalerState>(1); if (alloc_failed) { hulc_set_error("hulc_scaler_enable: allocation failed"); return 1; } }
+        ScalerState h; memset(&h, 0, sizeof(h));
+        h.scale = init_scale; h.growth = growth; h.backoff = backoff; h.interval = interval;
+        HIP_CHECK(hipMemcpyAsync(scaler_mem, &h, sizeof(h), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        scaler = scaler_mem;
+        return 0;
+    }
+    ScalerState* scaler_mem = nullptr;
+    int scaler_get(float* scale, int32_t* tracker, int64_t* skipped, int32_t* last_inf) override {
+        if (!scaler) { if (scale) *scale = 1.f; if (tracker) *tracker = 0; if (skipped) *skipped = 0; if (last_inf) *last_inf = 0; return 0; }
+        ScalerState h;
+        HIP_CHECK(hipMemcpyAsync(&h, scaler, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (scale) *scale = h.scale; if (tracker) *tracker = h.growth_tracker; if (skipped) *skipped = h.skipped; if (last_inf) *last_inf = h.last_found_inf;
+        return 0;
+    }
+    int scaler_set(float scale, int32_t tracker) override {
+        if (!scaler) { hulc_set_error("hulc_scaler_set: the loss scaler is off (hulc_scaler_enable first)"); return 1; }
+        if (!(scale > 0.f) || tracker < 0) { hulc_set_error("hulc_scaler_set: need scale > 0, growth_tracker >= 0"); return 1; }
+        ScalerState h;
+        HIP_CHECK(hipMemcpyAsync(&h, scaler, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        h.scale = scale; h.growth_tracker = tracker;
+        HIP_CHECK(hipMemcpyAsync(scaler, &h, sizeof(h), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    }
+
     int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) override {
         if (!bound) { hulc_set_error("hulc_adam_step before hulc_bind_params"); return 1; }
         const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
         const double bc1d = 1.0 - pow((double)b1, (double)step), bc2d = 1.0 - pow((double)b2, (double)step);
         (void)bc1; (void)bc2;
+        if (scaler) hipLaunchKernelGGL(nonfinite_check_kernel, dim3(2048), dim3(256), 0, st, G, (long long)numel, scaler);      // after the (host-side) all-reduce: every rank sees the same flag
         hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale,
-                           std::is_same<T, float>::value ? (bf16_t*)nullptr : (bf16_t*)wshadow);
+                           std::is_same<T, float>::value ? (h16_t*)nullptr : (h16_t*)wshadow, (const ScalerState*)scaler);
+        if (scaler) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, st, scaler);
         if (hipGetLastError() != hipSuccess) { hulc_set_error("adam launch failed"); return 1; }
         return prepare_weights(true);
     }
@@ -1655,7 +1633,18 @@ struct Engine : IEngine {
         return 0;
     }
     static float host_to_f(float x) { return x; }
-    static float host_to_f(bf16_t x) { uint32_t u = ((uint32_t)x) << 16; float f; memcpy(&f, &u, 4); return f; }
+#ifdef HULC_HALF_F16
+    static float host_to_f(h16_t x) {      // IEEE binary16 -> float on the host
+        const uint32_t sgn = (uint32_t)(x >> 15) << 31, ex = (x >> 10) & 31, man = x & 1023;
+        uint32_t u;
+        if (ex == 0) { float f = ldexpf((float)man, -24); memcpy(&u, &f, 4); u |= sgn; }
+        else if (ex == 31) u = sgn | 0x7f800000u | (man << 13);
+        else u = sgn | ((ex + 112) << 23) | (man << 13);
+        float f; memcpy(&f, &u, 4); return f;
+    }
+#else
+    static float host_to_f(h16_t x) { uint32_t u = ((uint32_t)x) << 16; float f; memcpy(&f, &u, 4); return f; }
+#endif
     int get_plan_idx(int32_t* out, int64_t cap) override {
         HIP_CHECK(hipStreamSynchronize(st));
         int64_t cnt = std::min<int64_t>(cap, (int64_t)cur.B * NCAT);
@@ -1663,3 +1652,44 @@ struct Engine : IEngine {
         return 0;
     }
 };
+
+// per-kernel test entry (hulc_k_gemm_nt): C (fp32) = relu?(A B^T + bias) through the production GEMM kernels of this translation unit's
+// 16-bit type (or fp32 when is_f32; bf16 unit only).  relu bit 2 (value 4): force the register-staged kernel instead of the LDS-DMA one.
+int k_gemm_nt(int is_f32, const void* A, const void* B, float* C, int M, int N, int K, long long lda, long long ldb, long long ldc, const float* bias, int relu,
+              void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    EpiP ep; ep.out = C; ep.out_f32 = 1; ep.bias = bias; ep.relu = relu & 1;
+    if (!is_f32 && !(relu & 4) && M >= 512 && N >= 128) {
+        const DenseLoader<h16_t> a = dense<h16_t>((const h16_t*)A, M, lda), b = dense<h16_t>((const h16_t*)B, N, ldb);
+        if (gemm_glds_ok(a, b, ep, M, N, K)) {
+            launch_gemm_glds(st, a, b, dense_out(ldc), ep, M, N, K);
+            if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
+            return 0;
+        }
+    }
+    if (is_f32) {
+#ifdef HULC_HALF_F16
+        hulc_set_error("hulc_k_gemm_nt: the fp32 kernels live in the bf16 translation unit"); return 1;
+#else
+        if (M >= 512 && N >= 128) launch_gemm<float, 128, 128>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+        else launch_gemm<float, 64, 64>(st, dense<float>((const float*)A, M, lda), dense<float>((const float*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+#endif
+    } else {
+        if (M >= 512 && N >= 128) launch_gemm<h16_t, 128, 128>(st, dense<h16_t>((const h16_t*)A, M, lda), dense<h16_t>((const h16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+        else launch_gemm<h16_t, 64, 64>(st, dense<h16_t>((const h16_t*)A, M, lda), dense<h16_t>((const h16_t*)B, N, ldb), dense_out(ldc), ep, M, N, K);
+    }
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_gemm_nt: launch failed"); return 1; }
+    return 0;
+}
+
+// factory of this translation unit (iengine.h): fp32 + bf16 engines in capi.hip, the fp16 engine in engine_f16.hip
+IEngine* make_engine(const hulc_config& cfg, int* rc) {
+#ifdef HULC_HALF_F16
+    auto* e = new Engine<h16_t>(cfg); *rc = e->alloc_all(); return e;
+#else
+    if (cfg.dtype == HULC_DTYPE_F32) { auto* e = new Engine<float>(cfg); *rc = e->alloc_all(); return e; }
+    auto* e = new Engine<h16_t>(cfg); *rc = e->alloc_all(); return e;
+#endif
+}
+
+}  // namespace HULC_NS

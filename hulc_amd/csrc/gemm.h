@@ -16,6 +16,8 @@
 #pragma once
 #include "common.h"
 
+namespace HULC_NS {
+
 struct EpiP {
     void* out = nullptr;
     int out_f32 = 0;
@@ -357,8 +359,8 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
         }
         if constexpr (sizeof(T) == 2) {
             uint2 w;
-            w.x = pack2bf(v[0], v[1]);
-            w.y = pack2bf(v[2], v[3]);
+            w.x = pack2h(v[0], v[1]);
+            w.y = pack2h(v[2], v[3]);
             *reinterpret_cast<uint2*>(op) = w;
         } else {
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -375,7 +377,7 @@ DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, 
 // kernel
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int BK> struct LdsLd;
-template <int BK> struct LdsLd<bf16_t, BK> { static constexpr int v = BK + 16; };  // 96 / 160 B rows: pitch = 2 (mod 4) 16-B slots -> conflict-free ds_read_b128 (MI355X_MICROARCH.md §LDS)
+template <int BK> struct LdsLd<h16_t, BK> { static constexpr int v = BK + 16; };  // 96 / 160 B rows: pitch = 2 (mod 4) 16-B slots -> conflict-free ds_read_b128 (MI355X_MICROARCH.md §LDS)
 template <int BK> struct LdsLd<float, BK> { static constexpr int v = BK + 2; };    // 2*row + g distinct banks for b32 reads
 
 // piece numbering inside a [BR rows][32 k] operand tile:
@@ -474,16 +476,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, BL bl, OM om, EpiP ep,
             const T* bp = Bs + (wn * WN + (lane & 15)) * LD + (lane >> 4) * 8;
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk) {
-                bf16x8_t a[TM], b[TN];
+                h16x8_t a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 16 * LD + kk * 32);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const h16x8_t*>(ap + i * 16 * LD + kk * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 16 * LD + kk * 32);
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const h16x8_t*>(bp + j * 16 * LD + kk * 32);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
+                        acc[i][j] = MFMA_16x16x32_H(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
             }
         } else {
             const T* ap = As + (wm * WM + (lane & 15)) * LD + (lane >> 4);
@@ -548,7 +550,7 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 //   each XCD's L2 sees 4 A panels x 8 B panels instead of the whole of B.
 // ---------------------------------------------------------------------------------------------------------
 template <int NST, int NW>      // NW = 4 (wave tile 64x64) or 8 waves (wave tile 32x64: two waves per SIMD hide each other's DMA issue / LDS latency)
-__global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<bf16_t> al, DenseLoader<bf16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
+__global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> al, DenseLoader<h16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
                                                            int tiles_m, int tiles_n) {
     constexpr int STAGE = 32 * 1024;
     constexpr int PW = 16 / NW;                  // 8-row pieces of each operand a wave DMAs per stage
@@ -571,8 +573,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<bf16_t> 
     }
     const int m0 = tm * 128, n0 = tn * 128;
     const int r = lane >> 3, cs = (lane & 7) ^ (r & 6);
-    const bf16_t* asrc[PW];
-    const bf16_t* bsrc[PW];
+    const h16_t* asrc[PW];
+    const h16_t* bsrc[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         asrc[j] = al.row(min(m0 + (wave * PW + j) * 8 + r, M - 1), 0).base + cs * 8;
@@ -622,15 +624,15 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<bf16_t> 
 #pragma unroll 1
         for (int kk = 0; kk < nkk; ++kk) {
             const int chunk = (((kk << 2) + g) ^ (li & 6)) << 4;
-            bf16x8_t a[TM], b[4];
+            h16x8_t a[TM], b[4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(__attribute__((address_space(3))) bf16x8_t*)(sa + i * 2048 + chunk);
+            for (int i = 0; i < TM; ++i) a[i] = *(__attribute__((address_space(3))) h16x8_t*)(sa + i * 2048 + chunk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) bf16x8_t*)(sb + j * 2048 + chunk);
+            for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb + j * 2048 + chunk);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
+                for (int j = 0; j < 4; ++j) acc[i][j] = MFMA_16x16x32_H(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane owns 4 consecutive columns
         }
         buf = buf == NST - 1 ? 0 : buf + 1;
     }
@@ -645,17 +647,17 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<bf16_t> 
                 const int col = n0 + wn * 64 + j * 16 + g * 4;
                 if (col < N) {
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    epi_store4<bf16_t>(ep, v4, rrow, col, N, obase + col);
+                    epi_store4<h16_t>(ep, v4, rrow, col, N, obase + col);
                 }
             }
         }
     }
 }
-static inline bool gemm_glds_ok(const DenseLoader<bf16_t>& a, const DenseLoader<bf16_t>& b, const EpiP& ep, int M, int N, int K) {
-    auto row_ok = [](const DenseLoader<bf16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0; };
+static inline bool gemm_glds_ok(const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const EpiP& ep, int M, int N, int K) {
+    auto row_ok = [](const DenseLoader<h16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0; };
     return K >= 128 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
 }
-static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<bf16_t>& a, const DenseLoader<bf16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
+static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
     static const int nw = getenv("HULC_GLDS_NW") ? atoi(getenv("HULC_GLDS_NW")) : 8;
     static bool attr_set = false;
     if (!attr_set) {
@@ -676,7 +678,7 @@ static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<bf16_t>& a
 // Requirements: K % 128 == 0, N % 16 == 0, 16-B aligned rows.
 // ---------------------------------------------------------------------------------------------------------
 template <int NW, int MT, int KS = 0>   // KS > 0: K == NW*32*KS exactly -> every load of the wave is issued up front (one latency exposure)
-__global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+__global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W,
                                                              long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
     __shared__ float red[NW][MT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -684,47 +686,47 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
     const int m0 = blockIdx.y * (MT * 16);          // row block of MT*16 rows
     const int kq = K / NW, kb = wave * kq;          // K % (NW*32) == 0
     const int g = lane >> 4, i = lane & 15;
-    const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
-    const bf16_t* ap[MT];
+    const h16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    const h16_t* ap[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) ap[mt] = A + (long long)min(m0 + mt * 16 + i, M - 1) * lda + kb + g * 8;
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (KS > 0) {
-        bf16x8_t b[KS], a[KS][MT];
+        h16x8_t b[KS], a[KS][MT];
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
-            b[u] = *reinterpret_cast<const bf16x8_t*>(wp + u * 32);
+            b[u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + u * 32);
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const h16x8_t*>(ap[mt] + u * 32);
         }
 #pragma unroll
         for (int u = 0; u < KS; ++u)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][mt], b[u], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA_16x16x32_H(a[u][mt], b[u], acc[mt], 0, 0, 0);
     } else {
     // batches of 4 k-steps: issue all (1+MT)*4 16-byte loads, then the MFMAs (memory-level parallelism per wave)
     int k = 0;
     for (; k + 128 <= kq; k += 128) {
-        bf16x8_t b[4], a[4][MT];
+        h16x8_t b[4], a[4][MT];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + u * 32);
+            b[u] = *reinterpret_cast<const h16x8_t*>(wp + k + u * 32);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k + u * 32);
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const h16x8_t*>(ap[mt] + k + u * 32);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][mt], b[u], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA_16x16x32_H(a[u][mt], b[u], acc[mt], 0, 0, 0);
     }
     for (; k < kq; k += 32) {
-        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + k);
+        const h16x8_t b = *reinterpret_cast<const h16x8_t*>(wp + k);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap[mt] + k);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+            const h16x8_t a = *reinterpret_cast<const h16x8_t*>(ap[mt] + k);
+            acc[mt] = MFMA_16x16x32_H(a, b, acc[mt], 0, 0, 0);
         }
     }
     }
@@ -742,7 +744,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const bf16_t* __re
         const int col = n0 + (l & 15);
         if (row < M && col < N) {
             const int rrow = ep.res_rowmod > 0 ? row % ep.res_rowmod : row;
-            epi_store<bf16_t>(ep, v, rrow, col, om.offset(row, 0) + col);
+            epi_store<h16_t>(ep, v, rrow, col, om.offset(row, 0) + col);
         }
     }
 }
@@ -760,7 +762,7 @@ static bool gemm_use_glds = true;   // tests / tools can force the register-frag
 // fragment-shaped 16 x 64 B loads, which the texture-address path serves at ~2/3 of the full-line rate (tools/loadbench.hip:
 // 192 KB/CU in 4.3 us vs 7.4 us).  Each wave DMAs exactly the k-range it multiplies, so no barrier sits between load and MFMA.
 template <int MT, int KQ32, int NW = 8>   // KQ32 = k-steps (of 32) per wave = K / (NW * 32)
-__global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W,
+__global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W,
                                                          long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
     constexpr int PCW = KQ32 / 2;               // 128-byte pieces (64 k) per row per wave
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -777,7 +779,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __res
         const int r = lane >> 3, c = (lane & 7) ^ (r & 6);
 #pragma unroll
         for (int rg = 0; rg < MT * 2; ++rg) {
-            const bf16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
+            const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
 #pragma unroll
             for (int pc = 0; pc < PCW; ++pc)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
@@ -785,17 +787,17 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __res
         }
     }
     // ---- W: fragments straight to registers (one third of the bytes)
-    const bf16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
-    bf16x8_t b[KQ32];
+    const h16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    h16x8_t b[KQ32];
 #pragma unroll
-    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + u * 32);
+    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
     // ---- epilogue operands of this thread's 4 outputs (threads < MT*64), fetched under the operand stream
     const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
     const bool ethread = tid < MT * 64 && erow < M;
     const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
     const long long eo = ethread ? om.offset(erow, 0) + ecol : 0;
     EpiPre4 pre;
-    if (ethread) pre = epi_prefetch4<bf16_t>(ep, errow, ecol, N, eo);
+    if (ethread) pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -810,8 +812,8 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __res
             const int chunk = ((u & 1) * 4 + g) ^ (r & 6);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bf16x8_t a = *(__attribute__((address_space(3))) bf16x8_t*)(fb + (mt * 2 * PCW + (u >> 1)) * 1024 + chunk * 16);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a, acc[mt], 0, 0, 0);   // D^T: lane (row i, g) owns columns g*4..g*4+3
+                const h16x8_t a = *(__attribute__((address_space(3))) h16x8_t*)(fb + (mt * 2 * PCW + (u >> 1)) * 1024 + chunk * 16);
+                acc[mt] = MFMA_16x16x32_H(b[u], a, acc[mt], 0, 0, 0);   // D^T: lane (row i, g) owns columns g*4..g*4+3
             }
         }
     }
@@ -827,12 +829,12 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const bf16_t* __res
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[w * MT * 64 + tid];
         const float v4[4] = {v[0], v[1], v[2], v[3]};
-        epi_apply4<bf16_t>(ep, pre, v4, errow, ecol, N, eo);
+        epi_apply4<h16_t>(ep, pre, v4, errow, ecol, N, eo);
     }
     KSTAMP(5);
 }
 template <int MT, int KQ32>
-static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                        const DenseOut& om, const EpiP& ep) {
     const size_t lds = (size_t)8 * MT * 2 * (KQ32 / 2) * 1024;
     static bool attr_set = false;
@@ -843,7 +845,7 @@ static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const bf16_t* 
     hipLaunchKernelGGL((skinny_lds_kernel<MT, KQ32>), grid, dim3(512), lds, st, A, lda, W, ldw, M, N, K, om, ep);
 }
 // returns false when the shape is not covered (caller uses the register-fragment kernel)
-static inline bool launch_skinny_lds(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K, int MT,
+static inline bool launch_skinny_lds(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K, int MT,
                                      const DenseOut& om, const EpiP& ep) {
     if (K % 512 != 0 || K > 2048 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0) return false;
     if ((size_t)MT * 16 * K * 2 > 128 * 1024 || (MT != 2 && MT != 4 && !(MT == 1 && K == 2048))) return false;
@@ -869,7 +871,7 @@ static inline bool launch_skinny_lds(hipStream_t st, const bf16_t* A, long long 
     return true;
 }
 template <int NW>
-static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+static inline void launch_skinny_nw(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                     const DenseOut& om, const EpiP& ep) {
     // The kernel is bound by the per-CU load path (~10 B/clk/CU): every workgroup streams its A rows (M x K) and a 16-row W slice.
     // With only N/16 workgroups (128 at N = 2048) half the CUs idle, so split the rows in two 32-row blocks when that fills the chip.
@@ -890,7 +892,7 @@ static inline void launch_skinny_nw(hipStream_t st, const bf16_t* A, long long l
         default: hipLaunchKernelGGL((skinny_gemm_kernel<NW, 4>), grid, block, 0, st, A, lda, W, ldw, M, N, K, om, ep); break;
     }
 }
-static inline void launch_skinny(hipStream_t st, const bf16_t* A, long long lda, const bf16_t* W, long long ldw, int M, int N, int K,
+static inline void launch_skinny(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                  const DenseOut& om, const EpiP& ep) {
     if (K % 512 == 0) launch_skinny_nw<8>(st, A, lda, W, ldw, M, N, K, om, ep);     // 8 waves x >=2 k-steps
     else launch_skinny_nw<4>(st, A, lda, W, ldw, M, N, K, om, ep);
@@ -903,3 +905,5 @@ static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, 
     const bool shape = M <= 64 || ((shortk || K >= 512) && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
     return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }
+
+}  // namespace HULC_NS

@@ -1,0 +1,87 @@
+// hulc_amd/csrc/iengine.h — the interface the C-ABI (capi.hip) drives; implemented by Engine<T> (engine.h) once per compute type:
+// fp32 (parity) and bf16 in capi.hip's translation unit, fp16 in engine_f16.hip (common.h explains the per-TU half format).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hulc_hip.h"
+
+void hulc_set_error(const char* fmt, ...);
+
+struct IEngine {
+    virtual ~IEngine() {}
+    virtual int bind(float* p, float* g, float* m, float* v, int64_t numel, int n, const char* const* names, const int64_t* offs,
+                     const int64_t* numels) = 0;
+    virtual int prepare_weights(bool shadow_fresh = false) = 0;
+    virtual int zero_grads() = 0;
+    virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
+    virtual int forward_pair(const hulc_batch* vis, const hulc_batch* lang, float lw, float cw, float* out8, int on_host) = 0;
+    virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
+    virtual int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
+                         float* pred_pr_out) = 0;
+    virtual int rollout_reset() = 0;
+    virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
+                             const int32_t* plan_inject, int32_t* plan_out) = 0;
+    virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
+    virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
+    virtual int scaler_enable(float init_scale, float growth, float backoff, int interval) = 0;
+    virtual int scaler_get(float* scale, int32_t* tracker, int64_t* skipped, int32_t* last_inf) = 0;
+    virtual int scaler_set(float scale, int32_t tracker) = 0;
+    virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
+    virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
+    virtual int64_t workspace_bytes() const = 0;
+    virtual void set_kl_beta(float b) = 0;
+    virtual void set_dropout(float p) = 0;
+    void set_timing(bool on, const char* filter) { timing = on; timing_filter = filter ? filter : ""; }
+    hipStream_t st = nullptr;
+    // ---- per-kernel-class HIP-event timers (bench.py roofline leg): events are recorded on `st` around the launches of a class
+    struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };
+    std::map<std::string, KTimer> timers;
+    bool timing = false;
+    std::string timing_filter;      // empty = every class; else only this class (keeps event overhead out of the timed region)
+    int timer_depth = 0;            // a group scope (e.g. the S recurrent steps) suppresses the per-launch scopes inside it
+    struct TimerScope {
+        IEngine* e; IEngine::KTimer* t;
+        TimerScope(IEngine* e_, const char* name, const char* bound, double flops, double bytes, int nlaunch = 1) : e(e_), t(nullptr) {
+            if (!e->timing || e->timer_depth > 0) return;
+            if (!e->timing_filter.empty() && e->timing_filter != name) return;
+            e->timer_depth++;
+            t = &e->timers[name];
+            if (t->name.empty()) { t->name = name; t->bound = bound; }
+            if (t->used == t->ev.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); t->ev.emplace_back(a, b); }
+            t->flops += flops; t->bytes += bytes; t->launches += nlaunch;
+            hipEventRecord(t->ev[t->used].first, e->st);
+        }
+        ~TimerScope() { if (t) { hipEventRecord(t->ev[t->used].second, e->st); t->used++; e->timer_depth--; } }
+    };
+    int timers_read(char* out, int64_t cap, bool reset) {
+        hipStreamSynchronize(st);
+        std::string js = "{";
+        bool first = true;
+        for (auto& kv : timers) {
+            KTimer& t = kv.second;
+            double ms = 0;
+            for (size_t i = 0; i < t.used; ++i) { float x = 0; hipEventElapsedTime(&x, t.ev[i].first, t.ev[i].second); ms += x; }
+            char buf[512];
+            snprintf(buf, sizeof(buf), "%s\"%s\": {\"bound\": \"%s\", \"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                     t.name.c_str(), t.bound.c_str(), t.launches, ms, t.flops, t.bytes);
+            js += buf; first = false;
+            if (reset) { t.used = 0; t.flops = t.bytes = 0; t.launches = 0; }
+        }
+        js += "}";
+        if ((int64_t)js.size() + 1 > cap) { hulc_set_error("hulc_timers_read: buffer too small"); return 1; }
+        memcpy(out, js.c_str(), js.size() + 1);
+        return 0;
+    }
+};
+
+// factories, one per translation unit
+#define HULC_TU_DECLS                                                                                                                         \
+    IEngine* make_engine(const hulc_config& cfg, int* rc);                                                                                   \
+    int k_gemm_nt(int is_f32, const void* A, const void* B, float* C, int M, int N, int K, long long lda, long long ldb, long long ldc, \
+                  const float* bias, int relu, void* stream);
+namespace hulc_bf16 { HULC_TU_DECLS }   // capi.hip: HULC_DTYPE_F32 / HULC_DTYPE_BF16
+namespace hulc_f16 { HULC_TU_DECLS }    // engine_f16.hip: HULC_DTYPE_F16

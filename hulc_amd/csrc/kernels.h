@@ -4,6 +4,8 @@
 #pragma once
 #include "common.h"
 
+namespace HULC_NS {
+
 // =========================================================================================================
 // casts, transposes, packs
 // =========================================================================================================
@@ -61,10 +63,10 @@ __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __
 
 // 64x64-tile bf16 transpose: 16-byte global accesses on both sides (the 32x32 element-wise tile above moves 64-byte row
 // segments: 1.6 TB/s on the 94 MB weight set); falls back to guarded element accesses on ragged / unaligned tiles.
-DEVI void transpose_tile64_bf16(const TrDesc& D, int b, unsigned short (*tile)[66]) {
+DEVI void transpose_tile64_h16(const TrDesc& D, int b, unsigned short (*tile)[66]) {
     const int c0 = (b % D.tiles_x) * 64, r0 = (b / D.tiles_x) * 64;
-    const bf16_t* src = reinterpret_cast<const bf16_t*>(D.src);
-    bf16_t* dst = reinterpret_cast<bf16_t*>(D.dst);
+    const h16_t* src = reinterpret_cast<const h16_t*>(D.src);
+    h16_t* dst = reinterpret_cast<h16_t*>(D.dst);
     const bool vin = (D.lds % 8) == 0 && ((uintptr_t)src % 16) == 0, vout = (D.ldt % 8) == 0 && ((uintptr_t)dst % 16) == 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -84,7 +86,7 @@ DEVI void transpose_tile64_bf16(const TrDesc& D, int b, unsigned short (*tile)[6
     if (D.cs && threadIdx.x < 64 && c0 + (int)threadIdx.x < D.C) {      // fused bias gradient: column sums of this tile (pad rows are zeros)
         float sum = 0.f;
 #pragma unroll 16
-        for (int rr = 0; rr < 64; ++rr) sum += bf2f(tile[rr][threadIdx.x]);
+        for (int rr = 0; rr < 64; ++rr) sum += h2f(tile[rr][threadIdx.x]);
         unsafeAtomicAdd(D.cs + c0 + threadIdx.x, sum);
         if (D.cs2) unsafeAtomicAdd(D.cs2 + c0 + threadIdx.x, sum);
     }
@@ -110,14 +112,14 @@ __global__ void __launch_bounds__(256) batched_transpose64_kernel(const TrDesc* 
     int d = 0;
     while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
     const TrDesc D = desc[d];
-    transpose_tile64_bf16(D, blockIdx.x - D.blk0, tile);
+    transpose_tile64_h16(D, blockIdx.x - D.blk0, tile);
 }
 // two transposes in one launch (the dY / X pair of a large-M Linear weight gradient); descriptors by value
 struct TrPair { TrDesc d[2]; };
 __global__ void __launch_bounds__(256) pair_transpose64_kernel(TrPair pr) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
     const TrDesc D = ((int)blockIdx.x >= pr.d[1].blk0) ? pr.d[1] : pr.d[0];
-    transpose_tile64_bf16(D, blockIdx.x - D.blk0, tile);
+    transpose_tile64_h16(D, blockIdx.x - D.blk0, tile);
 }
 template <typename T>
 __global__ void __launch_bounds__(256) pair_transpose_kernel(TrPair pr) {
@@ -385,12 +387,12 @@ __global__ void __launch_bounds__(256) spatial_softmax_bwd_kernel(const T* __res
 
 // bf16, C = 64 versions: a thread owns 8 channels (one 16-byte load per pixel) of every 32nd pixel, so a frame is 14 wide
 // iterations instead of 110 two-byte ones; the forward keeps 8 online-softmax states per thread and merges the 32 pixel groups in LDS.
-__global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const bf16_t* __restrict__ f, int H, int W, bf16_t* __restrict__ out,
+__global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const h16_t* __restrict__ f, int H, int W, h16_t* __restrict__ out,
                                                                     float* __restrict__ stats /*[N][64][4]*/) {
     __shared__ float sm[32][65], ss[32][65], sx[32][65], sy[32][65];
     const int n = blockIdx.x, cg = threadIdx.x & 7, pg = threadIdx.x >> 3;
     const int HW = H * W;
-    const bf16_t* p = f + (long long)n * HW * 64 + cg * 8;
+    const h16_t* p = f + (long long)n * HW * 64 + cg * 8;
     float m[8], s[8], ax[8], ay[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; s[e] = 0.f; ax[e] = 0.f; ay[e] = 0.f; }
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const bf16_t
             const unsigned wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = __uint_as_float((e & 1) ? (wd[e >> 1] & 0xffff0000u) : (wd[e >> 1] << 16));
+                const float v = (e & 1) ? h2f_hi(wd[e >> 1]) : h2f_lo(wd[e >> 1]);
                 if (v > m[e]) {
                     const float sc = __expf(m[e] - v);
                     s[e] *= sc; ax[e] *= sc; ay[e] *= sc;
@@ -436,13 +438,13 @@ __global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const bf16_t
         const float inv = 1.f / S;
         const float ex = X * inv, ey = Y * inv;
         const long long o = (long long)n * 128 + 2 * c;
-        out[o] = f2bf(ex); out[o + 1] = f2bf(ey);
+        out[o] = f2h(ex); out[o + 1] = f2h(ey);
         float* st = stats + ((long long)n * 64 + c) * 4;
         st[0] = M; st[1] = inv; st[2] = ex; st[3] = ey;
     }
 }
-__global__ void __launch_bounds__(256) spatial_softmax_bwd64_kernel(const bf16_t* __restrict__ f, const float* __restrict__ stats,
-                                                                    const float* __restrict__ dout /*[N][128] fp32*/, int H, int W, bf16_t* __restrict__ df) {
+__global__ void __launch_bounds__(256) spatial_softmax_bwd64_kernel(const h16_t* __restrict__ f, const float* __restrict__ stats,
+                                                                    const float* __restrict__ dout /*[N][128] fp32*/, int H, int W, h16_t* __restrict__ df) {
     const int n = blockIdx.x, cg = threadIdx.x & 7, pg = threadIdx.x >> 3;
     const int HW = H * W;
     float M[8], inv[8], ex[8], ey[8], dex[8], dey[8];
@@ -469,12 +471,12 @@ __global__ void __launch_bounds__(256) spatial_softmax_bwd64_kernel(const bf16_t
             float g[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = __uint_as_float((e & 1) ? (wd[e >> 1] & 0xffff0000u) : (wd[e >> 1] << 16));
+                const float v = (e & 1) ? h2f_hi(wd[e >> 1]) : h2f_lo(wd[e >> 1]);
                 const float pr = __expf(v - M[e]) * inv[e];
                 g[e] = (v > 0.f) ? pr * (dex[e] * (lx - ex[e]) + dey[e] * (ly - ey[e])) : 0.f;
             }
             uint4 o;
-            o.x = pack2bf(g[0], g[1]); o.y = pack2bf(g[2], g[3]); o.z = pack2bf(g[4], g[5]); o.w = pack2bf(g[6], g[7]);
+            o.x = pack2h(g[0], g[1]); o.y = pack2h(g[2], g[3]); o.z = pack2h(g[4], g[5]); o.w = pack2h(g[6], g[7]);
             *reinterpret_cast<uint4*>(df + base + (long long)q * 64) = o;
         }
     }
@@ -761,7 +763,8 @@ __global__ void __launch_bounds__(64) plan_kl_sample_kernel(const float* __restr
                                                             int NCAT, int NCLS, const int* __restrict__ idx_in, int* __restrict__ idx_out,
                                                             float* __restrict__ probs /*[B][NCAT][NCLS]*/, float* __restrict__ kl_cat /*[B][NCAT]*/,
                                                             float* __restrict__ dpp, float* __restrict__ dpr, float w_pp, float w_pr,
-                                                            unsigned long long seed) {
+                                                            unsigned long long seed, const float* __restrict__ lscale = nullptr) {
+    if (lscale) { const float ls = lscale[0]; w_pp *= ls; w_pr *= ls; }      // dynamic loss scale (fp16 mode): gradients only, the KL value is unscaled
     const int bc = blockIdx.x, lane = threadIdx.x;
     const long long base = (long long)bc * NCLS;
     const bool ok = lane < NCLS;
@@ -805,9 +808,10 @@ template <typename T>
 __global__ void normal_kl_sample_kernel(const float* __restrict__ pr_state, const float* __restrict__ pp_state, int B, int n,
                                         const float* __restrict__ eps_in, float* __restrict__ eps_out, float* __restrict__ plan_f,
                                         T* __restrict__ plan_t, float* __restrict__ kl_elem, float* __restrict__ dpp, float* __restrict__ dpr,
-                                        float w_pp, float w_pr, unsigned long long seed) {
+                                        float w_pp, float w_pr, unsigned long long seed, const float* __restrict__ lscale = nullptr) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n) return;
+    if (lscale) { const float ls = lscale[0]; w_pp *= ls; w_pr *= ls; }
     const int b = idx / n, j = idx % n;
     const long long o = (long long)b * 2 * n + j;
     const float m1 = pr_state[o], v1 = pr_state[o + n], s1 = softplus_k(v1) + 1e-4f;
@@ -1102,7 +1106,8 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
                                      const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
                                      float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
                                      float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads,
-                                     int discrete_gripper = 1) {
+                                     int discrete_gripper = 1, const float* __restrict__ lscale = nullptr) {
+    if (lscale) grad_scale *= lscale[0];       // dynamic loss scale (fp16 mode): d heads only, the loss rows stay unscaled
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = gid >> 3, slot = gid & 7;                  // time-major row: r = t*B + b
     if (r >= B * S) return;
@@ -1248,7 +1253,9 @@ __global__ void __launch_bounds__(256) sum_rows_pair_kernel(const float* __restr
 // =========================================================================================================
 __global__ void __launch_bounds__(64) clip_loss_kernel(const float* __restrict__ img, const float* __restrict__ txt, int n, int D,
                                                        const float* __restrict__ logit_scale, float w, float* __restrict__ loss_out,
-                                                       float* __restrict__ dimg, float* __restrict__ dtxt, float* __restrict__ dlogit_scale) {
+                                                       float* __restrict__ dimg, float* __restrict__ dtxt, float* __restrict__ dlogit_scale,
+                                                       const float* __restrict__ lscale = nullptr) {
+    if (lscale) w *= lscale[0];
     __shared__ float in_[64][33], tn_[64][33], ni[64], nt[64], L[64][65], dL[64][65], rowlse[64], collse[64], red[64];
     const int i = threadIdx.x;
     const float s = __expf(logit_scale[0]);
@@ -1339,8 +1346,62 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int
 // Adam (torch.optim.Adam defaults; conf/model/optimizer/adam.yaml) over the flat parameter buffer,
 // fused with the gradient scale (1/world for the DP mean) — one pass over p, g, m, v.
 // =========================================================================================================
+// =========================================================================================================
+// Dynamic loss scaling (fp16 mode) — torch.cuda.amp.GradScaler semantics, the scaler Lightning's native-AMP plugin drives at
+// `precision: 16` (conf/trainer/play_trainer.yaml:3): the loss gradient is multiplied by `scale` at its sources (logistic / KL /
+// CLIP loss kernels read scale from here), the optimizer step divides it out again and is SKIPPED when any gradient is non-finite;
+// scale *= backoff on a skipped step, *= growth after `interval` consecutive good steps (torch/amp/grad_scaler.py, _amp_update_scale_).
+// The state lives on the device so that no step waits for the host.
+// =========================================================================================================
+struct ScalerState {
+    float scale;            // read by the loss kernels as lscale[0] (first member)
+    float growth, backoff;
+    int interval;
+    int growth_tracker;
+    int found_inf;          // set by nonfinite_check_kernel of the current step
+    int last_found_inf;     // of the most recent finished step
+    int skipped;            // optimizer steps skipped so far
+    int steps;              // optimizer steps taken (not skipped)
+};
+// found_inf |= any(!isfinite(g))   (grid-stride, 16-byte loads; one atomic per wave that saw one)
+__global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __restrict__ g, long long n, ScalerState* __restrict__ ss) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    unsigned bad = 0;
+    for (; i + 3 < n; i += stride) {
+        const uint4 u = *reinterpret_cast<const uint4*>(g + i);
+        // non-finite <=> exponent field all ones
+        bad |= ((u.x & 0x7f800000u) == 0x7f800000u) | ((u.y & 0x7f800000u) == 0x7f800000u) | ((u.z & 0x7f800000u) == 0x7f800000u) | ((u.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (i < n)
+        for (long long j = i; j < n && j < i + 4; ++j) bad |= ((__float_as_uint(g[j]) & 0x7f800000u) == 0x7f800000u);
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ss->found_inf, 1);
+}
+__global__ void scaler_update_kernel(ScalerState* __restrict__ ss) {
+    if (ss->found_inf) { ss->scale *= ss->backoff; ss->growth_tracker = 0; ss->skipped++; }
+    else {
+        ss->steps++;
+        const int ok = ss->growth_tracker + 1;
+        if (ok == ss->interval) {
+            const float ns = ss->scale * ss->growth;
+            if (isfinite(ns)) ss->scale = ns;
+            ss->growth_tracker = 0;
+        } else ss->growth_tracker = ok;
+    }
+    ss->last_found_inf = ss->found_inf;
+    ss->found_inf = 0;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, bf16_t* __restrict__ shadow) {
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, h16_t* __restrict__ shadow,
+                            const ScalerState* __restrict__ ss = nullptr) {
+    if (ss) {                           // fp16 mode: unscale; a step with non-finite gradients changes nothing (GradScaler.step skips
+        if (ss->found_inf) return;      // optimizer.step(), so Adam's own step count — the bias corrections — only counts the steps taken)
+        gscale /= ss->scale;
+        const float t = (float)(ss->steps + 1);
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
     for (; i + 3 < n; i += stride) {
@@ -1355,10 +1416,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             P[e] -= (lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
         }
         *reinterpret_cast<float4*>(p + i) = pp;
-        if (shadow) {      // bf16 compute copy of the parameters, refreshed in the same pass
+        if (shadow) {      // 16-bit compute copy of the parameters, refreshed in the same pass
             uint2 o;
-            o.x = pack2bf(pp.x, pp.y);
-            o.y = pack2bf(pp.z, pp.w);
+            o.x = pack2h(pp.x, pp.y);
+            o.y = pack2h(pp.z, pp.w);
             *reinterpret_cast<uint2*>(shadow + i) = o;
         }
         *reinterpret_cast<float4*>(m + i) = mm;
@@ -1380,3 +1441,5 @@ __global__ void gather_embg_kernel(const T* __restrict__ emb, T* __restrict__ ou
 __global__ void pack_losses_kernel(float* __restrict__ l) {
     l[4] = l[0] + l[1]; l[5] = l[1]; l[6] = l[0]; l[7] = l[2];
 }
+
+}  // namespace HULC_NS

@@ -16,6 +16,8 @@
 #include "gemm.h"
 #include "kernels.h"
 
+namespace HULC_NS {
+
 // x[t][:] = LayerNorm(word[ids[t]] + pos[t % L] + type[0])       one wave per token, H % 64 == 0, H <= 1024
 __global__ void __launch_bounds__(256) sbert_embed_ln_kernel(const int* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
                                                              const float* __restrict__ type0, const float* __restrict__ g, const float* __restrict__ b, int T,
@@ -110,6 +112,9 @@ __global__ void __launch_bounds__(256) sbert_pool_kernel(const float* __restrict
     for (int k = 0; k < n; ++k) out[(long long)b * H + lane + 64 * k] = v[k] / nrm;
 }
 
+}  // namespace HULC_NS
+
+using namespace HULC_NS;   // sbert.h is included by capi.hip only (fp32: lives in the bf16/fp32 translation unit)
 struct hulc_sbert {
     hulc_sbert_config cfg;
     hipStream_t st = nullptr;

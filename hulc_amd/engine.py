@@ -268,6 +268,20 @@ class StepEngine:
         self.adam_t += 1
         L.check(self.lib.hulc_adam_step(self.ctx, lr, b1, b2, eps, self.adam_t, grad_scale))
 
+    # ---- dynamic loss scaling (fp16 mode; torch.cuda.amp.GradScaler semantics, include/hulc_hip.h: hulc_scaler_*) ----------
+    def scaler_enable(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        """init_scale <= 0 switches scaling off.  fp16 engines start with GradScaler's defaults, fp32 / bf16 engines with it off."""
+        L.check(self.lib.hulc_scaler_enable(self.ctx, float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval)))
+
+    def scaler_state(self) -> Dict:
+        """{"scale", "growth_tracker", "skipped_steps", "last_found_inf"} — synchronises the stream.  flat_grads holds gradients x scale."""
+        sc, tr, sk, fi = C.c_float(), C.c_int32(), C.c_int64(), C.c_int32()
+        L.check(self.lib.hulc_scaler_get(self.ctx, C.byref(sc), C.byref(tr), C.byref(sk), C.byref(fi)))
+        return dict(scale=sc.value, growth_tracker=tr.value, skipped_steps=sk.value, last_found_inf=fi.value)
+
+    def scaler_load(self, scale: float, growth_tracker: int = 0):
+        L.check(self.lib.hulc_scaler_set(self.ctx, float(scale), int(growth_tracker)))
+
     def get_tensor(self, name: str, n: int) -> np.ndarray:
         out = np.zeros(n, np.float32)
         got = C.c_int64()

@@ -58,14 +58,20 @@ class FusedAdam:
 
     def state_dict(self):
         e = self.module.engine
-        return dict(step=e.adam_t, exp_avg=e.adam_m.clone(), exp_avg_sq=e.adam_v.clone(),
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        sd = dict(step=e.adam_t, exp_avg=e.adam_m.clone(), exp_avg_sq=e.adam_v.clone(),
+                  param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        if e.dtype == "fp16":       # Lightning keeps GradScaler.state_dict() next to the optimizer states ("native_amp_scaling_state")
+            st = e.scaler_state()
+            sd["grad_scaler"] = dict(scale=st["scale"], _growth_tracker=st["growth_tracker"])
+        return sd
 
     def load_state_dict(self, sd):
         e = self.module.engine
         e.adam_t = int(sd["step"])
         e.adam_m.copy_(sd["exp_avg"])
         e.adam_v.copy_(sd["exp_avg_sq"])
+        if e.dtype == "fp16" and sd.get("grad_scaler"):
+            e.scaler_load(float(sd["grad_scaler"]["scale"]), int(sd["grad_scaler"].get("_growth_tracker", 0)))
 
 
 class ConstantSchedule:
@@ -170,7 +176,12 @@ class Hulc(torch.nn.Module):
         max_window = 32 if isinstance(mw, str) else int(mw)      # a dangling ${...} (vision_only datasets) falls back to 32
         self.dims = spec.ModelDims(kind=self.kind, max_window=max_window, use_clip=self.use_clip_auxiliary_loss,
                                    rnn_type="gru" if (self.kind == "mcil" and rnn_type == "nn.GRU") else "rnn")
-        self.precision = {"16": "bf16", "bf16": "bf16", "32": "fp32", "fp32": "fp32"}[str(precision)]
+        # Lightning precision flags: 16 / "16-mixed" = native AMP fp16 + GradScaler (the reference's conf/trainer/play_trainer.yaml:3) ->
+        # the fp16 engine with its on-device loss scaler; bf16 needs none; 32 = the fp32 parity engine
+        pmap = {"16": "fp16", "fp16": "fp16", "16-mixed": "fp16", "bf16": "bf16", "bf16-mixed": "bf16", "32": "fp32", "fp32": "fp32", "32-true": "fp32"}
+        if str(precision) not in pmap:
+            raise ValueError(f"precision {precision!r}: one of {sorted(pmap)}")
+        self.precision = pmap[str(precision)]
         self.dropout_p = 0.0 if self.kind == "mcil" else float(_get(pr, "dropout_p", 0.1))
         self.pair_modalities = os.environ.get("HULC_PAIR", "1") != "0"      # vis + lang of a step as one paired pass (see training_step)
         self._engine_kw = dict(max_batch=int(max_batch_size) * (2 if self.pair_modalities else 1), max_seq=int(max_seq_len or max_window), dtype=self.precision, device=device,

@@ -19,6 +19,7 @@
  *   hulc_backward      <- autograd backward of the above (Lightning: loss.backward())
  *   hulc_adam_step     <- torch.optim.Adam.step                   hulc/models/hulc.py:239-252, conf/model/optimizer/adam.yaml
  *   hulc_zero_grads    <- optimizer.zero_grad()
+ *   hulc_scaler_*      <- torch.cuda.amp.GradScaler (Lightning NativeMixedPrecisionPlugin at precision: 16, conf/trainer/play_trainer.yaml:3)
  * The gradient all-reduce (DDPStrategy, hulc/training.py:64-69) stays on the host side: one RCCL all-reduce over the
  * flat gradient buffer this library writes.
  */
@@ -33,7 +34,7 @@ extern "C" {
 typedef struct hulc_ctx hulc_ctx;
 
 enum { HULC_KIND_HULC = 0, HULC_KIND_GCBC = 1, HULC_KIND_MCIL = 2, HULC_KIND_MCIL_GRU = 3 };   /* MCIL_GRU: conf/model/mcil.yaml with plan_recognition.rnn_type=nn.GRU */
-enum { HULC_DTYPE_F32 = 0, HULC_DTYPE_BF16 = 1 };
+enum { HULC_DTYPE_F32 = 0, HULC_DTYPE_BF16 = 1, HULC_DTYPE_F16 = 2 };   /* F16: IEEE half operands + dynamic loss scaling (hulc_scaler_*), the reference's `precision: 16` */
 
 typedef struct hulc_config {
     int32_t kind;            /* HULC_KIND_*  (conf/model/hulc.yaml:16, gcbc.yaml:16, mcil.yaml:16) */
@@ -122,6 +123,19 @@ int hulc_backward_part(hulc_ctx* ctx, int32_t part);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
 
+/* ---- fp16 mode (HULC_DTYPE_F16): dynamic loss scaling = torch.cuda.amp.GradScaler, which Lightning's native-AMP plugin drives for the
+ * reference's `precision: 16` (conf/trainer/play_trainer.yaml:3; fp16 autocast for matmuls/convs, fp32 for softmax / LayerNorm / losses
+ * and the fp32 island of decoders/utils/gripper_control.py:17,40 — the same split this library uses).  The scaler state lives on the
+ * device: the loss kernels multiply the loss gradient by `scale`, hulc_adam_step checks the (all-reduced) gradient buffer for
+ * non-finite values, divides the scale out, SKIPS the parameter update on inf/nan (its bias corrections count taken steps only, the
+ * `step` argument is then ignored) and updates the scale: *= backoff_factor on a skipped step, *= growth_factor after
+ * growth_interval consecutive good steps (torch/amp/grad_scaler.py).  The bound gradient buffer holds SCALED gradients.
+ * An F16 context starts with GradScaler's defaults (65536, 2, 0.5, 2000); init_scale <= 0 turns scaling off; F32 / BF16 contexts
+ * start with it off.  hulc_scaler_get synchronises (checkpointing: Lightning stores the scaler state next to the optimizer's). */
+int hulc_scaler_enable(hulc_ctx* ctx, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval);
+int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf /* each optional */);
+int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker);
+
 /* ---- Validation forward: one modality of Hulc.validation_step (hulc/models/hulc.py:770-797) = lmp_val
  * (:301-388): plan proposal and plan recognition each sample a plan (distributions.py:37-41), the decoder is run with both
  * (LogisticDecoderRNN.loss_and_act, logistic_decoder_rnn.py:85-100): NLL loss, a sampled action (_sample :234-258) mapped back to
@@ -200,7 +214,8 @@ int hulc_timers_read(hulc_ctx* ctx, char* json_out, int64_t cap, int32_t reset);
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* host_out, int64_t cap, int64_t* n);
 int hulc_get_plan_idx(hulc_ctx* ctx, int32_t* host_out, int64_t cap);
 
-/* Per-kernel test entry points (device pointers; dtype selects fp32 / bf16(uint16) storage of A, B). */
+/* Per-kernel test entry points (device pointers; dtype selects fp32 / bf16 / fp16 storage of A, B — HULC_DTYPE_F16 for hulc_k_gemm_nt only,
+ * the other half-precision entries run the bf16 build of the kernels; the fp16 build of every kernel is covered by the fp16 step tests). */
 int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                    int64_t ldb, int64_t ldc, const float* bias, int32_t relu, void* hip_stream);
 /* conv weight-gradient kernel alone (bf16 NHWC activations): which = 2 (4x4 s2, 32->64) or 3 (3x3 s1, 64->64); square frames of

@@ -16,12 +16,13 @@ CASES = {
     "hulc_visonly": ("hulc", 3, 0, 8, False, "all", 0.05, 3),
     "gcbc_s16": ("gcbc", 2, 2, 16, True, "all", 0.05, 4),
     "hulc_edge": ("hulc", 1, 2, 5, True, "none", 0.6, 5),
+    "hulc_s64": ("hulc", 2, 2, 64, True, "all", 0.05, 6, 64),        # BASELINE config 5's window length; 9th field = position-table rows
 }
 
 
 def load_case(name):
-    kind, Bv, Bl, S, use_clip, aux_mask, edge_frac, seed = CASES[name]
-    dims = spec.ModelDims(kind=kind, max_window=32, use_clip=use_clip)
+    kind, Bv, Bl, S, use_clip, aux_mask, edge_frac, seed = CASES[name][:8]
+    dims = spec.ModelDims(kind=kind, max_window=CASES[name][8] if len(CASES[name]) > 8 else 32, use_clip=use_clip)
     P = spec.init_all(dims, seed=seed, ln_jitter=True)
     batch = synthetic.make_batch(Bv, Bl, S, seed=seed, edge_frac=edge_frac, aux_mask=aux_mask)
     fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
@@ -63,6 +64,42 @@ def check_grads(G, fx, tol_l2=5e-3, tol_norm=2e-3, label=""):
             if e > tol_l2:
                 bad.append((n, "rel_l2", e))
     assert not bad, f"{label} gradient mismatches: {bad[:8]} (+{max(0, len(bad) - 8)} more)"
+
+
+# Tensors whose fp32 evaluation — the reference's own as much as ours — sits above 1e-3 of the fp64 truth: the conv gradients sum
+# O(10^5..10^6) per-pixel terms in fp32 (accumulation order), and a ReLU pre-activation within fp32 noise of zero flips its mask.
+# Everything NOT named here is held to 1e-3 rel-L2 against the reference's float64 gradients.
+FP32_NOISY = ("conv_model.0.bias", "conv_model.2.bias", "conv_model.4.bias", "conv_model.0.weight", "conv_model.2.weight", "conv_model.4.weight")
+
+
+def check_grads64(G, fx, tol_l2=1e-3, tol_noisy=5e-3, label="", noisy=FP32_NOISY, scale=1.0):
+    """G: name -> full gradient array.  Against the reference's FLOAT64 gradient entries (grad64/ gradsamp64/ gradnorm64/, tools/gen_golden.py):
+    rel-L2 <= tol_l2 for every tensor, tol_noisy for the named fp32-noise-limited ones.  Returns the worst (error, name) per class."""
+    bad, worst, worst_noisy = [], (0.0, ""), (0.0, "")
+    for key in fx.files:
+        if not key.startswith("gradnorm64/"):
+            continue
+        n = key[len("gradnorm64/"):]
+        ref_norm = float(fx[key])
+        g = np.asarray(G[n], np.float64) / scale
+        if ref_norm < 1e-12:
+            if float(np.sqrt((g ** 2).sum())) > 1e-7:
+                bad.append((n, "norm-nonzero"))
+            continue
+        if "grad64/" + n in fx.files:
+            e = rel_l2(g, fx["grad64/" + n])
+        else:
+            e = rel_l2(g.reshape(-1)[sample_idx(n, g.size)], fx["gradsamp64/" + n])
+        e = max(e, abs(float(np.sqrt((g ** 2).sum())) - ref_norm) / ref_norm)
+        is_noisy = any(n.endswith(x) for x in noisy)
+        if is_noisy:
+            worst_noisy = max(worst_noisy, (e, n))
+        else:
+            worst = max(worst, (e, n))
+        if e > (tol_noisy if is_noisy else tol_l2):
+            bad.append((n, round(e, 6)))
+    assert not bad, f"{label} gradient mismatches vs the fp64 reference: {bad[:10]} (+{max(0, len(bad) - 10)} more)"
+    return worst, worst_noisy
 
 
 def grad_entries(fx, n):

@@ -1,0 +1,167 @@
+"""GPU (-m gpu): the fp16 engine (HULC_DTYPE_F16, the reference's `precision: 16`, conf/trainer/play_trainer.yaml:3) and its on-device
+dynamic loss scaler (torch.cuda.amp.GradScaler semantics) through the C-ABI.
+
+* the step in fp16 against the reference fixtures (loss within 3e-3, gradient cosine > 0.995 after unscaling), including the S = 64
+  fixture of BASELINE config 5's window length;
+* the scaler state machine against a trajectory recorded from torch's GradScaler (tests/golden/grad_scaler.npz,
+  tools/gen_golden_scaler.py): scale / growth tracker / skipped steps / Adam's own step count;
+* overflow injection: a loss scale large enough to overflow the fp16 gradient intermediates -> the step is skipped, the scale backs off
+  until the gradients are finite again;
+* `precision=16` selects fp16 (not bf16)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import hulc_oracle as O  # noqa: E402
+from golden_util import ROOT, load_case  # noqa: E402
+from test_gpu_parity import _engine, grads_np, run_step  # noqa: E402
+
+
+def _cos(Gg, G):
+    a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
+    b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))), float(np.linalg.norm(a) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("name,scale", [("hulc_s32", 1024.0), ("hulc_s64", 4096.0), ("hulc_edge", 512.0), ("gcbc_s16", 1024.0)])
+def test_fp16_step_close_to_reference(name, scale):
+    dims, P, batch, fx = load_case(name)
+    Bmax = max(mb["actions"].shape[0] for mb in batch.values())
+    S = next(iter(batch.values()))["actions"].shape[1]
+    eng = _engine(dims, Bmax, S, "fp16")
+    st = eng.scaler_state()
+    assert st["scale"] == 65536.0 and st["growth_tracker"] == 0          # GradScaler() defaults at context creation
+    eng.scaler_enable(init_scale=scale)
+    eng.load_numpy(P)
+    losses_o, G = O.training_step(P, dims, batch)
+    tot, per = run_step(eng, batch)
+    ref = float(fx["loss_total"])
+    assert abs(tot - ref) <= 3e-3 * abs(ref), (tot, ref)                   # losses are reported UNscaled
+    Gg = {n: g / scale for n, g in grads_np(eng).items()}                  # the gradient buffer holds gradients x scale
+    assert all(np.isfinite(g).all() for g in Gg.values())
+    cos, ratio = _cos(Gg, G)
+    assert cos > 0.995, cos
+    assert abs(ratio - 1) < 0.02, ratio
+    # the reference's fp64 gradient entries (sampled / full): same cosine gate on what the fixture holds
+    a, b = [], []
+    for key in fx.files:
+        if key.startswith("grad64/") or key.startswith("gradsamp64/"):
+            n = key.split("/", 1)[1]
+            g = Gg[n].reshape(-1)
+            if key.startswith("gradsamp64/"):
+                from golden_util import sample_idx
+                g = g[sample_idx(n, g.size)]
+            a.append(g.astype(np.float64)); b.append(np.asarray(fx[key], np.float64).reshape(-1))
+    a, b = np.concatenate(a), np.concatenate(b)
+    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.995
+    # one optimizer step with finite gradients: taken, scale unchanged, tracker 1, parameters close to the fixture's torch.optim.Adam step
+    p_before = eng.flat_params.clone()
+    eng.adam_step()
+    st = eng.scaler_state()
+    assert st == dict(scale=scale, growth_tracker=1, skipped_steps=0, last_found_inf=0), st
+    assert not torch.equal(p_before, eng.flat_params)
+    pv = eng.views(eng.flat_params)
+    n = "action_decoder.rnn.bias_hh_l1"
+    if "adam1/" + n in fx.files:
+        d_ref = fx["adam1/" + n].reshape(-1) - P[n].reshape(-1)
+        d_got = pv[n].detach().cpu().numpy().reshape(-1) - P[n].reshape(-1)
+        assert np.mean(np.sign(d_ref) == np.sign(d_got)) > 0.97           # Adam's first step is lr * sign(g): sign agreement
+    eng.close()
+
+
+def test_grad_scaler_state_machine_matches_torch():
+    """Write gradients x scale (+ inf / nan on the recorded steps) into the bound gradient buffer and step: scale, growth tracker and the
+    first 257 parameters must follow torch.amp.GradScaler + torch.optim.Adam exactly (skipped steps do not advance Adam's step count)."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "grad_scaler.npz"))
+    dims, P, batch, _ = load_case("hulc_tiny")
+    eng = _engine(dims, 2, 4, "fp32")             # the scaler is independent of the compute type; fp32 keeps the Adam comparison tight
+    eng.load_numpy(P)
+    names = sorted({k.split("/")[0] for k in fx.files})
+    assert len(names) == 3
+    for name in names:
+        s0, gf, bf, gi, n, _seed = fx[f"{name}/cfg"]
+        eng.scaler_enable(init_scale=float(s0), growth_factor=float(gf), backoff_factor=float(bf), growth_interval=int(gi))
+        eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_t = 0
+        eng.flat_params[:257] = torch.from_numpy(fx[f"{name}/p0"]).cuda()
+        infs = set(int(i) for i in fx[f"{name}/inf_steps"])
+        skipped = 0
+        for t in range(int(n)):
+            scale = eng.scaler_state()["scale"]
+            eng.flat_grads.zero_()
+            g = torch.from_numpy(fx[f"{name}/grads"][t]).cuda() * scale
+            if t in infs:
+                g[(7 * t) % 257] = float("inf") if t % 2 == 0 else float("nan")
+                skipped += 1
+            eng.flat_grads[:257] = g
+            eng.adam_step()
+            st = eng.scaler_state()
+            assert st["scale"] == float(fx[f"{name}/scales"][t]), (name, t, st)
+            assert st["growth_tracker"] == int(fx[f"{name}/trackers"][t]), (name, t, st)
+            assert st["skipped_steps"] == skipped and st["last_found_inf"] == int(t in infs)
+            got = eng.flat_params[:257].cpu().numpy()
+            np.testing.assert_allclose(got, fx[f"{name}/params"][t], rtol=2e-6, atol=2e-7, err_msg=f"{name} step {t}")
+    eng.scaler_enable(init_scale=0.0)             # off again: plain Adam
+    assert eng.scaler_state()["scale"] == 1.0
+    eng.close()
+
+
+def test_fp16_overflow_skips_step_and_backs_off():
+    dims, P, batch, fx = load_case("hulc_tiny")
+    eng = _engine(dims, 2, 4, "fp16")
+    eng.load_numpy(P)
+    eng.scaler_enable(init_scale=2.0 ** 40)       # far beyond fp16 range for the decoder gradients: every step overflows at first
+    p0 = eng.flat_params.clone()
+    m0 = eng.adam_m.clone()
+    nskip = 0
+    for it in range(48):
+        tot, _ = run_step(eng, batch)
+        assert abs(tot - float(fx["loss_total"])) <= 3e-3 * abs(float(fx["loss_total"]))   # the forward never sees the scale
+        eng.adam_step()
+        st = eng.scaler_state()
+        if st["last_found_inf"]:
+            nskip += 1
+            assert torch.equal(p0, eng.flat_params) and torch.equal(m0, eng.adam_m)        # skipped: nothing moved
+            assert st["scale"] == 2.0 ** (40 - nskip) and st["growth_tracker"] == 0
+        else:
+            break
+    assert 1 <= nskip < 48 and st["skipped_steps"] == nskip
+    assert not torch.equal(p0, eng.flat_params)                                            # first finite step was taken
+    assert np.isfinite(eng.flat_params.cpu().numpy()).all()
+    eng.close()
+
+
+def test_fp16_gemm_kernels():
+    """hulc_k_gemm_nt with HULC_DTYPE_F16: the fp16 build of the LDS-DMA and register-staged GEMM kernels vs fp64."""
+    from hulc_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for (M, N, K, force) in [(70, 50, 72, 0), (1030, 260, 64, 0), (1024, 256, 512, 0), (1024, 256, 512, 4), (64, 2048, 2048, 0)]:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Bm = (rng.standard_normal((N, K)) + np.arange(N)[:, None] * 0.01).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        a = torch.from_numpy(A).cuda().to(torch.float16).contiguous()
+        b = torch.from_numpy(Bm).cuda().to(torch.float16).contiguous()
+        ref = np.maximum(a.float().cpu().numpy().astype(np.float64) @ b.float().cpu().numpy().astype(np.float64).T + bias, 0)
+        c = torch.zeros(M, N, device="cuda")
+        bd = torch.from_numpy(bias).cuda()
+        L.check(lib.hulc_k_gemm_nt(L.DTYPE["fp16"], a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, K, K, N, bd.data_ptr(), 1 | force, None))
+        torch.cuda.synchronize()
+        err = np.abs(c.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err < 2e-5, (M, N, K, force, err)          # operands already fp16-exact: only fp32 accumulation order differs
+
+
+def test_module_precision_16_selects_fp16():
+    from hulc_amd.hulc import Hulc
+    m = Hulc(precision=16, max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
+    assert m.precision == "fp16" and m.engine.dtype == "fp16"
+    assert m.engine.scaler_state()["scale"] == 65536.0
+    sd = m.configure_optimizers()["optimizer"].state_dict()
+    assert sd["grad_scaler"] == dict(scale=65536.0, _growth_tracker=0)
+    m.engine.close()
+    m2 = Hulc(precision="bf16", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
+    assert m2.engine.dtype == "bf16" and "grad_scaler" not in m2.configure_optimizers()["optimizer"].state_dict()
+    m2.engine.close()

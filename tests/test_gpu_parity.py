@@ -8,7 +8,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 import hulc_oracle as O  # noqa: E402
-from golden_util import CASES, adam_close, check_grads, grad_entries, load_case, rel_l2, sample_idx  # noqa: E402
+from golden_util import CASES, FP32_NOISY, adam_close, check_grads, check_grads64, grad_entries, load_case, rel_l2, sample_idx  # noqa: E402
 
 
 def _engine(dims, B, S, dtype, dropout=0.0, **kw):
@@ -78,10 +78,16 @@ def test_fp32_step_matches_oracle_and_reference(name):
         assert np.array_equal(eng.plan_idx(B), batch[sc]["plan_idx"])
     # gradients: vs oracle (tight) and vs the reference fixture entries
     Gg = grads_np(eng)
-    worst = max(rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6)
-    assert worst < 1e-2, worst
-    assert np.median([rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6]) < 2e-4
-    check_grads(Gg, fx, tol_l2=1e-2, tol_norm=5e-3, label=name)
+    errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    noisy = lambda n: any(n.endswith(x) for x in FP32_NOISY)      # conv weight / bias sums: fp32 accumulation-order + ReLU-flip limited (golden_util)
+    worst = max((e, n) for n, e in errs.items() if not noisy(n))
+    worst_noisy = max((e, n) for n, e in errs.items() if noisy(n))
+    assert worst[0] < 1e-3, worst
+    assert worst_noisy[0] < 5e-3, worst_noisy
+    assert np.median(list(errs.values())) < 2e-4
+    check_grads(Gg, fx, tol_l2=1e-2, tol_norm=5e-3, label=name)          # the reference's own fp32 gradients (noisy themselves)
+    w64, wn64 = check_grads64(Gg, fx, label=name)                         # its float64 gradients: 1e-3 / 5e-3 for the named conv tensors
+    print(f"[{name}] HIP fp32 grads: vs oracle worst {worst[0]:.2e} ({worst[1]}) noisy {worst_noisy[0]:.2e}; vs fp64 reference worst {w64[0]:.2e} ({w64[1]}) noisy {wn64[0]:.2e} ({wn64[1]})")
     for key in fx.files:
         if key.startswith("gradnone/"):
             assert not np.any(Gg[key[len("gradnone/"):]])

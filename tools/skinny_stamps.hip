@@ -6,7 +6,7 @@
 #include <algorithm>
 int main() {
     const int M = 64, N = 2048, K = 2048;
-    bf16_t *A, *W, *O;
+    h16_t *A, *W, *O;
     hipMalloc(&A, (size_t)33 * M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&O, (size_t)M * N * 2);
     hipMemset(A, 0, (size_t)33 * M * K * 2); hipMemset(W, 0, (size_t)N * K * 2);
     EpiP ep; 
