@@ -200,7 +200,17 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
                      int32_t OUTH, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvTileP p{}; p.img = (const h16_t*)img; p.IMH = p.IMW = IMH; p.w = (const h16_t*)w; p.out = (h16_t*)out; p.OUTH = p.OUTW = OUTH;
-    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & ~1; p.Nf = Nf;
+    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & 30; p.Nf = Nf;
+    // modes 7..9 = the production forms: 7 = mode 1 that also EMITS the ReLU bitmask of its output into `mask` (unsigned[Nf][OUTH][OUTW][2]);
+    // 8 / 9 = modes 2 / 3 with `mask` = ReLU bitmask words (2 / 1 per output pixel) staged through LDS.  relu bit 5 (32): dynamic work claiming.
+    if (mode == 7) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 1; }
+    else if (mode == 8 || mode == 9) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode -= 6; }
+    if (relu & 32) {
+        static int* ctr = nullptr;
+        if (!ctr && hipMalloc(&ctr, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; }
+        hipMemsetAsync(ctr, 0, 256, st);
+        p.work_ctr = ctr;
+    }
     bool ok = false;
     if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);

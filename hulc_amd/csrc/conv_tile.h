@@ -23,7 +23,8 @@ struct ConvTileP {
     h16_t* out; int OUTH, OUTW;
     const float* bias;
     const h16_t* mask;
-    const unsigned* maskbits; // CN <= 32 only: one word per output pixel, bit c = (layer input channel c > 0) — 16x fewer mask bytes than `mask`
+    const unsigned* maskbits; // CN/32 words per output pixel, bit c%32 of word c/32 = (layer input channel c > 0) — 16x fewer mask bytes than `mask`;
+                             // staged through LDS with the band, so the multiply loop issues no global loads (the next band's prefetch stays in flight)
     int relu;
     int dbg;                 // bench ablation: bit 1 = skip the MFMA/epilogue phase, bit 2 = skip the global prefetch loads
     int Nf, RB, nbands, LW, LR;
@@ -31,6 +32,8 @@ struct ConvTileP {
     int* work_ctr;           // optional zero-initialised device counter: items beyond the first round are CLAIMED (atomicAdd) instead of strided,
                              // so a workgroup that starts late (CUs held by an overlapped RCCL collective) takes less work instead of
                              // doubling the kernel's time
+    unsigned* bits_out;      // forward, CN == 64, relu: also emit the ReLU bitmask of the output, 2 words per pixel (bit c of word c/32 = out channel c > 0)
+                             // = what the dgrad of this layer's consumer reads as `maskbits` instead of the 16-bit activations (64x fewer bytes)
 };
 
 // ds_read_b128 is serviced in four fixed 16-lane groups, each mixing lanes of two k-chunk groups g (MI355X_MICROARCH.md §LDS):
@@ -53,11 +56,19 @@ struct ConvTileCfg {
     static constexpr int NT = CN / 16;
     static constexpr int PF = 10;                              // prefetch registers (uint4) per thread
     static constexpr int MT = (CN / 16 <= 2) ? 4 : 2;          // m-tiles (16 pixels) per wave pass: LDS reads per MFMA = (MT+NT)/(MT*NT)
-    static size_t w_bytes() { return (size_t)NCLS * CN * WS; }
+    static constexpr size_t w_bytes() { return (size_t)NCLS * CN * WS; }
     // the band is stored as SI row planes (window row wr -> plane wr % SI, row wr / SI) so that the pixels of consecutive OUTPUT
     // rows are LP apart for every tap: pixel(pi, tap) = pi*SI + plane/row/col offset of the tap
-    static size_t lds_bytes(int LR, int LP) { return w_bytes() + (size_t)(SI * ((LR + SI - 1) / SI) * LP) * XS; }
+    static constexpr int WPP = (CN + 31) / 32;                 // mask words per output pixel
+    static constexpr int MAXMW = 2048;                         // mask words staged per band (one 16-byte register per thread)
+    static constexpr size_t band_bytes(int LR, int LP) { return ((size_t)(SI * ((LR + SI - 1) / SI) * LP) * XS + 15) / 16 * 16; }
+    static constexpr size_t lds_bytes(int LR, int LP) { return w_bytes() + band_bytes(LR, LP) + CN * 4 + MAXMW * 4 + 16; }
 };
+
+// x / d for 0 <= x < 2^16, 1 <= d <= 64 with inv = 1.f / d: (x + 0.5) / d is at least 0.5 / d away from an integer, far beyond the fp32
+// rounding error of the product — 3 VALU instructions instead of the ~40 of a runtime integer division (the band staging and m-tile
+// index maths below ran ~2 800 VALU cycles per band per SIMD on divisions alone: 1.2 us of a 7 us band)
+DEVI int fast_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
 __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
@@ -65,6 +76,8 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* wl = (lds_char*)smem;
     lds_char* xl = wl + C::NCLS * CN * C::WS;
+    lds_char* bl = xl + C::band_bytes(p.LR, p.LP);              // bias[CN] fp32
+    lds_char* ml = bl + CN * 4;                                 // mask words of the current band
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     // ---- weights -> LDS (once).  LDS row nn*16 + t of a class holds channel (t>>2)*4*NT + nn*4 + (t&3): after the MFMA lane
@@ -77,12 +90,20 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             const int ch = (t >> 2) * 4 * C::NT + nn * 4 + (t & 3);
             *(lds_u32x4*)(wl + r * C::WS + c * 16) = *reinterpret_cast<const u32x4_t*>(p.w + (long long)(cls * CN + ch) * (TA * TB * CK) + c * 8);
         }
+        if (tid < CN) *(__attribute__((address_space(3))) float*)(bl + tid * 4) = p.bias ? p.bias[tid] : 0.f;
     }
     const int nitems = p.Nf * p.nbands;
     const int wchunks = p.LR * p.LW * C::CH;
     const int Q = p.LP / SI;                                    // m-index pitch (band pixels per output row)
     const int PLR = (p.LR + SI - 1) / SI;                       // rows per LDS row plane
-    u32x4_t pf[C::PF];
+    const float invLW = 1.f / (float)p.LW, invQ = 1.f / (float)Q;
+    // ---- prefetch of a band into registers: UNCONDITIONAL loads from clamped addresses; the zero border is applied when the band is
+    // committed to LDS (pin bit k), and the multiply loop below issues no global load at all — so nothing forces a wait on these loads
+    // before the MFMAs and the next band's HBM latency hides under the current band's multiply phase.
+    u32x4_t pf[C::PF], pfm;
+    unsigned pin = 0;
+    int mwords = 0;                                             // mask words of the prefetched band
+    typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
     auto prefetch = [&](int item) {
         if (p.dbg & 4) return;
         const int f = item / p.nbands, b = item % p.nbands;
@@ -90,18 +111,25 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         const int rlo = REV ? i0 - (TA - 1) : i0 * SI;
         const int clo = REV ? -(TB - 1) : 0;
         const h16_t* base = p.img + (long long)f * p.IMH * p.IMW * CK;
+        pin = 0;
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             const int q = tid + k * 512;
             const int qc = min(q, wchunks - 1);
             const int pix = qc / C::CH, c = qc % C::CH;
-            const int wr = pix / p.LW, wc = pix % p.LW;
+            const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
             const int ir = rlo + wr, ic = clo + wc;
             const bool in = ir >= 0 && ir < p.IMH && ic >= 0 && ic < p.IMW;
             const int irc = min(max(ir, 0), p.IMH - 1), icc = min(max(ic, 0), p.IMW - 1);
-            u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + ((long long)irc * p.IMW + icc) * CK + c * 8);   // always-valid address
-            if (!in) v = u32x4_t{0u, 0u, 0u, 0u};
-            pf[k] = v;
+            pf[k] = *reinterpret_cast<const u32x4_t*>(base + ((long long)irc * p.IMW + icc) * CK + c * 8);   // always-valid address
+            pin |= (in ? 1u : 0u) << k;
+        }
+        if (p.maskbits) {                                       // ReLU bitmask rows of the band's output rows [i0*OS, (i0+RB)*OS)
+            const int r0 = i0 * OS, r1 = min((i0 + p.RB) * OS, p.OUTH);
+            mwords = max(0, r1 - r0) * p.OUTW * C::WPP;
+            const long long mb = ((long long)f * p.OUTH + r0) * p.OUTW * C::WPP;
+            const int mo = min(tid * 4, max(mwords - 4, 0));    // clamped: the last thread(s) re-read valid words (their LDS slot is unused)
+            pfm = *reinterpret_cast<const u32x4_a4*>(p.maskbits + mb + mo);
         }
     };
     // LDS byte offset of this thread's k-th staged chunk (band-invariant)
@@ -110,7 +138,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     for (int k = 0; k < C::PF; ++k) {
         const int q = min(tid + k * 512, wchunks - 1);
         const int pix = q / C::CH, c = q % C::CH;
-        const int wr = pix / p.LW, wc = pix % p.LW;
+        const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
         soff[k] = (((wr % SI) * PLR + wr / SI) * p.LP + wc) * C::XS + c * 16;
     }
     __shared__ int s_next[2];
@@ -121,7 +149,16 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         __syncthreads();                                        // previous band fully consumed (and weights visible)
 #pragma unroll
         for (int k = 0; k < C::PF; ++k)
-            if (tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = pf[k];
+            if (tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = ((pin >> k) & 1u) ? pf[k] : u32x4_t{0u, 0u, 0u, 0u};
+        if (p.maskbits && tid * 4 < mwords) {
+            if (tid * 4 + 4 <= mwords) *(lds_u32x4*)(ml + tid * 16) = pfm;
+            else {                                              // ragged tail: the clamped load holds words [mwords-4, mwords)
+                const int sh = tid * 4 - max(mwords - 4, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e + sh < 4) *(__attribute__((address_space(3))) unsigned*)(ml + (tid * 4 + e) * 4) = pfm[e + sh];
+            }
+        }
         __syncthreads();
         const int cur = item;
         item = p.work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
@@ -157,34 +194,22 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             const int pbase = REV ? (TA - 1) * p.LP + (TB - 1) : 0;
             int xoff[C::MT];
             int opix[C::MT];                                    // output pixel offset (elements / CN) or -1
+            int moff[C::MT];                                    // LDS byte offset of the pixel's mask word for this lane's channels
 #pragma unroll
             for (int mm = 0; mm < C::MT; ++mm) {
                 const int pi = (mt0 + mm) * 16 + li;
-                const int ri = pi / Q, j = pi - ri * Q;
+                const int ri = fast_div(pi, invQ), j = pi - ri * Q;
                 const bool ok = pi < npi && j < NJ;
                 xoff[mm] = (min(pi, last) * SI + pbase) * C::XS + g * 16;
                 opix[mm] = ok ? (((i0 + ri) * OS + ph) * p.OUTW + j * OS + pw) : -1;
+                moff[mm] = ok ? (((ri * OS + ph) * p.OUTW + j * OS + pw) * C::WPP + (C::WPP == 2 ? (g >> 1) : 0)) * 4 : 0;
             }
             f32x4 acc[C::MT][C::NT];
 #pragma unroll
             for (int mm = 0; mm < C::MT; ++mm)
 #pragma unroll
                 for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // mask (dgrad: ReLU mask of the layer input) fetched now, consumed in the epilogue -> its HBM latency hides behind the MFMAs
             constexpr int EW = C::NT / 2;                       // 16-byte words per pixel per lane (lane owns 4*NT consecutive channels)
-            u32x4_t mk[C::MT][EW];
-            unsigned mkw[C::MT];
-            if (p.maskbits) {
-#pragma unroll
-                for (int mm = 0; mm < C::MT; ++mm) mkw[mm] = p.maskbits[(long long)f * p.OUTH * p.OUTW + max(opix[mm], 0)];
-            } else if (p.mask) {
-#pragma unroll
-                for (int mm = 0; mm < C::MT; ++mm) {
-                    const long long ob = ((long long)f * p.OUTH * p.OUTW + max(opix[mm], 0)) * CN + g * 4 * C::NT;
-#pragma unroll
-                    for (int e = 0; e < EW; ++e) mk[mm][e] = *reinterpret_cast<const u32x4_t*>(p.mask + ob + e * 8);
-                }
-            }
             lds_char* wrow = wl + (cls * CN + li) * C::WS + g * 16;
             constexpr int KS = CK / 32, NS = TA * TB * KS;      // k-steps of 32; NS is even for every instantiation
             static_assert(NS % 2 == 0, "pipelined loop handles k-steps in pairs");
@@ -218,13 +243,16 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             float bb[4 * C::NT];
 #pragma unroll
             for (int e = 0; e < C::NT; ++e) {
-                float4 t = p.bias ? *reinterpret_cast<const float4*>(p.bias + g * 4 * C::NT + e * 4) : float4{0.f, 0.f, 0.f, 0.f};
-                bb[e * 4 + 0] = t.x; bb[e * 4 + 1] = t.y; bb[e * 4 + 2] = t.z; bb[e * 4 + 3] = t.w;
+                const f32x4 t = *(__attribute__((address_space(3))) f32x4*)(bl + (g * 4 * C::NT + e * 4) * 4);
+                bb[e * 4 + 0] = t[0]; bb[e * 4 + 1] = t[1]; bb[e * 4 + 2] = t[2]; bb[e * 4 + 3] = t[3];
             }
 #pragma unroll
             for (int mm = 0; mm < C::MT; ++mm) {
-                if (opix[mm] < 0) continue;
-                const long long obase = ((long long)f * p.OUTH * p.OUTW + opix[mm]) * CN + g * 4 * C::NT;
+                unsigned obits = 0;                             // forward: ReLU bitmask of this lane's 4*NT channels
+                unsigned mkw = 0;
+                if (p.maskbits) mkw = *(__attribute__((address_space(3))) unsigned*)(ml + moff[mm]);
+                const long long opx = (long long)f * p.OUTH * p.OUTW + max(opix[mm], 0);
+                const long long obase = opx * CN + g * 4 * C::NT;
 #pragma unroll
                 for (int e = 0; e < EW; ++e) {
                     float v[8];
@@ -236,19 +264,27 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                     }
                     if (p.maskbits) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = ((mkw[mm] >> ((g * 4 * C::NT + e * 8 + r) & 31)) & 1u) ? v[r] : 0.f;
-                    } else if (p.mask) {
+                        for (int r = 0; r < 8; ++r) v[r] = ((mkw >> ((g * 4 * C::NT + e * 8 + r) & 31)) & 1u) ? v[r] : 0.f;
+                    } else if (p.mask) {                        // 16-bit mask values (per-kernel tests): loaded here, drains the prefetch
+                        const u32x4_t mk = *reinterpret_cast<const u32x4_t*>(p.mask + obase + e * 8);
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const unsigned wd = mk[mm][e][r >> 1];
-                            const h16_t mb = (h16_t)((r & 1) ? (wd >> 16) : (wd & 0xffff));
-                            v[r] = h2f(mb) > 0.f ? v[r] : 0.f;
-                        }
+                        for (int r = 0; r < 8; ++r) v[r] = ((r & 1) ? h2f_hi(mk[r >> 1]) : h2f_lo(mk[r >> 1])) > 0.f ? v[r] : 0.f;
                     }
                     u32x4_t o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = pack2h(v[2 * r], v[2 * r + 1]);
-                    *reinterpret_cast<u32x4_t*>(p.out + obase + e * 8) = o;
+                    if (opix[mm] >= 0) *reinterpret_cast<u32x4_t*>(p.out + obase + e * 8) = o;
+                    if constexpr (!REV && CN == 64) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) obits |= (((o[r] & 0xffffu) ? 1u : 0u) | ((o[r] >> 16) ? 2u : 0u)) << (e * 8 + 2 * r);
+                    }
+                }
+                if constexpr (!REV && CN == 64) {
+                    if (p.bits_out) {                           // lanes (li, g = 0..3) of a pixel: g pairs form one 32-bit word
+                        unsigned w = obits << ((g & 1) * 16);
+                        w |= __shfl_xor(w, 16);
+                        if (opix[mm] >= 0 && (g & 1) == 0) p.bits_out[opx * 2 + (g >> 1)] = w;
+                    }
                 }
             }
         }
@@ -270,6 +306,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
         const int RB = (NI + nb - 1) / nb;
         const int LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA;
         if ((long long)LR * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LR, p.LP) > 160 * 1024 - 64) continue;   // 64 B left for the kernel's static __shared__ (work-claim slots)
+        if (p.maskbits && (long long)RB * OS * p.OUTW * C::WPP > C::MAXMW) continue;                                   // the band's mask rows travel in one register per thread
         double cost = 0.25 * nb;                                   // per-band barrier / staging overhead, in units of one wave round
         for (int b = 0; b < nb; ++b) {
             int groups = 0;

@@ -91,7 +91,7 @@ struct Engine : IEngine {
     std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0;
 
     // ---- workspace (per modality pass)
-    struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; } aS, aG;
+    struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; unsigned* m2bits = nullptr; } aS, aG;
     T *dact1, *dact2, *dact3, *d_g0, *d_f1, *d_f2t; float* d_ss;
     T *emb, *lang_t, *gl1, *gl2, *goal_t, *ppx, *ppa[4], *xm, *seqf_t, *embg, *Cb, *Zx0, *Zx1, *H0, *H1, *dheads, *dH1, *dZ1, *dH0, *dZ0, *dC;
     float *gl3, *goal_st, *pp_logits, *seqf, *pr_logits, *probs, *klcat, *dpp_kl, *dpr_kl, *Cplan, *heads, *rowloss, *a_tcp;
@@ -140,6 +140,7 @@ struct Engine : IEngine {
         static const bool use_bits = getenv("HULC_MASKBITS") ? atoi(getenv("HULC_MASKBITS")) != 0 : true;
         a.m1bits = (use_bits && std::is_same<T, h16_t>::value) ? alloc<unsigned>((int64_t)maxN * H1 * H1) : nullptr;   // ReLU bitmask of a1 (conv2 dgrad)
         a.a2 = alloc<T>((int64_t)maxN * H2 * H2 * 64, (s + "a2").c_str());
+        a.m2bits = (use_bits && std::is_same<T, h16_t>::value) ? alloc<unsigned>((int64_t)maxN * H2 * H2 * 2) : nullptr;   // ReLU bitmask of a2 (conv3 dgrad), emitted by conv2's forward
         a.a3 = alloc<T>((int64_t)maxN * H3 * H3 * 64, (s + "a3").c_str());
         a.ss = gripper ? nullptr : alloc<T>((int64_t)maxN * 128, (s + "ss").c_str());
         a.ssstats = gripper ? nullptr : alloc<float>((int64_t)maxN * 64 * 4);
@@ -600,7 +601,7 @@ struct Engine : IEngine {
         }
         bool tiled = false;
         if constexpr (std::is_same<T, h16_t>::value) {   // raw-tile kernels (conv_tile.h): weights resident in LDS, bands streamed once
-            ConvTileP p2{}; p2.img = a.a1; p2.IMH = p2.IMW = e.H1; p2.w = e.c2.Wf; p2.out = a.a2; p2.OUTH = p2.OUTW = e.H2; p2.bias = e.c2.b32; p2.relu = 1; p2.Nf = Nf;
+            ConvTileP p2{}; p2.img = a.a1; p2.IMH = p2.IMW = e.H1; p2.w = e.c2.Wf; p2.out = a.a2; p2.OUTH = p2.OUTW = e.H2; p2.bias = e.c2.b32; p2.relu = 1; p2.Nf = Nf; p2.bits_out = a.m2bits;
             ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
             const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
             TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
@@ -669,7 +670,7 @@ struct Engine : IEngine {
     }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
         if constexpr (std::is_same<T, h16_t>::value) {
-            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = mask; p.maskbits = (c.I <= 32) ? maskbits : nullptr; p.Nf = g.Nf; p.work_ctr = next_ctr();
+            ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = maskbits ? nullptr : mask; p.maskbits = maskbits; p.Nf = g.Nf; p.work_ctr = next_ctr();
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
@@ -731,7 +732,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((permute_cols_kernel<float, float>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, dw7_tmp, e.fc7.dW, 128, 64, 49, 1, 1);
         }
         conv_wgrad(e.c3, dact3, a.a2, g3, false);
-        conv_dgrad(e.c3, dact3, g3, dact2, a.a2);
+        conv_dgrad(e.c3, dact3, g3, dact2, a.a2, a.m2bits);
         conv_wgrad(e.c2, dact2, a.a1, g2, false);
         conv_dgrad(e.c2, dact2, g2, dact1, a.a1, a.m1bits);
         if (!src2) { conv_wgrad(e.c1, dact1, x, g1, true); return; }
@@ -1110,7 +1111,7 @@ struct Engine : IEngine {
     int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang, const int32_t* plan_inject,
                      int32_t* plan_out) override {
         if (!bound) { hulc_set_error("hulc_rollout_plan before hulc_bind_params"); return 1; }
-        if (cfg.kind == HULC_KIND_GCBC) { hulc_set_error("hulc_rollout_plan: the GCBC model kind has no latent plan"); return 1; }
+        const bool gcbc = cfg.kind == HULC_KIND_GCBC;      // gcbc.py:286-320: only the latent goal is encoded (once per rollout), the decoder acts without a plan
         if ((goal_lang != nullptr) == (goal_static != nullptr && goal_gripper != nullptr)) {
             hulc_set_error("hulc_rollout_plan: give either the two goal images or the language embedding");
             return 1;
@@ -1138,14 +1139,15 @@ struct Engine : IEngine {
             sample_cont(pp_logits, nullptr, reinterpret_cast<const float*>(plan_inject), 1, site_seed(50));
             HIP_CHECK(hipMemcpyAsync(roll_plan_c, plan_t, sizeof(T) * (PLAN / 2), hipMemcpyDeviceToDevice, st));
             if (plan_out) HIP_CHECK(hipMemcpyAsync(plan_out, plan_f, sizeof(float) * (PLAN / 2), hipMemcpyDefault, st));
-        } else {
+        } else if (!gcbc) {
         if (plan_inject) { HIP_CHECK(hipMemcpyAsync(pidx_in, plan_inject, sizeof(int) * NCAT, hipMemcpyDefault, st)); inj = pidx_in; }
         hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(NCAT), dim3(64), 0, st, pp_logits, (const float*)nullptr, 1, NCAT, NCLS, inj, roll_plan, probs, klcat, dpp_kl,
                            dpr_kl, 0.f, 0.f, site_seed(50));
         }
         HIP_CHECK(hipMemcpyAsync(roll_goal, goal_t, sizeof(T) * GOAL, hipMemcpyDeviceToDevice, st));
-        roll_has_h = false; roll_has_plan = true;      // action_decoder.clear_hidden_state() (hulc.py:925 / :946)
-        if (plan_out && !mcil) HIP_CHECK(hipMemcpyAsync(plan_out, roll_plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+        if (!gcbc) roll_has_h = false;                 // action_decoder.clear_hidden_state() (hulc.py:925 / :946); GCBC.step never clears it (gcbc.py:286-320)
+        roll_has_plan = true;
+        if (plan_out && !mcil && !gcbc) HIP_CHECK(hipMemcpyAsync(plan_out, roll_plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_plan"); return 1; }
         return 0;

@@ -160,7 +160,20 @@ class Hulc(torch.nn.Module):
                    (_get(distribution, "class_size", 32), 32)]
         chk += [(_get(ad, "n_mixtures", 10), 10), (_get(ad, "hidden_size", 2048), 2048), (_get(ad, "num_layers", 2), 2),
                 (_get(ad, "rnn_model", "rnn_decoder"), "rnn_decoder"), (_get(ad, "policy_rnn_dropout_p", 0.0), 0.0),
-                (_get(visual_goal, "latent_goal_features", 32), 32)]
+                (_get(visual_goal, "latent_goal_features", 32), 32),
+                # options that change the maths and have no built path: action bounds other than +-1 (the engine's bin width is
+                # 1/(num_classes-1), logistic_decoder_rnn.py:157-182), loaded statistics.yaml bounds, the plan-recognition normalisation flags
+                (bool(_get(ad, "load_action_bounds", False)), False), (bool(_get(pr, "encoder_normalize", False)), False),
+                (bool(_get(pr, "positional_normalize", False)), False)]
+        for key, want in (("act_max_bound", 1.0), ("act_min_bound", -1.0)):
+            b = _get(ad, key, None)
+            if b is not None and not isinstance(b, str) and any(float(x) != want for x in np.asarray(b, np.float64).reshape(-1)):
+                raise NotImplementedError(f"action_decoder.{key} {b!r}: the built loss uses bounds of {want:+.0f} on every dimension (conf/datamodule/default.yaml)")
+        if self.KIND != "mcil" and not any(mcil_flags):
+            chk += [(bool(_get(pr, "position_embedding", True)), True)]
+            sl = _get(ad, "perceptual_emb_slice", [64, 128])
+            if sl is not None and not isinstance(sl, str) and [int(x) for x in sl] != [64, 128]:
+                raise NotImplementedError(f"action_decoder.perceptual_emb_slice {sl!r}: the decoder is built on the gripper half [64, 128] (hulc_default.yaml:15)")
         for got, want in chk:
             if got != want:
                 raise NotImplementedError(f"configuration value {got!r} differs from the built architecture ({want!r})")
@@ -195,6 +208,7 @@ class Hulc(torch.nn.Module):
             self._params[n].grad = g
         self.reset_parameters(seed)
         self.logged: Dict[str, float] = {}
+        self._epoch_acc: Dict[str, list] = {}
         self._grads_reduced = False
         self.global_step = 0
         self.rollout_step_counter = 0
@@ -238,6 +252,13 @@ class Hulc(torch.nn.Module):
         unexpected = [k for k in state_dict if k not in self._params and k not in self._buffers_dict()]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        # buffers that parametrise the loss: a checkpoint trained with other bounds would load and run with wrong bin widths
+        for k, want in self._buffers_dict().items():
+            if k in state_dict and any(k.endswith(x) for x in ("action_max_bound", "action_min_bound", "gripper_bounds", "temperature")):
+                got = state_dict[k].detach().to("cpu", torch.float32).reshape(-1)
+                if got.numel() != want.numel() or not torch.allclose(got, want.reshape(-1), atol=1e-6):
+                    raise RuntimeError(f"load_state_dict: buffer {k} = {got[:4].tolist()}... differs from the built-in value {want.reshape(-1)[:4].tolist()}... "
+                                       "(the engine hard-codes action bounds +-1 and spatial-softmax temperature 1)")
         with torch.no_grad():
             for n, p in self._params.items():
                 if n in state_dict:
@@ -261,8 +282,31 @@ class Hulc(torch.nn.Module):
     def eval(self):  # type: ignore[override]
         return self.train(False)
 
-    def log(self, name: str, value, **kw):
-        self.logged[name] = float(value)
+    def log(self, name: str, value, on_step: bool = False, on_epoch: bool = True, batch_size: Optional[int] = None, **kw):
+        """LightningModule.log as the reference uses it (hulc.py:470-536: on_step=False, on_epoch=True, batch_size=b): `logged` keeps the
+        latest value, `epoch_metrics()` the batch-size-weighted mean over the epoch that Lightning reduces at epoch end."""
+        v = float(value)
+        self.logged[name] = v
+        if on_epoch:
+            w = float(batch_size) if batch_size else 1.0
+            acc = self._epoch_acc.setdefault(name, [0.0, 0.0])
+            acc[0] += v * w
+            acc[1] += w
+
+    def epoch_metrics(self, reset: bool = False) -> Dict[str, float]:
+        """Weighted epoch means of every metric logged with on_epoch=True since the last reset, averaged over ranks (sync_dist)."""
+        names = sorted(self._epoch_acc)
+        if not names:
+            return {}
+        if parallel.world_size() > 1:
+            t = torch.tensor([[self._epoch_acc[n][0], self._epoch_acc[n][1]] for n in names], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t)
+            sums = {n: (float(t[i, 0]), float(t[i, 1])) for i, n in enumerate(names)}
+        else:
+            sums = {n: tuple(self._epoch_acc[n]) for n in names}
+        if reset:
+            self._epoch_acc = {}
+        return {n: s / max(w, 1e-30) for n, (s, w) in sums.items()}
 
     def set_kl_beta(self, kl_beta):
         """hulc.py:563-565 — called by the KL-schedule callbacks."""
@@ -289,8 +333,14 @@ class Hulc(torch.nn.Module):
     def _modality_batch(dataset_batch: Dict[str, Any], is_lang: bool, device) -> Dict[str, Any]:
         """Reference batch dict (hulc.py:395-414) -> engine inputs."""
         f = lambda t: t.to(device=device, dtype=torch.float32, non_blocking=True)
-        mb = dict(rgb_static=f(dataset_batch["rgb_obs"]["rgb_static"]), rgb_gripper=f(dataset_batch["rgb_obs"]["rgb_gripper"]),
+        # uint8 (B,S,H,W,3) dataset frames take the fused ingest path (scale / normalise / RandomShiftsAug inside conv1, include/hulc_hip.h
+        # frames_u8) and must NOT be cast: a float copy of 0..255 values would be fed unnormalised
+        img = lambda t: t.to(device=device, non_blocking=True) if t.dtype == torch.uint8 else f(t)
+        mb = dict(rgb_static=img(dataset_batch["rgb_obs"]["rgb_static"]), rgb_gripper=img(dataset_batch["rgb_obs"]["rgb_gripper"]),
                   actions=f(dataset_batch["actions"]), robot_obs=f(dataset_batch["state_info"]["robot_obs"]))
+        for k in ("shift_static", "shift_gripper", "pad_static", "pad_gripper"):       # optional RandomShiftsAug draws of the ingest path
+            if dataset_batch.get(k) is not None:
+                mb[k] = dataset_batch[k].to(device=device) if torch.is_tensor(dataset_batch[k]) else dataset_batch[k]
         if is_lang:
             mb["lang"] = f(dataset_batch["lang"])            # KeyError 'lang' like the reference (hulc.py:440)
             m = dataset_batch["use_for_aux_lang_loss"]
@@ -351,7 +401,7 @@ class Hulc(torch.nn.Module):
         total = tot / nmod
         if self.use_clip_auxiliary_loss:
             total = total + self.clip_auxiliary_loss_beta * clip
-            self.log("train/lang_clip_loss", parallel.mean_scalar(self.clip_auxiliary_loss_beta * clip), on_step=False, on_epoch=True, sync_dist=True)
+            self.log("train/lang_clip_loss", parallel.mean_scalar(self.clip_auxiliary_loss_beta * clip, device=eng.device), on_step=False, on_epoch=True, sync_dist=True)
         if self.kind != "gcbc":
             self.log("train/kl_loss", kl / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
         self.log("train/action_loss", act / nmod, on_step=False, on_epoch=True, batch_size=total_bs)
@@ -466,3 +516,37 @@ class GCBC(Hulc):
     loss = action loss (+ CLIP aux), plan_proposal.* and plan_recognition.fc_state.* never receive a gradient."""
 
     KIND = "gcbc"
+
+    def reset(self):
+        """gcbc.py:281-285: only the latent goal is dropped — the decoder's hidden state is NOT cleared by the reference's GCBC
+        (LogisticDecoderRNN.act keeps self.hidden_state, and nothing in gcbc.py calls clear_hidden_state); mirrored here."""
+        self.latent_goal = None
+
+    def step(self, obs, goal, noise: Optional[Dict] = None):
+        """gcbc.py:287-320: encode the goal once per rollout (language embedding, or obs + goal frame as one 2-frame window through the
+        visual goal encoder), then one stateful decoder step without a plan per call."""
+        noise = noise or {}
+        o = self._rollout_obs(obs)
+        if self.latent_goal is None:
+            if isinstance(goal, str):
+                if self.lang_embeddings is None:
+                    raise RuntimeError("call load_lang_embeddings() before stepping with a language goal (hulc.py:871)")
+                g = torch.from_numpy(np.asarray(self.lang_embeddings[goal], np.float32)).reshape(-1)
+            else:
+                g = dict(rgb_static=goal["rgb_obs"]["rgb_static"], rgb_gripper=goal["rgb_obs"]["rgb_gripper"])
+            self.engine.rollout_plan(o, g)
+            self.latent_goal = True
+        action = self.engine.rollout_act(o, u_mix=noise.get("u_mix"), u_act=noise.get("u_act"))
+        return torch.from_numpy(action).reshape(1, 1, 7)
+
+
+def initialize_pretrained_weights(model: Hulc, cfg) -> None:
+    """hulc/utils/utils.py:7-16: load `cfg.pretrain_chk` non-strictly; the position-embedding table is trimmed to this model's window
+    (load_state_dict does the row trimming), `pretrain_exclude_pr` drops every plan_recognition.* tensor first."""
+    ck = torch.load(str(_get(cfg, "pretrain_chk")), map_location="cpu", weights_only=False)
+    sd = dict(ck["state_dict"])
+    if _get(cfg, "pretrain_exclude_pr", False):
+        for key in list(sd.keys()):
+            if key.startswith("plan_recognition"):
+                del sd[key]
+    model.load_state_dict(sd, strict=False)

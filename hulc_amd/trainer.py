@@ -94,6 +94,10 @@ class KLSigmoidSchedule(KLLinearSchedule):
     """kl_callbacks.py:39-59: sigmoid ramp between start and end epoch."""
 
     def _beta(self, epoch):
+        if epoch < self.start:                 # kl_callbacks.py:41-44: exactly 0 before the ramp, exactly max after it
+            return 0.0
+        if epoch > self.end:
+            return self.max
         x = (epoch - self.start) / max(1, (self.end - self.start))
         return self.max / (1.0 + math.exp(-(12.0 * x - 6.0)))
 
@@ -114,7 +118,8 @@ def save_checkpoint(path, module, optimizer, epoch, global_step):
     """Lightning-style checkpoint dict; `state_dict` keys are the reference's."""
     torch.save({"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in module.state_dict().items()},
                 "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()}],
-                "hyper_parameters": {"kind": module.KIND, "use_clip_auxiliary_loss": module.use_clip_auxiliary_loss}}, path)
+                "hyper_parameters": {"kind": module.kind, "use_clip_auxiliary_loss": module.use_clip_auxiliary_loss, "precision": module.precision,
+                                     "rnn_type": module.dims.rnn_type, "max_window": module.dims.max_window}}, path)
 
 
 def get_last_checkpoint(log_dir: str) -> Optional[str]:
@@ -137,6 +142,7 @@ class Trainer:
         self.rank, self.world, self.local = 0, 1, 0
         self.optimizer = None
         self.history: List[Dict[str, float]] = []
+        self.epoch_history: List[Dict[str, float]] = []
 
     def validate(self, module, datamodule) -> Dict[str, float]:
         """Lightning's validation loop for this module: eval mode, validation_step over the val batches, mean of every `val*` metric."""
@@ -164,6 +170,12 @@ class Trainer:
         self.optimizer, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
         if ckpt_path:
             ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+            hp = ck.get("hyper_parameters") or {}
+            if hp.get("kind", module.kind) != module.kind or hp.get("rnn_type", module.dims.rnn_type) != module.dims.rnn_type:
+                raise RuntimeError(f"checkpoint {ckpt_path} holds a {hp.get('kind')!r} ({hp.get('rnn_type')}) model, this run builds {module.kind!r} "
+                                   f"({module.dims.rnn_type}): refusing to resume (pass a fresh log_dir or the matching model= option)")
+            if self.rank == 0:
+                print(f"[hulc_amd] resuming from {ckpt_path} (epoch {ck.get('epoch')}, global_step {ck.get('global_step')})", flush=True)
             module.load_state_dict(ck["state_dict"])
             self.optimizer.load_state_dict({k: (v.to(module.device) if torch.is_tensor(v) else v) for k, v in ck["optimizer_states"][0].items()})
             self.current_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
@@ -191,6 +203,12 @@ class Trainer:
                     break
             if (self.current_epoch + 1) % self.check_val_every_n_epoch == 0 and self.limit_val_batches != 0 and not done:
                 self.validate(module, datamodule)                             # Lightning: validation loop at the end of the epoch
+            # Lightning reduces `on_step=False, on_epoch=True` metrics at the end of the epoch: batch-size weighted means (hulc.py:470-536)
+            if hasattr(module, "epoch_metrics"):
+                em = module.epoch_metrics(reset=True)
+                self.epoch_history.append(dict(epoch=self.current_epoch, **em))
+                if self.rank == 0 and em:
+                    print(f"[hulc_amd] epoch {self.current_epoch} means: " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(em.items()) if k.startswith("train/")), flush=True)
             for cb in self.callbacks:
                 if hasattr(cb, "on_train_epoch_end"):
                     cb.on_train_epoch_end(self, module)

@@ -25,10 +25,28 @@ def train(overrides=None, conf_dir: str = CONF_DIR):
     device = f"cuda:{local}"
     dm = config.instantiate({k: v for k, v in cfg.datamodule.items() if k not in ("root_data_dir", "action_space", "action_max", "action_min")},
                             device=device, seed=cfg.seed)
-    chk = get_last_checkpoint(cfg.log_dir)               # resume like training.py:38-46
+    # The reference runs inside a fresh timestamped Hydra directory (conf/config.yaml hydra.run.dir) and resumes from the newest
+    # checkpoint found THERE (training.py:38-46), i.e. only when the same run directory is re-entered.  Here: log_dir may contain
+    # "{now}" (expanded once on rank 0, then shared); the default conf writes runs/<date>/<time>; `resume=true` or an explicit
+    # `log_dir=<existing run>` re-enters a run.
+    log_dir = str(cfg.log_dir)
+    if "{now}" in log_dir:
+        import time as _t
+        stamp = _t.strftime("%Y-%m-%d/%H-%M-%S")
+        if world > 1:
+            import torch.distributed as dist
+            box = [stamp]
+            dist.broadcast_object_list(box, src=0)
+            stamp = box[0]
+        log_dir = log_dir.replace("{now}", stamp)
+    cfg.log_dir = log_dir
+    chk = get_last_checkpoint(log_dir)                   # resume like training.py:38-46 (a fresh {now} directory holds none)
     if "lang" not in cfg.datamodule.get("modalities", ["vis", "lang"]):
         cfg.model.use_clip_auxiliary_loss = False        # SURVEY trap T4
     model = config.instantiate(cfg.model, device=device, max_seq_len=cfg.datamodule.max_window_size)
+    if chk is None and cfg.get("pretrain_chk"):          # training.py:45-46 -> hulc/utils/utils.py:7-16
+        from .hulc import initialize_pretrained_weights
+        initialize_pretrained_weights(model, cfg)
     callbacks = [config.instantiate(c) for c in cfg.callbacks.values() if isinstance(c, dict) and "_target_" in c]
     tr = Trainer(max_epochs=cfg.trainer.max_epochs, max_steps=cfg.trainer.get("max_steps", -1), log_dir=cfg.log_dir, callbacks=callbacks)
     hist = tr.fit(model, dm, ckpt_path=chk)

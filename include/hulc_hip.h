@@ -165,7 +165,9 @@ int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* 
  * hulc_rollout_plan  = get_pp_plan_vision (:905-927: obs and goal frame encoded as one 2-frame window) or get_pp_plan_lang
  *                      (:929-948): latent goal + a plan sampled from the plan proposal; clears the decoder's hidden state.
  * hulc_rollout_act   = predict_with_plan (:881-903): encode the current frame, one recurrent step, sample, tcp -> world.
- * The replan_freq counter lives in the host wrapper (hulc_amd.hulc.Hulc.step).  B = 1. */
+ * The replan_freq counter lives in the host wrapper (hulc_amd.hulc.Hulc.step).  B = 1.
+ * HULC_KIND_GCBC (GCBC.reset / step, hulc/models/gcbc.py:281-320): hulc_rollout_plan only encodes the latent goal (once per rollout,
+ * plan_idx_* ignored), hulc_rollout_act runs the decoder without a plan. */
 typedef struct hulc_rollout_obs {
     const float* rgb_static;     /* (1,1,3,200,200) device */
     const float* rgb_gripper;    /* (1,1,3,84,84)   device */
@@ -223,7 +225,10 @@ int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* hip_stream);
 /* raw-tile conv kernels alone (bf16 NHWC, square frames): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of
  * (1). img side IMH, out side OUTH; w = packed weights as produced by hulc_prepare_weights (fwd [co][(kh,kw,ci)], dgrad per-parity
- * [class][ci][(a,b,co)]); bias fp32 / mask bf16 optional. Asynchronous on hip_stream. */
+ * [class][ci][(a,b,co)]); bias fp32 / mask bf16 optional. Asynchronous on hip_stream.
+ * Modes 4..6: conv1 forward (fp32 NCHW / uint8 NHWC / uint8 + shifts in `mask`).  Modes 7..9 = the forms the engine runs: 7 = mode 1
+ * that also emits the ReLU bitmask of its output into `mask` (uint32 [Nf][OUTH][OUTW][2]); 8 / 9 = modes 2 / 3 with `mask` = ReLU
+ * bitmask words (2 / 1 per output pixel).  relu: bit 0 = ReLU, bit 5 (32) = dynamic work claiming, bits 1..4 = bench ablations. */
 int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
                      int32_t OUTH, int32_t relu, void* hip_stream);
 /* skinny GEMM kernel alone (bf16 in / bf16 out), variant = waves*10 + row-tiles-per-workgroup; asynchronous. */

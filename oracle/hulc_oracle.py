@@ -872,6 +872,9 @@ class Rollout:
         self.reset()
 
     def reset(self):
+        if self.dims.kind == "gcbc" and hasattr(self, "h"):      # gcbc.py:281-285: `self.latent_goal = None` and nothing else
+            self.goal = None
+            return
         self.plan = None
         self.goal = None
         self.h = None
@@ -881,6 +884,20 @@ class Rollout:
         """obs: rgb_static (1,1,3,200,200), rgb_gripper (1,1,3,84,84), robot_obs_raw (1,1,15); goal: same two images (vision)
         or a (1,384) language embedding; noise: plan_idx (1,n_cat) on replan steps, u_mix (1,1,6,10), u_act (1,1,6)."""
         P, dims = self.P, self.dims
+        if dims.kind == "gcbc":
+            # GCBC.reset / step (gcbc.py:281-320): the goal is encoded once per rollout (reset() only drops the goal); the decoder runs
+            # without a plan and its hidden state is never cleared — LogisticDecoderRNN.act keeps it and gcbc.py has no clear_hidden_state call
+            if self.goal is None:
+                if isinstance(goal, dict):
+                    emb = encode(P, np.concatenate([obs["rgb_static"], goal["rgb_static"]], 1), np.concatenate([obs["rgb_gripper"], goal["rgb_gripper"]], 1))
+                    self.goal = goal_encode(P, emb[:, -1], False)
+                else:
+                    self.goal = goal_encode(P, goal, True)
+            emb = encode(P, obs["rgb_static"], obs["rgb_gripper"])
+            probs, lsr, means, grip, self.h = decoder_heads(P, None, emb, self.goal, dims, self.h)
+            pred = logistic_sample(probs, lsr, means, grip, noise["u_mix"], noise["u_act"])
+            self.counter += 1
+            return tcp_to_world_frame(pred, obs["robot_obs_raw"])
         if self.counter % self.replan_freq == 0:
             if isinstance(goal, dict):
                 emb = encode(P, np.concatenate([obs["rgb_static"], goal["rgb_static"]], 1), np.concatenate([obs["rgb_gripper"], goal["rgb_gripper"]], 1))

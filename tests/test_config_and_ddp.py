@@ -49,6 +49,29 @@ def test_kl_schedules():
     assert lin._beta(0) == 0 and abs(lin._beta(30) - 0.005) < 1e-9 and lin._beta(60) == 0.01
     sig = KLSigmoidSchedule(10, 50, 0.01)
     assert sig._beta(10) < 1e-4 and abs(sig._beta(30) - 0.005) < 1e-9 and sig._beta(50) > 0.0099
+    # outside [start, end] the reference clamps exactly (kl_callbacks.py:41-44): 0 before, max after — no extrapolated sigmoid tail
+    assert sig._beta(0) == 0.0 and sig._beta(9) == 0.0 and sig._beta(51) == 0.01 and sig._beta(1000) == 0.01
+    # values of the reference formula sigmoid((x - shift) / (scale / 12)), shift = (end + start) / 2, scale = end - start
+    import math
+    for ep in (10, 17, 30, 42, 50):
+        want = 0.01 / (1.0 + math.exp(-((ep - 30.0) / (40.0 / 12.0))))
+        assert abs(sig._beta(ep) - want) < 1e-12
+
+
+def test_state_manifest_covers_spec_layout():
+    """tests/golden/state_manifest.json (tools/gen_golden_ckpt.py = the reference's state_dict()): every PARAMETER key and shape of every
+    model kind equals hulc_amd.spec.layout — the flat-buffer layout the engine binds by name."""
+    import json
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_manifest.json")))
+    from hulc_amd import spec
+    for name, kind, kw in (("hulc_w32", "hulc", dict(max_window=32)), ("hulc_w64", "hulc", dict(max_window=64)), ("gcbc_w32", "gcbc", dict(max_window=32)),
+                           ("mcil_w32", "mcil", dict(max_window=32, use_clip=False)), ("mcil_gru_w32", "mcil", dict(max_window=32, use_clip=False, rnn_type="gru"))):
+        lay, total = spec.layout(spec.ModelDims(kind=kind, **kw))
+        ref = {k: tuple(e["shape"]) for k, e in man[name]["state_dict"].items() if e["param"]}
+        assert set(ref) == set(lay), (name, set(ref) ^ set(lay))
+        for k, shp in ref.items():
+            assert tuple(lay[k][1]) == shp, (name, k)
+        assert sum(int(np.prod(s)) if len(s) else 1 for s in ref.values()) == man[name]["n_params"]
 
 
 def _ddp_worker(rank, world, port, out):

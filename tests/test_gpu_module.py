@@ -151,3 +151,162 @@ def test_module_validation_step_and_rollout_match_reference():
             a = m.step(obs, goal, noise=dict(plan_idx=rfx[f"plan_idx_{mode}"][t][0], u_mix=rfx[f"u_mix_{mode}"][t][0, 0], u_act=rfx[f"u_act_{mode}"][t][0, 0]))
             assert a.shape == (1, 1, 7)
             assert np.abs(a.numpy()[0, 0] - rfx[f"actions_{mode}"][0, t]).max() <= 2e-3, (mode, t)
+
+
+def test_gcbc_module_rollout_matches_reference():
+    """GCBC.reset / step through the module and the C-ABI (hulc_rollout_plan encodes only the goal for HULC_KIND_GCBC) against the
+    reference fixture — including the hidden state that the reference's GCBC keeps across reset() (gcbc.py:281-320)."""
+    from hulc_amd.hulc import GCBC
+    from hulc_amd.utils import synthetic
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "rollout_gcbc.npz"))
+    nvis, nlang, seed = (int(v) for v in fx["meta"])
+    n = max(nvis, nlang)
+    dims = spec.ModelDims(kind="gcbc", max_window=32, use_clip=True)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    frames = synthetic.make_batch(1, 1, n + 1, seed=seed, edge_frac=0.0, aux_mask="all")
+    m = GCBC(precision="fp32", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m.lang_embeddings = {"do the task": frames["lang"]["lang"][0:1]}
+    for mode, ns in (("vis", nvis), ("lang", nlang)):
+        mb = frames[mode]
+        m.reset()
+        goal = "do the task" if mode == "lang" else dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, n:n + 1]),
+                                                                        rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, n:n + 1])))
+        for t in range(ns):
+            obs = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, t:t + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, t:t + 1])),
+                       depth_obs={}, robot_obs=torch.zeros(1, 1, 8), robot_obs_raw=torch.from_numpy(mb["robot_obs"][:, t:t + 1]))
+            a = m.step(obs, goal, noise=dict(u_mix=fx[f"u_mix_{mode}"][t][0, 0], u_act=fx[f"u_act_{mode}"][t][0, 0]))
+            assert np.abs(a.numpy()[0, 0] - fx[f"actions_{mode}"][0, t]).max() <= 2e-3, (mode, t)
+    m.engine.close()
+
+
+def _manifest(name):
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "state_manifest.json")))[name]["state_dict"]
+
+
+def _ckpt_from_manifest(name, seed=0):
+    """A reference-layout Lightning checkpoint dict: every key of the reference's state_dict() (parameters + buffers, manifest values for
+    the buffers), random parameter values, plus the Lightning bookkeeping keys the loader must tolerate."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, e in _manifest(name).items():
+        if e["param"]:
+            sd[k] = torch.randn(*e["shape"], generator=g) * 0.05 if e["shape"] else torch.tensor(2.6)
+        elif "value" in e:
+            sd[k] = torch.tensor(e["value"], dtype=getattr(torch, e["dtype"])).reshape(e["shape"])
+        else:
+            sd[k] = torch.zeros(*e["shape"], dtype=getattr(torch, e["dtype"]))
+    return {"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.8.6", "state_dict": sd, "optimizer_states": [], "lr_schedulers": [],
+            "hyper_parameters": {"kl_beta": 0.01, "replan_freq": 30}}
+
+
+def test_reference_checkpoint_interop(tmp_path):
+    """reference state_dict layout (tests/golden/state_manifest.json = the unmodified reference's state_dict()):
+    strict load of a full reference checkpoint, state_dict() round trip to the reference key set, position-embedding trimming
+    64 -> 32 rows and `pretrain_exclude_pr` (hulc/utils/utils.py:7-16), and rejection of checkpoints whose loss buffers differ."""
+    from hulc_amd.hulc import Hulc, initialize_pretrained_weights
+    ck = _ckpt_from_manifest("hulc_w32", seed=1)
+    m = Hulc(precision="fp32", max_batch_size=2, max_seq_len=4)
+    missing, unexpected = m.load_state_dict(ck["state_dict"], strict=True)             # every reference key is known, none is missing
+    assert missing == [] and unexpected == []
+    out = m.state_dict()
+    assert set(out) == set(ck["state_dict"])                                            # round trip: exactly the reference key set
+    for k, v in ck["state_dict"].items():
+        assert tuple(out[k].shape) == tuple(v.shape), k
+        if _manifest("hulc_w32")[k]["param"]:
+            assert torch.equal(out[k].cpu(), v.to(torch.float32)), k
+        else:
+            assert torch.allclose(out[k].cpu().float(), v.float()), k                   # built-in buffers carry the reference's values
+    # pretrained initialisation from a max_window = 64 checkpoint: the position table is trimmed to this model's 32 rows
+    ck64 = _ckpt_from_manifest("hulc_w64", seed=2)
+    path = str(tmp_path / "pre.ckpt")
+    torch.save(ck64, path)
+    w_before = m.state_dict()["plan_recognition.fc.weight"].clone()
+    initialize_pretrained_weights(m, dict(pretrain_chk=path))
+    pos = m.state_dict()["plan_recognition.position_embeddings.weight"]
+    assert pos.shape == (32, 128) and torch.equal(pos.cpu(), ck64["state_dict"]["plan_recognition.position_embeddings.weight"][:32])
+    assert torch.equal(m.state_dict()["plan_recognition.fc.weight"].cpu(), ck64["state_dict"]["plan_recognition.fc.weight"])
+    # pretrain_exclude_pr: every plan_recognition.* tensor keeps its current value, everything else is taken from the checkpoint
+    ck3 = _ckpt_from_manifest("hulc_w64", seed=3)
+    torch.save(ck3, path)
+    pr_before = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("plan_recognition")}
+    initialize_pretrained_weights(m, dict(pretrain_chk=path, pretrain_exclude_pr=True))
+    after = m.state_dict()
+    for k, v in pr_before.items():
+        assert torch.equal(after[k], v), k
+    assert torch.equal(after["action_decoder.rnn.weight_hh_l0"].cpu(), ck3["state_dict"]["action_decoder.rnn.weight_hh_l0"])
+    assert not torch.equal(w_before.cpu(), after["plan_recognition.fc.weight"].cpu())
+    # a checkpoint trained with other action bounds must not load silently (the engine's bin width is built for +-1)
+    bad = dict(ck["state_dict"])
+    bad["action_decoder.action_max_bound"] = bad["action_decoder.action_max_bound"] * 0.5
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    with pytest.raises(RuntimeError):                                                   # strict: unknown / missing keys
+        m.load_state_dict({**ck["state_dict"], "not_a_key": torch.zeros(1)}, strict=True)
+    m.engine.close()
+
+
+def test_gcbc_and_mcil_checkpoints_load_strictly():
+    from hulc_amd.hulc import GCBC, Hulc
+    g = GCBC(precision="fp32", max_batch_size=2, max_seq_len=4)
+    assert g.load_state_dict(_ckpt_from_manifest("gcbc_w32")["state_dict"], strict=True) == ([], [])
+    assert set(g.state_dict()) == set(_manifest("gcbc_w32"))
+    g.engine.close()
+    cfg = config.compose(os.path.join(ROOT, "conf"), "config", ["model=mcil", "trainer.precision=fp32", "datamodule.batch_size=2"])
+    mc = config.instantiate(cfg.model, device="cuda:0", max_seq_len=4)
+    assert mc.load_state_dict(_ckpt_from_manifest("mcil_w32")["state_dict"], strict=True) == ([], [])
+    assert set(mc.state_dict()) == set(_manifest("mcil_w32"))
+    mc.engine.close()
+
+
+def test_epoch_metrics_are_batch_size_weighted_means():
+    """`self.log(..., on_step=False, on_epoch=True, batch_size=b)` (hulc.py:470-536): Lightning reduces these to batch-size weighted
+    epoch means; `logged` keeps the latest value."""
+    from hulc_amd.hulc import Hulc
+    m = Hulc(precision="fp32", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
+    m.log("train/x", 1.0, on_step=False, on_epoch=True, batch_size=2)
+    m.log("train/x", 4.0, on_step=False, on_epoch=True, batch_size=6)
+    m.log("val/y", 3.0, sync_dist=True)
+    m.log("val/y", 5.0, sync_dist=True)
+    assert m.logged["train/x"] == 4.0
+    em = m.epoch_metrics(reset=True)
+    assert abs(em["train/x"] - (1.0 * 2 + 4.0 * 6) / 8) < 1e-12 and abs(em["val/y"] - 4.0) < 1e-12
+    assert m.epoch_metrics() == {}
+    m.engine.close()
+
+
+def test_constructor_rejects_options_that_change_the_maths():
+    from hulc_amd.hulc import Hulc
+    kw = dict(precision="fp32", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
+    for bad in (dict(action_decoder=dict(act_max_bound=[0.5] * 7)), dict(action_decoder=dict(load_action_bounds=True)),
+                dict(plan_recognition=dict(encoder_normalize=True)), dict(plan_recognition=dict(positional_normalize=True)),
+                dict(plan_recognition=dict(position_embedding=False)), dict(action_decoder=dict(perceptual_emb_slice=[0, 64]))):
+        with pytest.raises(NotImplementedError):
+            Hulc(**kw, **bad)
+    with pytest.raises(ValueError):
+        Hulc(**{**kw, "precision": "8"})
+    ok = Hulc(**kw, action_decoder=dict(act_max_bound=[1.0] * 7, act_min_bound=[-1.0] * 7, perceptual_emb_slice=[64, 128]))
+    ok.engine.close()
+
+
+def test_uint8_frames_take_the_ingest_path():
+    """uint8 (B,S,H,W,3) frames handed to the module are NOT cast to float (they would be fed unnormalised): the fused ingest path runs
+    and the loss equals the step fed the transformed fp32 NCHW frames."""
+    from hulc_amd.hulc import Hulc
+    g = torch.Generator().manual_seed(5)
+    Bm, Sm = 2, 4
+    u8s = torch.randint(0, 256, (Bm, Sm, 200, 200, 3), generator=g, dtype=torch.uint8)
+    u8g = torch.randint(0, 256, (Bm, Sm, 84, 84, 3), generator=g, dtype=torch.uint8)
+    tf = lambda u: ((u.float() / 255.0 - 0.5) / 0.5).permute(0, 1, 4, 2, 3).contiguous()
+    act = torch.rand(Bm, Sm, 7, generator=g) * 2 - 1
+    act[..., 6] = 1.0
+    ro = torch.randn(Bm, Sm, 15, generator=g) * 0.3
+    plan = torch.randint(0, 32, (Bm, 32), generator=g, dtype=torch.int32)
+    base = dict(depth_obs={}, robot_obs=torch.zeros(Bm, Sm, 8), actions=act, state_info=dict(robot_obs=ro), idx=torch.arange(Bm), plan_idx=plan)
+    m = Hulc(precision="fp32", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
+    m.eval()
+    l_f32 = float(m.training_step({"vis": dict(base, rgb_obs=dict(rgb_static=tf(u8s), rgb_gripper=tf(u8g)))}, 0))
+    l_u8 = float(m.training_step({"vis": dict(base, rgb_obs=dict(rgb_static=u8s, rgb_gripper=u8g))}, 0))
+    assert abs(l_u8 - l_f32) <= 1e-5 * abs(l_f32), (l_u8, l_f32)
+    m.engine.close()

@@ -28,7 +28,8 @@ w("config.yaml", """defaults:
   - callbacks: default
   - _self_
 seed: 42
-log_dir: ./runs
+# one directory per run, like the reference's hydra.run.dir (runs/<date>/<time>): a re-launched command starts fresh; pass log_dir=<run dir> to resume it
+log_dir: ./runs/{now}
 """, H.format("conf/config.yaml"))
 
 for name, tgt in (("hulc", "hulc.models.hulc.Hulc"), ("gcbc", "hulc.models.gcbc.GCBC")):
@@ -118,8 +119,11 @@ w("loss/default.yaml", dict(kl_beta=0.01, kl_balancing_mix=0.8, state_recon_beta
 w("training/default_training.yaml", dict(lr=2.0e-4), H.format("training/default_training.yaml"))
 w("trainer/mi355x.yaml", dict(devices=1, accelerator="gpu", precision="bf16", max_epochs=100, max_steps=-1, val_check_interval=1.0,
                              sync_batchnorm=False, allreduce_bucket_mb=0),
-  "hulc_amd trainer group (reference: conf/trainer/play_trainer.yaml, precision 16 = fp16 AMP -> bf16 MFMA here; "
-  "allreduce_bucket_mb=0 = one flat RCCL all-reduce)")
+  "hulc_amd trainer group: bf16 MFMA operands (no loss scaling needed); trainer=play_trainer is the reference's group (precision 16 = "
+  "fp16 + dynamic loss scaling); allreduce_bucket_mb=0 = one flat RCCL all-reduce")
+w("trainer/play_trainer.yaml", dict(devices=1, accelerator="gpu", precision=16, val_check_interval=1.0, max_epochs=100, max_steps=-1, sync_batchnorm=False,
+                                    allreduce_bucket_mb=0),
+  H.format("conf/trainer/play_trainer.yaml") + " — precision 16 = Lightning native AMP: the fp16 engine + on-device GradScaler (hulc_scaler_*)")
 w("datamodule/synthetic.yaml", dict(_target_="hulc_amd.trainer.SyntheticDataModule", root_data_dir="", action_space=7,
                                    action_max=[1.0] * 7, action_min=[-1.0] * 7, max_window_size=32, min_window_size=20, batch_size=32,
                                    modalities=["vis", "lang"], steps_per_epoch=50),

@@ -177,6 +177,54 @@ def run_rollout(name, outdir, seed=21, nsteps=5, replan_freq=2, kind="hulc"):
         print(f"[{name}/{mode}] rollout oracle-vs-reference max |action diff| {worst:.2e}")
 
 
+def run_rollout_gcbc(name, outdir, seed=23, nvis=3, nlang=3):
+    """GCBC.reset / step (gcbc.py:281-320): a vision-goal rollout, reset(), then a language-goal rollout with the SAME model object —
+    the reference's GCBC never clears the decoder's hidden state, so the second rollout starts from the first one's last state."""
+    dims = spec.ModelDims(kind="gcbc", max_window=32, use_clip=True)
+    P = spec.init_all(dims, seed=seed, ln_jitter=True)
+    model = ref_harness.build_reference("gcbc", max_window=32, use_clip=True)
+    model.eval()
+    load_params(model, P)
+    n = max(nvis, nlang)
+    frames = synthetic.make_batch(1, 1, n + 1, seed=seed, edge_frac=0.0, aux_mask="all")
+    vis, lang = frames["vis"], frames["lang"]
+    fx = {"meta": np.array([nvis, nlang, seed], np.int64)}
+    model.lang_embeddings = {"do the task": lang["lang"][0:1].reshape(1, 1, 384)}
+    torch.manual_seed(77 + seed)
+    for mode, mb, ns in (("vis", vis, nvis), ("lang", lang, nlang)):
+        model.reset()
+        if mode == "vis":
+            goal = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, n:n + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, n:n + 1])),
+                        depth_obs={}, robot_obs=torch.zeros(1, 1, 8))
+        else:
+            goal = "do the task"
+        acts, umix, uact = [], [], []
+        for t in range(ns):
+            obs = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, t:t + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, t:t + 1])),
+                       depth_obs={}, robot_obs=torch.zeros(1, 1, 8), robot_obs_raw=torch.from_numpy(mb["robot_obs"][:, t:t + 1]))
+            with RandRecorder() as rr:
+                a = model.step(obs, goal)
+            assert len(rr.draws) == 2
+            umix.append(rr.draws[0]); uact.append(rr.draws[1])
+            acts.append(a.detach().numpy().copy())
+        fx[f"actions_{mode}"] = np.concatenate(acts, 1)
+        fx[f"u_mix_{mode}"] = np.stack(umix, 0)
+        fx[f"u_act_{mode}"] = np.stack(uact, 0)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **fx)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import hulc_oracle as O
+    ro = O.Rollout(P, dims, 30)
+    for mode, mb, ns in (("vis", vis, nvis), ("lang", lang, nlang)):
+        ro.reset()
+        goal = dict(rgb_static=mb["rgb_static"][:, n:n + 1], rgb_gripper=mb["rgb_gripper"][:, n:n + 1]) if mode == "vis" else lang["lang"][0:1]
+        worst = 0.0
+        for t in range(ns):
+            obs = dict(rgb_static=mb["rgb_static"][:, t:t + 1], rgb_gripper=mb["rgb_gripper"][:, t:t + 1], robot_obs_raw=mb["robot_obs"][:, t:t + 1])
+            a = ro.step(obs, goal, dict(u_mix=fx[f"u_mix_{mode}"][t], u_act=fx[f"u_act_{mode}"][t]))
+            worst = max(worst, np.abs(a - fx[f"actions_{mode}"][:, t:t + 1]).max())
+        print(f"[{name}/{mode}] rollout oracle-vs-reference max |action diff| {worst:.2e}")
+
+
 if __name__ == "__main__":
     out = os.path.join(ROOT, "tests", "golden")
     only = sys.argv[1:]
@@ -187,3 +235,5 @@ if __name__ == "__main__":
         run_rollout("rollout_hulc", out)
     if not only or "rollout_mcil" in only:
         run_rollout("rollout_mcil", out, seed=22, kind="mcil")
+    if not only or "rollout_gcbc" in only:
+        run_rollout_gcbc("rollout_gcbc", out)

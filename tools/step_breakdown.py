@@ -3,11 +3,11 @@ import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 d = collections.defaultdict(lambda: [0.0, 0])
 for r in step:
-    n = r["Kernel_Name"].replace("unsigned short", "bf16")[:96]
+    n = r["Kernel_Name"].replace("unsigned short", "h16").replace("hulc_bf16::", "").replace("hulc_f16::", "")[:110]
     d[n][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; d[n][1] += 1
 tot = sum(v[0] for v in d.values())
 print(f"{len(step)} kernels, busy {tot:.1f} us")
