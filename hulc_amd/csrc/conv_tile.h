@@ -54,7 +54,7 @@ struct ConvTileCfg {
     static constexpr int WS = WROW + pad_slots(WROW / 16, 1) * 16;   // LDS bytes per weight row
     static constexpr int NCLS = OS * OS;
     static constexpr int NT = CN / 16;
-    static constexpr int PF = 10;                              // prefetch registers (uint4) per thread
+    static constexpr int PF = 10;                              // prefetch registers (uint4) per thread: bands of up to 5 120 16-byte chunks (only the slots a band shape uses issue loads)
     static constexpr int MT = (CN / 16 <= 2) ? 4 : 2;          // m-tiles (16 pixels) per wave pass: LDS reads per MFMA = (MT+NT)/(MT*NT)
     static constexpr size_t w_bytes() { return (size_t)NCLS * CN * WS; }
     // the band is stored as SI row planes (window row wr -> plane wr % SI, row wr / SI) so that the pixels of consecutive OUTPUT
@@ -62,8 +62,15 @@ struct ConvTileCfg {
     static constexpr int WPP = (CN + 31) / 32;                 // mask words per output pixel
     static constexpr int MAXMW = 2048;                         // mask words staged per band (one 16-byte register per thread)
     static constexpr size_t band_bytes(int LR, int LP) { return ((size_t)(SI * ((LR + SI - 1) / SI) * LP) * XS + 15) / 16 * 16; }
-    static constexpr size_t lds_bytes(int LR, int LP) { return w_bytes() + band_bytes(LR, LP) + CN * 4 + MAXMW * 4 + 16; }
+    static constexpr size_t lds_bytes(int LR, int LP, bool with_mask = true) { return w_bytes() + band_bytes(LR, LP) + CN * 4 + (with_mask ? MAXMW * 4 : 0) + 16; }
 };
+
+#ifdef HULC_CT_STAMPS     // tools/ct_stamps.hip only: shader-clock stamps of the phases of every band (never defined in the library build)
+__device__ unsigned long long g_ct_stamps[256 * 8 * 64 * 8];     // [workgroup][wave][band iteration][phase]
+#define CTSTAMP(n) do { if (lane == 0 && iter < 64) g_ct_stamps[((blockIdx.x * 8 + wave) * 64 + iter) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CTSTAMP(n)
+#endif
 
 // x / d for 0 <= x < 2^16, 1 <= d <= 64 with inv = 1.f / d: (x + 0.5) / d is at least 0.5 / d away from an integer, far beyond the fp32
 // rounding error of the product — 3 VALU instructions instead of the ~40 of a runtime integer division (the band staging and m-tile
@@ -97,32 +104,47 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     const int Q = p.LP / SI;                                    // m-index pitch (band pixels per output row)
     const int PLR = (p.LR + SI - 1) / SI;                       // rows per LDS row plane
     const float invLW = 1.f / (float)p.LW, invQ = 1.f / (float)Q;
+    const int nslots = (wchunks + 511) >> 9;                    // prefetch registers this band shape uses (uniform): the others issue NO load —
+                                                                // every wave-level load costs the CU's address unit 16 cycles whether its data is used or not
     // ---- prefetch of a band into registers: UNCONDITIONAL loads from clamped addresses; the zero border is applied when the band is
     // committed to LDS (pin bit k), and the multiply loop below issues no global load at all — so nothing forces a wait on these loads
-    // before the MFMAs and the next band's HBM latency hides under the current band's multiply phase.
+    // before the MFMAs and the next band's HBM latency hides under the current band's multiply phase.  Only the slots the band shape
+    // uses issue a load (a wave-level 16-byte load occupies the CU's address unit for 16 cycles whether its data is used or not), and
+    // the band-invariant part of every slot's address — window row, clamped column offset, column-in-range — is computed once
+    // (pk[k]); per band a slot costs a row clamp and one multiply-add (tools/ct_stamps.hip: this phase was 2 600 of a band's 13 800
+    // cycles with the matrix pipes idle; spreading the loads over the MFMA loop instead made the loop slower by as much).
     u32x4_t pf[C::PF], pfm;
     unsigned pin = 0;
     int mwords = 0;                                             // mask words of the prefetched band
     typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
+    unsigned pk[C::PF];                                         // bit 31: column inside the image; bits 16..23: window row; bits 0..15: (clamped col * CK + chunk * 8) / 8
+    {
+        const int clo = REV ? -(TB - 1) : 0;
+#pragma unroll
+        for (int k = 0; k < C::PF; ++k) {
+            const int qc = min(tid + k * 512, wchunks - 1);
+            const int pix = qc / C::CH, c = qc % C::CH;
+            const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
+            const int ic = clo + wc;
+            const int icc = min(max(ic, 0), p.IMW - 1);
+            pk[k] = ((ic >= 0 && ic < p.IMW) ? 0x80000000u : 0u) | ((unsigned)wr << 16) | (unsigned)(icc * C::CH + c);
+        }
+    }
+    const int rowel = p.IMW * CK;                               // elements per image row
     auto prefetch = [&](int item) {
         if (p.dbg & 4) return;
         const int f = item / p.nbands, b = item % p.nbands;
         const int i0 = b * p.RB;
         const int rlo = REV ? i0 - (TA - 1) : i0 * SI;
-        const int clo = REV ? -(TB - 1) : 0;
-        const h16_t* base = p.img + (long long)f * p.IMH * p.IMW * CK;
+        const h16_t* base = p.img + (long long)f * p.IMH * rowel;
         pin = 0;
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
-            const int q = tid + k * 512;
-            const int qc = min(q, wchunks - 1);
-            const int pix = qc / C::CH, c = qc % C::CH;
-            const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
-            const int ir = rlo + wr, ic = clo + wc;
-            const bool in = ir >= 0 && ir < p.IMH && ic >= 0 && ic < p.IMW;
-            const int irc = min(max(ir, 0), p.IMH - 1), icc = min(max(ic, 0), p.IMW - 1);
-            pf[k] = *reinterpret_cast<const u32x4_t*>(base + ((long long)irc * p.IMW + icc) * CK + c * 8);   // always-valid address
-            pin |= (in ? 1u : 0u) << k;
+            if (k >= nslots) break;
+            const int ir = rlo + (int)((pk[k] >> 16) & 0xffu);
+            const int irc = min(max(ir, 0), p.IMH - 1);
+            pf[k] = *reinterpret_cast<const u32x4_t*>(base + irc * rowel + (int)(pk[k] & 0xffffu) * 8);   // always-valid address
+            pin |= ((ir == irc && (pk[k] >> 31)) ? 1u : 0u) << k;
         }
         if (p.maskbits) {                                       // ReLU bitmask rows of the band's output rows [i0*OS, (i0+RB)*OS)
             const int r0 = i0 * OS, r1 = min((i0 + p.RB) * OS, p.OUTH);
@@ -146,10 +168,12 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     if (item < nitems) prefetch(item);
     while (item < nitems) {
         if (p.work_ctr && tid == 0) s_next[iter & 1] = (int)gridDim.x + atomicAdd(p.work_ctr, 1);   // claimed early: its latency hides under the LDS write
+        CTSTAMP(0);
         __syncthreads();                                        // previous band fully consumed (and weights visible)
+        CTSTAMP(1);
 #pragma unroll
         for (int k = 0; k < C::PF; ++k)
-            if (tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = ((pin >> k) & 1u) ? pf[k] : u32x4_t{0u, 0u, 0u, 0u};
+            if (k < nslots && tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = ((pin >> k) & 1u) ? pf[k] : u32x4_t{0u, 0u, 0u, 0u};
         if (p.maskbits && tid * 4 < mwords) {
             if (tid * 4 + 4 <= mwords) *(lds_u32x4*)(ml + tid * 16) = pfm;
             else {                                              // ragged tail: the clamped load holds words [mwords-4, mwords)
@@ -159,11 +183,19 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                     if (e + sh < 4) *(__attribute__((address_space(3))) unsigned*)(ml + (tid * 4 + e) * 4) = pfm[e + sh];
             }
         }
+        CTSTAMP(2);
         __syncthreads();
+        CTSTAMP(3);
         const int cur = item;
         item = p.work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
+        // Phase skew between the two waves of a SIMD (waves w and w + 4): the first half issues the next band's prefetch (address
+        // arithmetic + loads: VALU / address-unit work) BEFORE its multiply phase, the second half after its first group's MFMAs.  Released
+        // by the same barrier, the two would otherwise run every phase in lockstep — both computing addresses while the matrix pipe idles,
+        // then both contending for it; skewed, one half's prefetch and epilogues run beside the other half's MFMAs.
+        bool pref_pending = item < nitems;
+        if (pref_pending && (wave < 4 || (p.dbg & 64))) { prefetch(item); pref_pending = false; }       // dbg bit 6: no skew (A/B)
+        CTSTAMP(4);
         ++iter;
-        if (item < nitems) prefetch(item);                      // in flight during the MFMAs below
         const int f = cur / p.nbands, b = cur % p.nbands;
         const int i0 = b * p.RB;
         // work items of this band = (parity class, group of MT m-tiles), dealt round-robin to the 8 waves
@@ -230,6 +262,9 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                     for (int nn = 0; nn < C::NT; ++nn) acc[mm][nn] = MFMA_16x16x32_H(wf[nn], xf[mm], acc[mm][nn], 0, 0, 0);
             };
             // software pipeline: the LDS reads of k-step s+1 are in flight while the MFMAs of k-step s issue
+#ifdef HULC_CT_STAMPS
+            --iter; CTSTAMP(5); ++iter;
+#endif
             frag_load(xf0, wf0, 0);
 #pragma unroll 1
             for (int s2 = (p.dbg & 16) ? NS : 0; s2 < NS; s2 += 2) {
@@ -238,6 +273,11 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                 if (s2 + 2 < NS) frag_load(xf0, wf0, s2 + 2);
                 frag_mma(xf1, wf1);
             }
+            if (pref_pending) { prefetch(item); pref_pending = false; }
+#ifdef HULC_CT_STAMPS
+            asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[C::MT - 1][C::NT - 1][3]));      // the stamp below must follow the last MFMA's result
+            --iter; CTSTAMP(6); ++iter;
+#endif
             if ((p.dbg & 8) && acc[0][0][0] != 12345.678f) continue;
             // ---- epilogue: lane holds channels g*4*NT .. +4*NT-1 of pixel li of each m-tile
             float bb[4 * C::NT];
@@ -287,7 +327,11 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                     }
                 }
             }
+#ifdef HULC_CT_STAMPS
+            --iter; CTSTAMP(7); ++iter;
+#endif
         }
+        if (pref_pending) prefetch(item);                       // a wave without a group in this band
     }
 }
 
@@ -305,7 +349,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     for (int nb = 1; nb <= NI; ++nb) {
         const int RB = (NI + nb - 1) / nb;
         const int LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA;
-        if ((long long)LR * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LR, p.LP) > 160 * 1024 - 64) continue;   // 64 B left for the kernel's static __shared__ (work-claim slots)
+        if ((long long)LR * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LR, p.LP, p.maskbits != nullptr) > 160 * 1024 - 64) continue;   // 64 B left for the kernel's static __shared__ (work-claim slots)
         if (p.maskbits && (long long)RB * OS * p.OUTW * C::WPP > C::MAXMW) continue;                                   // the band's mask rows travel in one register per thread
         double cost = 0.25 * nb;                                   // per-band barrier / staging overhead, in units of one wave round
         for (int b = 0; b < nb; ++b) {
@@ -324,7 +368,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     p.nbands = best_nb;
     p.RB = (NI + best_nb - 1) / best_nb;
     p.LR = REV ? p.RB + TA - 1 : (p.RB - 1) * SI + TA;
-    const size_t lds = C::lds_bytes(p.LR, p.LP);
+    const size_t lds = C::lds_bytes(p.LR, p.LP, p.maskbits != nullptr);      // without a bitmask the 8 KB mask region is not allocated: conv3's forward then holds a WHOLE frame per band
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);

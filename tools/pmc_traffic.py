@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 d = sys.argv[1]
 # the recurrent step is the M=64, N=K=2048 launch of the skinny kernel: grid (128, 2) x 1024 threads (the same kernel also serves
 # many-row GEMMs with other grids; dispatches are keyed by kernel name + grid size so those stay out of the class)
-CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128")),
+CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128", "gemm_kernel<h16, 128, 128")),
            ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
            ("conv_tile_fwd", ("1, 1, false>(ConvTileP)", "2, 1, false>(ConvTileP)")), ("conv_tile_dgrad", ("true>(ConvTileP)",)), ("adam", ("adam_kernel",))]
 per = {}
@@ -30,11 +30,13 @@ with open(f"{d}/pmc_hbm_per_kernel.csv", "w") as fo:
     for r in sorted(rows, key=lambda r: -r[4] * r[1]):
         wr.writerow([r[0] if len(r[0]) <= 160 else r[0][:160] + (r[0][r[0].rfind(' [grid='):] if ' [grid=' in r[0] else ''), r[1], round(r[2], 1), round(r[3], 1), int(r[4])])
 traffic = {}
-for cls, pats in CLASSES:
-    tot = 0.0; n = 0
-    for r in rows:
+acc = {cls: [0.0, 0] for cls, _ in CLASSES}
+for r in rows:          # every dispatch row belongs to the FIRST class it matches: the recurrent-step dispatches (listed first, keyed by grid size)
+    for cls, pats in CLASSES:      # therefore do not leak into `skinny_gemm`, whose algorithmic bytes they would not be comparable with
         if any((all(q in r[0] for q in p) if isinstance(p, tuple) else p in r[0]) for p in pats):
-            tot += r[4] * r[1]; n += r[1]
+            acc[cls][0] += r[4] * r[1]; acc[cls][1] += r[1]
+            break
+for cls, (tot, n) in acc.items():
     if n:
         traffic[cls] = int(tot / n)
 json.dump(traffic, open(f"{d}/pmc_traffic.json", "w"), indent=1)
