@@ -134,6 +134,8 @@ def main():
                          "mcil_gru: the same with plan_recognition.rnn_type=nn.GRU (BASELINE config 4)")
     ap.add_argument("--preroll", type=int, default=300, help="untimed steps before the warm-up (≈1.5 s: clock ramp of an idle GPU)")
     ap.add_argument("--pair", type=int, default=1, help="with --lang 1: both modalities as ONE 2B-window pass (hulc_forward_loss_pair); 0 = one pass per modality like the reference")
+    ap.add_argument("--bucket", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="N > 1: wire format of the gradient all-reduce buckets (fp32 = the reference's; the engine's 16-bit type halves the bytes per link)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -155,6 +157,10 @@ def main():
     paired = bool(args.lang) and bool(args.pair)
     eng = StepEngine(dims, B if paired else Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
+    # N > 1: the library's own RCCL communicator (hulc_backward_allreduce: reverse-forward buckets overlapped with the backward); the
+    # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  Falls back to
+    # torch.distributed all-reduces if RCCL cannot be initialised in this process (reported in the JSON line).
+    lib_comm = parallel.setup_comm(eng, args.bucket) if world > 1 else False
     mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest))]
     if args.lang:
         mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest)))
@@ -268,6 +274,8 @@ def main():
             "model_flops_per_window": None if mcil else FLOP_PER_WINDOW_S32 * S / 32.0,      # SURVEY §8(d) counts the headline model only
             "step_tflops": None if mcil else round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
             "roofline": rl,
+            "allreduce": None if world == 1 else ({"path": "libhulc_hip RCCL (hulc_backward_allreduce)", "bucket_dtype": args.bucket, "buckets": eng.comm_buckets(),
+                                                  **eng.comm_stats()} if lib_comm else {"path": "torch.distributed nccl (fallback)", "bucket_dtype": "fp32"}),
             "kernel_classes": kernel_classes,
             # fp16: GradScaler state after the timed steps; skipped_in_timed_region counts optimizer steps the scaler skipped (inf/nan) inside it
             "loss_scaler": None if sc0 is None else dict(eng.scaler_state(), skipped_in_timed_region=eng.scaler_state()["skipped_steps"] - sc0["skipped_steps"]),

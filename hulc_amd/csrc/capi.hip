@@ -137,6 +137,38 @@ int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* ids, const int32_t* mask, 
     return ctx->encode(ids, mask, B, L, out);
 }
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
+int hulc_comm_unique_id(void* out, int64_t cap) {
+    if (!out || cap < 128) { hulc_set_error("hulc_comm_unique_id: need a 128-byte buffer"); return 1; }
+    if (!GradComm::load_api()) return 1;
+    GradComm::UniqueId id;
+    const int rc = GradComm::api().get_id(&id);
+    if (rc != 0) { hulc_set_error("ncclGetUniqueId failed: %s", GradComm::err(rc)); return 1; }
+    memcpy(out, &id, 128);
+    return 0;
+}
+int hulc_comm_init(hulc_ctx* ctx, const void* unique_id, int32_t rank, int32_t world) {
+    if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world) { hulc_set_error("hulc_comm_init: bad argument"); return 1; }
+    return ctx->e->comm_init(unique_id, rank, world);
+}
+int hulc_comm_destroy(hulc_ctx* ctx) { return ctx ? ctx->e->comm_destroy() : 0; }
+int hulc_comm_buckets(hulc_ctx* ctx, int64_t* lo, int64_t* hi, int32_t cap) {
+    if (!ctx || !lo || !hi) { hulc_set_error("hulc_comm_buckets: null argument"); return -1; }
+    return ctx->e->comm_buckets(lo, hi, cap);
+}
+int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes) {
+    if (!ctx || !ctx->e->comm) { hulc_set_error("hulc_comm_stats: no communicator"); return 1; }
+    if (n_collectives) *n_collectives = ctx->e->comm->n_collectives;
+    if (bytes) *bytes = ctx->e->comm->bytes_reduced;
+    return 0;
+}
+int hulc_allreduce_grads(hulc_ctx* ctx, int32_t bucket_dtype) {
+    if (!ctx) { hulc_set_error("hulc_allreduce_grads: null context"); return 1; }
+    return ctx->e->allreduce_grads(bucket_dtype);
+}
+int hulc_backward_allreduce(hulc_ctx* ctx, int32_t bucket_dtype) {
+    if (!ctx) { hulc_set_error("hulc_backward_allreduce: null context"); return 1; }
+    return ctx->e->backward_allreduce(bucket_dtype);
+}
 int hulc_scaler_enable(hulc_ctx* ctx, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval) {
     if (!ctx) { hulc_set_error("hulc_scaler_enable: null context"); return 1; }
     return ctx->e->scaler_enable(init_scale, growth_factor, backoff_factor, growth_interval);

@@ -1,0 +1,83 @@
+// hulc_amd/csrc/comm.h — the gradient all-reduce of the data-parallel step, owned by the library: RCCL over xGMI on its own HIP stream.
+//
+// Replaces the reference's Lightning DDPStrategy (hulc/training.py:64-69: DDP(find_unused_parameters=False) = mean of per-rank gradients);
+// the 1/world factor stays folded into the Adam kernel (grad_scale).  One process per GPU; the host passes in the 128-byte ncclUniqueId
+// it distributed among the ranks (torch.distributed / any store), this file does the rest:
+//   * RCCL is resolved at run time (dlopen "librccl.so.1": in a PyTorch-ROCm process that is the copy torch already loaded, so there is ONE
+//     RCCL instance per process; nothing links against it and the library still loads on a box without RCCL),
+//   * collectives run on a private high-priority stream; an event from the engine stream gates each bucket, one event back gates whatever
+//     the engine enqueues after the backward (Adam) — no host synchronisation anywhere,
+//   * buckets are module groups of the flat gradient buffer in REVERSE-FORWARD order (action decoder -> plan proposal -> plan recognition ->
+//     goal encoders -> perceptual encoders): each is reduced as soon as the backward stage that finalises it has been enqueued, so the
+//     first 61 MB leave while the rest of the backward still computes (Engine::backward, engine.h).
+//   * bucket dtype fp32 (the reference's: fp32 gradients) or bf16 (half the bytes on the wire: xGMI rings are per-link bound; the sum is
+//     then taken in bf16 by RCCL and widened back, a precision trade the host opts into).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+void hulc_set_error(const char* fmt, ...);
+
+struct GradComm {
+    typedef struct { char internal[128]; } UniqueId;          // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+    typedef void* Comm;
+    enum { F16 = 6, F32 = 7, BF16 = 9, SUM = 0 };             // ncclDataType_t / ncclRedOp_t values (rccl.h)
+    typedef int (*GetUniqueIdFn)(UniqueId*);
+    typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
+    typedef int (*CommDestroyFn)(Comm);
+    typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+    typedef const char* (*GetErrorStringFn)(int);
+    struct Api { void* lib = nullptr; GetUniqueIdFn get_id = nullptr; CommInitRankFn init = nullptr; CommDestroyFn destroy = nullptr; AllReduceFn allreduce = nullptr; GetErrorStringFn errstr = nullptr; };
+
+    static Api& api() { static Api a; return a; }
+    static bool load_api() {
+        Api& a = api();
+        if (a.lib) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.lib) break; }
+        if (!a.lib) { hulc_set_error("RCCL not found (dlopen librccl.so.1): %s", dlerror()); return false; }
+        a.get_id = (GetUniqueIdFn)dlsym(a.lib, "ncclGetUniqueId"); a.init = (CommInitRankFn)dlsym(a.lib, "ncclCommInitRank");
+        a.destroy = (CommDestroyFn)dlsym(a.lib, "ncclCommDestroy"); a.allreduce = (AllReduceFn)dlsym(a.lib, "ncclAllReduce");
+        a.errstr = (GetErrorStringFn)dlsym(a.lib, "ncclGetErrorString");
+        if (!a.get_id || !a.init || !a.destroy || !a.allreduce) { hulc_set_error("RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce"); a.lib = nullptr; return false; }
+        return true;
+    }
+    static const char* err(int rc) { return api().errstr ? api().errstr(rc) : "rccl error"; }
+
+    Comm comm = nullptr;
+    hipStream_t cs = nullptr;                                  // the collectives' stream
+    int rank = 0, world = 1;
+    std::vector<hipEvent_t> ev; size_t ev_used = 0;
+    void* stage = nullptr; int64_t stage_elems = 0;            // bf16 staging buffer (bf16 bucket mode)
+    long long n_collectives = 0; double bytes_reduced = 0;     // statistics (tests / bench JSON)
+
+    int init(const void* unique_id, int rank_, int world_) {
+        if (!load_api()) return 1;
+        rank = rank_; world = world_;
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);             // hi = greatest priority (numerically lowest)
+        if (hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi) != hipSuccess) { hulc_set_error("hulc_comm_init: stream creation failed"); return 1; }
+        UniqueId id; memcpy(&id, unique_id, sizeof(id));
+        const int rc = api().init(&comm, world, id, rank);
+        if (rc != 0) { hulc_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, err(rc)); comm = nullptr; return 1; }
+        return 0;
+    }
+    ~GradComm() {
+        if (comm) { hipStreamSynchronize(cs); api().destroy(comm); }
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+        if (cs) hipStreamDestroy(cs);
+        if (stage) hipFree(stage);
+    }
+    hipEvent_t next_event() {
+        if (ev_used == ev.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); ev.push_back(e); }
+        return ev[ev_used++];
+    }
+    // the collectives' stream waits for everything enqueued on `st` so far
+    void gate_from(hipStream_t st) { hipEvent_t e = next_event(); hipEventRecord(e, st); hipStreamWaitEvent(cs, e, 0); }
+    // `st` waits for everything enqueued on the collectives' stream so far; event slots are recycled per step
+    void gate_to(hipStream_t st) { hipEvent_t e = next_event(); hipEventRecord(e, cs); hipStreamWaitEvent(st, e, 0); ev_used = 0; }
+};

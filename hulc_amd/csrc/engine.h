@@ -3,6 +3,7 @@
 // forward+loss, backward and Adam on one HIP stream.  T = float (parity mode) or h16_t (bench mode).
 // Reference call stack restated here: SURVEY.md §3.2 (hulc/models/hulc.py:390-537).
 #pragma once
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -266,6 +267,8 @@ struct Engine : IEngine {
         tab.clear(); trdesc.clear(); tr_blocks = 0;
         if (!std::is_same<T, float>::value && !wshadow) wshadow = alloc<T>(numel);
         for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
+        tab_order.assign(tab.begin(), tab.end());
+        std::sort(tab_order.begin(), tab_order.end(), [](const std::pair<std::string, Ref>& a, const std::pair<std::string, Ref>& b) { return a.second.off < b.second.off; });
         try {
             bind_enc(encS, "perceptual_encoder.rgb_static_encoder.", false, 200);
             bind_enc(encG, "perceptual_encoder.rgb_gripper_encoder.", true, 84);
@@ -1378,6 +1381,110 @@ struct Engine : IEngine {
     }
 
     // ---------------------------------------------------------------- backward
+    // ---------------------------------------------------------------- gradient all-reduce buckets (comm.h)
+    // Module groups of the flat buffer (hulc_amd/spec.py::layout keeps each group contiguous), in the order the backward finalises them.
+    struct Bucket { int64_t lo, hi; };
+    Bucket group_range(const char* prefix) const {          // [first element, end of the last (64-padded) tensor) of the tensors named prefix*
+        int64_t lo = numel, hi = 0;
+        const std::string a(prefix);
+        for (const auto& kv : tab_order)
+            if (kv.first.compare(0, a.size(), a) == 0) { lo = std::min(lo, kv.second.off); hi = std::max(hi, kv.second.off + (kv.second.n + 63) / 64 * 64); }
+        if (hi <= lo) return Bucket{0, 0};
+        return Bucket{lo, std::min<int64_t>(hi, numel)};
+    }
+    std::vector<std::pair<std::string, Ref>> tab_order;       // (name, ref) sorted by offset
+    // issue order: [action_decoder .. end of buffer] (decoder, CLIP head, logit_scale) | plan_proposal | plan_recognition | goal encoders | perceptual encoders
+    std::vector<Bucket> bucket_plan() const {
+        std::vector<Bucket> v;
+        const Bucket dec = group_range("action_decoder.");
+        v.push_back(Bucket{dec.lo, numel});
+        v.push_back(group_range("plan_proposal."));
+        v.push_back(group_range("plan_recognition."));
+        const Bucket vg = group_range("visual_goal."), lg = group_range("language_goal.");
+        v.push_back(Bucket{std::min(vg.lo, lg.lo), std::max(vg.hi, lg.hi)});
+        v.push_back(group_range("perceptual_encoder."));
+        return v;
+    }
+    int comm_buckets(int64_t* lo, int64_t* hi, int cap) override {
+        if (!bound) { hulc_set_error("hulc_comm_buckets before hulc_bind_params"); return -1; }
+        const std::vector<Bucket> v = bucket_plan();
+        for (int i = 0; i < (int)v.size() && i < cap; ++i) { lo[i] = v[i].lo; hi[i] = v[i].hi; }
+        return (int)v.size();
+    }
+    int ar_dtype = -1;          // >= 0 while a backward with overlapped all-reduce is running: bucket dtype
+    unsigned ar_sent = 0;       // bit i: bucket i already issued in this backward
+    // SUM all-reduce of G[lo, hi) on the collectives' stream, ordered after everything enqueued on `st` so far
+    int reduce_range(int64_t lo, int64_t hi, int dtype) {
+        if (hi <= lo) return 0;
+        GradComm& c = *comm;
+        c.gate_from(st);
+        const size_t n = (size_t)(hi - lo);
+        int rc;
+        if (dtype == HULC_DTYPE_BF16 || dtype == HULC_DTYPE_F16) {
+            // 16-bit wire format: G -> staging (this unit's 16-bit type), all-reduce, widen back.  bf16 keeps fp32's range (no scaling needed);
+            // fp16 is offered for the fp16 engine, whose gradients are already loss-scaled into fp16's range.
+            if (c.stage_elems < numel) {
+                if (c.stage) hipFree(c.stage);
+                if (hipMalloc(&c.stage, (size_t)numel * 2 + 256) != hipSuccess) { hulc_set_error("hulc_allreduce_grads: staging buffer allocation failed"); return 1; }
+                c.stage_elems = numel;
+            }
+            h16_t* sg = reinterpret_cast<h16_t*>(c.stage) + lo;
+            hipLaunchKernelGGL((cast_kernel<float, h16_t>), dim3(std::min<long long>(2048, cdiv((long long)n, 1024))), dim3(256), 0, c.cs, G + lo, sg, (long long)n);
+#ifdef HULC_HALF_F16
+            const int wire = GradComm::F16;
+#else
+            const int wire = GradComm::BF16;
+#endif
+            rc = GradComm::api().allreduce(sg, sg, n, wire, GradComm::SUM, c.comm, c.cs);
+            hipLaunchKernelGGL((cast_kernel<h16_t, float>), dim3(std::min<long long>(2048, cdiv((long long)n, 1024))), dim3(256), 0, c.cs, sg, G + lo, (long long)n);
+            c.bytes_reduced += 2.0 * n;
+        } else {
+            rc = GradComm::api().allreduce(G + lo, G + lo, n, GradComm::F32, GradComm::SUM, c.comm, c.cs);
+            c.bytes_reduced += 4.0 * n;
+        }
+        c.n_collectives++;
+        if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }
+        return 0;
+    }
+    // called by backward() after the stage that finalises bucket i has been enqueued
+    int bucket_ready(int i) {
+        if (ar_dtype < 0 || (ar_sent >> i) & 1u) return 0;
+        const std::vector<Bucket> v = bucket_plan();
+        ar_sent |= 1u << i;
+        return reduce_range(v[i].lo, v[i].hi, ar_dtype);
+    }
+    int check_ar_dtype(int dtype, const char* who) {
+        if (!comm) { hulc_set_error("%s: no communicator (hulc_comm_init first)", who); return 1; }
+        if (dtype != HULC_DTYPE_F32 && dtype != HULC_DTYPE_BF16 && dtype != HULC_DTYPE_F16) { hulc_set_error("%s: bucket dtype must be HULC_DTYPE_F32 or a 16-bit type", who); return 1; }
+        if (dtype != HULC_DTYPE_F32) {
+            if (std::is_same<T, float>::value) { hulc_set_error("%s: 16-bit buckets need a bf16 / fp16 engine (the fp32 engine has no 16-bit kernels in its unit)", who); return 1; }
+#ifdef HULC_HALF_F16
+            if (dtype != HULC_DTYPE_F16) { hulc_set_error("%s: the fp16 engine offers fp16 buckets (loss-scaled gradients), not bf16", who); return 1; }
+#else
+            if (dtype != HULC_DTYPE_BF16) { hulc_set_error("%s: the bf16 engine offers bf16 buckets, not fp16", who); return 1; }
+#endif
+        }
+        return 0;
+    }
+    int allreduce_grads(int dtype) override {
+        if (check_ar_dtype(dtype, "hulc_allreduce_grads")) return 1;
+        if (!bound) { hulc_set_error("hulc_allreduce_grads before hulc_bind_params"); return 1; }
+        if (bwd_stage != 0) { hulc_set_error("hulc_allreduce_grads: encoder part of the backward still pending"); return 1; }
+        if (reduce_range(0, numel, dtype)) return 1;
+        comm->gate_to(st);
+        return 0;
+    }
+    int backward_allreduce(int dtype) override {
+        if (check_ar_dtype(dtype, "hulc_backward_allreduce")) return 1;
+        ar_dtype = dtype; ar_sent = 0;
+        int rc = backward(-1);
+        if (!rc) for (int i = 0; i < 5 && !rc; ++i) rc = bucket_ready(i);     // whatever no stage hook covered (model kinds without that stage)
+        ar_dtype = -1;
+        if (rc) return rc;
+        comm->gate_to(st);                 // Adam (or anything enqueued next on the engine stream) runs after the last collective
+        return 0;
+    }
+
     int bwd_stage = 0;    // 0: nothing pending; 1: part 0 done, encoders pending
     int backward(int part = -1) override {
         if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
@@ -1468,6 +1575,7 @@ struct Engine : IEngine {
             }
         }
         STAGE("decoder_bwd");
+        if (bucket_ready(0)) return 1;       // action_decoder.*, proj_vis_lang.*, logit_scale are final: their all-reduce starts under the rest of the backward
         // ---- straight-through + KL -> logits grads; plan proposal backward
         if (hulc) {
             hipLaunchKernelGGL(st_softmax_bwd_kernel, dim3(B * NCAT), dim3(64), 0, st, probs, dplan, dpr_kl, NCLS, dprl);
@@ -1477,6 +1585,7 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            if (bucket_ready(1)) return 1;   // plan_proposal.* final
             // fc_state of plan recognition
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
             { EpiP ep = epi(dseqf, true); ep.accumulate = 1; lin_dgrad(dprl_t, B, pr_fs, ep, dense_out(FCH)); }
@@ -1491,6 +1600,7 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            if (bucket_ready(1)) return 1;   // plan_proposal.* final
             if (gru) bigru_bwd(dprl_t, B, S); else birnn_bwd(dprl_t, B, S);
         }
         // ---- plan recognition backward
@@ -1524,6 +1634,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dy_f, B, S, EMB, dpos);
         }
         STAGE("plan_recognition_bwd");
+        if (bucket_ready(1) || bucket_ready(2)) return 1;   // plan_recognition.* final (plan_proposal too for the kinds that never touch it)
         // ---- goal encoder backward
         if (pair) {
             const int Bv = pairBv, Bl = B - pairBv;
@@ -1547,6 +1658,7 @@ struct Engine : IEngine {
             }
         }
         }
+        if (bucket_ready(3)) return 1;       // visual_goal.*, language_goal.* final
         if (part == 0) {
             if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
             bwd_stage = 1;
@@ -1561,6 +1673,7 @@ struct Engine : IEngine {
             enc_bwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
             STAGE("enc_gripper_bwd");
         }
+        if (bucket_ready(4)) return 1;       // perceptual_encoder.* final
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;
         bwd_stage = 0;

@@ -268,6 +268,45 @@ class StepEngine:
         self.adam_t += 1
         L.check(self.lib.hulc_adam_step(self.ctx, lr, b1, b2, eps, self.adam_t, grad_scale))
 
+    # ---- data-parallel gradient all-reduce owned by the library (RCCL over xGMI, include/hulc_hip.h: hulc_comm_*) ---------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the 128-byte ncclUniqueId every rank must pass to comm_init (distribute it with any store / torch.distributed)."""
+        buf = C.create_string_buffer(128)
+        L.check(L.load().hulc_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(self.lib.hulc_comm_init(self.ctx, buf, int(rank), int(world)))
+        self.has_comm = True
+
+    def comm_destroy(self):
+        if getattr(self, "has_comm", False):
+            self.lib.hulc_comm_destroy(self.ctx)
+            self.has_comm = False
+
+    def comm_buckets(self):
+        """[(lo, hi)] element ranges of the flat gradient buffer in the order hulc_backward_allreduce reduces them."""
+        lo, hi = (C.c_int64 * 8)(), (C.c_int64 * 8)()
+        n = self.lib.hulc_comm_buckets(self.ctx, lo, hi, 8)
+        if n < 0:
+            L.check(1)
+        return [(int(lo[i]), int(hi[i])) for i in range(n)]
+
+    def comm_stats(self) -> Dict:
+        n, b = C.c_int64(), C.c_double()
+        L.check(self.lib.hulc_comm_stats(self.ctx, C.byref(n), C.byref(b)))
+        return dict(collectives=n.value, bytes=b.value)
+
+    def allreduce_grads(self, bucket_dtype: str = "fp32"):
+        """One SUM all-reduce of the whole gradient buffer (after backward()); stream-ordered, no host sync."""
+        L.check(self.lib.hulc_allreduce_grads(self.ctx, L.DTYPE[bucket_dtype]))
+
+    def backward_allreduce(self, bucket_dtype: str = "fp32"):
+        """backward() of the step's last forward with the bucketed SUM all-reduce overlapped (reverse-forward order)."""
+        L.check(self.lib.hulc_backward_allreduce(self.ctx, L.DTYPE[bucket_dtype]))
+
     # ---- dynamic loss scaling (fp16 mode; torch.cuda.amp.GradScaler semantics, include/hulc_hip.h: hulc_scaler_*) ----------
     def scaler_enable(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
         """init_scale <= 0 switches scaling off.  fp16 engines start with GradScaler's defaults, fp32 / bf16 engines with it off."""
@@ -298,6 +337,7 @@ class StepEngine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            self.comm_destroy()
             self.lib.hulc_ctx_destroy(self.ctx)
             self.ctx = None
 

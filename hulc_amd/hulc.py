@@ -50,8 +50,11 @@ class FusedAdam:
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         world = parallel.world_size()
-        if not self.module._grads_reduced:               # training_step already overlapped the all-reduce with the encoder backward
-            parallel.allreduce_sum_(self.module.engine.flat_grads)
+        if not self.module._grads_reduced:               # training_step already overlapped the all-reduce with the backward
+            if getattr(self.module.engine, "has_comm", False):
+                self.module.engine.allreduce_grads(getattr(self.module.engine, "comm_bucket_dtype", "fp32"))
+            else:
+                parallel.allreduce_sum_(self.module.engine.flat_grads)
         self.module._grads_reduced = False
         self.module.engine.adam_step(lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], grad_scale=1.0 / world)
         return loss
@@ -210,6 +213,7 @@ class Hulc(torch.nn.Module):
         self.logged: Dict[str, float] = {}
         self._epoch_acc: Dict[str, list] = {}
         self._grads_reduced = False
+        self._comm_tried = False
         self.global_step = 0
         self.rollout_step_counter = 0
         self.latent_goal = None
@@ -354,6 +358,9 @@ class Hulc(torch.nn.Module):
     def training_step(self, batch: Dict[str, Dict], batch_idx: int) -> torch.Tensor:
         """hulc.py:390-537.  Computes the loss AND accumulates its gradients (see module docstring)."""
         eng = self.engine
+        if not self._comm_tried and parallel.world_size() > 1:      # first step of a multi-GPU run: the library's own RCCL communicator
+            self._comm_tried = True
+            parallel.setup_comm(eng, os.environ.get("HULC_BUCKET_DTYPE", "fp32"))
         eng.zero_grads()
         nmod = len(batch)
         if self.use_clip_auxiliary_loss and not any("lang" in s for s in batch):

@@ -70,6 +70,49 @@ def mean_scalar(x: float, device=None) -> float:
     return float(t.item()) / world_size()
 
 
+BUCKET_GROUPS = (("action_decoder.", None), ("plan_proposal.",), ("plan_recognition.",), ("visual_goal.", "language_goal."), ("perceptual_encoder.",))
+
+
+def bucket_schedule(layout, numel: int):
+    """The bucket ranges of the flat gradient buffer in the order the backward finalises them (reverse-forward: decoder first, the
+    perceptual encoders last) — the host-side mirror of Engine::bucket_plan (hulc_amd/csrc/engine.h; `hulc_comm_buckets` returns the
+    library's own list, tests compare the two).  layout: name -> (offset, shape) from hulc_amd.spec.layout."""
+    import numpy as np
+
+    def rng(prefixes):
+        lo, hi = numel, 0
+        for n, (off, shape) in layout.items():
+            if any(n.startswith(p) for p in prefixes if p):
+                k = int(np.prod(shape)) if len(shape) else 1
+                lo, hi = min(lo, off), max(hi, off + (k + 63) // 64 * 64)
+        return (lo, min(hi, numel)) if hi > lo else (0, 0)
+    out = []
+    for g in BUCKET_GROUPS:
+        lo, hi = rng(g)
+        if g[-1] is None:                  # the first bucket runs to the end of the buffer (CLIP head, logit_scale)
+            hi = numel
+        out.append((lo, hi))
+    return out
+
+
+def setup_comm(engine, bucket_dtype: str = "fp32") -> bool:
+    """Create the library's own RCCL communicator for `engine` (world > 1, GPU): rank 0's ncclUniqueId travels over the already
+    initialised torch.distributed group, everything after that is RCCL inside libhulc_hip (hulc_backward_allreduce).  Returns False —
+    and leaves the torch.distributed path in place — when RCCL cannot be initialised (the reason is logged once)."""
+    if world_size() == 1 or not torch.cuda.is_available() or os.environ.get("HULC_DP_COMM", "capi") != "capi":
+        return False
+    try:
+        box = [engine.comm_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        engine.comm_init(box[0], dist.get_rank(), dist.get_world_size())
+        engine.comm_bucket_dtype = bucket_dtype
+        return True
+    except Exception as e:                 # pragma: no cover  (multi-GPU only)
+        if dist.get_rank() == 0:
+            print(f"[hulc_amd] library RCCL communicator unavailable ({e}); gradients go through torch.distributed", flush=True)
+        return False
+
+
 def backward_overlapped(engine) -> None:
     """Backward of the LAST modality pass of a step with the gradient all-reduce overlapped (world > 1).
 
@@ -80,6 +123,9 @@ def backward_overlapped(engine) -> None:
     """
     if world_size() == 1:
         engine.backward()
+        return
+    if getattr(engine, "has_comm", False):                    # the library's own RCCL communicator: bucketed, reverse-forward order, event-ordered
+        engine.backward_allreduce(getattr(engine, "comm_bucket_dtype", "fp32"))
         return
     if os.environ.get("HULC_DP_OVERLAP", "1") == "0":        # experiment knob: plain backward, then one all-reduce
         engine.backward()

@@ -20,8 +20,7 @@
  *   hulc_adam_step     <- torch.optim.Adam.step                   hulc/models/hulc.py:239-252, conf/model/optimizer/adam.yaml
  *   hulc_zero_grads    <- optimizer.zero_grad()
  *   hulc_scaler_*      <- torch.cuda.amp.GradScaler (Lightning NativeMixedPrecisionPlugin at precision: 16, conf/trainer/play_trainer.yaml:3)
- * The gradient all-reduce (DDPStrategy, hulc/training.py:64-69) stays on the host side: one RCCL all-reduce over the
- * flat gradient buffer this library writes.
+ *   hulc_backward_allreduce / hulc_allreduce_grads <- DDPStrategy's gradient all-reduce   hulc/training.py:64-69  (RCCL, in the library)
  */
 #ifndef HULC_HIP_H
 #define HULC_HIP_H
@@ -122,6 +121,27 @@ int hulc_backward(hulc_ctx* ctx);
 int hulc_backward_part(hulc_ctx* ctx, int32_t part);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+
+/* ---- Data-parallel gradient all-reduce, owned by the library (replaces Lightning's DDPStrategy, hulc/training.py:64-69: mean of the
+ * per-rank gradients; the 1/world factor is hulc_adam_step's grad_scale).  RCCL over xGMI on a private high-priority stream, ordered
+ * against the context's stream by events only (no host synchronisation).  One process per GPU:
+ *   rank 0: hulc_comm_unique_id(id) -> the host distributes the 128 bytes (any store / torch.distributed) -> every rank: hulc_comm_init.
+ * hulc_backward_allreduce = hulc_backward of the step's LAST forward with the SUM all-reduce overlapped: the flat gradient buffer is
+ *   reduced in module-group buckets in reverse-forward order — [action_decoder.* .. end of buffer] (61 MB fp32), plan_proposal.*,
+ *   plan_recognition.*, visual_goal.* + language_goal.*, perceptual_encoder.* — each issued as soon as the backward stage that finalises
+ *   it has been enqueued, so the wire is busy while the rest of the backward (the encoder convolutions last) still computes.  Whatever is
+ *   enqueued on the context's stream afterwards (hulc_adam_step) waits for the last collective.
+ * hulc_allreduce_grads = one all-reduce of the whole buffer after a finished hulc_backward (no overlap).
+ * bucket_dtype: HULC_DTYPE_F32 (the reference's fp32 gradients) or the engine's 16-bit type (HULC_DTYPE_BF16 for a bf16 context,
+ *   HULC_DTYPE_F16 for an fp16 one): the gradients cross the wire in 16 bits (half the bytes: xGMI rings are per-link bound), are summed
+ *   by RCCL in that type and widened back.  hulc_comm_buckets returns the bucket ranges (element offsets) in issue order. */
+int hulc_comm_unique_id(void* out_host /*128 bytes*/, int64_t cap);
+int hulc_comm_init(hulc_ctx* ctx, const void* unique_id_host, int32_t rank, int32_t world);
+int hulc_comm_destroy(hulc_ctx* ctx);
+int hulc_comm_buckets(hulc_ctx* ctx, int64_t* lo, int64_t* hi, int32_t cap);      /* returns the number of buckets, < 0 on error */
+int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes_on_wire_per_rank);
+int hulc_allreduce_grads(hulc_ctx* ctx, int32_t bucket_dtype);
+int hulc_backward_allreduce(hulc_ctx* ctx, int32_t bucket_dtype);
 
 /* ---- fp16 mode (HULC_DTYPE_F16): dynamic loss scaling = torch.cuda.amp.GradScaler, which Lightning's native-AMP plugin drives for the
  * reference's `precision: 16` (conf/trainer/play_trainer.yaml:3; fp16 autocast for matmuls/convs, fp32 for softmax / LayerNorm / losses

@@ -157,3 +157,52 @@ def test_backward_overlapped_allreduce_gloo():
     e = _FakeEngine(0)
     parallel.backward_overlapped(e)                                   # world 1: plain whole backward
     assert e.calls == [-1]
+
+
+def _bucket_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hulc_amd import parallel, spec
+    parallel.init_from_env("gloo")
+    d = spec.ModelDims()
+    lay, total = spec.layout(d)
+    sched = parallel.bucket_schedule(lay, total)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(total, generator=g)
+    mine = flat.clone()
+    # the REAL bucket schedule of the library (reverse-forward module groups), one async collective per bucket in issue order
+    works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in sched]
+    for w in works:
+        w.wait()
+    other = torch.randn(total, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    out.put((rank, bool(torch.allclose(flat, mine + other, rtol=0, atol=1e-6)), sched))
+    dist.destroy_process_group()
+
+
+def test_bucket_schedule_partitions_buffer_and_reduces_world2():
+    """The library's bucket plan (hulc_amd.parallel.bucket_schedule mirrors Engine::bucket_plan; the GPU test compares the two) driven with
+    real tensors over 2 gloo ranks: reverse-forward order, a partition of the flat buffer, every element reduced exactly once."""
+    import torch.multiprocessing as mp
+    from hulc_amd import parallel, spec
+    for kind, kw in (("hulc", {}), ("gcbc", {}), ("mcil", dict(use_clip=False)), ("mcil", dict(use_clip=False, rnn_type="gru"))):
+        lay, total = spec.layout(spec.ModelDims(kind=kind, **kw))
+        s = parallel.bucket_schedule(lay, total)
+        assert len(s) == 5 and s[0][1] == total and s[-1][0] == 0
+        t = sorted(s)
+        assert t[0][0] == 0 and t[-1][1] == total and all(t[i][1] == t[i + 1][0] for i in range(4)), (kind, s)   # a partition of the buffer
+        assert [n for n in ("action_decoder.", "plan_proposal.", "plan_recognition.", "visual_goal.", "perceptual_encoder.")
+                if not (s[["action_decoder.", "plan_proposal.", "plan_recognition.", "visual_goal.", "perceptual_encoder."].index(n)][0]
+                        <= min(off for k, (off, _) in lay.items() if k.startswith(n)) < s[["action_decoder.", "plan_proposal.", "plan_recognition.", "visual_goal.", "perceptual_encoder."].index(n)][1])] == []   # issue order = the order the backward finalises the groups
+        first = min(off for n, (off, _) in lay.items() if n.startswith("action_decoder."))
+        assert s[0][0] == first and s[-1][1] == min(off for n, (off, _) in lay.items() if not n.startswith("perceptual_encoder."))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    ps = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]

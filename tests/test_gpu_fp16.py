@@ -165,3 +165,57 @@ def test_module_precision_16_selects_fp16():
     m2 = Hulc(precision="bf16", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
     assert m2.engine.dtype == "bf16" and "grad_scaler" not in m2.configure_optimizers()["optimizer"].state_dict()
     m2.engine.close()
+
+
+def test_library_rccl_allreduce_world1_and_bucket_plan():
+    """hulc_comm_* / hulc_backward_allreduce through the C-ABI with a 1-rank RCCL communicator (all this box offers): RCCL is resolved,
+    the communicator initialises, every bucket is issued on the private stream in reverse-forward order, the event ordering lets the
+    following Adam step see the reduced buffer, and a 1-rank SUM leaves the gradients bit-identical (fp32 buckets) / bf16-rounded
+    (bf16 buckets).  The library's bucket ranges equal the host-side mirror hulc_amd.parallel.bucket_schedule."""
+    from hulc_amd import parallel, spec
+    dims, P, batch, fx = load_case("hulc_tiny")
+    for dtype, bucket in (("fp32", "fp32"), ("bf16", "fp32"), ("bf16", "bf16")):
+        eng = _engine(dims, 2, 4, dtype)
+        eng.load_numpy(P)
+        lay, numel = spec.layout(dims)
+        assert eng.comm_buckets() == parallel.bucket_schedule(lay, numel)
+        bk = eng.comm_buckets()
+        assert bk[0][1] == numel and bk[-1][0] == 0                                               # decoder (.. end of buffer) first, encoders last
+        t = sorted(bk)
+        assert sum(hi - lo for lo, hi in bk) == numel and all(t[i][1] == t[i + 1][0] for i in range(len(t) - 1))      # a partition of the buffer
+        tot_ref, _ = run_step(eng, batch)
+        g_ref = eng.flat_grads.clone()
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        with pytest.raises(RuntimeError):
+            eng.comm_init(eng.comm_unique_id(), 0, 1)                                             # one communicator per context
+        # same step, last backward with the overlapped bucketed all-reduce
+        eng.zero_grads()
+        scopes = list(batch)
+        for i, sc in enumerate(scopes):
+            from test_gpu_parity import to_dev
+            eng.forward_loss(to_dev(batch[sc]), "lang" in sc, 1.0 / len(scopes), 3.0, step=0)
+            if i == len(scopes) - 1:
+                eng.backward_allreduce(bucket)
+            else:
+                eng.backward()
+        torch.cuda.synchronize()
+        st = eng.comm_stats()
+        assert st["collectives"] == 5 and st["bytes"] == numel * (4 if bucket == "fp32" else 2)
+        if bucket == "fp32":
+            if dtype == "fp32":
+                assert torch.equal(eng.flat_grads, g_ref)                                          # fp32 engine is deterministic: bit-identical
+            else:
+                assert torch.allclose(eng.flat_grads, g_ref, rtol=1e-3, atol=1e-6)                 # bf16 engine: atomics reorder sums
+        else:
+            rel = ((eng.flat_grads - g_ref).double().norm() / g_ref.double().norm()).item()
+            assert 1e-5 < rel < 4e-3, rel                                                          # went through bf16 on the wire
+        # whole-buffer form + Adam ordered after it (no host sync in between)
+        p0 = eng.flat_params.clone()
+        eng.allreduce_grads(bucket)
+        eng.adam_step()
+        torch.cuda.synchronize()
+        assert eng.comm_stats()["collectives"] == 6 and not torch.equal(p0, eng.flat_params)
+        if dtype == "fp32":
+            with pytest.raises(RuntimeError):
+                eng.allreduce_grads("bf16")                                                        # no 16-bit kernels in the fp32 unit
+        eng.close()
