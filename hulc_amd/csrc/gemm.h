@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
 }
 static inline bool gemm_glds_ok(const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const EpiP& ep, int M, int N, int K) {
     auto row_ok = [](const DenseLoader<h16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0; };
-    return K >= 128 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
+    return K >= 64 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
 }
 static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
     static const int nw = getenv("HULC_GLDS_NW") ? atoi(getenv("HULC_GLDS_NW")) : 8;
@@ -684,7 +684,12 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const h16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int m0 = blockIdx.y * (MT * 16);          // row block of MT*16 rows
-    const int kq = K / NW, kb = wave * kq;          // K % (NW*32) == 0
+    // K % 32 == 0.  The waves split the K/32 k-steps as evenly as they divide: wave w takes steps/NW (+1 for the first steps % NW waves),
+    // so K need not be a multiple of NW*32 (the gripper encoder's fc of K = 3136 = 98 steps ran on the generic 32x32-tile kernel before:
+    // 25 serial k-steps per tile, 48 us for 1.6 GFLOP)
+    const int ksteps = K >> 5, kbase = ksteps / NW, krem = ksteps % NW;
+    const int kq = KS > 0 ? K / NW : (kbase + (wave < krem ? 1 : 0)) * 32;
+    const int kb = KS > 0 ? wave * kq : (wave * kbase + min(wave, krem)) * 32;
     const int g = lane >> 4, i = lane & 15;
     const h16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
     const h16_t* ap[MT];
@@ -903,7 +908,7 @@ static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, 
     //  0.03 ms SLOWER in an A/B on one box — kept off)
     static const bool shortk = getenv("HULC_SKINNY_SHORTK") ? atoi(getenv("HULC_SKINNY_SHORTK")) != 0 : false;
     const bool shape = M <= 64 || ((shortk || K >= 512) && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
-    return shape && (K % 128) == 0 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
+    return shape && (K % 32) == 0 && K >= 128 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }
 
 }  // namespace HULC_NS

@@ -127,7 +127,8 @@ def test_conv_wgrad_tr(which, IH, CI, KH, S):
 # variants 20x: the LDS-DMA kernel with MT = x row tiles per workgroup (201: the 16-row blocks of the M <= 32 recurrent step; 202 with a
 # ragged last block and many rows: the K = 2048 many-row routing)
 @pytest.mark.parametrize("M,N,K,variant", [(64, 2048, 2048, 82), (64, 2048, 2048, 84), (37, 256, 512, 82), (5, 32, 128, 41), (16, 1024, 4096, 81),
-                                           (64, 2048, 2048, 202), (32, 2048, 2048, 201), (27, 2048, 2048, 201), (500, 128, 2048, 202), (64, 6144, 2048, 202)])
+                                           (64, 2048, 2048, 202), (32, 2048, 2048, 201), (27, 2048, 2048, 201), (500, 128, 2048, 202), (64, 6144, 2048, 202),
+                                           (300, 128, 3136, 44), (64, 2048, 160, 42), (64, 64, 96, 41)])     # K % 128 != 0: uneven k-step split over the waves
 def test_skinny_gemm(M, N, K, variant):
     L, lib = _lib()
     rng = np.random.default_rng(M + N)
@@ -154,7 +155,7 @@ def test_tr_read_lane_mapping():
             assert o[l, j] == (l >> 4) * 2048 + (j * 4 + (l & 15) // 4) * 64 + (l & 15) % 4
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 2048, 2048), (2048, 1120, 2048), (2048, 2048, 1120), (1000, 200, 160), (520, 136, 128)])
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 2048), (2048, 1120, 2048), (2048, 2048, 1120), (1000, 200, 160), (520, 136, 128), (2048, 2048, 64), (640, 256, 96)])
 def test_gemm_glds_matches_fp64(M, N, K):
     """3-stage LDS-DMA GEMM (gemm_glds_kernel, the RNN input/weight-gradient GEMMs): ragged tiles, K % 64 == 32 tail, bias + ReLU
     epilogue, against an fp64 product of the same bf16-rounded operands; also equal to the register-staged kernel."""
