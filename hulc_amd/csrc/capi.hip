@@ -264,7 +264,7 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
     hipStream_t st = (hipStream_t)stream;
     EpiP ep; ep.out = out; ep.out_f32 = 0;
     const int NW = variant / 10, MT = variant % 10;
-    dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
+    dim3 grid(N / 16, MT > 0 ? (M + MT * 16 - 1) / (MT * 16) : 1);
     const h16_t* a = (const h16_t*)A; const h16_t* w = (const h16_t*)W;
 #define SK(nw, mt) hipLaunchKernelGGL((skinny_gemm_kernel<nw, mt>), grid, dim3(nw * 64), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep)
     if (NW == 8 && MT == 2) SK(8, 2); else if (NW == 8 && MT == 4) SK(8, 4); else if (NW == 4 && MT == 2) SK(4, 2); else if (NW == 4 && MT == 4) SK(4, 4);
@@ -273,6 +273,7 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
     else if (NW == 9 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<8, 2, 8>), grid, dim3(512), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
     else if (NW == 17 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<16, 2, 4>), grid, dim3(1024), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
     else if (NW == 20) { if (!launch_skinny_lds(st, a, (long long)K, w, (long long)K, M, N, K, MT, dense_out(N), ep)) { hulc_set_error("hulc_k_skinny: shape not covered by the LDS kernel"); return 1; } }
+    else if (NW == 30) launch_skinny(st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);       // the production router (incl. the K-chunked LDS kernel)
     else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;

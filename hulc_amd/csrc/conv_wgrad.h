@@ -528,7 +528,7 @@ __global__ void ingest_u8_kernel(const unsigned char* __restrict__ in, const int
 // ---------------------------------------------------------------------------------------------------------------------
 struct Wgrad1Cfg {
     static constexpr int CO = 32, KH = 8, KW = 8, S = 4, C = 3;
-    static constexpr int DYS = CO * 2 + 16;
+    static constexpr int DYS = CO * 2 + 32;     // 96 B = 32 x odd: the 4 pixel rows x 4 chunks of a tr-read group fall on distinct bank pairs (80 B pitched pixel 3 onto pixel 0: 44 % conflict cycles, tools/pmc_sq.sh)
     static size_t lds_bytes(int R, int IW, int OW, bool u8 = false) {
         const int OWp = (OW + 7) / 8 * 8;
         const int XR = (R - 1) * S + KH;

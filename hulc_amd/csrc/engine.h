@@ -667,7 +667,12 @@ struct Engine : IEngine {
                 launch_gemm<T, 64, 64>(st, la, lb, dense_out(Kc), ep, c.O, Kc, (int)npix, 1, nsplit);
             }
         }
-        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(cdiv(c.O * Kc, 1024), (!std::is_same<T, float>::value && nsplit >= 64) ? 16 : 1), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
+        // slab parts over grid.y, each landing with one fp32 atomic per element.  16 parts: more (21 / 24 / 64 for conv3 / conv2 / conv1) made
+        // every launch slower (23 / 11.3 / 10.9 us against 18.6 / 9.5 / 9.6: the scattered atomics, not the slab stream, are the cost)
+        const int ybl = cdiv(c.O * Kc, 1024);
+        static const int ypart_env = getenv("HULC_UNPACK_Y") ? atoi(getenv("HULC_UNPACK_Y")) : 16;
+        const int yparts = (!std::is_same<T, float>::value && nsplit >= 64) ? ypart_env : 1;
+        hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ybl, yparts), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
@@ -1244,6 +1249,13 @@ struct Engine : IEngine {
         for (int i = 0; i < S; ++i) {
             const long long t = at(i);
             const T* hp = i ? g.H + at(i - 1) * BH : nullptr;
+            if constexpr (std::is_same<T, h16_t>::value) {      // GEMM + gate arithmetic of the step in one launch (gemm.h: gru_step_lds_kernel)
+                static const bool fused = getenv("HULC_GRU_FUSED") ? atoi(getenv("HULC_GRU_FUSED")) != 0 : true;
+                if (i && fused) {
+                    TimerScope ts(this, "gru_step", "hbm", 2.0 * B * 3 * HID * HID, ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
+                    if (launch_gru_step(st, hp, whh.W, B, HID, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH)) continue;
+                }
+            }
             if (i) { EpiP ep = epi(gGf, true); ep.bias = bhh; gemm(dense<T>(hp, B, HID), dense<T>(whh.W, 3 * HID, HID), dense_out(3 * HID), ep, B, 3 * HID, HID); }
             hipLaunchKernelGGL((gru_gate_fwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, g.Zx + t * 3 * BH, i ? gGf : (const float*)nullptr, bhh, hp, B, HID,
                                g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH);

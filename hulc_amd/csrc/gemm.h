@@ -838,6 +838,221 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __rest
     }
     KSTAMP(5);
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// One time step of torch.nn.GRU (mcil variant, plan_recognition.rnn_type = nn.GRU; plan_recognition_net.py:12-42) in ONE launch:
+//   g = h_prev W_hh^T + b_hh (N = 3 x H gate blocks r | z | n), then r = sig(zx_r + g_r), z = sig(zx_z + g_z), n = tanh(zx_n + r g_n),
+//   h' = (1 - z) n + z h_prev;  r, z, n and g_n are kept for the backward.
+// Same structure as skinny_lds_kernel (A rows by LDS-DMA, W fragments straight to registers, K split over 16 waves), but a workgroup owns
+// the SAME 16 hidden units of all three gate blocks: the A rows it stages (2/3 of the bytes a workgroup pulls) feed three MFMAs instead of
+// one, the grid is one workgroup per CU (128 column tiles x 2 row blocks) instead of three waves of them, and the gate arithmetic runs in
+// the epilogue on values that never leave the chip (before: a 24 MB fp32 `g` round trip and a second launch per step).
+// K = 2048, rows of A 128-byte aligned, H % 16 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT, int KQ32, int NW>
+__global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W, long long ldw, int M, int H,
+                                                             const h16_t* __restrict__ zx, const float* __restrict__ bhh, h16_t* __restrict__ h_out,
+                                                             h16_t* __restrict__ r_out, h16_t* __restrict__ z_out, h16_t* __restrict__ n_out, h16_t* __restrict__ gn_out) {
+    constexpr int PCW = KQ32 / 2;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    typedef __attribute__((address_space(3))) char lchar;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;                              // hidden units n0 .. n0+15 of every gate block
+    const int m0 = blockIdx.y * (MT * 16);
+    const int kq = KQ32 * 32, kb = wave * kq;
+    const int g = lane >> 4, i = lane & 15;
+    lchar* wbase = (lchar*)sk_smem + wave * (MT * 2 * PCW * 1024);
+    {
+        const int r = lane >> 3, c = (lane & 7) ^ (r & 6);
+#pragma unroll
+        for (int rg = 0; rg < MT * 2; ++rg) {
+            const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
+#pragma unroll
+            for (int pc = 0; pc < PCW; ++pc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
+                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+        }
+    }
+    h16x8_t b[3][KQ32];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) {
+        const h16_t* wp = W + (long long)(gate * H + n0 + i) * ldw + kb + g * 8;
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u) b[gate][u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
+    }
+    // epilogue operands of this thread's 4 hidden units (threads < MT*64), fetched under the operand stream
+    const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
+    const bool ethread = tid < MT * 64 && erow < M;
+    uint2 zxv[3] = {uint2{0u, 0u}, uint2{0u, 0u}, uint2{0u, 0u}}, hpv = uint2{0u, 0u};
+    float4 bv[3];
+    if (ethread) {
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) {
+            zxv[gate] = *reinterpret_cast<const uint2*>(zx + (long long)erow * 3 * H + gate * H + ecol);
+            bv[gate] = *reinterpret_cast<const float4*>(bhh + gate * H + ecol);
+        }
+        hpv = *reinterpret_cast<const uint2*>(A + (long long)erow * lda + ecol);
+    }
+    f32x4 acc[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) acc[mt][gate] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's own DMA has landed (no other wave reads it)
+    {
+        const int r = i & 7;
+        lchar* fb = wbase + (i >> 3) * (PCW * 1024) + r * 128;
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u) {
+            const int chunk = ((u & 1) * 4 + g) ^ (r & 6);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h16x8_t a = *(__attribute__((address_space(3))) h16x8_t*)(fb + (mt * 2 * PCW + (u >> 1)) * 1024 + chunk * 16);
+#pragma unroll
+                for (int gate = 0; gate < 3; ++gate) acc[mt][gate] = MFMA_16x16x32_H(b[gate][u], a, acc[mt][gate], 0, 0, 0);   // D^T: lane (row i, g) owns units g*4..g*4+3
+            }
+        }
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);      // [NW][MT][3][64 lanes]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) red[((wave * MT + mt) * 3 + gate) * 64 + lane] = acc[mt][gate];
+    __syncthreads();
+    if (ethread) {
+        const int mt = tid >> 6, l = tid & 63;
+        f32x4 gs[3];
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) {
+            f32x4 v = red[((0 * MT + mt) * 3 + gate) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += red[((w * MT + mt) * 3 + gate) * 64 + l];
+            gs[gate] = v;
+        }
+        const float* bb[3] = {&bv[0].x, &bv[1].x, &bv[2].x};
+        float hn[4], rr[4], zz[4], nn[4], gn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned wr_ = e < 2 ? zxv[0].x : zxv[0].y, wz_ = e < 2 ? zxv[1].x : zxv[1].y, wn_ = e < 2 ? zxv[2].x : zxv[2].y, wh_ = e < 2 ? hpv.x : hpv.y;
+            const float xr = (e & 1) ? h2f_hi(wr_) : h2f_lo(wr_), xz = (e & 1) ? h2f_hi(wz_) : h2f_lo(wz_), xn = (e & 1) ? h2f_hi(wn_) : h2f_lo(wn_);
+            const float hp = (e & 1) ? h2f_hi(wh_) : h2f_lo(wh_);
+            const float gr = gs[0][e] + bb[0][e], gz = gs[1][e] + bb[1][e];
+            gn[e] = gs[2][e] + bb[2][e];
+            rr[e] = 1.f / (1.f + __expf(-(xr + gr)));
+            zz[e] = 1.f / (1.f + __expf(-(xz + gz)));
+            nn[e] = tanhf(xn + rr[e] * gn[e]);
+            hn[e] = (1.f - zz[e]) * nn[e] + zz[e] * hp;
+        }
+        const long long o = (long long)erow * H + ecol;
+        *reinterpret_cast<uint2*>(h_out + o) = uint2{pack2h(hn[0], hn[1]), pack2h(hn[2], hn[3])};
+        *reinterpret_cast<uint2*>(r_out + o) = uint2{pack2h(rr[0], rr[1]), pack2h(rr[2], rr[3])};
+        *reinterpret_cast<uint2*>(z_out + o) = uint2{pack2h(zz[0], zz[1]), pack2h(zz[2], zz[3])};
+        *reinterpret_cast<uint2*>(n_out + o) = uint2{pack2h(nn[0], nn[1]), pack2h(nn[2], nn[3])};
+        *reinterpret_cast<uint2*>(gn_out + o) = uint2{pack2h(gn[0], gn[1]), pack2h(gn[2], gn[3])};
+    }
+}
+// returns false when the shape is not covered (the caller then runs the GEMM + gate kernel pair)
+static inline bool launch_gru_step(hipStream_t st, const h16_t* hprev, const h16_t* Whh, int M, int H, const h16_t* zx, const float* bhh, h16_t* h_out, h16_t* r_out,
+                                   h16_t* z_out, h16_t* n_out, h16_t* gn_out) {
+    if (H != 2048 || M < 1 || ((uintptr_t)hprev % 128) != 0 || ((uintptr_t)Whh % 16) != 0) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)gru_step_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    dim3 grid(H / 16, (M + 31) / 32);
+    // LDS: the A region (16 waves x 2 x 2 x 2 KB = 128 KB) is reused for the 16 x 2 x 3 K-partials (96 KB)
+    hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, hprev, (long long)H, Whh, (long long)H, M, H, zx, bhh, h_out, r_out,
+                       z_out, n_out, gn_out);
+    return true;
+}
+
+// skinny_lds_kernel for K = NCH x 2048 (the GRU's BPTT step: dh = dG W_hh with K = 3 x 2048): the same 16-wave structure walks the K chunks
+// one after the other through the SAME LDS regions — a wave only ever reads the region it DMAs into, so there is no barrier between chunks,
+// just the wave's own lgkmcnt(0) (fragment reads done) before the next chunk's DMA and vmcnt(0) before its MFMAs.  The W fragments of the
+// next chunk are requested before the current chunk's MFMAs.  Replaces the register-fragment kernel for these shapes (18 -> 14 us per step).
+template <int MT, int KQ32, int NW>
+__global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W, long long ldw, int M, int N,
+                                                                  int K, DenseOut om, EpiP ep) {
+    constexpr int PCW = KQ32 / 2, KCH = NW * KQ32 * 32;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    typedef __attribute__((address_space(3))) char lchar;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
+    const int kq = KQ32 * 32, kb = wave * kq;
+    const int g = lane >> 4, i = lane & 15;
+    const int nch = K / KCH;
+    lchar* wbase = (lchar*)sk_smem + wave * (MT * 2 * PCW * 1024);
+    auto dma_chunk = [&](int ch) {
+        const int r = lane >> 3, c = (lane & 7) ^ (r & 6);
+#pragma unroll
+        for (int rg = 0; rg < MT * 2; ++rg) {
+            const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + (long long)ch * KCH + kb + c * 8;
+#pragma unroll
+            for (int pc = 0; pc < PCW; ++pc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
+                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+        }
+    };
+    const h16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    dma_chunk(0);
+    h16x8_t b[KQ32];
+#pragma unroll
+    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
+    const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
+    const bool ethread = tid < MT * 64 && erow < M;
+    const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
+    const long long eo = ethread ? om.offset(erow, 0) + ecol : 0;
+    EpiPre4 pre;
+    if (ethread) pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r7 = i & 7;
+    lchar* fb = wbase + (i >> 3) * (PCW * 1024) + r7 * 128;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this chunk's DMA and W fragments have landed
+        h16x8_t a[KQ32][MT];
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u) {
+            const int chunk = ((u & 1) * 4 + g) ^ (r7 & 6);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *(__attribute__((address_space(3))) h16x8_t*)(fb + (mt * 2 * PCW + (u >> 1)) * 1024 + chunk * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments are in registers: the region may be overwritten
+        h16x8_t bc[KQ32];
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u) bc[u] = b[u];
+        if (ch + 1 < nch) {                                         // next chunk in flight under this chunk's MFMAs
+            dma_chunk(ch + 1);
+#pragma unroll
+            for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + (long long)(ch + 1) * KCH + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < KQ32; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA_16x16x32_H(bc[u], a[u][mt], acc[mt], 0, 0, 0);
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    if (ethread) {
+        f32x4 v = red[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w * MT * 64 + tid];
+        const float v4[4] = {v[0], v[1], v[2], v[3]};
+        epi_apply4<h16_t>(ep, pre, v4, errow, ecol, N, eo);
+    }
+}
+static inline bool launch_skinny_lds_kchunk(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K, const DenseOut& om,
+                                            const EpiP& ep) {
+    if (K % 2048 != 0 || K <= 2048 || M > 64 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0 || (N % 16) != 0) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)skinny_lds_kchunk_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((skinny_lds_kchunk_kernel<2, 4, 16>), dim3(N / 16, (M + 31) / 32), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep);
+    return true;
+}
+
 template <int MT, int KQ32>
 static inline void launch_skinny_lds_t(hipStream_t st, dim3 grid, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                        const DenseOut& om, const EpiP& ep) {
@@ -899,6 +1114,8 @@ static inline void launch_skinny_nw(hipStream_t st, const h16_t* A, long long ld
 }
 static inline void launch_skinny(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                  const DenseOut& om, const EpiP& ep) {
+    static const bool kchunk = getenv("HULC_SKINNY_KCHUNK") ? atoi(getenv("HULC_SKINNY_KCHUNK")) != 0 : true;
+    if (kchunk && skinny_use_lds && M > 16 && launch_skinny_lds_kchunk(st, A, lda, W, ldw, M, N, K, om, ep)) return;     // K = n x 2048, M <= 64 (GRU BPTT step)
     if (K % 512 == 0) launch_skinny_nw<8>(st, A, lda, W, ldw, M, N, K, om, ep);     // 8 waves x >=2 k-steps
     else launch_skinny_nw<4>(st, A, lda, W, ldw, M, N, K, om, ep);
 }

@@ -128,7 +128,8 @@ def test_conv_wgrad_tr(which, IH, CI, KH, S):
 # ragged last block and many rows: the K = 2048 many-row routing)
 @pytest.mark.parametrize("M,N,K,variant", [(64, 2048, 2048, 82), (64, 2048, 2048, 84), (37, 256, 512, 82), (5, 32, 128, 41), (16, 1024, 4096, 81),
                                            (64, 2048, 2048, 202), (32, 2048, 2048, 201), (27, 2048, 2048, 201), (500, 128, 2048, 202), (64, 6144, 2048, 202),
-                                           (300, 128, 3136, 44), (64, 2048, 160, 42), (64, 64, 96, 41)])     # K % 128 != 0: uneven k-step split over the waves
+                                           (300, 128, 3136, 44), (64, 2048, 160, 42), (64, 64, 96, 41),
+                                           (64, 2048, 6144, 300), (37, 1024, 4096, 300), (64, 512, 2048, 300)])      # 300: the production router; K = n x 2048 -> K-chunked LDS kernel     # K % 128 != 0: uneven k-step split over the waves
 def test_skinny_gemm(M, N, K, variant):
     L, lib = _lib()
     rng = np.random.default_rng(M + N)

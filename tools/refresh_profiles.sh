@@ -1,11 +1,15 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): regenerates every measurement that profiles/ holds for this round into gpurun_out/r01/.
-#   1. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) -> per-kernel-class HBM bytes per launch (profiles/r01_pmc_traffic.json)
+# Runs ON THE GPU BOX (via gpurun): regenerates every measurement profiles/ holds for a round into gpurun_out/<tag>/ (default tag r02);
+# `tools/collect_profiles.py <tag>` then copies the summaries into profiles/ and rewrites profiles/README.md.
+#   1. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) -> per-kernel-class HBM bytes per launch (pmc_traffic.json)
 #   2. rocprofv3 --kernel-trace --stats of the bench command (9 steps: 2 warm-up + 2 survey + 5 timed)
-#   3. the official bench line (N=1, defaults, with cpu_baseline), which picks roofline.traffic from step 1
+#   3. two SQ counter passes (tools/pmc_sq.sh): MFMA-pipe utilisation, LDS bank conflicts, wait breakdown per kernel (mfma_util.csv)
+#   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
+#   5. the probes behind DESIGN.md's numbers: tools/bin/ct_stamps (conv tile phases), tools/bin/gridbar2 (XCD barrier + sc1 publish)
+T=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01
+O=$R/gpurun_out/$T
 mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --preroll 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1 </dev/null
@@ -13,16 +17,26 @@ done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline > $O/stats.log 2>&1 </dev/null
 cd $R
 python tools/pmc_traffic.py $O > $O/pmc_traffic.log
-cp $O/pmc_traffic.json $R/profiles/r01_pmc_traffic.json
+mkdir -p $R/profiles && cp $O/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json      # bench.py reads the newest profiles/r*_pmc_traffic.json
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 test -n "$f" && cp $f $O/kernel_stats.csv && python tools/prof_summary.py $O/kernel_stats.csv 9 45 > $O/kernel_stats_summary.txt
-timeout 600 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err </dev/null
-timeout 300 python $R/bench.py --ingest u8 --no-cpu-baseline > $O/bench_n1_u8.json 2>/dev/null </dev/null
-timeout 300 python $R/bench.py --lang 1 --no-cpu-baseline > $O/bench_n1_vislang.json 2>/dev/null </dev/null
-timeout 300 python $R/bench.py --lang 1 --pair 0 --no-cpu-baseline > $O/bench_n1_vislang_seq.json 2>/dev/null </dev/null
-timeout 300 python $R/bench.py --model mcil --no-cpu-baseline > $O/bench_n1_mcil.json 2>/dev/null </dev/null
-timeout 300 python $R/bench.py --model mcil_gru --no-cpu-baseline > $O/bench_n1_mcil_gru.json 2>/dev/null </dev/null
-timeout 300 python $R/bench.py --seq 64 --batch 32 --no-cpu-baseline > $O/bench_n1_s64.json 2>/dev/null </dev/null
+bash tools/pmc_sq.sh $T/sq > $O/sq.log 2>&1
+cd $R
+timeout 900 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err </dev/null
+b() { name=$1; shift; timeout 400 python $R/bench.py --no-cpu-baseline "$@" > $O/bench_n1_$name.json 2>/dev/null </dev/null; }
+b fp16 --dtype fp16
+b s64 --seq 64 --batch 32
+b s64_fp16 --seq 64 --batch 32 --dtype fp16
+b s64_fp16_vislang --seq 64 --batch 32 --dtype fp16 --lang 1
+b u8 --ingest u8
+b vislang --lang 1
+b vislang_seq --lang 1 --pair 0
+b mcil --model mcil
+b mcil_gru --model mcil_gru
+test -x tools/bin/ct_stamps && timeout 120 tools/bin/ct_stamps > $O/ct_stamps.txt 2>&1
+test -x tools/bin/gridbar2 && timeout 120 tools/bin/gridbar2 > $O/gridbar2.txt 2>&1
+test -x tools/bin/gridbar && timeout 120 tools/bin/gridbar > $O/gridbar.txt 2>&1
 tail -1 $O/bench_n1.json | cut -c1-400
 head -8 $O/kernel_stats_summary.txt
-cat $O/pmc_traffic.log | tail -12
+tail -12 $O/pmc_traffic.log
+head -14 $O/sq/summary.txt
