@@ -408,7 +408,13 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
     for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
     const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 4), *reinterpret_cast<const float4*>(bias + 16 + g * 4)};
     const int nitems = Nf * nbands;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // frame-wise (fw, experiment knob HULC_C1_FW=1): a workgroup walks the bands of one frame back to back so that the rows two bands share come
+    // from L2 — what cut conv1's weight gradient by 25 % measured 0.4 % SLOWER here (4 resident workgroups per CU already re-read those rows
+    // from the XCD's L2 within microseconds; the frame-wise order only removes the interleaving of their phases): default item-wise
+    const bool fw = Nf >= (int)gridDim.x && !(dbg & 32);
+    for (int it = blockIdx.x; fw ? (it < Nf) : (it < nitems); it += gridDim.x)
+    for (int bnd = 0; bnd < (fw ? nbands : 1); ++bnd) {
+        const int item = fw ? it * nbands + bnd : it;
         const int f = item / nbands, b = item % nbands;
         const int oh0 = b * R;
         const int ih0 = oh0 * 4;
@@ -487,6 +493,8 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
     while (R > 1 && lds_of(R) > (size_t)lds_kb * 1024) --R;
     const int nbands = (OH + R - 1) / R;
     R = (OH + nbands - 1) / nbands;
+    static const int fw_env = getenv("HULC_C1_FW") ? atoi(getenv("HULC_C1_FW")) : 0;    // same-box A/B: frame-wise 4.458 vs item-wise 4.440 ms/step -> off
+    if (!fw_env) dbg |= 32;
     static const int occ = getenv("HULC_C1_OCC") ? atoi(getenv("HULC_C1_OCC")) : 4;      // min waves per SIMD the register allocation targets: 128 VGPRs (5 spilled) lets all 4 workgroups of a CU be resident (133 -> only 3); A/B on one box: -0.8 % of the step
     static bool attr_set = false;
     if (!attr_set) {

@@ -631,8 +631,196 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 of the kernel above for the fp32 NCHW boundary (the headline configuration): 8 waves, 2 workgroups per CU, and the NEXT band's
+// frames + dY rows prefetched into registers while the current band multiplies.
+//   v1 runs 4 workgroups per CU that each stage a band (loads -> wait -> convert -> LDS) and then multiply it; the HBM stream stalls
+//   whenever the resident workgroups are all converting / multiplying, the bands are 3 output rows tall (39 KB of LDS each), so every
+//   band re-stages 4 of its 16 input rows (33 % over-fetch) and pays its barriers for 12 new rows.  It moved 1.53 GB in 370 us (3.6 of
+//   the ~6.3 TB/s a streaming copy reaches).
+//   v2: bands of 7 output rows (32 input rows: 14 % over-fetch, 7 bands per 49-row frame), 13 x 16 B per thread in flight for the whole
+//   multiply phase of the previous band (106 KB per workgroup), zero rows applied at the commit, the two wave halves split the pixel
+//   units and are summed through LDS at the end.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PFX, int PFY>
+__global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __restrict__ X, int* __restrict__ work_ctr, const h16_t* __restrict__ dY, float* __restrict__ part,
+                                                                 float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands) {
+    using C = Wgrad1Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * C::S + C::KH;
+    const int XRS = IW * 2 + 16;
+    const int xbytes = C::C * XR * XRS + 512;
+    const int dypix = R * OWp + 8;
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xbytes;
+    for (int i = tid * 16; i < xbytes + dypix * C::DYS; i += 512 * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+    const int W4 = IW >> 2;
+    const int nx = C::C * XR * W4, ny = R * OW * 4;               // 16-byte chunks of a band: fp32 frame quads, dY channel quarters
+    // band-invariant slot descriptors, one register each: frame slots (channel << 16 | row << 8 | float4 column), dY slots (row << 16 | chunk)
+    int xd[PFX], yd[PFY];
+#pragma unroll
+    for (int k = 0; k < PFX; ++k) {
+        const int e = min(tid + k * 512, nx - 1);
+        const int c = e / (XR * W4), rem = e - c * (XR * W4), r = rem / W4, q4 = rem - r * W4;
+        xd[k] = (c << 16) | (r << 8) | q4;
+    }
+#pragma unroll
+    for (int k = 0; k < PFY; ++k) {
+        const int e = min(tid + k * 512, ny - 1);
+        const int r = e / (OW * 4), i = e - r * (OW * 4);
+        yd[k] = (r << 16) | i;
+    }
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2, q = a & 3;
+    const int ccolA = q * 8;
+    const int nt0 = (wave & 3) * 3, uh = wave >> 2;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 px[PFX];
+    u32x4_t py[PFY];
+    int xrows = 0, yrows = 0;                                     // rows of the prefetched band inside the frame (others are zeros)
+    const int nitems = Nf * nbands;
+    auto prefetch = [&](int item) {
+        const int f = item / nbands, oh0 = (item % nbands) * R;
+        const int ih0 = oh0 * C::S;
+        xrows = min(XR, IH - ih0); yrows = min(R, OH - oh0);
+        const float* xb = X + ((long long)f * C::C * IH + ih0) * IW;
+        const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
+#pragma unroll
+        for (int k = 0; k < PFX; ++k) {
+            const int c = xd[k] >> 16, r = (xd[k] >> 8) & 0xff, q4 = xd[k] & 0xff;
+            px[k] = *reinterpret_cast<const float4*>(xb + (c * IH + min(r, xrows - 1)) * IW + q4 * 4);       // rows below the frame: re-read a valid row (zeroed at the commit)
+        }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k) {
+            const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+            py[k] = *reinterpret_cast<const u32x4_t*>(yb + (min(r, yrows - 1) * OW) * C::CO + i * 8);
+        }
+    };
+    // A workgroup walks the bands of ONE frame back to back (work unit = frame, claimed dynamically): the (KH - S) input rows two
+    // consecutive bands share are then re-read by the same CU a few microseconds later and come from L2 instead of HBM (with the bands of
+    // a frame dealt to different workgroups the PMC counters showed 27 % more HBM bytes than the frames hold).
+    __shared__ int s_next[2];
+    int frame = blockIdx.x, fiter = 0, band = 0;
+    int item = frame * nbands;
+    if (frame < Nf) prefetch(item);
+    while (frame < Nf) {
+        if (band == 0 && work_ctr && tid == 0) s_next[fiter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);
+        __syncthreads();                                          // previous band consumed (first pass: zero fill visible)
+        const int cxr = xrows, cyr = yrows;
+#pragma unroll
+        for (int k = 0; k < PFX; ++k)
+            if (tid + k * 512 < nx) {
+                const int c = xd[k] >> 16, r = (xd[k] >> 8) & 0xff, q4 = xd[k] & 0xff;
+                const bool in = r < cxr;
+                u32x2_t o;
+                o[0] = in ? pack2h(px[k].x, px[k].y) : 0u;
+                o[1] = in ? pack2h(px[k].z, px[k].w) : 0u;
+                *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + r) * XRS + q4 * 8) = o;
+            }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k)
+            if (tid + k * 512 < ny) {
+                const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+                const u32x4_t v = r < cyr ? py[k] : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
+                *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
+            }
+        __syncthreads();
+        if (++band == nbands) {                                   // next frame (its claim was written at the frame's first band: >= 1 barrier ago)
+            band = 0;
+            frame = work_ctr ? s_next[fiter & 1] : frame + (int)gridDim.x;
+            ++fiter;
+        }
+        item = frame * nbands + band;
+        if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
+        const int units = R * U;
+#pragma unroll 1
+        for (int u0 = uh * 4; u0 < units; u0 += 8) {
+            const int u = u0 + g;
+            const bool valid = u < units;
+            const int r = valid ? u / U : 0, ow0 = valid ? (u - (u / U) * U) * 8 : 0;
+            const int pixA = valid ? r * OWp + ow0 : R * OWp;
+            lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
+            h16x8_t af[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int nt = nt0 + j;
+                const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
+                lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
+                const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the two unit halves (waves w and w + 4) are summed through LDS, then one slab per workgroup
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (uh == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) red[((wave & 3) * 6 + j * 2 + c) * 64 + lane] = acc[j][c];
+    }
+    __syncthreads();
+    if (uh == 0) {
+        float* out = part + (long long)blockIdx.x * C::CO * 192;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 v = acc[j][c] + red[((wave & 3) * 6 + j * 2 + c) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * 192 + (nt0 + j) * 16 + a] = v[r];
+            }
+    }
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) redf[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C::CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float sacc = 0.f;
+        for (int t = cgrp; t < 512; t += 4) sacc += redf[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, sacc);
+    }
+}
+
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
+    static const int v2 = getenv("HULC_W1_V2") ? atoi(getenv("HULC_W1_V2")) : 1;
+    if (v2 && !X.u8 && (IW % 4) == 0) {
+        // tallest band whose images fit 2 workgroups per CU and whose chunks fit the prefetch slots (8 frame + 2 dY registers of 16 B per thread:
+        // 10 + 3 slots spilled 46 registers of in-flight data at the 128-VGPR budget of 2 x 8 waves per CU, which serialised the prefetch)
+        int R = OH;
+        auto fits = [&](int r) {
+            const int XR = (r - 1) * Wgrad1Cfg::S + Wgrad1Cfg::KH;
+            return Wgrad1Cfg::lds_bytes(r, IW, OW) <= (size_t)79 * 1024 && (long long)3 * XR * (IW / 4) <= 6 * 512 && (long long)r * OW * 4 <= 2 * 512 && XR < 128 && r < 128;
+        };
+        while (R > 1 && !fits(R)) --R;
+        if (fits(R)) {
+            const int nb = (OH + R - 1) / R;
+            R = (OH + nb - 1) / nb;
+            const size_t lds = std::max<size_t>(Wgrad1Cfg::lds_bytes(R, IW, OW), 512 * 8 * sizeof(float));
+            static bool attr2 = false;
+            if (!attr2) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2 = true; }
+            const int grid = std::min(std::min(Nf, 512), max_blocks);
+            hipLaunchKernelGGL((conv1_wgrad_tr2_kernel<6, 2>), dim3(grid), dim3(512), lds, st, reinterpret_cast<const float*>(X.X), work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
+            return grid;
+        }
+    }
     static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
     static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
     if (env_wg > 0) max_blocks = env_wg;
