@@ -486,6 +486,8 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
 }
 static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16_t* W, const float* bias, h16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
                                     unsigned* maskbits = nullptr) {
+    // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
+    //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
     auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = getenv("HULC_C1_WG") ? atoi(getenv("HULC_C1_WG")) : 1024;
