@@ -80,4 +80,19 @@ if marker in s:
 else:
     s = s.rstrip() + "\n\n" + gen + "\n"
 open(P("README.md"), "w").write(s)
+r = open(os.path.join(ROOT, "README.md")).read()
+m0, m1 = "<!-- BEGIN numbers (tools/collect_profiles.py) -->", "<!-- END numbers -->"
+txt = f"""{m0}
+Round 2 (1 x MI355X, B=64 windows, seq_len 32, bf16): **{d['value'] / 1000:.1f} k trajectory-windows/s, {d['ms_per_step']} ms/step** at the reference's fp32
+boundary (round 1: 13.7 k / 4.686 ms); {var['fp16']['value'] / 1000:.1f} k in fp16 with the on-device GradScaler (the reference's `precision: 16`);
+{var['u8']['value'] / 1000:.1f} k with uint8 ingest; {var['vislang']['value'] / 1000:.1f} k for 32 vis + 32 lang + CLIP as one paired pass ({var['vislang_seq']['value'] / 1000:.1f} k with the reference's one pass per
+modality); BASELINE config 5 (seq_len 64 x 32 windows, fp16): {var['s64_fp16']['value'] / 1000:.2f} k.  CPU baseline (the step on torch's CPU library kernels, host cores of
+the GPU box): {cb['value']} windows/s with {cb['cores']} threads; the reference itself did 8.0-12.2 windows/s on 8 vCPU (BASELINE.md).
+Validation forward and stateful rollout (`validation_step`, `reset`/`step`, also for GCBC) run on the same kernels; the reference's `model=mcil`
+configuration (BiRNN plan recognition, continuous latent plan) trains, validates and rolls out on the same engine: {var['mcil']['value'] / 1000:.1f} k windows/s
+(`bench.py --model mcil`), {var['mcil_gru']['value'] / 1000:.1f} k with the `rnn_type=nn.GRU` plan encoder of BASELINE config 4 (`--model mcil_gru`).  Multi-GPU: one process per
+GPU, the gradient all-reduce is the library's own (RCCL over xGMI, bucketed in reverse-forward order under the backward: `hulc_backward_allreduce`).
+{m1}"""
+r = r[:r.index(m0)] + txt + r[r.index(m1) + len(m1):]
+open(os.path.join(ROOT, "README.md"), "w").write(r)
 print("ok", d["value"], d["ms_per_step"])
