@@ -491,7 +491,20 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, rows, n, g, b, out, ldo, outf, ldf, stats);
     }
     void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
-                long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db) {
+                long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db, float drop_p = 0.f, unsigned long long drop_seed = 0) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            static const bool fused = getenv("HULC_LN_FUSED") ? atoi(getenv("HULC_LN_FUSED")) != 0 : true;
+            if (fused) {
+                const int rpb = rows >= 1024 ? 16 : 4;
+                hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
+                                   drop_p, drop_seed, rpb, dg, db);
+                return;
+            }
+        }
+        if ((drop_p > 0.f || drop_seed != 0) && dxt && dxf) {       // unfused: dx first, its 16-bit copy through the dropout mask in a second launch
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, (T*)nullptr, 0);
+            hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)rows * n, 256)), dim3(256), 0, st, dxf, (float*)nullptr, dxt, (long long)rows * n, drop_p, drop_seed);
+        } else
         hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt);
         const int nsplit = std::max(1, std::min(64, cdiv(rows, 64)));
         if constexpr (std::is_same<T, h16_t>::value) {
@@ -1590,9 +1603,7 @@ struct Engine : IEngine {
         if (bucket_ready(0)) return 1;       // action_decoder.*, proj_vis_lang.*, logit_scale are final: their all-reduce starts under the rest of the backward
         // ---- straight-through + KL -> logits grads; plan proposal backward
         if (hulc) {
-            hipLaunchKernelGGL(st_softmax_bwd_kernel, dim3(B * NCAT), dim3(64), 0, st, probs, dplan, dpr_kl, NCLS, dprl);
-            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dprl, dprl_t, (long long)B * PLAN);
-            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dpp_kl, dppl_t, (long long)B * PLAN);
+            hipLaunchKernelGGL((st_softmax_bwd_kernel<T>), dim3(B * NCAT), dim3(64), 0, st, probs, dplan, dpr_kl, NCLS, dprl, dprl_t, dpp_kl, dppl_t);
             DenseOut om = dense_out(EMB + GOAL);
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
@@ -1624,15 +1635,13 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(bcast_over_s_kernel, dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dxm, B, S, EMB, dx);
             for (int l = 1; l >= 0; --l) {
                 // LN2
-                ln_bwd(dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, nullptr, 0, d_tr_n2g[l], d_tr_n2b[l]);
-                hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dy_f, (float*)nullptr, dt_c, (long long)N * EMB, dp, site_seed(4 + 4 * l));
+                ln_bwd(dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n2g[l], d_tr_n2b[l], dp, site_seed(4 + 4 * l));   // dt_c = dropout mask of the FFN branch applied to dy_f
                 lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
                 { EpiP ep = epi(dt_a, false); ep.mask = hff[l]; ep.alpha = dp > 0.f ? 1.f / (1.f - dp) : 1.f; lin_dgrad(dt_c, N, tr_l2[l], ep, dense_out(FF)); }
                 lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
                 { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
                 // LN1
-                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, nullptr, 0, d_tr_n1g[l], d_tr_n1b[l]);
-                hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dy_f, (float*)nullptr, dt_c, (long long)N * EMB, dp, site_seed(2 + 4 * l));
+                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
                 lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
                 { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
                 if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));

@@ -564,6 +564,53 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         if (dx_t) dx_t[(long long)row * ldt + lane + 64] = from_f<T>(d);
     }
 }
+// 16-bit engines: the whole LayerNorm backward in ONE launch.  A workgroup walks `rows_per_block` rows (one wave per row at a time): dx as above — the
+// 16-bit copy optionally through the dropout mask of the residual branch the gradient flows into next (the forward applied that mask in the
+// producing GEMM's epilogue; index = row * n + col as there) — and the parameter gradients from per-lane partial sums over the block's rows,
+// reduced over the 4 waves in LDS and added with one fp32 atomic per column per block.  Replaces layernorm_bwd_kernel +
+// layernorm_param_grad_kernel (+ dropout_apply_kernel in the transformer): 7 + 7 + 4 launches of ~5 us per step become 7.
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                                  long long ldx, const float* __restrict__ stats, const float* __restrict__ g,
+                                                                  int rows, int n, float* __restrict__ dx_f32, long long ldd, int accumulate,
+                                                                  T* __restrict__ dx_t, long long ldt, float drop_p, unsigned long long seed,
+                                                                  int rows_per_block, float* __restrict__ dg, float* __restrict__ db) {
+    __shared__ float red[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const float g0 = lane < n ? g[lane] : 0.f, g1 = lane + 64 < n ? g[lane + 64] : 0.f;
+    float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float* xr = x + (long long)row * ldx;
+        const float* dr = dy + (long long)row * lddy;
+        float xh0 = 0.f, xh1 = 0.f, d0 = 0.f, d1 = 0.f;
+        if (lane < n) { xh0 = (xr[lane] - mean) * rstd; d0 = dr[lane]; }
+        if (lane + 64 < n) { xh1 = (xr[lane + 64] - mean) * rstd; d1 = dr[lane + 64]; }
+        sg0 += d0 * xh0; sb0 += d0; sg1 += d1 * xh1; sb1 += d1;
+        const float q0 = d0 * g0, q1 = d1 * g1;
+        const float m1 = wave_sum(q0 + q1) / n;
+        const float m2 = wave_sum(q0 * xh0 + q1 * xh1) / n;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = lane + h * 64;
+            if (col < n) {
+                const float d = rstd * ((h ? q1 : q0) - m1 - (h ? xh1 : xh0) * m2);
+                if (dx_f32) { float* o = dx_f32 + (long long)row * ldd + col; *o = accumulate ? *o + d : d; }
+                if (dx_t) {
+                    float v = d;
+                    if (drop_p > 0.f) v = hash_uniform(seed, (long long)row * n + col) < drop_p ? 0.f : v / (1.f - drop_p);
+                    dx_t[(long long)row * ldt + col] = from_f<T>(v);
+                }
+            }
+        }
+    }
+    if (!dg) return;
+    red[wave][lane] = sg0; red[wave][64 + lane] = sg1; red[wave][128 + lane] = sb0; red[wave][192 + lane] = sb1;
+    __syncthreads();
+    const int t = threadIdx.x, col = t & 127;
+    if (col < n) unsafeAtomicAdd((t < 128 ? dg : db) + col, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+}
 // partial sums for dgamma[c] = sum_r dy*xhat and dbeta[c] = sum_r dy over a row chunk (grid.y); part = [2][nsplit][n]
 __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                                    long long ldx, const float* __restrict__ stats, int rows, int n,
@@ -889,14 +936,23 @@ __global__ void gru_gate_bwd_kernel(const T* __restrict__ dH, const T* __restric
     direct[idx] = from_f<T>(dh * z);
 }
 // dpr_logits[b][cat][:] = probs * (dplan - sum(probs*dplan)) + dpr_kl
+// also emits the compute-precision copies the two backward passes start from: out_t (this gradient) and dpp_t (= dpp_kl, the plan-proposal
+// logits' KL gradient of the same shape) — two cast launches less
+template <typename T>
 __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dplan,
-                                                            const float* __restrict__ dpr_kl, int NCLS, float* __restrict__ out) {
+                                                            const float* __restrict__ dpr_kl, int NCLS, float* __restrict__ out, T* __restrict__ out_t,
+                                                            const float* __restrict__ dpp_kl, T* __restrict__ dpp_t) {
     const long long base = (long long)blockIdx.x * NCLS;
     const int lane = threadIdx.x;
     const bool ok = lane < NCLS;
     const float p = ok ? probs[base + lane] : 0.f, d = ok ? dplan[base + lane] : 0.f;
     const float dot = wave_sum(p * d);
-    if (ok) out[base + lane] = p * (d - dot) + dpr_kl[base + lane];
+    if (ok) {
+        const float v = p * (d - dot) + dpr_kl[base + lane];
+        out[base + lane] = v;
+        out_t[base + lane] = from_f<T>(v);
+        dpp_t[base + lane] = from_f<T>(dpp_kl[base + lane]);
+    }
 }
 
 // =========================================================================================================
