@@ -34,6 +34,12 @@ struct ConvTileP {
                              // doubling the kernel's time
     unsigned* bits_out;      // forward, CN == 64, relu: also emit the ReLU bitmask of the output, 2 words per pixel (bit c of word c/32 = out channel c > 0)
                              // = what the dgrad of this layer's consumer reads as `maskbits` instead of the 16-bit activations (64x fewer bytes)
+    int FPB;                 // frames per band (set by launch_conv_tile; > 1 only with nbands == 1): small frames (the gripper camera's 9x9 / 20x20
+                             // maps) are stacked FPB to a band so that a band feeds all 8 waves and the per-band barriers / staging are paid once per
+                             // FPB frames.  Forward: the frames are contiguous in memory, the band is simply FPB*IMH rows and the output rows that
+                             // straddle two frames are computed and dropped.  Dgrad: the band is a VIRTUAL stack with VPI = IMH + TA - 1 rows per
+                             // frame (IMH real rows + the zero rows the full correlation needs between frames), so no computed row is wasted.
+    int VPI, VPO;            // rows per frame of the stacked band in window-row space (VPI) and in class-output-row space (VPO)
 };
 
 // ds_read_b128 is serviced in four fixed 16-lane groups, each mixing lanes of two k-chunk groups g (MI355X_MICROARCH.md §LDS):
@@ -99,7 +105,8 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         }
         if (tid < CN) *(__attribute__((address_space(3))) float*)(bl + tid * 4) = p.bias ? p.bias[tid] : 0.f;
     }
-    const int nitems = p.Nf * p.nbands;
+    const bool multi = p.FPB > 1;
+    const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
     const int wchunks = p.LR * p.LW * C::CH;
     const int Q = p.LP / SI;                                    // m-index pitch (band pixels per output row)
     const int PLR = (p.LR + SI - 1) / SI;                       // rows per LDS row plane
@@ -117,9 +124,11 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     unsigned pin = 0;
     int mwords = 0;                                             // mask words of the prefetched band
     typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
-    unsigned pk[C::PF];                                         // bit 31: column inside the image; bits 16..23: window row; bits 0..15: (clamped col * CK + chunk * 8) / 8
+    unsigned pk[C::PF];                                         // bit 31: column inside the image; bit 30: (stacked band) a zero row between frames;
+                                                                // bits 16..23: window row (stacked band: row of the stacked frames in memory); bits 0..15: (clamped col * CK + chunk * 8) / 8
     {
         const int clo = REV ? -(TB - 1) : 0;
+        const float invVPI = 1.f / (float)max(p.VPI, 1);
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             const int qc = min(tid + k * 512, wchunks - 1);
@@ -127,27 +136,36 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
             const int ic = clo + wc;
             const int icc = min(max(ic, 0), p.IMW - 1);
-            pk[k] = ((ic >= 0 && ic < p.IMW) ? 0x80000000u : 0u) | ((unsigned)wr << 16) | (unsigned)(icc * C::CH + c);
+            unsigned row = (unsigned)wr, gap = 0u;
+            if (multi && REV) {                                 // window row -> (frame of the band, row of that frame); rows >= IMH of a frame's VPI are zeros
+                const int v = wr - (TA - 1);
+                const int ff = v < 0 ? 0 : fast_div(v, invVPI), r = v - ff * p.VPI;
+                gap = (v < 0 || r >= p.IMH) ? 0x40000000u : 0u;
+                row = (unsigned)(ff * p.IMH + min(max(r, 0), p.IMH - 1));
+            }
+            pk[k] = ((ic >= 0 && ic < p.IMW) ? 0x80000000u : 0u) | gap | (row << 16) | (unsigned)(icc * C::CH + c);
         }
     }
     const int rowel = p.IMW * CK;                               // elements per image row
     auto prefetch = [&](int item) {
         if (p.dbg & 4) return;
-        const int f = item / p.nbands, b = item % p.nbands;
+        const int f = multi ? item * p.FPB : item / p.nbands, b = multi ? 0 : item % p.nbands;
+        const int nfr = multi ? min(p.FPB, p.Nf - f) : 1;       // frames of this band (the last stacked band may be short: its missing frames stage as zeros)
         const int i0 = b * p.RB;
-        const int rlo = REV ? i0 - (TA - 1) : i0 * SI;
+        const int rlo = multi ? 0 : (REV ? i0 - (TA - 1) : i0 * SI);
+        const int imh = nfr * p.IMH;
         const h16_t* base = p.img + (long long)f * p.IMH * rowel;
         pin = 0;
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             if (k >= nslots) break;
             const int ir = rlo + (int)((pk[k] >> 16) & 0xffu);
-            const int irc = min(max(ir, 0), p.IMH - 1);
+            const int irc = min(max(ir, 0), imh - 1);
             pf[k] = *reinterpret_cast<const u32x4_t*>(base + irc * rowel + (int)(pk[k] & 0xffffu) * 8);   // always-valid address
-            pin |= ((ir == irc && (pk[k] >> 31)) ? 1u : 0u) << k;
+            pin |= ((ir == irc && (pk[k] >> 30) == 2u) ? 1u : 0u) << k;
         }
-        if (p.maskbits) {                                       // ReLU bitmask rows of the band's output rows [i0*OS, (i0+RB)*OS)
-            const int r0 = i0 * OS, r1 = min((i0 + p.RB) * OS, p.OUTH);
+        if (p.maskbits) {                                       // ReLU bitmask rows of the band's output rows [i0*OS, (i0+RB)*OS)  (stacked band: of its nfr whole frames)
+            const int r0 = i0 * OS, r1 = multi ? nfr * p.OUTH : min((i0 + p.RB) * OS, p.OUTH);
             mwords = max(0, r1 - r0) * p.OUTW * C::WPP;
             const long long mb = ((long long)f * p.OUTH + r0) * p.OUTW * C::WPP;
             const int mo = min(tid * 4, max(mwords - 4, 0));    // clamped: the last thread(s) re-read valid words (their LDS slot is unused)
@@ -196,13 +214,16 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         if (pref_pending && (wave < 4 || (p.dbg & 64))) { prefetch(item); pref_pending = false; }       // dbg bit 6: no skew (A/B)
         CTSTAMP(4);
         ++iter;
-        const int f = cur / p.nbands, b = cur % p.nbands;
+        const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
         const int i0 = b * p.RB;
+        // class rows of the band: one frame's (OUTH - ph) / OS, or — stacked band — VPO per frame but the last
+        auto class_rows = [&](int ph) {
+            const int NIf = (p.OUTH - ph + OS - 1) / OS;
+            return multi ? (REV ? (p.FPB - 1) * p.VPO + NIf : p.RB) : NIf;
+        };
         // work items of this band = (parity class, group of MT m-tiles), dealt round-robin to the 8 waves
         auto groups_of = [&](int cls) {
-            const int ph = cls / OS;
-            const int NI = (p.OUTH - ph + OS - 1) / OS;
-            const int RBe = max(0, min(p.RB, NI - i0));
+            const int RBe = max(0, min(p.RB, class_rows(cls / OS) - i0));
             return (((RBe * Q + 15) >> 4) + C::MT - 1) / C::MT;
         };
         int total_groups = 0;
@@ -218,8 +239,10 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
                 base += groups_of(c);
             }
             const int ph = cls / OS, pw = cls % OS;
-            const int NI = (p.OUTH - ph + OS - 1) / OS, NJ = (p.OUTW - pw + OS - 1) / OS;
+            const int NIf = (p.OUTH - ph + OS - 1) / OS;     // class rows of ONE frame
+            const int NI = class_rows(ph), NJ = (p.OUTW - pw + OS - 1) / OS;
             const int RBe = min(p.RB, NI - i0);
+            const float invVPO = 1.f / (float)max(p.VPO, 1);
             const int npi = RBe * Q;
             const int last = npi - Q + NJ - 1;                  // last valid pixel index: lanes beyond it are clamped (reads stay in the band)
             const int mt0 = (wi - mybase) * C::MT;
@@ -231,10 +254,16 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
             for (int mm = 0; mm < C::MT; ++mm) {
                 const int pi = (mt0 + mm) * 16 + li;
                 const int ri = fast_div(pi, invQ), j = pi - ri * Q;
-                const bool ok = pi < npi && j < NJ;
+                bool ok = pi < npi && j < NJ;
+                int orow = (i0 + ri) * OS + ph, mrow = ri * OS + ph;      // output row in the frame / in the band's mask rows
+                if (multi) {                                    // stacked band: class row ri = frame ff of the band, row rr; rows beyond the frame's own are dropped
+                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO;
+                    ok = ok && rr < NIf && f + ff < p.Nf;
+                    orow = mrow = ff * p.OUTH + rr * OS + ph;
+                }
                 xoff[mm] = (min(pi, last) * SI + pbase) * C::XS + g * 16;
-                opix[mm] = ok ? (((i0 + ri) * OS + ph) * p.OUTW + j * OS + pw) : -1;
-                moff[mm] = ok ? (((ri * OS + ph) * p.OUTW + j * OS + pw) * C::WPP + (C::WPP == 2 ? (g >> 1) : 0)) * 4 : 0;
+                opix[mm] = ok ? (orow * p.OUTW + j * OS + pw) : -1;
+                moff[mm] = ok ? ((mrow * p.OUTW + j * OS + pw) * C::WPP + (C::WPP == 2 ? (g >> 1) : 0)) * 4 : 0;
             }
             f32x4 acc[C::MT][C::NT];
 #pragma unroll
@@ -368,13 +397,45 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     p.nbands = best_nb;
     p.RB = (NI + best_nb - 1) / best_nb;
     p.LR = REV ? p.RB + TA - 1 : (p.RB - 1) * SI + TA;
+    p.FPB = 1; p.VPI = p.VPO = 0;
+    // ---- small frames (whole frame per band and still only a fraction of an 8-wave round): stack FPB frames to a band.  Cost of a launch =
+    // bands per workgroup x (per-band overhead + 8-wave rounds of the band's groups); one frame per band leaves most waves without a group
+    // (7x7 outputs = 2 groups) and pays the two barriers + staging per frame (tools/ct_stamps.hip: ~2.5 us against a ~5.5 us full round).
+    static const int fpb_env = getenv("HULC_CT_FPB") ? atoi(getenv("HULC_CT_FPB")) : -1;      // A/B: 1 = off, n = force n frames where it fits
+    if (best_nb == 1 && fpb_env != 1 && p.Nf > 1 && (REV || p.IMH % SI == 0)) {
+        const int vpi = REV ? p.IMH + TA - 1 : p.IMH, vpo = REV ? vpi : p.IMH / SI;
+        auto band_cost = [&](int fpb, int& RBo, int& LRo) -> double {
+            RBo = REV ? fpb * vpo : (fpb * p.IMH - TA) / SI + 1;
+            LRo = REV ? RBo + TA - 1 : fpb * p.IMH;
+            if (fpb * p.IMH > 255 || LRo > 255) return -1.0;
+            if ((long long)LRo * p.LW * C::CH > 512ll * C::PF || C::lds_bytes(LRo, p.LP, p.maskbits != nullptr) > 160 * 1024 - 64) return -1.0;
+            if (p.maskbits && (long long)fpb * p.OUTH * p.OUTW * C::WPP > C::MAXMW) return -1.0;
+            int groups = 0;
+            for (int cls = 0; cls < C::NCLS; ++cls) {
+                const int NIf = REV ? (p.OUTH - cls / OS + OS - 1) / OS : NI;
+                const int rows = fpb == 1 ? NIf : (REV ? (fpb - 1) * vpo + NIf : RBo);
+                groups += (((rows * Q + 15) >> 4) + C::MT - 1) / C::MT;
+            }
+            const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
+            return (double)((items + wgs - 1) / wgs) * (0.45 + (groups + 7) / 8);
+        };
+        int RB1, LR1, bestf = 1;
+        double bc = band_cost(1, RB1, LR1);
+        for (int fpb = 2; fpb <= 32; ++fpb) {
+            int RBf, LRf;
+            const double c = band_cost(fpb, RBf, LRf);
+            if (c < 0) break;
+            if ((fpb_env > 1 && fpb <= fpb_env) || (fpb_env < 0 && c < bc - 1e-9)) { bc = c; bestf = fpb; p.RB = RBf; p.LR = LRf; }
+        }
+        if (bestf > 1) { p.FPB = bestf; p.VPI = vpi; p.VPO = vpo; }
+    }
     const size_t lds = C::lds_bytes(p.LR, p.LP, p.maskbits != nullptr);      // without a bitmask the 8 KB mask region is not allocated: conv3's forward then holds a WHOLE frame per band
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
-    const int items = p.Nf * p.nbands;
+    const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
     const int grid = items < 256 ? items : 256;
     hipLaunchKernelGGL((conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>), dim3(grid), dim3(512), lds, st, p);
     return true;

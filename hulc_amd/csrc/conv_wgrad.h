@@ -182,7 +182,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const h16_t* __re
 template <int CI, int CO, int KH, int KW, int S, int NWV>
 __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                             float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
-                                                            int* __restrict__ work_ctr) {
+                                                            int* __restrict__ work_ctr, int FPB) {
+    // FPB > 1 (small frames, nbands == 1): FPB frames are stacked to one band.  X rows of consecutive frames are contiguous in memory; dY is staged
+    // with a pitch of VP = IH / S rows per frame, its OH real rows followed by rows that stay zero from the initial LDS fill, so that dY row v still
+    // sits over X row v * S and the pixel runs that cross into the next frame multiply zeros.  R = (FPB - 1) * VP + OH virtual rows.
     using C = WgradCfg<CI, CO, KH, KW, S>;
     constexpr int NTH = NWV * 64, PF = 8192 / NTH, CTH = C::CT / (NWV / 4), CHY = CO / 8, CHX = CI / 8;   // NWV = 8 or 16 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,14 +199,18 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
     for (int i = tid * 16; i < xpix * C::XS + dypix * C::DYS; i += NTH * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
 
     // ---- this thread's chunks: index ci = tid + k*512 over [dY band chunks | X band chunks]
-    const int ndy = R * OW * CHY, nx = XR * IW * CHX, nch = ndy + nx;
+    const bool stacked = FPB > 1;
+    const int VP = IH / S;
+    const int ndy = (stacked ? FPB * OH : R) * OW * CHY, nx = XR * IW * CHX, nch = ndy + nx;
     unsigned pk[PF];                               // bit 31: X chunk; bits 17..30: LDS offset / 16; bits 0..16: global element offset / 8
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int ci = min(tid + k * NTH, nch - 1);
         if (ci < ndy) {
             const int pix = ci / CHY, c = ci % CHY;
-            const int r = pix / OW, ow = pix % OW;
+            int r = pix / OW;
+            const int ow = pix % OW;
+            if (stacked) r = (r / OH) * VP + r % OH;      // memory row (frame, row) -> virtual row of the stacked band
             pk[k] = ((unsigned)((xpix * C::XS + (r * OWp + ow) * C::DYS + c * 16) >> 4) << 17) | (unsigned)ci;
         } else {
             const int cx = ci - ndy;
@@ -224,15 +231,17 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     u32x4_t pf[PF];
-    const int nitems = Nf * nbands;
+    const int nitems = stacked ? (Nf + FPB - 1) / FPB : Nf * nbands;
     unsigned zmask = 0, zmask_cur = 0;
     auto prefetch = [&](int item) {
         zmask = 0;
         if (dbg & 2) return;
-        const int f = item / nbands, oh0 = (item % nbands) * R;
+        const int f = stacked ? item * FPB : item / nbands, oh0 = stacked ? 0 : (item % nbands) * R;
+        const int nfr = stacked ? min(FPB, Nf - f) : 1;         // the last stacked band may be short: its missing frames stage as zero dY
         const h16_t* ybase = dY + ((long long)f * OH + oh0) * OW * CO;
         const h16_t* xbase = X + ((long long)f * IH + oh0 * S) * IW * CI;
-        const int ylim = (min(R, OH - oh0) * OW * CHY - 1), xlim = (min(XR, IH - oh0 * S) * IW * CHX - 1);   // last in-frame chunk
+        const int yrows = stacked ? nfr * OH : min(R, OH - oh0), xrows = stacked ? min(XR, nfr * IH) : min(XR, IH - oh0 * S);
+        const int ylim = yrows * OW * CHY - 1, xlim = xrows * IW * CHX - 1;   // last in-frame chunk
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const bool isx = (pk[k] >> 31) != 0;
@@ -339,19 +348,34 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
     if (!v1) {
         // fewest balanced bands whose chunks fit the 16 x 512 prefetch slots and whose images fit in 160 KB (16 KB kept for the bias reduction)
         for (int nb = 1; nb <= OH; ++nb) {
-            const int R = (OH + nb - 1) / nb, XR = (R - 1) * S + KH;
-            const long long chunks = (long long)R * OW * (CO / 8) + (long long)XR * IW * (CI / 8);
-            const size_t lds = std::max<size_t>(C::lds_bytes(R, IW, OW), NWV * 64 * 8 * sizeof(float));
+            int R = (OH + nb - 1) / nb, XR = (R - 1) * S + KH;
+            long long chunks = (long long)R * OW * (CO / 8) + (long long)XR * IW * (CI / 8);
+            size_t lds = std::max<size_t>(C::lds_bytes(R, IW, OW), NWV * 64 * 8 * sizeof(float));
             if (chunks > 16 * 512 || lds > 160 * 1024 - 64 || (long long)XR * IW * CI >= (1 << 20)) continue;
+            // small frames (whole frame per band): stack FPB frames to a band — the two barriers, the staging and the exposed load latency of a band
+            // (~5 us, against ~0.5 us of MFMAs for a 7x7 gripper map) are then paid once per FPB frames.  Largest FPB that fits LDS and the prefetch
+            // slots and still leaves every workgroup two bands (the second one's loads fly under the first one's MFMAs).
+            int fpb = 1;
+            static const int fpb_env = getenv("HULC_WG_FPB") ? atoi(getenv("HULC_WG_FPB")) : -1;     // A/B: 1 = off, n = at most n
+            if (nb == 1 && IH % S == 0 && fpb_env != 1) {
+                for (int f = 2; f <= 16; ++f) {
+                    const int Rf = (f - 1) * (IH / S) + OH, XRf = (Rf - 1) * S + KH;
+                    const long long ch = (long long)f * OH * OW * (CO / 8) + (long long)XRf * IW * (CI / 8);
+                    const size_t l = std::max<size_t>(C::lds_bytes(Rf, IW, OW), NWV * 64 * 8 * sizeof(float));
+                    if (ch > 16 * 512 || l > 160 * 1024 - 64 || (long long)XRf * IW * CI >= (1 << 20)) break;
+                    if (fpb_env > 1 ? f > fpb_env : (Nf + f - 1) / f < 2 * std::min(256, max_blocks)) break;
+                    fpb = f; R = Rf; XR = XRf; chunks = ch; lds = l;
+                }
+            }
             static bool attr8 = false;
             if (!attr8) {
                 hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
                 attr8 = true;
             }
-            const int items = Nf * nb;
+            const int items = fpb > 1 ? (Nf + fpb - 1) / fpb : Nf * nb;
             const int grid = std::min(std::min(items, 256), max_blocks);
             static const int dbg = getenv("HULC_WGRAD_DBG") ? atoi(getenv("HULC_WGRAD_DBG")) : 0;   // bench ablation only
-            hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr);
+            hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
             return grid;
         }
     }

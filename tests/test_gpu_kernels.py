@@ -54,8 +54,10 @@ def conv_wgrad_ref(X, dY, KH, S):
     return out.reshape(co, -1)
 
 
-@pytest.mark.parametrize("IH,CI,KH,S,fmode,dmode", [(23, 64, 3, 1, 0, 2), (9, 64, 3, 1, 0, 2), (49, 32, 4, 2, 1, 3), (20, 32, 4, 2, 1, 3)])
-@pytest.mark.parametrize("Nf", [1, 7])
+# Nf = 7 / 1501 on the gripper shapes (9x9, 20x20): stacked bands (ConvTileP::FPB frames per band) with a short last band
+@pytest.mark.parametrize("IH,CI,KH,S,fmode,dmode,Nf", [(23, 64, 3, 1, 0, 2, 1), (23, 64, 3, 1, 0, 2, 7), (9, 64, 3, 1, 0, 2, 1), (9, 64, 3, 1, 0, 2, 7),
+                                                       (9, 64, 3, 1, 0, 2, 1501), (49, 32, 4, 2, 1, 3, 1), (49, 32, 4, 2, 1, 3, 7), (20, 32, 4, 2, 1, 3, 1),
+                                                       (20, 32, 4, 2, 1, 3, 7), (20, 32, 4, 2, 1, 3, 1027)])
 def test_conv_tile_fwd_and_dgrad(IH, CI, KH, S, fmode, dmode, Nf):
     L, lib = _lib()
     rng = np.random.default_rng(IH * 10 + Nf)
