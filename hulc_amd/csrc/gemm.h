@@ -284,7 +284,7 @@ struct EpiPre4 {
 template <typename T>
 DEVI EpiPre4 epi_prefetch4(const EpiP& ep, int rrow, int col, int N, long long o) {
     EpiPre4 p;
-    p.vec = (col + 3 < N) && ((o & 3) == 0) && !ep.atomic && ep.drop_p == 0.f &&
+    p.vec = (col + 3 < N) && ((o & 3) == 0) && !ep.atomic &&
             (!ep.res || (((long long)rrow * ep.res_ld + col) & 3) == 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p.b[r] = 0.f; p.rv[r] = 0.f; p.mk[r] = 1.f; }
@@ -341,6 +341,10 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = p.mk[r] > 0.f ? v[r] : 0.f;
         }
+    }
+    if (ep.drop_p > 0.f) {           // same element index and scale as epi_store (the backward re-derives the mask from them)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = hash_uniform(ep.drop_seed, (unsigned long long)(o + r)) < ep.drop_p ? 0.f : v[r] * (1.f / (1.f - ep.drop_p));
     }
     if (ep.res_late) {
 #pragma unroll
