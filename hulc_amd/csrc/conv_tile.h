@@ -83,9 +83,12 @@ __device__ unsigned long long g_ct_stamps[256 * 8 * 64 * 8];     // [workgroup][
 // index maths below ran ~2 800 VALU cycles per band per SIMD on divisions alone: 1.2 us of a 7 us band)
 DEVI int fast_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
-template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
-__global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
+// NWV = waves per workgroup: 8, or 16 (four waves per SIMD, <= 128 VGPRs: while one wave sits in its epilogue / group setup three others can feed
+// the matrix pipe; the prefetch registers halve with the thread count doubling)
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV, int NWV = 8>
+__global__ void __launch_bounds__(NWV * 64) conv_tile_kernel(ConvTileP p) {
     using C = ConvTileCfg<CK, CN, TA, TB, SI, OS, REV>;
+    constexpr int NTH = NWV * 64, PF = C::PF * 8 / NWV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* wl = (lds_char*)smem;
     lds_char* xl = wl + C::NCLS * CN * C::WS;
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     // (pixel li, group g) then owns the 4*NT CONSECUTIVE channels g*4*NT.. of its pixel (16/32-byte epilogue accesses)
     {
         constexpr int ROWCH = C::WROW / 16;                     // 16-byte chunks per weight row
-        for (int i = tid; i < C::NCLS * CN * ROWCH; i += 512) {
+        for (int i = tid; i < C::NCLS * CN * ROWCH; i += NTH) {
             const int r = i / ROWCH, c = i % ROWCH;
             const int cls = r / CN, rr = r % CN, nn = rr >> 4, t = rr & 15;
             const int ch = (t >> 2) * 4 * C::NT + nn * 4 + (t & 3);
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     const int Q = p.LP / SI;                                    // m-index pitch (band pixels per output row)
     const int PLR = (p.LR + SI - 1) / SI;                       // rows per LDS row plane
     const float invLW = 1.f / (float)p.LW, invQ = 1.f / (float)Q;
-    const int nslots = (wchunks + 511) >> 9;                    // prefetch registers this band shape uses (uniform): the others issue NO load —
+    const int nslots = (wchunks + NTH - 1) / NTH;                    // prefetch registers this band shape uses (uniform): the others issue NO load —
                                                                 // every wave-level load costs the CU's address unit 16 cycles whether its data is used or not
     // ---- prefetch of a band into registers: UNCONDITIONAL loads from clamped addresses; the zero border is applied when the band is
     // committed to LDS (pin bit k), and the multiply loop below issues no global load at all — so nothing forces a wait on these loads
@@ -120,18 +123,18 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
     // the band-invariant part of every slot's address — window row, clamped column offset, column-in-range — is computed once
     // (pk[k]); per band a slot costs a row clamp and one multiply-add (tools/ct_stamps.hip: this phase was 2 600 of a band's 13 800
     // cycles with the matrix pipes idle; spreading the loads over the MFMA loop instead made the loop slower by as much).
-    u32x4_t pf[C::PF], pfm;
+    u32x4_t pf[PF], pfm;
     unsigned pin = 0;
     int mwords = 0;                                             // mask words of the prefetched band
     typedef u32x4_t __attribute__((aligned(4))) u32x4_a4;
-    unsigned pk[C::PF];                                         // bit 31: column inside the image; bit 30: (stacked band) a zero row between frames;
+    unsigned pk[PF];                                         // bit 31: column inside the image; bit 30: (stacked band) a zero row between frames;
                                                                 // bits 16..23: window row (stacked band: row of the stacked frames in memory); bits 0..15: (clamped col * CK + chunk * 8) / 8
     {
         const int clo = REV ? -(TB - 1) : 0;
         const float invVPI = 1.f / (float)max(p.VPI, 1);
 #pragma unroll
-        for (int k = 0; k < C::PF; ++k) {
-            const int qc = min(tid + k * 512, wchunks - 1);
+        for (int k = 0; k < PF; ++k) {
+            const int qc = min(tid + k * NTH, wchunks - 1);
             const int pix = qc / C::CH, c = qc % C::CH;
             const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
             const int ic = clo + wc;
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         const h16_t* base = p.img + (long long)f * p.IMH * rowel;
         pin = 0;
 #pragma unroll
-        for (int k = 0; k < C::PF; ++k) {
+        for (int k = 0; k < PF; ++k) {
             if (k >= nslots) break;
             const int ir = rlo + (int)((pk[k] >> 16) & 0xffu);
             const int irc = min(max(ir, 0), imh - 1);
@@ -173,10 +176,10 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         }
     };
     // LDS byte offset of this thread's k-th staged chunk (band-invariant)
-    int soff[C::PF];
+    int soff[PF];
 #pragma unroll
-    for (int k = 0; k < C::PF; ++k) {
-        const int q = min(tid + k * 512, wchunks - 1);
+    for (int k = 0; k < PF; ++k) {
+        const int q = min(tid + k * NTH, wchunks - 1);
         const int pix = q / C::CH, c = q % C::CH;
         const int wr = fast_div(pix, invLW), wc = pix - wr * p.LW;
         soff[k] = (((wr % SI) * PLR + wr / SI) * p.LP + wc) * C::XS + c * 16;
@@ -190,8 +193,8 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         __syncthreads();                                        // previous band fully consumed (and weights visible)
         CTSTAMP(1);
 #pragma unroll
-        for (int k = 0; k < C::PF; ++k)
-            if (k < nslots && tid + k * 512 < wchunks) *(lds_u32x4*)(xl + soff[k]) = ((pin >> k) & 1u) ? pf[k] : u32x4_t{0u, 0u, 0u, 0u};
+        for (int k = 0; k < PF; ++k)
+            if (k < nslots && tid + k * NTH < wchunks) *(lds_u32x4*)(xl + soff[k]) = ((pin >> k) & 1u) ? pf[k] : u32x4_t{0u, 0u, 0u, 0u};
         if (p.maskbits && tid * 4 < mwords) {
             if (tid * 4 + 4 <= mwords) *(lds_u32x4*)(ml + tid * 16) = pfm;
             else {                                              // ragged tail: the clamped load holds words [mwords-4, mwords)
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         // by the same barrier, the two would otherwise run every phase in lockstep — both computing addresses while the matrix pipe idles,
         // then both contending for it; skewed, one half's prefetch and epilogues run beside the other half's MFMAs.
         bool pref_pending = item < nitems;
-        if (pref_pending && (wave < 4 || (p.dbg & 64))) { prefetch(item); pref_pending = false; }       // dbg bit 6: no skew (A/B)
+        if (pref_pending && (wave < NWV / 2 || (p.dbg & 64))) { prefetch(item); pref_pending = false; }       // dbg bit 6: no skew (A/B)
         CTSTAMP(4);
         ++iter;
         const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
         for (int c = 0; c < C::NCLS; ++c) total_groups += groups_of(c);
         if (p.dbg & 2) total_groups = 0;
 #pragma unroll 1
-        for (int wi = wave; wi < total_groups; wi += 8) {
+        for (int wi = wave; wi < total_groups; wi += NWV) {
             int cls = 0, mybase = 0, base = 0;
 #pragma unroll
             for (int c = 0; c < C::NCLS; ++c) {
@@ -365,8 +368,8 @@ __global__ void __launch_bounds__(512) conv_tile_kernel(ConvTileP p) {
 }
 
 // host side: pick the band height (fewest 8-wave rounds), launch persistent workgroups. Returns false if the shape does not fit.
-template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
-static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV, int NWV>
+static inline bool launch_conv_tile_nw(hipStream_t st, ConvTileP p) {
     using C = ConvTileCfg<CK, CN, TA, TB, SI, OS, REV>;
     const int NI = REV ? (p.OUTH + OS - 1) / OS : p.OUTH;          // class rows (class 0 is the largest)
     const int NJ = REV ? (p.OUTW + OS - 1) / OS : p.OUTW;
@@ -388,7 +391,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
                 const int RBe = std::max(0, std::min(RB, NIc - b * RB));
                 groups += (((RBe * Q + 15) >> 4) + C::MT - 1) / C::MT;
             }
-            cost += (groups + 7) / 8;
+            cost += (groups + NWV - 1) / NWV;
         }
         if (cost < best) { best = cost; best_nb = nb; }
         if (nb >= 8 && best_nb) break;
@@ -417,7 +420,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
                 groups += (((rows * Q + 15) >> 4) + C::MT - 1) / C::MT;
             }
             const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
-            return (double)((items + wgs - 1) / wgs) * (0.45 + (groups + 7) / 8);
+            return (double)((items + wgs - 1) / wgs) * (0.45 + (groups + NWV - 1) / NWV);
         };
         int RB1, LR1, bestf = 1;
         double bc = band_cost(1, RB1, LR1);
@@ -432,13 +435,19 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.LR, p.LP, p.maskbits != nullptr);      // without a bitmask the 8 KB mask region is not allocated: conv3's forward then holds a WHOLE frame per band
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        hipFuncSetAttribute((const void*)conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
     const int grid = items < 256 ? items : 256;
-    hipLaunchKernelGGL((conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_tile_kernel<CK, CN, TA, TB, SI, OS, REV, NWV>), dim3(grid), dim3(NWV * 64), lds, st, p);
     return true;
+}
+template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
+static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
+    // 16 waves (four per SIMD, 128 VGPRs) measured +0.41 ms per step: the 8-wave kernels hold ~220 VGPRs (prefetch slots, double-buffered fragments,
+    // 32 accumulators) and the 16-wave build spills ~110 of them into the multiply loop — not instantiated
+    return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 8>(st, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
