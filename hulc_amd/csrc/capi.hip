@@ -205,6 +205,25 @@ int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* str
     return 0;
 }
 
+int hulc_k_attention(int32_t variant, const float* qkv, float* P, float* ao, const float* dao, float* dqkv, int32_t B, int32_t S, float drop_p,
+                     uint64_t seed, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int D = 128, NH = 8;
+    if (S < 1 || S > 64 || (variant == 1 && S > 32)) { hulc_set_error("hulc_k_attention: S=%d not covered by variant %d", S, variant); return 1; }
+    const dim3 grid(B * NH), block(64);
+    if (!dao) {
+        if (variant == 1) hipLaunchKernelGGL((attention_fwd32_kernel<float>), grid, block, 0, st, qkv, B, S, D, NH, P, ao, drop_p, (unsigned long long)seed);
+        else if (S <= 32) hipLaunchKernelGGL((attention_fwd_kernel<float, 32>), grid, block, 0, st, qkv, B, S, D, NH, P, ao, drop_p, (unsigned long long)seed);
+        else hipLaunchKernelGGL((attention_fwd_kernel<float, 64>), grid, block, 0, st, qkv, B, S, D, NH, P, ao, drop_p, (unsigned long long)seed);
+    } else {
+        if (variant == 1) hipLaunchKernelGGL((attention_bwd32_kernel<float>), grid, block, 0, st, qkv, P, dao, B, S, D, NH, dqkv, drop_p, (unsigned long long)seed);
+        else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<float, 32>), grid, block, 0, st, qkv, P, dao, B, S, D, NH, dqkv, drop_p, (unsigned long long)seed);
+        else hipLaunchKernelGGL((attention_bwd_kernel<float, 64>), grid, block, 0, st, qkv, P, dao, B, S, D, NH, dqkv, drop_p, (unsigned long long)seed);
+    }
+    if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_attention: launch failed"); return 1; }
+    return 0;
+}
+
 // conv wgrad unit-test entry (bf16 NHWC): out[CO][KH*KW*CI] (packed (kh,kw,ci) order, fp32, overwritten)
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* stream) {
     hipStream_t st = (hipStream_t)stream;

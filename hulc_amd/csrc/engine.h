@@ -848,7 +848,11 @@ struct Engine : IEngine {
         hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0));
         for (int l = 0; l < 2; ++l) {
             { EpiP ep = epi(qkv[l], false); lin_fwd(xt[l], EMB, N, tr_in[l], ep, 3 * EMB); }
-            if (S <= 32) hipLaunchKernelGGL((attention_fwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
+            // two lanes per query row in the 16-bit engines; the fp32 (parity) engine keeps the one-lane kernel's summation order: the hulc_visonly
+            // fixture has an FFN pre-activation within fp32 epsilon of zero, and an epsilon-level change upstream flips its ReLU (1e-3 gradient gate)
+            static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
+            if (S <= 32 && att32) hipLaunchKernelGGL((attention_fwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
+            else if (S <= 32) hipLaunchKernelGGL((attention_fwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             else hipLaunchKernelGGL((attention_fwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             { EpiP ep = epi(y1[l], true); ep.res = xf[l]; ep.res_f32 = 1; ep.res_ld = EMB; ep.res_late = 1; ep.drop_p = dp; ep.drop_seed = site_seed(2 + 4 * l);
               lin_fwd(ao[l], EMB, N, tr_out[l], ep, EMB); }
@@ -977,7 +981,8 @@ struct Engine : IEngine {
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
-            hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, 256)), dim3(256), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
+            static const int ll_block = getenv("HULC_LL_BLOCK") ? atoi(getenv("HULC_LL_BLOCK")) : 64;     // one wave per workgroup: 256 CUs x 1 wave instead of 64 CUs x 4 (the kernel is one long serial chain per thread)
+            hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, ll_block)), dim3(ll_block), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
             if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);
             else hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
@@ -1644,7 +1649,9 @@ struct Engine : IEngine {
                 ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
                 lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
                 { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
-                if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
+                if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }

@@ -775,6 +775,137 @@ __global__ void __launch_bounds__(64) attention_bwd_kernel(const T* __restrict__
     for (int d = 0; d < HD; ++d) { o[d] = from_f<T>(dq[d] * 0.25f); o[D + d] = from_f<T>(dk[d]); o[2 * D + d] = from_f<T>(dv[d]); }
 }
 
+// S <= 32 (the benchmark's windows): the same two kernels with BOTH halves of the wave working — lane (i, hf = lane >> 5) handles the keys
+// [16 hf, 16 hf + 16) of query row i and the halves are combined with one cross-half shuffle per value.  The one-lane-per-query kernels above leave
+// 32 of 64 lanes idle and run at half a wave per SIMD, i.e. at the latency of one thread's serial chain (14 / 22 us per launch for 2 MB of data).
+template <typename T>
+__global__ void __launch_bounds__(64) attention_fwd32_kernel(const T* __restrict__ qkv, int B, int S, int D, int NH, float* __restrict__ P,
+                                                             T* __restrict__ ao, float drop_p, unsigned long long seed) {
+    constexpr int HD = 16, SMAX = 32, HJ = 16;
+    __shared__ float q[SMAX][HD + 1], k[SMAX][HD + 1], v[SMAX][HD + 1];
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x & 31, hf = threadIdx.x >> 5;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+        if (hf == 0) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); }
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) v[i][d] = to_f<T>(r[2 * D + d]);
+        }
+    }
+    __syncthreads();
+    if (i >= S) return;                       // both halves of a query leave together: the shuffles below pair live lanes only
+    float sc[HJ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = hf * HJ + jj;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[i][d] * k[j < S ? j : 0][d];
+        sc[jj] = j < S ? s : -INFINITY;
+        m = fmaxf(m, sc[jj]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float den = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) { sc[jj] = (hf * HJ + jj) < S ? __expf(sc[jj] - m) : 0.f; den += sc[jj]; }
+    den += __shfl_xor(den, 32);
+    const float inv = 1.f / den;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float* Pr = P + (((long long)b * NH + h) * S + i) * S;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = hf * HJ + jj;
+        if (j < S) {
+            float p = sc[jj] * inv;
+            Pr[j] = p;
+            if (drop_p > 0.f) p = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : p / (1.f - drop_p);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] += p * v[j][d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] += __shfl_xor(o[d], 32);
+    T* orow = ao + (long long)(b * S + i) * D + h * HD + hf * 8;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) orow[d] = from_f<T>(hf ? o[8 + d] : o[d]);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) attention_bwd32_kernel(const T* __restrict__ qkv, const float* __restrict__ P, const T* __restrict__ dao,
+                                                             int B, int S, int D, int NH, T* __restrict__ dqkv, float drop_p,
+                                                             unsigned long long seed) {
+    constexpr int HD = 16, SMAX = 32, HJ = 16;
+    __shared__ float q[SMAX][HD + 1], k[SMAX][HD + 1], v[SMAX][HD + 1], dO[SMAX][HD + 1];
+    __shared__ float dS[SMAX][SMAX + 1];    // dS[i][j]
+    __shared__ float Pd[SMAX][SMAX + 1];    // dropped P[i][j] (for dV)
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x & 31, hf = threadIdx.x >> 5;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+        const T* g = dao + (long long)(b * S + i) * D + h * HD;
+        if (hf == 0) {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); }
+        } else {
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { v[i][d] = to_f<T>(r[2 * D + d]); dO[i][d] = to_f<T>(g[d]); }
+        }
+    }
+    __syncthreads();
+    if (i < S) {
+        const float* Pr = P + (((long long)b * NH + h) * S + i) * S;
+        float dot = 0.f;
+        float dp[HJ], pv[HJ];
+#pragma unroll
+        for (int jj = 0; jj < HJ; ++jj) {
+            const int j = hf * HJ + jj;
+            dp[jj] = 0.f; pv[jj] = 0.f;
+            if (j < S) {
+                float dpj = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) dpj += dO[i][d] * v[j][d];
+                const float p = Pr[j];
+                float keep = 1.f;
+                if (drop_p > 0.f) keep = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : 1.f / (1.f - drop_p);
+                Pd[i][j] = p * keep;
+                dpj *= keep;              // grad w.r.t. pre-dropout P
+                dp[jj] = dpj; pv[jj] = p;
+                dot += dpj * p;
+            }
+        }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int jj = 0; jj < HJ; ++jj) if (hf * HJ + jj < S) dS[i][hf * HJ + jj] = pv[jj] * (dp[jj] - dot);
+    }
+    __syncthreads();
+    if (i >= S) return;
+    float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dq[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = hf * HJ + jj;
+        if (j >= S) break;
+        const float s_ij = dS[i][j], s_ji = dS[j][i], p_ji = Pd[j][i];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            dq[d] += s_ij * k[j][d];
+            dk[d] += s_ji * q[j][d];          // q already carries the 1/sqrt(hd) scale
+            dv[d] += p_ji * dO[j][d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dq[d] += __shfl_xor(dq[d], 32); dk[d] += __shfl_xor(dk[d], 32); dv[d] += __shfl_xor(dv[d], 32); }
+    T* o = dqkv + (long long)(b * S + i) * 3 * D + h * HD + hf * 8;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const int e = hf * 8 + d;
+        o[d] = from_f<T>(dq[e] * 0.25f); o[D + d] = from_f<T>(dk[e]); o[2 * D + d] = from_f<T>(dv[e]);
+    }
+}
+
 // xm[b][d] = mean_t x[b][t][d]   (fp32 in, T out)
 template <typename T>
 __global__ void mean_over_s_kernel(const float* __restrict__ x, int B, int S, int D, T* __restrict__ out) {

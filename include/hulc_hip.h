@@ -255,6 +255,12 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
 int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K, int32_t variant, void* hip_stream);
 int hulc_k_trread_probe(const int32_t* elem_index_per_lane /*64*/, uint16_t* out /*64x4*/, void* hip_stream);
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);
+/* the transformer's attention kernels alone (8 heads of 16, fp32 storage so that the check against a float64 softmax is tight):
+ * qkv [B*S][384]; forward (dao == NULL): P [B][8][S][S] (post-softmax, pre-dropout) and ao [B*S][128] are written; backward (dao [B*S][128]
+ * given): reads qkv, P, dao and writes dqkv [B*S][384].  variant 0 = one lane per query row (any S <= 64), 1 = the S <= 32 kernels the
+ * engine runs (two lanes per query row).  drop_p / seed: the attention-probability dropout (mask = hash(seed, element index)). */
+int hulc_k_attention(int32_t variant, const float* qkv, float* P, float* ao, const float* dao, float* dqkv, int32_t B, int32_t S,
+                     float drop_p, uint64_t seed, void* hip_stream);
 
 #ifdef __cplusplus
 }

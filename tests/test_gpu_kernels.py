@@ -176,3 +176,37 @@ def test_gemm_glds_matches_fp64(M, N, K):
     err = ((c.double() - ref).abs().max() / ref.abs().max()).item()
     assert err < 2e-5, err                       # fp32 accumulation of exact bf16 products
     assert (c - c_old).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("variant,S", [(0, 5), (0, 32), (0, 47), (1, 1), (1, 5), (1, 8), (1, 16), (1, 17), (1, 20), (1, 32)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_kernels(variant, S, drop_p):
+    """Forward and backward attention kernels (plan_recognition_net.py:94-117: nn.TransformerEncoderLayer, 8 heads of 16) against float64;
+    with dropout the two kernel variants must draw the same mask (the backward re-derives it from the element index)."""
+    L, lib = _lib()
+    B, D, NH, HD = 3, 128, 8, 16
+    g = torch.Generator(device="cuda"); g.manual_seed(S * 10 + variant)
+    qkv = torch.randn(B * S, 3 * D, device="cuda", generator=g)
+    dao = torch.randn(B * S, D, device="cuda", generator=g)
+    P = torch.zeros(B, NH, S, S, device="cuda"); ao = torch.zeros(B * S, D, device="cuda"); dqkv = torch.zeros(B * S, 3 * D, device="cuda")
+    seed = 1234567
+    L.check(lib.hulc_k_attention(variant, qkv.data_ptr(), P.data_ptr(), ao.data_ptr(), None, None, B, S, drop_p, seed, None))
+    L.check(lib.hulc_k_attention(variant, qkv.data_ptr(), P.data_ptr(), None, dao.data_ptr(), dqkv.data_ptr(), B, S, drop_p, seed, None))
+    torch.cuda.synchronize()
+    x = qkv.double().reshape(B, S, 3, NH, HD).permute(2, 0, 3, 1, 4)          # (3, B, NH, S, HD)
+    q, k, v = (t.clone().requires_grad_(True) for t in x)
+    Pref = torch.softmax(q @ k.transpose(-1, -2) / 4.0, dim=-1)
+    assert (P.double() - Pref).abs().max().item() < 2e-6
+    if drop_p > 0:      # the mask the kernel drew: recovered from a second, mask-revealing forward (v = identity-like is not available) -> use variant 0 as the mask oracle
+        P0 = torch.zeros_like(P); ao0 = torch.zeros_like(ao); dq0 = torch.zeros_like(dqkv)
+        L.check(lib.hulc_k_attention(0, qkv.data_ptr(), P0.data_ptr(), ao0.data_ptr(), None, None, B, S, drop_p, seed, None))
+        L.check(lib.hulc_k_attention(0, qkv.data_ptr(), P0.data_ptr(), None, dao.data_ptr(), dq0.data_ptr(), B, S, drop_p, seed, None))
+        torch.cuda.synchronize()
+        assert (ao - ao0).abs().max().item() < 1e-5 * ao0.abs().max().item() + 1e-6
+        assert (dqkv - dq0).abs().max().item() < 1e-5 * dq0.abs().max().item() + 1e-6
+        return
+    out = (Pref @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    assert (ao.double() - out).abs().max().item() < 1e-5
+    out.backward(dao.double())
+    ref = torch.stack([q.grad, k.grad, v.grad]).permute(1, 3, 0, 2, 4).reshape(B * S, 3 * D)
+    assert (dqkv.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()

@@ -37,6 +37,11 @@ static void run(const char* name, int Nf, int IMH, int OUTH, int wrows, int wcol
     if (!REV && CN == 64 && SI == 2) p.bits_out = bits;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) launch_conv_tile<CK, CN, TA, TB, SI, OS, REV>(0, p);
+    hipDeviceSynchronize();
+    {   // stale stamps of an earlier case (more bands per workgroup) must not be read as bands of this one
+        std::vector<unsigned long long> z(256 * 8 * 64 * 8, 0ull);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_ct_stamps), z.data(), z.size() * 8);
+    }
     hipEventRecord(e0);
     for (int i = 0; i < 5; ++i) launch_conv_tile<CK, CN, TA, TB, SI, OS, REV>(0, p);
     hipEventRecord(e1); hipDeviceSynchronize();
@@ -44,7 +49,7 @@ static void run(const char* name, int Nf, int IMH, int OUTH, int wrows, int wcol
     std::vector<unsigned long long> h(256 * 8 * 64 * 8);
     hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ct_stamps), h.size() * 8);
     // phases per band (wave-averaged over workgroups / waves / bands 1..n-2): deltas between consecutive stamps
-    const char* nm[8] = {"wait barrier1 (others' epilogues)", "commit band -> LDS (incl. vmcnt wait)", "wait barrier2", "prefetch issue + addr math", "group setup", "MFMA loop", "epilogue", "(to next band start)"};
+    const char* nm[8] = {"wait barrier1 (others' epilogues)", "commit band -> LDS (incl. vmcnt wait)", "wait barrier2", "prefetch issue + addr math", "earlier groups of the band + last group's setup", "MFMA loop (last group)", "epilogue (last group)", "(to next band start)"};
     double acc[8] = {0}; long cnt = 0; double band_total = 0;
     int nb_seen = 0;
     for (int b = 0; b < 256; ++b)
@@ -62,8 +67,8 @@ static void run(const char* name, int Nf, int IMH, int OUTH, int wrows, int wcol
                 ++cnt;
             }
         }
-    printf("%s: %.1f us per launch, %d bands per workgroup; per band (ticks of s_memtime = 100 MHz? see ratio), %ld samples\n", name, ms / 5 * 1e3, nb_seen, cnt);
-    for (int ph = 0; ph < 8; ++ph) printf("   %-40s %8.0f ticks  %5.1f %%\n", nm[ph], acc[ph] / cnt, 100.0 * acc[ph] / band_total);
+    printf("%s: %.1f us per launch, %d bands per workgroup; per band (s_memtime ticks; stamps 5-7 are overwritten per group, so they time the wave's LAST group of the band), %ld samples\n", name, ms / 5 * 1e3, nb_seen, cnt);
+    for (int ph = 0; ph < 8; ++ph) printf("   %-52s %8.0f ticks  %5.1f %%\n", nm[ph], acc[ph] / cnt, 100.0 * acc[ph] / band_total);
     printf("   band total %.0f ticks -> %.2f us per band if the launch is all bands\n", band_total / cnt, ms / 5 * 1e3 / std::max(1, nb_seen));
     hipFree(img); hipFree(w); hipFree(out); hipFree(bias); hipFree(bits);
 }
