@@ -7,7 +7,8 @@ O = os.path.join(ROOT, "gpurun_out", T)
 P = lambda f: os.path.join(ROOT, "profiles", f)
 copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.csv", "kernel_stats_summary.txt": "kernel_stats_summary.txt",
           "pmc_hbm_per_kernel.csv": "pmc_hbm_per_kernel.csv", "pmc_traffic.json": "pmc_traffic.json", "sq/mfma_util.csv": "mfma_util.csv",
-          "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt"}
+          "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
+          "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt"}
 for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
@@ -52,6 +53,8 @@ files = f"""| file | what | command |
 | `{T}_kernel_stats.csv`, `{T}_kernel_stats_summary.txt` | rocprofv3 per-kernel stats of the bench command (9 steps: 2 warm-up + 2 survey + 5 timed), top 45 per step | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline`, `tools/prof_summary.py` |
 | `{T}_pmc_hbm_per_kernel.csv`, `{T}_pmc_traffic.json` | FETCH_SIZE / WRITE_SIZE per dispatch (two separate `--pmc` passes) and the per-launch HBM bytes per kernel class, `(2 x FETCH_SIZE + WRITE_SIZE) x 1024` (MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE reports half of a wide coalesced read; calibration: `adam` reads 5 and writes 3.5 arrays of 47.05 M fp32 = 1.41 GB algorithmic against {t.get('adam', 0) / 1e9:.2f} GB measured); every dispatch is counted in the FIRST class it matches, so the recurrent-step dispatches (keyed by their grid) are not in `skinny_gemm`; `bench.py` reports the dominant class's value as `roofline.traffic` | `tools/pmc_traffic.py` |
 | `{T}_mfma_util.csv`, `{T}_mfma_util_summary.txt` | per kernel: MFMA-pipe utilisation, `SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES`, MFMA TFLOP/s from `SQ_INSTS_VALU_MFMA_MOPS_BF16`, LDS bank-conflict rate (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE`), wait breakdown — two SQ passes of 8 counters | `tools/pmc_sq.sh`, `tools/pmc_sq_summary.py` |
+| `{T}_step_sequence.txt` | every launch of ONE step in order (consecutive identical launches collapsed) from the same kernel trace: launches per step, which memsets / transposes / small kernels remain and how long each takes.  The per-step call counts of `{T}_kernel_stats_summary.txt` divide a 9-step profile that also holds the engine's one-time workspace zero-fills (≈160 `fillBufferAligned`) and bench.py's input generation; a step itself issues 3 memsets (gradient buffer, loss slots, the backward's zero arena) | `tools/step_seq.py` |
+| `{T}_conv_tile_gripper_fpb.txt` | the four conv tile kernels on the gripper camera's shapes with 1 frame per band and with the stacked bands the launch picks | `tools/time_conv_tile_gripper.py` |
 | `{T}_conv_tile_phase_stamps.txt` | shader-clock stamps of the phases of every band of the raw-tile conv kernels (what the conv work of this round was steered by) | `tools/bin/ct_stamps` (tools/ct_stamps.hip) |
 | `{T}_gridbar_xcd_barrier.txt`, `{T}_gridbar_naive_barrier.txt` | grid barrier + cross-XCD exchange cost with the fast primitives (XCD-hierarchical barrier, relaxed polls, `sc1` write-through publish) and with round 1's acquire-polled single counter | `tools/bin/gridbar2`, `tools/bin/gridbar` |
 """

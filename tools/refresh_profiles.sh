@@ -20,6 +20,8 @@ python tools/pmc_traffic.py $O > $O/pmc_traffic.log
 mkdir -p $R/profiles && cp $O/pmc_traffic.json $R/profiles/${T}_pmc_traffic.json      # bench.py reads the newest profiles/r*_pmc_traffic.json
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 test -n "$f" && cp $f $O/kernel_stats.csv && python tools/prof_summary.py $O/kernel_stats.csv 9 45 > $O/kernel_stats_summary.txt
+python tools/step_seq.py $O/stats > $O/step_sequence.txt 2>&1
+( HULC_CT_FPB=1 python tools/time_conv_tile_gripper.py 2>/dev/null | tail -1; python tools/time_conv_tile_gripper.py 2>/dev/null | tail -1 ) > $O/conv_tile_gripper.txt
 bash tools/pmc_sq.sh $T/sq > $O/sq.log 2>&1
 cd $R
 timeout 900 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err </dev/null
