@@ -101,16 +101,28 @@ def setup_comm(engine, bucket_dtype: str = "fp32") -> bool:
     and leaves the torch.distributed path in place — when RCCL cannot be initialised (the reason is logged once)."""
     if world_size() == 1 or not torch.cuda.is_available() or os.environ.get("HULC_DP_COMM", "capi") != "capi":
         return False
+    err = None
     try:
         box = [engine.comm_unique_id() if dist.get_rank() == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        engine.comm_init(box[0], dist.get_rank(), dist.get_world_size())
+    except Exception as e:                 # pragma: no cover  (multi-GPU only)
+        box, err = [None], e
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is not None:
+        try:
+            engine.comm_init(box[0], dist.get_rank(), dist.get_world_size())
+        except Exception as e:             # pragma: no cover
+            err = e
+    # every rank must take the SAME path (a rank left on torch.distributed would wait forever for the others' collective): agree on the outcome
+    ok = torch.tensor([0 if (err is not None or box[0] is None) else 1], dtype=torch.int32, device=engine.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
         engine.comm_bucket_dtype = bucket_dtype
         return True
-    except Exception as e:                 # pragma: no cover  (multi-GPU only)
-        if dist.get_rank() == 0:
-            print(f"[hulc_amd] library RCCL communicator unavailable ({e}); gradients go through torch.distributed", flush=True)
-        return False
+    if getattr(engine, "has_comm", False):
+        engine.comm_destroy()
+    if dist.get_rank() == 0:
+        print(f"[hulc_amd] library RCCL communicator unavailable ({err if err is not None else 'failed on another rank'}); gradients go through torch.distributed", flush=True)
+    return False
 
 
 def backward_overlapped(engine) -> None:
