@@ -297,6 +297,10 @@ __global__ void __launch_bounds__(NWV * 64) conv_tile_kernel(ConvTileP p) {
 #ifdef HULC_CT_STAMPS
             --iter; CTSTAMP(5); ++iter;
 #endif
+            if constexpr (NWV > 8) {             // four waves per SIMD hide each other's LDS latency: one fragment set (24 VGPRs less)
+#pragma unroll 1
+                for (int s1 = (p.dbg & 16) ? NS : 0; s1 < NS; ++s1) { frag_load(xf0, wf0, s1); frag_mma(xf0, wf0); }
+            } else {
             frag_load(xf0, wf0, 0);
 #pragma unroll 1
             for (int s2 = (p.dbg & 16) ? NS : 0; s2 < NS; s2 += 2) {
@@ -305,6 +309,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_tile_kernel(ConvTileP p) {
                 if (s2 + 2 < NS) frag_load(xf0, wf0, s2 + 2);
                 frag_mma(xf1, wf1);
             }
+            }
             if (pref_pending) { prefetch(item); pref_pending = false; }
 #ifdef HULC_CT_STAMPS
             asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[C::MT - 1][C::NT - 1][3]));      // the stamp below must follow the last MFMA's result
@@ -312,11 +317,13 @@ __global__ void __launch_bounds__(NWV * 64) conv_tile_kernel(ConvTileP p) {
 #endif
             if ((p.dbg & 8) && acc[0][0][0] != 12345.678f) continue;
             // ---- epilogue: lane holds channels g*4*NT .. +4*NT-1 of pixel li of each m-tile
-            float bb[4 * C::NT];
+            float bb[NWV > 8 ? 1 : 4 * C::NT];      // 16 waves: the bias quads are read from LDS where they are added (16 VGPRs less)
+            if constexpr (NWV <= 8) {
 #pragma unroll
             for (int e = 0; e < C::NT; ++e) {
                 const f32x4 t = *(__attribute__((address_space(3))) f32x4*)(bl + (g * 4 * C::NT + e * 4) * 4);
                 bb[e * 4 + 0] = t[0]; bb[e * 4 + 1] = t[1]; bb[e * 4 + 2] = t[2]; bb[e * 4 + 3] = t[3];
+            }
             }
 #pragma unroll
             for (int mm = 0; mm < C::MT; ++mm) {
@@ -328,8 +335,14 @@ __global__ void __launch_bounds__(NWV * 64) conv_tile_kernel(ConvTileP p) {
 #pragma unroll
                 for (int e = 0; e < EW; ++e) {
                     float v[8];
+                    if constexpr (NWV > 8) {
+                        const f32x4 t0 = *(__attribute__((address_space(3))) f32x4*)(bl + (g * 4 * C::NT + e * 8) * 4), t1 = *(__attribute__((address_space(3))) f32x4*)(bl + (g * 4 * C::NT + e * 8 + 4) * 4);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = acc[mm][e * 2 + (r >> 2)][r & 3] + (r < 4 ? t0[r & 3] : t1[r & 3]);
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = acc[mm][e * 2 + (r >> 2)][r & 3] + bb[e * 8 + r];
+                    }
                     if (p.relu) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -445,8 +458,13 @@ static inline bool launch_conv_tile_nw(hipStream_t st, ConvTileP p) {
 }
 template <int CK, int CN, int TA, int TB, int SI, int OS, bool REV>
 static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
-    // 16 waves (four per SIMD, 128 VGPRs) measured +0.41 ms per step: the 8-wave kernels hold ~220 VGPRs (prefetch slots, double-buffered fragments,
-    // 32 accumulators) and the 16-wave build spills ~110 of them into the multiply loop — not instantiated
+    // 16 waves (four per SIMD, 128 VGPRs, one fragment set instead of the software-pipelined pair): the dgrad kernels fit (0 / 31 spilled registers,
+    // none inside the multiply loop) and gain 5-11 % — while one wave sits in its epilogue or group setup three others feed the matrix pipe.  The
+    // forward kernels do not fit: the compiler spills the band prefetch registers, i.e. waits for the loads right where they are issued
+    // (load phase alone 28 -> 76 us for conv3); they stay at 8 waves.  HULC_CT_NW=8 / 16 forces one width for every kernel (A/B).
+    static const int nw = getenv("HULC_CT_NW") ? atoi(getenv("HULC_CT_NW")) : 0;
+    if constexpr (REV) { if (nw != 8) return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 16>(st, p); }
+    else { if (nw == 16) return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 16>(st, p); }
     return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 8>(st, p);
 }
 

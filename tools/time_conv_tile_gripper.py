@@ -16,13 +16,14 @@ def run(mode, img, w, bias, mask, out, IMH, OUTH, dbg):
     return e0.elapsed_time(e1) / 10 * 1e3
 b64 = torch.zeros(64, device="cuda")
 i32 = lambda *s: torch.randint(-2**31, 2**31 - 1, s, device="cuda", dtype=torch.int32)
-cases = [("fwd3 9->7", 0, (Nf, 9, 9, 64), (64, 576), b64, None, (Nf, 7, 7, 64), 9, 7, 1),
-         ("fwd2 20->9 (+bits)", 7, (Nf, 20, 20, 32), (64, 512), b64, i32(Nf, 9, 9, 2), (Nf, 9, 9, 64), 20, 9, 1),
-         ("dgrad3 7->9 (bits)", 8, (Nf, 7, 7, 64), (64, 576), None, i32(Nf, 9, 9, 2), (Nf, 9, 9, 64), 7, 9, 32),
-         ("dgrad2 9->20 (bits)", 9, (Nf, 9, 9, 64), (128, 256), None, i32(Nf, 20, 20, 1), (Nf, 20, 20, 32), 9, 20, 32)]
+H1, H2, H3 = (49, 23, 21) if os.environ.get("SHAPES") == "static" else (20, 9, 7)      # SHAPES=static: the static camera's maps
+cases = [(f"fwd3 {H2}->{H3}", 0, (Nf, H2, H2, 64), (64, 576), b64, None, (Nf, H3, H3, 64), H2, H3, 1),
+         (f"fwd2 {H1}->{H2} (+bits)", 7, (Nf, H1, H1, 32), (64, 512), b64, i32(Nf, H2, H2, 2), (Nf, H2, H2, 64), H1, H2, 1),
+         (f"dgrad3 {H3}->{H2} (bits)", 8, (Nf, H3, H3, 64), (64, 576), None, i32(Nf, H2, H2, 2), (Nf, H2, H2, 64), H3, H2, 32),
+         (f"dgrad2 {H2}->{H1} (bits)", 9, (Nf, H2, H2, 64), (128, 256), None, i32(Nf, H1, H1, 1), (Nf, H1, H1, 32), H2, H1, 32)]
 res = []
 for name, mode, ishape, wshape, bias, mask, oshape, IMH, OUTH, dbg in cases:
     img = torch.randn(*ishape, device="cuda").to(torch.bfloat16); w = (torch.randn(*wshape, device="cuda") * 0.05).to(torch.bfloat16)
     out = torch.zeros(*oshape, device="cuda", dtype=torch.bfloat16)
     res.append(f"{name}: {run(mode, img, w, bias, mask, out, IMH, OUTH, dbg):.1f} us")
-print(f"HULC_CT_FPB={os.environ.get('HULC_CT_FPB', 'auto')}:  " + "   ".join(res))
+print(f"HULC_CT_FPB={os.environ.get('HULC_CT_FPB', 'auto')} HULC_CT_NW={os.environ.get('HULC_CT_NW', '8')}:  " + "   ".join(res))
