@@ -26,4 +26,4 @@ for name, mode, ishape, wshape, bias, mask, oshape, IMH, OUTH, dbg in cases:
     img = torch.randn(*ishape, device="cuda").to(torch.bfloat16); w = (torch.randn(*wshape, device="cuda") * 0.05).to(torch.bfloat16)
     out = torch.zeros(*oshape, device="cuda", dtype=torch.bfloat16)
     res.append(f"{name}: {run(mode, img, w, bias, mask, out, IMH, OUTH, dbg):.1f} us")
-print(f"HULC_CT_FPB={os.environ.get('HULC_CT_FPB', 'auto')} HULC_CT_NW={os.environ.get('HULC_CT_NW', '8')}:  " + "   ".join(res))
+print(f"HULC_CT_FPB={os.environ.get('HULC_CT_FPB', 'auto')} HULC_CT_NW={os.environ.get('HULC_CT_NW', 'default (8 fwd / 16 dgrad)')}:  " + "   ".join(res))
