@@ -1283,13 +1283,30 @@ struct Engine : IEngine {
     void gru_recur_bwd(GruBuf& g, const T* dH, const LinW& whh, int B, int S, bool rev, bool dH_last_only) {
         const long long BH = (long long)B * HID;
         auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i); };
+        bool fused_prev = false;                 // the gate backward of this step already ran in the previous GEMM's epilogue
         for (int i = S - 1; i >= 0; --i) {
             const long long t = at(i);
             const T* dh = dH_last_only ? (i == S - 1 ? dH : nullptr) : dH + t * BH;
+            if (!fused_prev)
             hipLaunchKernelGGL((gru_gate_bwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dh, i == S - 1 ? (const T*)nullptr : gcarA, g.R + t * BH, g.Z + t * BH,
                                g.N + t * BH, g.GN + t * BH, i ? g.H + at(i - 1) * BH : (const T*)nullptr, B, HID, g.dZx + t * 3 * BH, g.dG + t * 3 * BH, gcarB);
-            if (i) { EpiP ep = epi(gcarA, false); ep.res = gcarB; ep.res_ld = HID;
-                     gemm(dense<T>(g.dG + t * 3 * BH, B, 3 * HID), dense<T>(whh.Wt, HID, 3 * HID), dense_out(HID), ep, B, HID, 3 * HID); }
+            fused_prev = false;
+            if (!i) break;
+            if constexpr (std::is_same<T, h16_t>::value) {      // carry GEMM + the gate backward of step i-1 in one launch (gemm.h: GruBwdP)
+                static const bool fused = getenv("HULC_GRU_FUSED_BWD") ? atoi(getenv("HULC_GRU_FUSED_BWD")) != 0 : true;
+                if (fused && skinny_use_lds) {
+                    const long long tp = at(i - 1);
+                    GruBwdP gbp{};
+                    gbp.dH = dH_last_only ? nullptr : dH + tp * BH;
+                    gbp.R = g.R + tp * BH; gbp.Z = g.Z + tp * BH; gbp.Nn = g.N + tp * BH; gbp.GN = g.GN + tp * BH;
+                    gbp.Hprev = i - 1 ? g.H + at(i - 2) * BH : nullptr;
+                    gbp.dzx = g.dZx + tp * 3 * BH; gbp.dg = g.dG + tp * 3 * BH; gbp.direct = gcarB; gbp.direct_in = gcarB;     // each thread reads its 4 direct[t] values before it writes direct[t-1] over them
+                    EpiP ep = epi(gcarA, false);
+                    if (launch_skinny_lds_kchunk(st, g.dG + t * 3 * BH, 3 * HID, whh.Wt, 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp)) { fused_prev = true; continue; }
+                }
+            }
+            { EpiP ep = epi(gcarA, false); ep.res = gcarB; ep.res_ld = HID;
+              gemm(dense<T>(g.dG + t * 3 * BH, B, 3 * HID), dense<T>(whh.Wt, HID, 3 * HID), dense_out(HID), ep, B, HID, 3 * HID); }
         }
     }
     // weight / bias gradients of one recurrence from dZx, dG, its states H and its input X [S][B][K] (ldx), into dW_ih (+ column offset, lddw)

@@ -972,9 +972,17 @@ static inline bool launch_gru_step(hipStream_t st, const h16_t* hprev, const h16
 // one after the other through the SAME LDS regions — a wave only ever reads the region it DMAs into, so there is no barrier between chunks,
 // just the wave's own lgkmcnt(0) (fragment reads done) before the next chunk's DMA and vmcnt(0) before its MFMAs.  The W fragments of the
 // next chunk are requested before the current chunk's MFMAs.  Replaces the register-fragment kernel for these shapes (18 -> 14 us per step).
+// Optional GRU epilogue (BPTT of torch.nn.GRU, plan_recognition_net.py:12-42): the GEMM computes the carry dG[t] W_hh into step t-1; with `gb.dzx` set
+// the gate backward of step t-1 runs right here on the fp32 carry — dh = dH[t-1] + carry + direct[t] -> dzx = (dr, dz, dn), dg = (dr, dz, dn r),
+// direct[t-1] = dh z — instead of in a launch of its own between every two GEMMs of the chain (97 launches of 4.2 us per step at S = 32).
+struct GruBwdP {
+    const h16_t *dH, *R, *Z, *Nn, *GN, *Hprev;      // step t-1: incoming state gradient (or null), saved gates, previous state (or null = 0)
+    h16_t *dzx, *dg, *direct;                        // outputs for step t-1: [M][3H], [M][3H], [M][H]; dzx == nullptr: plain GEMM epilogue
+    const h16_t* direct_in;                          // direct[t] (dh_t z_t), added to the carry
+};
 template <int MT, int KQ32, int NW>
 __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W, long long ldw, int M, int N,
-                                                                  int K, DenseOut om, EpiP ep) {
+                                                                  int K, DenseOut om, EpiP ep, GruBwdP gb) {
     constexpr int PCW = KQ32 / 2, KCH = NW * KQ32 * 32;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     typedef __attribute__((address_space(3))) char lchar;
@@ -1005,7 +1013,15 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
     const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
     const long long eo = ethread ? om.offset(erow, 0) + ecol : 0;
     EpiPre4 pre;
-    if (ethread) pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo);
+    uint2 gq[7];                                         // GRU epilogue operands of this thread's 4 outputs: dH, R, Z, N, GN, Hprev, direct_in (4 x 16 bit each)
+    const long long gidx = (long long)erow * N + ecol;
+    if (ethread) {
+        if (gb.dzx) {
+            const h16_t* src[7] = {gb.dH, gb.R, gb.Z, gb.Nn, gb.GN, gb.Hprev, gb.direct_in};
+#pragma unroll
+            for (int q = 0; q < 7; ++q) gq[q] = src[q] ? *reinterpret_cast<const uint2*>(src[q] + gidx) : uint2{0u, 0u};
+        } else pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo);
+    }
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1045,15 +1061,33 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[w * MT * 64 + tid];
         const float v4[4] = {v[0], v[1], v[2], v[3]};
-        epi_apply4<h16_t>(ep, pre, v4, errow, ecol, N, eo);
+        if (gb.dzx) {
+            auto un = [](const uint2& u, int r) { const unsigned w = r < 2 ? u.x : u.y; return (r & 1) ? h2f_hi(w) : h2f_lo(w); };
+            float dr[4], dz[4], dn[4], dnr[4], dir[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dh = un(gq[0], r) + v4[r] + un(gq[6], r);
+                const float rr = un(gq[1], r), z = un(gq[2], r), n = un(gq[3], r), gn = un(gq[4], r), hp = un(gq[5], r);
+                dn[r] = dh * (1.f - z) * (1.f - n * n);
+                dz[r] = dh * (hp - n) * z * (1.f - z);
+                dr[r] = dn[r] * gn * rr * (1.f - rr);
+                dnr[r] = dn[r] * rr;
+                dir[r] = dh * z;
+            }
+            auto st4 = [](h16_t* p, const float (&x)[4]) { uint2 w; w.x = pack2h(x[0], x[1]); w.y = pack2h(x[2], x[3]); *reinterpret_cast<uint2*>(p) = w; };
+            const long long o3 = (long long)erow * 3 * N + ecol;
+            st4(gb.dzx + o3, dr); st4(gb.dzx + o3 + N, dz); st4(gb.dzx + o3 + 2 * N, dn);
+            st4(gb.dg + o3, dr); st4(gb.dg + o3 + N, dz); st4(gb.dg + o3 + 2 * N, dnr);
+            st4(gb.direct + gidx, dir);
+        } else epi_apply4<h16_t>(ep, pre, v4, errow, ecol, N, eo);
     }
 }
 static inline bool launch_skinny_lds_kchunk(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K, const DenseOut& om,
-                                            const EpiP& ep) {
+                                            const EpiP& ep, const GruBwdP& gb = GruBwdP{}) {
     if (K % 2048 != 0 || K <= 2048 || M > 64 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0 || (N % 16) != 0) return false;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)skinny_lds_kchunk_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((skinny_lds_kchunk_kernel<2, 4, 16>), dim3(N / 16, (M + 31) / 32), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep);
+    hipLaunchKernelGGL((skinny_lds_kchunk_kernel<2, 4, 16>), dim3(N / 16, (M + 31) / 32), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep, gb);
     return true;
 }
 
