@@ -73,6 +73,7 @@ struct Engine : IEngine {
     // mcil plan recognition (plan_recognition_net.py:14-42): 2-layer bidirectional tanh RNN; [layer][direction]
     LinW bw_ih[2][2], bw_hh[2][2];
     const float *bb_ih[2][2], *bb_hh[2][2]; float *dbb_ih[2][2], *dbb_hh[2][2];
+    T* gcarB2 = nullptr;      // second direct-path buffer of the paired BiGRU BPTT
     T *bZ0[2] = {nullptr, nullptr}, *bH0[2], *bZ1, *bH1, *bh1b, *bxcat, *bdx, *bdH0[2], *bdZ0[2], *bdZ1, *bdz1b, *plan_t;
     float *plan_f, *plan_eps, *plan_eps_in, *klel;
     // GRU variant: per recurrence c (0: layer 0 fwd, 1: layer 0 reverse, 2: layer 1 fwd; 3: the single evaluated step of layer 1 reverse)
@@ -1231,6 +1232,54 @@ struct Engine : IEngine {
         }
     }
 
+    // The two directions of a bidirectional layer are independent chains of S dependent launches each: advanced in lockstep, one launch (grid.z = 2)
+    // carries step i of both — the same work per launch boundary paid once instead of twice (gemm.h: Skinny2).  Direction 0 runs t = 0..S-1,
+    // direction 1 (reverse) t = S-1..0.  Shapes the dual launch does not cover fall back to the two sequential recurrences.
+    static bool pair_dirs() { static const bool on = getenv("HULC_PAIR_DIRS") ? atoi(getenv("HULC_PAIR_DIRS")) != 0 : true; return on; }
+    void rnn_fwd2(T* const Zx[2], T* const H[2], const LinW* const whh[2], int B, int S, int act) {
+        const long long BH = (long long)B * HID;
+        bool dual = false;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1;
+        if (dual) {
+            auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
+            for (int d = 0; d < 2; ++d) hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx[d] + at(d, 0), H[d] + at(d, 0), BH, act);
+            TimerScope ts(this, "rnn_step_gemm", "hbm", 4.0 * B * HID * HID * (S - 1), 2 * ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
+            for (int i = 1; i < S; ++i) {
+                EpiP ep[2];
+                for (int d = 0; d < 2; ++d) { ep[d] = epi(H[d] + at(d, i), false); ep[d].bias = nullptr; ep[d].res = Zx[d] + at(d, i); ep[d].res_ld = HID; ep[d].relu = act; }
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    if (launch_skinny_lds_dual(st, H[0] + at(0, i - 1), whh[0]->W, ep[0], H[1] + at(1, i - 1), whh[1]->W, ep[1], HID, HID, B, HID, HID, dense_out(HID))) continue;
+                }
+                for (int d = 0; d < 2; ++d) gemm(dense<T>(H[d] + at(d, i - 1), B, HID), dense<T>(whh[d]->W, HID, HID), dense_out(HID), ep[d], B, HID, HID);
+            }
+            return;
+        }
+        for (int d = 0; d < 2; ++d) rnn_fwd(Zx[d], H[d], *whh[d], B, S, nullptr, act, d == 1);
+    }
+    void rnn_bwd2(T* const dH[2], T* const H[2], T* const dZ[2], const LinW* const whh[2], int B, int S, int act) {
+        const long long BH = (long long)B * HID;
+        bool dual = false;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1;
+        if (dual) {
+            auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
+            for (int d = 0; d < 2; ++d)
+                hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH[d] + at(d, S - 1), H[d] + at(d, S - 1), dZ[d] + at(d, S - 1), BH, act);
+            TimerScope ts(this, "rnn_step_gemm", "hbm", 4.0 * B * HID * HID * (S - 1), 2 * ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
+            for (int i = S - 2; i >= 0; --i) {
+                EpiP ep[2];
+                for (int d = 0; d < 2; ++d) {
+                    ep[d] = epi(dZ[d] + at(d, i), false); ep[d].mask = H[d] + at(d, i); ep[d].mask_tanh = act == 2; ep[d].res = dH[d] + at(d, i); ep[d].res_ld = HID;
+                }
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    if (launch_skinny_lds_dual(st, dZ[0] + at(0, i + 1), whh[0]->Wt, ep[0], dZ[1] + at(1, i + 1), whh[1]->Wt, ep[1], HID, HID, B, HID, HID, dense_out(HID))) continue;
+                }
+                for (int d = 0; d < 2; ++d) gemm(dense<T>(dZ[d] + at(d, i + 1), B, HID), dense<T>(whh[d]->Wt, HID, HID), dense_out(HID), ep[d], B, HID, HID);
+            }
+            return;
+        }
+        for (int d = 0; d < 2; ++d) rnn_bwd(dH[d], H[d], dZ[d], *whh[d], B, S, act, d == 1, false);
+    }
+
     // ---------------------------------------------------------------- mcil plan recognition (plan_recognition_net.py:14-42)
     // nn.RNN(tanh, 2 layers, bidirectional) over the time-major embedding; x = output[:, -1] = [fwd state after the last step |
     // reverse state at the last position (its FIRST step, so the layer-1 reverse recurrence never runs)]; pr_state = fc_state(x).
@@ -1239,10 +1288,10 @@ struct Engine : IEngine {
         const long long BH = (long long)B * HID;
         hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * EMB, 256)), dim3(256), 0, st, emb, embg, B, S, EMB);
         for (int d = 0; d < 2; ++d) {
-            { EpiP ep = epi(bZ0[d], false); ep.bias = bb_ih[0][d]; ep.bias2 = bb_hh[0][d];
-              gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, HID, EMB), dense_out(HID), ep, SB, HID, EMB); }
-            rnn_fwd(bZ0[d], bH0[d], bw_hh[0][d], B, S, nullptr, 2, d == 1);
+            EpiP ep = epi(bZ0[d], false); ep.bias = bb_ih[0][d]; ep.bias2 = bb_hh[0][d];
+            gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, HID, EMB), dense_out(HID), ep, SB, HID, EMB);
         }
+        { const LinW* w2[2] = {&bw_hh[0][0], &bw_hh[0][1]}; rnn_fwd2(bZ0, bH0, w2, B, S, 2); }
         // layer 1 forward direction: input [H0f | H0b] -> two K = 2048 GEMMs against the column halves of W_ih_l1
         { EpiP ep = epi(bZ1, false); ep.bias = bb_ih[1][0]; ep.bias2 = bb_hh[1][0];
           gemm(dense<T>(bH0[0], SB, HID), dense<T>(bw_ih[1][0].W, HID, 2 * HID), dense_out(HID), ep, SB, HID, HID); }
@@ -1271,7 +1320,8 @@ struct Engine : IEngine {
                 static const bool fused = getenv("HULC_GRU_FUSED") ? atoi(getenv("HULC_GRU_FUSED")) != 0 : true;
                 if (i && fused) {
                     TimerScope ts(this, "gru_step", "hbm", 2.0 * B * 3 * HID * HID, ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
-                    if (launch_gru_step(st, hp, whh.W, B, HID, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH)) continue;
+                    const GruStepP q{hp, whh.W, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH};
+                    if (launch_gru_step(st, &q, 1, B, HID)) continue;
                 }
             }
             if (i) { EpiP ep = epi(gGf, true); ep.bias = bhh; gemm(dense<T>(hp, B, HID), dense<T>(whh.W, 3 * HID, HID), dense_out(3 * HID), ep, B, 3 * HID, HID); }
@@ -1309,6 +1359,74 @@ struct Engine : IEngine {
               gemm(dense<T>(g.dG + t * 3 * BH, B, 3 * HID), dense<T>(whh.Wt, HID, 3 * HID), dense_out(HID), ep, B, HID, 3 * HID); }
         }
     }
+    // both directions of a BiGRU layer in lockstep (see rnn_fwd2): g[0] runs t = 0..S-1, g[1] t = S-1..0
+    void gru_recur_fwd2(GruBuf* const g[2], const LinW* const whh[2], const float* const bhh[2], int B, int S) {
+        const long long BH = (long long)B * HID;
+        bool dual = false;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1 && skinny_use_lds;
+        if (dual) {
+            auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i); };
+            for (int i = 0; i < S; ++i) {
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    if (i) {
+                        GruStepP q[2];
+                        for (int d = 0; d < 2; ++d) {
+                            const long long t = at(d, i);
+                            q[d] = GruStepP{g[d]->H + at(d, i - 1) * BH, whh[d]->W, g[d]->Zx + t * 3 * BH, bhh[d], g[d]->H + t * BH, g[d]->R + t * BH, g[d]->Z + t * BH,
+                                            g[d]->N + t * BH, g[d]->GN + t * BH};
+                        }
+                        TimerScope ts(this, "gru_step", "hbm", 4.0 * B * 3 * HID * HID, 2 * ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
+                        if (launch_gru_step(st, q, 2, B, HID)) continue;
+                    }
+                }
+                for (int d = 0; d < 2; ++d) {
+                    const long long t = at(d, i);
+                    const T* hp = i ? g[d]->H + at(d, i - 1) * BH : nullptr;
+                    if (i) { EpiP ep = epi(gGf, true); ep.bias = bhh[d]; gemm(dense<T>(hp, B, HID), dense<T>(whh[d]->W, 3 * HID, HID), dense_out(3 * HID), ep, B, 3 * HID, HID); }
+                    hipLaunchKernelGGL((gru_gate_fwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, g[d]->Zx + t * 3 * BH, i ? gGf : (const float*)nullptr, bhh[d], hp, B, HID,
+                                       g[d]->H + t * BH, g[d]->R + t * BH, g[d]->Z + t * BH, g[d]->N + t * BH, g[d]->GN + t * BH);
+                }
+            }
+            return;
+        }
+        for (int d = 0; d < 2; ++d) gru_recur_fwd(*g[d], *whh[d], bhh[d], B, S, d == 1);
+    }
+    void gru_recur_bwd2(GruBuf* const g[2], T* const dH[2], const LinW* const whh[2], int B, int S) {
+        const long long BH = (long long)B * HID;
+        bool dual = false;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1 && skinny_use_lds && B <= 64 && (3 * HID) % 2048 == 0 && 3 * HID > 2048;   // = what launch_skinny_lds_kchunk covers
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (dual) {
+                if (!gcarB2) gcarB2 = alloc<T>((int64_t)maxB * HID);
+                auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i); };
+                T* carry[2] = {gcarB, gcarB2};
+                for (int d = 0; d < 2; ++d) {      // last processed step of each direction: no carry yet
+                    const long long t = at(d, S - 1);
+                    hipLaunchKernelGGL((gru_gate_bwd_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH[d] + t * BH, (const T*)nullptr, g[d]->R + t * BH, g[d]->Z + t * BH,
+                                       g[d]->N + t * BH, g[d]->GN + t * BH, g[d]->H + at(d, S - 2) * BH, B, HID, g[d]->dZx + t * 3 * BH, g[d]->dG + t * 3 * BH, carry[d]);
+                }
+                bool ok = true;
+                for (int i = S - 1; i >= 1 && ok; --i) {
+                    GruBwdP gbp[2];
+                    for (int d = 0; d < 2; ++d) {
+                        const long long tp = at(d, i - 1);
+                        gbp[d] = GruBwdP{};
+                        gbp[d].dH = dH[d] + tp * BH;
+                        gbp[d].R = g[d]->R + tp * BH; gbp[d].Z = g[d]->Z + tp * BH; gbp[d].Nn = g[d]->N + tp * BH; gbp[d].GN = g[d]->GN + tp * BH;
+                        gbp[d].Hprev = i - 1 ? g[d]->H + at(d, i - 2) * BH : nullptr;
+                        gbp[d].dzx = g[d]->dZx + tp * 3 * BH; gbp[d].dg = g[d]->dG + tp * 3 * BH; gbp[d].direct = carry[d]; gbp[d].direct_in = carry[d];
+                    }
+                    EpiP ep = epi(gcarA, false);
+                    KChunk2 p2; p2.A = g[1]->dG + at(1, i) * 3 * BH; p2.W = whh[1]->Wt; p2.ep = ep; p2.gb = gbp[1];
+                    ok = launch_skinny_lds_kchunk(st, g[0]->dG + at(0, i) * 3 * BH, 3 * HID, whh[0]->Wt, 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp[0], &p2);
+                }
+                if (ok) return;
+                hulc_set_error("gru_recur_bwd2: dual launch rejected mid-chain");      // shapes are checked identically every step: cannot happen after the first
+                return;
+            }
+        }
+        for (int d = 0; d < 2; ++d) gru_recur_bwd(*g[d], dH[d], *whh[d], B, S, d == 1, false);
+    }
     // weight / bias gradients of one recurrence from dZx, dG, its states H and its input X [S][B][K] (ldx), into dW_ih (+ column offset, lddw)
     void gru_param_grads(GruBuf& g, const LinW& wih, const LinW& whh, float* dbih, float* dbhh, int B, int S, bool rev) {
         const int SB = S * B, mp = ldpad(SB), H3 = 3 * HID;
@@ -1325,10 +1443,11 @@ struct Engine : IEngine {
         gb[0].H = bH0[0]; gb[1].H = bH0[1]; gb[2].H = bH1; gb[3].H = bh1b;
         hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * EMB, 256)), dim3(256), 0, st, emb, embg, B, S, EMB);
         for (int d = 0; d < 2; ++d) {
-            { EpiP ep = epi(gb[d].Zx, false); ep.bias = bb_ih[0][d];
-              gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, H3, EMB), dense_out(H3), ep, SB, H3, EMB); }
-            gru_recur_fwd(gb[d], bw_hh[0][d], bb_hh[0][d], B, S, d == 1);
+            EpiP ep = epi(gb[d].Zx, false); ep.bias = bb_ih[0][d];
+            gemm(dense<T>(embg, SB, EMB), dense<T>(bw_ih[0][d].W, H3, EMB), dense_out(H3), ep, SB, H3, EMB);
         }
+        { GruBuf* g2[2] = {&gb[0], &gb[1]}; const LinW* w2[2] = {&bw_hh[0][0], &bw_hh[0][1]}; const float* b2[2] = {bb_hh[0][0], bb_hh[0][1]};
+          gru_recur_fwd2(g2, w2, b2, B, S); }
         for (int d = 0; d < 2; ++d) {      // layer 1 input [H0f | H0b]: two K = 2048 GEMMs against the column halves of W_ih_l1; d = 1: reverse direction, t = S-1 only
             const int M = d ? B : SB;
             const long long off = d ? (S - 1) * BH : 0;
@@ -1371,8 +1490,8 @@ struct Engine : IEngine {
             gemm(dense<T>(tA, H3, mp), dense<T>(tB, HID, mp), dense_out(2 * HID), ep, H3, HID, SB);
         }
         // ---- layer 0, both directions
+        { GruBuf* g2[2] = {&gb[0], &gb[1]}; const LinW* w2[2] = {&bw_hh[0][0], &bw_hh[0][1]}; gru_recur_bwd2(g2, bdH0, w2, B, S); }
         for (int d = 0; d < 2; ++d) {
-            gru_recur_bwd(gb[d], bdH0[d], bw_hh[0][d], B, S, d == 1, false);
             gru_param_grads(gb[d], bw_ih[0][d], bw_hh[0][d], dbb_ih[0][d], dbb_hh[0][d], B, S, d == 1);
             transpose_pair(gb[d].dZx, H3, tA, SB, H3, embg, EMB, tB, SB, EMB, mp);
             { EpiP ep = epi(bw_ih[0][d].dW, true); ep.accumulate = 1; gemm(dense<T>(tA, H3, mp), dense<T>(tB, EMB, mp), dense_out(EMB), ep, H3, EMB, SB); }
@@ -1412,9 +1531,9 @@ struct Engine : IEngine {
             gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(2 * HID), ep, HID, HID, SB);
         }
         colsum(bdZ1, HID, SB, HID, dbb_ih[1][0], dbb_hh[1][0]);
-        // ---- layer 0, both directions
+        // ---- layer 0, both directions (BPTT of the two in lockstep)
+        { const LinW* w2[2] = {&bw_hh[0][0], &bw_hh[0][1]}; rnn_bwd2(bdH0, bH0, bdZ0, w2, B, S, 2); }
         for (int d = 0; d < 2; ++d) {
-            rnn_bwd(bdH0[d], bH0[d], bdZ0[d], bw_hh[0][d], B, S, 2, d == 1, false);
             transpose_pair(bdZ0[d], HID, tA, SB, HID, bH0[d], HID, tB, SB, HID, mp);
             if (S > 1) { EpiP ep = epi(bw_hh[0][d].dW, true); ep.accumulate = 1;     // forward: dZ[t] x H[t-1]; reverse: dZ[t] x H[t+1]
               gemm(dense<T>(tA + (d ? 0 : B), HID, mp), dense<T>(tB + (d ? B : 0), HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }

@@ -770,9 +770,16 @@ static bool gemm_use_glds = true;   // tests / tools can force the register-frag
 // 8 rows x 128 B, XOR-swizzled on the SOURCE address so the later ds_read_b128 fragments are conflict-free) instead of
 // fragment-shaped 16 x 64 B loads, which the texture-address path serves at ~2/3 of the full-line rate (tools/loadbench.hip:
 // 192 KB/CU in 4.3 us vs 7.4 us).  Each wave DMAs exactly the k-range it multiplies, so no barrier sits between load and MFMA.
-template <int MT, int KQ32, int NW = 8>   // KQ32 = k-steps (of 32) per wave = K / (NW * 32)
-__global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W,
-                                                         long long ldw, int M, int N, int K, DenseOut om, EpiP ep) {
+// A second, INDEPENDENT problem of the same shape can ride in the same launch (blockIdx.z == 1: A2 / W2 / ep2) — the two directions of a
+// bidirectional recurrence advance one time step each per launch, and the chain pays one launch boundary instead of two.
+struct Skinny2 { const h16_t* A; const h16_t* W; EpiP ep; };
+template <int MT, int KQ32, int NW = 8, bool DUAL = false>   // KQ32 = k-steps (of 32) per wave = K / (NW * 32); DUAL: a separate instantiation, the single-problem code is untouched
+__global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __restrict__ A_, long long lda, const h16_t* __restrict__ W_,
+                                                         long long ldw, int M, int N, int K, DenseOut om, EpiP ep_, Skinny2 p2 = Skinny2{}) {
+    const bool second = DUAL && blockIdx.z != 0;
+    const h16_t* __restrict__ A = second ? p2.A : A_;
+    const h16_t* __restrict__ W = second ? p2.W : W_;
+    const EpiP& ep = second ? p2.ep : ep_;
     constexpr int PCW = KQ32 / 2;               // 128-byte pieces (64 k) per row per wave
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     typedef __attribute__((address_space(3))) char lchar;
@@ -852,10 +859,12 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __rest
 // the epilogue on values that never leave the chip (before: a 24 MB fp32 `g` round trip and a second launch per step).
 // K = 2048, rows of A 128-byte aligned, H % 16 == 0.
 // ---------------------------------------------------------------------------------------------------------------------
+struct GruStepP { const h16_t* A; const h16_t* W; const h16_t* zx; const float* bhh; h16_t *h_out, *r_out, *z_out, *n_out, *gn_out; };
 template <int MT, int KQ32, int NW>
-__global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W, long long ldw, int M, int H,
-                                                             const h16_t* __restrict__ zx, const float* __restrict__ bhh, h16_t* __restrict__ h_out,
-                                                             h16_t* __restrict__ r_out, h16_t* __restrict__ z_out, h16_t* __restrict__ n_out, h16_t* __restrict__ gn_out) {
+__global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruStepP q1, long long lda, long long ldw, int M, int H) {     // blockIdx.z selects the problem (see Skinny2)
+    const GruStepP& q = blockIdx.z ? q1 : q0;
+    const h16_t* __restrict__ A = q.A; const h16_t* __restrict__ W = q.W; const h16_t* __restrict__ zx = q.zx; const float* __restrict__ bhh = q.bhh;
+    h16_t* __restrict__ h_out = q.h_out; h16_t* __restrict__ r_out = q.r_out; h16_t* __restrict__ z_out = q.z_out; h16_t* __restrict__ n_out = q.n_out; h16_t* __restrict__ gn_out = q.gn_out;
     constexpr int PCW = KQ32 / 2;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     typedef __attribute__((address_space(3))) char lchar;
@@ -956,15 +965,15 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(const h16_t* __re
     }
 }
 // returns false when the shape is not covered (the caller then runs the GEMM + gate kernel pair)
-static inline bool launch_gru_step(hipStream_t st, const h16_t* hprev, const h16_t* Whh, int M, int H, const h16_t* zx, const float* bhh, h16_t* h_out, h16_t* r_out,
-                                   h16_t* z_out, h16_t* n_out, h16_t* gn_out) {
-    if (H != 2048 || M < 1 || ((uintptr_t)hprev % 128) != 0 || ((uintptr_t)Whh % 16) != 0) return false;
+// nprob = 2: q[1] is a second independent recurrence (the other direction of the BiGRU) advanced by the same launch
+static inline bool launch_gru_step(hipStream_t st, const GruStepP* q, int nprob, int M, int H) {
+    for (int k = 0; k < nprob; ++k)
+        if (H != 2048 || M < 1 || ((uintptr_t)q[k].A % 128) != 0 || ((uintptr_t)q[k].W % 16) != 0) return false;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)gru_step_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    dim3 grid(H / 16, (M + 31) / 32);
+    dim3 grid(H / 16, (M + 31) / 32, nprob);
     // LDS: the A region (16 waves x 2 x 2 x 2 KB = 128 KB) is reused for the 16 x 2 x 3 K-partials (96 KB)
-    hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, hprev, (long long)H, Whh, (long long)H, M, H, zx, bhh, h_out, r_out,
-                       z_out, n_out, gn_out);
+    hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, q[0], q[nprob - 1], (long long)H, (long long)H, M, H);
     return true;
 }
 
@@ -980,9 +989,14 @@ struct GruBwdP {
     h16_t *dzx, *dg, *direct;                        // outputs for step t-1: [M][3H], [M][3H], [M][H]; dzx == nullptr: plain GEMM epilogue
     const h16_t* direct_in;                          // direct[t] (dh_t z_t), added to the carry
 };
+struct KChunk2 { const h16_t* A; const h16_t* W; EpiP ep; GruBwdP gb; };
 template <int MT, int KQ32, int NW>
-__global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t* __restrict__ A, long long lda, const h16_t* __restrict__ W, long long ldw, int M, int N,
-                                                                  int K, DenseOut om, EpiP ep, GruBwdP gb) {
+__global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t* __restrict__ A_, long long lda, const h16_t* __restrict__ W_, long long ldw, int M, int N,
+                                                                  int K, DenseOut om, EpiP ep_, GruBwdP gb_, KChunk2 p2 = KChunk2{}) {      // blockIdx.z == 1: the second problem (see Skinny2)
+    const h16_t* __restrict__ A = blockIdx.z ? p2.A : A_;
+    const h16_t* __restrict__ W = blockIdx.z ? p2.W : W_;
+    const EpiP& ep = blockIdx.z ? p2.ep : ep_;
+    const GruBwdP& gb = blockIdx.z ? p2.gb : gb_;
     constexpr int PCW = KQ32 / 2, KCH = NW * KQ32 * 32;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     typedef __attribute__((address_space(3))) char lchar;
@@ -1083,11 +1097,13 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
     }
 }
 static inline bool launch_skinny_lds_kchunk(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K, const DenseOut& om,
-                                            const EpiP& ep, const GruBwdP& gb = GruBwdP{}) {
+                                            const EpiP& ep, const GruBwdP& gb = GruBwdP{}, const KChunk2* p2 = nullptr) {
     if (K % 2048 != 0 || K <= 2048 || M > 64 || (lda % 64) != 0 || ((uintptr_t)A % 128) != 0 || (N % 16) != 0) return false;
+    if (p2 && ((uintptr_t)p2->A % 128) != 0) return false;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)skinny_lds_kchunk_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((skinny_lds_kchunk_kernel<2, 4, 16>), dim3(N / 16, (M + 31) / 32), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep, gb);
+    hipLaunchKernelGGL((skinny_lds_kchunk_kernel<2, 4, 16>), dim3(N / 16, (M + 31) / 32, p2 ? 2 : 1), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A, lda, W, ldw, M, N, K, om, ep, gb,
+                       p2 ? *p2 : KChunk2{});
     return true;
 }
 
@@ -1126,6 +1142,17 @@ static inline bool launch_skinny_lds(hipStream_t st, const h16_t* A, long long l
     if (MT == 2) { if (kq32 == 8) SKL(2, 8); else if (kq32 == 4) SKL(2, 4); else if (kq32 == 2) SKL(2, 2); else return false; }
     else { if (kq32 == 4) SKL(4, 4); else if (kq32 == 2) SKL(4, 2); else return false; }
 #undef SKL
+    return true;
+}
+// two independent [M <= 64] x [N] x [K = 2048] recurrent steps in ONE launch of skinny_lds_kernel<2, 4, 16> (grid.z = 2); false: shape not covered
+static inline bool launch_skinny_lds_dual(hipStream_t st, const h16_t* A0, const h16_t* W0, const EpiP& ep0, const h16_t* A1, const h16_t* W1, const EpiP& ep1, long long lda,
+                                          long long ldw, int M, int N, int K, const DenseOut& om) {
+    if (!skinny_use_lds || K != 2048 || M <= 32 || M > 64 || (N % 16) != 0 || (lda % 64) != 0 || ((uintptr_t)A0 % 128) != 0 || ((uintptr_t)A1 % 128) != 0 ||
+        ((uintptr_t)W0 % 16) != 0 || ((uintptr_t)W1 % 16) != 0 || (ldw % 8) != 0) return false;
+    static bool attr16 = false;
+    if (!attr16) { hipFuncSetAttribute((const void*)skinny_lds_kernel<2, 4, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
+    Skinny2 p2; p2.A = A1; p2.W = W1; p2.ep = ep1;
+    hipLaunchKernelGGL((skinny_lds_kernel<2, 4, 16, true>), dim3(N / 16, (M + 31) / 32, 2), dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, A0, lda, W0, ldw, M, N, K, om, ep0, p2);
     return true;
 }
 template <int NW>
