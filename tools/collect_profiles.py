@@ -29,7 +29,7 @@ def grp(pred):
         return 0.0, 0.0, 0.0
     return (sum(float(r["mfma_util"]) * float(r["total_us"]) for r in sel) / tus, sum(float(r["mfma_tflops"]) * float(r["total_us"]) for r in sel) / tus, tus)
 groups = [("conv (conv1 fwd/wgrad, conv2/3 fwd, dgrad, wgrad)", lambda k: "conv" in k and "unpack" not in k),
-          ("RNN decoder, recurrent step (skinny_lds, M=64)", lambda k: "skinny_lds_kernel<2, 4, 16> [grid=262144]" in k),
+          ("RNN decoder, recurrent step (skinny_lds, M=64)", lambda k: "skinny_lds_kernel<2, 4, 16, false> [grid=262144]" in k),
           ("RNN decoder, batched GEMMs (gemm_glds 128x128)", lambda k: "gemm_glds" in k),
           ("transformer + MLP small GEMMs (gemm_kernel 32/64 tiles, other skinny)", lambda k: ("gemm_kernel<" in k) or ("skinny" in k and "[grid=262144]" not in k) or "lin_bwd" in k)]
 grows = "| GEMM group | MFMA-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (time x 2.4 GHz x 1024 SIMDs)) | MFMA TFLOP/s (SQ_INSTS_VALU_MFMA_MOPS x 512 / time) | % of 2.5 PF | profiled us in the 5 dispatched steps |\n|---|---|---|---|---|\n"

@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 d = sys.argv[1]
 # the recurrent step is the M=64, N=K=2048 launch of the skinny kernel: grid (128, 2) x 1024 threads (the same kernel also serves
 # many-row GEMMs with other grids; dispatches are keyed by kernel name + grid size so those stay out of the class)
-CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128", "gemm_kernel<h16, 128, 128")),
+CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16, false>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128", "gemm_kernel<h16, 128, 128")),
            ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
            ("conv_tile_fwd", (("conv_tile_kernel", "false>("),)), ("conv_tile_dgrad", (("conv_tile_kernel", "true>("),)), ("adam", ("adam_kernel",))]
 per = {}
