@@ -293,6 +293,11 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
     else if (NW == 17 && MT == 2) hipLaunchKernelGGL((skinny_gemm_kernel<16, 2, 4>), grid, dim3(1024), 0, st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);
     else if (NW == 20) { if (!launch_skinny_lds(st, a, (long long)K, w, (long long)K, M, N, K, MT, dense_out(N), ep)) { hulc_set_error("hulc_k_skinny: shape not covered by the LDS kernel"); return 1; } }
     else if (NW == 30) launch_skinny(st, a, (long long)K, w, (long long)K, M, N, K, dense_out(N), ep);       // the production router (incl. the K-chunked LDS kernel)
+    else if (NW == 40) {      // two independent problems in one launch (the paired directions of a bidirectional recurrence): the second one lives at A + M*K, W + N*K, out + M*N
+        EpiP ep2 = ep; ep2.out = (h16_t*)out + (long long)M * N;
+        if (!launch_skinny_lds_dual(st, a, w, ep, a + (long long)M * K, w + (long long)N * K, ep2, (long long)K, (long long)K, M, N, K, dense_out(N))) {
+            hulc_set_error("hulc_k_skinny: shape not covered by the dual launch"); return 1; }
+    }
     else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -251,7 +251,8 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
  * bitmask words (2 / 1 per output pixel).  relu: bit 0 = ReLU, bit 5 (32) = dynamic work claiming, bits 1..4 = bench ablations. */
 int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
                      int32_t OUTH, int32_t relu, void* hip_stream);
-/* skinny GEMM kernel alone (bf16 in / bf16 out), variant = waves*10 + row-tiles-per-workgroup; asynchronous. */
+/* skinny GEMM kernel alone (bf16 in / bf16 out), variant = waves*10 + row-tiles-per-workgroup; 300 = the production router; 400 = TWO
+ * independent problems in one launch (second one at A + M*K, W + N*K, out + M*N; 32 < M <= 64, K = 2048); asynchronous. */
 int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K, int32_t variant, void* hip_stream);
 int hulc_k_trread_probe(const int32_t* elem_index_per_lane /*64*/, uint16_t* out /*64x4*/, void* hip_stream);
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);

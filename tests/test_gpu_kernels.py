@@ -144,6 +144,22 @@ def test_skinny_gemm(M, N, K, variant):
     assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3
 
 
+@pytest.mark.parametrize("M", [40, 64])
+def test_skinny_dual_launch(M):
+    """Two independent recurrent-step GEMMs in one launch (grid.z = 2: the paired directions of the bidirectional plan encoders)."""
+    L, lib = _lib()
+    N = K = 2048
+    rng = np.random.default_rng(M)
+    A = bf(rng.standard_normal((2, M, K)))
+    W = bf(rng.standard_normal((2, N, K)) * 0.05 + np.arange(N)[None, :, None] * 1e-4)
+    out = torch.zeros(2, M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_skinny(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, 400, None))
+    torch.cuda.synchronize()
+    for z in range(2):
+        ref = f64(A[z]) @ f64(W[z]).T
+        assert np.abs(f64(out[z]) - ref).max() / np.abs(ref).max() < 6e-3, z
+
+
 def test_tr_read_lane_mapping():
     """ds_read_b64_tr_b16: lane i of a 16-lane group receives element (i & 3) of the chunks addressed by lanes j*4 + (i >> 2)."""
     L, lib = _lib()
