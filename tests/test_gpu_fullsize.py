@@ -89,6 +89,34 @@ def test_bf16_mode_tracks_fp32_mode_full_size():
     assert l_after["total_mod"] < l16["total_mod"], (l_after, l16)
 
 
+@pytest.mark.parametrize("rnn_type", ["rnn", "gru"])
+def test_mcil_bf16_mode_tracks_fp32_mode_full_size(rnn_type):
+    """BASELINE configs 3/4 shapes (mcil, BiRNN / BiGRU plan encoder) at B=64, S=32: the 16-bit engine runs the paired-direction launches
+    (grid.z = 2 recurrent steps, fused GRU gate backward) that only exist at M > 32 rows; the fp32 engine runs the plain per-direction
+    recurrences.  Same bars as the HULC test above."""
+    dev = torch.device("cuda:0")
+    dims = spec.ModelDims(kind="mcil", max_window=32, use_clip=False, rnn_type=rnn_type)
+    mb = synth_batch(B, S, dev, seed=7)
+    g = torch.Generator(device=dev); g.manual_seed(13)
+    mb["plan_eps"] = torch.randn(B, 256, device=dev, generator=g)          # injected reparametrisation noise: both engines sample the same plan
+    e32 = _engine(dims, B, "fp32")
+    l32, g32 = _step(e32, mb)
+    e32.close()
+    e16 = _engine(dims, B, "bf16")
+    l16, g16 = _step(e16, mb)
+    assert abs(l16["total_mod"] - l32["total_mod"]) <= 3e-3 * abs(l32["total_mod"]), (l16, l32)
+    cos = (torch.dot(g16.double(), g32.double()) / (g16.double().norm() * g32.double().norm())).item()
+    assert cos > 0.995, cos
+    # the plan encoder's own gradients (what the paired launches produce)
+    views32, views16 = e16.views(g32), e16.views(g16)
+    for n in views32:
+        if "birnn_model.weight_hh" in n:
+            a, b = views32[n].double().reshape(-1), views16[n].double().reshape(-1)
+            if a.norm() > 0:
+                assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.99, n
+    e16.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # >= 2 work items per CU (VERDICT r1 item 3): the persistent one-workgroup-per-CU conv kernels with dynamic work claiming, the ReLU
 # bitmask hand-off between conv2's forward and conv3's dgrad, and the XCD tile order — against float64 references at hundreds of frames.
