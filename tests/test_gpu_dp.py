@@ -1,0 +1,77 @@
+"""Two data-parallel ranks on ONE GPU (gloo between the processes; RCCL refuses two ranks on one device): the real engine's split backward
+(`backward(0)` -> async all-reduce of the non-encoder slice -> `backward(1)` -> encoder slice, hulc_amd.parallel.backward_overlapped) must leave
+on every rank the SUM of the ranks' gradients, and SUM / world must equal the single-process gradient of the concatenated batch (every loss term
+is a mean over windows — what data parallelism relies on).  fp32 (parity) engine, dropout off, injected plan sample."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+B, S = 8, 8
+
+
+def _make(dev):
+    from bench import synth_batch
+    mb = synth_batch(B, S, dev, seed=5)
+    g = torch.Generator(device=dev); g.manual_seed(17)
+    mb["plan_idx"] = torch.randint(0, 32, (B, 32), device=dev, generator=g, dtype=torch.int32)
+    return mb
+
+
+def _slice(mb, lo, hi):
+    return {k: (v[lo:hi].contiguous() if torch.is_tensor(v) else v) for k, v in mb.items()}
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", HULC_DP_COMM="torch")
+    import torch.distributed as dist
+    from hulc_amd import parallel, spec
+    from hulc_amd.engine import StepEngine
+    parallel.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    dims = spec.ModelDims(kind="hulc", max_window=S, use_clip=False)
+    eng = StepEngine(dims, B, S, dtype="fp32", device="cuda:0", dropout_p=0.0, seed=3)
+    eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+    mb = _slice(_make(dev), rank * B // world, (rank + 1) * B // world)
+    eng.zero_grads()
+    eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+    parallel.backward_overlapped(eng)
+    torch.cuda.synchronize()
+    out[rank] = eng.flat_grads.cpu().numpy()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_sum_equals_full_batch_gradient():
+    import torch.multiprocessing as mp
+    from hulc_amd import spec
+    from hulc_amd.engine import StepEngine
+    out = mp.Manager().dict()
+    try:
+        mp.spawn(_worker, args=(2, 29800 + os.getpid() % 150, out), nprocs=2, join=True)
+    except Exception as e:                      # a torch build whose gloo cannot reduce device tensors
+        if "gloo" in str(e).lower() or "not supported" in str(e).lower():
+            pytest.skip(f"gloo cannot all-reduce device tensors here: {e}")
+        raise
+    g0, g1 = out[0], out[1]
+    assert np.array_equal(g0, g1)               # both ranks hold the same SUM
+    dev = torch.device("cuda:0")
+    dims = spec.ModelDims(kind="hulc", max_window=S, use_clip=False)
+    eng = StepEngine(dims, B, S, dtype="fp32", device="cuda:0", dropout_p=0.0, seed=3)
+    eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+    eng.zero_grads()
+    eng.forward_loss(_make(dev), False, 1.0, 3.0, step=0)
+    eng.backward()
+    torch.cuda.synchronize()
+    full = eng.flat_grads.cpu().numpy().astype(np.float64)
+    eng.close()
+    rel = np.linalg.norm(g0.astype(np.float64) / 2 - full) / np.linalg.norm(full)
+    assert rel < 1e-4, rel
