@@ -75,3 +75,43 @@ def test_two_ranks_one_gpu_sum_equals_full_batch_gradient():
     eng.close()
     rel = np.linalg.norm(g0.astype(np.float64) / 2 - full) / np.linalg.norm(full)
     assert rel < 1e-4, rel
+
+
+def _module_worker(rank, world, port, out):
+    """Hulc.training_step (vis + lang + CLIP: the logged-scalar all-reduce of hulc.py:512-532) + FusedAdam.step on two ranks of one GPU.
+    HULC_DP_COMM is left at its default: the library RCCL communicator is attempted, RCCL refuses two ranks on one device, every rank must
+    agree on the torch.distributed fallback (parallel.setup_comm) and the step must complete with identical parameters on both ranks."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.pop("HULC_DP_COMM", None)
+    import torch.distributed as dist
+    from golden_util import load_case
+    from hulc_amd import config, parallel
+    from test_gpu_module import ref_style_batch
+    parallel.init_from_env("gloo")
+    dims, P, batch, fx = load_case("hulc_tiny")
+    cfg = config.compose(os.path.join(ROOT, "conf"), "config", ["model=hulc", "trainer.precision=fp32", "datamodule.batch_size=4"])
+    model = config.instantiate(cfg.model, device="cuda:0", max_seq_len=32)
+    model.load_state_dict({n: torch.from_numpy(P[n]) for n in P}, strict=False)
+    model.eval()
+    loss = float(model.training_step(ref_style_batch(batch), 0))
+    opt = model.configure_optimizers()["optimizer"]
+    opt.step()
+    torch.cuda.synchronize()
+    w = dict(model.named_parameters())["action_decoder.mean_fc.weight"].detach().cpu().numpy().copy()
+    out[rank] = (loss, model.logged["train/lang_clip_loss"], bool(getattr(model.engine, "has_comm", False)), w)
+    dist.destroy_process_group()
+
+
+def test_module_training_step_and_adam_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+    from golden_util import load_case
+    out = mp.Manager().dict()
+    mp.spawn(_module_worker, args=(2, 29500 + os.getpid() % 150, out), nprocs=2, join=True)
+    (l0, c0, comm0, w0), (l1, c1, comm1, w1) = out[0], out[1]
+    _, _, _, fx = load_case("hulc_tiny")
+    ref = float(fx["loss_total"])
+    assert abs(l0 - ref) <= 1e-3 * abs(ref) and abs(l1 - ref) <= 1e-3 * abs(ref)      # both ranks ran the same batch
+    assert abs(c0 - c1) < 1e-6                                                         # the logged scalar is the mean over ranks on both
+    assert comm0 == comm1                                                              # one collective path for the whole job
+    assert np.array_equal(w0, w1) and np.isfinite(w0).all()                            # identical parameters after the step (mean gradient of identical ranks)
