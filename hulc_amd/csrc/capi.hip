@@ -210,6 +210,15 @@ int hulc_k_attention(int32_t variant, const float* qkv, float* P, float* ao, con
     hipStream_t st = (hipStream_t)stream;
     const int D = 128, NH = 8;
     if (S < 1 || S > 64 || (variant == 1 && S > 32)) { hulc_set_error("hulc_k_attention: S=%d not covered by variant %d", S, variant); return 1; }
+    if (variant == 2) {                         // four waves per (b, head): the S <= 64 kernels the 16-bit engines run for S > 32
+        if (!dao) hipLaunchKernelGGL((attention_fwd64_kernel<float>), dim3(B * NH), dim3(256), 0, st, qkv, B, S, D, NH, P, ao, drop_p, (unsigned long long)seed);
+        else {
+            hipFuncSetAttribute((const void*)attention_bwd64_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD64_LDS);
+            hipLaunchKernelGGL((attention_bwd64_kernel<float>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv, P, dao, B, S, D, NH, dqkv, drop_p, (unsigned long long)seed);
+        }
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("hulc_k_attention: launch failed"); return 1; }
+        return 0;
+    }
     const dim3 grid(B * NH), block(64);
     if (!dao) {
         if (variant == 1) hipLaunchKernelGGL((attention_fwd32_kernel<float>), grid, block, 0, st, qkv, B, S, D, NH, P, ao, drop_p, (unsigned long long)seed);

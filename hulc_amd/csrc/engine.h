@@ -854,6 +854,7 @@ struct Engine : IEngine {
             static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
             if (S <= 32 && att32) hipLaunchKernelGGL((attention_fwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             else if (S <= 32) hipLaunchKernelGGL((attention_fwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
+            else if (att32) hipLaunchKernelGGL((attention_fwd64_kernel<T>), dim3(B * NH), dim3(256), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             else hipLaunchKernelGGL((attention_fwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             { EpiP ep = epi(y1[l], true); ep.res = xf[l]; ep.res_f32 = 1; ep.res_ld = EMB; ep.res_late = 1; ep.drop_p = dp; ep.drop_seed = site_seed(2 + 4 * l);
               lin_fwd(ao[l], EMB, N, tr_out[l], ep, EMB); }
@@ -1788,6 +1789,11 @@ struct Engine : IEngine {
                 static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
                 if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                else if (att32) {
+                    static bool attr = false;
+                    if (!attr) { hipFuncSetAttribute((const void*)attention_bwd64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD64_LDS); attr = true; }
+                    hipLaunchKernelGGL((attention_bwd64_kernel<T>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                }
                 else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }

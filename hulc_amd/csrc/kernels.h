@@ -906,6 +906,148 @@ __global__ void __launch_bounds__(64) attention_bwd32_kernel(const T* __restrict
     }
 }
 
+// 32 < S <= 64 (BASELINE config 5's windows): four waves per (b, head), wave w handles the keys [16 w, 16 w + 16) of every query row (lane = row);
+// the four partials of a row meet in LDS.  The one-lane-per-row kernels take 47 / 52 us per launch at S = 64, B = 32 (64 serial keys per thread).
+template <typename T>
+__global__ void __launch_bounds__(256) attention_fwd64_kernel(const T* __restrict__ qkv, int B, int S, int D, int NH, float* __restrict__ P,
+                                                              T* __restrict__ ao, float drop_p, unsigned long long seed) {
+    constexpr int HD = 16, SMAX = 64, HJ = 16;
+    __shared__ float q[SMAX][HD + 1], k[SMAX][HD + 1], v[SMAX][HD + 1];
+    __shared__ float pm[4][SMAX], pd[4][SMAX], po[4][SMAX][HD + 1];
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+#pragma unroll
+        for (int d = w * 4; d < w * 4 + 4; ++d) { q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); v[i][d] = to_f<T>(r[2 * D + d]); }
+    }
+    __syncthreads();
+    const bool live = i < S;
+    float sc[HJ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = w * HJ + jj;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[live ? i : 0][d] * k[j < S ? j : 0][d];
+        sc[jj] = (live && j < S) ? s : -INFINITY;
+        m = fmaxf(m, sc[jj]);
+    }
+    pm[w][i] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(pm[0][i], pm[1][i]), fmaxf(pm[2][i], pm[3][i]));
+    float den = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) { sc[jj] = (live && w * HJ + jj < S) ? __expf(sc[jj] - m) : 0.f; den += sc[jj]; }
+    pd[w][i] = den;
+    __syncthreads();
+    den = (pd[0][i] + pd[1][i]) + (pd[2][i] + pd[3][i]);
+    const float inv = live ? 1.f / den : 0.f;
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float* Pr = P + (((long long)b * NH + h) * S + (live ? i : 0)) * S;
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = w * HJ + jj;
+        if (live && j < S) {
+            float p = sc[jj] * inv;
+            Pr[j] = p;
+            if (drop_p > 0.f) p = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : p / (1.f - drop_p);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] += p * v[j][d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) po[w][i][d] = o[d];
+    __syncthreads();
+    if (!live) return;
+    T* orow = ao + (long long)(b * S + i) * D + h * HD + w * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { const int e = w * 4 + d; orow[d] = from_f<T>((po[0][i][e] + po[1][i][e]) + (po[2][i][e] + po[3][i][e])); }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) attention_bwd64_kernel(const T* __restrict__ qkv, const float* __restrict__ P, const T* __restrict__ dao,
+                                                              int B, int S, int D, int NH, T* __restrict__ dqkv, float drop_p,
+                                                              unsigned long long seed) {
+    constexpr int HD = 16, SMAX = 64, HJ = 16;
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    float (*q)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(att_smem);
+    float (*k)[HD + 1] = q + SMAX;
+    float (*v)[HD + 1] = k + SMAX;
+    float (*dO)[HD + 1] = v + SMAX;
+    float (*dS)[SMAX + 1] = reinterpret_cast<float (*)[SMAX + 1]>(dO + SMAX);     // dS[i][j]
+    float (*Pd)[SMAX + 1] = dS + SMAX;                                             // dropped P[i][j] (for dV)
+    float (*pdot)[SMAX] = reinterpret_cast<float (*)[SMAX]>(Pd + SMAX);            // [4][SMAX]
+    float (*pg)[SMAX][3 * HD + 1] = reinterpret_cast<float (*)[SMAX][3 * HD + 1]>(pdot + 4);   // [4][SMAX][49]: partial dq | dk | dv
+    const int b = blockIdx.x / NH, h = blockIdx.x % NH, i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (i < S) {
+        const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
+        const T* g = dao + (long long)(b * S + i) * D + h * HD;
+#pragma unroll
+        for (int d = w * 4; d < w * 4 + 4; ++d) {
+            q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); v[i][d] = to_f<T>(r[2 * D + d]); dO[i][d] = to_f<T>(g[d]);
+        }
+    }
+    __syncthreads();
+    const bool live = i < S;
+    const float* Pr = P + (((long long)b * NH + h) * S + (live ? i : 0)) * S;
+    float dot = 0.f;
+    float dp[HJ], pv[HJ];
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) {
+        const int j = w * HJ + jj;
+        dp[jj] = 0.f; pv[jj] = 0.f;
+        if (live && j < S) {
+            float dpj = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dpj += dO[i][d] * v[j][d];
+            const float p = Pr[j];
+            float keep = 1.f;
+            if (drop_p > 0.f) keep = hash_uniform(seed, (((long long)b * NH + h) * S + i) * S + j) < drop_p ? 0.f : 1.f / (1.f - drop_p);
+            Pd[i][j] = p * keep;
+            dpj *= keep;
+            dp[jj] = dpj; pv[jj] = p;
+            dot += dpj * p;
+        }
+    }
+    pdot[w][i] = dot;
+    __syncthreads();
+    dot = (pdot[0][i] + pdot[1][i]) + (pdot[2][i] + pdot[3][i]);
+#pragma unroll
+    for (int jj = 0; jj < HJ; ++jj) if (live && w * HJ + jj < S) dS[i][w * HJ + jj] = pv[jj] * (dp[jj] - dot);
+    __syncthreads();
+    float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dq[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    if (live)
+        for (int jj = 0; jj < HJ; ++jj) {
+            const int j = w * HJ + jj;
+            if (j >= S) break;
+            const float s_ij = dS[i][j], s_ji = dS[j][i], p_ji = Pd[j][i];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dq[d] += s_ij * k[j][d];
+                dk[d] += s_ji * q[j][d];
+                dv[d] += p_ji * dO[j][d];
+            }
+        }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { pg[w][i][d] = dq[d]; pg[w][i][HD + d] = dk[d]; pg[w][i][2 * HD + d] = dv[d]; }
+    __syncthreads();
+    if (!live) return;
+    T* o = dqkv + (long long)(b * S + i) * 3 * D + h * HD + w * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int e = w * 4 + d;
+        const float sq = (pg[0][i][e] + pg[1][i][e]) + (pg[2][i][e] + pg[3][i][e]);
+        const float sk = (pg[0][i][HD + e] + pg[1][i][HD + e]) + (pg[2][i][HD + e] + pg[3][i][HD + e]);
+        const float sv = (pg[0][i][2 * HD + e] + pg[1][i][2 * HD + e]) + (pg[2][i][2 * HD + e] + pg[3][i][2 * HD + e]);
+        o[d] = from_f<T>(sq * 0.25f); o[D + d] = from_f<T>(sk); o[2 * D + d] = from_f<T>(sv);
+    }
+}
+static constexpr size_t ATT_BWD64_LDS = sizeof(float) * (4 * 64 * 17 + 2 * 64 * 65 + 4 * 64 + 4 * 64 * 49);
+
 // xm[b][d] = mean_t x[b][t][d]   (fp32 in, T out)
 template <typename T>
 __global__ void mean_over_s_kernel(const float* __restrict__ x, int B, int S, int D, T* __restrict__ out) {

@@ -259,7 +259,7 @@ int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip
 /* the transformer's attention kernels alone (8 heads of 16, fp32 storage so that the check against a float64 softmax is tight):
  * qkv [B*S][384]; forward (dao == NULL): P [B][8][S][S] (post-softmax, pre-dropout) and ao [B*S][128] are written; backward (dao [B*S][128]
  * given): reads qkv, P, dao and writes dqkv [B*S][384].  variant 0 = one lane per query row (any S <= 64), 1 = the S <= 32 kernels the
- * engine runs (two lanes per query row).  drop_p / seed: the attention-probability dropout (mask = hash(seed, element index)). */
+ * engine runs (two lanes per query row), 2 = its kernels for 32 < S <= 64 (four waves per head, any S <= 64).  drop_p / seed: the attention-probability dropout (mask = hash(seed, element index)). */
 int hulc_k_attention(int32_t variant, const float* qkv, float* P, float* ao, const float* dao, float* dqkv, int32_t B, int32_t S,
                      float drop_p, uint64_t seed, void* hip_stream);
 

@@ -194,7 +194,7 @@ def test_gemm_glds_matches_fp64(M, N, K):
     assert (c - c_old).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("variant,S", [(0, 5), (0, 32), (0, 47), (1, 1), (1, 5), (1, 8), (1, 16), (1, 17), (1, 20), (1, 32)])
+@pytest.mark.parametrize("variant,S", [(0, 5), (0, 32), (0, 47), (1, 1), (1, 5), (1, 8), (1, 16), (1, 17), (1, 20), (1, 32), (2, 33), (2, 47), (2, 64), (2, 9)])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
 def test_attention_kernels(variant, S, drop_p):
     """Forward and backward attention kernels (plan_recognition_net.py:94-117: nn.TransformerEncoderLayer, 8 heads of 16) against float64;
