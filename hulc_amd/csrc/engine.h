@@ -1003,6 +1003,10 @@ struct Engine : IEngine {
             { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
             { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
             { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
+            static const bool clip_wide = getenv("HULC_CLIP_WIDE") ? atoi(getenv("HULC_CLIP_WIDE")) != 0 : true;
+            if (clip_wide && GOAL <= 32 && !std::is_same<T, float>::value)
+                hipLaunchKernelGGL(clip_loss_wide_kernel, dim3(1), dim3(1024), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale, lscale());
+            else
             hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale, lscale());
         }
         STAGE("clip_fwd");

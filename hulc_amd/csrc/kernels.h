@@ -1655,6 +1655,77 @@ __global__ void __launch_bounds__(64) clip_loss_kernel(const float* __restrict__
         }
     }
 }
+// The same with 1024 threads (one workgroup): the 64-thread kernel walks n x n x D products per thread in series (83 us at n = 32 rows); here a
+// thread owns one (i, j) logit, then one (row, d) gradient element — every loop is n or D long.  Deterministic (fixed-order tree reductions).
+__global__ void __launch_bounds__(1024) clip_loss_wide_kernel(const float* __restrict__ img, const float* __restrict__ txt, int n, int D,
+                                                              const float* __restrict__ logit_scale, float w, float* __restrict__ loss_out,
+                                                              float* __restrict__ dimg, float* __restrict__ dtxt, float* __restrict__ dlogit_scale,
+                                                              const float* __restrict__ lscale = nullptr) {
+    if (lscale) w *= lscale[0];
+    __shared__ float in_[64][33], tn_[64][33], ni[64], nt[64], L[64][65], dL[64][65], rowlse[64], collse[64], red[2][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float s = __expf(logit_scale[0]);
+    // ---- norms: thread (row r, half h): h = 0 img, 1 txt
+    if (t < 2 * n) {
+        const int r = t >> 1, h = t & 1;
+        const float* src = (h ? txt : img) + (long long)r * D;
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a += src[d] * src[d];
+        a = sqrtf(a);
+        (h ? nt : ni)[r] = a;
+        for (int d = 0; d < D; ++d) (h ? tn_ : in_)[r][d] = src[d] / a;
+    }
+    __syncthreads();
+    for (int p = t; p < n * n; p += 1024) {
+        const int i = p / n, j = p - i * n;
+        float c = 0.f;
+        for (int d = 0; d < D; ++d) c += in_[i][d] * tn_[j][d];
+        L[i][j] = s * c;
+    }
+    __syncthreads();
+    if (t < 2 * n) {                                  // t < n: row i = t; else column i = t - n
+        const bool col = t >= n;
+        const int i = col ? t - n : t;
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) m = fmaxf(m, col ? L[j][i] : L[i][j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += __expf((col ? L[j][i] : L[i][j]) - m);
+        (col ? collse : rowlse)[i] = m + __logf(se);
+    }
+    __syncthreads();
+    float part = 0.f, dsp = 0.f;
+    for (int p = t; p < n * n; p += 1024) {
+        const int i = p / n, j = p - i * n;
+        const float g = ((__expf(L[i][j] - rowlse[i]) - (i == j)) + (__expf(L[i][j] - collse[j]) - (i == j))) / (2.f * n);
+        dL[i][j] = g;
+        dsp += g * (L[i][j] / s);
+        if (i == j) part += (rowlse[i] - L[i][i]) + (collse[i] - L[i][i]);
+    }
+    part = wave_sum(part); dsp = wave_sum(dsp);
+    if (lane == 0) { red[0][wave] = part; red[1][wave] = dsp; }
+    __syncthreads();
+    if (t == 0) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < 16; ++k) { a += red[0][k]; b += red[1][k]; }
+        loss_out[0] = a / (2.f * n);
+        dlogit_scale[0] += w * b * s;
+    }
+    // ---- gradients: thread (tensor h, row i, column d); D == 32 -> the 32 d's of a row are one half-wave
+    for (int e = t; e < 2 * n * 32; e += 1024) {
+        const int h = e / (n * 32), r = (e >> 5) % n, d = e & 31;
+        float acc = 0.f;
+        if (d < D) {
+            if (h == 0) { for (int j = 0; j < n; ++j) acc += dL[r][j] * tn_[j][d]; }
+            else        { for (int j = 0; j < n; ++j) acc += dL[j][r] * in_[j][d]; }
+        }
+        acc *= s;
+        const float own = d < D ? (h ? tn_[r][d] : in_[r][d]) : 0.f;
+        float dotp = own * acc;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) dotp += __shfl_xor(dotp, o, 32);
+        if (d < D) (h ? dtxt : dimg)[(long long)r * D + d] = w * (acc - own * dotp) / (h ? nt[r] : ni[r]);
+    }
+}
 // gather rows by index list: dst[i][:] = src[rows[i]][:]  ; scatter-add reverse
 template <typename TS, typename TD>
 __global__ void gather_rows_kernel(const TS* __restrict__ src, long long lds_, const int* __restrict__ rows, int n, int C, TD* __restrict__ dst) {
