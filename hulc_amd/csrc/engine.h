@@ -922,11 +922,14 @@ struct Engine : IEngine {
             if (alloc_failed) { hulc_set_error("hulc_forward_loss_pair: workspace allocation failed"); return 1; }
         }
         const size_t na = sizeof(float) * Bv * S * 7, nr = sizeof(float) * Bv * S * 15;
-        HIP_CHECK(hipMemcpyAsync(act_j, vb->actions, na, hipMemcpyDefault, st)); HIP_CHECK(hipMemcpyAsync((char*)act_j + na, lb->actions, na, hipMemcpyDefault, st));
-        HIP_CHECK(hipMemcpyAsync(ro_j, vb->robot_obs, nr, hipMemcpyDefault, st)); HIP_CHECK(hipMemcpyAsync((char*)ro_j + nr, lb->robot_obs, nr, hipMemcpyDefault, st));
+        MultiCopy mc{}; int nseg = 0;          // the joins of the two modalities' actions / robot_obs (device memory by the hulc_batch contract): one launch
+        auto seg = [&](void* dst, const void* src, size_t bytes) { mc.dst[nseg] = (unsigned*)dst; mc.src[nseg] = (const unsigned*)src; mc.words[nseg] = (int)(bytes / 4); ++nseg; };
+        seg(act_j, vb->actions, na); seg((char*)act_j + na, lb->actions, na);
+        seg(ro_j, vb->robot_obs, nr); seg((char*)ro_j + nr, lb->robot_obs, nr);
         hulc_batch jb = *vb;
         jb.B = B; jb.actions = act_j; jb.robot_obs = ro_j; jb.lang = lb->lang; jb.is_lang = 0;
-        if (vb->plan_idx) {
+        hipLaunchKernelGGL(multi_copy_kernel, dim3(16, nseg), dim3(256), 0, st, mc);
+        if (vb->plan_idx) {                    // injected draws (parity tests) may live in host memory: plain copies
             HIP_CHECK(hipMemcpyAsync(pidx_j, vb->plan_idx, sizeof(int) * Bv * NCAT, hipMemcpyDefault, st));
             HIP_CHECK(hipMemcpyAsync(pidx_j + Bv * NCAT, lb->plan_idx, sizeof(int) * Bv * NCAT, hipMemcpyDefault, st));
             jb.plan_idx = pidx_j;

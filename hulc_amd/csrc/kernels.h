@@ -1558,14 +1558,25 @@ __global__ void __launch_bounds__(256) sum_reduce_kernel(const float* __restrict
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// up to 8 small device-to-device copies in ONE launch (the paired pass joins the two modalities' actions / robot_obs / injected draws: six
+// hipMemcpyAsync of a few KB cost ~5 us each on the engine's stream); 4-byte words, blockIdx.y = segment
+struct MultiCopy { const unsigned* src[8]; unsigned* dst[8]; int words[8]; };
+__global__ void multi_copy_kernel(MultiCopy mc) {
+    const int seg = blockIdx.y;
+    const unsigned* __restrict__ s = mc.src[seg];
+    unsigned* __restrict__ d = mc.dst[seg];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mc.words[seg]; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
 // paired pass: the per-row loss partials [S*B][8] (time-major rows t*B + b) summed separately for the windows b < Bv and b >= Bv
+// (a thread takes whole rows: one modulo and two 16-byte loads per row — the element-wise version paid a runtime division per float, 18 us)
 __global__ void __launch_bounds__(256) sum_rows_pair_kernel(const float* __restrict__ x, int rows, int B, int Bv, float scale, float* __restrict__ out_v,
                                                             float* __restrict__ out_l) {
     __shared__ float red[2][256];
     float sv = 0.f, sl = 0.f;
-    for (int i = threadIdx.x; i < rows * 8; i += 256) {
-        const float v = x[i];
-        if ((i >> 3) % B < Bv) sv += v; else sl += v;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(x + (long long)r * 8), b = *reinterpret_cast<const float4*>(x + (long long)r * 8 + 4);
+        const float v = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+        if (r % B < Bv) sv += v; else sl += v;
     }
     red[0][threadIdx.x] = sv; red[1][threadIdx.x] = sl;
     __syncthreads();
