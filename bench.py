@@ -179,9 +179,12 @@ def main():
     eng = StepEngine(dims, B if paired else Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
     # N > 1: the library's own RCCL communicator (hulc_backward_allreduce: reverse-forward buckets overlapped with the backward); the
-    # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  Falls back to
-    # torch.distributed all-reduces if RCCL cannot be initialised in this process (reported in the JSON line).
+    # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  HULC_DP_COMM=capi (the default)
+    # makes a communicator that cannot be brought up an ERROR on every rank — a run that quietly measured torch.distributed all-reduces
+    # would be Lightning-DDP-shaped, not the product; HULC_DP_COMM=torch / auto select that path explicitly.
     lib_comm = parallel.setup_comm(eng, args.bucket) if world > 1 else False
+    if world > 1 and not lib_comm and parallel.comm_mode() == "capi":
+        raise SystemExit("bench.py: the library RCCL communicator is not up and HULC_DP_COMM=capi — refusing to time the torch.distributed fallback")
     mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest))]
     if args.lang:
         mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest)))
@@ -210,6 +213,58 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1, before anything is timed: the collective checks ITSELF on this job's real gradients — one step's library-RCCL bucketed SUM
+    # (hulc_backward_allreduce) against the same local gradients through ONE flat torch.distributed all-reduce.  The first multi-GPU box
+    # this code meets is the driver's; the numbers it reports carry their own evidence (JSON: allreduce.selfcheck).
+    selfcheck = None
+    if lib_comm:
+        import torch.distributed as dist
+        eng.zero_grads()
+        if paired:
+            eng.forward_loss_pair(mods[0][1], mods[1][1], 0.5, 3.0, step=0, sync_losses=False)
+        else:
+            for k, (name, mb) in enumerate(mods):
+                eng.forward_loss(mb, name == "lang", 1.0 / nmod, 3.0, step=0, sync_losses=False)
+                if k < nmod - 1:
+                    eng.backward()
+        eng.backward()
+        torch.cuda.synchronize()
+        g_loc = eng.flat_grads.clone()
+        g_ref = g_loc.clone()
+        dist.all_reduce(g_ref, op=dist.ReduceOp.SUM)
+        eng.allreduce_grads(args.bucket)                  # the library communicator on the same local gradients (whole-buffer form)
+        torch.cuda.synchronize()
+        nref = g_ref.double().norm().item()
+        rel_flat = (eng.flat_grads.double() - g_ref.double()).norm().item() / max(nref, 1e-30)
+        # and the bucketed, overlapped form on a fresh backward of the same step.  The categorical plan sample of the first pass is injected
+        # (16-bit engines reorder atomic sums run to run: a logit moving by an ulp could flip a draw and change the gradient by percents);
+        # dropout masks and the mcil eps are counter-based on (seed, step) and repeat by themselves
+        mods2 = mods
+        if not mcil and (paired or nmod == 1):
+            pidx = torch.from_numpy(eng.plan_idx(B if paired else Bmod)).to(dev)
+            mods2 = [(name, dict(mb, plan_idx=pidx[k * Bmod:(k + 1) * Bmod].contiguous())) for k, (name, mb) in enumerate(mods)]
+        eng.zero_grads()
+        if paired:
+            eng.forward_loss_pair(mods2[0][1], mods2[1][1], 0.5, 3.0, step=0, sync_losses=False)
+        else:
+            for k, (name, mb) in enumerate(mods2):
+                eng.forward_loss(mb, name == "lang", 1.0 / nmod, 3.0, step=0, sync_losses=False)
+                if k < nmod - 1:
+                    eng.backward()
+        eng.backward_allreduce(args.bucket)
+        torch.cuda.synchronize()
+        rel_bkt = (eng.flat_grads.double() - g_ref.double()).norm().item() / max(nref, 1e-30)
+        differs = (g_loc.double() - g_ref.double()).norm().item() / max(nref, 1e-30)
+        tol = 2e-2 if args.bucket != "fp32" else (1e-6 if args.dtype == "fp32" else 5e-3)
+        if mods2 is mods and not mcil:
+            tol = 0.2                                     # one pass per modality: the first modality's draw is not injected
+        selfcheck = dict(rel_l2_whole_buffer=rel_flat, rel_l2_bucketed_overlapped=rel_bkt, local_vs_sum=differs, tolerance=tol,
+                         reference="one flat torch.distributed SUM all-reduce of the same local gradients")
+        ok = torch.tensor([1 if (rel_flat <= (2e-2 if args.bucket != "fp32" else 1e-6) and rel_bkt <= tol and (world == 1 or differs > 1e-4)) else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            raise SystemExit(f"bench.py rank {rank}: library RCCL all-reduce self-check FAILED: {selfcheck}")
 
     # pre-roll (untimed, before the W warm-up steps): a GPU that has just been idle needs a few hundred ms of load before its clocks
     # settle — the first bench process on a fresh box measured 4.89 ms/step against 4.61 for every later one with warm-up alone
@@ -295,8 +350,10 @@ def main():
             "model_flops_per_window": None if mcil else FLOP_PER_WINDOW_S32 * S / 32.0,      # SURVEY §8(d) counts the headline model only
             "step_tflops": None if mcil else round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
             "roofline": rl,
-            "allreduce": None if world == 1 else ({"path": "libhulc_hip RCCL (hulc_backward_allreduce)", "bucket_dtype": args.bucket, "buckets": eng.comm_buckets(),
-                                                  **eng.comm_stats()} if lib_comm else {"path": "torch.distributed nccl (fallback)", "bucket_dtype": "fp32"}),
+            "allreduce": None if world == 1 else ({"path": "libhulc_hip RCCL (hulc_backward_allreduce)", "rccl_ranks": world, "bucket_dtype": args.bucket, "buckets": eng.comm_buckets(),
+                                                  "bucket_bytes": [(hi - lo) * (4 if args.bucket == "fp32" else 2) for lo, hi in eng.comm_buckets()],
+                                                  "selfcheck": selfcheck, **eng.comm_stats()} if lib_comm else
+                                                 {"path": "torch.distributed nccl (HULC_DP_COMM=%s)" % parallel.comm_mode(), "bucket_dtype": "fp32"}),
             "kernel_classes": kernel_classes,
             # fp16: GradScaler state after the timed steps; skipped_in_timed_region counts optimizer steps the scaler skipped (inf/nan) inside it
             "loss_scaler": None if sc0 is None else dict(eng.scaler_state(), skipped_in_timed_region=eng.scaler_state()["skipped_steps"] - sc0["skipped_steps"]),

@@ -146,6 +146,10 @@ int hulc_comm_unique_id(void* out, int64_t cap) {
     memcpy(out, &id, 128);
     return 0;
 }
+int hulc_comm_prepare(hulc_ctx* ctx) {
+    if (!ctx) { hulc_set_error("hulc_comm_prepare: null context"); return 1; }
+    return ctx->e->comm_prepare();
+}
 int hulc_comm_init(hulc_ctx* ctx, const void* unique_id, int32_t rank, int32_t world) {
     if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world) { hulc_set_error("hulc_comm_init: bad argument"); return 1; }
     return ctx->e->comm_init(unique_id, rank, world);
@@ -173,13 +177,13 @@ int hulc_scaler_enable(hulc_ctx* ctx, float init_scale, float growth_factor, flo
     if (!ctx) { hulc_set_error("hulc_scaler_enable: null context"); return 1; }
     return ctx->e->scaler_enable(init_scale, growth_factor, backoff_factor, growth_interval);
 }
-int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf) {
+int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf, int64_t* taken_steps) {
     if (!ctx) { hulc_set_error("hulc_scaler_get: null context"); return 1; }
-    return ctx->e->scaler_get(scale, growth_tracker, skipped_steps, last_found_inf);
+    return ctx->e->scaler_get(scale, growth_tracker, skipped_steps, last_found_inf, taken_steps);
 }
-int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker) {
+int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker, int64_t taken_steps) {
     if (!ctx) { hulc_set_error("hulc_scaler_set: null context"); return 1; }
-    return ctx->e->scaler_set(scale, growth_tracker);
+    return ctx->e->scaler_set(scale, growth_tracker, taken_steps);
 }
 int hulc_set_kl_beta(hulc_ctx* ctx, float b) { ctx->e->set_kl_beta(b); return 0; }
 int hulc_set_dropout(hulc_ctx* ctx, float p) {

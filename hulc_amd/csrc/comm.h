@@ -55,12 +55,19 @@ struct GradComm {
     void* stage = nullptr; int64_t stage_elems = 0;            // bf16 staging buffer (bf16 bucket mode)
     long long n_collectives = 0; double bytes_reduced = 0;     // statistics (tests / bench JSON)
 
-    int init(const void* unique_id, int rank_, int world_) {
+    // everything that can fail on ONE rank only (RCCL not loadable, no stream): done before any rank enters the blocking ncclCommInitRank, so
+    // the host can agree on the outcome first (hulc_comm_prepare -> all ranks vote -> hulc_comm_init) instead of deadlocking the healthy ranks
+    int prepare() {
         if (!load_api()) return 1;
-        rank = rank_; world = world_;
+        if (cs) return 0;
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);             // hi = greatest priority (numerically lowest)
-        if (hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi) != hipSuccess) { hulc_set_error("hulc_comm_init: stream creation failed"); return 1; }
+        if (hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi) != hipSuccess) { cs = nullptr; hulc_set_error("hulc_comm_prepare: stream creation failed"); return 1; }
+        return 0;
+    }
+    int init(const void* unique_id, int rank_, int world_) {
+        if (prepare()) return 1;
+        rank = rank_; world = world_;
         UniqueId id; memcpy(&id, unique_id, sizeof(id));
         const int rc = api().init(&comm, world, id, rank);
         if (rc != 0) { hulc_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, err(rc)); comm = nullptr; return 1; }

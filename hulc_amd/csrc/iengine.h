@@ -13,7 +13,7 @@
 void hulc_set_error(const char* fmt, ...);
 
 struct IEngine {
-    virtual ~IEngine() { delete comm; }
+    virtual ~IEngine() { delete comm; delete comm_pending; }
     virtual int bind(float* p, float* g, float* m, float* v, int64_t numel, int n, const char* const* names, const int64_t* offs,
                      const int64_t* numels) = 0;
     virtual int prepare_weights(bool shadow_fresh = false) = 0;
@@ -29,21 +29,30 @@ struct IEngine {
     virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
     virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
     virtual int scaler_enable(float init_scale, float growth, float backoff, int interval) = 0;
-    virtual int scaler_get(float* scale, int32_t* tracker, int64_t* skipped, int32_t* last_inf) = 0;
-    virtual int scaler_set(float scale, int32_t tracker) = 0;
+    virtual int scaler_get(float* scale, int32_t* tracker, int64_t* skipped, int32_t* last_inf, int64_t* taken) = 0;
+    virtual int scaler_set(float scale, int32_t tracker, int64_t taken) = 0;
     // ---- data-parallel gradient all-reduce (comm.h): whole buffer after a finished backward, or bucketed inside the backward
     virtual int allreduce_grads(int bucket_dtype) = 0;
     virtual int backward_allreduce(int bucket_dtype) = 0;
     virtual int comm_buckets(int64_t* lo, int64_t* hi, int cap) = 0;        // the bucket ranges in issue order; returns their number
     GradComm* comm = nullptr;
+    GradComm* comm_pending = nullptr;       // prepared (RCCL resolved, private stream) but not yet initialised
+    int comm_prepare() {
+        if (comm || comm_pending) return 0;
+        GradComm* c = new GradComm();
+        if (c->prepare()) { delete c; return 1; }
+        comm_pending = c;
+        return 0;
+    }
     int comm_init(const void* unique_id, int rank, int world) {
         if (comm) { hulc_set_error("hulc_comm_init: this context already has a communicator"); return 1; }
-        GradComm* c = new GradComm();
+        if (comm_prepare()) return 1;
+        GradComm* c = comm_pending; comm_pending = nullptr;
         if (c->init(unique_id, rank, world)) { delete c; return 1; }
         comm = c;
         return 0;
     }
-    int comm_destroy() { delete comm; comm = nullptr; return 0; }
+    int comm_destroy() { delete comm; comm = nullptr; delete comm_pending; comm_pending = nullptr; return 0; }
     virtual int get_tensor(const char* name, float* out, int64_t cap, int64_t* n) = 0;
     virtual int get_plan_idx(int32_t* out, int64_t cap) = 0;
     virtual int64_t workspace_bytes() const = 0;

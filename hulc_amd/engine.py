@@ -276,6 +276,10 @@ class StepEngine:
         L.check(L.load().hulc_comm_unique_id(buf, 128))
         return buf.raw
 
+    def comm_prepare(self):
+        """Phase 1 of comm_init (RCCL resolved, private stream created): can fail on one rank alone, so agree on it before comm_init blocks."""
+        L.check(self.lib.hulc_comm_prepare(self.ctx))
+
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         L.check(self.lib.hulc_comm_init(self.ctx, buf, int(rank), int(world)))
@@ -313,13 +317,14 @@ class StepEngine:
         L.check(self.lib.hulc_scaler_enable(self.ctx, float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval)))
 
     def scaler_state(self) -> Dict:
-        """{"scale", "growth_tracker", "skipped_steps", "last_found_inf"} — synchronises the stream.  flat_grads holds gradients x scale."""
-        sc, tr, sk, fi = C.c_float(), C.c_int32(), C.c_int64(), C.c_int32()
-        L.check(self.lib.hulc_scaler_get(self.ctx, C.byref(sc), C.byref(tr), C.byref(sk), C.byref(fi)))
-        return dict(scale=sc.value, growth_tracker=tr.value, skipped_steps=sk.value, last_found_inf=fi.value)
+        """{"scale", "growth_tracker", "skipped_steps", "last_found_inf", "taken_steps"} — synchronises the stream.  flat_grads holds gradients x scale."""
+        sc, tr, sk, fi, tk = C.c_float(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64()
+        L.check(self.lib.hulc_scaler_get(self.ctx, C.byref(sc), C.byref(tr), C.byref(sk), C.byref(fi), C.byref(tk)))
+        return dict(scale=sc.value, growth_tracker=tr.value, skipped_steps=sk.value, last_found_inf=fi.value, taken_steps=tk.value)
 
-    def scaler_load(self, scale: float, growth_tracker: int = 0):
-        L.check(self.lib.hulc_scaler_set(self.ctx, float(scale), int(growth_tracker)))
+    def scaler_load(self, scale: float, growth_tracker: int = 0, taken_steps: int = -1):
+        """taken_steps >= 0 also restores the device-side count of optimizer steps taken (Adam's bias corrections in fp16 mode)."""
+        L.check(self.lib.hulc_scaler_set(self.ctx, float(scale), int(growth_tracker), int(taken_steps)))
 
     def get_tensor(self, name: str, n: int) -> np.ndarray:
         out = np.zeros(n, np.float32)

@@ -65,7 +65,10 @@ class FusedAdam:
                   param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
         if e.dtype == "fp16":       # Lightning keeps GradScaler.state_dict() next to the optimizer states ("native_amp_scaling_state")
             st = e.scaler_state()
-            sd["grad_scaler"] = dict(scale=st["scale"], _growth_tracker=st["growth_tracker"])
+            # torch's optimizer `step` only counts the steps GradScaler let through; the fp16 Adam kernel takes its bias corrections from that
+            # (device-side) count, so it is what a checkpoint must carry — `calls` keeps the number of optimizer.step() calls made
+            sd["step"] = int(st["taken_steps"])
+            sd["grad_scaler"] = dict(scale=st["scale"], _growth_tracker=st["growth_tracker"], skipped_steps=int(st["skipped_steps"]), calls=int(e.adam_t))
         return sd
 
     def load_state_dict(self, sd):
@@ -73,8 +76,14 @@ class FusedAdam:
         e.adam_t = int(sd["step"])
         e.adam_m.copy_(sd["exp_avg"])
         e.adam_v.copy_(sd["exp_avg_sq"])
-        if e.dtype == "fp16" and sd.get("grad_scaler"):
-            e.scaler_load(float(sd["grad_scaler"]["scale"]), int(sd["grad_scaler"].get("_growth_tracker", 0)))
+        if e.dtype == "fp16":       # the taken-step count travels as `step` (torch semantics); without it Adam would restart its bias corrections at t = 1 on warm moments
+            gs = sd.get("grad_scaler") or {}
+            e.adam_t = int(gs.get("calls", sd["step"]))
+            if gs:
+                e.scaler_load(float(gs["scale"]), int(gs.get("_growth_tracker", 0)), int(sd["step"]))
+            else:                   # a checkpoint without scaler state (e.g. saved by an fp32 / bf16 run): keep the current scale, restore the count
+                st = e.scaler_state()
+                e.scaler_load(float(st["scale"]), int(st["growth_tracker"]), int(sd["step"]))
 
 
 class ConstantSchedule:

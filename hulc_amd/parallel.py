@@ -95,34 +95,78 @@ def bucket_schedule(layout, numel: int):
     return out
 
 
+def comm_mode() -> str:
+    """HULC_DP_COMM: `capi` (default) = the library's own RCCL communicator, and failing to bring it up is an ERROR on every rank;
+    `auto` = try it, fall back (loudly) to torch.distributed all-reduces; `torch` = torch.distributed only."""
+    m = os.environ.get("HULC_DP_COMM", "capi")
+    if m not in ("capi", "auto", "torch"):
+        raise ValueError(f"HULC_DP_COMM={m!r}: expected capi | auto | torch")
+    return m
+
+
+def _vote(ok: bool, device) -> bool:
+    """True iff EVERY rank reports ok (MIN all-reduce): all ranks leave with the same answer."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def setup_comm(engine, bucket_dtype: str = "fp32") -> bool:
     """Create the library's own RCCL communicator for `engine` (world > 1, GPU): rank 0's ncclUniqueId travels over the already
-    initialised torch.distributed group, everything after that is RCCL inside libhulc_hip (hulc_backward_allreduce).  Returns False —
-    and leaves the torch.distributed path in place — when RCCL cannot be initialised (the reason is logged once)."""
-    if world_size() == 1 or not torch.cuda.is_available() or os.environ.get("HULC_DP_COMM", "capi") != "capi":
+    initialised torch.distributed group, everything after that is RCCL inside libhulc_hip (hulc_backward_allreduce).
+
+    Three phases, each closed by a vote of all ranks, so that a failure on one rank can neither split the job between two collective
+    paths nor leave the healthy ranks blocked in ncclCommInitRank: (1) hulc_comm_prepare — RCCL resolved, private stream
+    created: the rank-local failure modes; (2) rank 0 draws the unique id and broadcasts it; (3) hulc_comm_init.  Returns True when the
+    library path is up.  Otherwise: HULC_DP_COMM=capi (default) raises on every rank; =auto prints the reason once and returns False
+    (gradients then go through torch.distributed); =torch never tries."""
+    mode = comm_mode()
+    if world_size() == 1 or not torch.cuda.is_available() or mode == "torch":
         return False
+    dev = engine.device
     err = None
+
+    def fail(phase):
+        if getattr(engine, "has_comm", False):
+            engine.comm_destroy()
+        msg = f"library RCCL communicator unavailable ({phase}: {err if err is not None else 'failed on another rank'})"
+        if mode == "capi":
+            raise RuntimeError(f"[hulc_amd] {msg}; set HULC_DP_COMM=auto (fall back to torch.distributed) or HULC_DP_COMM=torch to run without it")
+        if dist.get_rank() == 0:
+            print(f"[hulc_amd] {msg}; gradients go through torch.distributed", flush=True)
+        return False
+
     try:
-        box = [engine.comm_unique_id() if dist.get_rank() == 0 else None]
-    except Exception as e:                 # pragma: no cover  (multi-GPU only)
-        box, err = [None], e
-    dist.broadcast_object_list(box, src=0)
-    if box[0] is not None:
+        engine.comm_prepare()
+    except Exception as e:                 # pragma: no cover  (needs a box without RCCL)
+        err = e
+    if not _vote(err is None, dev):
+        return fail("hulc_comm_prepare")
+    box = [None]
+    if dist.get_rank() == 0:
         try:
-            engine.comm_init(box[0], dist.get_rank(), dist.get_world_size())
+            box = [engine.comm_unique_id()]
         except Exception as e:             # pragma: no cover
             err = e
-    # every rank must take the SAME path (a rank left on torch.distributed would wait forever for the others' collective): agree on the outcome
-    ok = torch.tensor([0 if (err is not None or box[0] is None) else 1], dtype=torch.int32, device=engine.device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        engine.comm_bucket_dtype = bucket_dtype
-        return True
-    if getattr(engine, "has_comm", False):
-        engine.comm_destroy()
-    if dist.get_rank() == 0:
-        print(f"[hulc_amd] library RCCL communicator unavailable ({err if err is not None else 'failed on another rank'}); gradients go through torch.distributed", flush=True)
-    return False
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return fail("ncclGetUniqueId on rank 0")
+    try:
+        engine.comm_init(box[0], dist.get_rank(), dist.get_world_size())
+    except Exception as e:
+        err = e
+    if not _vote(err is None, dev):
+        return fail("hulc_comm_init")
+    engine.comm_bucket_dtype = bucket_dtype
+    check_bucket_plan(engine.comm_buckets(), engine.numel)
+    return True
+
+
+def check_bucket_plan(buckets, numel: int) -> None:
+    """The buckets of hulc_backward_allreduce must partition [0, numel): disjoint, gap-free, every element reduced exactly once."""
+    t = sorted(buckets)
+    if not t or t[0][0] != 0 or t[-1][1] != numel or any(t[i][1] != t[i + 1][0] for i in range(len(t) - 1)) or any(hi < lo for lo, hi in t):
+        raise RuntimeError(f"gradient buckets {buckets} do not partition [0, {numel})")
 
 
 def backward_overlapped(engine) -> None:

@@ -136,6 +136,10 @@ int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps,
  *   HULC_DTYPE_F16 for an fp16 one): the gradients cross the wire in 16 bits (half the bytes: xGMI rings are per-link bound), are summed
  *   by RCCL in that type and widened back.  hulc_comm_buckets returns the bucket ranges (element offsets) in issue order. */
 int hulc_comm_unique_id(void* out_host /*128 bytes*/, int64_t cap);
+/* Optional first phase of hulc_comm_init: resolves RCCL and creates the private stream — everything that can fail on one rank alone.  A
+ * host that calls it on every rank and agrees on the result BEFORE any rank calls hulc_comm_init (which blocks in ncclCommInitRank until all
+ * ranks arrive) cannot be deadlocked by a rank-local failure. */
+int hulc_comm_prepare(hulc_ctx* ctx);
 int hulc_comm_init(hulc_ctx* ctx, const void* unique_id_host, int32_t rank, int32_t world);
 int hulc_comm_destroy(hulc_ctx* ctx);
 int hulc_comm_buckets(hulc_ctx* ctx, int64_t* lo, int64_t* hi, int32_t cap);      /* returns the number of buckets, < 0 on error */
@@ -153,8 +157,12 @@ int hulc_backward_allreduce(hulc_ctx* ctx, int32_t bucket_dtype);
  * An F16 context starts with GradScaler's defaults (65536, 2, 0.5, 2000); init_scale <= 0 turns scaling off; F32 / BF16 contexts
  * start with it off.  hulc_scaler_get synchronises (checkpointing: Lightning stores the scaler state next to the optimizer's). */
 int hulc_scaler_enable(hulc_ctx* ctx, float init_scale, float growth_factor, float backoff_factor, int32_t growth_interval);
-int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf /* each optional */);
-int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker);
+int hulc_scaler_get(hulc_ctx* ctx, float* scale, int32_t* growth_tracker, int64_t* skipped_steps, int32_t* last_found_inf,
+                    int64_t* taken_steps /* each optional */);
+/* taken_steps = optimizer steps actually taken (not skipped): Adam's bias corrections run on this device-side count in fp16 mode, exactly as
+ * torch's optimizer `step` state only advances when GradScaler.step() lets optimizer.step() run.  It is part of a checkpoint: resuming with
+ * warm moments and a zero count would shrink the first thousands of updates.  taken_steps < 0 leaves the count unchanged. */
+int hulc_scaler_set(hulc_ctx* ctx, float scale, int32_t growth_tracker, int64_t taken_steps);
 
 /* ---- Validation forward: one modality of Hulc.validation_step (hulc/models/hulc.py:770-797) = lmp_val
  * (:301-388): plan proposal and plan recognition each sample a plan (distributions.py:37-41), the decoder is run with both

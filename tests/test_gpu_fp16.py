@@ -62,7 +62,7 @@ def test_fp16_step_close_to_reference(name, scale):
     p_before = eng.flat_params.clone()
     eng.adam_step()
     st = eng.scaler_state()
-    assert st == dict(scale=scale, growth_tracker=1, skipped_steps=0, last_found_inf=0), st
+    assert st == dict(scale=scale, growth_tracker=1, skipped_steps=0, last_found_inf=0, taken_steps=1), st
     assert not torch.equal(p_before, eng.flat_params)
     pv = eng.views(eng.flat_params)
     n = "action_decoder.rnn.bias_hh_l1"
@@ -160,7 +160,7 @@ def test_module_precision_16_selects_fp16():
     assert m.precision == "fp16" and m.engine.dtype == "fp16"
     assert m.engine.scaler_state()["scale"] == 65536.0
     sd = m.configure_optimizers()["optimizer"].state_dict()
-    assert sd["grad_scaler"] == dict(scale=65536.0, _growth_tracker=0)
+    assert sd["grad_scaler"] == dict(scale=65536.0, _growth_tracker=0, skipped_steps=0, calls=0) and sd["step"] == 0
     m.engine.close()
     m2 = Hulc(precision="bf16", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False)
     assert m2.engine.dtype == "bf16" and "grad_scaler" not in m2.configure_optimizers()["optimizer"].state_dict()
@@ -219,3 +219,61 @@ def test_library_rccl_allreduce_world1_and_bucket_plan():
             with pytest.raises(RuntimeError):
                 eng.allreduce_grads("bf16")                                                        # no 16-bit kernels in the fp32 unit
         eng.close()
+
+
+def test_fp16_checkpoint_resume_continues_the_trajectory():
+    """in fp16 mode Adam's bias corrections run on the device-side count of TAKEN steps; a checkpoint must carry it.  An
+    uninterrupted run of 6 optimizer steps (one of them skipped by an injected overflow) equals: 3 steps -> state_dict -> a NEW module
+    -> load_state_dict -> 3 more steps.  Without the restored count the resumed run would restart at t = 1 on warm moments and its
+    first update would be ~3x too small (bias correction 1 - 0.9 = 0.1 against 1 - 0.9^3 = 0.27)."""
+    from hulc_amd.hulc import Hulc
+    from hulc_amd.utils import synthetic
+
+    from test_gpu_parity import to_dev
+
+    def make():
+        m = Hulc(precision=16, max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=False, seed=11)
+        m.engine.set_dropout(0.0)
+        m.engine.scaler_enable(init_scale=1024.0)        # well inside fp16's range for this model: the only skipped step is the injected one
+        return m, m.configure_optimizers()["optimizer"]
+
+    def steps(m, opt, lo, hi, overflow_at=-1):
+        eng = m.engine
+        for i in range(lo, hi):
+            opt.zero_grad()
+            for sc, mb in synthetic.make_batch(2, 0, 4, seed=100 + i).items():
+                eng.forward_loss(to_dev(mb), "lang" in sc, 1.0, 3.0, step=i)        # injected plan draw: both runs see the same samples
+                eng.backward()
+            if i == overflow_at:
+                eng.flat_grads[5] = float("inf")
+            m._grads_reduced = True       # world = 1: nothing to reduce
+            opt.step()
+
+    m, opt = make()
+    p0 = m.engine.flat_params.clone()
+    steps(m, opt, 0, 6, overflow_at=1)
+    ref = m.engine.flat_params.clone()
+    st_ref = m.engine.scaler_state()
+    assert st_ref["taken_steps"] == 5 and st_ref["skipped_steps"] == 1
+    m.engine.close()
+
+    m1, opt1 = make()
+    assert torch.equal(m1.engine.flat_params, p0)
+    steps(m1, opt1, 0, 3, overflow_at=1)
+    sd_opt = opt1.state_dict()
+    assert sd_opt["step"] == 2 and sd_opt["grad_scaler"]["calls"] == 3 and sd_opt["grad_scaler"]["skipped_steps"] == 1
+    params = m1.engine.flat_params.clone()
+    m1.engine.close()
+
+    m2, opt2 = make()
+    m2.engine.flat_params.copy_(params)
+    m2.engine.prepare_weights()
+    opt2.load_state_dict(sd_opt)
+    st = m2.engine.scaler_state()
+    assert st["taken_steps"] == 2 and st["scale"] == sd_opt["grad_scaler"]["scale"]
+    steps(m2, opt2, 3, 6)
+    got = m2.engine.flat_params
+    rel = ((got - ref).double().norm() / (ref - p0).double().norm()).item()
+    assert rel < 2e-3, rel            # same trajectory (fp16 atomics reorder sums; a restarted bias correction would be off by > 0.3)
+    assert m2.engine.scaler_state()["taken_steps"] == 5
+    m2.engine.close()
