@@ -120,6 +120,9 @@ struct Engine : IEngine {
     T* barena = nullptr; int64_t barena_n = 0, barena_used = 0; bool barena_overflow = false;
     std::vector<std::function<void()>> deferred;              // weight-gradient work queued until the recurrent chains of the backward are done
     static bool side_enabled() { static const bool on = getenv("HULC_SIDE") ? atoi(getenv("HULC_SIDE")) != 0 : true; return on; }
+    // experiment knob (same-box A/B): bit 0 = the decoder's big weight-gradient GEMMs on the side stream, bit 1 = every other lin_wgrad on the side
+    // stream, bit 2 = those are batched per stage (one event pair per flush instead of one per launch)
+    static int side_mode() { static const int m = getenv("HULC_SIDE_MODE") ? atoi(getenv("HULC_SIDE_MODE")) : 7; return m; }
     hipEvent_t side_event() {
         if (sev_used == sev.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); sev.push_back(e); }
         return sev[sev_used++];
@@ -127,7 +130,7 @@ struct Engine : IEngine {
     // RAII: launches inside the scope go to the side stream, ordered after everything enqueued on the main stream so far
     struct Side {
         Engine* e; bool act; hipStream_t s0 = nullptr; T *a0 = nullptr, *b0 = nullptr; float* c0 = nullptr;
-        explicit Side(Engine* e_) : e(e_), act(e_->side_on && e_->sst && e_->st != e_->sst) {
+        explicit Side(Engine* e_, bool want = true) : e(e_), act(want && e_->side_on && e_->sst && e_->st != e_->sst) {
             if (!act) return;
             hipEvent_t ev = e->side_event(); hipEventRecord(ev, e->st); hipStreamWaitEvent(e->sst, ev, 0);
             s0 = e->st; a0 = e->tA; b0 = e->tB; c0 = e->cspart;
@@ -149,7 +152,13 @@ struct Engine : IEngine {
     }
     // weight-gradient work that must not run beside a recurrent chain: queued, flushed to the side stream once the chains are enqueued
     void defer(std::function<void()> f) { if (side_on) deferred.push_back(std::move(f)); else f(); }
-    void flush_deferred() { if (deferred.empty()) return; { Side sd(this); for (auto& f : deferred) f(); } deferred.clear(); }
+    void flush_deferred() {
+        if (deferred.empty()) return;
+        std::vector<std::function<void()>> work; work.swap(deferred);
+        in_flush = true;
+        { Side sd(this); for (auto& f : work) f(); }
+        in_flush = false;
+    }
     // main stream waits for the side stream (end of the non-encoder backward)
     void side_join() {
         flush_deferred();
@@ -522,8 +531,13 @@ struct Engine : IEngine {
         gemm(dense<T>(X, M, ldx), dense<T>(L.W, L.N, L.K), dense_out(ldo), ep, M, L.N, L.K);
     }
     // weight + bias grads of Y = X W^T: dW[N][K] += dY^T X ; db += colsum(dY).  dY [M][N] dense, X [M][K] (ldx)
+    bool in_flush = false;
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
-        Side sd(this);       // inside the non-encoder backward: on the side stream (no-op otherwise)
+        if (side_on && !in_flush && (side_mode() & 2) && (side_mode() & 4)) {     // queued: flushed to the side stream at the end of the stage
+            deferred.push_back([=] { lin_wgrad(dY, X, ldx, M, N, K, dW, lddw, db, db2); });
+            return;
+        }
+        Side sd(this, (side_mode() & 2) != 0 || in_flush);       // inside the non-encoder backward: on the side stream (no-op otherwise)
         if constexpr (std::is_same<T, h16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
                 hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
@@ -1784,7 +1798,7 @@ struct Engine : IEngine {
             rnn_bwd(dH1, H1, dZ1, whh1, B, S);
             { EpiP ep = epi(dH0, false); gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
             rnn_bwd(dH0, H0, dZ0, whh0, B, S);
-            defer([=] {
+            auto dec_wgrads = [=] {
                 const int mp = ldpad(SB);
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
@@ -1797,8 +1811,9 @@ struct Engine : IEngine {
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
                 { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
-            });
-            flush_deferred();
+            };
+            if (side_mode() & 1) { defer(dec_wgrads); flush_deferred(); }
+            else { flush_deferred(); dec_wgrads(); }
             // d emb (gripper half), scattered back to (B,S,128)[..., 64:128]
             { EpiP ep = epi(demb + (EMB - DE), true); ep.accumulate = 1;
               gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, DE, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, DE, HID); }
@@ -1823,6 +1838,7 @@ struct Engine : IEngine {
             }
         }
         STAGE("decoder_bwd");
+        flush_deferred();
         if (bucket_ready(0)) return 1;       // action_decoder.*, proj_vis_lang.*, logit_scale are final: their all-reduce starts under the rest of the backward
         // ---- straight-through + KL -> logits grads; plan proposal backward
         if (hulc) {
@@ -1831,6 +1847,7 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            flush_deferred();
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             // fc_state of plan recognition
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
@@ -1846,6 +1863,7 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            flush_deferred();
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             if (gru) bigru_bwd(dprl_t, B, S); else birnn_bwd(dprl_t, B, S);
         }
@@ -1880,6 +1898,7 @@ struct Engine : IEngine {
                 else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_ao, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
+                flush_deferred();        // this layer's four weight gradients: one hand-over to the side stream
             }
             // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
             hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dx, dy_f, (T*)nullptr, (long long)N * EMB, dp, site_seed(0));
@@ -1887,6 +1906,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dy_f, B, S, EMB, dpos);
         }
         STAGE("plan_recognition_bwd");
+        flush_deferred();
         if (bucket_ready(1) || bucket_ready(2)) return 1;   // plan_recognition.* final (plan_proposal too for the kinds that never touch it)
         // ---- goal encoder backward
         if (pair) {

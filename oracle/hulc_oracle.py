@@ -26,12 +26,58 @@ F32 = np.float32
 # ----------------------------------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------------------------------
+# ---- rounding-aware mode (tests of the bf16 / fp16 engines).  The half-precision engines keep fp32 master weights and fp32
+# accumulation but every GEMM / convolution OPERAND — weights, stored activations, stored gradients — is a 16-bit value.  With
+# set_operand_rounding("bf16" | "fp16") this oracle rounds exactly those operands (round-to-nearest-even, what v_cvt / the engine's pack2h do)
+# and the handful of 16-bit tensors that non-GEMM kernels read (q(): conv3's output under the spatial softmax, qkv, the attention output
+# gradient, the recurrent pre-activations / states / state gradients, emb, goal), so its ReLU masks and pre-activations follow the engine's to
+# fp32 summation-order noise instead of differing by 2^-9 relative — per-tensor gradient gates tighten from 0.2 to 2e-2.  Default (None) is the
+# plain fp32 restatement every golden-vector test uses; nothing in the product imports this file.
+_QMODE = None
+_GSCALE = 1.0
+
+
+def set_operand_rounding(mode, grad_scale=1.0):
+    """None (fp32, default) | "bf16" | "fp16".  grad_scale (a power of two): the fp16 engine's loss scale — its 16-bit GRADIENT tensors hold
+    gradient x scale (GradScaler semantics), so their rounding / underflow happens at that magnitude (qg)."""
+    global _QMODE, _GSCALE
+    if mode in ("fp32", ""):
+        mode = None
+    assert mode in (None, "bf16", "fp16"), mode
+    _QMODE, _GSCALE = mode, float(grad_scale)
+
+
+def q(x):
+    """x as the 16-bit engines store it (values rounded to the mode's format, returned as float32); identity in fp32 mode."""
+    if _QMODE is None:
+        return x
+    x = np.ascontiguousarray(x, F32)
+    if _QMODE == "fp16":
+        return x.astype(np.float16).astype(F32)
+    u = x.view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)                 # round to nearest even on the 16 dropped bits
+    out = ((u + r) & np.uint32(0xFFFF0000)).view(F32)
+    return np.where(np.isfinite(x), out, x).astype(F32)
+
+
+def qg(x):
+    """a stored 16-bit GRADIENT tensor: like q(), at the loss-scaled magnitude in fp16 mode."""
+    if _QMODE != "fp16" or _GSCALE == 1.0:
+        return q(x)
+    return (q(np.asarray(x, F32) * F32(_GSCALE)) / F32(_GSCALE)).astype(F32)
+
+
+def mm(a, b):
+    """a @ b with both operands as the engine holds them (16-bit in rounding-aware mode), fp32 accumulate."""
+    return q(a) @ q(b)
+
+
 def relu(x):
     return np.maximum(x, 0)
 
 
 def linear(x, w, b=None):
-    y = x @ w.T
+    y = mm(x, w.T)
     if b is not None:
         y = y + b
     return y.astype(F32)
@@ -39,7 +85,8 @@ def linear(x, w, b=None):
 
 def linear_bwd(x, w, dy):
     """returns dx, dw, db for y = x w^T + b ; x (M,K), w (N,K), dy (M,N)"""
-    return (dy @ w).astype(F32), (dy.T @ x).astype(F32), dy.sum(0).astype(F32)
+    dy = qg(dy)
+    return (dy @ q(w)).astype(F32), (dy.T @ q(x)).astype(F32), dy.sum(0).astype(F32)
 
 
 def _im2col(x, kh, kw, s):
@@ -54,22 +101,22 @@ def _im2col(x, kh, kw, s):
 def conv2d(x, w, b, s):
     """nn.Conv2d, no padding (vision_network.py:38-45, vision_network_gripper.py:12-17)."""
     o, c, kh, kw = w.shape
-    col, oh, ow = _im2col(np.ascontiguousarray(x), kh, kw, s)
-    y = col @ w.reshape(o, -1).T + b
+    col, oh, ow = _im2col(np.ascontiguousarray(q(x)), kh, kw, s)
+    y = col @ q(w).reshape(o, -1).T + b
     return np.ascontiguousarray(y.reshape(x.shape[0], oh, ow, o).transpose(0, 3, 1, 2)).astype(F32)
 
 
 def conv2d_bwd(x, w, dy, s, need_dx=True):
     o, c, kh, kw = w.shape
     n = x.shape[0]
-    col, oh, ow = _im2col(np.ascontiguousarray(x), kh, kw, s)
-    dy2 = dy.transpose(0, 2, 3, 1).reshape(-1, o)
+    col, oh, ow = _im2col(np.ascontiguousarray(q(x)), kh, kw, s)
+    dy2 = qg(dy.transpose(0, 2, 3, 1).reshape(-1, o))
     dw = (dy2.T @ col).reshape(w.shape).astype(F32)
     db = dy2.sum(0).astype(F32)
     dx = None
     if need_dx:
-        dcol = (dy2 @ w.reshape(o, -1)).reshape(n, oh, ow, c, kh, kw)
-        dx = np.zeros_like(x)
+        dcol = (dy2 @ q(w).reshape(o, -1)).reshape(n, oh, ow, c, kh, kw)
+        dx = np.zeros_like(x, dtype=F32)
         for i in range(kh):
             for j in range(kw):
                 dx[:, :, i:i + s * oh:s, j:j + s * ow:s] += dcol[:, :, :, :, i, j].transpose(0, 3, 1, 2)
@@ -144,11 +191,12 @@ def static_encoder_fwd(P, pre, x):
     c["x"] = x
     c["a1"] = relu(conv2d(x, P[pre + "conv_model.0.weight"], P[pre + "conv_model.0.bias"], 4))
     c["a2"] = relu(conv2d(c["a1"], P[pre + "conv_model.2.weight"], P[pre + "conv_model.2.bias"], 2))
-    c["a3"] = relu(conv2d(c["a2"], P[pre + "conv_model.4.weight"], P[pre + "conv_model.4.bias"], 1))
+    c["a3"] = q(relu(conv2d(c["a2"], P[pre + "conv_model.4.weight"], P[pre + "conv_model.4.bias"], 1)))   # q: the spatial softmax reads the stored 16-bit map
     c["ss"], c["ss_cache"] = spatial_softmax(c["a3"])
     c["f1"] = relu(linear(c["ss"], P[pre + "fc1.0.weight"], P[pre + "fc1.0.bias"]))
     c["f2"] = linear(c["f1"], P[pre + "fc2.weight"], P[pre + "fc2.bias"])
     c["out"], c["ln_cache"] = layer_norm(c["f2"], P[pre + "ln.weight"], P[pre + "ln.bias"])
+    c["out"] = q(c["out"])                    # perceptual_emb is a stored 16-bit tensor (read by the position add, the goal / plan MLPs, the decoder)
     return c["out"], c
 
 
@@ -193,6 +241,7 @@ def gripper_encoder_fwd(P, pre, x):
     c["f1"] = relu(linear(c["g0"], P[pre + "fc1.0.weight"], P[pre + "fc1.0.bias"]))
     c["f2"] = linear(c["f1"], P[pre + "fc2.weight"], P[pre + "fc2.bias"])
     c["out"], c["ln_cache"] = layer_norm(c["f2"], P[pre + "ln.weight"], P[pre + "ln.bias"])
+    c["out"] = q(c["out"])
     return c["out"], c
 
 
@@ -259,13 +308,13 @@ def plan_recognition_fwd(P, emb, heads=8):
     for l in range(2):
         L = f"{pr}transformer_encoder.layers.{l}."
         lc = {"x_in": x}
-        qkv = linear(x.reshape(B * S, D), P[L + "self_attn.in_proj_weight"], P[L + "self_attn.in_proj_bias"])
+        qkv = q(linear(x.reshape(B * S, D), P[L + "self_attn.in_proj_weight"], P[L + "self_attn.in_proj_bias"]))   # q: the attention kernel reads the stored qkv
         qkv = qkv.reshape(B, S, 3, heads, hd).transpose(2, 0, 3, 1, 4)          # (3,B,H,S,hd)
-        q, k, v = qkv[0], qkv[1], qkv[2]
-        sc = (q * F32(1.0 / math.sqrt(hd))) @ k.transpose(0, 1, 3, 2)
+        qh, k, v = qkv[0], qkv[1], qkv[2]
+        sc = (qh * F32(1.0 / math.sqrt(hd))) @ k.transpose(0, 1, 3, 2)
         pa = softmax(sc, -1).astype(F32)
         ao = (pa @ v).transpose(0, 2, 1, 3).reshape(B * S, D).astype(F32)
-        lc.update(q=q, k=k, v=v, pa=pa, ao=ao)
+        lc.update(q=qh, k=k, v=v, pa=pa, ao=ao)
         sa = linear(ao, P[L + "self_attn.out_proj.weight"], P[L + "self_attn.out_proj.bias"]).reshape(B, S, D)
         x1, lc["ln1"] = layer_norm(x + sa, P[L + "norm1.weight"], P[L + "norm1.bias"])
         lc["x1"] = x1
@@ -276,8 +325,11 @@ def plan_recognition_fwd(P, emb, heads=8):
         lc["x_out"] = x
         c["layers"].append(lc)
     c["x_final"] = x
-    y = linear(x.reshape(B * S, D), P[pr + "fc.weight"], P[pr + "fc.bias"]).reshape(B, S, -1)   # :113
-    seq_feat = y.mean(1).astype(F32)                                                          # :114
+    if _QMODE is None:
+        y = linear(x.reshape(B * S, D), P[pr + "fc.weight"], P[pr + "fc.bias"]).reshape(B, S, -1)   # :113
+        seq_feat = y.mean(1).astype(F32)                                                          # :114
+    else:           # the engine hoists the mean over S before the affine fc (exact in real arithmetic): its GEMM operand is the 16-bit mean
+        seq_feat = linear(x.mean(1).astype(F32), P[pr + "fc.weight"], P[pr + "fc.bias"])
     logits = linear(seq_feat, P[pr + "fc_state.0.weight"], P[pr + "fc_state.0.bias"])          # :115
     c["seq_feat"] = seq_feat
     return logits, seq_feat, c
@@ -294,11 +346,15 @@ def plan_recognition_bwd(P, G, c, dlogits, dseq_feat, heads=8, fc_state_used=Tru
         _acc(G, pr + "fc_state.0.weight", dw)
         _acc(G, pr + "fc_state.0.bias", db)
         dsf = dsf + d
-    dy = np.repeat((dsf / S)[:, None, :], S, 1).reshape(B * S, -1).astype(F32)
-    d, dw, db = linear_bwd(x.reshape(B * S, D), P[pr + "fc.weight"], dy)
+    if _QMODE is None:
+        dy = np.repeat((dsf / S)[:, None, :], S, 1).reshape(B * S, -1).astype(F32)
+        d, dw, db = linear_bwd(x.reshape(B * S, D), P[pr + "fc.weight"], dy)
+        dx = d.reshape(B, S, D)
+    else:           # mirror of the hoisted mean: fc's gradients from the (B, 128) mean, d x = d mean / S on every token
+        d, dw, db = linear_bwd(x.mean(1).astype(F32), P[pr + "fc.weight"], dsf)
+        dx = np.repeat((d / S)[:, None, :], S, 1).astype(F32)
     _acc(G, pr + "fc.weight", dw)
     _acc(G, pr + "fc.bias", db)
-    dx = d.reshape(B, S, D)
     for l in (1, 0):
         L = f"{pr}transformer_encoder.layers.{l}."
         lc = c["layers"][l]
@@ -319,14 +375,14 @@ def plan_recognition_bwd(P, G, c, dlogits, dseq_feat, heads=8, fc_state_used=Tru
         dao, dw, db = linear_bwd(lc["ao"], P[L + "self_attn.out_proj.weight"], dr1.reshape(B * S, D))
         _acc(G, L + "self_attn.out_proj.weight", dw)
         _acc(G, L + "self_attn.out_proj.bias", db)
-        dao = dao.reshape(B, S, heads, hd).transpose(0, 2, 1, 3)                  # (B,H,S,hd)
-        pa, q, k, v = lc["pa"], lc["q"], lc["k"], lc["v"]
+        dao = qg(dao).reshape(B, S, heads, hd).transpose(0, 2, 1, 3)               # (B,H,S,hd); q: the attention backward reads the stored 16-bit gradient
+        pa, qh, k, v = lc["pa"], lc["q"], lc["k"], lc["v"]
         dv = pa.transpose(0, 1, 3, 2) @ dao
         dpa = dao @ v.transpose(0, 1, 3, 2)
         dsc = pa * (dpa - (dpa * pa).sum(-1, keepdims=True))
         scale = F32(1.0 / math.sqrt(hd))
         dq = (dsc @ k) * scale
-        dk = dsc.transpose(0, 1, 3, 2) @ (q * scale)
+        dk = dsc.transpose(0, 1, 3, 2) @ (qh * scale)
         dqkv = np.stack([dq, dk, dv], 0).transpose(1, 3, 0, 2, 4).reshape(B * S, 3 * D).astype(F32)
         dxin, dw, db = linear_bwd(lc["x_in"].reshape(B * S, D), P[L + "self_attn.in_proj_weight"], dqkv)
         _acc(G, L + "self_attn.in_proj_weight", dw)
@@ -388,11 +444,11 @@ def rnn_fwd(P, pre, x, h0=None):
     for l in range(2):
         wih, whh = P[f"{pre}weight_ih_l{l}"], P[f"{pre}weight_hh_l{l}"]
         b = P[f"{pre}bias_ih_l{l}"] + P[f"{pre}bias_hh_l{l}"]
-        zx = (inp.reshape(B * S, -1) @ wih.T + b).reshape(B, S, -1)
+        zx = q((mm(inp.reshape(B * S, -1), wih.T) + b).reshape(B, S, -1))     # q: the hoisted input projection is stored (16-bit) and added in the step's epilogue
         H = np.zeros((B, S, whh.shape[0]), F32)
         h = np.zeros((B, whh.shape[0]), F32) if h0 is None else h0[l].astype(F32)
         for t in range(S):
-            h = relu(zx[:, t] + h @ whh.T).astype(F32)
+            h = q(relu(zx[:, t] + mm(h, whh.T)).astype(F32))
             H[:, t] = h
         c[f"H{l}"] = H
         hn.append(h)
@@ -410,17 +466,18 @@ def rnn_bwd(P, G, pre, c, dH1):
         inp = c["H0"] if l == 1 else c["x"]
         dZ = np.zeros((B, S, Hn), F32)
         carry = np.zeros((B, Hn), F32)
+        dout = qg(dout)                                  # dH of the layer is a stored 16-bit tensor (residual operand of the BPTT step)
         for t in reversed(range(S)):
-            dz = (dout[:, t] + carry) * (H[:, t] > 0)
+            dz = qg((dout[:, t] + carry) * (H[:, t] > 0))
             dZ[:, t] = dz
-            carry = dz @ whh
+            carry = dz @ q(whh)
         dz2 = dZ.reshape(B * S, Hn)
         Hprev = np.concatenate([np.zeros((B, 1, Hn), F32), H[:, :-1]], 1).reshape(B * S, Hn)
-        _acc(G, f"{pre}weight_hh_l{l}", dz2.T @ Hprev)
-        _acc(G, f"{pre}weight_ih_l{l}", dz2.T @ inp.reshape(B * S, -1))
+        _acc(G, f"{pre}weight_hh_l{l}", dz2.T @ q(Hprev))
+        _acc(G, f"{pre}weight_ih_l{l}", dz2.T @ q(inp.reshape(B * S, -1)))
         _acc(G, f"{pre}bias_ih_l{l}", dz2.sum(0))
         _acc(G, f"{pre}bias_hh_l{l}", dz2.sum(0))
-        dout = (dz2 @ wih).reshape(B, S, -1).astype(F32)
+        dout = (dz2 @ q(wih)).reshape(B, S, -1).astype(F32)
     return dout       # grad w.r.t. decoder input x
 
 
@@ -997,6 +1054,7 @@ def modality_fwd(P, dims, mb, is_lang):
     else:
         gpre, c["goal_acts"] = mlp_fwd(P, VG_NAMES, emb[:, -1], False)
         goal, c["goal_ln"] = layer_norm(gpre, P["visual_goal.ln.weight"], P["visual_goal.ln.bias"])
+    goal = q(goal)                          # latent_goal is a stored 16-bit tensor in the half-precision engines
     c["goal"] = goal
     if dims.kind == "mcil":
         pr_state, seq_feat, c["pr"] = (bigru_fwd if dims.rnn_type == "gru" else birnn_fwd)(P, emb)
