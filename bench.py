@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--pair", type=int, default=1, help="with --lang 1: both modalities as ONE 2B-window pass (hulc_forward_loss_pair); 0 = one pass per modality like the reference")
     ap.add_argument("--bucket", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="N > 1: wire format of the gradient all-reduce buckets (fp32 = the reference's; the engine's 16-bit type halves the bytes per link)")
+    ap.add_argument("--h2d", type=int, default=0, help="with --ingest u8: 1 = every step's uint8 frames come from PINNED HOST memory (async H2D on a copy stream into a "
+                                                      "double buffer, overlapped with the previous step) — the PCIe-inclusive row SURVEY §8(d) asks for; never the headline `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -190,7 +192,42 @@ def main():
         mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest)))
     nmod = len(mods)
 
+    # --h2d 1: the frames of every step cross PCIe.  Pinned host copies of the uint8 (B,S,H,W,C) frames; two device buffers per camera; the copy
+    # of step i+1's frames is issued on a copy stream when step i starts (it may not start earlier: the buffer it overwrites is read by step i-1's
+    # conv1 weight gradient, the last kernels of that step) and step i+1 waits for its event — the transfer hides under step i's compute as far as
+    # PCIe allows (289 MB per step at B = 64: ~5 ms at 55-60 GB/s, longer than the step itself).
+    h2d = None
+    if args.h2d:
+        if args.ingest != "u8" or args.lang:
+            raise SystemExit("--h2d 1 needs --ingest u8 (vision-only)")
+        mb0 = mods[0][1]
+        h2d = dict(host={k: mb0[k].cpu().pin_memory() for k in ("rgb_static", "rgb_gripper")},
+                   dev=[{k: torch.empty_like(mb0[k]) for k in ("rgb_static", "rgb_gripper")} for _ in range(2)],
+                   stream=torch.cuda.Stream(device=dev), ready=[torch.cuda.Event(), torch.cuda.Event()], free=[torch.cuda.Event(), torch.cuda.Event()], n=0)
+
+        def h2d_issue(slot):
+            with torch.cuda.stream(h2d["stream"]):
+                h2d["stream"].wait_event(h2d["free"][slot])          # the step that last read this buffer has finished
+                for k in ("rgb_static", "rgb_gripper"):
+                    h2d["dev"][slot][k].copy_(h2d["host"][k], non_blocking=True)
+                h2d["ready"][slot].record(h2d["stream"])
+        for sl in range(2):
+            h2d["free"][sl].record(torch.cuda.current_stream(dev))
+        h2d_issue(0)
+
     def step(i):
+        if h2d is not None:
+            slot = h2d["n"] % 2
+            h2d["n"] += 1
+            h2d_issue(1 - slot)                                       # next step's frames: in flight while this step computes
+            torch.cuda.current_stream(dev).wait_event(h2d["ready"][slot])
+            mods[0] = (mods[0][0], dict(mods[0][1], **h2d["dev"][slot]))
+            _step(i)
+            h2d["free"][slot].record(torch.cuda.current_stream(dev))
+            return
+        _step(i)
+
+    def _step(i):
         eng.zero_grads()
         if paired:
             eng.forward_loss_pair(mods[0][1], mods[1][1], 0.5, 3.0, step=i, sync_losses=False)
@@ -283,12 +320,18 @@ def main():
     # timed region: events only around the dominant class (on the engine's stream), so the timers do not perturb the step
     eng.timers_enable(True, dominant)
     sc0 = eng.scaler_state() if args.dtype == "fp16" else None
+    # one event per step boundary on the engine's stream (= torch's current stream): per-step device times for median / p10 / p90 next to the
+    # wall-clock mean the contract's `ms_per_step` is (an event record costs no synchronisation and ~1 us of stream time)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    evs[0].record()
     for i in range(args.steps):
         step(args.warmup + i)
+        evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -329,6 +372,24 @@ def main():
                 "ms_per_step": round(t["ms"] / args.steps, 4),
                 "per_launch": {"algorithmic_flops": t["flops"] / max(1, t["launches"]), "algorithmic_bytes": t["bytes"] / max(1, t["launches"])}}
 
+    def step_roofline():
+        """Whole step against both ceilings with SURVEY §8(d)'s ALGORITHMIC work (every tensor moved the minimum number of times without
+        inter-layer fusion): per window (S = 32) input frames 4 517 376 elements read twice (conv1 forward + weight gradient), conv activations
+        5 121 024 elements x 5 touches, post-encoder activations ~0.3 M x 5, in the engine's element size (frames: 4 B at the fp32 boundary,
+        1 B with uint8 ingest); per step 470 M fp32 elements of weight / gradient / optimizer traffic (independent of B)."""
+        es = 4 if args.dtype == "fp32" else 2
+        fe = 1 if args.ingest == "u8" else 4
+        r = S / 32.0
+        bytes_window = 4517376 * r * fe * 2 + (5121024 + 300000) * r * es * 5
+        bytes_step = bytes_window * B + 470e6 * 4
+        flops_step = FLOP_PER_WINDOW_S32 * r * B
+        t = float(np.median(per_step)) * 1e-3
+        peak_f = (MFMA_BF16_PEAK_TFLOPS if args.dtype != "fp32" else 157.3) * 1e12
+        t_hbm, t_mfma = bytes_step / (HBM_PEAK_GBS * 1e9), flops_step / peak_f
+        return {"algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_step": flops_step, "hbm_frac": round(t_hbm / t, 4), "mfma_frac": round(t_mfma / t, 4),
+                "binding": "hbm" if t_hbm > t_mfma else "mfma", "ceiling_windows_per_s": round(B / max(t_hbm, t_mfma), 1),
+                "achieved_over_min_ceiling": round(max(t_hbm, t_mfma) / t, 4), "at": "median step time, per GPU"}
+
     if rank == 0:
         rl = roofline(timers)
         kernel_classes = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] / args.steps,
@@ -343,12 +404,16 @@ def main():
             "config": {"workload": "%s training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper %s frames, "
                                    "fwd+loss+bwd+%sAdam, dropout %s" % (("HULC (model=mcil: Bi%s plan recognition, continuous plan)" % ("GRU" if args.model == "mcil_gru" else "RNN")) if mcil else "HULC",
                                                                         ("32 vis + 32 lang" + ("" if mcil else " + CLIP aux") + (" as one paired pass" if paired else ", one pass per modality")) if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
-                                                                        B, S, "uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" if args.ingest == "u8" else "fp32 NCHW",
+                                                                        B, S, ("uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" + (", frames copied from PINNED HOST memory every step (async H2D, double-buffered)" if args.h2d else "")) if args.ingest == "u8" else "fp32 NCHW",
                                                                         "RCCL all-reduce+" if world > 1 else "", "0.0" if mcil else "0.1"),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "last_losses": {"total_mod": loss[0], "kl": loss[1], "action": loss[2], "clip": loss[3]},
             "model_flops_per_window": None if mcil else FLOP_PER_WINDOW_S32 * S / 32.0,      # SURVEY §8(d) counts the headline model only
             "step_tflops": None if mcil else round(wps / world * FLOP_PER_WINDOW_S32 * S / 32.0 / 1e12, 2),
+            # per-step device times (HIP events at the step boundaries): the mean above is wall clock incl. host stalls; SURVEY §8(d) asks for the median
+            "step_ms": {"median": round(float(np.median(per_step)), 4), "p10": round(float(np.percentile(per_step, 10)), 4), "p90": round(float(np.percentile(per_step, 90)), 4),
+                        "min": round(float(per_step.min()), 4), "max": round(float(per_step.max()), 4), "windows_per_s_at_median": round(B * world / (float(np.median(per_step)) * 1e-3), 1)},
+            "roofline_step": None if mcil else step_roofline(),
             "roofline": rl,
             "allreduce": None if world == 1 else ({"path": "libhulc_hip RCCL (hulc_backward_allreduce)", "rccl_ranks": world, "bucket_dtype": args.bucket, "buckets": eng.comm_buckets(),
                                                   "bucket_bytes": [(hi - lo) * (4 if args.bucket == "fp32" else 2) for lo, hi in eng.comm_buckets()],

@@ -4,7 +4,6 @@
 // Reference call stack restated here: SURVEY.md §3.2 (hulc/models/hulc.py:390-537).
 #pragma once
 #include <algorithm>
-#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -108,69 +107,6 @@ struct Engine : IEngine {
     T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
     T *tA, *tB; int64_t tcap;
     float *part; int64_t partcap; float* cspart;
-    // ---- side stream (non-encoder backward): every weight / bias gradient of the decoder, plan networks, transformer and goal encoders is off the
-    // critical path — nothing reads dW / db before the bucket's all-reduce or Adam — so those launches (transposes, the four 2048^3 decoder GEMMs,
-    // the small-M fused kernels) go to a second, lower-priority stream and fill the CUs the latency-bound dgrad chain leaves idle.  The side stream
-    // has its own transposed-operand / column-sum scratch (tA2 / tB2 / cspart2); dY buffers it reads come from a per-backward bump arena (bs()) so
-    // that the main chain never overwrites an operand the side stream has not consumed yet.  Joined before the encoder backward (whose persistent
-    // conv kernels want whole CUs) — never beside the recurrent chains (co-scheduling with them measured +0.3 ms/step in round 2).
-    hipStream_t sst = nullptr; std::vector<hipEvent_t> sev; size_t sev_used = 0;
-    bool side_on = false, side_dirty = false;
-    T *tA2 = nullptr, *tB2 = nullptr; float* cspart2 = nullptr;
-    T* barena = nullptr; int64_t barena_n = 0, barena_used = 0; bool barena_overflow = false;
-    std::vector<std::function<void()>> deferred;              // weight-gradient work queued until the recurrent chains of the backward are done
-    static bool side_enabled() { static const bool on = getenv("HULC_SIDE") ? atoi(getenv("HULC_SIDE")) != 0 : true; return on; }
-    // experiment knob (same-box A/B): bit 0 = the decoder's big weight-gradient GEMMs on the side stream, bit 1 = every other lin_wgrad on the side
-    // stream, bit 2 = those are batched per stage (one event pair per flush instead of one per launch)
-    static int side_mode() { static const int m = getenv("HULC_SIDE_MODE") ? atoi(getenv("HULC_SIDE_MODE")) : 7; return m; }
-    hipEvent_t side_event() {
-        if (sev_used == sev.size()) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); sev.push_back(e); }
-        return sev[sev_used++];
-    }
-    // RAII: launches inside the scope go to the side stream, ordered after everything enqueued on the main stream so far
-    struct Side {
-        Engine* e; bool act; hipStream_t s0 = nullptr; T *a0 = nullptr, *b0 = nullptr; float* c0 = nullptr;
-        explicit Side(Engine* e_, bool want = true) : e(e_), act(want && e_->side_on && e_->sst && e_->st != e_->sst) {
-            if (!act) return;
-            hipEvent_t ev = e->side_event(); hipEventRecord(ev, e->st); hipStreamWaitEvent(e->sst, ev, 0);
-            s0 = e->st; a0 = e->tA; b0 = e->tB; c0 = e->cspart;
-            e->st = e->sst; e->tA = e->tA2; e->tB = e->tB2; e->cspart = e->cspart2; e->side_dirty = true;
-        }
-        ~Side() { if (act) { e->st = s0; e->tA = a0; e->tB = b0; e->cspart = c0; } }
-        Side(const Side&) = delete; Side& operator=(const Side&) = delete;
-    };
-    void side_begin() {
-        sev_used = 0; barena_used = 0; deferred.clear();
-        side_on = false;
-        if (!side_enabled()) return;
-        if (!sst) {
-            int lo = 0, hi = 0;
-            hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least priority
-            if (hipStreamCreateWithPriority(&sst, hipStreamNonBlocking, lo) != hipSuccess) { sst = nullptr; return; }
-        }
-        side_on = true;
-    }
-    // weight-gradient work that must not run beside a recurrent chain: queued, flushed to the side stream once the chains are enqueued
-    void defer(std::function<void()> f) { if (side_on) deferred.push_back(std::move(f)); else f(); }
-    void flush_deferred() {
-        if (deferred.empty()) return;
-        std::vector<std::function<void()>> work; work.swap(deferred);
-        in_flush = true;
-        { Side sd(this); for (auto& f : work) f(); }
-        in_flush = false;
-    }
-    // main stream waits for the side stream (end of the non-encoder backward)
-    void side_join() {
-        flush_deferred();
-        if (side_dirty) { hipEvent_t ev = side_event(); hipEventRecord(ev, sst); hipStreamWaitEvent(st, ev, 0); side_dirty = false; }
-        side_on = false;
-    }
-    // per-backward scratch that is never reused within one backward (so the side stream's reads cannot race a later write of the main chain)
-    T* bs(int64_t n) {
-        n = (n + 127) / 128 * 128;
-        if (barena_used + n > barena_n) { barena_overflow = true; return barena; }
-        T* p = barena + barena_used; barena_used += n; return p;
-    }
     // clip
     int* auxrows; T *sf_m, *im1, *g_m, *la1, *img_t, *txt_t; float *img, *txt, *dimg, *dtxt, *dsf_m, *dg_m; T *dimg_t, *dtxt_t, *dim1, *dla1;
     float* losses;   // [8]: 0 action, 1 kl(sum klcat), 2 clip
@@ -188,11 +124,7 @@ struct Engine : IEngine {
         KIN = dec_plan + DE + GOAL;
         maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
     }
-    ~Engine() override {
-        if (sst) { hipStreamSynchronize(sst); hipStreamDestroy(sst); }
-        for (hipEvent_t e : sev) hipEventDestroy(e);
-        for (void* p : allocs) hipFree(p);
-    }
+    ~Engine() override { for (void* p : allocs) hipFree(p); }
     int64_t workspace_bytes() const override { return ws_bytes; }
     void set_kl_beta(float b) override { cfg.kl_beta = b; }
     void set_dropout(float p) override { cfg.dropout_p = p; }
@@ -260,9 +192,6 @@ struct Engine : IEngine {
         tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>((gru ? 3 : 1) * HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
         tA = alloc<T>(tcap); tB = alloc<T>(tcap);
         partcap = 1024ll * 64 * 576; part = alloc<float>(partcap); cspart = alloc<float>(1024 * 2048);
-        tA2 = alloc<T>(tcap); tB2 = alloc<T>(tcap); cspart2 = alloc<float>(1024 * 2048);
-        barena_n = N * (2 * (3 * EMB + FF + 3 * EMB)) + 24 * B * std::max<int64_t>(HID, FCH) + 65536;      // transformer: per layer 3 x [N][EMB] + [N][FF] + [N][3 EMB]; MLP chains: one [B][HID] per layer
-        barena = alloc<T>(barena_n);
         auxrows = alloc<int>(B); sf_m = alloc<T>(B * FCH); im1 = alloc<T>(B * 128); g_m = alloc<T>(B * GOAL); la1 = alloc<T>(B * 128);
         img = alloc<float>(B * GOAL, "clip_img"); txt = alloc<float>(B * GOAL, "clip_txt"); img_t = alloc<T>(B * GOAL); txt_t = alloc<T>(B * GOAL);
         dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
@@ -531,13 +460,7 @@ struct Engine : IEngine {
         gemm(dense<T>(X, M, ldx), dense<T>(L.W, L.N, L.K), dense_out(ldo), ep, M, L.N, L.K);
     }
     // weight + bias grads of Y = X W^T: dW[N][K] += dY^T X ; db += colsum(dY).  dY [M][N] dense, X [M][K] (ldx)
-    bool in_flush = false;
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
-        if (side_on && !in_flush && (side_mode() & 2) && (side_mode() & 4)) {     // queued: flushed to the side stream at the end of the stage
-            deferred.push_back([=] { lin_wgrad(dY, X, ldx, M, N, K, dW, lddw, db, db2); });
-            return;
-        }
-        Side sd(this, (side_mode() & 2) != 0 || in_flush);       // inside the non-encoder backward: on the side stream (no-op otherwise)
         if constexpr (std::is_same<T, h16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
                 hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
@@ -860,13 +783,13 @@ struct Engine : IEngine {
     // dy: T [M][N_last]; x: first-layer input (ldx). dxf: optional fp32 output (accumulating) with map
     void mlp_bwd(const T* dy, const T* x, long long ldx, int M, LinW* L, int n, T** acts, T* s0, T* s1, float* dxf, const DenseOut* om, int dx_acc) {
         const T* d = dy;
-        (void)s0; (void)s1;
+        T* scratch[2] = {s0, s1};
         for (int i = n - 1; i >= 0; --i) {
             const T* in = i > 0 ? acts[i - 1] : x;
             const long long ld = i > 0 ? L[i - 1].N : ldx;
             lin_wgrad(d, in, ld, M, L[i].N, L[i].K, L[i].dW, L[i].K, L[i].db);
             if (i > 0) {
-                T* o = bs((long long)M * L[i].K);         // a fresh buffer per layer: the side stream's weight-gradient launch may still be reading the previous one
+                T* o = scratch[i & 1];
                 EpiP ep = epi(o, false); ep.mask = acts[i - 1];
                 lin_dgrad(d, M, L[i], ep, dense_out(L[i].K));
                 d = o;
@@ -1669,7 +1592,6 @@ struct Engine : IEngine {
         if (hi <= lo) return 0;
         GradComm& c = *comm;
         c.gate_from(st);
-        if (side_dirty) c.gate_from(sst);    // weight gradients of this bucket may still be in flight on the side stream
         const size_t n = (size_t)(hi - lo);
         int rc;
         if (dtype == HULC_DTYPE_BF16 || dtype == HULC_DTYPE_F16) {
@@ -1760,7 +1682,6 @@ struct Engine : IEngine {
         if (part == 1) goto encoders;
         HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
         work_ctr_next = 0;
-        side_begin();                        // weight-gradient launches of this part go to the side stream (joined before the encoders)
         {
         bool have_dseq = false;
         // ---- CLIP backward
@@ -1769,15 +1690,15 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, dimg, dimg_t, (long long)n * GOAL);
             hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, dtxt, dtxt_t, (long long)n * GOAL);
             // image branch: img = im2(relu(im0(sf)))
-            defer([=] { lin_wgrad(dimg_t, im1, 128, n, GOAL, 128, cl_im2.dW, 128, cl_im2.db); });
+            lin_wgrad(dimg_t, im1, 128, n, GOAL, 128, cl_im2.dW, 128, cl_im2.db);
             { EpiP ep = epi(dim1, false); ep.mask = im1; lin_dgrad(dimg_t, n, cl_im2, ep, dense_out(128)); }
-            defer([=] { lin_wgrad(dim1, sf_m, FCH, n, 128, FCH, cl_im0.dW, FCH, cl_im0.db); });
+            lin_wgrad(dim1, sf_m, FCH, n, 128, FCH, cl_im0.dW, FCH, cl_im0.db);
             { EpiP ep = epi(dsf_m, true); lin_dgrad(dim1, n, cl_im0, ep, dense_out(FCH)); }
             hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(n * FCH, 256)), dim3(256), 0, st, dsf_m, auxrows, n, FCH, dseqf, (long long)FCH);
             // text branch
-            defer([=] { lin_wgrad(dtxt_t, la1, 128, n, GOAL, 128, cl_la2.dW, 128, cl_la2.db); });
+            lin_wgrad(dtxt_t, la1, 128, n, GOAL, 128, cl_la2.dW, 128, cl_la2.db);
             { EpiP ep = epi(dla1, false); ep.mask = la1; lin_dgrad(dtxt_t, n, cl_la2, ep, dense_out(128)); }
-            defer([=] { lin_wgrad(dla1, g_m, GOAL, n, 128, GOAL, cl_la0.dW, GOAL, cl_la0.db); });
+            lin_wgrad(dla1, g_m, GOAL, n, 128, GOAL, cl_la0.dW, GOAL, cl_la0.db);
             { EpiP ep = epi(dg_m, true); lin_dgrad(dla1, n, cl_la0, ep, dense_out(GOAL)); }
             hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(n * GOAL, 256)), dim3(256), 0, st, dg_m, auxrows, n, GOAL, dgoal, (long long)GOAL);
             have_dseq = true;
@@ -1787,18 +1708,15 @@ struct Engine : IEngine {
         {
             // heads
             { EpiP ep = epi(dH1, false); gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
-            defer([=] {
-                lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
+            lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
+            {
                 const HeadPack hp = head_pack();
                 const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
                 hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, dwheads_tmp, dbheads_tmp, HID);
-            });
-            // the critical path first: layer 1 BPTT -> dH0 -> layer 0 BPTT (two chains of S dependent launches); the weight gradients of both
-            // layers (four 2048^3-class GEMMs + transposes, ~0.2 ms that feed nothing downstream) follow on the side stream once the chains are enqueued
+            }
+            // layer 1 BPTT
             rnn_bwd(dH1, H1, dZ1, whh1, B, S);
-            { EpiP ep = epi(dH0, false); gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
-            rnn_bwd(dH0, H0, dZ0, whh0, B, S);
-            auto dec_wgrads = [=] {
+            {
                 const int mp = ldpad(SB);
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
@@ -1806,31 +1724,34 @@ struct Engine : IEngine {
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
                 { EpiP ep = epi(wih1.dW, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
                 colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
+            }
+            { EpiP ep = epi(dH0, false); gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            // layer 0 BPTT
+            rnn_bwd(dH0, H0, dZ0, whh0, B, S);
+            {
+                const int mp = ldpad(SB);
                 transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp);
                 if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
                 { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
-            };
-            if (side_mode() & 1) { defer(dec_wgrads); flush_deferred(); }
-            else { flush_deferred(); dec_wgrads(); }
+            }
             // d emb (gripper half), scattered back to (B,S,128)[..., 64:128]
             { EpiP ep = epi(demb + (EMB - DE), true); ep.accumulate = 1;
               gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, DE, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, DE, HID); }
             hipLaunchKernelGGL((sum_over_t_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dZ0, S, BH, dC);
-            {   // bias / goal-column / plan-column gradients of W_ih0: side stream
-                Side sd(this);
-                colsum(dC, HID, B, HID, dbih0, dbhh0);
+            colsum(dC, HID, B, HID, dbih0, dbhh0);
+            { EpiP ep = epi(dgoal, true); ep.accumulate = 1;
+              gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + DE) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
+            {
                 const int mp = ldpad(B);
                 transpose_pair(dC, HID, tA, B, HID, goal_t, GOAL, tB, B, GOAL, mp);
                 EpiP ep = epi(dwih0 + dec_plan + DE, true); ep.accumulate = 1;
                 gemm(dense<T>(tA, HID, mp), dense<T>(tB, GOAL, mp), dense_out(KIN), ep, HID, GOAL, B);
-                if (hulc) hipLaunchKernelGGL((plan_scatter_grad_lds_kernel<T>), dim3(NCAT, cdiv(HID, 64)), dim3(64), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
             }
-            { EpiP ep = epi(dgoal, true); ep.accumulate = 1;
-              gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + DE) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
             if (hulc) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, PLAN, HID), dense_out(PLAN), ep, B, PLAN, HID); }
+                hipLaunchKernelGGL((plan_scatter_grad_lds_kernel<T>), dim3(NCAT, cdiv(HID, 64)), dim3(64), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
             }
             if (mcil) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, dec_plan, HID), dense_out(dec_plan), ep, B, dec_plan, HID); }
@@ -1838,7 +1759,6 @@ struct Engine : IEngine {
             }
         }
         STAGE("decoder_bwd");
-        flush_deferred();
         if (bucket_ready(0)) return 1;       // action_decoder.*, proj_vis_lang.*, logit_scale are final: their all-reduce starts under the rest of the backward
         // ---- straight-through + KL -> logits grads; plan proposal backward
         if (hulc) {
@@ -1847,7 +1767,6 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
-            flush_deferred();
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             // fc_state of plan recognition
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
@@ -1863,7 +1782,6 @@ struct Engine : IEngine {
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
             copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
             copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
-            flush_deferred();
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             if (gru) bigru_bwd(dprl_t, B, S); else birnn_bwd(dprl_t, B, S);
         }
@@ -1875,8 +1793,6 @@ struct Engine : IEngine {
             float* dx = dxa; float* dnext = dxb;
             hipLaunchKernelGGL(bcast_over_s_kernel, dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dxm, B, S, EMB, dx);
             for (int l = 1; l >= 0; --l) {
-                // 16-bit gradient operands of this layer: fresh arena buffers (each is read by a weight-gradient launch on the side stream)
-                T* dt_c = bs((long long)N * EMB); T* dt_a = bs((long long)N * FF); T* dt_c1 = bs((long long)N * EMB); T* dt_ao = bs((long long)N * EMB); T* dt_b = bs((long long)N * 3 * EMB);
                 // LN2
                 ln_bwd(dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n2g[l], d_tr_n2b[l], dp, site_seed(4 + 4 * l));   // dt_c = dropout mask of the FFN branch applied to dy_f
                 lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
@@ -1884,21 +1800,20 @@ struct Engine : IEngine {
                 lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
                 { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
                 // LN1
-                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c1, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
-                lin_wgrad(dt_c1, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
-                { EpiP ep = epi(dt_ao, false); lin_dgrad(dt_c1, N, tr_out[l], ep, dense_out(EMB)); }
+                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
+                lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
+                { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
                 static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
-                if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_ao, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
-                else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_ao, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 else if (att32) {
                     static bool attr = false;
                     if (!attr) { hipFuncSetAttribute((const void*)attention_bwd64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD64_LDS); attr = true; }
-                    hipLaunchKernelGGL((attention_bwd64_kernel<T>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv[l], Pat[l], dt_ao, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                    hipLaunchKernelGGL((attention_bwd64_kernel<T>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 }
-                else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_ao, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
-                flush_deferred();        // this layer's four weight gradients: one hand-over to the side stream
             }
             // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
             hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dx, dy_f, (T*)nullptr, (long long)N * EMB, dp, site_seed(0));
@@ -1906,7 +1821,6 @@ struct Engine : IEngine {
             hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dy_f, B, S, EMB, dpos);
         }
         STAGE("plan_recognition_bwd");
-        flush_deferred();
         if (bucket_ready(1) || bucket_ready(2)) return 1;   // plan_recognition.* final (plan_proposal too for the kinds that never touch it)
         // ---- goal encoder backward
         if (pair) {
@@ -1931,8 +1845,6 @@ struct Engine : IEngine {
             }
         }
         }
-        side_join();                         // the encoder backward (persistent conv kernels, whole CUs each) starts after the side stream has drained
-        if (barena_overflow) { hulc_set_error("hulc_backward: backward scratch arena too small (B=%d S=%d)", B, S); barena_overflow = false; return 1; }
         if (bucket_ready(3)) return 1;       // visual_goal.*, language_goal.* final
         if (part == 0) {
             if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }

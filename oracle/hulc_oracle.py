@@ -299,12 +299,22 @@ def mlp_bwd(P, G, names, acts, d, last_relu):
 # ----------------------------------------------------------------------------------------------------
 # plan recognition transformer (plan_recognition_net.py:94-117 ; nn.TransformerEncoderLayer post-LN, relu)
 # ----------------------------------------------------------------------------------------------------
-def plan_recognition_fwd(P, emb, heads=8):
+def plan_recognition_fwd(P, emb, heads=8, drop=None):
+    """drop = (p, numpy Generator): TRAIN mode — inverted dropout with the oracle's OWN masks at the five kinds of site the reference has
+    (plan_recognition_net.py:111 on emb + pos; nn.TransformerEncoderLayer(dropout=p): attention weights, after out_proj, after the FFN
+    activation, after linear2).  Forward only: the cache does not carry the masks (the statistical train-mode test compares mean losses)."""
     pr = "plan_recognition."
     B, S, D = emb.shape
     hd = D // heads
     c = {"layers": []}
-    x = (emb + P[pr + "position_embeddings.weight"][:S][None]).astype(F32)      # :101-105
+
+    def _drop(t):
+        if drop is None:
+            return t
+        pdrop, rng = drop
+        keep = rng.random(t.shape) >= pdrop
+        return (t * keep / F32(1.0 - pdrop)).astype(F32)
+    x = _drop((emb + P[pr + "position_embeddings.weight"][:S][None]).astype(F32))      # :101-105, :111
     for l in range(2):
         L = f"{pr}transformer_encoder.layers.{l}."
         lc = {"x_in": x}
@@ -312,15 +322,15 @@ def plan_recognition_fwd(P, emb, heads=8):
         qkv = qkv.reshape(B, S, 3, heads, hd).transpose(2, 0, 3, 1, 4)          # (3,B,H,S,hd)
         qh, k, v = qkv[0], qkv[1], qkv[2]
         sc = (qh * F32(1.0 / math.sqrt(hd))) @ k.transpose(0, 1, 3, 2)
-        pa = softmax(sc, -1).astype(F32)
+        pa = _drop(softmax(sc, -1).astype(F32))
         ao = (pa @ v).transpose(0, 2, 1, 3).reshape(B * S, D).astype(F32)
         lc.update(q=qh, k=k, v=v, pa=pa, ao=ao)
-        sa = linear(ao, P[L + "self_attn.out_proj.weight"], P[L + "self_attn.out_proj.bias"]).reshape(B, S, D)
+        sa = _drop(linear(ao, P[L + "self_attn.out_proj.weight"], P[L + "self_attn.out_proj.bias"])).reshape(B, S, D)
         x1, lc["ln1"] = layer_norm(x + sa, P[L + "norm1.weight"], P[L + "norm1.bias"])
         lc["x1"] = x1
-        h = relu(linear(x1.reshape(B * S, D), P[L + "linear1.weight"], P[L + "linear1.bias"]))
+        h = _drop(relu(linear(x1.reshape(B * S, D), P[L + "linear1.weight"], P[L + "linear1.bias"])))
         lc["h"] = h
-        ff = linear(h, P[L + "linear2.weight"], P[L + "linear2.bias"]).reshape(B, S, D)
+        ff = _drop(linear(h, P[L + "linear2.weight"], P[L + "linear2.bias"])).reshape(B, S, D)
         x, lc["ln2"] = layer_norm(x1 + ff, P[L + "norm2.weight"], P[L + "norm2.bias"])
         lc["x_out"] = x
         c["layers"].append(lc)
@@ -1171,6 +1181,33 @@ def training_step(P, dims, batch, clip_beta=3.0, want_grads=True, keep_cache=Fal
     if keep_cache:
         return losses, G, caches
     return losses, G
+
+
+def train_mode_losses(P, dims, mb, rng, dropout_p=0.1, enc_cache=None):
+    """One TRAIN-mode forward of the vision-goal HULC step with the oracle's own stochastic draws: dropout masks in the
+    plan-recognition transformer (plan_recognition_net.py:111 + the encoder layers) and the categorical plan sample drawn from the posterior
+    (hulc.py:289 rsample()).  Returns (dict(action, kl, total), enc_cache); the perceptual encoders are deterministic, so their output is
+    computed once and passed back in through enc_cache."""
+    B, S = mb["actions"].shape[:2]
+    if enc_cache is None:
+        xs = mb["rgb_static"].reshape((B * S,) + mb["rgb_static"].shape[2:]).astype(F32)
+        xg = mb["rgb_gripper"].reshape((B * S,) + mb["rgb_gripper"].shape[2:]).astype(F32)
+        es, _ = static_encoder_fwd(P, "perceptual_encoder.rgb_static_encoder.", xs)
+        eg, _ = gripper_encoder_fwd(P, "perceptual_encoder.rgb_gripper_encoder.", xg)
+        enc_cache = np.concatenate([es.reshape(B, S, -1), eg.reshape(B, S, -1)], -1).astype(F32)
+    emb = enc_cache
+    gpre, _ = mlp_fwd(P, VG_NAMES, emb[:, -1], False)
+    goal, _ = layer_norm(gpre, P["visual_goal.ln.weight"], P["visual_goal.ln.bias"])
+    pr_logits, _, _ = plan_recognition_fwd(P, emb, dims.heads, drop=(dropout_p, rng) if dropout_p > 0 else None)
+    pp_logits, _ = mlp_fwd(P, PP_NAMES, np.concatenate([emb[:, 0], goal], -1), False)
+    probs = softmax(pr_logits.reshape(B, dims.n_cat, dims.n_cls).astype(np.float64), -1)
+    u = rng.random((B, dims.n_cat, 1))
+    idx = np.minimum((np.cumsum(probs, -1) < u).sum(-1), dims.n_cls - 1)          # inverse-CDF categorical draw per (window, category)
+    onehot = np.zeros((B, dims.n_cat, dims.n_cls), F32)
+    np.put_along_axis(onehot, idx[..., None], 1.0, -1)
+    act, _ = decoder_loss_fwd(P, onehot.reshape(B, -1), emb, goal, mb["actions"], mb["robot_obs"], dims)
+    kl, _, _ = kl_loss(pp_logits, pr_logits, dims)
+    return dict(action=float(act), kl=float(kl), total=float(act + kl)), enc_cache
 
 
 def adam_step(P, G, state, step, lr=2e-4, b1=0.9, b2=0.999, eps=1e-8):

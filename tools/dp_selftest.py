@@ -7,7 +7,7 @@ One process per GPU.  For every (model kind, engine precision, bucket wire forma
 rank-different batch:
   A. hulc_backward                         -> local gradients -> ONE flat torch.distributed (RCCL via torch) SUM all-reduce   = the reference sum
   B. hulc_backward_allreduce(bucket dtype) -> the library's own communicator: five reverse-forward buckets on the private stream, gated by
-     events from the engine stream AND the weight-gradient side stream, overlapped with the backward
+     events from the engine stream, overlapped with the backward
 and compares B with A on every rank:
   * fp32 engine (deterministic kernels) + fp32 buckets: BIT-FOR-BIT at world 2 (a two-operand fp32 sum has one rounding whatever the ring
     order), <= 1e-6 relative at world > 2 (ring chunking differs between a 188 MB and a 60 MB collective);

@@ -6,9 +6,11 @@ import collections, csv, glob, json, sys
 d = sys.argv[1]
 # the recurrent step is the M=64, N=K=2048 launch of the skinny kernel: grid (128, 2) x 1024 threads (the same kernel also serves
 # many-row GEMMs with other grids; dispatches are keyed by kernel name + grid size so those stay out of the class)
+# patterns are substrings that survive re-templating (round 2 lost the conv classes when the tile kernels gained a wave-count template
+# parameter: "false>(" no longer matched "false, 8>("): the REV flag is matched as ", false," / ", true," anywhere in the argument list
 CLASSES = [("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16, false>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128", "gemm_kernel<h16, 128, 128")),
-           ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr_kernel",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
-           ("conv_tile_fwd", (("conv_tile_kernel", "false>("),)), ("conv_tile_dgrad", (("conv_tile_kernel", "true>("),)), ("adam", ("adam_kernel",))]
+           ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<")),
+           ("conv_tile_fwd", (("conv_tile_kernel<", ", false,"),)), ("conv_tile_dgrad", (("conv_tile_kernel<", ", true,"),)), ("adam", ("adam_kernel",))]
 per = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob(f"{d}/pmc_{name}/**/*counter_collection.csv", recursive=True)
@@ -39,6 +41,9 @@ for r in rows:          # every dispatch row belongs to the FIRST class it match
 for cls, (tot, n) in acc.items():
     if n:
         traffic[cls] = int(tot / n)
+missing = [cls for cls, (tot, n) in acc.items() if not n]
+if missing:
+    print("WARNING: no dispatch matched class(es) " + ", ".join(missing) + " — update CLASSES in tools/pmc_traffic.py", file=sys.stderr)
 json.dump(traffic, open(f"{d}/pmc_traffic.json", "w"), indent=1)
 for k, v in traffic.items():
     print(f"{k:18s} {v / 1e6:10.2f} MB per launch")
