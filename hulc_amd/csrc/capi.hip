@@ -276,7 +276,11 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
         p.work_ctr = ctr;
     }
     bool ok = false;
-    if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
+    // modes 10 / 11 / 17: modes 0 / 1 / 7 on the weights-in-registers kernels (conv_reg.h)
+    if (mode == 17) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 11; }
+    if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
+    else if (mode == 11) ok = launch_conv_reg_fwd<32, 4, 4, 2>(st, p);
+    else if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);
     else if (mode == 2) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
     else if (mode == 3) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);

@@ -22,6 +22,18 @@ void hulc_set_error(const char* fmt, ...);
 
 #define DEVI __device__ __forceinline__
 
+// Kernel-routing / debugging switches.  The PRODUCTION build has none: every HULC_SWITCH("NAME", default) is the compile-time constant
+// `default`, so the library contains exactly one code path per launch site (an environment switch per A/B experiment doubled
+// an untested path each).  An experiment build (`HULC_BUILD_AB=1 python -c "import __graft_entry__ as g; g.build()"`, i.e. -DHULC_AB_SWITCHES)
+// reads the same names from the environment once per process; tools/ab_env.sh needs that build.
+#ifdef HULC_AB_SWITCHES
+#include <cstdlib>
+static inline int hulc_switch_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define HULC_SWITCH(name, dflt) hulc_switch_env(name, dflt)
+#else
+#define HULC_SWITCH(name, dflt) (dflt)
+#endif
+
 #ifdef HULC_HALF_F16
 #define HULC_NS hulc_f16
 #define HULC_HALF_NAME "fp16"

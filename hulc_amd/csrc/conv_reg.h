@@ -1,0 +1,243 @@
+// hulc_amd/csrc/conv_reg.h — forward conv2 / conv3 (NHWC 16-bit activations, 64 output channels) with the WEIGHTS IN REGISTERS.
+//
+// conv_tile.h keeps the packed weight matrix in LDS (64-74 KB of the CU's 160 KB) next to one register-staged band: every MFMA of its
+// loop reads a weight fragment AND an image fragment from LDS (0.75 reads per MFMA at 2 x 4 fragments = 75 % of the matrix-pipe time),
+// the band is staged through 40 prefetch registers and a commit phase, and two barriers per band put all eight waves in lockstep
+// (profiles/r02_conv_tile_phase_stamps.txt: multiply loop 49 % of a band).  Round 3 turns the kernel around:
+//
+//   * v_mfma_f32_32x32x16: A = 32 output channels x 16 k held in REGISTERS for the whole launch (a wave owns one channel half: 32 x K
+//     weights = 128 VGPRs for conv2's K = 512, 144 for conv3's K = 576), B = 32 pixels x 16 k: ONE ds_read_b128 per MFMA and per 16 k
+//     (0.0625 LDS bytes per MAC against 0.094), and no LDS byte spent on weights;
+//   * the freed LDS holds TWO bands (a whole 23 x 23 x 64 frame each for conv3; a third of a 49 x 49 x 32 frame for conv2): the next band
+//     arrives by LDS-DMA (global_load_lds_dwordx4, no staging registers, no commit phase) while the current one is multiplied — one
+//     barrier per band;
+//   * stride-2 input is stored as 2 x 2 row / column parity planes, so the 32 pixels of a fragment are adjacent staged pixels for every
+//     tap; the staged pixel pitch is an ODD number of 16-byte slots (5 / 9), which makes every ds_read_b128 lane group hit 16 distinct
+//     slot residues (conflict-free: MI355X_MICROARCH.md §LDS — the groups {0-3,12-15,20-27}, ... cover all residues mod 16);
+//   * the weight rows are permuted so that a lane ends up with 16 CONSECUTIVE output channels of its pixel (two 16-byte stores), and the
+//     ReLU bitmask the next layer's data-gradient kernel reads is emitted with one cross-half shuffle.
+//
+// Reference arithmetic: nn.Conv2d(32, 64, 4, stride 2) + ReLU, nn.Conv2d(64, 64, 3, stride 1) + ReLU
+// (hulc/models/perceptual_encoders/vision_network.py:38-45, vision_network_gripper.py:12-17); fp32 accumulation, bias added in fp32.
+#pragma once
+#include "conv_tile.h"
+
+namespace HULC_NS {
+
+#ifdef HULC_HALF_F16
+#define MFMA_32x32x16_H __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+#define MFMA_32x32x16_H __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CK, int TA, int TB, int SI>
+struct ConvRegCfg {
+    static constexpr int CH = CK / 8;                          // 16-byte chunks per pixel
+    static constexpr int XSS = (CH & 1) ? CH : CH + 1;         // staged slots per pixel: odd
+    static constexpr int XS = XSS * 16;
+    static constexpr int K = TA * TB * CK, NS = K / 16, KS = CK / 16;
+    static constexpr int NPL = SI * SI;                        // parity planes
+    static constexpr int PF = 10;                              // DMA rounds per band per thread (512 threads x 16 B each)
+    static constexpr size_t band_bytes(int PLR, int PLC) { return ((size_t)NPL * PLR * PLC * XS + 1023) / 1024 * 1024; }   // whole 1 KB DMA pieces
+    static constexpr size_t lds_bytes(int PLR, int PLC) { return 2 * band_bytes(PLR, PLC) + 256; }
+};
+
+// p.LR = input rows of a band, p.RB = output rows of a band, p.LW = IMW, p.LP = plane columns (PLC), p.VPI = plane rows (PLR),
+// p.FPB / p.VPO as in conv_tile.h (stacked small frames: VPO = IMH / SI output-row slots per frame)
+template <int CK, int TA, int TB, int SI>
+__global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
+    using C = ConvRegCfg<CK, TA, TB, SI>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, lj = lane & 31;
+    const int chw = wave & 1, pq = wave >> 1;                  // channel half, pixel quarter of this wave
+    const int PLR = p.VPI, PLC = p.LP, plane_px = PLR * PLC;
+    const size_t bbytes = C::band_bytes(PLR, PLC);
+    lds_char* const lbase = (lds_char*)smem;
+    lds_char* const bl = lbase + 2 * bbytes;                   // bias[64] fp32
+    if (tid < 64) *(__attribute__((address_space(3))) float*)(bl + tid * 4) = p.bias ? p.bias[tid] : 0.f;
+    // ---- weights -> registers (once).  MFMA row i of this wave's A operand carries channel chw*32 + 16*((i>>2)&1) + 4*(i>>3) + (i&3):
+    // with the 32x32 C/D map (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) lane half h then owns channels chw*32 + 16h + reg, reg = 0..15
+    h16x8_t wf[C::NS];
+    {
+        const int chn = chw * 32 + 16 * ((lj >> 2) & 1) + 4 * (lj >> 3) + (lj & 3);
+        const h16_t* wr = p.w + (long long)chn * C::K + h * 8;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) wf[s] = *reinterpret_cast<const h16x8_t*>(wr + s * 16);
+    }
+    // ---- DMA plan: thread (wave, lane) fills LDS slot q = (k*8 + wave)*64 + lane in round k (one wave instruction = 1 KB of consecutive
+    // slots).  Slot -> (plane, plane row, plane col, chunk) -> source (input row, col, chunk); the pad slot of a pixel and the cells beyond
+    // the band re-load a valid chunk (never read).  pk: bits 20..31 input row of the band, bits 0..19 (col * CH + chunk)
+    const int multi = p.FPB > 1;
+    const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
+    const int npieces = (int)(bbytes / 1024), nrounds = (npieces + 7) / 8;      // 1 KB pieces of a band; piece k*8 + wave is this wave's in round k
+    unsigned pk[C::PF];
+    {
+        const float invX = 1.f / (float)C::XSS, invPP = 1.f / (float)plane_px, invPLC = 1.f / (float)PLC;
+#pragma unroll
+        for (int k = 0; k < C::PF; ++k) {
+            const int q = (k * 8 + wave) * 64 + lane;
+            const int ps = fast_div(q, invX);
+            int chunk = q - ps * C::XSS;
+            if (chunk >= C::CH) chunk = 0;
+            int pl = fast_div(ps, invPP);
+            int rem = ps - pl * plane_px;
+            if (pl >= C::NPL) { pl = 0; rem = 0; }
+            const int prow = fast_div(rem, invPLC), pcol = rem - prow * PLC;
+            const int r = min(prow * SI + pl / SI, p.LR - 1), c = min(pcol * SI + pl % SI, p.IMW - 1);
+            pk[k] = ((unsigned)r << 20) | (unsigned)(c * C::CH + chunk);
+        }
+    }
+    const int rowel = p.IMW * CK;
+    auto dma = [&](int item, int bi) {
+        const int f = multi ? item * p.FPB : item / p.nbands, b = multi ? 0 : item % p.nbands;
+        const int nfr = multi ? min(p.FPB, p.Nf - f) : 1;
+        const int r0 = b * p.RB * SI, rmax = nfr * p.IMH - 1;
+        const h16_t* src0 = p.img + (long long)f * p.IMH * rowel;
+        lds_char* dst = lbase + bi * bbytes + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < C::PF; ++k) {
+            if (k >= nrounds || k * 8 + wave >= npieces) break;     // wave-uniform
+            const int r = min(r0 + (int)(pk[k] >> 20), rmax);
+            const h16_t* s = src0 + (long long)r * rowel + (int)(pk[k] & 0xfffffu) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * 8192), 16, 0, 0);
+        }
+    };
+    // per-tap LDS offsets (uniform): plane (ta % SI, tb % SI), shifted by (ta / SI) plane rows and tb / SI columns
+    int toff[TA * TB];
+#pragma unroll
+    for (int t = 0; t < TA * TB; ++t) {
+        const int ta = t / TB, tb = t % TB;
+        toff[t] = ((((ta % SI) * SI + tb % SI) * PLR + ta / SI) * PLC + tb / SI) * C::XS;
+    }
+    const float invPLC = 1.f / (float)PLC, invVPO = 1.f / (float)max(p.VPO, 1);
+    int item = blockIdx.x, nb = 0;
+    if (item < nitems) dma(item, 0);
+    while (item < nitems) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the band has landed (and its stores of the previous band are out)
+        __syncthreads();                                        // ... everyone's has; and every wave is done reading the other buffer
+        const int cur = item;
+        item += (int)gridDim.x;
+        if (item < nitems) dma(item, nb ^ 1);                   // the next band streams in under this band's MFMAs
+        lds_char* const xb = lbase + nb * bbytes;
+        nb ^= 1;
+        const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
+        const int i0 = b * p.RB;
+        const int rows_total = multi ? p.RB : p.OUTH;           // output-row slots of the whole item
+        const int RBe = min(p.RB, rows_total - i0);
+        const int npi = RBe * PLC, ntiles = (npi + 31) >> 5, last = npi - PLC + p.OUTW - 1;
+#pragma unroll 1
+        for (int t0 = pq * 2; t0 < ntiles; t0 += 8) {
+            const bool two = t0 + 1 < ntiles;                   // uniform
+            const int pi0 = t0 * 32 + lj, pi1 = pi0 + 32;
+            lds_char* const x0 = xb + min(pi0, last) * C::XS + h * 16;
+            lds_char* const x1 = xb + min(pi1, last) * C::XS + h * 16;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            if (two) {
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    const int o = toff[s / C::KS] + (s % C::KS) * 32;
+                    const h16x8_t xf0 = *(__attribute__((address_space(3))) h16x8_t*)(x0 + o);
+                    const h16x8_t xf1 = *(__attribute__((address_space(3))) h16x8_t*)(x1 + o);
+                    acc0 = MFMA_32x32x16_H(wf[s], xf0, acc0, 0, 0, 0);
+                    acc1 = MFMA_32x32x16_H(wf[s], xf1, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    const int o = toff[s / C::KS] + (s % C::KS) * 32;
+                    const h16x8_t xf0 = *(__attribute__((address_space(3))) h16x8_t*)(x0 + o);
+                    acc0 = MFMA_32x32x16_H(wf[s], xf0, acc0, 0, 0, 0);
+                }
+            }
+            // ---- epilogue: lane = (pixel lj, half h) holds channels chw*32 + 16h + [0, 16)
+            f32x4 bb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bb[e] = *(__attribute__((address_space(3))) f32x4*)(bl + (chw * 32 + 16 * h + 4 * e) * 4);
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                if (mm == 1 && !two) break;
+                const int pi = mm ? pi1 : pi0;
+                const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
+                bool ok = pi < npi && j < p.OUTW;
+                long long opx;
+                if (multi) {
+                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO;
+                    ok = ok && rr < p.OUTH && f + ff < p.Nf;
+                    opx = ((long long)(f + ff) * p.OUTH + rr) * p.OUTW + j;
+                } else opx = ((long long)f * p.OUTH + i0 + ri) * p.OUTW + j;
+                const f32x16& a = mm ? acc1 : acc0;
+                u32x4_t o[2];
+                unsigned obits = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v0 = fmaxf(a[2 * e] + bb[e >> 1][(2 * e) & 3], 0.f), v1 = fmaxf(a[2 * e + 1] + bb[e >> 1][(2 * e + 1) & 3], 0.f);
+                    const unsigned w = pack2h(v0, v1);
+                    o[e >> 2][e & 3] = w;
+                    obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
+                }
+                if (ok) {
+                    u32x4_t* op = reinterpret_cast<u32x4_t*>(p.out + opx * 64 + chw * 32 + 16 * h);
+                    op[0] = o[0]; op[1] = o[1];
+                }
+                if (p.bits_out) {                               // word chw of the pixel = channels chw*32 .. +31: halves h = 0 / 1 give bits 0..15 / 16..31
+                    unsigned w = obits << (16 * h);
+                    w |= __shfl_xor(w, 32);
+                    if (ok && h == 0) p.bits_out[opx * 2 + chw] = w;
+                }
+            }
+        }
+    }
+}
+
+// host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
+template <int CK, int TA, int TB, int SI>
+static inline bool launch_conv_reg_fwd(hipStream_t st, ConvTileP p) {
+    using C = ConvRegCfg<CK, TA, TB, SI>;
+    if (p.mask || p.maskbits || !p.relu || p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
+    const size_t cap = 160 * 1024 - 64;
+    p.LW = p.IMW;
+    p.LP = (p.IMW + SI - 1) / SI;                               // plane columns = m-index pitch
+    p.FPB = 1; p.VPO = 0;
+    int best_nb = 0;
+    for (int nb = 1; nb <= p.OUTH; ++nb) {
+        const int RB = (p.OUTH + nb - 1) / nb, LR = (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
+        if (C::lds_bytes(PLR, p.LP) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PF * 8192 && LR < 4096) { best_nb = nb; break; }     // PF rounds of 8 x 1 KB
+    }
+    if (!best_nb) return false;
+    p.nbands = best_nb;
+    p.RB = (p.OUTH + best_nb - 1) / best_nb;
+    p.nbands = (p.OUTH + p.RB - 1) / p.RB;
+    p.LR = (p.RB - 1) * SI + TA;
+    p.VPI = (p.LR + SI - 1) / SI;
+    if (best_nb == 1 && p.Nf > 1 && p.IMH % SI == 0) {          // stack FPB frames to a band: a band should feed the 8 waves' 16 tile slots
+        const int vpo = p.IMH / SI;
+        int bestf = 1; double bc = 1e30;
+        for (int fpb = 1; fpb <= 32; ++fpb) {
+            const int LR = fpb * p.IMH, PLR = LR / SI, RB = (LR - TA) / SI + 1;
+            if (C::lds_bytes(PLR, p.LP) > cap || C::band_bytes(PLR, p.LP) > (size_t)C::PF * 8192 || LR >= 4096) break;
+            const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + 7) / 8;     // a wave pass = 2 tiles, 4 pixel quarters
+            const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
+            const double c = (double)((items + wgs - 1) / wgs) * (0.35 + rounds);
+            if (c < bc - 1e-9) { bc = c; bestf = fpb; }
+        }
+        if (bestf > 1) {
+            p.FPB = bestf; p.VPO = vpo;
+            p.LR = bestf * p.IMH; p.VPI = p.LR / SI; p.RB = (p.LR - TA) / SI + 1;
+        }
+    }
+    const size_t lds = C::lds_bytes(p.VPI, p.LP);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_reg_fwd_kernel<CK, TA, TB, SI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        attr_set = true;
+    }
+    const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
+    hipLaunchKernelGGL((conv_reg_fwd_kernel<CK, TA, TB, SI>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
+    return true;
+}
+
+}  // namespace HULC_NS

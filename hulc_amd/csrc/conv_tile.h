@@ -417,7 +417,7 @@ static inline bool launch_conv_tile_nw(hipStream_t st, ConvTileP p) {
     // ---- small frames (whole frame per band and still only a fraction of an 8-wave round): stack FPB frames to a band.  Cost of a launch =
     // bands per workgroup x (per-band overhead + 8-wave rounds of the band's groups); one frame per band leaves most waves without a group
     // (7x7 outputs = 2 groups) and pays the two barriers + staging per frame (tools/ct_stamps.hip: ~2.5 us against a ~5.5 us full round).
-    static const int fpb_env = getenv("HULC_CT_FPB") ? atoi(getenv("HULC_CT_FPB")) : -1;      // A/B: 1 = off, n = force n frames where it fits
+    static const int fpb_env = HULC_SWITCH("HULC_CT_FPB", -1);      // A/B: 1 = off, n = force n frames where it fits
     if (best_nb == 1 && fpb_env != 1 && p.Nf > 1 && (REV || p.IMH % SI == 0)) {
         const int vpi = REV ? p.IMH + TA - 1 : p.IMH, vpo = REV ? vpi : p.IMH / SI;
         auto band_cost = [&](int fpb, int& RBo, int& LRo) -> double {
@@ -462,7 +462,7 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     // none inside the multiply loop) and gain 5-11 % — while one wave sits in its epilogue or group setup three others feed the matrix pipe.  The
     // forward kernels do not fit: the compiler spills the band prefetch registers, i.e. waits for the loads right where they are issued
     // (load phase alone 28 -> 76 us for conv3); they stay at 8 waves.  HULC_CT_NW=8 / 16 forces one width for every kernel (A/B).
-    static const int nw = getenv("HULC_CT_NW") ? atoi(getenv("HULC_CT_NW")) : 0;
+    static const int nw = HULC_SWITCH("HULC_CT_NW", 0);
     if constexpr (REV) { if (nw != 8) return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 16>(st, p); }
     else { if (nw == 16) return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 16>(st, p); }
     return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 8>(st, p);
@@ -577,15 +577,15 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
     // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
     //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
     auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
-    static const int lds_kb = getenv("HULC_C1_LDS") ? atoi(getenv("HULC_C1_LDS")) : 39;   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
-    static const int max_wg = getenv("HULC_C1_WG") ? atoi(getenv("HULC_C1_WG")) : 1024;
+    static const int lds_kb = HULC_SWITCH("HULC_C1_LDS", 39);   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
+    static const int max_wg = HULC_SWITCH("HULC_C1_WG", 1024);
     int R = OH;
     while (R > 1 && lds_of(R) > (size_t)lds_kb * 1024) --R;
     const int nbands = (OH + R - 1) / R;
     R = (OH + nbands - 1) / nbands;
-    static const int fw_env = getenv("HULC_C1_FW") ? atoi(getenv("HULC_C1_FW")) : 0;    // same-box A/B: frame-wise 4.458 vs item-wise 4.440 ms/step -> off
+    static const int fw_env = HULC_SWITCH("HULC_C1_FW", 0);    // same-box A/B: frame-wise 4.458 vs item-wise 4.440 ms/step -> off
     if (!fw_env) dbg |= 32;
-    static const int occ = getenv("HULC_C1_OCC") ? atoi(getenv("HULC_C1_OCC")) : 4;      // min waves per SIMD the register allocation targets: 128 VGPRs (5 spilled) lets all 4 workgroups of a CU be resident (133 -> only 3); A/B on one box: -0.8 % of the step
+    static const int occ = HULC_SWITCH("HULC_C1_OCC", 4);      // min waves per SIMD the register allocation targets: 128 VGPRs (5 spilled) lets all 4 workgroups of a CU be resident (133 -> only 3); A/B on one box: -0.8 % of the step
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv1_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -343,7 +343,7 @@ template <int CI, int CO, int KH, int KW, int S>
 static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                        int OW, int max_blocks, int* work_ctr = nullptr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
-    static const bool v1 = getenv("HULC_WGRAD_V1") != nullptr;
+    static const bool v1 = HULC_SWITCH("HULC_WGRAD_V1", 0) != 0;
     constexpr int NWV = 8;                                   // 16 waves (one co-tile each, 4 waves per SIMD) measured slower: 0.43 vs 0.40 ms/step
     if (!v1) {
         // fewest balanced bands whose chunks fit the 16 x 512 prefetch slots and whose images fit in 160 KB (16 KB kept for the bias reduction)
@@ -356,7 +356,7 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
             // (~5 us, against ~0.5 us of MFMAs for a 7x7 gripper map) are then paid once per FPB frames.  Largest FPB that fits LDS and the prefetch
             // slots and still leaves every workgroup two bands (the second one's loads fly under the first one's MFMAs).
             int fpb = 1;
-            static const int fpb_env = getenv("HULC_WG_FPB") ? atoi(getenv("HULC_WG_FPB")) : -1;     // A/B: 1 = off, n = at most n
+            static const int fpb_env = HULC_SWITCH("HULC_WG_FPB", -1);     // A/B: 1 = off, n = at most n
             if (nb == 1 && IH % S == 0 && fpb_env != 1) {
                 for (int f = 2; f <= 16; ++f) {
                     const int Rf = (f - 1) * (IH / S) + OH, XRf = (Rf - 1) * S + KH;
@@ -374,7 +374,7 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
             }
             const int items = fpb > 1 ? (Nf + fpb - 1) / fpb : Nf * nb;
             const int grid = std::min(std::min(items, 256), max_blocks);
-            static const int dbg = getenv("HULC_WGRAD_DBG") ? atoi(getenv("HULC_WGRAD_DBG")) : 0;   // bench ablation only
+            static const int dbg = HULC_SWITCH("HULC_WGRAD_DBG", 0);   // bench ablation only
             hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
             return grid;
         }
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
 
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
-    static const int v2 = getenv("HULC_W1_V2") ? atoi(getenv("HULC_W1_V2")) : 1;
+    static const int v2 = HULC_SWITCH("HULC_W1_V2", 1);
     if (v2 && !X.u8 && (IW % 4) == 0) {
         // tallest band whose images fit 2 workgroups per CU and whose chunks fit the prefetch slots (8 frame + 2 dY registers of 16 B per thread:
         // 10 + 3 slots spilled 46 registers of in-flight data at the 128-VGPR budget of 2 x 8 waves per CU, which serialised the prefetch)
@@ -845,8 +845,8 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
             return grid;
         }
     }
-    static const int lds_kb = getenv("HULC_W1_LDS") ? atoi(getenv("HULC_W1_LDS")) : 39;   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
-    static const int env_wg = getenv("HULC_W1_WG") ? atoi(getenv("HULC_W1_WG")) : 0;
+    static const int lds_kb = HULC_SWITCH("HULC_W1_LDS", 39);   // 4 workgroups per CU (0.44 vs 0.50 ms/step at 2 per CU with 78 KB bands)
+    static const int env_wg = HULC_SWITCH("HULC_W1_WG", 0);
     if (env_wg > 0) max_blocks = env_wg;
     int R = OH;
     while (R > 1 && Wgrad1Cfg::lds_bytes(R, IW, OW, X.u8) > (size_t)lds_kb * 1024) --R;

@@ -13,12 +13,13 @@
 #include "kernels.h"
 #include "conv_wgrad.h"
 #include "conv_tile.h"
+#include "conv_reg.h"
 
 namespace HULC_NS {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // HULC_DEBUG_SYNC=1: synchronise after every stage and trace its name to stderr (bring-up / fault localisation)
-static inline bool hulc_dbg() { static int v = -1; if (v < 0) { const char* e = getenv("HULC_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+static inline bool hulc_dbg() { static const bool v = HULC_SWITCH("HULC_DEBUG_SYNC", 0) != 0; return v; }
 #define STAGE(name) do { if (hulc_dbg()) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[hulc] stage %s -> %s\n", name, hipGetErrorString(e_)); fflush(stderr); } } while (0)
 #define HIP_CHECK_VOID(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { hulc_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e_)); } } while (0)
 
@@ -139,7 +140,7 @@ struct Engine : IEngine {
         const int H1 = (IH - 8) / 4 + 1, H2 = (H1 - 4) / 2 + 1, H3 = H2 - 2;
         std::string s(pre);
         a.a1 = alloc<T>((int64_t)maxN * H1 * H1 * 32, (s + "a1").c_str());
-        static const bool use_bits = getenv("HULC_MASKBITS") ? atoi(getenv("HULC_MASKBITS")) != 0 : true;
+        static const bool use_bits = HULC_SWITCH("HULC_MASKBITS", 1) != 0;
         a.m1bits = (use_bits && std::is_same<T, h16_t>::value) ? alloc<unsigned>((int64_t)maxN * H1 * H1) : nullptr;   // ReLU bitmask of a1 (conv2 dgrad)
         a.a2 = alloc<T>((int64_t)maxN * H2 * H2 * 64, (s + "a2").c_str());
         a.m2bits = (use_bits && std::is_same<T, h16_t>::value) ? alloc<unsigned>((int64_t)maxN * H2 * H2 * 2) : nullptr;   // ReLU bitmask of a2 (conv3 dgrad), emitted by conv2's forward
@@ -395,7 +396,7 @@ struct Engine : IEngine {
     }
     // dense NT GEMM with tile selection
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
-        static const bool trace = getenv("HULC_TRACE_GEMM") != nullptr;
+        static const bool trace = HULC_SWITCH("HULC_TRACE_GEMM", 0) != 0;
         if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%lld ldb=%lld f32out=%d acc=%d atomic=%d\n", M, N, K, a.s1, b.s1, ep.out_f32, ep.accumulate, ep.atomic);
         const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
         if constexpr (std::is_same<T, h16_t>::value) {
@@ -417,7 +418,7 @@ struct Engine : IEngine {
         }
         else {
             // small-N / short-K GEMMs (transformer, encoder heads) are bound by the exposed L2 latency of each k-step: a deeper BK means fewer of them
-            static const int small_bk = getenv("HULC_SMALL_BK") ? atoi(getenv("HULC_SMALL_BK")) : 128;     // A/B on one box: 4.764 (32) / 4.739 (64) / 4.728 ms per step (128)
+            static const int small_bk = HULC_SWITCH("HULC_SMALL_BK", 128);     // A/B on one box: 4.764 (32) / 4.739 (64) / 4.728 ms per step (128)
             const bool t64 = w64 >= 128 || (M <= 64 && N <= 64);
             if constexpr (std::is_same<T, h16_t>::value) {
                 if (small_bk == 128 && K >= 128) {
@@ -466,7 +467,7 @@ struct Engine : IEngine {
                 hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
                 return;
             }
-            static const bool fused_largem = getenv("HULC_LINBWD_LARGEM") ? atoi(getenv("HULC_LINBWD_LARGEM")) != 0 : false;   // measured 0.25 ms/step SLOWER than transposes + NT GEMM (A/B, same box): off
+            static const bool fused_largem = HULC_SWITCH("HULC_LINBWD_LARGEM", 0) != 0;   // measured 0.25 ms/step SLOWER than transposes + NT GEMM (A/B, same box): off
             if (fused_largem && (long long)N * K <= 2048ll * 512) {
                 // token-major layers (M = B*S): the same kernel, rows split over blockIdx.z (~256 workgroups), partials by atomics
                 const int tiles = cdiv(N, 64) * cdiv(K, 128);
@@ -494,7 +495,7 @@ struct Engine : IEngine {
     void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
                 long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db, float drop_p = 0.f, unsigned long long drop_seed = 0) {
         if constexpr (std::is_same<T, h16_t>::value) {
-            static const bool fused = getenv("HULC_LN_FUSED") ? atoi(getenv("HULC_LN_FUSED")) != 0 : true;
+            static const bool fused = HULC_SWITCH("HULC_LN_FUSED", 1) != 0;
             if (fused) {
                 const int rpb = rows >= 1024 ? 16 : 4;
                 hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
@@ -622,7 +623,10 @@ struct Engine : IEngine {
             ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
             const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
             TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
-            tiled = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2) && launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
+            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 3);      // A/B: bit 0 = conv2, bit 1 = conv3 forward on the weights-in-registers kernel (conv_reg.h)
+            const bool t2 = ((conv_reg & 1) && launch_conv_reg_fwd<32, 4, 4, 2>(st, p2)) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
+            const bool t3 = ((conv_reg & 2) && launch_conv_reg_fwd<64, 3, 3, 1>(st, p3)) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
+            tiled = t2 && t3;
         }
         if (!tiled) {
             {
@@ -684,7 +688,7 @@ struct Engine : IEngine {
         // slab parts over grid.y, each landing with one fp32 atomic per element.  16 parts: more (21 / 24 / 64 for conv3 / conv2 / conv1) made
         // every launch slower (23 / 11.3 / 10.9 us against 18.6 / 9.5 / 9.6: the scattered atomics, not the slab stream, are the cost)
         const int ybl = cdiv(c.O * Kc, 1024);
-        static const int ypart_env = getenv("HULC_UNPACK_Y") ? atoi(getenv("HULC_UNPACK_Y")) : 16;
+        static const int ypart_env = HULC_SWITCH("HULC_UNPACK_Y", 16);
         const int yparts = (!std::is_same<T, float>::value && nsplit >= 64) ? ypart_env : 1;
         hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ybl, yparts), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
@@ -851,7 +855,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(qkv[l], false); lin_fwd(xt[l], EMB, N, tr_in[l], ep, 3 * EMB); }
             // two lanes per query row in the 16-bit engines; the fp32 (parity) engine keeps the one-lane kernel's summation order: the hulc_visonly
             // fixture has an FFN pre-activation within fp32 epsilon of zero, and an epsilon-level change upstream flips its ReLU (1e-3 gradient gate)
-            static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
+            static const bool att32 = (HULC_SWITCH("HULC_ATT32", 1) != 0) && !std::is_same<T, float>::value;
             if (S <= 32 && att32) hipLaunchKernelGGL((attention_fwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             else if (S <= 32) hipLaunchKernelGGL((attention_fwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
             else if (att32) hipLaunchKernelGGL((attention_fwd64_kernel<T>), dim3(B * NH), dim3(256), 0, st, qkv[l], B, S, EMB, NH, Pat[l], ao[l], dp, site_seed(1 + 4 * l));
@@ -986,7 +990,7 @@ struct Engine : IEngine {
         {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
-            static const int ll_block = getenv("HULC_LL_BLOCK") ? atoi(getenv("HULC_LL_BLOCK")) : 64;     // one wave per workgroup: 256 CUs x 1 wave instead of 64 CUs x 4 (the kernel is one long serial chain per thread)
+            static const int ll_block = HULC_SWITCH("HULC_LL_BLOCK", 64);     // one wave per workgroup: 256 CUs x 1 wave instead of 64 CUs x 4 (the kernel is one long serial chain per thread)
             hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, ll_block)), dim3(ll_block), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
             if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);
@@ -1006,7 +1010,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(img, true); lin_fwd(im1, 128, n, cl_im2, ep, GOAL); }
             { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
             { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
-            static const bool clip_wide = getenv("HULC_CLIP_WIDE") ? atoi(getenv("HULC_CLIP_WIDE")) != 0 : true;
+            static const bool clip_wide = HULC_SWITCH("HULC_CLIP_WIDE", 1) != 0;
             if (clip_wide && GOAL <= 32 && !std::is_same<T, float>::value)
                 hipLaunchKernelGGL(clip_loss_wide_kernel, dim3(1), dim3(1024), 0, st, img, txt, n, GOAL, logit_scale, cw, (pair ? losses2 : losses) + 2, dimg, dtxt, dlogit_scale, lscale());
             else
@@ -1243,7 +1247,7 @@ struct Engine : IEngine {
     // The two directions of a bidirectional layer are independent chains of S dependent launches each: advanced in lockstep, one launch (grid.z = 2)
     // carries step i of both — the same work per launch boundary paid once instead of twice (gemm.h: Skinny2).  Direction 0 runs t = 0..S-1,
     // direction 1 (reverse) t = S-1..0.  Shapes the dual launch does not cover fall back to the two sequential recurrences.
-    static bool pair_dirs() { static const bool on = getenv("HULC_PAIR_DIRS") ? atoi(getenv("HULC_PAIR_DIRS")) != 0 : true; return on; }
+    static bool pair_dirs() { static const bool on = HULC_SWITCH("HULC_PAIR_DIRS", 1) != 0; return on; }
     void rnn_fwd2(T* const Zx[2], T* const H[2], const LinW* const whh[2], int B, int S, int act) {
         const long long BH = (long long)B * HID;
         bool dual = false;
@@ -1325,7 +1329,7 @@ struct Engine : IEngine {
             const long long t = at(i);
             const T* hp = i ? g.H + at(i - 1) * BH : nullptr;
             if constexpr (std::is_same<T, h16_t>::value) {      // GEMM + gate arithmetic of the step in one launch (gemm.h: gru_step_lds_kernel)
-                static const bool fused = getenv("HULC_GRU_FUSED") ? atoi(getenv("HULC_GRU_FUSED")) != 0 : true;
+                static const bool fused = HULC_SWITCH("HULC_GRU_FUSED", 1) != 0;
                 if (i && fused) {
                     TimerScope ts(this, "gru_step", "hbm", 2.0 * B * 3 * HID * HID, ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
                     const GruStepP q{hp, whh.W, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH};
@@ -1351,7 +1355,7 @@ struct Engine : IEngine {
             fused_prev = false;
             if (!i) break;
             if constexpr (std::is_same<T, h16_t>::value) {      // carry GEMM + the gate backward of step i-1 in one launch (gemm.h: GruBwdP)
-                static const bool fused = getenv("HULC_GRU_FUSED_BWD") ? atoi(getenv("HULC_GRU_FUSED_BWD")) != 0 : true;
+                static const bool fused = HULC_SWITCH("HULC_GRU_FUSED_BWD", 1) != 0;
                 if (fused && skinny_use_lds) {
                     const long long tp = at(i - 1);
                     GruBwdP gbp{};
@@ -1803,7 +1807,7 @@ struct Engine : IEngine {
                 ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
                 lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
                 { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
-                static const bool att32 = (getenv("HULC_ATT32") ? atoi(getenv("HULC_ATT32")) != 0 : true) && !std::is_same<T, float>::value;
+                static const bool att32 = (HULC_SWITCH("HULC_ATT32", 1) != 0) && !std::is_same<T, float>::value;
                 if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
                 else if (att32) {

@@ -662,7 +662,7 @@ static inline bool gemm_glds_ok(const DenseLoader<h16_t>& a, const DenseLoader<h
     return K >= 64 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);
 }
 static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
-    static const int nw = getenv("HULC_GLDS_NW") ? atoi(getenv("HULC_GLDS_NW")) : 8;
+    static const int nw = HULC_SWITCH("HULC_GLDS_NW", 8);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -1126,7 +1126,7 @@ static inline bool launch_skinny_lds(hipStream_t st, const h16_t* A, long long l
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16));
     const int kq32 = K / 256;
 #define SKL(mt, kq) launch_skinny_lds_t<mt, kq>(st, grid, A, lda, W, ldw, M, N, K, om, ep)
-    static const int nw16 = getenv("HULC_SKINNY_NW16") ? atoi(getenv("HULC_SKINNY_NW16")) : 1;   // A/B: -0.6 % of the step
+    static const int nw16 = HULC_SWITCH("HULC_SKINNY_NW16", 1);   // A/B: -0.6 % of the step
     if (MT == 1) {                                  // M <= 32 recurrent step (32 + 32 windows per GPU): 16-row blocks so that 2 x 128 workgroups fill the chip
         static bool attr1 = false;
         if (!attr1) { hipFuncSetAttribute((const void*)skinny_lds_kernel<1, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
@@ -1162,11 +1162,11 @@ static inline void launch_skinny_nw(hipStream_t st, const h16_t* A, long long ld
     // With only N/16 workgroups (128 at N = 2048) half the CUs idle, so split the rows in two 32-row blocks when that fills the chip.
     int MT = M >= 64 ? 4 : (M + 15) / 16;
     if (M > 32 && (N / 16) * ((M + 63) / 64) <= 160) MT = 2;
-    static const bool mt2k = getenv("HULC_SKINNY_MT2K") ? atoi(getenv("HULC_SKINNY_MT2K")) != 0 : true;
+    static const bool mt2k = HULC_SWITCH("HULC_SKINNY_MT2K", 1) != 0;
     // K = 2048 (GRU recurrent step with N = 3 x 2048; the many-row weight-gradient / small-N GEMMs over 2048 tokens): 32-row blocks keep the
     // LDS-DMA kernel eligible (64 rows x 2048 would not fit LDS) and double the workgroup count of the small-M cases
     if (mt2k && M > 32 && K == 2048 && NW == 8) MT = 2;
-    static const bool mt1 = getenv("HULC_SKINNY_MT1") ? atoi(getenv("HULC_SKINNY_MT1")) != 0 : true;
+    static const bool mt1 = HULC_SWITCH("HULC_SKINNY_MT1", 1) != 0;
     if (mt1 && M > 16 && M <= 32 && K == 2048 && NW == 8 && (N / 16) * 2 <= 320) MT = 1;     // 16-row blocks: twice the workgroups, 128 KB instead of 192 KB each
     if (NW == 8 && skinny_use_lds && launch_skinny_lds(st, A, lda, W, ldw, M, N, K, MT, om, ep)) return;
     dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16)), block(NW * 64);
@@ -1179,7 +1179,7 @@ static inline void launch_skinny_nw(hipStream_t st, const h16_t* A, long long ld
 }
 static inline void launch_skinny(hipStream_t st, const h16_t* A, long long lda, const h16_t* W, long long ldw, int M, int N, int K,
                                  const DenseOut& om, const EpiP& ep) {
-    static const bool kchunk = getenv("HULC_SKINNY_KCHUNK") ? atoi(getenv("HULC_SKINNY_KCHUNK")) != 0 : true;
+    static const bool kchunk = HULC_SWITCH("HULC_SKINNY_KCHUNK", 1) != 0;
     if (kchunk && skinny_use_lds && M > 16 && launch_skinny_lds_kchunk(st, A, lda, W, ldw, M, N, K, om, ep)) return;     // K = n x 2048, M <= 64 (GRU BPTT step)
     if (K % 512 == 0) launch_skinny_nw<8>(st, A, lda, W, ldw, M, N, K, om, ep);     // 8 waves x >=2 k-steps
     else launch_skinny_nw<4>(st, A, lda, W, ldw, M, N, K, om, ep);
@@ -1188,7 +1188,7 @@ static inline bool skinny_ok(int M, int N, int K, long long lda, long long ldw, 
     // many-row use: every 64-row block of A is re-read by each of the N/16 column workgroups -> only when M*N is small
     // (short K: the skinny kernel is shorter per launch at M = 2048, N = 128, K = 128..512 (5 vs 12 us in rocprof) but the step got
     //  0.03 ms SLOWER in an A/B on one box — kept off)
-    static const bool shortk = getenv("HULC_SKINNY_SHORTK") ? atoi(getenv("HULC_SKINNY_SHORTK")) != 0 : false;
+    static const bool shortk = HULC_SWITCH("HULC_SKINNY_SHORTK", 0) != 0;
     const bool shape = M <= 64 || ((shortk || K >= 512) && (long long)M * N <= 524288 && (long long)((M + 63) / 64) * (N / 16) >= 16);
     return shape && (K % 32) == 0 && K >= 128 && (N % 16) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }

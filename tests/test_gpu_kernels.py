@@ -226,3 +226,31 @@ def test_attention_kernels(variant, S, drop_p):
     out.backward(dao.double())
     ref = torch.stack([q.grad, k.grad, v.grad]).permute(1, 3, 0, 2, 4).reshape(B * S, 3 * D)
     assert (dqkv.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
+# the weights-in-registers forward kernels (conv_reg.h): modes 10 / 11 = conv3 / conv2 forward, 17 = conv2 forward that also emits its ReLU bitmask.
+# Shapes: both cameras (static 23 / 49, gripper 9 / 20 with stacked frames), Nf not a multiple of the stack, > 256 frames (several items per workgroup)
+@pytest.mark.parametrize("IH,CI,KH,S,mode,Nf", [(23, 64, 3, 1, 10, 1), (23, 64, 3, 1, 10, 7), (23, 64, 3, 1, 10, 530), (9, 64, 3, 1, 10, 1), (9, 64, 3, 1, 10, 7), (9, 64, 3, 1, 10, 1501),
+                                                (49, 32, 4, 2, 11, 1), (49, 32, 4, 2, 11, 7), (49, 32, 4, 2, 11, 300), (20, 32, 4, 2, 11, 1), (20, 32, 4, 2, 11, 7), (20, 32, 4, 2, 11, 1027),
+                                                (49, 32, 4, 2, 17, 5), (20, 32, 4, 2, 17, 1027), (31, 64, 3, 1, 10, 3), (30, 32, 4, 2, 11, 3)])
+def test_conv_reg_fwd(IH, CI, KH, S, mode, Nf):
+    L, lib = _lib()
+    rng = np.random.default_rng(IH * 10 + Nf)
+    OH = (IH - KH) // S + 1
+    Wb = f64(bf((rng.standard_normal((64, CI, KH, KH)) + np.arange(64)[:, None, None, None] * 0.01) * 0.1))     # asymmetric in the channel index
+    X = bf(rng.standard_normal((Nf, IH, IH, CI)))
+    b = rng.standard_normal(64).astype(np.float32)
+    wf = bf(Wb.transpose(0, 2, 3, 1).reshape(64, -1))
+    out = torch.full((Nf, OH, OH, 64), 7.0, device="cuda", dtype=torch.bfloat16)       # every output must be overwritten
+    bits = torch.full((Nf, OH, OH, 2), -1, device="cuda", dtype=torch.int32) if mode == 17 else None
+    L.check(lib.hulc_k_conv_tile(mode, X.data_ptr(), wf.data_ptr(), torch.from_numpy(b).cuda().data_ptr(), bits.data_ptr() if bits is not None else None,
+                                 out.data_ptr(), Nf, IH, OH, 1, None))
+    torch.cuda.synchronize()
+    ref = conv_fwd_ref(f64(X), Wb, b, S)
+    err = np.abs(f64(out) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
+    assert err.max() < 6e-3, (err.max(), int(err.argmax()))          # bf16 output rounding; worst FRAME
+    if bits is not None:
+        w = bits.to(torch.int64) & 0xFFFFFFFF
+        sh = torch.arange(32, device="cuda")
+        got = ((w[..., None] >> sh) & 1).reshape(Nf, OH, OH, 64).bool()
+        assert torch.equal(got, out > 0)

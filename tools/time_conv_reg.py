@@ -1,0 +1,26 @@
+"""conv2 / conv3 FORWARD on 2048 frames: the LDS-resident-weights kernels (conv_tile.h, modes 0 / 7) against the weights-in-registers kernels
+(conv_reg.h, modes 10 / 17), both cameras' shapes.   python tools/time_conv_reg.py"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hulc_amd import lib as L
+lib = L.load()
+Nf = 2048
+def run(mode, img, w, bias, mask, out, IMH, OUTH, dbg=1):
+    args = (mode, img.data_ptr(), w.data_ptr(), bias.data_ptr(), mask.data_ptr() if mask is not None else None, out.data_ptr(), Nf, IMH, OUTH, dbg, None)
+    for _ in range(3): L.check(lib.hulc_k_conv_tile(*args))
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    for _ in range(10): lib.hulc_k_conv_tile(*args)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 10 * 1e3
+b64 = torch.zeros(64, device="cuda")
+i32 = lambda *s: torch.zeros(s, device="cuda", dtype=torch.int32)
+for cam, (H1, H2, H3) in (("static", (49, 23, 21)), ("gripper", (20, 9, 7))):
+    x2 = torch.randn(Nf, H1, H1, 32, device="cuda").to(torch.bfloat16); w2 = (torch.randn(64, 512, device="cuda") * 0.05).to(torch.bfloat16)
+    x3 = torch.randn(Nf, H2, H2, 64, device="cuda").to(torch.bfloat16); w3 = (torch.randn(64, 576, device="cuda") * 0.05).to(torch.bfloat16)
+    o2 = torch.zeros(Nf, H2, H2, 64, device="cuda", dtype=torch.bfloat16); o3 = torch.zeros(Nf, H3, H3, 64, device="cuda", dtype=torch.bfloat16)
+    bits = i32(Nf, H2, H2, 2)
+    mb2 = (Nf * (H1 * H1 * 32 + H2 * H2 * 64) * 2) / 1e6; mb3 = (Nf * (H2 * H2 * 64 + H3 * H3 * 64) * 2) / 1e6
+    t = dict(tile2=run(7, x2, w2, b64, bits, o2, H1, H2), reg2=run(17, x2, w2, b64, bits, o2, H1, H2), tile3=run(0, x3, w3, b64, None, o3, H2, H3), reg3=run(10, x3, w3, b64, None, o3, H2, H3))
+    print(f"{cam}: conv2 fwd (+bits) tile {t['tile2']:.1f} us -> reg {t['reg2']:.1f} us ({mb2 / t['reg2'] * 1e-3:.2f} TB/s of {mb2:.0f} MB);  "
+          f"conv3 fwd tile {t['tile3']:.1f} us -> reg {t['reg3']:.1f} us ({mb3 / t['reg3'] * 1e-3:.2f} TB/s of {mb3:.0f} MB)")
