@@ -43,11 +43,18 @@ struct ConvRegCfg {
     static constexpr size_t lds_bytes(int PLR, int PLC) { return 2 * band_bytes(PLR, PLC) + 256; }
 };
 
-// p.LR = input rows of a band, p.RB = output rows of a band, p.LW = IMW, p.LP = plane columns (PLC), p.VPI = plane rows (PLR),
-// p.FPB / p.VPO as in conv_tile.h (stacked small frames: VPO = IMH / SI output-row slots per frame)
-template <int CK, int TA, int TB, int SI>
-__global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
+// p.LR = staged rows of a band, p.RB = output rows of a band, p.LW = staged width (REV: IMW + 2 (TB - 1)), p.LP = plane columns (PLC),
+// p.VPI = plane rows (PLR), p.FPB frames per band, p.VPO = output-row slots per frame of a stacked band.
+//
+// REV = false: forward.   out[i][j][cn] = relu( sum_{ta,tb,ck} img[i*SI+ta][j*SI+tb][ck] W[cn][(ta,tb,ck)] + bias[cn] )
+// REV = true (SI = 1): data gradient of a stride-1 convolution = the same correlation over the ZERO-PADDED gradient image
+//   out[i][j][cn] = mask * sum_{ta,tb,ck} P[i + TA-1-ta][j + TB-1-tb][ck] W[cn][(ta,tb,ck)],  P[r][c] = img[r-(TA-1)][c-(TB-1)] or 0;
+//   the border cells are staged from a zero page (p.zeros) by the same DMA; stacked small frames share their TA-1 border rows (a frame
+//   takes IMH + TA - 1 staged rows = exactly its OUTH output rows: no computed row is dropped).
+template <int CK, int TA, int TB, int SI, bool REV>
+__global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
+    static_assert(!REV || SI == 1, "the data-gradient form covers stride 1 (conv3); conv2's parity classes have their own kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, lj = lane & 31;
@@ -67,8 +74,9 @@ __global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
         for (int s = 0; s < C::NS; ++s) wf[s] = *reinterpret_cast<const h16x8_t*>(wr + s * 16);
     }
     // ---- DMA plan: thread (wave, lane) fills LDS slot q = (k*8 + wave)*64 + lane in round k (one wave instruction = 1 KB of consecutive
-    // slots).  Slot -> (plane, plane row, plane col, chunk) -> source (input row, col, chunk); the pad slot of a pixel and the cells beyond
-    // the band re-load a valid chunk (never read).  pk: bits 20..31 input row of the band, bits 0..19 (col * CH + chunk)
+    // slots).  Slot -> (plane, plane row, plane col, chunk) -> staged (row, col, chunk); the pad slot of a pixel and the cells beyond the
+    // band re-load a valid chunk (never read).  pk: bit 31 = column inside the image, bits 20..30 staged row of the band, bits 0..19
+    // (image col * CH + chunk)
     const int multi = p.FPB > 1;
     const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
     const int npieces = (int)(bbytes / 1024), nrounds = (npieces + 7) / 8;      // 1 KB pieces of a band; piece k*8 + wave is this wave's in round k
@@ -85,11 +93,16 @@ __global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
             int rem = ps - pl * plane_px;
             if (pl >= C::NPL) { pl = 0; rem = 0; }
             const int prow = fast_div(rem, invPLC), pcol = rem - prow * PLC;
-            const int r = min(prow * SI + pl / SI, p.LR - 1), c = min(pcol * SI + pl % SI, p.IMW - 1);
-            pk[k] = ((unsigned)r << 20) | (unsigned)(c * C::CH + chunk);
+            const int r = min(prow * SI + pl / SI, p.LR - 1);
+            int c = pcol * SI + pl % SI;
+            unsigned cin = 0x80000000u;
+            if (REV) { c -= TB - 1; if (c < 0 || c >= p.IMW) cin = 0u; }
+            c = min(max(c, 0), p.IMW - 1);
+            pk[k] = cin | ((unsigned)r << 20) | (unsigned)(c * C::CH + chunk);
         }
     }
     const int rowel = p.IMW * CK;
+    const float invVPI = 1.f / (float)(p.IMH + TA - 1);
     auto dma = [&](int item, int bi) {
         const int f = multi ? item * p.FPB : item / p.nbands, b = multi ? 0 : item % p.nbands;
         const int nfr = multi ? min(p.FPB, p.Nf - f) : 1;
@@ -99,27 +112,32 @@ __global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             if (k >= nrounds || k * 8 + wave >= npieces) break;     // wave-uniform
-            const int r = min(r0 + (int)(pk[k] >> 20), rmax);
-            const h16_t* s = src0 + (long long)r * rowel + (int)(pk[k] & 0xfffffu) * 8;
+            const int sr = r0 + (int)((pk[k] >> 20) & 0x7ffu);      // staged row of the item
+            const h16_t* s;
+            if (REV) {        // staged row -> (frame of the stack, image row): rows [0, TA-1) of a frame's IMH + TA - 1 are its zero border
+                const int ff = fast_div(sr, invVPI), r = sr - ff * (p.IMH + TA - 1) - (TA - 1);
+                const bool ok = (pk[k] >> 31) && r >= 0 && r < p.IMH && ff < nfr;
+                s = ok ? src0 + (long long)(ff * p.IMH + r) * rowel + (int)(pk[k] & 0xfffffu) * 8 : p.zeros;
+            } else s = src0 + (long long)min(sr, rmax) * rowel + (int)(pk[k] & 0xfffffu) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * 8192), 16, 0, 0);
         }
     };
-    // per-tap LDS offsets (uniform): plane (ta % SI, tb % SI), shifted by (ta / SI) plane rows and tb / SI columns
+    // per-tap LDS offsets (uniform): plane (ta % SI, tb % SI), shifted by (ta / SI) plane rows and tb / SI columns; REV: the flipped tap
     int toff[TA * TB];
 #pragma unroll
     for (int t = 0; t < TA * TB; ++t) {
-        const int ta = t / TB, tb = t % TB;
+        const int ta = REV ? TA - 1 - t / TB : t / TB, tb = REV ? TB - 1 - t % TB : t % TB;
         toff[t] = ((((ta % SI) * SI + tb % SI) * PLR + ta / SI) * PLC + tb / SI) * C::XS;
     }
     const float invPLC = 1.f / (float)PLC, invVPO = 1.f / (float)max(p.VPO, 1);
     int item = blockIdx.x, nb = 0;
     if (item < nitems) dma(item, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     while (item < nitems) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the band has landed (and its stores of the previous band are out)
-        __syncthreads();                                        // ... everyone's has; and every wave is done reading the other buffer
+        __syncthreads();                                        // every wave's share of this band has landed (each waited for its own DMAs
+                                                                // before arriving) and every wave is done reading the other buffer
         const int cur = item;
         item += (int)gridDim.x;
-        if (item < nitems) dma(item, nb ^ 1);                   // the next band streams in under this band's MFMAs
         lds_char* const xb = lbase + nb * bbytes;
         nb ^= 1;
         const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
@@ -127,10 +145,30 @@ __global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
         const int rows_total = multi ? p.RB : p.OUTH;           // output-row slots of the whole item
         const int RBe = min(p.RB, rows_total - i0);
         const int npi = RBe * PLC, ntiles = (npi + 31) >> 5, last = npi - PLC + p.OUTW - 1;
+        // the next band streams in under this band's MFMAs.  Waves 0-3 issue their DMA pieces now; waves 4-7 (the second wave of each
+        // SIMD) after their first tile pair when they have two, so that one wave of a SIMD starts multiplying at once while the other
+        // spends its ~0.3 us of DMA issue
+        bool pend = item < nitems;
+        if (pend && (wave < 4 || pq * 2 + 8 >= ntiles)) { dma(item, nb); pend = false; }
+        bool waited = false;
 #pragma unroll 1
         for (int t0 = pq * 2; t0 < ntiles; t0 += 8) {
             const bool two = t0 + 1 < ntiles;                   // uniform
             const int pi0 = t0 * 32 + lj, pi1 = pi0 + 32;
+            // output pixels of the two tiles (and, REV, their ReLU mask words — loaded BEFORE the multiply loop)
+            long long opx[2]; bool ok[2]; unsigned mw[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int pi = mm ? pi1 : pi0;
+                const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
+                ok[mm] = pi < npi && j < p.OUTW && (mm == 0 || two);
+                if (multi) {
+                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO;
+                    ok[mm] = ok[mm] && rr < p.OUTH && f + ff < p.Nf;
+                    opx[mm] = ((long long)(f + ff) * p.OUTH + rr) * p.OUTW + j;
+                } else opx[mm] = ((long long)f * p.OUTH + i0 + ri) * p.OUTW + j;
+                if (REV && p.maskbits && ok[mm]) mw[mm] = p.maskbits[opx[mm] * 2 + chw];
+            }
             lds_char* const x0 = xb + min(pi0, last) * C::XS + h * 16;
             lds_char* const x1 = xb + min(pi1, last) * C::XS + h * 16;
             f32x16 acc0, acc1;
@@ -153,72 +191,83 @@ __global__ void __launch_bounds__(512) conv_reg_fwd_kernel(ConvTileP p) {
                     acc0 = MFMA_32x32x16_H(wf[s], xf0, acc0, 0, 0, 0);
                 }
             }
+            if (pend) { dma(item, nb); pend = false; }
+            if (t0 + 8 >= ntiles) {                             // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // multiply loop ago) and the earlier stores are waited for HERE, so that the
+                waited = true;                                  // stores below stay in flight across the barrier
+            }
             // ---- epilogue: lane = (pixel lj, half h) holds channels chw*32 + 16h + [0, 16)
             f32x4 bb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bb[e] = *(__attribute__((address_space(3))) f32x4*)(bl + (chw * 32 + 16 * h + 4 * e) * 4);
+            for (int e = 0; e < 4; ++e) bb[e] = REV ? f32x4{0.f, 0.f, 0.f, 0.f} : *(__attribute__((address_space(3))) f32x4*)(bl + (chw * 32 + 16 * h + 4 * e) * 4);
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 if (mm == 1 && !two) break;
-                const int pi = mm ? pi1 : pi0;
-                const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
-                bool ok = pi < npi && j < p.OUTW;
-                long long opx;
-                if (multi) {
-                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO;
-                    ok = ok && rr < p.OUTH && f + ff < p.Nf;
-                    opx = ((long long)(f + ff) * p.OUTH + rr) * p.OUTW + j;
-                } else opx = ((long long)f * p.OUTH + i0 + ri) * p.OUTW + j;
                 const f32x16& a = mm ? acc1 : acc0;
+                h16_t* const optr = p.out + opx[mm] * 64 + chw * 32 + 16 * h;
+                u32x4_t mk[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+                if (REV && p.mask && ok[mm]) {                  // 16-bit mask values (per-kernel tests)
+                    const u32x4_t* mp = reinterpret_cast<const u32x4_t*>(p.mask + opx[mm] * 64 + chw * 32 + 16 * h);
+                    mk[0] = mp[0]; mk[1] = mp[1];
+                }
                 u32x4_t o[2];
                 unsigned obits = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v0 = fmaxf(a[2 * e] + bb[e >> 1][(2 * e) & 3], 0.f), v1 = fmaxf(a[2 * e + 1] + bb[e >> 1][(2 * e + 1) & 3], 0.f);
+                    float v0 = a[2 * e] + bb[e >> 1][(2 * e) & 3], v1 = a[2 * e + 1] + bb[e >> 1][(2 * e + 1) & 3];
+                    if (!REV || p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    if (REV) {
+                        if (p.maskbits) { v0 = ((mw[mm] >> (16 * h + 2 * e)) & 1u) ? v0 : 0.f; v1 = ((mw[mm] >> (16 * h + 2 * e + 1)) & 1u) ? v1 : 0.f; }
+                        else if (p.mask) { const unsigned m = mk[e >> 2][e & 3]; v0 = h2f_lo(m) > 0.f ? v0 : 0.f; v1 = h2f_hi(m) > 0.f ? v1 : 0.f; }
+                    }
                     const unsigned w = pack2h(v0, v1);
                     o[e >> 2][e & 3] = w;
                     obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
                 }
-                if (ok) {
-                    u32x4_t* op = reinterpret_cast<u32x4_t*>(p.out + opx * 64 + chw * 32 + 16 * h);
+                if (ok[mm]) {
+                    u32x4_t* op = reinterpret_cast<u32x4_t*>(optr);
                     op[0] = o[0]; op[1] = o[1];
                 }
-                if (p.bits_out) {                               // word chw of the pixel = channels chw*32 .. +31: halves h = 0 / 1 give bits 0..15 / 16..31
+                if (!REV && p.bits_out) {                       // word chw of the pixel = channels chw*32 .. +31: halves h = 0 / 1 give bits 0..15 / 16..31
                     unsigned w = obits << (16 * h);
                     w |= __shfl_xor(w, 32);
-                    if (ok && h == 0) p.bits_out[opx * 2 + chw] = w;
+                    if (ok[mm] && h == 0) p.bits_out[opx[mm] * 2 + chw] = w;
                 }
             }
         }
+        if (pend) dma(item, nb);
+        if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI>
-static inline bool launch_conv_reg_fwd(hipStream_t st, ConvTileP p) {
+template <int CK, int TA, int TB, int SI, bool REV>
+static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
-    if (p.mask || p.maskbits || !p.relu || p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
+    if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
+    if (!REV && (p.mask || p.maskbits || !p.relu)) return false;
+    if (REV && (!p.zeros || p.OUTH != p.IMH + TA - 1)) return false;
     const size_t cap = 160 * 1024 - 64;
-    p.LW = p.IMW;
-    p.LP = (p.IMW + SI - 1) / SI;                               // plane columns = m-index pitch
+    p.LW = REV ? p.IMW + 2 * (TB - 1) : p.IMW;
+    p.LP = (p.LW + SI - 1) / SI;                                // plane columns = m-index pitch
     p.FPB = 1; p.VPO = 0;
+    auto fits = [&](int LR, int PLR) { return C::lds_bytes(PLR, p.LP) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PF * 8192 && LR < 2048; };
     int best_nb = 0;
     for (int nb = 1; nb <= p.OUTH; ++nb) {
-        const int RB = (p.OUTH + nb - 1) / nb, LR = (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
-        if (C::lds_bytes(PLR, p.LP) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PF * 8192 && LR < 4096) { best_nb = nb; break; }     // PF rounds of 8 x 1 KB
+        const int RB = (p.OUTH + nb - 1) / nb, LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
+        if (fits(LR, PLR)) { best_nb = nb; break; }
     }
     if (!best_nb) return false;
-    p.nbands = best_nb;
     p.RB = (p.OUTH + best_nb - 1) / best_nb;
     p.nbands = (p.OUTH + p.RB - 1) / p.RB;
-    p.LR = (p.RB - 1) * SI + TA;
+    p.LR = REV ? p.RB + TA - 1 : (p.RB - 1) * SI + TA;
     p.VPI = (p.LR + SI - 1) / SI;
-    if (best_nb == 1 && p.Nf > 1 && p.IMH % SI == 0) {          // stack FPB frames to a band: a band should feed the 8 waves' 16 tile slots
-        const int vpo = p.IMH / SI;
+    if (p.nbands == 1 && p.Nf > 1 && (REV || p.IMH % SI == 0)) {   // stack FPB frames to a band: a band should feed the 8 waves' 16 tile slots
+        const int vpo = REV ? p.IMH + TA - 1 : p.IMH / SI;
         int bestf = 1; double bc = 1e30;
         for (int fpb = 1; fpb <= 32; ++fpb) {
-            const int LR = fpb * p.IMH, PLR = LR / SI, RB = (LR - TA) / SI + 1;
-            if (C::lds_bytes(PLR, p.LP) > cap || C::band_bytes(PLR, p.LP) > (size_t)C::PF * 8192 || LR >= 4096) break;
+            const int LR = REV ? fpb * vpo + TA - 1 : fpb * p.IMH, PLR = (LR + SI - 1) / SI, RB = REV ? fpb * vpo : (LR - TA) / SI + 1;
+            if (!fits(LR, PLR)) break;
             const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + 7) / 8;     // a wave pass = 2 tiles, 4 pixel quarters
             const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
             const double c = (double)((items + wgs - 1) / wgs) * (0.35 + rounds);
@@ -226,18 +275,20 @@ static inline bool launch_conv_reg_fwd(hipStream_t st, ConvTileP p) {
         }
         if (bestf > 1) {
             p.FPB = bestf; p.VPO = vpo;
-            p.LR = bestf * p.IMH; p.VPI = p.LR / SI; p.RB = (p.LR - TA) / SI + 1;
+            p.LR = REV ? bestf * vpo + TA - 1 : bestf * p.IMH; p.VPI = (p.LR + SI - 1) / SI; p.RB = REV ? bestf * vpo : (p.LR - TA) / SI + 1;
         }
     }
     const size_t lds = C::lds_bytes(p.VPI, p.LP);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_fwd_kernel<CK, TA, TB, SI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_fwd_kernel<CK, TA, TB, SI>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
     return true;
 }
+template <int CK, int TA, int TB, int SI>
+static inline bool launch_conv_reg_fwd(hipStream_t st, const ConvTileP& p) { return launch_conv_reg<CK, TA, TB, SI, false>(st, p); }
 
 }  // namespace HULC_NS

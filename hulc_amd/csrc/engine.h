@@ -623,7 +623,7 @@ struct Engine : IEngine {
             ConvTileP p3{}; p3.img = a.a2; p3.IMH = p3.IMW = e.H2; p3.w = e.c3.Wf; p3.out = a.a3; p3.OUTH = p3.OUTW = e.H3; p3.bias = e.c3.b32; p3.relu = 1; p3.Nf = Nf;
             const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
             TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
-            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 3);      // A/B: bit 0 = conv2, bit 1 = conv3 forward on the weights-in-registers kernel (conv_reg.h)
+            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);      // A/B: bit 0 = conv2 forward, bit 1 = conv3 forward, bit 2 = conv3 data gradient on the weights-in-registers kernel (conv_reg.h)
             const bool t2 = ((conv_reg & 1) && launch_conv_reg_fwd<32, 4, 4, 2>(st, p2)) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
             const bool t3 = ((conv_reg & 2) && launch_conv_reg_fwd<64, 3, 3, 1>(st, p3)) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
             tiled = t2 && t3;
@@ -694,13 +694,19 @@ struct Engine : IEngine {
                            c.dW, c.O, c.I, c.KH, c.KW, c.nhwc);
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
+    h16_t* zero_page = nullptr;
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
         if constexpr (std::is_same<T, h16_t>::value) {
             ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = maskbits ? nullptr : mask; p.maskbits = maskbits; p.Nf = g.Nf; p.work_ctr = next_ctr();
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
-            if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);
+            if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) {
+                if (!zero_page) zero_page = alloc<h16_t>(128);      // zero-initialised by alloc(): the staged zero border of the data-gradient form
+                p.zeros = zero_page;
+                ok = ((conv_reg & 4) && maskbits && launch_conv_reg<64, 3, 3, 1, true>(st, p)) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+            }
             else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
             if (ok) return;
         }

@@ -17,6 +17,37 @@ from .trainer import Trainer, get_last_checkpoint
 CONF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
 
 
+def newest_run_with_checkpoint(pattern: str):
+    """The most recently written run directory matching `pattern` ("{now}" = any date/time pair) that holds a checkpoint, or None."""
+    import glob
+    runs = [d for d in glob.glob(pattern.replace("{now}", os.path.join("*", "*"))) if os.path.isdir(d) and get_last_checkpoint(d)]
+    return max(runs, key=lambda d: os.path.getmtime(get_last_checkpoint(d))) if runs else None
+
+
+def resolve_log_dir(log_dir: str, resume: bool, rank: int = 0, world: int = 1) -> str:
+    """`{now}` in log_dir expands to <date>/<time> — a fresh run directory (the reference's hydra.run.dir), decided on rank 0 and shared.
+    `resume=true` instead RE-ENTERS the newest existing run directory of that pattern that holds a checkpoint (a requeued / preempted job
+    continues instead of starting over; the reference gets the same effect from SLURM re-running inside the old Hydra directory); with no
+    such run it starts a fresh one.  An explicit `log_dir=<existing run>` (no `{now}`) is used as is and resumes whenever it holds a
+    checkpoint (training.py:38-46)."""
+    if "{now}" not in log_dir:
+        return log_dir
+    choice = None
+    if rank == 0:
+        choice = newest_run_with_checkpoint(log_dir) if resume else None
+        if choice is None:
+            import time as _t
+            choice = log_dir.replace("{now}", _t.strftime("%Y-%m-%d/%H-%M-%S"))
+        elif resume:
+            print(f"[hulc_amd] resume=true: re-entering {choice}", flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        box = [choice]
+        dist.broadcast_object_list(box, src=0)
+        choice = box[0]
+    return choice
+
+
 def train(overrides=None, conf_dir: str = CONF_DIR):
     cfg = config.compose(conf_dir, "config", overrides or [])
     rank, world, local = parallel.init_from_env()
@@ -27,18 +58,9 @@ def train(overrides=None, conf_dir: str = CONF_DIR):
                             device=device, seed=cfg.seed)
     # The reference runs inside a fresh timestamped Hydra directory (conf/config.yaml hydra.run.dir) and resumes from the newest
     # checkpoint found THERE (training.py:38-46), i.e. only when the same run directory is re-entered.  Here: log_dir may contain
-    # "{now}" (expanded once on rank 0, then shared); the default conf writes runs/<date>/<time>; `resume=true` or an explicit
-    # `log_dir=<existing run>` re-enters a run.
-    log_dir = str(cfg.log_dir)
-    if "{now}" in log_dir:
-        import time as _t
-        stamp = _t.strftime("%Y-%m-%d/%H-%M-%S")
-        if world > 1:
-            import torch.distributed as dist
-            box = [stamp]
-            dist.broadcast_object_list(box, src=0)
-            stamp = box[0]
-        log_dir = log_dir.replace("{now}", stamp)
+    # "{now}" (expanded once on rank 0, then shared); the default conf writes runs/<date>/<time>; `resume=true` re-enters the newest run
+    # of that pattern that holds a checkpoint, an explicit `log_dir=<existing run>` re-enters that run (resolve_log_dir).
+    log_dir = resolve_log_dir(str(cfg.log_dir), bool(cfg.get("resume", False)), rank, world)
     cfg.log_dir = log_dir
     chk = get_last_checkpoint(log_dir)                   # resume like training.py:38-46 (a fresh {now} directory holds none)
     if "lang" not in cfg.datamodule.get("modalities", ["vis", "lang"]):

@@ -206,3 +206,24 @@ def test_bucket_schedule_partitions_buffer_and_reduces_world2():
     for p in ps:
         p.join(60)
     assert all(ok for _, ok, _ in res) and res[0][2] == res[1][2]
+
+
+def test_resume_true_reenters_newest_run_with_checkpoint(tmp_path):
+    """`resume=true` picks the newest run directory under the log_dir pattern that holds a checkpoint; without one (or without the
+    flag) `{now}` expands to a fresh directory; an explicit log_dir is used as is."""
+    import time
+    from hulc_amd import training
+    pat = str(tmp_path / "runs" / "{now}")
+    fresh = training.resolve_log_dir(pat, resume=True)
+    assert fresh.startswith(str(tmp_path / "runs")) and "{now}" not in fresh          # nothing to resume: a fresh run
+    for i, name in enumerate(("2026-01-01/10-00-00", "2026-01-02/09-30-00", "2026-01-03/08-00-00")):
+        d = tmp_path / "runs" / name / "saved_models"
+        d.mkdir(parents=True)
+        if i < 2:                                                                      # the newest directory holds NO checkpoint
+            (d / f"epoch={i}.ckpt").write_bytes(b"x")
+            t = time.time() - 100 + i
+            os.utime(d / f"epoch={i}.ckpt", (t, t))
+    assert training.resolve_log_dir(pat, resume=True) == str(tmp_path / "runs" / "2026-01-02/09-30-00")
+    assert training.resolve_log_dir(pat, resume=False) not in [str(tmp_path / "runs" / n) for n in ("2026-01-01/10-00-00", "2026-01-02/09-30-00")]
+    explicit = str(tmp_path / "runs" / "2026-01-01/10-00-00")
+    assert training.resolve_log_dir(explicit, resume=False) == explicit

@@ -254,3 +254,31 @@ def test_conv_reg_fwd(IH, CI, KH, S, mode, Nf):
         sh = torch.arange(32, device="cuda")
         got = ((w[..., None] >> sh) & 1).reshape(Nf, OH, OH, 64).bool()
         assert torch.equal(got, out > 0)
+
+
+# conv3's data gradient on the weights-in-registers kernel (conv_reg.h, REV form): mode 12 = 16-bit mask values, 18 = the production ReLU bitmask.
+# IH = the layer INPUT size (output of the gradient); 23 / 9 = the two cameras, 31 = two bands per frame; stacked frames with a short last stack
+@pytest.mark.parametrize("IH,Nf,mode", [(23, 1, 12), (23, 7, 12), (23, 530, 18), (9, 1, 12), (9, 7, 18), (9, 1501, 18), (31, 3, 12), (31, 5, 18)])
+def test_conv_reg_dgrad3(IH, Nf, mode):
+    L, lib = _lib()
+    rng = np.random.default_rng(IH * 7 + Nf)
+    OH = IH - 2
+    Wb = f64(bf((rng.standard_normal((64, 64, 3, 3)) + np.arange(64)[None, :, None, None] * 0.01) * 0.1))
+    dY = bf(rng.standard_normal((Nf, OH, OH, 64)) * (np.arange(64) % 5 + 1))
+    wd = np.zeros((1, 64, 3, 3, 64))
+    for kh in range(3):
+        for kw in range(3):
+            wd[0, :, kh, kw, :] = Wb[:, :, kh, kw].T
+    maskv = rng.standard_normal((Nf, IH, IH, 64))
+    dx = torch.full((Nf, IH, IH, 64), 7.0, device="cuda", dtype=torch.bfloat16)      # every pixel must be overwritten
+    if mode == 12:
+        m = bf(maskv)
+    else:                                                                             # bit c%32 of word c/32 = (channel c > 0)
+        bits = (maskv > 0).reshape(Nf, IH, IH, 2, 32).astype(np.int64)
+        words = (bits << np.arange(32)).sum(-1).astype(np.uint32).view(np.int32)
+        m = torch.from_numpy(np.ascontiguousarray(words)).cuda()
+    L.check(lib.hulc_k_conv_tile(mode, dY.data_ptr(), bf(wd.reshape(64, -1)).data_ptr(), None, m.data_ptr(), dx.data_ptr(), Nf, OH, IH, 0, None))
+    torch.cuda.synchronize()
+    ref = conv_dgrad_ref(f64(dY), Wb, 1, IH) * (maskv > 0 if mode == 18 else f64(m) > 0)
+    err = np.abs(f64(dx) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
+    assert err.max() < 6e-3, (err.max(), int(err.argmax()))

@@ -28,8 +28,10 @@ w("config.yaml", """defaults:
   - callbacks: default
   - _self_
 seed: 42
-# one directory per run, like the reference's hydra.run.dir (runs/<date>/<time>): a re-launched command starts fresh; pass log_dir=<run dir> to resume it
+# one directory per run, like the reference's hydra.run.dir (runs/<date>/<time>): a re-launched command starts fresh;
+# resume=true re-enters the newest run directory that holds a checkpoint (requeued jobs), log_dir=<run dir> resumes that run
 log_dir: ./runs/{now}
+resume: false
 """, H.format("conf/config.yaml"))
 
 for name, tgt in (("hulc", "hulc.models.hulc.Hulc"), ("gcbc", "hulc.models.gcbc.GCBC")):

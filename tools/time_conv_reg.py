@@ -21,6 +21,8 @@ for cam, (H1, H2, H3) in (("static", (49, 23, 21)), ("gripper", (20, 9, 7))):
     o2 = torch.zeros(Nf, H2, H2, 64, device="cuda", dtype=torch.bfloat16); o3 = torch.zeros(Nf, H3, H3, 64, device="cuda", dtype=torch.bfloat16)
     bits = i32(Nf, H2, H2, 2)
     mb2 = (Nf * (H1 * H1 * 32 + H2 * H2 * 64) * 2) / 1e6; mb3 = (Nf * (H2 * H2 * 64 + H3 * H3 * 64) * 2) / 1e6
-    t = dict(tile2=run(7, x2, w2, b64, bits, o2, H1, H2), reg2=run(17, x2, w2, b64, bits, o2, H1, H2), tile3=run(0, x3, w3, b64, None, o3, H2, H3), reg3=run(10, x3, w3, b64, None, o3, H2, H3))
-    print(f"{cam}: conv2 fwd (+bits) tile {t['tile2']:.1f} us -> reg {t['reg2']:.1f} us ({mb2 / t['reg2'] * 1e-3:.2f} TB/s of {mb2:.0f} MB);  "
-          f"conv3 fwd tile {t['tile3']:.1f} us -> reg {t['reg3']:.1f} us ({mb3 / t['reg3'] * 1e-3:.2f} TB/s of {mb3:.0f} MB)")
+    t = dict(tile2=run(7, x2, w2, b64, bits, o2, H1, H2), reg2=run(17, x2, w2, b64, bits, o2, H1, H2), tile3=run(0, x3, w3, b64, None, o3, H2, H3), reg3=run(10, x3, w3, b64, None, o3, H2, H3),
+             tiled3=run(8, o3, w3, b64, bits, x3, H3, H2, 32), regd3=run(18, o3, w3, b64, bits, x3, H3, H2, 0))
+    print(f"{cam}: conv2 fwd (+bits) tile {t['tile2']:.1f} us -> reg {t['reg2']:.1f} us ({mb2 / t['reg2']:.2f} TB/s of {mb2:.0f} MB);  "
+          f"conv3 fwd tile {t['tile3']:.1f} us -> reg {t['reg3']:.1f} us ({mb3 / t['reg3']:.2f} TB/s of {mb3:.0f} MB);  "
+          f"conv3 dgrad (bits) tile {t['tiled3']:.1f} us -> reg {t['regd3']:.1f} us")
