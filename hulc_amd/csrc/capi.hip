@@ -279,7 +279,8 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     // modes 10 / 11 / 17: modes 0 / 1 / 7 on the weights-in-registers kernels (conv_reg.h); 12 / 18: modes 2 / 8 (conv3 data gradient, 16-bit mask / bitmask)
     if (mode == 17) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 11; }
     if (mode == 18) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 12; }
-    if (mode == 12) {
+    if (mode == 19) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 13; }      // 13 / 19: modes 3 / 9 (conv2 data gradient, four parity classes)
+    if (mode == 12 || mode == 13) {
         static void* zp = nullptr;
         if (!zp) { if (hipMalloc(&zp, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; } hipMemset(zp, 0, 256); }
         p.zeros = (const h16_t*)zp;
@@ -287,6 +288,7 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
     else if (mode == 11) ok = launch_conv_reg_fwd<32, 4, 4, 2>(st, p);
     else if (mode == 12) ok = launch_conv_reg<64, 3, 3, 1, true>(st, p);
+    else if (mode == 13) ok = launch_conv_reg<64, 2, 2, 1, true, 2>(st, p);
     else if (mode == 0) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p);
     else if (mode == 1) ok = launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p);
     else if (mode == 2) ok = launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);

@@ -20,6 +20,8 @@
 // Reference arithmetic: nn.Conv2d(32, 64, 4, stride 2) + ReLU, nn.Conv2d(64, 64, 3, stride 1) + ReLU
 // (hulc/models/perceptual_encoders/vision_network.py:38-45, vision_network_gripper.py:12-17); fp32 accumulation, bias added in fp32.
 #pragma once
+#include <type_traits>
+
 #include "conv_tile.h"
 
 namespace HULC_NS {
@@ -51,14 +53,20 @@ struct ConvRegCfg {
 //   out[i][j][cn] = mask * sum_{ta,tb,ck} P[i + TA-1-ta][j + TB-1-tb][ck] W[cn][(ta,tb,ck)],  P[r][c] = img[r-(TA-1)][c-(TB-1)] or 0;
 //   the border cells are staged from a zero page (p.zeros) by the same DMA; stacked small frames share their TA-1 border rows (a frame
 //   takes IMH + TA - 1 staged rows = exactly its OUTH output rows: no computed row is dropped).
-template <int CK, int TA, int TB, int SI, bool REV>
+//   OS = 2 (conv2, 4x4 stride 2): one such stride-1 correlation per output parity class (ph, pw) with TA = TB = 2 taps, 32 output channels and
+//   its own weight slab W[(ph,pw)][cn][(ta,tb,ck)]; out[i*2+ph][j*2+pw][cn].  The eight waves are 4 classes x 2 pixel halves (a wave holds its
+//   class's 32 x 256 weights: 64 VGPRs) instead of 2 channel halves x 4 pixel quarters.
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1>
 __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
-    static_assert(!REV || SI == 1, "the data-gradient form covers stride 1 (conv3); conv2's parity classes have their own kernel");
+    static_assert(!REV || SI == 1, "the data-gradient forms are stride-1 correlations (per parity class for OS = 2)");
+    static_assert(OS == 1 || REV, "output parity classes only exist in the data-gradient form");
+    constexpr int NCLS = OS * OS, CN = NCLS == 1 ? 64 : 32, PPARTS = NCLS == 1 ? 4 : 2, WPP = CN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, lj = lane & 31;
-    const int chw = wave & 1, pq = wave >> 1;                  // channel half, pixel quarter of this wave
+    const int cls = NCLS == 1 ? 0 : (wave & 3), ph = cls / OS, pw = cls % OS;
+    const int chw = NCLS == 1 ? (wave & 1) : 0, pq = NCLS == 1 ? (wave >> 1) : (wave >> 2);      // channel half / parity class, pixel part of this wave
     const int PLR = p.VPI, PLC = p.LP, plane_px = PLR * PLC;
     const size_t bbytes = C::band_bytes(PLR, PLC);
     lds_char* const lbase = (lds_char*)smem;
@@ -69,7 +77,7 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     h16x8_t wf[C::NS];
     {
         const int chn = chw * 32 + 16 * ((lj >> 2) & 1) + 4 * (lj >> 3) + (lj & 3);
-        const h16_t* wr = p.w + (long long)chn * C::K + h * 8;
+        const h16_t* wr = p.w + ((long long)cls * CN + chn) * C::K + h * 8;
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) wf[s] = *reinterpret_cast<const h16x8_t*>(wr + s * 16);
     }
@@ -80,30 +88,28 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     const int multi = p.FPB > 1;
     const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
     const int npieces = (int)(bbytes / 1024), nrounds = (npieces + 7) / 8;      // 1 KB pieces of a band; piece k*8 + wave is this wave's in round k
-    unsigned pk[C::PF];
-    {
-        const float invX = 1.f / (float)C::XSS, invPP = 1.f / (float)plane_px, invPLC = 1.f / (float)PLC;
-#pragma unroll
-        for (int k = 0; k < C::PF; ++k) {
-            const int q = (k * 8 + wave) * 64 + lane;
-            const int ps = fast_div(q, invX);
-            int chunk = q - ps * C::XSS;
-            if (chunk >= C::CH) chunk = 0;
-            int pl = fast_div(ps, invPP);
-            int rem = ps - pl * plane_px;
-            if (pl >= C::NPL) { pl = 0; rem = 0; }
-            const int prow = fast_div(rem, invPLC), pcol = rem - prow * PLC;
-            const int r = min(prow * SI + pl / SI, p.LR - 1);
-            int c = pcol * SI + pl % SI;
-            unsigned cin = 0x80000000u;
-            if (REV) { c -= TB - 1; if (c < 0 || c >= p.IMW) cin = 0u; }
-            c = min(max(c, 0), p.IMW - 1);
-            pk[k] = cin | ((unsigned)r << 20) | (unsigned)(c * C::CH + chunk);
-        }
-    }
+    const float invX = 1.f / (float)C::XSS, invPP = 1.f / (float)plane_px, invPLCd = 1.f / (float)PLC;
+    // slot q of a band -> bit 31 = column inside the image, bits 20..30 staged row of the band, bits 0..19 (image col * CH + chunk).  Recomputed per
+    // band (a dozen VALU operations per 16-byte piece) rather than kept in registers: the weights need them
+    auto slot_src = [&](int q) -> unsigned {
+        const int ps = fast_div(q, invX);
+        int chunk = q - ps * C::XSS;
+        if (chunk >= C::CH) chunk = 0;
+        int pl = fast_div(ps, invPP);
+        int rem = ps - pl * plane_px;
+        if (pl >= C::NPL) { pl = 0; rem = 0; }
+        const int prow = fast_div(rem, invPLCd), pcol = rem - prow * PLC;
+        const int r = min(prow * SI + pl / SI, p.LR - 1);
+        int c = pcol * SI + pl % SI;
+        unsigned cin = 0x80000000u;
+        if (REV) { c -= TB - 1; if (c < 0 || c >= p.IMW) cin = 0u; }
+        c = min(max(c, 0), p.IMW - 1);
+        return cin | ((unsigned)r << 20) | (unsigned)(c * C::CH + chunk);
+    };
     const int rowel = p.IMW * CK;
     const float invVPI = 1.f / (float)(p.IMH + TA - 1);
     auto dma = [&](int item, int bi) {
+        if (p.dbg & 4) return;                                  // timing ablation (tools/time_conv_reg.py): no loads
         const int f = multi ? item * p.FPB : item / p.nbands, b = multi ? 0 : item % p.nbands;
         const int nfr = multi ? min(p.FPB, p.Nf - f) : 1;
         const int r0 = b * p.RB * SI, rmax = nfr * p.IMH - 1;
@@ -112,13 +118,16 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
 #pragma unroll
         for (int k = 0; k < C::PF; ++k) {
             if (k >= nrounds || k * 8 + wave >= npieces) break;     // wave-uniform
-            const int sr = r0 + (int)((pk[k] >> 20) & 0x7ffu);      // staged row of the item
+            int q = (k * 8 + wave) * 64 + lane;
+            asm volatile("" : "+v"(q));                             // opaque: keeps the (band-invariant) decode from being hoisted back into ten live registers
+            const unsigned pkk = slot_src(q);
+            const int sr = r0 + (int)((pkk >> 20) & 0x7ffu);        // staged row of the item
             const h16_t* s;
             if (REV) {        // staged row -> (frame of the stack, image row): rows [0, TA-1) of a frame's IMH + TA - 1 are its zero border
                 const int ff = fast_div(sr, invVPI), r = sr - ff * (p.IMH + TA - 1) - (TA - 1);
-                const bool ok = (pk[k] >> 31) && r >= 0 && r < p.IMH && ff < nfr;
-                s = ok ? src0 + (long long)(ff * p.IMH + r) * rowel + (int)(pk[k] & 0xfffffu) * 8 : p.zeros;
-            } else s = src0 + (long long)min(sr, rmax) * rowel + (int)(pk[k] & 0xfffffu) * 8;
+                const bool ok = (pkk >> 31) && r >= 0 && r < p.IMH && ff < nfr;
+                s = ok ? src0 + (long long)(ff * p.IMH + r) * rowel + (int)(pkk & 0xfffffu) * 8 : p.zeros;
+            } else s = src0 + (long long)min(sr, rmax) * rowel + (int)(pkk & 0xfffffu) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * 8192), 16, 0, 0);
         }
     };
@@ -142,18 +151,21 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
         nb ^= 1;
         const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
         const int i0 = b * p.RB;
-        const int rows_total = multi ? p.RB : p.OUTH;           // output-row slots of the whole item
+        const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
+        const int rows_total = multi ? p.RB : NI0;              // output-row slots of the whole item
         const int RBe = min(p.RB, rows_total - i0);
-        const int npi = RBe * PLC, ntiles = (npi + 31) >> 5, last = npi - PLC + p.OUTW - 1;
+        const int npi = RBe * PLC, ntiles = (p.dbg & 2) ? 0 : (npi + 31) >> 5, last = npi - PLC + NJ0 - 1;      // dbg bit 1: no compute
         // the next band streams in under this band's MFMAs.  Waves 0-3 issue their DMA pieces now; waves 4-7 (the second wave of each
         // SIMD) after their first tile pair when they have two, so that one wave of a SIMD starts multiplying at once while the other
         // spends its ~0.3 us of DMA issue
+        // this wave's tiles: a contiguous, balanced share of the band's tiles (10 tiles over 4 parts = 2 + 3 + 2 + 3, walked as pairs + a single)
+        const int tbeg = pq * ntiles / PPARTS, tend = (pq + 1) * ntiles / PPARTS;
         bool pend = item < nitems;
-        if (pend && (wave < 4 || pq * 2 + 8 >= ntiles)) { dma(item, nb); pend = false; }
+        if (pend && (wave < 4 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
         bool waited = false;
 #pragma unroll 1
-        for (int t0 = pq * 2; t0 < ntiles; t0 += 8) {
-            const bool two = t0 + 1 < ntiles;                   // uniform
+        for (int t0 = tbeg; t0 < tend; t0 += 2) {
+            const bool two = t0 + 1 < tend;                     // uniform
             const int pi0 = t0 * 32 + lj, pi1 = pi0 + 32;
             // output pixels of the two tiles (and, REV, their ReLU mask words — loaded BEFORE the multiply loop)
             long long opx[2]; bool ok[2]; unsigned mw[2] = {0xffffffffu, 0xffffffffu};
@@ -161,41 +173,54 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
             for (int mm = 0; mm < 2; ++mm) {
                 const int pi = mm ? pi1 : pi0;
                 const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
-                ok[mm] = pi < npi && j < p.OUTW && (mm == 0 || two);
+                const int ocol = j * OS + pw;
+                ok[mm] = pi < npi && ocol < p.OUTW && (mm == 0 || two);
                 if (multi) {
-                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO;
-                    ok[mm] = ok[mm] && rr < p.OUTH && f + ff < p.Nf;
-                    opx[mm] = ((long long)(f + ff) * p.OUTH + rr) * p.OUTW + j;
-                } else opx[mm] = ((long long)f * p.OUTH + i0 + ri) * p.OUTW + j;
-                if (REV && p.maskbits && ok[mm]) mw[mm] = p.maskbits[opx[mm] * 2 + chw];
+                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO, orow = rr * OS + ph;
+                    ok[mm] = ok[mm] && orow < p.OUTH && f + ff < p.Nf;
+                    opx[mm] = ((long long)(f + ff) * p.OUTH + orow) * p.OUTW + ocol;
+                } else {
+                    const int orow = (i0 + ri) * OS + ph;
+                    ok[mm] = ok[mm] && orow < p.OUTH;
+                    opx[mm] = ((long long)f * p.OUTH + orow) * p.OUTW + ocol;
+                }
+                if (REV && p.maskbits && ok[mm]) mw[mm] = p.maskbits[opx[mm] * WPP + chw];
             }
             lds_char* const x0 = xb + min(pi0, last) * C::XS + h * 16;
             lds_char* const x1 = xb + min(pi1, last) * C::XS + h * 16;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            if (two) {
+            // multiply loop, fully unrolled, image fragments read TWO k-steps ahead through a ring of three register sets: left to itself the
+            // compiler reuses one set and waits for every ds_read right before its MFMA (lgkmcnt(0) between each pair: the matrix pipe sat
+            // idle for the LDS latency at every step — 64 us for conv3's forward against 31 us of MFMA issue)
+            auto mloop = [&](auto TWO) {
+                constexpr bool two_ = decltype(TWO)::value;
+                h16x8_t xa[3], xb[3];
+                auto ld = [&](int s_, int slot) {
+                    const int o = toff[s_ / C::KS] + (s_ % C::KS) * 32;
+                    xa[slot] = *(__attribute__((address_space(3))) h16x8_t*)(x0 + o);
+                    if (two_) xb[slot] = *(__attribute__((address_space(3))) h16x8_t*)(x1 + o);
+                };
+                ld(0, 0);
+                if (C::NS > 1) ld(1, 1);
 #pragma unroll
-                for (int s = 0; s < C::NS; ++s) {
-                    const int o = toff[s / C::KS] + (s % C::KS) * 32;
-                    const h16x8_t xf0 = *(__attribute__((address_space(3))) h16x8_t*)(x0 + o);
-                    const h16x8_t xf1 = *(__attribute__((address_space(3))) h16x8_t*)(x1 + o);
-                    acc0 = MFMA_32x32x16_H(wf[s], xf0, acc0, 0, 0, 0);
-                    acc1 = MFMA_32x32x16_H(wf[s], xf1, acc1, 0, 0, 0);
+                for (int s_ = 0; s_ < C::NS; ++s_) {
+                    if (s_ + 2 < C::NS) ld(s_ + 2, (s_ + 2) % 3);
+                    acc0 = MFMA_32x32x16_H(wf[s_], xa[s_ % 3], acc0, 0, 0, 0);
+                    if (two_) acc1 = MFMA_32x32x16_H(wf[s_], xb[s_ % 3], acc1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);          // the scheduler may not sink the reads of step s+2 below this step's MFMAs
                 }
-            } else {
-#pragma unroll
-                for (int s = 0; s < C::NS; ++s) {
-                    const int o = toff[s / C::KS] + (s % C::KS) * 32;
-                    const h16x8_t xf0 = *(__attribute__((address_space(3))) h16x8_t*)(x0 + o);
-                    acc0 = MFMA_32x32x16_H(wf[s], xf0, acc0, 0, 0, 0);
-                }
-            }
+            };
+            if (p.dbg & 16) {                                   // ablation: no multiply loop
+            } else if (two) mloop(std::true_type{});
+            else mloop(std::false_type{});
             if (pend) { dma(item, nb); pend = false; }
-            if (t0 + 8 >= ntiles) {                             // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
+            if (t0 + 2 >= tend) {                               // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // multiply loop ago) and the earlier stores are waited for HERE, so that the
                 waited = true;                                  // stores below stay in flight across the barrier
             }
+            if ((p.dbg & 8) && acc0[0] != 12345.678f) continue;   // ablation: no epilogue
             // ---- epilogue: lane = (pixel lj, half h) holds channels chw*32 + 16h + [0, 16)
             f32x4 bb[4];
 #pragma unroll
@@ -204,10 +229,10 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
             for (int mm = 0; mm < 2; ++mm) {
                 if (mm == 1 && !two) break;
                 const f32x16& a = mm ? acc1 : acc0;
-                h16_t* const optr = p.out + opx[mm] * 64 + chw * 32 + 16 * h;
+                h16_t* const optr = p.out + opx[mm] * CN + chw * 32 + 16 * h;
                 u32x4_t mk[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
                 if (REV && p.mask && ok[mm]) {                  // 16-bit mask values (per-kernel tests)
-                    const u32x4_t* mp = reinterpret_cast<const u32x4_t*>(p.mask + opx[mm] * 64 + chw * 32 + 16 * h);
+                    const u32x4_t* mp = reinterpret_cast<const u32x4_t*>(p.mask + opx[mm] * CN + chw * 32 + 16 * h);
                     mk[0] = mp[0]; mk[1] = mp[1];
                 }
                 u32x4_t o[2];
@@ -241,34 +266,35 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI, bool REV>
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
     if (!REV && (p.mask || p.maskbits || !p.relu)) return false;
-    if (REV && (!p.zeros || p.OUTH != p.IMH + TA - 1)) return false;
+    const int NI = REV ? (p.OUTH + OS - 1) / OS : p.OUTH;      // output rows to cover (REV: class rows of the largest class)
+    if (REV && (!p.zeros || NI > p.IMH + TA)) return false;
     const size_t cap = 160 * 1024 - 64;
-    p.LW = REV ? p.IMW + 2 * (TB - 1) : p.IMW;
+    p.LW = REV ? NI + TB - 1 : p.IMW;
     p.LP = (p.LW + SI - 1) / SI;                                // plane columns = m-index pitch
     p.FPB = 1; p.VPO = 0;
     auto fits = [&](int LR, int PLR) { return C::lds_bytes(PLR, p.LP) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PF * 8192 && LR < 2048; };
     int best_nb = 0;
-    for (int nb = 1; nb <= p.OUTH; ++nb) {
-        const int RB = (p.OUTH + nb - 1) / nb, LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
+    for (int nb = 1; nb <= NI; ++nb) {
+        const int RB = (NI + nb - 1) / nb, LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
         if (fits(LR, PLR)) { best_nb = nb; break; }
     }
     if (!best_nb) return false;
-    p.RB = (p.OUTH + best_nb - 1) / best_nb;
-    p.nbands = (p.OUTH + p.RB - 1) / p.RB;
+    p.RB = (NI + best_nb - 1) / best_nb;
+    p.nbands = (NI + p.RB - 1) / p.RB;
     p.LR = REV ? p.RB + TA - 1 : (p.RB - 1) * SI + TA;
     p.VPI = (p.LR + SI - 1) / SI;
-    if (p.nbands == 1 && p.Nf > 1 && (REV || p.IMH % SI == 0)) {   // stack FPB frames to a band: a band should feed the 8 waves' 16 tile slots
+    if (p.nbands == 1 && p.Nf > 1 && (REV ? p.OUTH == OS * (p.IMH + TA - 1) : p.IMH % SI == 0)) {   // stack FPB frames to a band: a band should feed the 8 waves' 16 tile slots
         const int vpo = REV ? p.IMH + TA - 1 : p.IMH / SI;
         int bestf = 1; double bc = 1e30;
         for (int fpb = 1; fpb <= 32; ++fpb) {
             const int LR = REV ? fpb * vpo + TA - 1 : fpb * p.IMH, PLR = (LR + SI - 1) / SI, RB = REV ? fpb * vpo : (LR - TA) / SI + 1;
             if (!fits(LR, PLR)) break;
-            const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + 7) / 8;     // a wave pass = 2 tiles, 4 pixel quarters
+            const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + (OS == 1 ? 7 : 3)) / (OS == 1 ? 8 : 4);     // a wave pass = 2 tiles; 4 (2) pixel parts
             const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
             const double c = (double)((items + wgs - 1) / wgs) * (0.35 + rounds);
             if (c < bc - 1e-9) { bc = c; bestf = fpb; }
@@ -281,11 +307,11 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.VPI, p.LP);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
     return true;
 }
 template <int CK, int TA, int TB, int SI>

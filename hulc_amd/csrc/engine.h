@@ -701,13 +701,17 @@ struct Engine : IEngine {
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
-            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);
+            static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 15);      // bit 2: conv3, bit 3: conv2 data gradient on conv_reg.h
             if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);      // zero-initialised by alloc(): the staged zero border of the data-gradient form
                 p.zeros = zero_page;
                 ok = ((conv_reg & 4) && maskbits && launch_conv_reg<64, 3, 3, 1, true>(st, p)) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
             }
-            else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) ok = launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+            else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) {
+                if (!zero_page) zero_page = alloc<h16_t>(128);
+                p.zeros = zero_page;
+                ok = ((conv_reg & 8) && maskbits && launch_conv_reg<64, 2, 2, 1, true, 2>(st, p)) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+            }
             if (ok) return;
         }
         ConvDgradLoader<T> l{dy, g, c.O};

@@ -282,3 +282,30 @@ def test_conv_reg_dgrad3(IH, Nf, mode):
     ref = conv_dgrad_ref(f64(dY), Wb, 1, IH) * (maskv > 0 if mode == 18 else f64(m) > 0)
     err = np.abs(f64(dx) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
     assert err.max() < 6e-3, (err.max(), int(err.argmax()))
+
+
+# conv2's data gradient (4x4 stride 2 -> four parity classes of 2x2-tap correlations) on conv_reg.h: mode 13 = 16-bit mask, 19 = ReLU bitmask (1 word / pixel)
+@pytest.mark.parametrize("IH,Nf,mode", [(49, 1, 13), (49, 5, 19), (49, 300, 19), (20, 1, 13), (20, 7, 19), (20, 1027, 19), (30, 3, 13), (33, 2, 19)])
+def test_conv_reg_dgrad2(IH, Nf, mode):
+    L, lib = _lib()
+    rng = np.random.default_rng(IH * 3 + Nf)
+    OH = (IH - 4) // 2 + 1
+    Wb = f64(bf((rng.standard_normal((64, 32, 4, 4)) + np.arange(32)[None, :, None, None] * 0.02) * 0.1))
+    dY = bf(rng.standard_normal((Nf, OH, OH, 64)) * (np.arange(64) % 5 + 1))
+    wd = np.zeros((4, 32, 2, 2, 64))
+    for kh in range(4):
+        for kw in range(4):
+            wd[(kh % 2) * 2 + kw % 2, :, kh // 2, kw // 2, :] = Wb[:, :, kh, kw].T
+    maskv = rng.standard_normal((Nf, IH, IH, 32))
+    dx = torch.full((Nf, IH, IH, 32), 7.0, device="cuda", dtype=torch.bfloat16)
+    if mode == 13:
+        m = bf(maskv)
+    else:
+        bits = (maskv > 0).astype(np.int64)
+        words = (bits << np.arange(32)).sum(-1).astype(np.uint32).view(np.int32)
+        m = torch.from_numpy(np.ascontiguousarray(words)).cuda()
+    L.check(lib.hulc_k_conv_tile(mode, dY.data_ptr(), bf(wd.reshape(4 * 32, -1)).data_ptr(), None, m.data_ptr(), dx.data_ptr(), Nf, OH, IH, 0, None))
+    torch.cuda.synchronize()
+    ref = conv_dgrad_ref(f64(dY), Wb, 2, IH) * (maskv > 0 if mode == 19 else f64(m) > 0)
+    err = np.abs(f64(dx) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
+    assert err.max() < 6e-3, (err.max(), int(err.argmax()))

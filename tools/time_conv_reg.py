@@ -19,10 +19,21 @@ for cam, (H1, H2, H3) in (("static", (49, 23, 21)), ("gripper", (20, 9, 7))):
     x2 = torch.randn(Nf, H1, H1, 32, device="cuda").to(torch.bfloat16); w2 = (torch.randn(64, 512, device="cuda") * 0.05).to(torch.bfloat16)
     x3 = torch.randn(Nf, H2, H2, 64, device="cuda").to(torch.bfloat16); w3 = (torch.randn(64, 576, device="cuda") * 0.05).to(torch.bfloat16)
     o2 = torch.zeros(Nf, H2, H2, 64, device="cuda", dtype=torch.bfloat16); o3 = torch.zeros(Nf, H3, H3, 64, device="cuda", dtype=torch.bfloat16)
-    bits = i32(Nf, H2, H2, 2)
+    bits = i32(Nf, H2, H2, 2); bits1 = i32(Nf, H1, H1, 1); wd2 = (torch.randn(128, 256, device="cuda") * 0.05).to(torch.bfloat16)
     mb2 = (Nf * (H1 * H1 * 32 + H2 * H2 * 64) * 2) / 1e6; mb3 = (Nf * (H2 * H2 * 64 + H3 * H3 * 64) * 2) / 1e6
     t = dict(tile2=run(7, x2, w2, b64, bits, o2, H1, H2), reg2=run(17, x2, w2, b64, bits, o2, H1, H2), tile3=run(0, x3, w3, b64, None, o3, H2, H3), reg3=run(10, x3, w3, b64, None, o3, H2, H3),
-             tiled3=run(8, o3, w3, b64, bits, x3, H3, H2, 32), regd3=run(18, o3, w3, b64, bits, x3, H3, H2, 0))
+             tiled3=run(8, o3, w3, b64, bits, x3, H3, H2, 32), regd3=run(18, o3, w3, b64, bits, x3, H3, H2, 0),
+             tiled2=run(9, o2, wd2, b64, bits1, x2, H2, H1, 32), regd2=run(19, o2, wd2, b64, bits1, x2, H2, H1, 0))
     print(f"{cam}: conv2 fwd (+bits) tile {t['tile2']:.1f} us -> reg {t['reg2']:.1f} us ({mb2 / t['reg2']:.2f} TB/s of {mb2:.0f} MB);  "
           f"conv3 fwd tile {t['tile3']:.1f} us -> reg {t['reg3']:.1f} us ({mb3 / t['reg3']:.2f} TB/s of {mb3:.0f} MB);  "
-          f"conv3 dgrad (bits) tile {t['tiled3']:.1f} us -> reg {t['regd3']:.1f} us")
+          f"conv3 dgrad (bits) tile {t['tiled3']:.1f} us -> reg {t['regd3']:.1f} us;  conv2 dgrad (bits) tile {t['tiled2']:.1f} us -> reg {t['regd2']:.1f} us")
+
+if os.environ.get("ABLATE"):
+    H1, H2, H3 = 49, 23, 21
+    x2 = torch.randn(Nf, H1, H1, 32, device="cuda").to(torch.bfloat16); w2 = (torch.randn(64, 512, device="cuda") * 0.05).to(torch.bfloat16)
+    x3 = torch.randn(Nf, H2, H2, 64, device="cuda").to(torch.bfloat16); w3 = (torch.randn(64, 576, device="cuda") * 0.05).to(torch.bfloat16)
+    o2 = torch.zeros(Nf, H2, H2, 64, device="cuda", dtype=torch.bfloat16); o3 = torch.zeros(Nf, H3, H3, 64, device="cuda", dtype=torch.bfloat16)
+    bits = i32(Nf, H2, H2, 2)
+    for name, mode, a in (("conv3 fwd", 10, (x3, w3, b64, None, o3, H2, H3)), ("conv2 fwd", 17, (x2, w2, b64, bits, o2, H1, H2)), ("conv3 dgrad", 18, (o3, w3, b64, bits, x3, H3, H2))):
+        r = {k: run(mode, *a, d | (1 if mode != 18 else 0)) for k, d in (("full", 0), ("no-dma", 4), ("no-compute", 2), ("no-epilogue", 8), ("no-mfma", 16), ("no-mfma-no-epi", 24), ("no-dma-no-epi", 12), ("dma-only", 2), ("nothing", 6))}
+        print(name, {k: round(v, 1) for k, v in r.items()})
