@@ -899,12 +899,15 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((plan_gather_t_kernel<T>), dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0T, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
             { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
               gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + DE, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
+            const long long BH = (long long)B * HID;
             { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
+              if (!h0_0) { ep.out2 = H0; ep.out2_lo = 0; ep.out2_hi = BH; ep.out2_relu = 1; }      // h_{-1} = 0: H0[0] = relu(Zx0[0]) written here
               gemm(dense<T>(embg, SB, DE), dense<T>(wih0 + dec_plan, HID, KIN), dense_out(HID), ep, SB, HID, DE); }
-            rnn_fwd(Zx0, H0, whh0, B, S, h0_0);
+            rnn_fwd(Zx0, H0, whh0, B, S, h0_0, 1, false, !h0_0);
             { EpiP ep = epi(Zx1, false); ep.bias = bih1; ep.bias2 = bhh1;
+              if (!h0_1) { ep.out2 = H1; ep.out2_lo = 0; ep.out2_hi = BH; ep.out2_relu = 1; }
               gemm(dense<T>(H0, SB, HID), dense<T>(wih1.W, HID, HID), dense_out(HID), ep, SB, HID, HID); }
-            rnn_fwd(Zx1, H1, whh1, B, S, h0_1);
+            rnn_fwd(Zx1, H1, whh1, B, S, h0_1, 1, false, !h0_1);
             { EpiP ep = epi(heads, true); ep.bias = bheads;
               gemm(dense<T>(H1, SB, HID), dense<T>(wheads, NHEAD, HID), dense_out(NHEAD), ep, SB, NHEAD, HID); }
     }
@@ -1228,13 +1231,14 @@ struct Engine : IEngine {
 
     // H[t] = act(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID].  act 1: ReLU (action decoder), 2: tanh (mcil BiRNN); rev: the
     // recurrence runs from t = S-1 down to 0 (nn.RNN's reverse direction, outputs stay at their own positions)
-    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S, const T* h0 = nullptr, int act = 1, bool rev = false) {
+    // first_done: H[0] = act(Zx[0]) was already written by the GEMM that produced Zx (EpiP::out2)
+    void rnn_fwd(const T* Zx, T* H, const LinW& whh, int B, int S, const T* h0 = nullptr, int act = 1, bool rev = false, bool first_done = false) {
         const long long BH = (long long)B * HID;
         auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i) * BH; };
         if (h0) {
             EpiP ep = epi(H + at(0), false); ep.res = Zx + at(0); ep.res_ld = HID; ep.relu = act;
             gemm(dense<T>(h0, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
-        } else hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx + at(0), H + at(0), BH, act);
+        } else if (!first_done) hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx + at(0), H + at(0), BH, act);
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int i = 1; i < S; ++i) {
             EpiP ep = epi(H + at(i), false); ep.res = Zx + at(i); ep.res_ld = HID; ep.relu = act;
@@ -1242,10 +1246,11 @@ struct Engine : IEngine {
         }
     }
     // dZ[t] = (dH[t] + dZ[t+1] Whh) * act'(H[t]).  dH_last_only: dH is [B][HID], the gradient of the LAST processed state alone.
-    void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S, int act = 1, bool rev = false, bool dH_last_only = false) {
+    // last_done: dZ[S-1] = dH[S-1] * act'(H[S-1]) was already written by the GEMM that produced dH (EpiP::out2)
+    void rnn_bwd(const T* dH, const T* H, T* dZ, const LinW& whh, int B, int S, int act = 1, bool rev = false, bool dH_last_only = false, bool last_done = false) {
         const long long BH = (long long)B * HID;
         auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i) * BH; };
-        hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH_last_only ? dH : dH + at(S - 1), H + at(S - 1), dZ + at(S - 1), BH, act);
+        if (!last_done) hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH_last_only ? dH : dH + at(S - 1), H + at(S - 1), dZ + at(S - 1), BH, act);
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int i = S - 2; i >= 0; --i) {
             EpiP ep = epi(dZ + at(i), false); ep.mask = H + at(i); ep.mask_tanh = act == 2;
@@ -1721,7 +1726,9 @@ struct Engine : IEngine {
         STAGE("clip_bwd");
         {
             // heads
-            { EpiP ep = epi(dH1, false); gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
+            const long long lastBH = (long long)(S - 1) * BH;          // the BPTT's first step (t = S-1) needs no multiplication: written by the GEMM that produces dH
+            { EpiP ep = epi(dH1, false); ep.out2 = dZ1 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H1 + lastBH;
+              gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
             lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
             {
                 const HeadPack hp = head_pack();
@@ -1729,22 +1736,25 @@ struct Engine : IEngine {
                 hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, dwheads_tmp, dbheads_tmp, HID);
             }
             // layer 1 BPTT
-            rnn_bwd(dH1, H1, dZ1, whh1, B, S);
+            rnn_bwd(dH1, H1, dZ1, whh1, B, S, 1, false, false, true);
             {
                 const int mp = ldpad(SB);
-                transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp);
+                constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // 16-bit engines: the dZ transpose adds its column sums (= both bias gradients) on the way
+                transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp, fuse_cs ? dbih1 : nullptr, fuse_cs ? dbhh1 : nullptr);
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
                 { EpiP ep = epi(wih1.dW, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
-                colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
+                if (!fuse_cs) colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
             }
-            { EpiP ep = epi(dH0, false); gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            { EpiP ep = epi(dH0, false); ep.out2 = dZ0 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H0 + lastBH;
+              gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
             // layer 0 BPTT
-            rnn_bwd(dH0, H0, dZ0, whh0, B, S);
+            rnn_bwd(dH0, H0, dZ0, whh0, B, S, 1, false, false, true);
             {
                 const int mp = ldpad(SB);
-                transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp);
+                // the column sums of dZ0 over all (t, b) rows = those of dC = sum_t dZ0: both bias gradients of layer 0 ride on this transpose too
+                transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp, std::is_same<T, h16_t>::value ? dbih0 : nullptr, std::is_same<T, h16_t>::value ? dbhh0 : nullptr);
                 if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
@@ -1754,7 +1764,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(demb + (EMB - DE), true); ep.accumulate = 1;
               gemm(dense<T>(dZ0, SB, HID), dense<T>(wih0T + (long long)dec_plan * HID, DE, HID), dense_out_map(B, EMB, (long long)S * EMB), ep, SB, DE, HID); }
             hipLaunchKernelGGL((sum_over_t_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dZ0, S, BH, dC);
-            colsum(dC, HID, B, HID, dbih0, dbhh0);
+            if constexpr (!std::is_same<T, h16_t>::value) colsum(dC, HID, B, HID, dbih0, dbhh0);
             { EpiP ep = epi(dgoal, true); ep.accumulate = 1;
               gemm(dense<T>(dC, B, HID), dense<T>(wih0T + (long long)(dec_plan + DE) * HID, GOAL, HID), dense_out(GOAL), ep, B, GOAL, HID); }
             {

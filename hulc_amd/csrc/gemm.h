@@ -37,6 +37,14 @@ struct EpiP {
     float alpha = 1.f;
     float drop_p = 0.f;          // inverted dropout applied after relu/mask (seeded by element offset)
     unsigned long long drop_seed = 0;
+    // second store of the elements whose offset lies in [out2_lo, out2_hi) (both multiples of 4): out2[o - out2_lo] = T(f(v)), f = ReLU
+    // (out2_relu) or the ReLU mask of out2_mask[o - out2_lo].  The batched GEMM in front of a recurrence writes the step that needs no
+    // multiplication with it: H[0] = relu(Zx[0]) (h_{-1} = 0) going forward, dZ[S-1] = dH[S-1] * (H[S-1] > 0) going backward — each was a
+    // 5 us elementwise launch at the head of a chain of dependent launches
+    void* out2 = nullptr;
+    long long out2_lo = 0, out2_hi = 0;
+    const void* out2_mask = nullptr;
+    int out2_relu = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -271,6 +279,12 @@ DEVI void epi_store(const EpiP& ep, float accv, int rrow, int col, long long o) 
         T* op = reinterpret_cast<T*>(ep.out) + o;
         *op = from_f<T>(ep.accumulate ? (to_f<T>(*op) + v) : v);
     }
+    if (ep.out2 && o >= ep.out2_lo && o < ep.out2_hi) {
+        const long long o2 = o - ep.out2_lo;
+        float w = ep.out2_relu ? fmaxf(v, 0.f) : v;
+        if (ep.out2_mask) w = to_f<T>(reinterpret_cast<const T*>(ep.out2_mask)[o2]) > 0.f ? w : 0.f;
+        reinterpret_cast<T*>(ep.out2)[o2] = from_f<T>(w);
+    }
 }
 
 // 4 consecutive output columns of one row (the MFMA is issued as D^T = B A^T, so a lane owns C[row][col..col+3]):
@@ -368,6 +382,26 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
             *reinterpret_cast<uint2*>(op) = w;
         } else {
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    if (ep.out2 && o >= ep.out2_lo && o < ep.out2_hi) {          // (accumulate is never combined with out2)
+        const long long o2 = o - ep.out2_lo;
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = ep.out2_relu ? fmaxf(v[r], 0.f) : v[r];
+        T* op2 = reinterpret_cast<T*>(ep.out2) + o2;
+        if (ep.out2_mask) {
+            const T* mp = reinterpret_cast<const T*>(ep.out2_mask) + o2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = to_f<T>(mp[r]) > 0.f ? w[r] : 0.f;
+        }
+        if constexpr (sizeof(T) == 2) {
+            uint2 u;
+            u.x = pack2h(w[0], w[1]);
+            u.y = pack2h(w[2], w[3]);
+            *reinterpret_cast<uint2*>(op2) = u;
+        } else {
+            *reinterpret_cast<float4*>(op2) = make_float4(w[0], w[1], w[2], w[3]);
         }
     }
 }

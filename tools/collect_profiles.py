@@ -1,15 +1,17 @@
 """Copy the summaries of gpurun_out/<tag>/ (written by tools/refresh_profiles.sh on the GPU box) into profiles/<tag>_* and regenerate the
-number-bearing tables of profiles/README.md from them.   usage: python tools/collect_profiles.py r02"""
+number-bearing tables of profiles/README.md from them.   usage: python tools/collect_profiles.py r03"""
 import json, os, shutil, sys, csv
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-T = sys.argv[1] if len(sys.argv) > 1 else "r02"
+T = sys.argv[1] if len(sys.argv) > 1 else "r03"
+RN = int(T[1:])
 O = os.path.join(ROOT, "gpurun_out", T)
 P = lambda f: os.path.join(ROOT, "profiles", f)
 copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.csv", "kernel_stats_summary.txt": "kernel_stats_summary.txt",
           "pmc_hbm_per_kernel.csv": "pmc_hbm_per_kernel.csv", "pmc_traffic.json": "pmc_traffic.json", "sq/mfma_util.csv": "mfma_util.csv",
           "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
-          "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt"}
-for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru"):
+          "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt", "conv_reg_vs_tile.txt": "conv_reg_vs_tile.txt", "conv_reg_ablation.txt": "conv_reg_ablation.txt",
+          "step_timeline.txt": "step_timeline.txt"}
+for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
     if os.path.exists(os.path.join(O, src)):
@@ -36,7 +38,8 @@ grows = "| GEMM group | MFMA-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (time 
 for name, pred in groups:
     u, tf, tus = grp(pred)
     grows += f"| {name} | {u:.3f} | {tf:.0f} | {tf / 25.0:.1f} % | {tus:.0f} |\n"
-var = {k: J("_" + k) for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru")}
+var = {k: J("_" + k) for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d")}
+sm, rs = d.get("step_ms") or {}, d.get("roofline_step") or {}
 sc = var["s64_fp16"].get("loss_scaler") or {}
 files = f"""| file | what | command |
 |---|---|---|
@@ -54,15 +57,19 @@ files = f"""| file | what | command |
 | `{T}_pmc_hbm_per_kernel.csv`, `{T}_pmc_traffic.json` | FETCH_SIZE / WRITE_SIZE per dispatch (two separate `--pmc` passes) and the per-launch HBM bytes per kernel class, `(2 x FETCH_SIZE + WRITE_SIZE) x 1024` (MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE reports half of a wide coalesced read; calibration: `adam` reads 5 and writes 3.5 arrays of 47.05 M fp32 = 1.41 GB algorithmic against {t.get('adam', 0) / 1e9:.2f} GB measured); every dispatch is counted in the FIRST class it matches, so the recurrent-step dispatches (keyed by their grid) are not in `skinny_gemm`; `bench.py` reports the dominant class's value as `roofline.traffic` | `tools/pmc_traffic.py` |
 | `{T}_mfma_util.csv`, `{T}_mfma_util_summary.txt` | per kernel: MFMA-pipe utilisation, `SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES`, MFMA TFLOP/s from `SQ_INSTS_VALU_MFMA_MOPS_BF16`, LDS bank-conflict rate (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE`), wait breakdown — two SQ passes of 8 counters | `tools/pmc_sq.sh`, `tools/pmc_sq_summary.py` |
 | `{T}_step_sequence.txt` | every launch of ONE step in order (consecutive identical launches collapsed) from the same kernel trace: launches per step, which memsets / transposes / small kernels remain and how long each takes.  The per-step call counts of `{T}_kernel_stats_summary.txt` divide a 9-step profile that also holds the engine's one-time workspace zero-fills (≈160 `fillBufferAligned`) and bench.py's input generation; a step itself issues 3 memsets (gradient buffer, loss slots, the backward's zero arena) | `tools/step_seq.py` |
+| `{T}_bench_n1_fp32.json` | the fp32 PARITY engine (exact-fp32 MFMA, `v_mfma_f32_16x16x4_f32`: 1/16 of the bf16 matrix rate): {var['fp32']['value']:.0f} windows/s, {var['fp32']['ms_per_step']} ms/step | `python bench.py --dtype fp32 --steps 20 --no-cpu-baseline` |
+| `{T}_bench_n1_u8_h2d.json` | uint8 ingest with every step's frames copied from PINNED HOST memory (async H2D on a copy stream, double-buffered; 289 MB per step): {var['u8_h2d']['value']:.0f} windows/s, median step {(var['u8_h2d'].get('step_ms') or {{}}).get('median')} ms — PCIe-bound, SURVEY §8(d)'s H2D-inclusive row (never the headline) | `python bench.py --ingest u8 --h2d 1 --no-cpu-baseline` |
+| `{T}_conv_reg_vs_tile.txt`, `{T}_conv_reg_ablation.txt` | conv2 / conv3 forward and data gradient on 2048 frames: LDS-resident-weights kernels (conv_tile.h) against the weights-in-registers kernels (conv_reg.h); and conv_reg with phases switched off (no DMA / no multiply loop / no epilogue) | `tools/time_conv_reg.py`, `ABLATE=1 tools/time_conv_reg.py` |
+| `{T}_step_timeline.txt` | every launch of one step with start offset, duration, gap and queue | `tools/step_timeline.py` |
 | `{T}_conv_tile_gripper_fpb.txt` | the four conv tile kernels on the gripper camera's shapes with 1 frame per band and with the stacked bands the launch picks | `tools/time_conv_tile_gripper.py` |
 | `{T}_conv_tile_phase_stamps.txt` | shader-clock stamps of the phases of every band of the raw-tile conv kernels (what the conv work of this round was steered by) | `tools/bin/ct_stamps` (tools/ct_stamps.hip) |
 | `{T}_gridbar_xcd_barrier.txt`, `{T}_gridbar_naive_barrier.txt` | grid barrier + cross-XCD exchange cost with the fast primitives (XCD-hierarchical barrier, relaxed polls, `sc1` write-through publish) and with round 1's acquire-polled single counter | `tools/bin/gridbar2`, `tools/bin/gridbar` |
 """
 s = open(P("README.md")).read()
-marker = "<!-- BEGIN generated by tools/collect_profiles.py -->"
-end = "<!-- END generated -->"
+marker = f"<!-- BEGIN generated {T} (tools/collect_profiles.py) -->"
+end = f"<!-- END generated {T} -->"
 gen = f"""{marker}
-## Round 2 files (`{T}_*`)
+## Round {RN} files (`{T}_*`)
 
 {files}
 ### Kernel classes, HIP-event timed inside bench.py (survey pass; includes event overhead)
@@ -74,21 +81,25 @@ Dominant class `{rl['kernel']}`: {rl['launches_per_step']:.0f} launches/step, {r
 ### MFMA utilisation per GEMM group (rocprofv3 SQ counters, `{T}_mfma_util.csv`)
 
 {grows}
+Per-step device times (HIP events at the step boundaries, {d['steps']} timed steps): median {sm.get('median')} ms, p10 {sm.get('p10')}, p90 {sm.get('p90')} (wall-clock mean {d['ms_per_step']}).
+Whole step against both ceilings with SURVEY §8(d)'s algorithmic work (`roofline_step`): {rs.get('algorithmic_bytes_per_step', 0) / 1e9:.2f} GB -> **{(rs.get('hbm_frac') or 0) * 100:.1f} % of the 8 TB/s HBM
+roofline**, {(rs.get('mfma_frac') or 0) * 100:.1f} % of the bf16 MFMA peak; binding ceiling {rs.get('binding')} = {rs.get('ceiling_windows_per_s')} windows/s.
 Whole step: {d['step_tflops']} TFLOP/s algorithmic (13.02 GFLOP/window x {d['value']:.0f} windows/s) = {d['step_tflops'] / 2500 * 100:.1f} % of the 2.5 PFLOP/s bf16 MFMA peak.
 cpu_baseline (`kind: port`): {cb['value']} windows/s with {cb['cores']} BLAS threads — {cb['sample']}; sweep {[(r['threads'], r['windows_per_s']) for r in cb['sweep']]};
 reference_anchor (the unmodified reference in the survey container, BASELINE.md §2): {cb['reference_anchor']['value']} windows/s on 8 vCPU.
 {end}"""
 if marker in s:
     s = s[:s.index(marker)] + gen + s[s.index(end) + len(end):]
-else:
-    s = s.rstrip() + "\n\n" + gen + "\n"
+else:                       # a new round: its block goes where the README marks it (or at the end)
+    slot = f"<!-- {T} generated block goes here -->"
+    s = s.replace(slot, gen) if slot in s else s.rstrip() + "\n\n" + gen + "\n"
 open(P("README.md"), "w").write(s)
 r = open(os.path.join(ROOT, "README.md")).read()
 m0, m1 = "<!-- BEGIN numbers (tools/collect_profiles.py) -->", "<!-- END numbers -->"
 txt = f"""{m0}
-Round 2 (1 x MI355X, B=64 windows, seq_len 32, bf16): **{d['value'] / 1000:.1f} k trajectory-windows/s, {d['ms_per_step']} ms/step** at the reference's fp32
-boundary (round 1: 13.7 k / 4.686 ms); {var['fp16']['value'] / 1000:.1f} k in fp16 with the on-device GradScaler (the reference's `precision: 16`);
-{var['u8']['value'] / 1000:.1f} k with uint8 ingest; {var['vislang']['value'] / 1000:.1f} k for 32 vis + 32 lang + CLIP as one paired pass ({var['vislang_seq']['value'] / 1000:.1f} k with the reference's one pass per
+Round {RN} (1 x MI355X, B=64 windows, seq_len 32, bf16): **{d['value'] / 1000:.1f} k trajectory-windows/s, {d['ms_per_step']} ms/step** (median step {sm.get('median')} ms) at the
+reference's fp32 boundary (round 1: 13.7 k / 4.686 ms; round 2: 14.9 k / 4.304 ms); {var['fp32']['value'] / 1000:.2f} k on the fp32 parity engine; {var['fp16']['value'] / 1000:.1f} k in fp16 with the on-device GradScaler (the reference's `precision: 16`);
+{var['u8']['value'] / 1000:.1f} k with uint8 ingest ({var['u8_h2d']['value'] / 1000:.1f} k when every step's frames also cross PCIe from pinned host memory); {var['vislang']['value'] / 1000:.1f} k for 32 vis + 32 lang + CLIP as one paired pass ({var['vislang_seq']['value'] / 1000:.1f} k with the reference's one pass per
 modality); BASELINE config 5 (seq_len 64 x 32 windows, fp16): {var['s64_fp16']['value'] / 1000:.2f} k.  CPU baseline (the step on torch's CPU library kernels, host cores of
 the GPU box): {cb['value']} windows/s with {cb['cores']} threads; the reference itself did 8.0-12.2 windows/s on 8 vCPU (BASELINE.md).
 Validation forward and stateful rollout (`validation_step`, `reset`/`step`, also for GCBC) run on the same kernels; the reference's `model=mcil`

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): regenerates every measurement profiles/ holds for a round into gpurun_out/<tag>/ (default tag r02);
+# Runs ON THE GPU BOX (via gpurun): regenerates every measurement profiles/ holds for a round into gpurun_out/<tag>/ (default tag r03);
 # `tools/collect_profiles.py <tag>` then copies the summaries into profiles/ and rewrites profiles/README.md.
 #   1. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) -> per-kernel-class HBM bytes per launch (pmc_traffic.json)
 #   2. rocprofv3 --kernel-trace --stats of the bench command (9 steps: 2 warm-up + 2 survey + 5 timed)
 #   3. two SQ counter passes (tools/pmc_sq.sh): MFMA-pipe utilisation, LDS bank conflicts, wait breakdown per kernel (mfma_util.csv)
 #   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
 #   5. the probes behind DESIGN.md's numbers: tools/bin/ct_stamps (conv tile phases), tools/bin/gridbar2 (XCD barrier + sc1 publish)
-T=${1:-r02}
+T=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$T
@@ -35,6 +35,11 @@ b vislang --lang 1
 b vislang_seq --lang 1 --pair 0
 b mcil --model mcil
 b mcil_gru --model mcil_gru
+b fp32 --dtype fp32 --steps 20                # the parity engine's throughput (v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 rate)
+b u8_h2d --ingest u8 --h2d 1                  # every step's uint8 frames copied from PINNED HOST memory (SURVEY 8(d)'s PCIe-inclusive row)
+python tools/time_conv_reg.py > $O/conv_reg_vs_tile.txt 2>/dev/null
+ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -3 > $O/conv_reg_ablation.txt
+python tools/step_timeline.py $O/stats "" 400 > $O/step_timeline.txt 2>&1
 test -x tools/bin/ct_stamps && timeout 120 tools/bin/ct_stamps > $O/ct_stamps.txt 2>&1
 test -x tools/bin/gridbar2 && timeout 120 tools/bin/gridbar2 > $O/gridbar2.txt 2>&1
 test -x tools/bin/gridbar && timeout 120 tools/bin/gridbar > $O/gridbar.txt 2>&1
