@@ -14,6 +14,7 @@
 #include "conv_wgrad.h"
 #include "conv_tile.h"
 #include "conv_reg.h"
+#include "tr_fused.h"
 
 namespace HULC_NS {
 
@@ -860,8 +861,29 @@ struct Engine : IEngine {
     void pr_fwd(int B, int S, float dp) {
         const int N = B * S;
         // ---- plan recognition transformer (plan_recognition_net.py:94-117)
-        hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0));
-        for (int l = 0; l < 2; ++l) {
+        bool fused = false;
+        if constexpr (std::is_same<T, h16_t>::value) {
+            static const bool tr_fused = HULC_SWITCH("HULC_TR_FUSED", 1) != 0;
+            fused = tr_fused && S <= 32;
+        }
+        hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0),
+                           fused ? y2[0] : (float*)nullptr, fused ? y2[1] : (float*)nullptr);
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (fused) {        // one launch per encoder layer (tr_fused.h); norm2 of layer 0 is the first step of layer 1's launch, the last norm2 a LayerNorm launch
+                for (int l = 0; l < 2; ++l) {
+                    TrLayerP q{};
+                    q.xin = l ? y2[0] : xf[0]; q.ln_in = l; q.ln_g = tr_n2g[0]; q.ln_b = tr_n2b[0]; q.xf_out = xf[1]; q.xt_out = xt[1]; q.st_out = st2[0];
+                    q.Wqkv = tr_in[l].W; q.Wo = tr_out[l].W; q.W1 = tr_l1[l].W; q.W2 = tr_l2[l].W;
+                    q.bqkv = tr_in[l].b32; q.bo = tr_out[l].b32; q.b1 = tr_l1[l].b32; q.b2 = tr_l2[l].b32; q.n1g = tr_n1g[l]; q.n1b = tr_n1b[l];
+                    q.qkv = qkv[l]; q.Pat = Pat[l]; q.ao = ao[l]; q.y1 = y1[l]; q.st1 = st1[l]; q.x1t = x1t[l]; q.x1f = x1f[l]; q.hff = hff[l]; q.y2 = y2[l];
+                    q.B = B; q.S = S; q.dp = dp;
+                    q.seed_att = site_seed(1 + 4 * l); q.seed_o = site_seed(2 + 4 * l); q.seed_h = site_seed(3 + 4 * l); q.seed_y = site_seed(4 + 4 * l);
+                    launch_tr_layer_fwd(st, q);
+                }
+                ln_fwd(y2[1], EMB, N, EMB, tr_n2g[1], tr_n2b[1], xt[2], EMB, xf[2], EMB, st2[1]);
+            }
+        }
+        for (int l = 0; l < 2 && !fused; ++l) {
             { EpiP ep = epi(qkv[l], false); lin_fwd(xt[l], EMB, N, tr_in[l], ep, 3 * EMB); }
             // two lanes per query row in the 16-bit engines; the fp32 (parity) engine keeps the one-lane kernel's summation order: the hulc_visonly
             // fixture has an FFN pre-activation within fp32 epsilon of zero, and an epsilon-level change upstream flips its ReLU (1e-3 gradient gate)

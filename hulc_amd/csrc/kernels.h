@@ -646,9 +646,10 @@ __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* 
 // x0[b,t,:] = emb[b,t,:] + pos[t,:] (+ dropout)  -> fp32 residual stream and T GEMM operand
 template <typename T>
 __global__ void posadd_kernel(const T* __restrict__ emb, const float* __restrict__ pos, int B, int S, int D, float* __restrict__ xf,
-                              T* __restrict__ xt, float drop_p, unsigned long long seed) {
+                              T* __restrict__ xt, float drop_p, unsigned long long seed, float* __restrict__ z0 = nullptr, float* __restrict__ z1 = nullptr) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * S * D) return;
+    if (z0) { z0[idx] = 0.f; z1[idx] = 0.f; }      // the fused transformer layers (tr_fused.h) accumulate their FFN output quarters into these
     const int d = idx % D;
     const int t = (idx / D) % S;
     float v = to_f<T>(emb[idx]) + pos[t * D + d];

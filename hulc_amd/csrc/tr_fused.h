@@ -1,0 +1,341 @@
+// hulc_amd/csrc/tr_fused.h — one plan-recognition transformer encoder layer, FORWARD, as ONE launch (16-bit engines, S <= 32).
+//
+// Reference: nn.TransformerEncoderLayer(d_model 128, 8 heads, dim_feedforward 2048, dropout p, post-LN, relu) as built by
+// hulc/models/plan_encoders/plan_recognition_net.py:78-92 and run at :112 —
+//   x1 = LN1(x + drop(out_proj(attention(x W_qkv^T + b))))
+//   x2 = LN2(x1 + drop(W2 drop(relu(x1 W1^T + b1)) + b2))
+//
+// The unfused path is 7 launches per layer (QKV GEMM, attention, out_proj GEMM, LN, FFN1 GEMM, FFN2 GEMM, LN): 2048 tokens x 128 features are
+// far too little work per launch — every one of them is launch / latency bound (4-17 us each, ~65 us per layer) with the CUs mostly idle, and
+// co-scheduling independent work next to them does not pay on this part.  Here a workgroup owns ONE WINDOW (S <= 32
+// tokens = one 32-row MFMA tile pair) and one quarter of the FFN's hidden units:
+//
+//   * phase A (computed by all four workgroups of a window; 128 KB of weights, a few hundred MFMAs): [LN of the previous layer's output] ->
+//     QKV GEMM -> attention of the 8 heads (one wave per head, two lanes per query row like attention_fwd32_kernel) -> out_proj + dropout +
+//     residual -> LN1.  Everything stays in LDS; the tensors the BACKWARD needs (qkv, attention probabilities, attention output, y1 = the
+//     LN1 input, LN1 statistics, x1 in fp32 and 16 bit — exactly what the unfused kernels save) are written by hidden-quarter 0 only;
+//   * phase B (this workgroup's 512 hidden units): h = drop(relu(x1 W1[q]^T + b1[q])) -> saved (16 bit) and kept in LDS -> partial
+//     y2 = h W2[:, q]^T, dropped with the output mask (the mask is linear in the partial sums), + b2 and the residual x1 from quarter 0,
+//     added to y2 with fp32 atomics (y2 is zeroed by the position-add kernel).
+//   LN2 needs all four partial sums: it is the FIRST step of the next layer's launch (ln_in), or the ordinary LayerNorm kernel after the last layer.
+//
+// A workgroup pulls 96 + 32 + 128 + 128 KB of weights through its CU's load path (the L2s serve each slice to 64 workgroups); the weight
+// fragments of every phase are requested BEFORE the phase in front of it starts (they depend on nothing computed here), so the only exposed
+// L2 latency is the first one.  MFMA orientation as in gemm.h: A = weight rows (16 output features), B = 16 tokens from LDS, so a lane owns 4
+// consecutive output features of one token.  Dropout masks use the same (seed, element index) hashes as the unfused kernels — the backward
+// (engine.h) re-derives them and is unchanged.
+#pragma once
+#include "common.h"
+#include "conv_wgrad.h"   // lds_char
+
+namespace HULC_NS {
+
+struct TrLayerP {
+    const float* xin;                 // [N][128] fp32: the layer input x (ln_in = 0), or the previous layer's pre-norm2 sum y2 (ln_in = 1)
+    int ln_in;
+    const float *ln_g, *ln_b;         // ln_in: norm2 of the previous layer
+    float* xf_out; h16_t* xt_out; float* st_out;      // ln_in: the normalised input is saved (fp32, 16 bit, mean / rstd) — quarter 0 writes
+    const h16_t *Wqkv, *Wo, *W1, *W2; // [384][128], [128][128], [2048][128], [128][2048]
+    const float *bqkv, *bo, *b1, *b2, *n1g, *n1b;
+    h16_t* qkv; float* Pat; h16_t* ao; float* y1; float* st1; h16_t* x1t; float* x1f; h16_t* hff; float* y2;
+    int B, S;
+    float dp;
+    unsigned long long seed_att, seed_o, seed_h, seed_y;
+};
+
+constexpr int TRF_D = 128, TRF_FF = 2048, TRF_NH = 8, TRF_HD = 16, TRF_NQ = 4, TRF_HQ = TRF_FF / TRF_NQ;       // hidden quarter = 512 units
+constexpr int TRF_XP = TRF_D * 2 + 32;          // LDS row pitch (bytes) of a [32][128] 16-bit operand: 18 slots = 2 (mod 4) -> conflict-free ds_read_b128
+constexpr int TRF_HP = TRF_HQ * 2 + 32;         // ... of the [32][512] hidden tile: 66 slots
+constexpr int TRF_QP = 3 * TRF_D * 2 + 16;      // qkv rows [32][384] 16 bit (read element-wise by the attention)
+constexpr size_t TRF_LDS = 32 * TRF_D * 4 * 2 + 32 * TRF_XP * 3 + 32 * TRF_QP + 32 * TRF_HP;
+
+__global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) h16_t lds_h16;
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    lds_char* const xf = (lds_char*)smem;                      // [32][128] fp32: x, then y1 in place
+    lds_char* const x1f = xf + 32 * TRF_D * 4;                 // [32][128] fp32: x1
+    lds_char* const xb = x1f + 32 * TRF_D * 4;                 // [32][XP] 16 bit: x
+    lds_char* const aob = xb + 32 * TRF_XP;                    // attention output
+    lds_char* const x1b = aob + 32 * TRF_XP;                   // x1
+    lds_char* const qb = x1b + 32 * TRF_XP;                    // qkv
+    lds_char* const hb = qb + 32 * TRF_QP;                     // hidden quarter
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x / TRF_NQ, hq = blockIdx.x % TRF_NQ;
+    const int S = p.S;
+    const long long row0 = (long long)w * S;
+    const bool lead = hq == 0;
+    const bool mt1 = S > 16;                                   // second 16-token tile in use
+    const float keep = 1.f / (1.f - p.dp);
+
+    // ---- weight fragments of the QKV GEMM: requested first (rows n = (3 wave + nt) * 16 + li, 8 k at g * 8 + ks * 32)
+    h16x8_t wq[3][4];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wq[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.Wqkv + (long long)((3 * wave + nt) * 16 + li) * TRF_D + ks * 32 + g * 8);
+
+    // ---- phase 0: x (optionally LN of the previous layer's sum) -> xf (fp32), xb (16 bit); rows >= S are zero
+    {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float v0 = 0.f, v1 = 0.f;
+            if (r < S) {
+                const float* xr = p.xin + (row0 + r) * TRF_D;
+                v0 = xr[lane]; v1 = xr[lane + 64];
+                if (p.ln_in) {
+                    const float mean = wave_sum(v0 + v1) * (1.f / TRF_D);
+                    const float d0 = v0 - mean, d1 = v1 - mean;
+                    const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / TRF_D) + 1e-5f);
+                    v0 = d0 * rstd * p.ln_g[lane] + p.ln_b[lane];
+                    v1 = d1 * rstd * p.ln_g[lane + 64] + p.ln_b[lane + 64];
+                    if (lead) {
+                        p.xf_out[(row0 + r) * TRF_D + lane] = v0; p.xf_out[(row0 + r) * TRF_D + lane + 64] = v1;
+                        p.xt_out[(row0 + r) * TRF_D + lane] = f2h(v0); p.xt_out[(row0 + r) * TRF_D + lane + 64] = f2h(v1);
+                        if (lane == 0) { p.st_out[2 * (row0 + r)] = mean; p.st_out[2 * (row0 + r) + 1] = rstd; }
+                    }
+                }
+            }
+            *(lds_f32*)(xf + (r * TRF_D + lane) * 4) = v0; *(lds_f32*)(xf + (r * TRF_D + lane + 64) * 4) = v1;
+            *(lds_h16*)(xb + r * TRF_XP + lane * 2) = f2h(v0); *(lds_h16*)(xb + r * TRF_XP + (lane + 64) * 2) = f2h(v1);
+        }
+    }
+    __syncthreads();
+    // weight fragments of the later phases: they depend on nothing computed here, so they travel while QKV / attention / LN1 run
+    h16x8_t wo[4], w1[4][4], w2[16];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(p.Wo + (long long)(wave * 16 + li) * TRF_D + ks * 32 + g * 8);
+
+    // ---- phase 1: qkv = x Wqkv^T + b  -> qb (LDS) [+ global]
+    {
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) { acc[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(xb + li * TRF_XP + ks * 64 + g * 16);
+            const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(xb + (16 + li) * TRF_XP + ks * 64 + g * 16);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                acc[nt][0] = MFMA_16x16x32_H(wq[nt][ks], b0, acc[nt][0], 0, 0, 0);
+                if (mt1) acc[nt][1] = MFMA_16x16x32_H(wq[nt][ks], b1, acc[nt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int n = (3 * wave + nt) * 16 + g * 4;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bqkv + n);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = mt * 16 + li;
+                u32x2_t o;
+                o[0] = pack2h(acc[nt][mt][0] + bb[0], acc[nt][mt][1] + bb[1]);
+                o[1] = pack2h(acc[nt][mt][2] + bb[2], acc[nt][mt][3] + bb[3]);
+                *(__attribute__((address_space(3))) u32x2_t*)(qb + m * TRF_QP + n * 2) = o;
+                if (lead && m < S) *reinterpret_cast<u32x2_t*>(p.qkv + (row0 + m) * (3 * TRF_D) + n) = o;
+            }
+        }
+    }
+    // FFN weight fragments (this workgroup's hidden quarter): W1 rows hq*512 + wave*64 + nt*16 + li; W2 rows wave*16 + li, k in the quarter
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.W1 + (long long)(hq * TRF_HQ + wave * 64 + nt * 16 + li) * TRF_D + ks * 32 + g * 8);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w2[ks] = *reinterpret_cast<const h16x8_t*>(p.W2 + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
+    __syncthreads();
+
+    // ---- phase 2: attention, one wave per head; lane (i = query row, hf = key half) — attention_fwd32_kernel on the LDS copy of qkv
+    {
+        const int h = wave, i = lane & 31, hf = lane >> 5;
+        if (i < S) {
+            float q[TRF_HD];
+            {
+                const lds_char* qr = qb + i * TRF_QP + h * TRF_HD * 2;
+#pragma unroll
+                for (int d = 0; d < TRF_HD; ++d) q[d] = h2f(*(lds_h16*)(qr + d * 2)) * 0.25f;
+            }
+            float sc[16];
+            float m = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = hf * 16 + jj;
+                const lds_char* kr = qb + (j < S ? j : 0) * TRF_QP + (TRF_D + h * TRF_HD) * 2;
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < TRF_HD; ++d) s += q[d] * h2f(*(lds_h16*)(kr + d * 2));
+                sc[jj] = j < S ? s : -INFINITY;
+                m = fmaxf(m, sc[jj]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float den = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) { sc[jj] = (hf * 16 + jj) < S ? __expf(sc[jj] - m) : 0.f; den += sc[jj]; }
+            den += __shfl_xor(den, 32);
+            const float inv = 1.f / den;
+            float o[TRF_HD];
+#pragma unroll
+            for (int d = 0; d < TRF_HD; ++d) o[d] = 0.f;
+            const long long pbase = (((long long)w * TRF_NH + h) * S + i) * S;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = hf * 16 + jj;
+                if (j < S) {
+                    float pr = sc[jj] * inv;
+                    if (lead) p.Pat[pbase + j] = pr;              // saved BEFORE its dropout (the backward re-derives the mask)
+                    if (p.dp > 0.f) pr = hash_uniform(p.seed_att, (unsigned long long)(pbase + j)) < p.dp ? 0.f : pr * keep;
+                    const lds_char* vr = qb + j * TRF_QP + (2 * TRF_D + h * TRF_HD) * 2;
+#pragma unroll
+                    for (int d = 0; d < TRF_HD; ++d) o[d] += pr * h2f(*(lds_h16*)(vr + d * 2));
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < TRF_HD; ++d) o[d] += __shfl_xor(o[d], 32);
+            u32x4_t ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = hf ? pack2h(o[8 + 2 * e], o[9 + 2 * e]) : pack2h(o[2 * e], o[2 * e + 1]);
+            *(lds_u32x4*)(aob + i * TRF_XP + (h * TRF_HD + hf * 8) * 2) = ov;
+            if (lead) *reinterpret_cast<u32x4_t*>(p.ao + (row0 + i) * TRF_D + h * TRF_HD + hf * 8) = ov;
+        } else {
+            *(lds_u32x4*)(aob + i * TRF_XP + (h * TRF_HD + hf * 8) * 2) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: y1 = x + drop(ao Wo^T + bo)  (in place in xf) [+ global]
+    {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(aob + li * TRF_XP + ks * 64 + g * 16);
+            acc[0] = MFMA_16x16x32_H(wo[ks], b0, acc[0], 0, 0, 0);
+            if (mt1) {
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(aob + (16 + li) * TRF_XP + ks * 64 + g * 16);
+                acc[1] = MFMA_16x16x32_H(wo[ks], b1, acc[1], 0, 0, 0);
+            }
+        }
+        const int n = wave * 16 + g * 4;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bo + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+            lds_char* xr = xf + (m * TRF_D + n) * 4;
+            const f32x4 res = *(__attribute__((address_space(3))) f32x4*)xr;
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][r] + bb[r];
+                if (p.dp > 0.f) v = hash_uniform(p.seed_o, (unsigned long long)((row0 + m) * TRF_D + n + r)) < p.dp ? 0.f : v * keep;
+                y[r] = m < S ? v + res[r] : 0.f;
+            }
+            *(__attribute__((address_space(3))) f32x4*)xr = y;
+            if (lead && m < S) *reinterpret_cast<f32x4*>(p.y1 + (row0 + m) * TRF_D + n) = y;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: x1 = LN1(y1) -> x1f (fp32), x1b (16 bit) [+ global, statistics]
+    {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float v0 = *(lds_f32*)(xf + (r * TRF_D + lane) * 4), v1 = *(lds_f32*)(xf + (r * TRF_D + lane + 64) * 4);
+            float o0 = 0.f, o1 = 0.f;
+            if (r < S) {
+                const float mean = wave_sum(v0 + v1) * (1.f / TRF_D);
+                const float d0 = v0 - mean, d1 = v1 - mean;
+                const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / TRF_D) + 1e-5f);
+                o0 = d0 * rstd * p.n1g[lane] + p.n1b[lane];
+                o1 = d1 * rstd * p.n1g[lane + 64] + p.n1b[lane + 64];
+                if (lead) {
+                    p.x1f[(row0 + r) * TRF_D + lane] = o0; p.x1f[(row0 + r) * TRF_D + lane + 64] = o1;
+                    p.x1t[(row0 + r) * TRF_D + lane] = f2h(o0); p.x1t[(row0 + r) * TRF_D + lane + 64] = f2h(o1);
+                    if (lane == 0) { p.st1[2 * (row0 + r)] = mean; p.st1[2 * (row0 + r) + 1] = rstd; }
+                }
+            }
+            *(lds_f32*)(x1f + (r * TRF_D + lane) * 4) = o0; *(lds_f32*)(x1f + (r * TRF_D + lane + 64) * 4) = o1;
+            *(lds_h16*)(x1b + r * TRF_XP + lane * 2) = f2h(o0); *(lds_h16*)(x1b + r * TRF_XP + (lane + 64) * 2) = f2h(o1);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 5: h = drop(relu(x1 W1[q]^T + b1[q]))  -> hb (LDS) + global hff
+    {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { acc[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(x1b + li * TRF_XP + ks * 64 + g * 16);
+            const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(x1b + (16 + li) * TRF_XP + ks * 64 + g * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt][0] = MFMA_16x16x32_H(w1[nt][ks], b0, acc[nt][0], 0, 0, 0);
+                if (mt1) acc[nt][1] = MFMA_16x16x32_H(w1[nt][ks], b1, acc[nt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int nl = wave * 64 + nt * 16 + g * 4, n = hq * TRF_HQ + nl;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1 + n);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = mt * 16 + li;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaxf(acc[nt][mt][r] + bb[r], 0.f);
+                    if (p.dp > 0.f) v[r] = hash_uniform(p.seed_h, (unsigned long long)((row0 + m) * TRF_FF + n + r)) < p.dp ? 0.f : v[r] * keep;
+                    if (m >= S) v[r] = 0.f;
+                }
+                u32x2_t o;
+                o[0] = pack2h(v[0], v[1]); o[1] = pack2h(v[2], v[3]);
+                *(__attribute__((address_space(3))) u32x2_t*)(hb + m * TRF_HP + nl * 2) = o;
+                if (m < S) *reinterpret_cast<u32x2_t*>(p.hff + (row0 + m) * TRF_FF + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 6: y2 += drop(h W2[:, q]^T [+ b2]) [+ x1]   (fp32 atomics: four quarters per element)
+    {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(hb + li * TRF_HP + ks * 64 + g * 16);
+            acc[0] = MFMA_16x16x32_H(w2[ks], b0, acc[0], 0, 0, 0);
+            if (mt1) {
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(hb + (16 + li) * TRF_HP + ks * 64 + g * 16);
+                acc[1] = MFMA_16x16x32_H(w2[ks], b1, acc[1], 0, 0, 0);
+            }
+        }
+        const int n = wave * 16 + g * 4;
+        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lead) bb = *reinterpret_cast<const f32x4*>(p.b2 + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+            if (m >= S) continue;
+            const f32x4 res = *(__attribute__((address_space(3))) f32x4*)(x1f + (m * TRF_D + n) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][r] + bb[r];
+                if (p.dp > 0.f) v = hash_uniform(p.seed_y, (unsigned long long)((row0 + m) * TRF_D + n + r)) < p.dp ? 0.f : v * keep;
+                if (lead) v += res[r];
+                unsafeAtomicAdd(p.y2 + (row0 + m) * TRF_D + n + r, v);
+            }
+        }
+    }
+}
+
+static inline void launch_tr_layer_fwd(hipStream_t st, const TrLayerP& p) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)tr_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRF_LDS); attr_set = true; }
+    hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(p.B * TRF_NQ), dim3(512), TRF_LDS, st, p);
+}
+
+}  // namespace HULC_NS
