@@ -154,6 +154,7 @@ def main():
                     help="hulc: the headline configuration; mcil: conf/model/mcil.yaml (BiRNN plan recognition, continuous plan, no CLIP loss); "
                          "mcil_gru: the same with plan_recognition.rnn_type=nn.GRU (BASELINE config 4)")
     ap.add_argument("--preroll", type=int, default=300, help="untimed steps before the warm-up (≈1.5 s: clock ramp of an idle GPU)")
+    ap.add_argument("--persist", type=int, default=1, help="hulc_set_option persistent_rnn: 1 = each 2048-wide recurrence as one persistent launch (default), 0 = one launch per time step")
     ap.add_argument("--pair", type=int, default=1, help="with --lang 1: both modalities as ONE 2B-window pass (hulc_forward_loss_pair); 0 = one pass per modality like the reference")
     ap.add_argument("--bucket", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="N > 1: wire format of the gradient all-reduce buckets (fp32 = the reference's; the engine's 16-bit type halves the bytes per link)")
@@ -179,6 +180,7 @@ def main():
     Bmod = B // 2 if args.lang else B
     paired = bool(args.lang) and bool(args.pair)
     eng = StepEngine(dims, B if paired else Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
+    eng.set_option("persistent_rnn", args.persist)
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
     # N > 1: the library's own RCCL communicator (hulc_backward_allreduce: reverse-forward buckets overlapped with the backward); the
     # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  HULC_DP_COMM=capi (the default)

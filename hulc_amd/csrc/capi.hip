@@ -191,6 +191,10 @@ int hulc_set_dropout(hulc_ctx* ctx, float p) {
     ctx->e->set_dropout(p);
     return 0;
 }
+int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx) { hulc_set_error("hulc_set_option: null context"); return 1; }
+    return ctx->e->set_option(name, (long long)value);
+}
 int hulc_timers_enable(hulc_ctx* ctx, int32_t on, const char* only_class) { ctx->e->set_timing(on != 0, only_class); return 0; }
 int hulc_timers_read(hulc_ctx* ctx, char* json_out, int64_t cap, int32_t reset) { return ctx->e->timers_read(json_out, cap, reset != 0); }
 int hulc_get_tensor(hulc_ctx* ctx, const char* name, float* out, int64_t cap, int64_t* n) { return ctx->e->get_tensor(name, out, cap, n); }
@@ -328,6 +332,18 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// one whole recurrence as a persistent launch (rnn_persist.h), bf16: X [S][B][2048] with X[q0] given; flags = RP_FLAG_WORDS zeroed uint32 words
+// (reused across calls with increasing launch_index >= 1), err = one zeroed uint32
+int hulc_k_rnn_persist(void* X, const void* W, const void* res, const void* mask, int32_t B, int32_t S, int32_t q0, int32_t dq, int32_t act, uint32_t* flags,
+                       uint32_t* err, uint32_t launch_index, void* stream) {
+    RnnPersistP p{};
+    p.X = (h16_t*)X; p.W = (const h16_t*)W; p.res = (const h16_t*)res; p.mask = (const h16_t*)mask; p.B = B; p.S = S; p.q0 = q0; p.dq = dq; p.act = act;
+    p.flags = flags; p.base = launch_index << 12; p.parity = (int)(launch_index & 1u); p.err = err; p.stamps = nullptr;
+    if (!launch_rnn_persist((hipStream_t)stream, p)) { hulc_set_error("hulc_k_rnn_persist: shape not covered (S >= 2, B <= 128)"); return 1; }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int32_t hulc_k_rnn_persist_flag_words(void) { return RP_FLAG_WORDS; }
 
 // probe of ds_read_b64_tr_b16 semantics (tests/tools only): LDS image lds[i] = i (uint16), lane l reads at element index addr[l]
 __global__ void trread_probe_kernel(const int* __restrict__ addr_in, unsigned short* __restrict__ out) {

@@ -15,6 +15,7 @@
 #include "conv_tile.h"
 #include "conv_reg.h"
 #include "tr_fused.h"
+#include "rnn_persist.h"
 
 namespace HULC_NS {
 
@@ -126,7 +127,7 @@ struct Engine : IEngine {
         KIN = dec_plan + DE + GOAL;
         maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
     }
-    ~Engine() override { for (void* p : allocs) hipFree(p); }
+    ~Engine() override { for (void* p : allocs) hipFree(p); if (rp_err_host) hipHostFree((void*)rp_err_host); }
     int64_t workspace_bytes() const override { return ws_bytes; }
     void set_kl_beta(float b) override { cfg.kl_beta = b; }
     void set_dropout(float p) override { cfg.dropout_p = p; }
@@ -986,6 +987,7 @@ struct Engine : IEngine {
     }
     int forward_impl(const hulc_batch* b, float lw, float cw, float* out, int on_host) {
         if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
+        if (persist_failed("hulc_forward_loss")) return 1;
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
             return 1;
@@ -1251,6 +1253,57 @@ struct Engine : IEngine {
         return 0;
     }
 
+    // ---- a whole recurrence X[q_s] = f(X[q_{s-1}] Wm^T, aux[q_s]), s = 1..S-1, as ONE persistent launch (rnn_persist.h; 16-bit engines, 2048-wide
+    // state).  false = not taken (fp32 engine, option off, shape not covered, or this device failed the first launch's census): the caller runs
+    // one launch per step.  The FIRST launch of a context is followed by a stream synchronisation and a look at the error word; a timeout in
+    // any later launch (the kernel's polls are bounded) is picked up by persist_failed() at the next API call, which reports the step as failed.
+    unsigned* rp_flags = nullptr;
+    volatile unsigned* rp_err_host = nullptr;
+    unsigned* rp_err_dev = nullptr;
+    unsigned rp_launches = 1;
+    int rp_B = -1;
+    bool rp_probed = false, rp_ok = false;
+    bool rnn_persist(T* X, const T* Wm, const T* res, const T* mask, int B, int S, int q0, int dq, int act) {
+        if constexpr (!std::is_same<T, h16_t>::value) return false;
+        else {
+            if (!persist_mode || HID != RP_HID || S < 3 || B > 16 * RP_NG || (rp_probed && !rp_ok)) return false;
+            if (!rp_flags) {
+                rp_flags = alloc<unsigned>(RP_FLAG_WORDS);
+                void* h = nullptr;
+                if (alloc_failed || hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&rp_err_dev, h, 0) != hipSuccess) { rp_probed = true; rp_ok = false; return false; }
+                rp_err_host = (volatile unsigned*)h; *rp_err_host = 0;
+            }
+            if (B != rp_B || rp_launches >= (1u << 19)) {     // another set of active groups, or the step counters near their wrap: restart the counters from a clean slate
+                hipMemsetAsync(rp_flags, 0, sizeof(unsigned) * RP_FLAG_WORDS, st);
+                rp_launches = 1; rp_B = B;
+            }
+            RnnPersistP p{};
+            p.X = X; p.W = Wm; p.res = res; p.mask = mask; p.B = B; p.S = S; p.q0 = q0; p.dq = dq; p.act = act;
+            p.flags = rp_flags; p.base = rp_launches << 12; p.parity = (int)(rp_launches & 1u); p.err = rp_err_dev; p.stamps = nullptr;
+            ++rp_launches;
+            TimerScope ts(this, "rnn_persist", "mfma", 2.0 * B * HID * HID * (S - 1), (double)HID * HID * sizeof(T) + 3.0 * S * B * HID * sizeof(T), 1);
+            if (!launch_rnn_persist(st, p)) return false;
+            if (!rp_probed) {
+                hipStreamSynchronize(st);
+                rp_probed = true; rp_ok = *rp_err_host == 0;
+                if (!rp_ok) {
+                    fprintf(stderr, "hulc: persistent recurrence unavailable on this device (census / co-residency check failed, code %u): one launch per time step\n", *rp_err_host);
+                    *rp_err_host = 0;
+                    return false;
+                }
+            }
+            return true;
+        }
+    }
+    // true (and an error message) if a persistent recurrence of an earlier call timed out: that call's results are invalid
+    bool persist_failed(const char* where) {
+        if (!rp_err_host || *rp_err_host == 0) return false;
+        hulc_set_error("%s: a persistent recurrence launch of the previous step timed out (code %u: the GPU's CUs were not all available — shared with another process?); "
+                       "its results are invalid.  persistent_rnn is now off for this context (hulc_set_option)", where, *rp_err_host);
+        *rp_err_host = 0; rp_ok = false; rp_probed = true;
+        return true;
+    }
+
     // H[t] = act(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID].  act 1: ReLU (action decoder), 2: tanh (mcil BiRNN); rev: the
     // recurrence runs from t = S-1 down to 0 (nn.RNN's reverse direction, outputs stay at their own positions)
     // first_done: H[0] = act(Zx[0]) was already written by the GEMM that produced Zx (EpiP::out2)
@@ -1261,6 +1314,7 @@ struct Engine : IEngine {
             EpiP ep = epi(H + at(0), false); ep.res = Zx + at(0); ep.res_ld = HID; ep.relu = act;
             gemm(dense<T>(h0, B, HID), dense<T>(whh.W, HID, HID), dense_out(HID), ep, B, HID, HID);
         } else if (!first_done) hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx + at(0), H + at(0), BH, act);
+        if (rnn_persist(H, whh.W, Zx, nullptr, B, S, rev ? S - 1 : 0, rev ? -1 : 1, act)) return;
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 3.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int i = 1; i < S; ++i) {
             EpiP ep = epi(H + at(i), false); ep.res = Zx + at(i); ep.res_ld = HID; ep.relu = act;
@@ -1273,6 +1327,7 @@ struct Engine : IEngine {
         const long long BH = (long long)B * HID;
         auto at = [&](int i) { return (long long)(rev ? S - 1 - i : i) * BH; };
         if (!last_done) hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH_last_only ? dH : dH + at(S - 1), H + at(S - 1), dZ + at(S - 1), BH, act);
+        if (rnn_persist(dZ, whh.Wt, dH_last_only ? nullptr : dH, H, B, S, rev ? 0 : S - 1, rev ? 1 : -1, act)) return;
         TimerScope ts(this, "rnn_step_gemm", "hbm", 2.0 * B * HID * HID * (S - 1), ((double)HID * HID + 4.0 * B * HID) * sizeof(T) * (S - 1), S - 1);
         for (int i = S - 2; i >= 0; --i) {
             EpiP ep = epi(dZ + at(i), false); ep.mask = H + at(i); ep.mask_tanh = act == 2;
@@ -1713,6 +1768,7 @@ struct Engine : IEngine {
     int bwd_stage = 0;    // 0: nothing pending; 1: part 0 done, encoders pending
     int backward(int part = -1) override {
         if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
+        if (persist_failed("hulc_backward")) return 1;
         if (part == 1 && bwd_stage != 1) { hulc_set_error("hulc_backward_part(1) must follow hulc_backward_part(0)"); return 1; }
         if (part != 1 && bwd_stage != 0) { hulc_set_error("hulc_backward: encoder part of the previous backward still pending"); return 1; }
         const hulc_batch* b = &cur;
@@ -1953,6 +2009,7 @@ struct Engine : IEngine {
 
     int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) override {
         if (!bound) { hulc_set_error("hulc_adam_step before hulc_bind_params"); return 1; }
+        if (persist_failed("hulc_adam_step")) return 1;
         const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
         const double bc1d = 1.0 - pow((double)b1, (double)step), bc2d = 1.0 - pow((double)b2, (double)step);
         (void)bc1; (void)bc2;

@@ -59,6 +59,15 @@ struct IEngine {
     virtual void set_kl_beta(float b) = 0;
     virtual void set_dropout(float p) = 0;
     void set_timing(bool on, const char* filter) { timing = on; timing_filter = filter ? filter : ""; }
+    // runtime options (hulc_set_option).  "persistent_rnn": 1 (default) = the 2048-wide recurrences of the 16-bit engines run as one
+    // persistent launch each (rnn_persist.h) after a first launch has verified the XCD census on this device; 0 = one launch per time step
+    // (what a process that SHARES the GPU's CUs with another process must choose: the persistent launch needs all 256 CUs resident)
+    int persist_mode = 1;
+    int set_option(const char* name, long long value) {
+        if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
+        hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
+        return 1;
+    }
     hipStream_t st = nullptr;
     // ---- per-kernel-class HIP-event timers (bench.py roofline leg): events are recorded on `st` around the launches of a class
     struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };

@@ -9,30 +9,39 @@
 // One launch per step (skinny_lds_kernel) pays, per step, a kernel boundary and the whole 8.4 MB weight matrix through the CUs' load paths
 // (192 KB per workgroup): 6.1 us for 0.54 GFLOP.  The recurrence only couples the 2048 features of ONE window, so the batch is split over
 // the chip's eight XCDs instead of the weight matrix over all 256 CUs:
-//   * workgroup (g = blockIdx % 8, j = blockIdx / 8) belongs to group g — observed to be XCD g (MI355X_MICROARCH.md, workgroup dispatch) —
-//     which advances the windows [g wpx, (g+1) wpx) through all S - 1 steps; within the group it owns output features [64 j, 64 j + 64);
-//   * its 64 x 2048 slice of the weight matrix (256 KB) is loaded ONCE into the CU's vector registers as MFMA A-fragments (wave w holds
-//     k in [128 w, 128 w + 128) of all 64 features: 16 x 16 B per lane = 64 VGPRs) and stays there for the whole launch: a step reads no
+//   * a workgroup reads the XCD it runs on from the hardware (HW_REG_XCC_ID) and claims one of that XCD's 32 slots (one returning atomic on a
+//     per-XCD census counter): group g = XCD g advances the windows [g wpx, (g+1) wpx) through all S - 1 steps, slot j owns the output
+//     features [64 j, 64 j + 64).  Groups are formed from what the hardware reports, not from blockIdx: the dispatcher is observed to place
+//     block b on XCD b % 8, which makes 32 per XCD, but nothing here assumes it — a launch whose XCDs are not populated 32 each raises
+//     `err` (bounded polls) and the engine keeps the launch-per-step path;
+//   * the 64 x 2048 slice of the weight matrix (256 KB) is loaded ONCE into the CU's vector registers as MFMA A-fragments (wave w of 8 holds
+//     k in [256 w, 256 w + 256) of all 64 features: 32 x 16 B per lane = 128 VGPRs) and stays there for the whole launch: a step reads no
 //     weight byte at all;
-//   * per step a wave loads the B-fragments of its k-range of the previous state (wpx windows x 256 B) straight from memory, issues 16 MFMAs
-//     (16x16x32; the token dimension of the tile is the group's <= 16 windows), the 16 k-partials meet in LDS (double-buffered by step
-//     parity: ONE workgroup barrier per step), wave 0 sums them, applies the step's epilogue (residual, ReLU / tanh or their derivative
-//     masks) and publishes the 64-feature slice of the new state;
-//   * hand-off inside a group: the slice is stored with 16-byte write-through (`sc1`) stores, the storing wave drains its vmcnt and then
-//     stores a step counter to its own flag word (`sc1`); a consuming wave polls exactly the TWO flags of the workgroups that produce its
-//     k-range (relaxed agent-scope loads + s_sleep) and reads the state with `sc1` loads — the {sc1 stores, sc1 loads} form of
-//     MI355X_MICROARCH.md "inter-workgroup visibility", valid for any placement: if the dispatcher ever put a group's workgroups on several
-//     XCDs the launch is slower, not wrong.  There is no grid-wide barrier and no cross-group traffic at all;
-//   * every poll loop is bounded; a timeout (workgroups not co-resident: somebody else holds CUs) raises `err` and lets the launch drain.
-// Flag words never need zeroing: a launch publishes base + s with a base the host advances by 4096 per launch.
+//   * per step a wave loads the B-fragments of its k-range of the previous state (wpx windows x 512 B), issues 32 MFMAs (16x16x32; the token
+//     dimension of the tile is the group's <= 16 windows), the 8 k-partials meet in LDS (double-buffered by step parity: ONE workgroup
+//     barrier per step), four reducer waves (one per SIMD) sum them, apply the step's epilogue (residual, ReLU / tanh or their derivative
+//     masks) and store the 64-feature slice of the new state;
+//   * hand-off: all communication stays INSIDE one XCD, whose L2 is the coherence point of its 32 CUs.  Producer: plain 16-byte stores (they
+//     write through the CU's L1 into the L2), `s_waitcnt vmcnt(0)`, an LDS arrival count of the four reducer waves, the last one stores the
+//     step counter into the mailbox line of each of the 32 consumers.  Consumer: every wave samples its workgroup's own 128-byte mailbox
+//     line with `sc1` loads (they bypass the L1, which another CU's stores never refresh, and are served by the L2 — the mailbox lines are
+//     rewritten every step and stay dirty-resident there) and then reads the state with `sc1` loads.  Measured alternatives (B = 64, S = 32,
+//     per step): write-through `sc1` stores + flags through memory, the placement-independent form, 5.6 - 9.3 us (no better than a launch
+//     per step: 4.2 us back to back); this form 2.6 - 3.2 us; the state as its own ready flag (slices pre-filled with a reserved NaN pattern,
+//     consumers re-reading until it is gone: one hop less on paper) 3.6 - 4.7 us — polling lines that are NOT being rewritten costs a memory
+//     round trip per sample, and sampling the payload itself saturates the L2.  There is no grid-wide barrier and no cross-XCD traffic;
+//   * every poll loop is bounded; a timeout (workgroups not co-resident: somebody else holds CUs; XCD population not 32) raises `err`.
+// Mailbox words never need zeroing: a launch publishes base + s with a base the host advances by 4096 per launch.  The census counters are
+// double-buffered by launch parity: a launch counts in one set and clears the other.
 #pragma once
 #include "common.h"
 
 namespace HULC_NS {
 
-constexpr int RP_HID = 2048, RP_NG = 8, RP_SLOTS = 32, RP_COLS = 64, RP_NW = 16, RP_KW = 128;
+constexpr int RP_HID = 2048, RP_NG = 8, RP_SLOTS = 32, RP_COLS = 64, RP_NW = 8, RP_KW = 256, RP_KS = RP_KW / 32;
 constexpr int RP_TPITCH = RP_COLS * 4 + 16;          // LDS pitch of one window's 64 fp32 partial sums: 17 slots -> conflict-free 16-byte writes
-constexpr int RP_FLAG_WORDS = RP_NG * 64;            // one 256-byte line pair per group
+constexpr int RP_MAIL_WORDS = RP_NG * RP_SLOTS * RP_SLOTS;
+constexpr int RP_FLAG_WORDS = RP_MAIL_WORDS + 2 * RP_NG * 32;     // mailbox[group][consumer][producer]: one 128-byte line per consumer workgroup
 
 struct RnnPersistP {
     h16_t* X;             // [S][B][2048]: the recurrence's own sequence (H going forward, dZ going backward)
@@ -42,85 +51,117 @@ struct RnnPersistP {
     int B, S, q0, dq;     // step s reads position q0 + (s-1) dq and writes q0 + s dq
     int act;              // mask == null: 1 ReLU, 2 tanh;  mask != null: 1 (H > 0), 2 (1 - H^2)
     int wpx;              // windows per group
-    unsigned* flags;      // [8][64]
+    unsigned* flags;      // [RP_FLAG_WORDS] mailboxes, then [2][8][32] census counters (one 128-byte line each)
     unsigned base;
-    unsigned* err;
+    int parity;           // launch parity: census set in use
+    unsigned* err;        // device-visible word (the engine maps a pinned host word): 1 = a poll timed out, 2 = an XCD held more than 32 workgroups
+    long long* stamps;    // RP_STAMPS builds (tools/rnn_persist_bench.hip): [S][2 waves][8] shader-clock stamps of workgroup 8
 };
+#ifdef RP_STAMPS
+#define RP_STAMP(i) do { if (p.stamps && blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 5)) p.stamps[(s * 2 + (wave ? 1 : 0)) * 8 + (i)] = clock64(); } while (0)
+#else
+#define RP_STAMP(i) do { } while (0)
+#endif
 
 typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int TOK>      // window capacity of a group: 8 or 16
-__global__ void __launch_bounds__(1024) rnn_persist_kernel(RnnPersistP p) {
+DEVI float rp_dpp_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }       // quad_perm [1,0,3,2]
+DEVI float rp_dpp_shl2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x102, 0xF, 0xF, true)); }      // row_shl:2 — lane i reads lane i + 2
+// TOK: window capacity of a group (8 or 16).  MODE: 0 ReLU(z), 1 tanh(z) (forward); 2 z * (mask > 0), 3 z * (1 - mask^2) (backward), z = product (+ res if RES)
+template <int TOK, int MODE, bool RES>
+__global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_c;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
-    constexpr int WS = TOK * RP_TPITCH + 32;          // per-wave partial block; + 32 B: the 16 blocks start in different bank groups
+    constexpr int WS = TOK * RP_TPITCH + 32;          // per-wave partial block; 4 WS = 128 (mod 256): the two partial halves a reducer pair reads never collide
     constexpr int BUF = RP_NW * WS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, gq = lane >> 4;
-    const int grp = blockIdx.x & (RP_NG - 1), slot = blockIdx.x >> 3;
+    __shared__ unsigned s_slot, done_cnt;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int grp = (int)(xcc & 7u);
+    if (tid == 0) {
+        unsigned* const census = p.flags + RP_MAIL_WORDS;
+        const unsigned sl = __hip_atomic_fetch_add(census + (p.parity * RP_NG + grp) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sl == 0) __hip_atomic_store(census + ((p.parity ^ 1) * RP_NG + grp) * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's set
+        if (sl >= (unsigned)RP_SLOTS) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_slot = sl;
+        done_cnt = 0;
+    }
+    __syncthreads();
+    const int slot = (int)s_slot;
+    if (slot >= RP_SLOTS) return;                     // an over-populated XCD: the launch is reported failed
     const int t0 = grp * p.wpx;
     const int nwin = min(p.wpx, p.B - t0);
     if (nwin <= 0) return;
     const long long BH = (long long)p.B * RP_HID;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0x7fffffff, 0x00020000);
 
-    // ---- the weight slice, once: rows 64 slot + 16 ct + li, k = 128 wave + 32 ks + 8 gq
-    h16x8_t wf[4][4];
+    // ---- the weight slice, once: rows 64 slot + 16 ct + li, k = 256 wave + 32 ks + 8 gq
+    h16x8_t wf[4][RP_KS];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < RP_KS; ++ks)
             wf[ct][ks] = *reinterpret_cast<const h16x8_t*>(p.W + (long long)(RP_COLS * slot + 16 * ct + li) * RP_HID + RP_KW * wave + 32 * ks + 8 * gq);
-
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0x7fffffff, 0x00020000);
-    const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(p.flags + grp * 64 + 2 * wave);
-    unsigned* const myflag = p.flags + grp * 64 + slot;
+    // mailbox[group][consumer slot][producer slot]: a consumer's waves sample their OWN 128-byte line; a producer's last reducer wave writes
+    // its step counter into the 32 lines of its group (one lane per consumer)
+    const unsigned* fl = p.flags + (grp * RP_SLOTS + slot) * RP_SLOTS;
     bool dead = false;
-    // wave 0's epilogue items: (window, 8-feature group) = lane (+ 64 for the second half of a 16-window group)
+    // reducer waves 0..3 (one per SIMD): wave r sums the 8 k-partials of windows r * TOK/4 .. + TOK/4; lane = (window tk, 4-feature group c4, partial half ph)
     constexpr int NIT = TOK / 8;
+    const int tk = lane >> 5, c4 = (lane >> 1) & 15, ph = lane & 1;
 
     for (int s = 1; s < p.S; ++s) {
         const long long qp = (long long)(p.q0 + (s - 1) * p.dq) * BH, qc = (long long)(p.q0 + s * p.dq) * BH;
-        // epilogue operands of this step: independent of the recurrence, requested before the wait
+        RP_STAMP(0);
+        // epilogue operands of this step: independent of the recurrence, requested before the wait (the lanes that will store: 8 features each)
         rp_u32x4 rv[NIT], mv[NIT];
-        if (wave == 0) {
+        if (wave < 4) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int tok = (lane >> 3) + 8 * it;
+                const int tok = wave * (TOK / 4) + it * 2 + tk;
                 rv[it] = rp_u32x4{0u, 0u, 0u, 0u}; mv[it] = rp_u32x4{0u, 0u, 0u, 0u};
-                if (tok < nwin) {
-                    const long long o = qc + (long long)(t0 + tok) * RP_HID + RP_COLS * slot + 8 * (lane & 7);
-                    if (p.res) rv[it] = *reinterpret_cast<const rp_u32x4*>(p.res + o);
-                    if (p.mask) mv[it] = *reinterpret_cast<const rp_u32x4*>(p.mask + o);
+                if (tok < nwin && (lane & 3) == 0) {
+                    const long long o = qc + (long long)(t0 + tok) * RP_HID + RP_COLS * slot + 4 * c4;
+                    if (RES) rv[it] = *reinterpret_cast<const rp_u32x4*>(p.res + o);
+                    if (MODE >= 2) mv[it] = *reinterpret_cast<const rp_u32x4*>(p.mask + o);
                 }
             }
         }
-        // ---- wait for the two producers of this wave's k-range (the first step's input comes from an earlier launch)
         if (s > 1 && !dead) {
+            // wait for all 32 producers of the group (lane = producer); all eight waves sample the line, so it is sampled several times per
+            // L2 round trip (the first step's input comes from an earlier launch)
             const unsigned want = p.base + (unsigned)(s - 1);
             int spins = 0;
             for (;;) {
-                const unsigned long long v = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)((unsigned)v - want) >= 0 && (int)((unsigned)(v >> 32) - want) >= 0) break;
-                if (++spins > (1 << 19)) { dead = true; if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(1);
+                unsigned v = want;
+                if (lane < RP_SLOTS) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)(v - want) >= 0)) break;
+                if (++spins > (1 << 18)) { dead = true; if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             }
         }
-        // ---- B fragments: window li, k = 128 wave + 32 ks + 8 gq (sc1: past the L1, which other CUs' stores never refresh)
-        h16x8_t bf[4];
+        RP_STAMP(1);
+        // ---- B fragments: window li, k = 256 wave + 32 ks + 8 gq (sc1: past the L1, which other CUs' stores never refresh; served by the XCD's L2)
+        h16x8_t bf[RP_KS];
         {
             const unsigned off = (unsigned)((qp + (long long)(t0 + li) * RP_HID + RP_KW * wave + 8 * gq) * 2);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < RP_KS; ++ks) {
                 rp_u32x4 v = rp_u32x4{0u, 0u, 0u, 0u};
                 if (li < nwin) v = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 64 * ks, 0, 16);
                 bf[ks] = *reinterpret_cast<h16x8_t*>(&v);
             }
         }
+#ifdef RP_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        RP_STAMP(2);
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < RP_KS; ++ks)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA_16x16x32_H(wf[ct][ks], bf[ks], acc[ct], 0, 0, 0);
         // ---- k-partials -> LDS: [parity][wave][window][64 features]; lane (li, gq) owns features 16 ct + 4 gq .. + 3 of window li
@@ -129,37 +170,50 @@ __global__ void __launch_bounds__(1024) rnn_persist_kernel(RnnPersistP p) {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) *(lds_f4*)(pb + wave * WS + li * RP_TPITCH + ct * 64 + gq * 16) = acc[ct];
         }
+        RP_STAMP(3);
         __syncthreads();
-        if (wave == 0) {
+        RP_STAMP(4);
+        if (wave < 4) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int tok = (lane >> 3) + 8 * it, c8 = lane & 7;
-                if (tok < nwin) {
-                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int tokl = wave * (TOK / 4) + it * 2 + tk;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (tokl < nwin) {
 #pragma unroll
-                    for (int w = 0; w < RP_NW; ++w) {
-                        a0 += *(lds_f4*)(pb + w * WS + tok * RP_TPITCH + c8 * 32);
-                        a1 += *(lds_f4*)(pb + w * WS + tok * RP_TPITCH + c8 * 32 + 16);
-                    }
-                    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    for (int w = 0; w < RP_NW / 2; ++w) a += *(lds_f4*)(pb + ((RP_NW / 2) * ph + w) * WS + tokl * RP_TPITCH + c4 * 16);
+                }
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a[e] + rp_dpp_xor1(a[e]);
+                // lanes (lane & 3) == 0 gather the neighbouring 4-feature group: 8 features = one 16-byte store
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] = rp_dpp_shl2(v[e]);
+                if (tokl < nwin && (lane & 3) == 0) {
                     rp_u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x0 = v[2 * e], x1 = v[2 * e + 1];
-                        if (p.res) { x0 += h2f_lo(rv[it][e]); x1 += h2f_hi(rv[it][e]); }
-                        if (p.mask) {
+                        if (RES) { x0 += h2f_lo(rv[it][e]); x1 += h2f_hi(rv[it][e]); }
+                        if (MODE == 0) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        else if (MODE == 1) { x0 = tanhf(x0); x1 = tanhf(x1); }
+                        else {
                             const float m0 = h2f_lo(mv[it][e]), m1 = h2f_hi(mv[it][e]);
-                            if (p.act == 2) { x0 *= 1.f - m0 * m0; x1 *= 1.f - m1 * m1; }
+                            if (MODE == 3) { x0 *= 1.f - m0 * m0; x1 *= 1.f - m1 * m1; }
                             else { x0 = m0 > 0.f ? x0 : 0.f; x1 = m1 > 0.f ? x1 : 0.f; }
-                        } else if (p.act == 1) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-                        else if (p.act == 2) { x0 = tanhf(x0); x1 = tanhf(x1); }
+                        }
                         o[e] = pack2h(x0, x1);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, xr, (unsigned)((qc + (long long)(t0 + tok) * RP_HID + RP_COLS * slot + 8 * c8) * 2), 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, xr, (unsigned)((qc + (long long)(t0 + tokl) * RP_HID + RP_COLS * slot + 4 * c4) * 2), 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slice has left this CU before its flag does
-            if (lane == 0) __hip_atomic_store(myflag, p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RP_STAMP(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the slice is in the L2
+            RP_STAMP(6);
+            unsigned prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(&done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev == 4u * (unsigned)s - 1u && lane < RP_SLOTS)    // the last of the four reducers: the whole slice is in the L2 -> every consumer's mailbox
+                __hip_atomic_store(p.flags + ((grp * RP_SLOTS + lane) * RP_SLOTS + slot), p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -167,18 +221,25 @@ __global__ void __launch_bounds__(1024) rnn_persist_kernel(RnnPersistP p) {
 static inline size_t rnn_persist_lds(int tok) { return (size_t)2 * RP_NW * (tok * RP_TPITCH + 32); }
 
 // false: shape not covered (the caller keeps the launch-per-step path).  X must lie below 2 GB from its base (buffer offsets are 32 bit).
+template <int TOK, int MODE, bool RES>
+static inline void rnn_persist_go(hipStream_t st, const RnnPersistP& p) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)rnn_persist_kernel<TOK, MODE, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_persist_lds(TOK)); attr = true; }
+    hipLaunchKernelGGL((rnn_persist_kernel<TOK, MODE, RES>), dim3(RP_NG * RP_SLOTS), dim3(RP_NW * 64), rnn_persist_lds(TOK), st, p);
+}
 static inline bool launch_rnn_persist(hipStream_t st, RnnPersistP p) {
-    if (p.B < 1 || p.S < 2) return false;
+    if (p.B < 1 || p.S < 2 || (p.act != 1 && p.act != 2)) return false;
     p.wpx = (p.B + RP_NG - 1) / RP_NG;
     if (p.wpx > 16 || (long long)p.S * p.B * RP_HID * 2 >= (1ll << 31)) return false;
-    static bool attr8 = false, attr16 = false;
-    if (p.wpx <= 8) {
-        if (!attr8) { hipFuncSetAttribute((const void*)rnn_persist_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_persist_lds(8)); attr8 = true; }
-        hipLaunchKernelGGL(rnn_persist_kernel<8>, dim3(RP_NG * RP_SLOTS), dim3(1024), rnn_persist_lds(8), st, p);
-    } else {
-        if (!attr16) { hipFuncSetAttribute((const void*)rnn_persist_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rnn_persist_lds(16)); attr16 = true; }
-        hipLaunchKernelGGL(rnn_persist_kernel<16>, dim3(RP_NG * RP_SLOTS), dim3(1024), rnn_persist_lds(16), st, p);
-    }
+    if (!p.mask && !p.res) return false;                 // a forward recurrence always has its input projection
+    const int mode = (p.mask ? 2 : 0) + (p.act == 2 ? 1 : 0);
+    const bool big = p.wpx > 8;
+#define RP_GO(M, R) do { if (big) rnn_persist_go<16, M, R>(st, p); else rnn_persist_go<8, M, R>(st, p); } while (0)
+    if (mode == 0) RP_GO(0, true);
+    else if (mode == 1) RP_GO(1, true);
+    else if (mode == 2) { if (p.res) RP_GO(2, true); else RP_GO(2, false); }
+    else { if (p.res) RP_GO(3, true); else RP_GO(3, false); }
+#undef RP_GO
     return true;
 }
 

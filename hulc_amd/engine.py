@@ -243,6 +243,10 @@ class StepEngine:
     def set_dropout(self, p: float):
         L.check(self.lib.hulc_set_dropout(self.ctx, float(p)))
 
+    def set_option(self, name: str, value: int):
+        """Runtime options of the context (include/hulc_hip.h: hulc_set_option), e.g. ``persistent_rnn`` = 0 when processes share one GPU."""
+        L.check(self.lib.hulc_set_option(self.ctx, name.encode(), int(value)))
+
     def timers_enable(self, on: bool = True, only: str = ""):
         L.check(self.lib.hulc_timers_enable(self.ctx, int(on), only.encode()))
 

@@ -234,6 +234,12 @@ int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* token_ids, const int32_t* 
 int hulc_set_kl_beta(hulc_ctx* ctx, float kl_beta);
 int hulc_set_dropout(hulc_ctx* ctx, float p);
 
+/* Runtime options of a context.  "persistent_rnn" (default 1): the 2048-wide recurrences (action decoder nn.RNN,
+ * hulc/models/decoders/utils/rnn.py:5-14; mcil's nn.RNN plan encoder, plan_recognition_net.py:12-42) run as ONE persistent launch per layer
+ * and direction in the 16-bit engines (csrc/rnn_persist.h) — it needs every CU of the GPU; 0 = one launch per time step (choose this when
+ * several processes share one GPU).  Returns non-zero for an unknown name. */
+int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value);
+
 /* HIP-event timers around the launches of each kernel class, recorded on the context's stream (bench.py's roofline leg).
  * hulc_timers_read synchronises and writes a JSON object {"class": {"bound","launches","ms","flops","bytes"}} (algorithmic
  * FLOPs / bytes summed over the timed launches). */
@@ -262,6 +268,13 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
 /* skinny GEMM kernel alone (bf16 in / bf16 out), variant = waves*10 + row-tiles-per-workgroup; 300 = the production router; 400 = TWO
  * independent problems in one launch (second one at A + M*K, W + N*K, out + M*N; 32 < M <= 64, K = 2048); asynchronous. */
 int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K, int32_t variant, void* hip_stream);
+/* one whole recurrence X[q0 + s dq] = f(X[q0 + (s-1) dq] W^T, res, mask), s = 1..S-1, as ONE persistent launch (bf16; csrc/rnn_persist.h).
+ * X, res, mask: [S][B][2048]; W [2048][2048]; mask == NULL: act 1 ReLU / 2 tanh of (product + res); mask given: (product + res) * (mask > 0)
+ * (act 1) or * (1 - mask^2) (act 2).  flags: hulc_k_rnn_persist_flag_words() zero-initialised uint32 (reusable with launch_index = 1, 2, ...),
+ * err: one zero-initialised uint32 (non-zero after a failed launch).  Needs all CUs of the GPU; asynchronous. */
+int hulc_k_rnn_persist(void* X, const void* W, const void* res, const void* mask, int32_t B, int32_t S, int32_t q0, int32_t dq, int32_t act,
+                       uint32_t* flags, uint32_t* err, uint32_t launch_index, void* hip_stream);
+int32_t hulc_k_rnn_persist_flag_words(void);
 int hulc_k_trread_probe(const int32_t* elem_index_per_lane /*64*/, uint16_t* out /*64x4*/, void* hip_stream);
 int hulc_k_cast(int32_t dtype, const float* src, void* dst, int64_t n, void* hip_stream);
 /* the transformer's attention kernels alone (8 heads of 16, fp32 storage so that the check against a float64 softmax is tight):

@@ -357,3 +357,80 @@ def test_fused_transformer_layer_matches_unfused_fp32_engine_under_dropout(B, S,
         tolw = 0.15 if dtype == "bf16" else 0.05
         bad = [(e, n) for e, n in live if e >= (tolw if P[n].ndim == 2 else 2 * tolw)]
         assert not bad, sorted(bad)[-3:]
+
+
+# ---- a whole 2048-wide recurrence as ONE persistent launch (csrc/rnn_persist.h) against float64, every step checked from the device's own
+# previous state (so rounding differences do not compound): forward ReLU / tanh with the Zx residual, backward with the ReLU / tanh derivative
+# mask and with / without the dH residual, both time directions; B from one window (one group active, 1 of 16 tile columns) to 128 (16 per
+# XCD), B = 13 / 100 (a ragged last group), S = 3 .. 33.  The flag words are reused across the launches of one test (launch_index 1, 2, ...),
+# as the engine reuses them across steps.
+@pytest.mark.parametrize("B,S", [(1, 3), (7, 5), (13, 9), (64, 32), (100, 4), (128, 6), (32, 33)])
+def test_rnn_persist_kernel(B, S):
+    import ctypes as C
+    L, lib = _lib()
+    H = 2048
+    rng = np.random.default_rng(B * 100 + S)
+    W = bf(rng.standard_normal((H, H)) * 0.03)
+    flags = torch.zeros(lib.hulc_k_rnn_persist_flag_words(), dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    Wd = f64(W)
+    launch = 0
+    for mode, act, rev, use_res in [("fwd", 1, False, True), ("fwd", 2, True, True), ("bwd", 1, False, True), ("bwd", 2, True, False), ("bwd", 1, True, False)]:
+        res = bf(rng.standard_normal((S, B, H)) * (0.5 if act == 2 else 1.0))
+        mask = bf(rng.standard_normal((S, B, H)) * (0.6 if act == 2 else 1.0))
+        q0, dq = (S - 1, -1) if rev else (0, 1)
+        X = torch.zeros((S, B, H), dtype=torch.bfloat16, device="cuda")
+        X[q0] = bf(np.abs(rng.standard_normal((B, H))) if mode == "fwd" else rng.standard_normal((B, H)))
+        launch += 1
+        L.check(lib.hulc_k_rnn_persist(X.data_ptr(), W.data_ptr(), res.data_ptr() if use_res else None, mask.data_ptr() if mode == "bwd" else None, B, S, q0, dq, act,
+                                       flags.data_ptr(), err.data_ptr(), launch, None))
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0, "persistent launch reported a timeout / census failure"
+        Xd, Rd, Md = f64(X), f64(res), f64(mask)
+        for s in range(1, S):
+            qp, qc = q0 + (s - 1) * dq, q0 + s * dq
+            z = Xd[qp] @ Wd.T + (Rd[qc] if use_res else 0.0)
+            if mode == "fwd":
+                ref = np.maximum(z, 0) if act == 1 else np.tanh(z)
+            else:
+                ref = z * (Md[qc] > 0) if act == 1 else z * (1 - Md[qc] ** 2)
+            e = np.abs(Xd[qc] - ref).max(1) / (np.abs(ref).max(1) + 1e-6)        # per window
+            assert e.max() < 6e-3, (mode, act, rev, s, float(e.max()), int(e.argmax()))
+
+
+# the engine's persistent recurrences (action decoder: 2 layers forward + 2 backward) against the same engine with one launch per time step
+# (hulc_set_option persistent_rnn = 0): the two paths sum the 2048 products of a state element in different orders, so states and gradients
+# agree to 16-bit rounding noise, not bit for bit
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,S", [(5, 7), (16, 32)])
+def test_engine_persistent_recurrence_matches_launch_per_step(B, S, dtype):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from hulc_amd import spec
+    from hulc_amd.engine import StepEngine
+    from hulc_amd.utils import synthetic
+    from test_gpu_parity import to_dev
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    P = spec.init_all(dims, seed=5, ln_jitter=True)
+    batch = synthetic.make_batch(B, 0, S, seed=17)["vis"]
+    res = {}
+    for persist in (1, 0):
+        eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=9)
+        eng.set_option("persistent_rnn", persist)
+        gs = 1.0
+        if dtype == "fp16":
+            gs = 256.0
+            eng.scaler_enable(init_scale=gs)
+        eng.load_numpy(P)
+        eng.zero_grads()
+        l = eng.forward_loss(to_dev(batch), False, 1.0, 0.0, step=3)
+        eng.backward()
+        torch.cuda.synchronize()
+        G = {n: t.detach().cpu().numpy() / gs for n, t in eng.views(eng.flat_grads).items()}
+        res[persist] = dict(loss=l, G=G)
+        eng.close()
+    a, b = res[0], res[1]
+    assert abs(a["loss"]["action"] - b["loss"]["action"]) <= 2e-3 * abs(a["loss"]["action"]) + 1e-5
+    rel = lambda u, v: float(np.linalg.norm(u.astype(np.float64) - v.astype(np.float64)) / max(np.linalg.norm(v.astype(np.float64)), 1e-30))
+    worst = max((rel(b["G"][n], a["G"][n]), n) for n in a["G"] if np.linalg.norm(a["G"][n]) > 1e-8)
+    assert worst[0] < (3e-2 if dtype == "bf16" else 1.5e-2), worst
