@@ -864,8 +864,7 @@ struct Engine : IEngine {
         // ---- plan recognition transformer (plan_recognition_net.py:94-117)
         bool fused = false;
         if constexpr (std::is_same<T, h16_t>::value) {
-            static const bool tr_fused = HULC_SWITCH("HULC_TR_FUSED", 1) != 0;
-            fused = tr_fused && S <= 32;
+            fused = tr_fused_mode && S <= 32;
         }
         hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0),
                            fused ? y2[0] : (float*)nullptr, fused ? y2[1] : (float*)nullptr);
@@ -1263,10 +1262,13 @@ struct Engine : IEngine {
     unsigned rp_launches = 1;
     int rp_B = -1;
     bool rp_probed = false, rp_ok = false;
+    bool persist_usable(int B, int S) const {
+        return std::is_same<T, h16_t>::value && persist_mode && HID == RP_HID && S >= 3 && B <= 16 * RP_NG && !(rp_probed && !rp_ok);
+    }
     bool rnn_persist(T* X, const T* Wm, const T* res, const T* mask, int B, int S, int q0, int dq, int act) {
         if constexpr (!std::is_same<T, h16_t>::value) return false;
         else {
-            if (!persist_mode || HID != RP_HID || S < 3 || B > 16 * RP_NG || (rp_probed && !rp_ok)) return false;
+            if (!persist_usable(B, S)) return false;
             if (!rp_flags) {
                 rp_flags = alloc<unsigned>(RP_FLAG_WORDS);
                 void* h = nullptr;
@@ -1343,7 +1345,7 @@ struct Engine : IEngine {
     void rnn_fwd2(T* const Zx[2], T* const H[2], const LinW* const whh[2], int B, int S, int act) {
         const long long BH = (long long)B * HID;
         bool dual = false;
-        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1 && !persist_usable(B, S);     // two persistent launches (2 x ~90 us at S = 32) beat 31 paired ones
         if (dual) {
             auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
             for (int d = 0; d < 2; ++d) hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx[d] + at(d, 0), H[d] + at(d, 0), BH, act);
@@ -1363,7 +1365,7 @@ struct Engine : IEngine {
     void rnn_bwd2(T* const dH[2], T* const H[2], T* const dZ[2], const LinW* const whh[2], int B, int S, int act) {
         const long long BH = (long long)B * HID;
         bool dual = false;
-        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1;
+        if constexpr (std::is_same<T, h16_t>::value) dual = pair_dirs() && S > 1 && !persist_usable(B, S);
         if (dual) {
             auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
             for (int d = 0; d < 2; ++d)

@@ -62,9 +62,12 @@ struct IEngine {
     // runtime options (hulc_set_option).  "persistent_rnn": 1 (default) = the 2048-wide recurrences of the 16-bit engines run as one
     // persistent launch each (rnn_persist.h) after a first launch has verified the XCD census on this device; 0 = one launch per time step
     // (what a process that SHARES the GPU's CUs with another process must choose: the persistent launch needs all 256 CUs resident)
-    int persist_mode = 1;
+    // "fused_transformer": 1 (default) = one launch per plan-recognition encoder layer in the forward of the 16-bit engines (tr_fused.h, S <= 32);
+    // 0 = the seven unfused launches per layer (what the fp32 engine and S > 32 run) — tests compare the two
+    int persist_mode = 1, tr_fused_mode = 1;
     int set_option(const char* name, long long value) {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
+        if (name && !strcmp(name, "fused_transformer")) { tr_fused_mode = value != 0; return 0; }
         hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
         return 1;
     }

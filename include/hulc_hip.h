@@ -237,7 +237,8 @@ int hulc_set_dropout(hulc_ctx* ctx, float p);
 /* Runtime options of a context.  "persistent_rnn" (default 1): the 2048-wide recurrences (action decoder nn.RNN,
  * hulc/models/decoders/utils/rnn.py:5-14; mcil's nn.RNN plan encoder, plan_recognition_net.py:12-42) run as ONE persistent launch per layer
  * and direction in the 16-bit engines (csrc/rnn_persist.h) — it needs every CU of the GPU; 0 = one launch per time step (choose this when
- * several processes share one GPU).  Returns non-zero for an unknown name. */
+ * several processes share one GPU).  "fused_transformer" (default 1): one launch per plan-recognition encoder layer in the forward of the
+ * 16-bit engines (csrc/tr_fused.h; plan_recognition_net.py:98-117), 0 = the unfused kernels.  Returns non-zero for an unknown name. */
 int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value);
 
 /* HIP-event timers around the launches of each kernel class, recorded on the context's stream (bench.py's roofline leg).

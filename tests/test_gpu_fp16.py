@@ -274,6 +274,10 @@ def test_fp16_checkpoint_resume_continues_the_trajectory():
     steps(m2, opt2, 3, 6)
     got = m2.engine.flat_params
     rel = ((got - ref).double().norm() / (ref - p0).double().norm()).item()
-    assert rel < 2e-3, rel            # same trajectory (fp16 atomics reorder sums; a restarted bias correction would be off by > 0.3)
+    # same trajectory up to what reordered fp32 atomics grow into over three steps of this tiny (B = 2, S = 4) model: two IDENTICAL fresh runs
+    # differ by 3e-4 in their step-0 gradients and by 0.5 - 1.5 % of the distance travelled after six steps (tools/resume_probe.py), and a
+    # stream synchronisation in the resumed context's first step (the persistent recurrence's one-time device check) is enough to change
+    # the order.  A restarted bias correction would be off by > 0.3.
+    assert rel < 0.1, rel
     assert m2.engine.scaler_state()["taken_steps"] == 5
     m2.engine.close()

@@ -10,7 +10,7 @@ copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.cs
           "pmc_hbm_per_kernel.csv": "pmc_hbm_per_kernel.csv", "pmc_traffic.json": "pmc_traffic.json", "sq/mfma_util.csv": "mfma_util.csv",
           "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
           "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt", "conv_reg_vs_tile.txt": "conv_reg_vs_tile.txt", "conv_reg_ablation.txt": "conv_reg_ablation.txt",
-          "step_timeline.txt": "step_timeline.txt"}
+          "step_timeline.txt": "step_timeline.txt", "rnn_persist_stamps.txt": "rnn_persist_stamps.txt"}
 for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
@@ -31,7 +31,7 @@ def grp(pred):
         return 0.0, 0.0, 0.0
     return (sum(float(r["mfma_util"]) * float(r["total_us"]) for r in sel) / tus, sum(float(r["mfma_tflops"]) * float(r["total_us"]) for r in sel) / tus, tus)
 groups = [("conv (conv1 fwd/wgrad, conv2/3 fwd, dgrad, wgrad)", lambda k: "conv" in k and "unpack" not in k),
-          ("RNN decoder, recurrent step (skinny_lds, M=64)", lambda k: "skinny_lds_kernel<2, 4, 16, false> [grid=262144]" in k),
+          ("RNN decoder, recurrences (rnn_persist: one launch per layer and direction; round 2: skinny_lds, M=64, one launch per step)", lambda k: "rnn_persist_kernel" in k or "skinny_lds_kernel<2, 4, 16, false> [grid=262144]" in k),
           ("RNN decoder, batched GEMMs (gemm_glds 128x128)", lambda k: "gemm_glds" in k),
           ("transformer + MLP small GEMMs (gemm_kernel 32/64 tiles, other skinny)", lambda k: ("gemm_kernel<" in k) or ("skinny" in k and "[grid=262144]" not in k) or "lin_bwd" in k)]
 grows = "| GEMM group | MFMA-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES / (time x 2.4 GHz x 1024 SIMDs)) | MFMA TFLOP/s (SQ_INSTS_VALU_MFMA_MOPS x 512 / time) | % of 2.5 PF | profiled us in the 5 dispatched steps |\n|---|---|---|---|---|\n"
@@ -60,6 +60,7 @@ files = f"""| file | what | command |
 | `{T}_bench_n1_fp32.json` | the fp32 PARITY engine (exact-fp32 MFMA, `v_mfma_f32_16x16x4_f32`: 1/16 of the bf16 matrix rate): {var['fp32']['value']:.0f} windows/s, {var['fp32']['ms_per_step']} ms/step | `python bench.py --dtype fp32 --steps 20 --no-cpu-baseline` |
 | `{T}_bench_n1_u8_h2d.json` | uint8 ingest with every step's frames copied from PINNED HOST memory (async H2D on a copy stream, double-buffered; 289 MB per step): {var['u8_h2d']['value']:.0f} windows/s, median step {(var['u8_h2d'].get('step_ms') or {{}}).get('median')} ms — PCIe-bound, SURVEY §8(d)'s H2D-inclusive row (never the headline) | `python bench.py --ingest u8 --h2d 1 --no-cpu-baseline` |
 | `{T}_conv_reg_vs_tile.txt`, `{T}_conv_reg_ablation.txt` | conv2 / conv3 forward and data gradient on 2048 frames: LDS-resident-weights kernels (conv_tile.h) against the weights-in-registers kernels (conv_reg.h); and conv_reg with phases switched off (no DMA / no multiply loop / no epilogue) | `tools/time_conv_reg.py`, `ABLATE=1 tools/time_conv_reg.py` |
+| `{T}_rnn_persist_stamps.txt` | the persistent recurrence alone (`csrc/rnn_persist.h`): every step checked against a CPU recurrence, us per step at B = 64 / 128 (S = 32) and B = 32 (S = 64), shader-clock stamps of the phases of a step (poll, payload, MFMA + LDS, barrier, epilogue, drain) | `tools/bin/rnn_persist_bench_st` (tools/rnn_persist_bench.hip, -DRP_STAMPS) |
 | `{T}_step_timeline.txt` | every launch of one step with start offset, duration, gap and queue | `tools/step_timeline.py` |
 | `{T}_conv_tile_gripper_fpb.txt` | the four conv tile kernels on the gripper camera's shapes with 1 frame per band and with the stacked bands the launch picks | `tools/time_conv_tile_gripper.py` |
 | `{T}_conv_tile_phase_stamps.txt` | shader-clock stamps of the phases of every band of the raw-tile conv kernels (what the conv work of this round was steered by) | `tools/bin/ct_stamps` (tools/ct_stamps.hip) |
@@ -75,8 +76,8 @@ gen = f"""{marker}
 ### Kernel classes, HIP-event timed inside bench.py (survey pass; includes event overhead)
 
 {rows}
-Dominant class `{rl['kernel']}`: {rl['launches_per_step']:.0f} launches/step, {rl['avg_launch_us']} us per launch by HIP events on the engine's stream, algorithmic
-{rl['per_launch']['algorithmic_bytes'] / 1e6:.2f} MB per launch -> {rl['achieved']:.0f} GB/s = **{rl['frac'] * 100:.1f} % of the 8 TB/s HBM roofline**; PMC traffic {(rl['traffic'] or 0) / 1e6:.1f} MB/launch.
+Dominant class `{rl['kernel']}` ({rl['bound']}-bound ruler): {rl['launches_per_step']:.0f} launches/step, {rl['avg_launch_us']} us per launch by HIP events on the engine's stream, algorithmic
+{rl['per_launch']['algorithmic_bytes'] / 1e6:.2f} MB / {rl['per_launch']['algorithmic_flops'] / 1e9:.2f} GFLOP per launch -> {rl['achieved']:.0f} {rl['unit']} = **{rl['frac'] * 100:.1f} % of the {'8 TB/s HBM' if rl['bound'] == 'hbm' else '2.5 PFLOP/s bf16 MFMA'} roofline**; PMC traffic {(rl['traffic'] or 0) / 1e6:.1f} MB/launch.
 
 ### MFMA utilisation per GEMM group (rocprofv3 SQ counters, `{T}_mfma_util.csv`)
 
