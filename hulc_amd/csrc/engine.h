@@ -403,7 +403,9 @@ struct Engine : IEngine {
         const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
         if constexpr (std::is_same<T, h16_t>::value) {
             if (a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p)) {
-                TimerScope ts(this, "skinny_gemm", "hbm", fl, by);
+                // two roles share the skinny kernels: M <= 64 layers stream a whole weight matrix per launch (weight-bound), many-row GEMMs
+                // (small-N heads / weight gradients with K = 2048) stream activations
+                TimerScope ts(this, M <= 64 ? "skinny_gemm_m64" : "skinny_gemm_rows", "hbm", fl, by);
                 launch_skinny(st, a.p, a.s1, b.p, b.s1, M, N, K, om, ep);
                 return;
             }
