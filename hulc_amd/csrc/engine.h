@@ -194,7 +194,8 @@ struct Engine : IEngine {
         dt_a = alloc<T>(std::max<int64_t>(N * FF, 2 * B * HID)); dt_b = alloc<T>(N * 3 * EMB); dt_c = alloc<T>(N * EMB); dgl3_t = alloc<T>(B * GOAL);
         tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>((gru ? 3 : 1) * HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
         tA = alloc<T>(tcap); tB = alloc<T>(tcap);
-        partcap = 1024ll * 64 * 576; part = alloc<float>(partcap); cspart = alloc<float>(1024 * 2048);
+        // conv weight-gradient slabs: the 16-bit engines keep the slabs of ALL convolutions of a backward (one batched unpack launch at its end)
+        partcap = std::is_same<T, h16_t>::value ? 96ll * 1024 * 1024 : 1024ll * 64 * 576; part = alloc<float>(partcap); cspart = alloc<float>(1024 * 2048);
         auxrows = alloc<int>(B); sf_m = alloc<T>(B * FCH); im1 = alloc<T>(B * 128); g_m = alloc<T>(B * GOAL); la1 = alloc<T>(B * 128);
         img = alloc<float>(B * GOAL, "clip_img"); txt = alloc<float>(B * GOAL, "clip_txt"); img_t = alloc<T>(B * GOAL); txt_t = alloc<T>(B * GOAL);
         dimg = alloc<float>(B * GOAL); dtxt = alloc<float>(B * GOAL); dimg_t = alloc<T>(B * GOAL); dtxt_t = alloc<T>(B * GOAL);
@@ -243,6 +244,12 @@ struct Engine : IEngine {
         d.tiles_x = cdiv(C, TRT); d.blk0 = tr_blocks; tr_blocks += d.tiles_x * cdiv(R, TRT);
         trdesc.push_back(d);
     }
+    // a transpose whose source is a packed compute-type buffer of this engine (not a parameter): T -> T in both engine kinds
+    void add_tr_packed(const T* src, T* wt, int R, int C) {
+        TrDesc d; d.src = src; d.dst = wt; d.lds = C; d.ldt = R; d.R = R; d.C = C;
+        d.tiles_x = cdiv(C, TRT); d.blk0 = tr_blocks; tr_blocks += d.tiles_x * cdiv(R, TRT);
+        trdesc.push_back(d);
+    }
     void bind_conv(ConvW& c, const std::string& name, int O, int I, int K, int S, int nhwc) {
         c.W32 = pw(name + ".weight"); c.b32 = pw(name + ".bias"); c.dW = gw(name + ".weight"); c.db = gw(name + ".bias");
         c.O = O; c.I = I; c.KH = c.KW = K; c.S = S; c.nhwc = nhwc;
@@ -260,6 +267,7 @@ struct Engine : IEngine {
             e.fc7.dW = gw(pre + "conv_model.7.weight"); e.fc7.db = gw(pre + "conv_model.7.bias");
             e.fc7.N = 128; e.fc7.K = 3136;
             if (!e.fc7.W) { e.fc7.W = alloc<T>(128 * 3136); e.fc7.Wt = alloc<T>(128 * 3136); e.fc7.own_w = true; }
+            add_tr_packed(e.fc7.W, e.fc7.Wt, 128, 3136);      // transposed copy of the PERMUTED weight (weight_pack_kernel writes it just before the batched transpose)
         }
         bind_lin(e.fc1, pre + "fc1.0", 512, 128);
         bind_lin(e.fc2, pre + "fc2", 64, 512);
@@ -327,6 +335,7 @@ struct Engine : IEngine {
             bind_lin(whh0, ad + "rnn.weight_hh_l0", HID, HID, false);
             bind_lin(wih1, ad + "rnn.weight_ih_l1", HID, HID, false);
             bind_lin(whh1, ad + "rnn.weight_hh_l1", HID, HID, false);
+            add_tr_packed(wheads, wheadsT, NHEAD, HID);      // the packed heads' transposed copy rides on the batched transpose as well
             const char* hn[4] = {"prob_fc", "mean_fc", "log_scale_fc", "gripper_fc"};
             for (int i = 0; i < 4; ++i) { head_w32[i] = head_b32[i] = nullptr; head_dw[i] = head_db[i] = nullptr; }
             for (int i = 0; i < (mcil ? 3 : 4); ++i) {
@@ -496,14 +505,17 @@ struct Engine : IEngine {
                 float* stats) {
         hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, rows, n, g, b, out, ldo, outf, ldf, stats);
     }
+    // bcast_rows > 0 (fused kernel only, see ln_bwd_can_bcast): dy holds one row per WINDOW, broadcast over its bcast_rows rows and divided by bcast_div
+    static constexpr bool ln_bwd_can_bcast = std::is_same<T, h16_t>::value;
     void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
-                long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db, float drop_p = 0.f, unsigned long long drop_seed = 0) {
+                long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db, float drop_p = 0.f, unsigned long long drop_seed = 0,
+                int bcast_rows = 0, float bcast_div = 1.f) {
         if constexpr (std::is_same<T, h16_t>::value) {
             static const bool fused = HULC_SWITCH("HULC_LN_FUSED", 1) != 0;
-            if (fused) {
+            if (fused || bcast_rows > 0) {
                 const int rpb = rows >= 1024 ? 16 : 4;
                 hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
-                                   drop_p, drop_seed, rpb, dg, db);
+                                   drop_p, drop_seed, rpb, dg, db, bcast_rows, bcast_div);
                 return;
             }
         }
@@ -530,9 +542,7 @@ struct Engine : IEngine {
         if constexpr (!std::is_same<T, float>::value) {
             if (!shadow_fresh) hipLaunchKernelGGL((cast_kernel<float, T>), dim3(2048), dim3(256), 0, st, P, wshadow, (long long)numel);
         }
-        if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
-        else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
-        {      // the six conv weight packs: one launch
+        {      // the six conv weight packs, the gripper fc7's NHWC column permutation and the packed decoder heads: one launch (weight_pack_kernel) ...
             ConvPackBatch d;
             int k = 0, blk = 0;
             for (EncW* e : {&encS, &encG})
@@ -541,22 +551,16 @@ struct Engine : IEngine {
                     d.blk0[k] = blk; blk += cdiv(c->O * c->I * c->KH * c->KW, 256); ++k;
                 }
             d.blk0[6] = blk;
-            hipLaunchKernelGGL((pack_conv_w_batched_kernel<T>), dim3(blk), dim3(256), 0, st, d);
-        }
-        for (EncW* e : {&encS, &encG}) {
-            if (e->gripper) {
-                // W7p[o][p*64+c] = W7[o][c*49+p]; then transposed copy
-                hipLaunchKernelGGL((permute_cols_kernel<float, T>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, e->fc7.W32, e->fc7.W, 128, 64, 49, 0, 0);
-                cast_tr<T, T>(e->fc7.W, 3136, nullptr, 0, e->fc7.Wt, 128, 128, 3136);
-            }
-        }
-        // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
-        {
+            const int blkA = blk, blkB = blkA + cdiv(128 * 3136, 256);
+            // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
             const HeadPack hp = head_pack();
             const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
-            hipLaunchKernelGGL((pack_heads_kernel<T>), dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, wheads, bheads, HID);
+            hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(blkB + cdiv((long long)rows * HID, 256)), dim3(256), 0, st, d, blkA, encG.fc7.W32, encG.fc7.W, 128, 64, 49, blkB, hp,
+                               wheads, bheads, HID);
         }
-        cast_tr<T, T>(wheads, HID, nullptr, 0, wheadsT, NHEAD, NHEAD, HID);
+        // ... then every transposed copy — the Linear weights, the permuted fc7 and the packed heads — in ONE batched launch
+        if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
         return 0;
@@ -659,10 +663,21 @@ struct Engine : IEngine {
         ln_fwd(a.f2, 64, Nf, 64, e.lng, e.lnb, emb + col0, EMB, nullptr, 0, a.lnst);
     }
     Conv1Src wgrad_src;                       // conv1 only: set by enc_bwd before conv_wgrad(e.c1, ...)
+    // 16-bit engines: the slab -> gradient reductions of the encoders' convolutions are collected and run as ONE launch (flush_unpacks) after
+    // both encoders' backward instead of one ~6-20 us launch behind each of the six weight-gradient kernels
+    UnpackBatch unpack_jobs{};
+    int64_t part_cur = 0;
+    int unpack_blocks = 0;
+    void flush_unpacks() {
+        if (unpack_jobs.n > 0) hipLaunchKernelGGL(unpack_conv_wgrad_batched_kernel, dim3(unpack_blocks, 16), dim3(256), 0, st, unpack_jobs);
+        unpack_jobs.n = 0; part_cur = 0; unpack_blocks = 0;
+    }
     void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {
         const int Kc = c.I * c.KH * c.KW;
         const long long npix = (long long)g.Nf * g.OH * g.OW;
         int nsplit = 0;
+        float* const part = this->part + part_cur;
+        const int64_t partcap = this->partcap - part_cur;
         if constexpr (std::is_same<T, h16_t>::value) {
             // raw-tile + transposing-LDS-read kernel (conv_wgrad.h); slabs = persistent workgroups
             TimerScope ts(this, conv1 ? "conv1_wgrad" : "conv_wgrad_tr", conv1 ? "hbm" : "mfma", 2.0 * npix * c.O * Kc,
@@ -692,6 +707,15 @@ struct Engine : IEngine {
         // slab parts over grid.y, each landing with one fp32 atomic per element.  16 parts: more (21 / 24 / 64 for conv3 / conv2 / conv1) made
         // every launch slower (23 / 11.3 / 10.9 us against 18.6 / 9.5 / 9.6: the scattered atomics, not the slab stream, are the cost)
         const int ybl = cdiv(c.O * Kc, 1024);
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (nsplit >= 64 && unpack_jobs.n < 8 && part_cur + (int64_t)nsplit * c.O * Kc <= this->partcap) {
+                UnpackJob& J = unpack_jobs.j[unpack_jobs.n++];
+                J.part = part; J.grad = c.dW; J.slab = (long long)c.O * Kc; J.nsplit = nsplit; J.O = c.O; J.I = c.I; J.KH = c.KH; J.KW = c.KW; J.nhwc = c.nhwc; J.blk0 = unpack_blocks;
+                unpack_blocks += ybl; part_cur += (int64_t)nsplit * c.O * Kc;
+                if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
+                return;
+            }
+        }
         static const int ypart_env = HULC_SWITCH("HULC_UNPACK_Y", 16);
         const int yparts = (!std::is_same<T, float>::value && nsplit >= 64) ? ypart_env : 1;
         hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ybl, yparts), dim3(256), 0, st, part, nsplit, (long long)c.O * Kc,   // fp32 (parity) mode: one deterministic pass, no atomics
@@ -904,8 +928,8 @@ struct Engine : IEngine {
         }
         // mean over S commutes with the affine fc (:113-114): seq_feat = fc(mean_t x)
         hipLaunchKernelGGL((mean_over_s_kernel<T>), dim3(cdiv(B * EMB, 256)), dim3(256), 0, st, xf[2], B, S, EMB, xm);
-        { EpiP ep = epi(seqf, true); lin_fwd(xm, EMB, B, pr_fc, ep, FCH); }
-        hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, seqf, seqf_t, (long long)B * FCH);
+        { EpiP ep = epi(seqf, true); ep.out2 = seqf_t; ep.out2_lo = 0; ep.out2_hi = (long long)B * FCH;      // the 16-bit copy the next GEMM reads: a second store of the epilogue
+          lin_fwd(xm, EMB, B, pr_fc, ep, FCH); }
         { EpiP ep = epi(pr_logits, true); lin_fwd(seqf_t, FCH, B, pr_fs, ep, PLAN); }
         STAGE("plan_recognition_fwd");
     }
@@ -915,12 +939,13 @@ struct Engine : IEngine {
         const int SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
             // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
-            hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * DE, 256)), dim3(256), 0, st, emb, embg, B, S, DE);
             if (mcil) {      // continuous plan (B,256): a GEMM against the plan columns of W_ih0 instead of the one-hot column gather
+                hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * DE, 256)), dim3(256), 0, st, emb, embg, B, S, DE);
                 EpiP ep = epi(Cplan, true); ep.bias = bih0; ep.bias2 = bhh0;
                 gemm(dense<T>(plan_t, B, dec_plan), dense<T>(wih0, HID, KIN), dense_out(HID), ep, B, HID, dec_plan);
-            } else
-            hipLaunchKernelGGL((plan_gather_t_kernel<T>), dim3(cdiv(B * HID, 256)), dim3(256), 0, st, wih0T, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0, bhh0, Cplan);
+            } else      // the one-hot plan gather and the time-major embedding copy are independent: one launch
+            hipLaunchKernelGGL((plan_gather_t_kernel<T>), dim3(cdiv(B * HID, 256) + cdiv(SB * DE, 256)), dim3(256), 0, st, wih0T, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0,
+                               bhh0, Cplan, emb, embg, S, DE);
             { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
               gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + DE, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
             const long long BH = (long long)B * HID;
@@ -1000,6 +1025,7 @@ struct Engine : IEngine {
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         const float dp = cfg.dropout_p;
         const int Bm = pair ? pairBv : B;                    // windows per modality: the reference's means (and so the gradient scales) are per modality
+        const float* kl_src = nullptr; int kl_n = 0;
         HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
         if (pair) HIP_CHECK(hipMemsetAsync(losses2, 0, 8 * sizeof(float), st));
         trunk_fwd(b, dp);
@@ -1011,8 +1037,10 @@ struct Engine : IEngine {
             const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL((normal_kl_sample_kernel<T>), dim3(cdiv(B * n, 256)), dim3(256), 0, st, pr_logits, pp_logits, B, n, eps, plan_eps, plan_f, plan_t, klel,
                                dpp_kl, dpr_kl, wpp, wpr, site_seed(20), lscale());
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, Bm * n, cfg.kl_beta / Bm, losses + 1);
-            if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel + (long long)Bm * n, Bm * n, cfg.kl_beta / Bm, losses2 + 1);
+            if (pair) {
+                hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel, Bm * n, cfg.kl_beta / Bm, losses + 1);
+                hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klel + (long long)Bm * n, Bm * n, cfg.kl_beta / Bm, losses2 + 1);
+            } else { kl_src = klel; kl_n = Bm * n; }      // summed by finish_losses_kernel at the end of the forward
         } else pr_fwd(B, S, dp);
         // ---- sample + KL (hulc.py:289-296, 539-561)
         if (hulc) {
@@ -1021,8 +1049,10 @@ struct Engine : IEngine {
             const float wpp = lw * cfg.kl_beta * cfg.kl_balancing_mix / Bm, wpr = lw * cfg.kl_beta * (1.f - cfg.kl_balancing_mix) / Bm;
             hipLaunchKernelGGL(plan_kl_sample_kernel, dim3(B * NCAT), dim3(64), 0, st, pr_logits, pp_logits, B, NCAT, NCLS, idx_in, pidx, probs, klcat, dpp_kl,
                                dpr_kl, wpp, wpr, site_seed(20), lscale());
-            hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, Bm * NCAT, cfg.kl_beta / Bm, losses + 1);
-            if (pair) hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat + Bm * NCAT, Bm * NCAT, cfg.kl_beta / Bm, losses2 + 1);
+            if (pair) {
+                hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat, Bm * NCAT, cfg.kl_beta / Bm, losses + 1);
+                hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, klcat + Bm * NCAT, Bm * NCAT, cfg.kl_beta / Bm, losses2 + 1);
+            } else { kl_src = klcat; kl_n = Bm * NCAT; }
         }
         // ---- action decoder (logistic_decoder_rnn.py:260-287): plan/goal terms hoisted out of the time loop
         {
@@ -1032,7 +1062,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, ll_block)), dim3(ll_block), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
             if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);
-            else hipLaunchKernelGGL(sum_reduce_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, losses + 0);
+            // one modality: the action-loss sum, the KL sum, the packing and the copy to a device `out` are ONE launch at the end (finish_losses_kernel)
         }
         STAGE("decoder_fwd");
         // ---- CLIP auxiliary loss (hulc.py:650-695), lang modality, masked rows
@@ -1057,14 +1087,17 @@ struct Engine : IEngine {
         STAGE("clip_fwd");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in forward"); return 1; }
         have_fwd = true;
-        if (out) {
-            // [total_mod, kl, action, clip]
-            hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses);
-            if (pair) hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses2);
-            const hipMemcpyKind kind = on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-            HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), kind, st));
-            if (pair) HIP_CHECK(hipMemcpyAsync(out + 4, losses2 + 4, 4 * sizeof(float), kind, st));
-            if (on_host) HIP_CHECK(hipStreamSynchronize(st));
+        // [total_mod, kl, action, clip]; a device `out` is written by the kernels themselves
+        float* const dev_out = (out && !on_host) ? out : nullptr;
+        if (!pair) hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, kl_src, kl_n, cfg.kl_beta / Bm, losses, dev_out);
+        else if (out) {
+            hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses, dev_out);
+            hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses2, dev_out ? dev_out + 4 : (float*)nullptr);
+        }
+        if (out && on_host) {
+            HIP_CHECK(hipMemcpyAsync(out, losses + 4, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (pair) HIP_CHECK(hipMemcpyAsync(out + 4, losses2 + 4, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
         }
         return 0;
     }
@@ -1784,7 +1817,7 @@ struct Engine : IEngine {
         HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
         work_ctr_next = 0;
         {
-        bool have_dseq = false;
+        bool have_dseq = false, dseq_cast_done = false;
         // ---- CLIP backward
         if (clip_n > 0) {
             const int n = clip_n;
@@ -1876,7 +1909,10 @@ struct Engine : IEngine {
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             // fc_state of plan recognition
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
-            { EpiP ep = epi(dseqf, true); ep.accumulate = 1; lin_dgrad(dprl_t, B, pr_fs, ep, dense_out(FCH)); }
+            { EpiP ep = epi(dseqf, true);
+              if (have_dseq) ep.accumulate = 1;       // the CLIP branch already wrote its share
+              else { ep.out2 = dseq_t; ep.out2_lo = 0; ep.out2_hi = (long long)B * FCH; dseq_cast_done = true; }     // sole contribution: plain store + the 16-bit copy in the same epilogue
+              lin_dgrad(dprl_t, B, pr_fs, ep, dense_out(FCH)); }
             have_dseq = true;
         }
         // ---- mcil: reparametrised sample + KL -> fc_state grads; plan proposal and BiRNN backward
@@ -1893,14 +1929,16 @@ struct Engine : IEngine {
         }
         // ---- plan recognition backward
         if (have_dseq) {
-            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, dseqf, dseq_t, (long long)B * FCH);
+            if (!dseq_cast_done) hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * FCH, 256)), dim3(256), 0, st, dseqf, dseq_t, (long long)B * FCH);
             lin_wgrad(dseq_t, xm, EMB, B, FCH, EMB, pr_fc.dW, EMB, pr_fc.db);
             { EpiP ep = epi(dxm, true); lin_dgrad(dseq_t, B, pr_fc, ep, dense_out(EMB)); }
             float* dx = dxa; float* dnext = dxb;
-            hipLaunchKernelGGL(bcast_over_s_kernel, dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dxm, B, S, EMB, dx);
+            if (!ln_bwd_can_bcast) hipLaunchKernelGGL(bcast_over_s_kernel, dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dxm, B, S, EMB, dx);
             for (int l = 1; l >= 0; --l) {
-                // LN2
-                ln_bwd(dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n2g[l], d_tr_n2b[l], dp, site_seed(4 + 4 * l));   // dt_c = dropout mask of the FFN branch applied to dy_f
+                // LN2 (16-bit engines: the last layer's incoming gradient dxm / S is broadcast over the window inside the kernel)
+                const bool bc = ln_bwd_can_bcast && l == 1;
+                ln_bwd(bc ? dxm : dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n2g[l], d_tr_n2b[l], dp, site_seed(4 + 4 * l),
+                       bc ? S : 0, (float)S);   // dt_c = dropout mask of the FFN branch applied to dy_f
                 lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
                 { EpiP ep = epi(dt_a, false); ep.mask = hff[l]; ep.alpha = dp > 0.f ? 1.f / (1.f - dp) : 1.f; lin_dgrad(dt_c, N, tr_l2[l], ep, dense_out(FF)); }
                 lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
@@ -1922,9 +1960,7 @@ struct Engine : IEngine {
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
             }
             // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
-            hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, dx, dy_f, (T*)nullptr, (long long)N * EMB, dp, site_seed(0));
-            copy2d<float, float>(dy_f, EMB, demb, EMB, N, EMB, 1);
-            hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dy_f, B, S, EMB, dpos);
+            hipLaunchKernelGGL(pr_input_bwd_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dx, B, S, EMB, dp, site_seed(0), demb, dpos);
         }
         STAGE("plan_recognition_bwd");
         if (bucket_ready(1) || bucket_ready(2)) return 1;   // plan_recognition.* final (plan_proposal too for the kinds that never touch it)
@@ -1964,6 +2000,7 @@ struct Engine : IEngine {
             enc_bwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr);
             STAGE("enc_static_bwd");
             enc_bwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
+            flush_unpacks();
             STAGE("enc_gripper_bwd");
         }
         if (bucket_ready(4)) return 1;       // perceptual_encoder.* final

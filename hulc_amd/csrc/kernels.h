@@ -206,6 +206,45 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsp
     }
 }
 
+// the same for up to eight convolutions in ONE launch (the encoders' backward deferred its six unpack launches to its end): job = the
+// convolution whose block range holds blockIdx.x; every job owns its own slab region
+struct UnpackJob { const float* part; float* grad; long long slab; int nsplit, O, I, KH, KW, nhwc, blk0; };
+struct UnpackBatch { UnpackJob j[8]; int n; };
+__global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
+    int k = 0;
+    while (k + 1 < ub.n && (int)blockIdx.x >= ub.j[k + 1].blk0) ++k;
+    const UnpackJob J = ub.j[k];
+    const int idx = ((blockIdx.x - J.blk0) * blockDim.x + threadIdx.x) * 4;
+    const int total = J.O * J.I * J.KH * J.KW;
+    if (idx >= total) return;
+    const int per = (J.nsplit + gridDim.y - 1) / gridDim.y;
+    const int z0 = blockIdx.y * per, z1 = min(J.nsplit, z0 + per);
+    if (z0 >= z1) return;
+    const float* part = J.part;
+    const long long slab = J.slab;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(part + (long long)z * slab + idx), b = *reinterpret_cast<const float4*>(part + (long long)(z + 1) * slab + idx);
+        const float4 c = *reinterpret_cast<const float4*>(part + (long long)(z + 2) * slab + idx), d = *reinterpret_cast<const float4*>(part + (long long)(z + 3) * slab + idx);
+        add4(s0, a); add4(s1, b); add4(s2, c); add4(s3, d);
+    }
+    for (; z < z1; ++z) add4(s0, *reinterpret_cast<const float4*>(part + (long long)z * slab + idx));
+    const float v[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int dst = idx + e;
+        if (J.nhwc) {
+            int ci = dst % J.I, t = dst / J.I;
+            int kw = t % J.KW; t /= J.KW;
+            int kh = t % J.KH, o = t / J.KH;
+            dst = ((o * J.I + ci) * J.KH + kh) * J.KW + kw;
+        }
+        unsafeAtomicAdd(J.grad + dst, v[e]);
+    }
+}
+
 // dst[r][perm(c)] = src[r][c] with c = ch*P + p  ->  perm(c) = p*CH + ch   (torch Flatten(C,H,W) <-> NHWC flatten)
 template <typename TS, typename TD>
 __global__ void permute_cols_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int R, int CH, int P, int inverse,
@@ -497,6 +536,56 @@ __global__ void pack_heads_kernel(HeadPack hp, T* __restrict__ wheads, float* __
     wheads[idx] = from_f<T>(hp.w[i][(long long)r * HID + k]);
     if (k == 0) bheads[idx / HID] = hp.b[i][r];
 }
+// the three independent repacks that follow an optimizer step in ONE launch (they were three): blocks [0, blkA) the six conv weight packs
+// (pack_conv_w_batched_kernel's body), [blkA, blkB) the gripper fc7's NHWC column permutation (permute_cols_kernel, R x (CH * P) fp32 -> T),
+// [blkB, ..) the packed decoder heads (pack_heads_kernel).  Their transposed copies ride on the batched transpose launch that follows.
+template <typename T>
+__global__ void __launch_bounds__(256) weight_pack_kernel(ConvPackBatch d, int blkA, const float* __restrict__ fc7_src, T* __restrict__ fc7_dst, int R7, int CH7,
+                                                          int P7, int blkB, HeadPack hp, T* __restrict__ wheads, float* __restrict__ bheads, int HID) {
+    const int bid = blockIdx.x;
+    if (bid < blkA) {
+        int c = 0;
+        while (c < 5 && bid >= d.blk0[c + 1]) ++c;
+        const int idx = (bid - d.blk0[c]) * blockDim.x + threadIdx.x;
+        const int O = d.O[c], I = d.I[c], KH = d.K[c], KW = d.K[c], S = d.S[c];
+        if (idx >= O * I * KH * KW) return;
+        int kw = idx % KW, t = idx / KW;
+        int kh = t % KH; t /= KH;
+        int ci = t % I, o = t / I;
+        const float v = d.w[c][idx];
+        T* wf = reinterpret_cast<T*>(d.wf[c]);
+        T* wd = reinterpret_cast<T*>(d.wd[c]);
+        if (wf) {
+            if (d.nhwc[c]) wf[(long long)o * (KH * KW * I) + (kh * KW + kw) * I + ci] = from_f<T>(v);
+            else wf[idx] = from_f<T>(v);
+        }
+        if (wd) {
+            const int ph = kh % S, a = kh / S, pw = kw % S, b = kw / S;
+            const int TA = KH / S, TB = KW / S;
+            const int zc = ph * S + pw;
+            wd[((long long)zc * I + ci) * (TA * TB * O) + (a * TB + b) * O + o] = from_f<T>(v);
+        }
+        return;
+    }
+    if (bid < blkB) {
+        const long long idx = (long long)(bid - blkA) * blockDim.x + threadIdx.x;
+        if (idx >= (long long)R7 * CH7 * P7) return;
+        const int c = idx % (CH7 * P7);
+        const long long r = idx / (CH7 * P7);
+        const int ch = c / P7, pp = c % P7;
+        fc7_dst[r * (CH7 * P7) + pp * CH7 + ch] = from_f<T>(fc7_src[idx]);
+        return;
+    }
+    const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
+    const long long idx = (long long)(bid - blkB) * blockDim.x + threadIdx.x;
+    if (idx >= (long long)total_rows * HID) return;
+    int r = (int)(idx / HID);
+    const int k = (int)(idx % HID);
+    int i = 0;
+    while (i < 3 && r >= hp.rows[i]) { r -= hp.rows[i]; ++i; }
+    wheads[idx] = from_f<T>(hp.w[i][(long long)r * HID + k]);
+    if (k == 0) bheads[idx / HID] = hp.b[i][r];
+}
 __global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ dw, const float* __restrict__ db, int HID) {
     const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,7 +663,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
                                                                   long long ldx, const float* __restrict__ stats, const float* __restrict__ g,
                                                                   int rows, int n, float* __restrict__ dx_f32, long long ldd, int accumulate,
                                                                   T* __restrict__ dx_t, long long ldt, float drop_p, unsigned long long seed,
-                                                                  int rows_per_block, float* __restrict__ dg, float* __restrict__ db) {
+                                                                  int rows_per_block, float* __restrict__ dg, float* __restrict__ db,
+                                                                  int dy_rowdiv = 0, float dy_div = 1.f) {
+    // dy_rowdiv > 0: the incoming gradient is a per-WINDOW vector broadcast over the window's dy_rowdiv rows and divided by dy_div
+    // (the mean over S in front of plan_recognition.fc: bcast_over_s_kernel's job, read here instead of materialised)
     __shared__ float red[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -583,10 +675,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
     for (int row = r0 + wave; row < r1; row += 4) {
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         const float* xr = x + (long long)row * ldx;
-        const float* dr = dy + (long long)row * lddy;
+        const float* dr = dy + (long long)(dy_rowdiv > 0 ? row / dy_rowdiv : row) * lddy;
         float xh0 = 0.f, xh1 = 0.f, d0 = 0.f, d1 = 0.f;
         if (lane < n) { xh0 = (xr[lane] - mean) * rstd; d0 = dr[lane]; }
         if (lane + 64 < n) { xh1 = (xr[lane + 64] - mean) * rstd; d1 = dr[lane + 64]; }
+        if (dy_rowdiv > 0) { d0 /= dy_div; d1 /= dy_div; }
         sg0 += d0 * xh0; sb0 += d0; sg1 += d1 * xh1; sb1 += d1;
         const float q0 = d0 * g0, q1 = d1 * g1;
         const float m1 = wave_sum(q0 + q1) / n;
@@ -1067,6 +1160,30 @@ __global__ void bcast_over_s_kernel(const float* __restrict__ dxm, int B, int S,
     const int b = idx / ((long long)S * D);
     dx[idx] = dxm[b * D + d] / S;
 }
+// backward of x0 = dropout(emb + pos) in ONE launch (was dropout_apply + copy2d + pos_grad): g = mask * dx / (1 - p);
+// demb[b][t][d] += g ; dpos[t][d] += sum_b g (b ascending, like pos_grad_kernel).  One thread per (t, d), eight windows in flight.
+__global__ void __launch_bounds__(256) pr_input_bwd_kernel(const float* __restrict__ dx, int B, int S, int D, float drop_p, unsigned long long seed,
+                                                           float* __restrict__ demb, float* __restrict__ dpos) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    const long long SD = (long long)S * D;
+    float s = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? dx[(b0 + u) * SD + idx] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (b0 + u >= B) break;
+            const long long o = (b0 + u) * SD + idx;
+            float g = v[u];
+            if (drop_p > 0.f) g = hash_uniform(seed, o) < drop_p ? 0.f : g / (1.f - drop_p);
+            demb[o] += g;
+            s += g;
+        }
+    }
+    dpos[idx] += s;
+}
 // dpos[t][d] += sum_b dx[b][t][d]
 __global__ void pos_grad_kernel(const float* __restrict__ dx, int B, int S, int D, float* __restrict__ dpos) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1236,7 +1353,20 @@ __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restr
 // read from the transposed compute copy WihT [KIN][H]: consecutive threads read consecutive i (coalesced)
 template <typename T>
 __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
-                                     const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out) {
+                                     const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out,
+                                     const T* __restrict__ emb = nullptr, T* __restrict__ embg = nullptr, int S = 0, int W = 0) {
+    // blocks past the B * H / blockDim of the plan gather carry the (independent) time-major copy of the embedding's last W columns
+    // (gather_embg_kernel's job: embg[(t*B+b)*W + c] = emb[(b*S+t)*128 + (128-W) + c]) — one launch instead of two
+    const int nb_plan = (B * H + blockDim.x - 1) / blockDim.x;
+    if ((int)blockIdx.x >= nb_plan) {
+        const int i2 = (blockIdx.x - nb_plan) * blockDim.x + threadIdx.x;
+        if (i2 < S * B * W) {
+            const int c = i2 % W, r = i2 / W;
+            const int t = r / B, b = r % B;
+            embg[i2] = emb[((long long)b * S + t) * 128 + (128 - W) + c];
+        }
+        return;
+    }
     // H % blockDim == 0: a block lies within one b, so its NCAT row indices are fetched once and the NCAT weight loads are independent
     __shared__ int sidx[64];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1531,6 +1661,49 @@ __global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, c
     if (slot == 7)
         for (int c = 3 * NO + (discrete_gripper ? 2 : 0); c < ldh; ++c) dr[c] = from_f<T>(0.f);
     row_loss[gid] = loss;
+}
+
+// scale * sum(x[0..n)) by one block of 256 threads (deterministic tree); the value is returned to thread 0
+DEVI float block_sum256(const float* __restrict__ x, int n, float* red) {
+    float s = 0.f;
+    if ((n & 3) == 0 && (reinterpret_cast<unsigned long long>(x) & 15) == 0) {      // 16-byte loads, 4 independent chains in flight
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const int n4 = n >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = threadIdx.x;
+        for (; i + 768 < n4; i += 1024) {
+            const float4 a = x4[i], b = x4[i + 256], c = x4[i + 512], d = x4[i + 768];
+            s0 += (a.x + a.y) + (a.z + a.w); s1 += (b.x + b.y) + (b.z + b.w); s2 += (c.x + c.y) + (c.z + c.w); s3 += (d.x + d.y) + (d.z + d.w);
+        }
+        for (; i < n4; i += 256) { const float4 a = x4[i]; s0 += (a.x + a.y) + (a.z + a.w); }
+        s = (s0 + s1) + (s2 + s3);
+    } else
+        for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+// the end of a one-modality forward in ONE launch (was: two sum_reduce launches, pack_losses, a 16-byte device copy): l[0] = s0 * sum(x0)
+// (action loss), l[1] = s1 * sum(x1) (KL; x1 == null keeps l[1]), l[4..7] = [action + kl, kl, action, clip], optionally copied to a DEVICE out[4].
+// Same summation order as sum_reduce_kernel.
+__global__ void __launch_bounds__(256) finish_losses_kernel(const float* __restrict__ x0, int n0, float s0, const float* __restrict__ x1, int n1, float s1,
+                                                            float* __restrict__ l, float* __restrict__ out) {
+    __shared__ float red[256];
+    const float a = block_sum256(x0, n0, red) * s0;
+    float k = 0.f;
+    if (x1) k = block_sum256(x1, n1, red) * s1;
+    if (threadIdx.x == 0) {
+        if (!x1) k = l[1];
+        l[0] = a; l[1] = k;
+        const float c = l[2];
+        l[4] = a + k; l[5] = k; l[6] = a; l[7] = c;
+        if (out) { out[0] = a + k; out[1] = k; out[2] = a; out[3] = c; }
+    }
 }
 
 // out[0] = scale * sum(x[0..n))   (single block, deterministic tree)
@@ -1849,9 +2022,10 @@ __global__ void gather_embg_kernel(const T* __restrict__ emb, T* __restrict__ ou
     const int t = r / B, b = r % B;
     out[idx] = emb[((long long)b * S + t) * 128 + (128 - W) + c];
 }
-// losses[4..7] = [action + kl, kl, action, clip]
-__global__ void pack_losses_kernel(float* __restrict__ l) {
+// losses[4..7] = [action + kl, kl, action, clip] (+ a copy to a DEVICE out[4])
+__global__ void pack_losses_kernel(float* __restrict__ l, float* __restrict__ out = nullptr) {
     l[4] = l[0] + l[1]; l[5] = l[1]; l[6] = l[0]; l[7] = l[2];
+    if (out) { out[0] = l[4]; out[1] = l[5]; out[2] = l[6]; out[3] = l[7]; }
 }
 
 }  // namespace HULC_NS
