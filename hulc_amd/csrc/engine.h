@@ -1960,7 +1960,10 @@ struct Engine : IEngine {
                 { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
             }
             // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
-            hipLaunchKernelGGL(pr_input_bwd_kernel, dim3(cdiv(S * EMB, 256)), dim3(256), 0, st, dx, B, S, EMB, dp, site_seed(0), demb, dpos);
+            {
+                const int bchunk = std::is_same<T, float>::value ? B : 8;       // fp32 (parity) engine: one deterministic pass over the windows
+                hipLaunchKernelGGL(pr_input_bwd_kernel, dim3(cdiv(S * EMB, 256), cdiv(B, bchunk)), dim3(256), 0, st, dx, B, S, EMB, dp, site_seed(0), demb, dpos, bchunk);
+            }
         }
         STAGE("plan_recognition_bwd");
         if (bucket_ready(1) || bucket_ready(2)) return 1;   // plan_recognition.* final (plan_proposal too for the kinds that never touch it)

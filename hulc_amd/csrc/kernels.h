@@ -1161,20 +1161,22 @@ __global__ void bcast_over_s_kernel(const float* __restrict__ dxm, int B, int S,
     dx[idx] = dxm[b * D + d] / S;
 }
 // backward of x0 = dropout(emb + pos) in ONE launch (was dropout_apply + copy2d + pos_grad): g = mask * dx / (1 - p);
-// demb[b][t][d] += g ; dpos[t][d] += sum_b g (b ascending, like pos_grad_kernel).  One thread per (t, d), eight windows in flight.
+// demb[b][t][d] += g ; dpos[t][d] += sum_b g.  One thread per (t, d) and window chunk (grid.y chunks of `bchunk` windows, eight in flight);
+// grid.y == 1 (fp32 parity engine) adds b ascending like pos_grad_kernel, grid.y > 1 lands each chunk's partial sum with one fp32 atomic.
 __global__ void __launch_bounds__(256) pr_input_bwd_kernel(const float* __restrict__ dx, int B, int S, int D, float drop_p, unsigned long long seed,
-                                                           float* __restrict__ demb, float* __restrict__ dpos) {
+                                                           float* __restrict__ demb, float* __restrict__ dpos, int bchunk) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * D) return;
     const long long SD = (long long)S * D;
+    const int blo = blockIdx.y * bchunk, bhi = min(B, blo + bchunk);
     float s = 0.f;
-    for (int b0 = 0; b0 < B; b0 += 8) {
+    for (int b0 = blo; b0 < bhi; b0 += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? dx[(b0 + u) * SD + idx] : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < bhi ? dx[(b0 + u) * SD + idx] : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (b0 + u >= B) break;
+            if (b0 + u >= bhi) break;
             const long long o = (b0 + u) * SD + idx;
             float g = v[u];
             if (drop_p > 0.f) g = hash_uniform(seed, o) < drop_p ? 0.f : g / (1.f - drop_p);
@@ -1182,7 +1184,8 @@ __global__ void __launch_bounds__(256) pr_input_bwd_kernel(const float* __restri
             s += g;
         }
     }
-    dpos[idx] += s;
+    if (gridDim.y > 1) unsafeAtomicAdd(dpos + idx, s);
+    else dpos[idx] += s;
 }
 // dpos[t][d] += sum_b dx[b][t][d]
 __global__ void pos_grad_kernel(const float* __restrict__ dx, int B, int S, int D, float* __restrict__ dpos) {
