@@ -822,6 +822,211 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same v2 structure for the uint8 (.., H, W, C) boundary (the uint8 path had kept v1).  The next
+// band is prefetched as RAW bytes — 4-byte chunks of the interleaved RGB rows (rows are multiples of 4 bytes for both cameras; 8 for the
+// static one only), the row clamp of RandomShiftsAug's replicate pad applied to the source row, plus the two edge pixels of every row —
+// 12 + 1 registers per thread for a quarter of the fp32 path's bytes.  Commit = raw rows + replicated margins into LDS, barrier, then the
+// ScaleImageTensor / Normalize / column-shift conversion of conv1_stage_band's second stage into the bf16 [c][row][iw] image.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PFX, int PFY>
+__global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, int* __restrict__ work_ctr, const h16_t* __restrict__ dY, float* __restrict__ part,
+                                                                  float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands) {
+    using C = Wgrad1Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * C::S + C::KH;
+    const int XRS = IW * 2 + 16;
+    const int xbytes = C::C * XR * XRS + 512;
+    const int dypix = R * OWp + 8;
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xbytes;
+    lds_char* raw = dyimg + dypix * C::DYS;
+    for (int i = tid * 16; i < xbytes + dypix * C::DYS; i += 512 * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+    const int W4 = IW >> 2;
+    const int RB = IW * 3, n4 = RB >> 2;                          // bytes / 4-byte chunks per source row
+    const int RP = conv1_raw_pitch(IW);
+    constexpr int LM = CONV1_RAW_MARGIN * 3;
+    const int nx = XR * n4, ny = R * OW * 4;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(S.X);
+    // raw slot k of this thread = chunk tid + 512 k of the [XR][n4] grid: (row, chunk) advanced incrementally from slot 0's — twelve
+    // descriptor registers next to twelve slots of in-flight data spilled 17 registers at the 128-VGPR budget and serialised the prefetch
+    // ... and the compiler hoists whatever is band-invariant out of the band loop and spills it just the same (a scratch reload in front of
+    // every prefetch load waits for the loads issued before it): slot 0's (row, chunk) is recomputed per band behind an opaque copy of tid
+    const int xdq = 512 / n4, xdr = 512 - xdq * n4;
+    int yd[PFY];
+#pragma unroll
+    for (int k = 0; k < PFY; ++k) {
+        const int e = min(tid + k * 512, ny - 1);
+        const int r = e / (OW * 4), i = e - r * (OW * 4);
+        yd[k] = (r << 16) | i;
+    }
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2, q = a & 3;
+    const int ccolA = q * 8;
+    const int nt0 = (wave & 3) * 3, uh = wave >> 2;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned px[PFX], pe = 0;
+    u32x4_t py[PFY];
+    int xrows = 0, yrows = 0, pdx = 0;
+    auto prefetch = [&](int item) {
+        const int f = item / nbands, oh0 = (item % nbands) * R;
+        const int ih0 = oh0 * C::S;
+        xrows = min(XR, IH - ih0); yrows = min(R, OH - oh0);
+        int dy = 0;
+        pdx = 0;
+        if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
+        const unsigned char* fb = Xb + (long long)f * IH * RB;
+        const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
+        {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            int r = t / n4, c4 = t - r * n4;
+#pragma unroll
+            for (int k = 0; k < PFX; ++k) {
+                const int rr = min(r, min(XR, xrows) - 1);            // slots past the band / rows below the frame: a valid row (dropped / zeroed at the commit)
+                px[k] = *reinterpret_cast<const unsigned*>(fb + min(max(ih0 + rr + dy, 0), IH - 1) * RB + c4 * 4);
+                c4 += xdr; r += xdq; if (c4 >= n4) { c4 -= n4; ++r; }
+            }
+        }
+        if (tid < 2 * XR) {                                       // the edge pixels of every row (replicated into the margins at the commit)
+            const int rr = tid >> 1, side = tid & 1;
+            pe = *reinterpret_cast<const unsigned*>(fb + (long long)min(max(ih0 + min(rr, xrows - 1) + dy, 0), IH - 1) * RB + (side ? RB - 4 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k) {
+            const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+            py[k] = *reinterpret_cast<const u32x4_t*>(yb + (min(r, yrows - 1) * OW) * C::CO + i * 8);
+        }
+    };
+    __shared__ int s_next[2];
+    int frame = blockIdx.x, fiter = 0, band = 0;
+    int item = frame * nbands;
+    if (frame < Nf) prefetch(item);
+    while (frame < Nf) {
+        if (band == 0 && work_ctr && tid == 0) s_next[fiter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);
+        __syncthreads();                                          // previous band consumed (first pass: zero fill visible)
+        const int cxr = xrows, cyr = yrows, dx = pdx;
+        {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            int r = t / n4, c4 = t - r * n4;
+#pragma unroll
+            for (int k = 0; k < PFX; ++k) {
+                if (t + k * 512 < nx) *(__attribute__((address_space(3))) unsigned*)(raw + r * RP + LM + c4 * 4) = px[k];
+                c4 += xdr; r += xdq; if (c4 >= n4) { c4 -= n4; ++r; }
+            }
+        }
+        if (tid < 2 * XR) {
+            const int rr = tid >> 1, side = tid & 1;
+            const unsigned pxl = side ? (pe >> 8) : (pe & 0xffffffu);
+            lds_char* dst = raw + rr * RP + (side ? LM + RB : 0);
+            for (int k = 0; k < CONV1_RAW_MARGIN; ++k) {
+                dst[k * 3 + 0] = (char)(pxl & 0xff); dst[k * 3 + 1] = (char)((pxl >> 8) & 0xff); dst[k * 3 + 2] = (char)((pxl >> 16) & 0xff);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k)
+            if (tid + k * 512 < ny) {
+                const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+                const u32x4_t v = r < cyr ? py[k] : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
+                *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
+            }
+        __syncthreads();                                          // raw rows complete
+        {
+            const float sc = 2.f / 255.f;
+            for (int e = tid; e < XR * W4; e += 512) {
+                const int r = e / W4, c = e - r * W4;
+                u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
+                if (r < cxr) {                                    // rows below the frame stay zero
+                    const int o = r * RP + LM + (c * 4 + dx) * 3;
+                    const int sh = o & 3;
+                    const __attribute__((address_space(3))) unsigned* wp = (const __attribute__((address_space(3))) unsigned*)(raw + (o & ~3));
+                    const unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                    const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
+                    float v[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = pack2h(v[ch], v[3 + ch]); ov[ch][1] = pack2h(v[6 + ch], v[9 + ch]); }
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + r) * XRS + c * 8) = ov[ch];
+            }
+        }
+        __syncthreads();
+        if (++band == nbands) {
+            band = 0;
+            frame = work_ctr ? s_next[fiter & 1] : frame + (int)gridDim.x;
+            ++fiter;
+        }
+        item = frame * nbands + band;
+        if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
+        const int units = R * U;
+#pragma unroll 1
+        for (int u0 = uh * 4; u0 < units; u0 += 8) {
+            const int u = u0 + g;
+            const bool valid = u < units;
+            const int r = valid ? u / U : 0, ow0 = valid ? (u - (u / U) * U) * 8 : 0;
+            const int pixA = valid ? r * OWp + ow0 : R * OWp;
+            lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
+            h16x8_t af[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int nt = nt0 + j;
+                const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
+                lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
+                const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the two unit halves (waves w and w + 4) are summed through LDS, then one slab per workgroup
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (uh == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) red[((wave & 3) * 6 + j * 2 + c) * 64 + lane] = acc[j][c];
+    }
+    __syncthreads();
+    if (uh == 0) {
+        float* out = part + (long long)blockIdx.x * C::CO * 192;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 v = acc[j][c] + red[((wave & 3) * 6 + j * 2 + c) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * 192 + (nt0 + j) * 16 + a] = v[r];
+            }
+    }
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) redf[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C::CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float sacc = 0.f;
+        for (int t = cgrp; t < 512; t += 4) sacc += redf[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, sacc);
+    }
+}
+
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
     static const int v2 = HULC_SWITCH("HULC_W1_V2", 1);
@@ -842,6 +1047,25 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
             if (!attr2) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2 = true; }
             const int grid = std::min(std::min(Nf, 512), max_blocks);
             hipLaunchKernelGGL((conv1_wgrad_tr2_kernel<6, 2>), dim3(grid), dim3(512), lds, st, reinterpret_cast<const float*>(X.X), work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
+            return grid;
+        }
+    }
+    if (v2 && X.u8 && (IW % 4) == 0) {
+        // uint8 boundary: 12 raw 4-byte slots + 2 dY slots per thread; the raw rows add their LDS area to the two images
+        int R = OH;
+        auto fits = [&](int r) {
+            const int XR = (r - 1) * Wgrad1Cfg::S + Wgrad1Cfg::KH;
+            return Wgrad1Cfg::lds_bytes(r, IW, OW, true) <= (size_t)79 * 1024 && (long long)XR * (IW * 3 / 4) <= 12 * 512 && (long long)r * OW * 4 <= 2 * 512 && 2 * XR <= 512 && r < 128;
+        };
+        while (R > 1 && !fits(R)) --R;
+        if (fits(R)) {
+            const int nb = (OH + R - 1) / R;
+            R = (OH + nb - 1) / nb;
+            const size_t lds = std::max<size_t>(Wgrad1Cfg::lds_bytes(R, IW, OW, true), 512 * 8 * sizeof(float));
+            static bool attr2u = false;
+            if (!attr2u) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2u_kernel<12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2u = true; }
+            const int grid = std::min(std::min(Nf, 512), max_blocks);
+            hipLaunchKernelGGL((conv1_wgrad_tr2u_kernel<12, 2>), dim3(grid), dim3(512), lds, st, X, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
             return grid;
         }
     }

@@ -1992,9 +1992,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    typedef float f32x4nt __attribute__((ext_vector_type(4)));
     for (; i + 3 < n; i += stride) {
-        float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
-        float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        // gradient and moments are touched once per step: non-temporal loads / stores keep them from displacing the parameters and their
+        // 16-bit shadow (read next by the weight repacks and the forward) in the L2 / memory-side cache (same-box A/B: -0.014 ms/step)
+        float4 pp = *reinterpret_cast<float4*>(p + i), gg, mm, vv;
+        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(g + i)); gg = make_float4(a[0], a[1], a[2], a[3]); }
+        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(m + i)); mm = make_float4(a[0], a[1], a[2], a[3]); }
+        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(v + i)); vv = make_float4(a[0], a[1], a[2], a[3]); }
         float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2010,8 +2015,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             o.y = pack2h(pp.z, pp.w);
             *reinterpret_cast<uint2*>(shadow + i) = o;
         }
-        *reinterpret_cast<float4*>(m + i) = mm;
-        *reinterpret_cast<float4*>(v + i) = vv;
+        __builtin_nontemporal_store(f32x4nt{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f32x4nt*>(m + i));
+        __builtin_nontemporal_store(f32x4nt{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4nt*>(v + i));
     }
 }
 
