@@ -1093,7 +1093,8 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
                                                              int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
-                                                             float* __restrict__ db2, int mchunk) {
+                                                             float* __restrict__ db2, int mchunk, int store = 0) {
+    // store != 0: dW / db are known to be all zeros (first backward after hulc_zero_grads): the tile is stored instead of read, added and written
     // Large M (token-major transformer / encoder layers): blockIdx.z owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
     // time and adds its partial with fp32 atomics — replaces "transpose dY, transpose X, split-K NT GEMM, column-sum" (4 launches).
     constexpr int TN = 64, TK = 128, YS = TN * 2 + 16, XS = TK * 2 + 16;
@@ -1118,7 +1119,7 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __rest
     float4 oldw[8];
     if (vec_ok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oldw[j] = *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4);
+        for (int j = 0; j < 8; ++j) oldw[j] = store ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4);
     }
     for (int m0 = mbeg; m0 < mend; m0 += 64) {
         if (m0 > mbeg) __syncthreads();

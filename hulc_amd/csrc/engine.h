@@ -477,7 +477,7 @@ struct Engine : IEngine {
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
         if constexpr (std::is_same<T, h16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
-                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64);
+                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64, grads_fresh ? 1 : 0);
                 return;
             }
             static const bool fused_largem = HULC_SWITCH("HULC_LINBWD_LARGEM", 0) != 0;   // measured 0.25 ms/step SLOWER than transposes + NT GEMM (A/B, same box): off
@@ -565,9 +565,15 @@ struct Engine : IEngine {
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
         return 0;
     }
+    // grads_fresh: the gradient buffer is all zeros (hulc_zero_grads was the last thing that touched it).  The first backward after it may STORE
+    // the weight gradients that have a single whole-tensor contribution instead of reading the zeros back and adding (200 MB of reads per step):
+    // 0 + x == x exactly, so the result is bit-identical.  A second backward before the next zero_grads (one pass per modality) accumulates.
+    bool grads_fresh = false;
+    int wacc() const { return grads_fresh ? 0 : 1; }
     int zero_grads() override {
         if (!bound) { hulc_set_error("hulc_zero_grads before hulc_bind_params"); return 1; }
         HIP_CHECK(hipMemsetAsync(G, 0, numel * sizeof(float), st));
+        grads_fresh = true;
         return 0;
     }
 
@@ -1856,10 +1862,10 @@ struct Engine : IEngine {
                 const int mp = ldpad(SB);
                 constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // 16-bit engines: the dZ transpose adds its column sums (= both bias gradients) on the way
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp, fuse_cs ? dbih1 : nullptr, fuse_cs ? dbhh1 : nullptr);
-                if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = 1;
+                if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = wacc();
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
-                { EpiP ep = epi(wih1.dW, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
+                { EpiP ep = epi(wih1.dW, true); ep.accumulate = wacc(); gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
                 if (!fuse_cs) colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
             }
             { EpiP ep = epi(dH0, false); ep.out2 = dZ0 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H0 + lastBH;
@@ -1870,7 +1876,7 @@ struct Engine : IEngine {
                 const int mp = ldpad(SB);
                 // the column sums of dZ0 over all (t, b) rows = those of dC = sum_t dZ0: both bias gradients of layer 0 ride on this transpose too
                 transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp, std::is_same<T, h16_t>::value ? dbih0 : nullptr, std::is_same<T, h16_t>::value ? dbhh0 : nullptr);
-                if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = 1;
+                if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = wacc();
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
                 { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
@@ -2010,6 +2016,7 @@ struct Engine : IEngine {
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;
         bwd_stage = 0;
+        grads_fresh = false;
         return 0;
     }
 
