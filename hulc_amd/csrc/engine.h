@@ -509,13 +509,13 @@ struct Engine : IEngine {
     static constexpr bool ln_bwd_can_bcast = std::is_same<T, h16_t>::value;
     void ln_bwd(const float* dy, long long lddy, const float* x, long long ldx, const float* stats, const float* g, int rows, int n, float* dxf,
                 long long ldd, int acc, T* dxt, long long ldt, float* dg, float* db, float drop_p = 0.f, unsigned long long drop_seed = 0,
-                int bcast_rows = 0, float bcast_div = 1.f) {
+                int bcast_rows = 0, float bcast_div = 1.f, int dy_parts = 1, long long dy_part_stride = 0) {
         if constexpr (std::is_same<T, h16_t>::value) {
             static const bool fused = HULC_SWITCH("HULC_LN_FUSED", 1) != 0;
-            if (fused || bcast_rows > 0) {
+            if (fused || bcast_rows > 0 || dy_parts > 1) {
                 const int rpb = rows >= 1024 ? 16 : 4;
                 hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
-                                   drop_p, drop_seed, rpb, dg, db, bcast_rows, bcast_div);
+                                   drop_p, drop_seed, rpb, dg, db, bcast_rows, bcast_div, dy_parts, dy_part_stride);
                 return;
             }
         }
@@ -568,6 +568,7 @@ struct Engine : IEngine {
     // grads_fresh: the gradient buffer is all zeros (hulc_zero_grads was the last thing that touched it).  The first backward after it may STORE
     // the weight gradients that have a single whole-tensor contribution instead of reading the zeros back and adding (200 MB of reads per step):
     // 0 + x == x exactly, so the result is bit-identical.  A second backward before the next zero_grads (one pass per modality) accumulates.
+    float* dparts = nullptr;                // fused FFN backward: the four hidden-quarter partials of the gradient entering norm1
     bool grads_fresh = false;
     int wacc() const { return grads_fresh ? 0 : 1; }
     int zero_grads() override {
@@ -1943,14 +1944,31 @@ struct Engine : IEngine {
             for (int l = 1; l >= 0; --l) {
                 // LN2 (16-bit engines: the last layer's incoming gradient dxm / S is broadcast over the window inside the kernel)
                 const bool bc = ln_bwd_can_bcast && l == 1;
+                bool ffn_fused = false;
+                if constexpr (std::is_same<T, h16_t>::value) ffn_fused = tr_fused_mode && S <= 32;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    if (ffn_fused) {      // LN2 backward + both data-gradient GEMMs of the FFN: one launch (tr_fused.h); the weight gradients read what it wrote
+                        if (!dparts) dparts = alloc<float>(4ll * maxN * EMB);
+                        TrFfnBwdP q{};
+                        q.dx = bc ? dxm : dx; q.bcast = bc ? 1 : 0; q.bdiv = (float)S; q.y2 = y2[l]; q.st2 = st2[l]; q.n2g = tr_n2g[l]; q.dg2 = d_tr_n2g[l]; q.db2 = d_tr_n2b[l];
+                        q.W2t = tr_l2[l].Wt; q.W1t = tr_l1[l].Wt; q.hff = hff[l]; q.dt_c = dt_c; q.dt_a = dt_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
+                        q.seed_y = site_seed(4 + 4 * l);
+                        launch_tr_ffn_bwd(st, q);
+                        lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
+                        lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
+                    }
+                }
+                if (!ffn_fused) {
                 ln_bwd(bc ? dxm : dx, EMB, y2[l], EMB, st2[l], tr_n2g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n2g[l], d_tr_n2b[l], dp, site_seed(4 + 4 * l),
                        bc ? S : 0, (float)S);   // dt_c = dropout mask of the FFN branch applied to dy_f
                 lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
                 { EpiP ep = epi(dt_a, false); ep.mask = hff[l]; ep.alpha = dp > 0.f ? 1.f / (1.f - dp) : 1.f; lin_dgrad(dt_c, N, tr_l2[l], ep, dense_out(FF)); }
                 lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
                 { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
-                // LN1
-                ln_bwd(dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l));
+                }
+                // LN1 (after the fused FFN backward its incoming gradient is the sum of the four hidden-quarter partials)
+                ln_bwd(ffn_fused ? dparts : dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l), 0, 1.f,
+                       ffn_fused ? 4 : 1, (long long)N * EMB);
                 lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
                 { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
                 static const bool att32 = (HULC_SWITCH("HULC_ATT32", 1) != 0) && !std::is_same<T, float>::value;

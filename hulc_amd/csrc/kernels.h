@@ -664,7 +664,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
                                                                   int rows, int n, float* __restrict__ dx_f32, long long ldd, int accumulate,
                                                                   T* __restrict__ dx_t, long long ldt, float drop_p, unsigned long long seed,
                                                                   int rows_per_block, float* __restrict__ dg, float* __restrict__ db,
-                                                                  int dy_rowdiv = 0, float dy_div = 1.f) {
+                                                                  int dy_rowdiv = 0, float dy_div = 1.f, int dy_parts = 1, long long dy_part_stride = 0) {
+    // dy_parts > 1: the incoming gradient is the sum of dy_parts arrays dy + i * dy_part_stride (the fused FFN backward's four partials)
     // dy_rowdiv > 0: the incoming gradient is a per-WINDOW vector broadcast over the window's dy_rowdiv rows and divided by dy_div
     // (the mean over S in front of plan_recognition.fc: bcast_over_s_kernel's job, read here instead of materialised)
     __shared__ float red[4][256];
@@ -677,8 +678,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
         const float* xr = x + (long long)row * ldx;
         const float* dr = dy + (long long)(dy_rowdiv > 0 ? row / dy_rowdiv : row) * lddy;
         float xh0 = 0.f, xh1 = 0.f, d0 = 0.f, d1 = 0.f;
-        if (lane < n) { xh0 = (xr[lane] - mean) * rstd; d0 = dr[lane]; }
-        if (lane + 64 < n) { xh1 = (xr[lane + 64] - mean) * rstd; d1 = dr[lane + 64]; }
+        if (lane < n) { xh0 = (xr[lane] - mean) * rstd; d0 = dr[lane]; for (int pp = 1; pp < dy_parts; ++pp) d0 += dr[pp * dy_part_stride + lane]; }
+        if (lane + 64 < n) { xh1 = (xr[lane + 64] - mean) * rstd; d1 = dr[lane + 64]; for (int pp = 1; pp < dy_parts; ++pp) d1 += dr[pp * dy_part_stride + lane + 64]; }
         if (dy_rowdiv > 0) { d0 /= dy_div; d1 /= dy_div; }
         sg0 += d0 * xh0; sb0 += d0; sg1 += d1 * xh1; sb1 += d1;
         const float q0 = d0 * g0, q1 = d1 * g1;

@@ -332,6 +332,177 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The FFN half of a layer's BACKWARD as one launch (was LayerNorm backward + the two data-gradient GEMMs: 11 + 18 + 15 us per layer, each
+// latency bound): workgroup = (window, quarter of the hidden units), like the forward.
+//   P0  dy2 = LN2_bwd(dx; y2, stats2, g2)           (all four quarters; quarter 0 adds the norm2 parameter gradients and writes dt_c)
+//       dt_c = T(dropout_y(dy2))                      the 16-bit operand of linear2's weight gradient (and of P1)
+//   P1  dh[:, q] = (dt_c W2[:, q]) / (1 - p) * (h > 0)   -> dt_a (16 bit, global: operand of linear1's weight gradient) and LDS
+//   P2  part[q] = dh[:, q] W1[q, :]  (+ dy2 for quarter 0: the residual path)      -> fp32 partial [4][N][128]; the LayerNorm backward that
+//       follows (norm1) sums the four partials while it loads its incoming gradient (no atomics: deterministic, nothing to zero)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct TrFfnBwdP {
+    const float* dx; int bcast; float bdiv;      // incoming gradient [N][128] fp32, or (bcast) one row per window divided by bdiv
+    const float *y2, *st2, *n2g;                 // LN2 input, (mean, rstd) per row, gamma
+    float *dg2, *db2;                            // norm2 parameter gradients (atomics, quarter 0)
+    const h16_t *W2t, *W1t;                      // [2048][128] = linear2.weight^T, [128][2048] = linear1.weight^T
+    const h16_t* hff;                            // [N][2048] saved hidden (post ReLU + dropout)
+    h16_t *dt_c, *dt_a;                          // [N][128], [N][2048] 16-bit gradient operands (written)
+    float* part;                                 // [4][N][128]
+    int B, S; long long N;
+    float dp; unsigned long long seed_y;
+};
+constexpr size_t TRB_LDS = 32 * TRF_D * 4 + 32 * TRF_XP + 32 * TRF_HP + 2 * 8 * 256 * 4;
+
+__global__ void __launch_bounds__(512) tr_ffn_bwd_kernel(TrFfnBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) h16_t lds_h16;
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    lds_char* const dyf = (lds_char*)smem;                     // [32][128] fp32: dy2
+    lds_char* const dcb = dyf + 32 * TRF_D * 4;                // [32][XP] 16 bit: dt_c
+    lds_char* const dhb = dcb + 32 * TRF_XP;                   // [32][HP] 16 bit: dh quarter
+    lds_char* const red = dhb + 32 * TRF_HP;                   // [2][8 waves][256] fp32: parameter-gradient partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x / TRF_NQ, hq = blockIdx.x % TRF_NQ;
+    const int S = p.S;
+    const long long row0 = (long long)w * S;
+    const bool lead = hq == 0;
+    const bool mt1 = S > 16;
+
+    // weight fragments of P1 (W2t rows hq*512 + wave*64 + nt*16 + li, 4 k-steps over the 128 features): requested first
+    h16x8_t w2[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            w2[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.W2t + (long long)(hq * TRF_HQ + wave * 64 + nt * 16 + li) * TRF_D + ks * 32 + g * 8);
+
+    // ---- P0: LayerNorm backward of the rows of this window (wave = 4 rows, lane = columns lane and lane + 64)
+    {
+        const float g0 = p.n2g[lane], g1 = p.n2g[lane + 64];
+        float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float o0 = 0.f, o1 = 0.f, t0 = 0.f, t1 = 0.f;
+            if (r < S) {
+                const long long row = row0 + r;
+                const float mean = p.st2[2 * row], rstd = p.st2[2 * row + 1];
+                const float* xr = p.y2 + row * TRF_D;
+                const float* dr = p.dx + (p.bcast ? (long long)w : row) * TRF_D;
+                const float xh0 = (xr[lane] - mean) * rstd, xh1 = (xr[lane + 64] - mean) * rstd;
+                float d0 = dr[lane], d1 = dr[lane + 64];
+                if (p.bcast) { d0 /= p.bdiv; d1 /= p.bdiv; }
+                sg0 += d0 * xh0; sb0 += d0; sg1 += d1 * xh1; sb1 += d1;
+                const float q0 = d0 * g0, q1 = d1 * g1;
+                const float m1 = wave_sum(q0 + q1) / TRF_D;
+                const float m2 = wave_sum(q0 * xh0 + q1 * xh1) / TRF_D;
+                o0 = rstd * (q0 - m1 - xh0 * m2); o1 = rstd * (q1 - m1 - xh1 * m2);
+                t0 = o0; t1 = o1;
+                if (p.dp > 0.f) {
+                    t0 = hash_uniform(p.seed_y, (unsigned long long)(row * TRF_D + lane)) < p.dp ? 0.f : t0 / (1.f - p.dp);
+                    t1 = hash_uniform(p.seed_y, (unsigned long long)(row * TRF_D + lane + 64)) < p.dp ? 0.f : t1 / (1.f - p.dp);
+                }
+                if (lead) { p.dt_c[row * TRF_D + lane] = f2h(t0); p.dt_c[row * TRF_D + lane + 64] = f2h(t1); }
+            }
+            *(lds_f32*)(dyf + (r * TRF_D + lane) * 4) = o0; *(lds_f32*)(dyf + (r * TRF_D + lane + 64) * 4) = o1;
+            *(lds_h16*)(dcb + r * TRF_XP + lane * 2) = f2h(t0); *(lds_h16*)(dcb + r * TRF_XP + (lane + 64) * 2) = f2h(t1);
+        }
+        if (lead) {
+            *(lds_f32*)(red + (wave * 256 + lane) * 4) = sg0; *(lds_f32*)(red + (wave * 256 + 64 + lane) * 4) = sg1;
+            *(lds_f32*)(red + (wave * 256 + 128 + lane) * 4) = sb0; *(lds_f32*)(red + (wave * 256 + 192 + lane) * 4) = sb1;
+        }
+    }
+    // mask operand of P1 (the saved hidden of this quarter) and the weight fragments of P2: independent of everything above
+    u32x2_t hm[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+            hm[nt][mt] = u32x2_t{0u, 0u};
+            if (m < S) hm[nt][mt] = *reinterpret_cast<const u32x2_t*>(p.hff + (row0 + m) * TRF_FF + hq * TRF_HQ + wave * 64 + nt * 16 + g * 4);
+        }
+    h16x8_t w1[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w1[ks] = *reinterpret_cast<const h16x8_t*>(p.W1t + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
+    __syncthreads();
+    if (lead && tid < 256) {          // norm2 parameter gradients: 8 wave partials per column -> one atomic each (columns 0..127 dgamma, 128..255 dbeta)
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) sum += *(lds_f32*)(red + (ww * 256 + tid) * 4);
+        unsafeAtomicAdd((tid < 128 ? p.dg2 : p.db2) + (tid & 127), sum);
+    }
+
+    // ---- P1: dh = (dt_c W2[:, q]) * alpha * (h > 0)  -> dhb (LDS) + dt_a (global)
+    {
+        const float alpha = p.dp > 0.f ? 1.f / (1.f - p.dp) : 1.f;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { acc[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(dcb + li * TRF_XP + ks * 64 + g * 16);
+            const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(dcb + (16 + li) * TRF_XP + ks * 64 + g * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt][0] = MFMA_16x16x32_H(w2[nt][ks], b0, acc[nt][0], 0, 0, 0);
+                if (mt1) acc[nt][1] = MFMA_16x16x32_H(w2[nt][ks], b1, acc[nt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int nl = wave * 64 + nt * 16 + g * 4, n = hq * TRF_HQ + nl;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = mt * 16 + li;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] * alpha;
+                v[0] = h2f_lo(hm[nt][mt][0]) > 0.f ? v[0] : 0.f; v[1] = h2f_hi(hm[nt][mt][0]) > 0.f ? v[1] : 0.f;
+                v[2] = h2f_lo(hm[nt][mt][1]) > 0.f ? v[2] : 0.f; v[3] = h2f_hi(hm[nt][mt][1]) > 0.f ? v[3] : 0.f;
+                u32x2_t o;
+                o[0] = pack2h(v[0], v[1]); o[1] = pack2h(v[2], v[3]);
+                if (m >= S) o = u32x2_t{0u, 0u};
+                *(__attribute__((address_space(3))) u32x2_t*)(dhb + m * TRF_HP + nl * 2) = o;
+                if (m < S) *reinterpret_cast<u32x2_t*>(p.dt_a + (row0 + m) * TRF_FF + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P2: part[q] = dh[:, q] W1[q, :] (+ dy2 for quarter 0)
+    {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(dhb + li * TRF_HP + ks * 64 + g * 16);
+            acc[0] = MFMA_16x16x32_H(w1[ks], b0, acc[0], 0, 0, 0);
+            if (mt1) {
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(dhb + (16 + li) * TRF_HP + ks * 64 + g * 16);
+                acc[1] = MFMA_16x16x32_H(w1[ks], b1, acc[1], 0, 0, 0);
+            }
+        }
+        const int n = wave * 16 + g * 4;
+        float* const out = p.part + (long long)hq * p.N * TRF_D;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+            if (m >= S) continue;
+            f32x4 v = acc[mt];
+            if (lead) { const f32x4 res = *(__attribute__((address_space(3))) f32x4*)(dyf + (m * TRF_D + n) * 4); v += res; }
+            *reinterpret_cast<f32x4*>(out + (row0 + m) * TRF_D + n) = v;
+        }
+    }
+}
+static inline void launch_tr_ffn_bwd(hipStream_t st, const TrFfnBwdP& p) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)tr_ffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRB_LDS); attr_set = true; }
+    hipLaunchKernelGGL(tr_ffn_bwd_kernel, dim3(p.B * TRF_NQ), dim3(512), TRB_LDS, st, p);
+}
+
 static inline void launch_tr_layer_fwd(hipStream_t st, const TrLayerP& p) {
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)tr_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRF_LDS); attr_set = true; }
