@@ -41,7 +41,13 @@ struct TrLayerP {
     int B, S;
     float dp;
     unsigned long long seed_att, seed_o, seed_h, seed_y;
+    long long* stamps;                // TRF_STAMPS builds (tools/tr_fused_bench.hip): shader-clock stamps of workgroup 5's phases
 };
+#ifdef TRF_STAMPS
+#define TRF_STAMP(i) do { if (p.stamps && blockIdx.x == 5 && tid == 0) p.stamps[i] = clock64(); } while (0)
+#else
+#define TRF_STAMP(i) do { } while (0)
+#endif
 
 constexpr int TRF_D = 128, TRF_FF = 2048, TRF_NH = 8, TRF_HD = 16, TRF_NQ = 4, TRF_HQ = TRF_FF / TRF_NQ;       // hidden quarter = 512 units
 constexpr int TRF_XP = TRF_D * 2 + 32;          // LDS row pitch (bytes) of a [32][128] 16-bit operand: 18 slots = 2 (mod 4) -> conflict-free ds_read_b128
@@ -70,12 +76,26 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     const bool mt1 = S > 16;                                   // second 16-token tile in use
     const float keep = 1.f / (1.f - p.dp);
 
+    TRF_STAMP(0);
     // ---- weight fragments of the QKV GEMM: requested first (rows n = (3 wave + nt) * 16 + li, 8 k at g * 8 + ks * 32)
     h16x8_t wq[3][4];
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wq[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.Wqkv + (long long)((3 * wave + nt) * 16 + li) * TRF_D + ks * 32 + g * 8);
+
+    // every small parameter the later phases need (biases, LayerNorm affine): requested NOW — a dependent global load in front of each
+    // phase's epilogue cost an exposed L2 round trip (~1 us) per phase (tools/tr_fused_bench.hip stamps: 3 - 8 us per phase for a few
+    // hundred MFMA cycles of work)
+    f32x4 pbq[3], pb1[4];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) pbq[nt] = *reinterpret_cast<const f32x4*>(p.bqkv + (3 * wave + nt) * 16 + g * 4);
+    const f32x4 pbo = *reinterpret_cast<const f32x4*>(p.bo + wave * 16 + g * 4);
+    f32x4 pb2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lead) pb2 = *reinterpret_cast<const f32x4*>(p.b2 + wave * 16 + g * 4);
+    const float pn1g0 = p.n1g[lane], pn1g1 = p.n1g[lane + 64], pn1b0 = p.n1b[lane], pn1b1 = p.n1b[lane + 64];
+    float plg0 = 0.f, plg1 = 0.f, plb0 = 0.f, plb1 = 0.f;
+    if (p.ln_in) { plg0 = p.ln_g[lane]; plg1 = p.ln_g[lane + 64]; plb0 = p.ln_b[lane]; plb1 = p.ln_b[lane + 64]; }
 
     // ---- phase 0: x (optionally LN of the previous layer's sum) -> xf (fp32), xb (16 bit); rows >= S are zero
     {
@@ -90,8 +110,8 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
                     const float mean = wave_sum(v0 + v1) * (1.f / TRF_D);
                     const float d0 = v0 - mean, d1 = v1 - mean;
                     const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / TRF_D) + 1e-5f);
-                    v0 = d0 * rstd * p.ln_g[lane] + p.ln_b[lane];
-                    v1 = d1 * rstd * p.ln_g[lane + 64] + p.ln_b[lane + 64];
+                    v0 = d0 * rstd * plg0 + plb0;
+                    v1 = d1 * rstd * plg1 + plb1;
                     if (lead) {
                         p.xf_out[(row0 + r) * TRF_D + lane] = v0; p.xf_out[(row0 + r) * TRF_D + lane + 64] = v1;
                         p.xt_out[(row0 + r) * TRF_D + lane] = f2h(v0); p.xt_out[(row0 + r) * TRF_D + lane + 64] = f2h(v1);
@@ -109,6 +129,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(p.Wo + (long long)(wave * 16 + li) * TRF_D + ks * 32 + g * 8);
 
+    TRF_STAMP(1);
     // ---- phase 1: qkv = x Wqkv^T + b  -> qb (LDS) [+ global]
     {
         f32x4 acc[3][2];
@@ -127,7 +148,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int n = (3 * wave + nt) * 16 + g * 4;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bqkv + n);
+            const f32x4 bb = pbq[nt];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = mt * 16 + li;
@@ -139,35 +160,42 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
             }
         }
     }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) pb1[nt] = *reinterpret_cast<const f32x4*>(p.b1 + hq * TRF_HQ + wave * 64 + nt * 16 + g * 4);
     // FFN weight fragments (this workgroup's hidden quarter): W1 rows hq*512 + wave*64 + nt*16 + li; W2 rows wave*16 + li, k in the quarter
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.W1 + (long long)(hq * TRF_HQ + wave * 64 + nt * 16 + li) * TRF_D + ks * 32 + g * 8);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) w2[ks] = *reinterpret_cast<const h16x8_t*>(p.W2 + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
     __syncthreads();
 
-    // ---- phase 2: attention, one wave per head; lane (i = query row, hf = key half) — attention_fwd32_kernel on the LDS copy of qkv
+    TRF_STAMP(2);
+    // ---- phase 2: attention, one wave per head; lane (i = query row, hf = key half) — attention_fwd32_kernel on the LDS copy of qkv.
+    // A head's 16 values of a row are 32 contiguous bytes: q / k / v rows are read as two 16-byte LDS loads (the first version read them with
+    // 2-byte loads — ~530 LDS instructions per lane; this phase was most of the launch's 35 us attention half)
     {
         const int h = wave, i = lane & 31, hf = lane >> 5;
+        auto row16 = [&](const lds_char* r, float (&o)[TRF_HD]) {
+            const u32x4_t a = *(const lds_u32x4*)r, b = *(const lds_u32x4*)(r + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[2 * e] = h2f_lo(a[e]); o[2 * e + 1] = h2f_hi(a[e]); o[8 + 2 * e] = h2f_lo(b[e]); o[9 + 2 * e] = h2f_hi(b[e]); }
+        };
         if (i < S) {
             float q[TRF_HD];
-            {
-                const lds_char* qr = qb + i * TRF_QP + h * TRF_HD * 2;
+            row16(qb + i * TRF_QP + h * TRF_HD * 2, q);
 #pragma unroll
-                for (int d = 0; d < TRF_HD; ++d) q[d] = h2f(*(lds_h16*)(qr + d * 2)) * 0.25f;
-            }
+            for (int d = 0; d < TRF_HD; ++d) q[d] *= 0.25f;
             float sc[16];
             float m = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) {
                 const int j = hf * 16 + jj;
-                const lds_char* kr = qb + (j < S ? j : 0) * TRF_QP + (TRF_D + h * TRF_HD) * 2;
+                float kk[TRF_HD];
+                row16(qb + (j < S ? j : 0) * TRF_QP + (TRF_D + h * TRF_HD) * 2, kk);
                 float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < TRF_HD; ++d) s += q[d] * h2f(*(lds_h16*)(kr + d * 2));
+                for (int d = 0; d < TRF_HD; ++d) s += q[d] * kk[d];
                 sc[jj] = j < S ? s : -INFINITY;
                 m = fmaxf(m, sc[jj]);
             }
@@ -188,9 +216,10 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
                     float pr = sc[jj] * inv;
                     if (lead) p.Pat[pbase + j] = pr;              // saved BEFORE its dropout (the backward re-derives the mask)
                     if (p.dp > 0.f) pr = hash_uniform(p.seed_att, (unsigned long long)(pbase + j)) < p.dp ? 0.f : pr * keep;
-                    const lds_char* vr = qb + j * TRF_QP + (2 * TRF_D + h * TRF_HD) * 2;
+                    float vv[TRF_HD];
+                    row16(qb + j * TRF_QP + (2 * TRF_D + h * TRF_HD) * 2, vv);
 #pragma unroll
-                    for (int d = 0; d < TRF_HD; ++d) o[d] += pr * h2f(*(lds_h16*)(vr + d * 2));
+                    for (int d = 0; d < TRF_HD; ++d) o[d] += pr * vv[d];
                 }
             }
 #pragma unroll
@@ -206,6 +235,11 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
     __syncthreads();
 
+    // W2 fragments of phase 6: requested only now — together with the attention's working set they exceeded the 256 registers of a wave
+    // (28 spilled: a spilled prefetch register turns the asynchronous load into load-wait-store at its issue point)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) w2[ks] = *reinterpret_cast<const h16x8_t*>(p.W2 + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
+    TRF_STAMP(3);
     // ---- phase 3: y1 = x + drop(ao Wo^T + bo)  (in place in xf) [+ global]
     {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -219,7 +253,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
             }
         }
         const int n = wave * 16 + g * 4;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bo + n);
+        const f32x4 bb = pbo;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = mt * 16 + li;
@@ -238,6 +272,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
     __syncthreads();
 
+    TRF_STAMP(4);
     // ---- phase 4: x1 = LN1(y1) -> x1f (fp32), x1b (16 bit) [+ global, statistics]
     {
 #pragma unroll
@@ -249,8 +284,8 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
                 const float mean = wave_sum(v0 + v1) * (1.f / TRF_D);
                 const float d0 = v0 - mean, d1 = v1 - mean;
                 const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / TRF_D) + 1e-5f);
-                o0 = d0 * rstd * p.n1g[lane] + p.n1b[lane];
-                o1 = d1 * rstd * p.n1g[lane + 64] + p.n1b[lane + 64];
+                o0 = d0 * rstd * pn1g0 + pn1b0;
+                o1 = d1 * rstd * pn1g1 + pn1b1;
                 if (lead) {
                     p.x1f[(row0 + r) * TRF_D + lane] = o0; p.x1f[(row0 + r) * TRF_D + lane + 64] = o1;
                     p.x1t[(row0 + r) * TRF_D + lane] = f2h(o0); p.x1t[(row0 + r) * TRF_D + lane + 64] = f2h(o1);
@@ -263,6 +298,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
     __syncthreads();
 
+    TRF_STAMP(5);
     // ---- phase 5: h = drop(relu(x1 W1[q]^T + b1[q]))  -> hb (LDS) + global hff
     {
         f32x4 acc[4][2];
@@ -281,7 +317,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int nl = wave * 64 + nt * 16 + g * 4, n = hq * TRF_HQ + nl;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1 + n);
+            const f32x4 bb = pb1[nt];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = mt * 16 + li;
@@ -301,6 +337,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
     __syncthreads();
 
+    TRF_STAMP(6);
     // ---- phase 6: y2 += drop(h W2[:, q]^T [+ b2]) [+ x1]   (fp32 atomics: four quarters per element)
     {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -314,8 +351,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
             }
         }
         const int n = wave * 16 + g * 4;
-        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lead) bb = *reinterpret_cast<const f32x4*>(p.b2 + n);
+        const f32x4 bb = pb2;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = mt * 16 + li;
@@ -330,6 +366,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
             }
         }
     }
+    TRF_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
