@@ -1091,19 +1091,18 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
 // fragments come from transposing reads, so no transposed activation copies (and no separate column-sum launches) are needed.
 // Orientation: A = X fragment (rows k), B = dY fragment (cols n)  ->  a lane owns dW[n][k..k+3]: float4 read-modify-write.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
-                                                             int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
-                                                             float* __restrict__ db2, int mchunk, int store = 0) {
+DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
+                              int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
+                              float* __restrict__ db2, int mchunk, int store, const int bx, const int by, const int bz, const int gz, char* smem) {
     // store != 0: dW / db are known to be all zeros (first backward after hulc_zero_grads): the tile is stored instead of read, added and written
-    // Large M (token-major transformer / encoder layers): blockIdx.z owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
+    // Large M (token-major transformer / encoder layers): block z (bz of gz) owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
     // time and adds its partial with fp32 atomics — replaces "transpose dY, transpose X, split-K NT GEMM, column-sum" (4 launches).
     constexpr int TN = 64, TK = 128, YS = TN * 2 + 16, XS = TK * 2 + 16;
-    __shared__ __attribute__((aligned(16))) char smem[64 * YS + 64 * XS];
     lds_char* yimg = (lds_char*)smem;
     lds_char* ximg = yimg + 64 * YS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
-    const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+    const int n0 = bx * TN, k0 = by * TK;
+    const int mbeg = bz * mchunk, mend = min(M, mbeg + mchunk);
     const int g = lane >> 4, a = lane & 15;
     const int prow = a >> 2, ccol = (a & 3) * 8;
     // wave w: n-tile w (16 columns of dY) x 8 k-tiles
@@ -1113,7 +1112,7 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __rest
     float bsum = 0.f;
     // the 8 dW quads this lane accumulates into are fetched NOW (single launch over M: plain read-modify-write), so their latency hides
     // under the staging / MFMA phase instead of serialising as 8 dependent load-add-store rounds at the end
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = gz > 1;
     const int n = n0 + wave * 16 + a;
     const bool vec_ok = !atomic && n < N && (lddw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) && k0 + TK <= K;
     float4 oldw[8];
@@ -1151,7 +1150,7 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __rest
                 acc[j] = MFMA_16x16x32_H(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
             }
         }
-        if (db && blockIdx.y == 0 && tid < TN) {
+        if (db && by == 0 && tid < TN) {
             for (int m = 0; m < 64; ++m) bsum += h2f(*(__attribute__((address_space(3))) h16_t*)(yimg + m * YS + tid * 2));
         }
     }
@@ -1182,10 +1181,30 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __rest
             }
         }
     }
-    if (db && blockIdx.y == 0 && tid < TN && n0 + tid < N) {
+    if (db && by == 0 && tid < TN && n0 + tid < N) {
         if (atomic) { unsafeAtomicAdd(db + n0 + tid, bsum); if (db2) unsafeAtomicAdd(db2 + n0 + tid, bsum); }
         else { db[n0 + tid] += bsum; if (db2) db2[n0 + tid] += bsum; }
     }
+}
+
+constexpr int LBS_LDS = 64 * (64 * 2 + 16) + 64 * (128 * 2 + 16);
+__global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
+                                                             int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
+                                                             float* __restrict__ db2, int mchunk, int store = 0) {
+    __shared__ __attribute__((aligned(16))) char smem[LBS_LDS];
+    lin_bwd_smallm_body(dY, ldy, X, ldx, M, N, K, dW, lddw, db, db2, mchunk, store, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem);
+}
+// the weight / bias gradients of up to eight M <= 64 Linear layers in ONE launch (the layers of an MLP's backward: each was a ~9 us launch
+// behind its own data-gradient GEMM); problem = the one whose block range holds blockIdx.x
+struct LinBwdJob { const h16_t* dY; const h16_t* X; float* dW; float* db; long long ldx, lddw; int N, K, nx, blk0; };
+struct LinBwdBatch { LinBwdJob j[8]; int n, M, store; };
+__global__ void __launch_bounds__(256) lin_bwd_smallm_batched_kernel(LinBwdBatch bt) {
+    __shared__ __attribute__((aligned(16))) char smem[LBS_LDS];
+    int k = 0;
+    while (k + 1 < bt.n && (int)blockIdx.x >= bt.j[k + 1].blk0) ++k;
+    const LinBwdJob J = bt.j[k];
+    const int b = blockIdx.x - J.blk0;
+    lin_bwd_smallm_body(J.dY, (long long)J.N, J.X, J.ldx, bt.M, J.N, J.K, J.dW, J.lddw, J.db, nullptr, 64, bt.store, b % J.nx, b / J.nx, 0, 1, smem);
 }
 
 }  // namespace HULC_NS

@@ -40,8 +40,9 @@ struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, 
 template <typename TS, typename TD>
 __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __restrict__ desc, int ndesc) {
     __shared__ float tile[32][33];
-    int d = 0;
-    while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const int d = lo;
     const TrDesc D = desc[d];
     const int b = blockIdx.x - D.blk0;
     const int c0 = (b % D.tiles_x) * 32, r0 = (b / D.tiles_x) * 32;
@@ -107,10 +108,19 @@ DEVI void transpose_tile64_h16(const TrDesc& D, int b, unsigned short (*tile)[66
         }
     }
 }
+// descriptor of block b: the last one whose first block is <= b.  Bisection: the linear walk made a block of a late matrix wait for up to ~60
+// dependent descriptor loads before it touched its tile
+DEVI int trdesc_find(const TrDesc* __restrict__ desc, int ndesc, int b) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 __global__ void __launch_bounds__(256) batched_transpose64_kernel(const TrDesc* __restrict__ desc, int ndesc) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
-    int d = 0;
-    while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
+    const int d = trdesc_find(desc, ndesc, (int)blockIdx.x);
     const TrDesc D = desc[d];
     transpose_tile64_h16(D, blockIdx.x - D.blk0, tile);
 }
