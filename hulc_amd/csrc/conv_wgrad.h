@@ -425,28 +425,33 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     const Step256 sq(W4);
     const RowCol q0{tid / W4, tid % W4};
     if (!s.u8) {
+        // all three channel planes of the band in ONE pass: element e of the [3][rows][W4] grid of 16-byte quads, NU quads in flight per thread.
+        // (A pass per channel had ~3 useful loads in flight per thread for a 16-row band — its other unrolled slots re-read a clamped element —
+        // and exposed the load latency three times per band.)
         const float* X = reinterpret_cast<const float*>(s.X);
-        for (int c = 0; c < 3; ++c) {
-            const float* src = X + (((long long)f * 3 + c) * IH + ih0) * IW;
-            lds_char* dst = ximg + c * XR * XRS;
-            RowCol p = q0;
-            while (p.r < rows) {                                      // 8 unconditional (clamped) 16-byte loads in flight per thread
-                RowCol e[8];
-                float4 v[8];
+        const float* src0 = X + ((long long)f * 3 * IH + ih0) * IW;
+        const int per = rows * W4, tot = 3 * per;
+        const float inv_per = 1.f / (float)per, inv_w4 = 1.f / (float)W4;
+        constexpr int NU = 6;       // conv1_fwd_kernel<4> runs at 128 VGPRs next to 48 registers of weight fragments: 10 in flight spilled 38
+        for (int e0 = tid; e0 < tot; e0 += 256 * NU) {
+            float4 v[NU];
+            int pk[NU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    e[u] = p; sq.adv(p);
-                    const bool in = e[u].r < rows;
-                    v[u] = *reinterpret_cast<const float4*>(src + ((long long)(in ? e[u].r : rows - 1) * W4 + (in ? e[u].c : W4 - 1)) * 4);
-                }
+            for (int u = 0; u < NU; ++u) {
+                const int e = min(e0 + u * 256, tot - 1);
+                const int c = (int)(((float)e + 0.5f) * inv_per), rem = e - c * per;
+                const int r = (int)(((float)rem + 0.5f) * inv_w4), q4 = rem - r * W4;
+                pk[u] = (c << 20) | (r << 8) | q4;
+                v[u] = *reinterpret_cast<const float4*>(src0 + ((long long)c * IH + r) * IW + q4 * 4);
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (e[u].r < rows) {
-                        u32x2_t o;
-                        o[0] = pack2h(v[u].x, v[u].y);
-                        o[1] = pack2h(v[u].z, v[u].w);
-                        *(__attribute__((address_space(3))) u32x2_t*)(dst + e[u].r * XRS + e[u].c * 8) = o;
-                    }
+            for (int u = 0; u < NU; ++u) {
+                if (e0 + u * 256 < tot) {
+                    const int c = pk[u] >> 20, r = (pk[u] >> 8) & 0xfff, q4 = pk[u] & 0xff;
+                    u32x2_t o;
+                    o[0] = pack2h(v[u].x, v[u].y);
+                    o[1] = pack2h(v[u].z, v[u].w);
+                    *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + r) * XRS + q4 * 8) = o;
                 }
             }
         }
