@@ -951,12 +951,17 @@ __global__ void __launch_bounds__(64) attention_bwd32_kernel(const T* __restrict
     if (i < S) {
         const T* r = qkv + (long long)(b * S + i) * 3 * D + h * HD;
         const T* g = dao + (long long)(b * S + i) * D + h * HD;
+        // a head's 16 values of a row are contiguous: two vector loads per operand instead of sixteen element loads (the kernel is one
+        // latency chain per wave; 32 dependent 2-byte loads per lane were most of its 16 us)
+        T a0[HD], a1[HD];
+        if (hf == 0) { load8<T>(r, *reinterpret_cast<T(*)[8]>(a0)); load8<T>(r + 8, *reinterpret_cast<T(*)[8]>(a0 + 8)); load8<T>(r + D, *reinterpret_cast<T(*)[8]>(a1)); load8<T>(r + D + 8, *reinterpret_cast<T(*)[8]>(a1 + 8)); }
+        else { load8<T>(r + 2 * D, *reinterpret_cast<T(*)[8]>(a0)); load8<T>(r + 2 * D + 8, *reinterpret_cast<T(*)[8]>(a0 + 8)); load8<T>(g, *reinterpret_cast<T(*)[8]>(a1)); load8<T>(g + 8, *reinterpret_cast<T(*)[8]>(a1 + 8)); }
         if (hf == 0) {
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { q[i][d] = to_f<T>(r[d]) * 0.25f; k[i][d] = to_f<T>(r[D + d]); }
+            for (int d = 0; d < HD; ++d) { q[i][d] = to_f<T>(a0[d]) * 0.25f; k[i][d] = to_f<T>(a1[d]); }
         } else {
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { v[i][d] = to_f<T>(r[2 * D + d]); dO[i][d] = to_f<T>(g[d]); }
+            for (int d = 0; d < HD; ++d) { v[i][d] = to_f<T>(a0[d]); dO[i][d] = to_f<T>(a1[d]); }
         }
     }
     __syncthreads();
@@ -1004,11 +1009,14 @@ __global__ void __launch_bounds__(64) attention_bwd32_kernel(const T* __restrict
 #pragma unroll
     for (int d = 0; d < HD; ++d) { dq[d] += __shfl_xor(dq[d], 32); dk[d] += __shfl_xor(dk[d], 32); dv[d] += __shfl_xor(dv[d], 32); }
     T* o = dqkv + (long long)(b * S + i) * 3 * D + h * HD + hf * 8;
+    Vec8<T> oq, ok, ov;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         const int e = hf * 8 + d;
-        o[d] = from_f<T>(dq[e] * 0.25f); o[D + d] = from_f<T>(dk[e]); o[2 * D + d] = from_f<T>(dv[e]);
+        oq.v[d] = from_f<T>((hf ? dq[8 + d] : dq[d]) * 0.25f); ok.v[d] = from_f<T>(hf ? dk[8 + d] : dk[d]); ov.v[d] = from_f<T>(hf ? dv[8 + d] : dv[d]);
+        (void)e;
     }
+    *reinterpret_cast<Vec8<T>*>(o) = oq; *reinterpret_cast<Vec8<T>*>(o + D) = ok; *reinterpret_cast<Vec8<T>*>(o + 2 * D) = ov;
 }
 
 // 32 < S <= 64 (BASELINE config 5's windows): four waves per (b, head), wave w handles the keys [16 w, 16 w + 16) of every query row (lane = row);
