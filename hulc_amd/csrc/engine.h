@@ -93,7 +93,7 @@ struct Engine : IEngine {
     float* dw7_tmp = nullptr;
     bool bound = false;
     T* wshadow = nullptr;                 // bf16 mode: flat compute copy of all parameters (written by the Adam kernel)
-    std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0;
+    std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0; unsigned short* blk2desc_dev = nullptr;
 
     // ---- workspace (per modality pass)
     struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; unsigned* m2bits = nullptr; } aS, aG;
@@ -127,7 +127,7 @@ struct Engine : IEngine {
         KIN = dec_plan + DE + GOAL;
         maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
     }
-    ~Engine() override { for (void* p : allocs) hipFree(p); if (rp_err_host) hipHostFree((void*)rp_err_host); }
+    ~Engine() override { for (void* p : allocs) hipFree(p); if (rp_err_host) hipHostFree((void*)rp_err_host); if (blk2desc_dev) hipFree(blk2desc_dev); if (trdesc_dev) hipFree(trdesc_dev); }
     int64_t workspace_bytes() const override { return ws_bytes; }
     void set_kl_beta(float b) override { cfg.kl_beta = b; }
     void set_dropout(float p) override { cfg.dropout_p = p; }
@@ -351,6 +351,16 @@ struct Engine : IEngine {
             hulc_set_error("hulc_bind_params: a required parameter name is missing from the table");
             return 1;
         }
+        if (blk2desc_dev) { hipFree(blk2desc_dev); blk2desc_dev = nullptr; }
+        {
+            std::vector<unsigned short> b2d((size_t)std::max(tr_blocks, 1));
+            for (size_t i = 0; i < trdesc.size(); ++i) {
+                const int end = i + 1 < trdesc.size() ? trdesc[i + 1].blk0 : tr_blocks;
+                for (int b = trdesc[i].blk0; b < end; ++b) b2d[b] = (unsigned short)i;
+            }
+            if (hipMalloc((void**)&blk2desc_dev, b2d.size() * sizeof(unsigned short)) != hipSuccess) alloc_failed = true;
+            else hipMemcpy(blk2desc_dev, b2d.data(), b2d.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+        }
         if (trdesc_dev) { hipFree(trdesc_dev); trdesc_dev = nullptr; }
         if (hipMalloc((void**)&trdesc_dev, sizeof(TrDesc) * trdesc.size()) != hipSuccess) alloc_failed = true;
         else hipMemcpy(trdesc_dev, trdesc.data(), sizeof(TrDesc) * trdesc.size(), hipMemcpyHostToDevice);
@@ -560,7 +570,7 @@ struct Engine : IEngine {
         }
         // ... then every transposed copy — the Linear weights, the permuted fc7 and the packed heads — in ONE batched launch
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
-        else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
         return 0;
