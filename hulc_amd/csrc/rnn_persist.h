@@ -22,9 +22,9 @@
 //     barrier per step), four reducer waves (one per SIMD) sum them, apply the step's epilogue (residual, ReLU / tanh or their derivative
 //     masks) and store the 64-feature slice of the new state;
 //   * hand-off: all communication stays INSIDE one XCD, whose L2 is the coherence point of its 32 CUs.  Producer: plain 16-byte stores (they
-//     write through the CU's L1 into the L2), `s_waitcnt vmcnt(0)`, an LDS arrival count of the four reducer waves, the last one stores the
-//     step counter into the mailbox line of each of the 32 consumers.  Consumer: every wave samples its workgroup's own 128-byte mailbox
-//     line with `sc1` loads (they bypass the L1, which another CU's stores never refresh, and are served by the L2 — the mailbox lines are
+//     write through the CU's L1 into the L2), `s_waitcnt vmcnt(0)`, then each of the four reducer waves stores the step counter into its own word
+//     of the mailbox of each of the 32 consumers.  Consumer: a wave samples the 16 words of the four producers of its k-range in its
+//     workgroup's own mailbox with `sc1` loads (they bypass the L1, which another CU's stores never refresh, and are served by the L2 — the mailbox lines are
 //     rewritten every step and stay dirty-resident there) and then reads the state with `sc1` loads.  Measured alternatives (B = 64, S = 32,
 //     per step): write-through `sc1` stores + flags through memory, the placement-independent form, 5.6 - 9.3 us (no better than a launch
 //     per step: 4.2 us back to back); this form 2.6 - 3.2 us; the state as its own ready flag (slices pre-filled with a reserved NaN pattern,
@@ -40,7 +40,7 @@ namespace HULC_NS {
 
 constexpr int RP_HID = 2048, RP_NG = 8, RP_SLOTS = 32, RP_COLS = 64, RP_NW = 8, RP_KW = 256, RP_KS = RP_KW / 32;
 constexpr int RP_TPITCH = RP_COLS * 4 + 16;          // LDS pitch of one window's 64 fp32 partial sums: 17 slots -> conflict-free 16-byte writes
-constexpr int RP_MAIL_WORDS = RP_NG * RP_SLOTS * RP_SLOTS;
+constexpr int RP_MAIL_WORDS = RP_NG * RP_SLOTS * RP_SLOTS * 4;        // mailbox[group][consumer][producer][reducer wave]: 512 bytes per consumer workgroup
 constexpr int RP_FLAG_WORDS = RP_MAIL_WORDS + 2 * RP_NG * 32;     // mailbox[group][consumer][producer]: one 128-byte line per consumer workgroup
 
 struct RnnPersistP {
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     constexpr int WS = TOK * RP_TPITCH + 32;          // per-wave partial block; 4 WS = 128 (mod 256): the two partial halves a reducer pair reads never collide
     constexpr int BUF = RP_NW * WS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, gq = lane >> 4;
-    __shared__ unsigned s_slot, done_cnt;
+    __shared__ unsigned s_slot;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int grp = (int)(xcc & 7u);
@@ -86,7 +86,6 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
         if (sl == 0) __hip_atomic_store(census + ((p.parity ^ 1) * RP_NG + grp) * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's set
         if (sl >= (unsigned)RP_SLOTS) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_slot = sl;
-        done_cnt = 0;
     }
     __syncthreads();
     const int slot = (int)s_slot;
@@ -104,9 +103,10 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
 #pragma unroll
         for (int ks = 0; ks < RP_KS; ++ks)
             wf[ct][ks] = *reinterpret_cast<const h16x8_t*>(p.W + (long long)(RP_COLS * slot + 16 * ct + li) * RP_HID + RP_KW * wave + 32 * ks + 8 * gq);
-    // mailbox[group][consumer slot][producer slot]: a consumer's waves sample their OWN 128-byte line; a producer's last reducer wave writes
-    // its step counter into the 32 lines of its group (one lane per consumer)
-    const unsigned* fl = p.flags + (grp * RP_SLOTS + slot) * RP_SLOTS;
+    // mailbox[group][consumer slot][producer slot][reducer wave]: each of a producer's four reducer waves posts its own word as soon as ITS part of
+    // the slice is in the L2 (no arrival count among them), into the 32 consumers' mailboxes (one lane per consumer); a consumer wave samples
+    // only the 16 words of the four producers whose features are its k-range — it does not wait for the slowest of all 32
+    const unsigned* fl = p.flags + ((grp * RP_SLOTS + slot) * RP_SLOTS + 4 * wave) * 4;
     bool dead = false;
     // reducer waves 0..3 (one per SIMD): wave r sums the 8 k-partials of windows r * TOK/4 .. + TOK/4; lane = (window tk, 4-feature group c4, partial half ph)
     constexpr int NIT = TOK / 8;
@@ -130,13 +130,12 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
             }
         }
         if (s > 1 && !dead) {
-            // wait for all 32 producers of the group (lane = producer); all eight waves sample the line, so it is sampled several times per
-            // L2 round trip (the first step's input comes from an earlier launch)
+            // wait for the four producers of this wave's k-range (lane = producer * 4 + reducer wave); the first step's input comes from an earlier launch
             const unsigned want = p.base + (unsigned)(s - 1);
             int spins = 0;
             for (;;) {
                 unsigned v = want;
-                if (lane < RP_SLOTS) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < 16) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((int)(v - want) >= 0)) break;
                 if (++spins > (1 << 18)) { dead = true; if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             }
@@ -209,11 +208,8 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
             RP_STAMP(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the slice is in the L2
             RP_STAMP(6);
-            unsigned prev = 0;
-            if (lane == 0) prev = __hip_atomic_fetch_add(&done_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            prev = __builtin_amdgcn_readfirstlane(prev);
-            if (prev == 4u * (unsigned)s - 1u && lane < RP_SLOTS)    // the last of the four reducers: the whole slice is in the L2 -> every consumer's mailbox
-                __hip_atomic_store(p.flags + ((grp * RP_SLOTS + lane) * RP_SLOTS + slot), p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < RP_SLOTS)      // this reducer wave's part of the slice is in the L2 -> its word in every consumer's mailbox
+                __hip_atomic_store(p.flags + (((grp * RP_SLOTS + lane) * RP_SLOTS + slot) * 4 + wave), p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
