@@ -141,7 +141,10 @@ def test_mcil_fit_loop_descends_validates_and_checkpoints(tmp_path, rnn_type):
     hist = tr.fit(model, Fixed())
     losses = [h["loss"] for h in hist]
     assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.5, losses
-    assert len(tr.val_history) == 2 and tr.val_history[1]["val_act/action_loss_pp"] < tr.val_history[0]["val_act/action_loss_pp"]
+    # the validation loss under the PROPOSAL plan is evaluated with a fresh random plan draw per epoch: after ten optimizer steps its epoch-to-epoch
+    # change (-1 .. -3 % typically) is of the order of that draw's noise (one run in ~6 of the whole suite saw +0.25 %); the descent itself is
+    # asserted on the training loss above
+    assert len(tr.val_history) == 2 and tr.val_history[1]["val_act/action_loss_pp"] < 1.02 * tr.val_history[0]["val_act/action_loss_pp"]
     assert "val_kl/vis_kl_loss" in tr.val_history[0] and "val_grip/lang_grip_sr_pr" in tr.val_history[0]
     ck = get_last_checkpoint(str(tmp_path))
     sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
