@@ -1587,7 +1587,8 @@ __global__ void relative_actions_kernel(const float* __restrict__ actions_abs, c
 // row_loss is [rows][8] (summed deterministically afterwards).  Each thread recomputes the row's tcp-frame action (cheap) so the
 // 7 partial losses of a row run in parallel instead of serially in one lane.
 template <typename T, int NMIXC>      // NMIXC = n_mixtures at compile time: the per-mixture arrays stay in registers (NMIX must equal it)
-__global__ void logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
+// launched with <= 256 threads: without the bound the compiler budgets for 1024 (128 VGPRs) and spilled 46 registers
+__global__ void __launch_bounds__(256) logistic_loss_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions /*[B][S][7]*/,
                                      const float* __restrict__ robot_obs /*[B][S][15]*/, int B, int S, int NMIX, int NDIM, int num_classes,
                                      float log_scale_min, float gripper_alpha, int gripper_control, float grad_scale,
                                      float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads,
