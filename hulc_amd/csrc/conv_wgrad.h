@@ -1098,7 +1098,9 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
 // ---------------------------------------------------------------------------------------------------------------------
 DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const h16_t* __restrict__ X, long long ldx,
                               int M, int N, int K, float* __restrict__ dW, long long lddw, float* __restrict__ db,
-                              float* __restrict__ db2, int mchunk, int store, const int bx, const int by, const int bz, const int gz, char* smem) {
+                              float* __restrict__ db2, int mchunk, int store, const int bx, const int by, const int bz, const int gz, char* smem,
+                              const bool slabs = false) {
+    // slabs: dW is this row chunk's OWN zero-assumed slab (plain stores, reduced later by the batched unpack launch); only the bias uses atomics
     // store != 0: dW / db are known to be all zeros (first backward after hulc_zero_grads): the tile is stored instead of read, added and written
     // Large M (token-major transformer / encoder layers): block z (bz of gz) owns rows [z*mchunk, (z+1)*mchunk), loops over them 64 at a
     // time and adds its partial with fp32 atomics — replaces "transpose dY, transpose X, split-K NT GEMM, column-sum" (4 launches).
@@ -1117,7 +1119,8 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
     float bsum = 0.f;
     // the 8 dW quads this lane accumulates into are fetched NOW (single launch over M: plain read-modify-write), so their latency hides
     // under the staging / MFMA phase instead of serialising as 8 dependent load-add-store rounds at the end
-    const bool atomic = gz > 1;
+    const bool atomic_b = gz > 1;
+    const bool atomic = atomic_b && !slabs;
     const int n = n0 + wave * 16 + a;
     const bool vec_ok = !atomic && n < N && (lddw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) && k0 + TK <= K;
     float4 oldw[8];
@@ -1187,7 +1190,7 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
         }
     }
     if (db && by == 0 && tid < TN && n0 + tid < N) {
-        if (atomic) { unsafeAtomicAdd(db + n0 + tid, bsum); if (db2) unsafeAtomicAdd(db2 + n0 + tid, bsum); }
+        if (atomic_b) { unsafeAtomicAdd(db + n0 + tid, bsum); if (db2) unsafeAtomicAdd(db2 + n0 + tid, bsum); }
         else { db[n0 + tid] += bsum; if (db2) db2[n0 + tid] += bsum; }
     }
 }
@@ -1201,15 +1204,17 @@ __global__ void __launch_bounds__(256) lin_bwd_smallm_kernel(const h16_t* __rest
 }
 // the weight / bias gradients of up to eight M <= 64 Linear layers in ONE launch (the layers of an MLP's backward: each was a ~9 us launch
 // behind its own data-gradient GEMM); problem = the one whose block range holds blockIdx.x
-struct LinBwdJob { const h16_t* dY; const h16_t* X; float* dW; float* db; long long ldx, lddw; int N, K, nx, blk0; };
-struct LinBwdBatch { LinBwdJob j[8]; int n, M, store; };
+struct LinBwdJob { const h16_t* dY; const h16_t* X; float* dW; float* db; long long ldx, lddw; int N, K, nx, blk0; float* part; };   // part: slabs [gridDim.y][N][K] (mchunk mode) or null
+struct LinBwdBatch { LinBwdJob j[8]; int n, M, store, mchunk; };      // mchunk > 0: rows split over blockIdx.y in chunks of mchunk (fp32 atomics)
 __global__ void __launch_bounds__(256) lin_bwd_smallm_batched_kernel(LinBwdBatch bt) {
     __shared__ __attribute__((aligned(16))) char smem[LBS_LDS];
     int k = 0;
     while (k + 1 < bt.n && (int)blockIdx.x >= bt.j[k + 1].blk0) ++k;
     const LinBwdJob J = bt.j[k];
     const int b = blockIdx.x - J.blk0;
-    lin_bwd_smallm_body(J.dY, (long long)J.N, J.X, J.ldx, bt.M, J.N, J.K, J.dW, J.lddw, J.db, nullptr, 64, bt.store, b % J.nx, b / J.nx, 0, 1, smem);
+    const bool slabs = bt.mchunk > 0 && J.part;
+    lin_bwd_smallm_body(J.dY, (long long)J.N, J.X, J.ldx, bt.M, J.N, J.K, slabs ? J.part + (long long)blockIdx.y * J.N * J.K : J.dW, slabs ? (long long)J.K : J.lddw, J.db, nullptr,
+                        bt.mchunk > 0 ? bt.mchunk : 64, slabs ? 1 : bt.store, b % J.nx, b / J.nx, blockIdx.y, gridDim.y, smem, slabs);
 }
 
 }  // namespace HULC_NS

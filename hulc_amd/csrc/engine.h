@@ -16,6 +16,7 @@
 #include "conv_reg.h"
 #include "tr_fused.h"
 #include "rnn_persist.h"
+#include "enc_tail.h"
 
 namespace HULC_NS {
 
@@ -98,6 +99,7 @@ struct Engine : IEngine {
     // ---- workspace (per modality pass)
     struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; unsigned* m2bits = nullptr; } aS, aG;
     T *dact1, *dact2, *dact3, *d_g0, *d_f1, *d_f2t; float* d_ss;
+    T *d_f1g = nullptr, *d_f2tg = nullptr;      // 16-bit engines: the gripper encoder's own copies (both tails' data gradients run as one launch)
     T *emb, *lang_t, *gl1, *gl2, *goal_t, *ppx, *ppa[4], *xm, *seqf_t, *embg, *Cb, *Zx0, *Zx1, *H0, *H1, *dheads, *dH1, *dZ1, *dH0, *dZ0, *dC;
     float *gl3, *goal_st, *pp_logits, *seqf, *pr_logits, *probs, *klcat, *dpp_kl, *dpr_kl, *Cplan, *heads, *rowloss, *a_tcp;
     int* pidx; int* pidx_in;
@@ -160,6 +162,7 @@ struct Engine : IEngine {
         alloc_enc(aG, 84, true, "g_");
         dact1 = alloc<T>(N * 49 * 49 * 32, "dact1"); dact2 = alloc<T>(N * 23 * 23 * 64, "dact2"); dact3 = alloc<T>(N * 21 * 21 * 64, "dact3");
         d_g0 = alloc<T>(N * 128); d_f1 = alloc<T>(N * 512); d_f2t = alloc<T>(N * 64); d_ss = alloc<float>(N * 128, "d_ss");
+        if constexpr (std::is_same<T, h16_t>::value) { d_f1g = alloc<T>(N * 512); d_f2tg = alloc<T>(N * 64); }
         emb = alloc<T>(N * EMB, "emb"); lang_t = alloc<T>(B * LANG); gl1 = alloc<T>(B * HID); gl2 = alloc<T>(B * HID);
         gl3 = alloc<float>(B * GOAL, "goal_pre"); goal_t = alloc<T>(B * GOAL, "goal"); goal_st = alloc<float>(B * 2);
         ppx = alloc<T>(B * (EMB + GOAL)); for (int i = 0; i < 4; ++i) ppa[i] = alloc<T>(B * HID);
@@ -624,7 +627,7 @@ struct Engine : IEngine {
     bool pair = false; int pairBv = 0; hulc_batch cur2;
     float *act_j = nullptr, *ro_j = nullptr, *eps_j = nullptr, *losses2 = nullptr; int* aux_j = nullptr;
     // src2 (paired pass): frames [0, Nf/2) come from src, [Nf/2, Nf) from src2 — conv1 runs once per source, the rest on all Nf frames
-    void enc_fwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr) {
+    void enc_fwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr, bool defer_tail = false) {
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
         for (int h = 0; h < (src2 ? 2 : 1); ++h) {
             const Conv1Src& sh = h ? *src2 : src;
@@ -675,10 +678,71 @@ struct Engine : IEngine {
             lin_fwd(a.a3, 3136, Nf, e.fc7, ep, 128);
             fin = a.g0; fk = 128;
         }
+        if (defer_tail) return;             // 16-bit engines: the dense tails of both cameras run as one launch (enc_tail_fwd_both)
         { EpiP ep = epi(a.f1, false); ep.relu = 1; lin_fwd(fin, fk, Nf, e.fc1, ep, 512); }
         { EpiP ep = epi(a.f2, true); lin_fwd(a.f1, 512, Nf, e.fc2, ep, 64); }
         ln_fwd(a.f2, 64, Nf, 64, e.lng, e.lnb, emb + col0, EMB, nullptr, 0, a.lnst);
     }
+    // fc1 + ReLU, fc2 and the LayerNorm of both encoders in one launch (enc_tail.h)
+    void enc_tail_fwd_both(int Nf) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            EncTailP q{};
+            const EncW* ew[2] = {&encS, &encG};
+            EncA* ea[2] = {&aS, &aG};
+            for (int k = 0; k < 2; ++k) {
+                EncTailCam& c = q.cam[k];
+                c.x = ew[k]->gripper ? ea[k]->g0 : ea[k]->ss; c.W1 = ew[k]->fc1.W; c.W2 = ew[k]->fc2.W; c.b1 = ew[k]->fc1.b32; c.b2 = ew[k]->fc2.b32;
+                c.lng = ew[k]->lng; c.lnb = ew[k]->lnb; c.f1 = ea[k]->f1; c.f2 = ea[k]->f2; c.lnst = ea[k]->lnst; c.col0 = k * 64;
+            }
+            q.emb = emb; q.Nf = Nf; q.ldemb = EMB;
+            launch_enc_tail_fwd(st, q);
+        }
+    }
+    // the data-gradient chain of both tails (LayerNorm, fc2, fc1) in one launch; the weight gradients follow in enc_bwd
+    void enc_tail_bwd_both(int Nf) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            EncTailBwdP q{};
+            const EncW* ew[2] = {&encS, &encG};
+            EncA* ea[2] = {&aS, &aG};
+            for (int k = 0; k < 2; ++k) {
+                EncTailBwdCam& c = q.cam[k];
+                c.f2 = ea[k]->f2; c.lnst = ea[k]->lnst; c.lng = ew[k]->lng; c.f1 = ea[k]->f1; c.W2t = ew[k]->fc2.Wt; c.W1t = ew[k]->fc1.Wt;
+                c.xmask = ew[k]->gripper ? ea[k]->g0 : nullptr; c.dlng = ew[k]->dlng; c.dlnb = ew[k]->dlnb;
+                c.d_f2 = ew[k]->gripper ? d_f2tg : d_f2t; c.d_f1 = ew[k]->gripper ? d_f1g : d_f1;
+                c.dx_f32 = ew[k]->gripper ? nullptr : d_ss; c.dx_t = ew[k]->gripper ? d_g0 : nullptr; c.col0 = k * 64;
+            }
+            q.demb = demb; q.Nf = Nf; q.ldemb = EMB;
+            launch_enc_tail_bwd(st, q);
+            // weight / bias gradients of the four Linear layers: one launch, frames split over blockIdx.y (fp32 atomics), operands read as they lie
+            static const int chunk = HULC_SWITCH("HULC_ENC_WGRAD_CHUNK", 256);
+            tail_wgrad_done = chunk > 0;
+            if (tail_wgrad_done) {
+                LinBwdBatch bt{}; bt.M = Nf; bt.store = 0; bt.mchunk = chunk;
+                int blk = 0;
+                const int nz = cdiv(Nf, chunk);
+                static const bool slab_ok = HULC_SWITCH("HULC_ENC_WGRAD_SLABS", 1) != 0;
+                for (int k = 0; k < 2; ++k)
+                    for (int l = 0; l < 2; ++l) {          // l = 0: fc2 (dY = d_f2, X = f1);  1: fc1 (dY = d_f1, X = the tail's input)
+                        const LinW& L = l ? ew[k]->fc1 : ew[k]->fc2;
+                        LinBwdJob& J = bt.j[bt.n++];
+                        J.dY = l ? q.cam[k].d_f1 : q.cam[k].d_f2; J.X = l ? (ew[k]->gripper ? ea[k]->g0 : ea[k]->ss) : ea[k]->f1;
+                        J.dW = L.dW; J.db = L.db; J.ldx = L.K; J.lddw = L.K; J.N = L.N; J.K = L.K; J.nx = cdiv(L.N, 64); J.blk0 = blk;
+                        blk += J.nx * cdiv(L.K, 128);
+                        // every row chunk writes its own slab; the slabs are summed into the gradient by the encoders' one unpack launch (no
+                        // per-element atomics here: 1.5 M of them made this launch 39 us)
+                        const int64_t need = (int64_t)nz * L.N * L.K;
+                        if (slab_ok && unpack_jobs.n < 12 && part_cur + need <= this->partcap) {
+                            J.part = this->part + part_cur;
+                            UnpackJob& U = unpack_jobs.j[unpack_jobs.n++];
+                            U.part = J.part; U.grad = L.dW; U.slab = (long long)L.N * L.K; U.nsplit = nz; U.O = L.N; U.I = L.K; U.KH = U.KW = 1; U.nhwc = 0; U.blk0 = unpack_blocks; U.ysplit = 1;
+                            unpack_blocks += cdiv(L.N * L.K, 1024); part_cur += need;
+                        }
+                    }
+                hipLaunchKernelGGL(lin_bwd_smallm_batched_kernel, dim3(blk, nz), dim3(256), 0, st, bt);
+            }
+        }
+    }
+    bool tail_wgrad_done = false;
     Conv1Src wgrad_src;                       // conv1 only: set by enc_bwd before conv_wgrad(e.c1, ...)
     // 16-bit engines: the slab -> gradient reductions of the encoders' convolutions are collected and run as ONE launch (flush_unpacks) after
     // both encoders' backward instead of one ~6-20 us launch behind each of the six weight-gradient kernels
@@ -725,9 +789,9 @@ struct Engine : IEngine {
         // every launch slower (23 / 11.3 / 10.9 us against 18.6 / 9.5 / 9.6: the scattered atomics, not the slab stream, are the cost)
         const int ybl = cdiv(c.O * Kc, 1024);
         if constexpr (std::is_same<T, h16_t>::value) {
-            if (nsplit >= 64 && unpack_jobs.n < 8 && part_cur + (int64_t)nsplit * c.O * Kc <= this->partcap) {
+            if (nsplit >= 64 && unpack_jobs.n < 12 && part_cur + (int64_t)nsplit * c.O * Kc <= this->partcap) {
                 UnpackJob& J = unpack_jobs.j[unpack_jobs.n++];
-                J.part = part; J.grad = c.dW; J.slab = (long long)c.O * Kc; J.nsplit = nsplit; J.O = c.O; J.I = c.I; J.KH = c.KH; J.KW = c.KW; J.nhwc = c.nhwc; J.blk0 = unpack_blocks;
+                J.part = part; J.grad = c.dW; J.slab = (long long)c.O * Kc; J.nsplit = nsplit; J.O = c.O; J.I = c.I; J.KH = c.KH; J.KW = c.KW; J.nhwc = c.nhwc; J.blk0 = unpack_blocks; J.ysplit = 0;
                 unpack_blocks += ybl; part_cur += (int64_t)nsplit * c.O * Kc;
                 if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
                 return;
@@ -788,25 +852,28 @@ struct Engine : IEngine {
         O o; int zc;
         DEVI long long offset(int r, int) const { return o.offset(r, zc); }
     };
-    void enc_bwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr) {
+    void enc_bwd(const EncW& e, EncA& a, const Conv1Src& src, int Nf, int col0, const Conv1Src* src2 = nullptr, bool tail_done = false) {
         wgrad_src = src;
         const float* x = nullptr;
         if constexpr (std::is_same<T, float>::value) x = src.u8 ? x32[e.gripper ? 1 : 0] : reinterpret_cast<const float*>(src.X);   // materialised by the forward
         ConvGeom g1 = geom(Nf, e.IH, 3, 8, 4), g2 = geom(Nf, e.H1, 32, 4, 2), g3 = geom(Nf, e.H2, 64, 3, 1);
+        T* const d_f1 = tail_done && e.gripper ? d_f1g : this->d_f1;
+        T* const d_f2t = tail_done && e.gripper ? d_f2tg : this->d_f2t;
         // LN bwd on demb[:, col0:col0+64]
-        ln_bwd(demb + col0, EMB, a.f2, 64, a.lnst, e.lng, Nf, 64, nullptr, 0, 0, d_f2t, 64, e.dlng, e.dlnb);
+        if (!tail_done) ln_bwd(demb + col0, EMB, a.f2, 64, a.lnst, e.lng, Nf, 64, nullptr, 0, 0, d_f2t, 64, e.dlng, e.dlnb);
         // fc2
-        { EpiP ep = epi(d_f1, false); ep.mask = a.f1; lin_dgrad(d_f2t, Nf, e.fc2, ep, dense_out(512)); }
-        lin_wgrad(d_f2t, a.f1, 512, Nf, 64, 512, e.fc2.dW, 512, e.fc2.db);
+        if (!tail_done) { EpiP ep = epi(d_f1, false); ep.mask = a.f1; lin_dgrad(d_f2t, Nf, e.fc2, ep, dense_out(512)); }
+        const bool wdone = tail_done && tail_wgrad_done;
+        if (!wdone) lin_wgrad(d_f2t, a.f1, 512, Nf, 64, 512, e.fc2.dW, 512, e.fc2.db);
         const int H3 = e.H3;
         if (!e.gripper) {
-            { EpiP ep = epi(d_ss, true); lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
-            lin_wgrad(d_f1, a.ss, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
+            if (!tail_done) { EpiP ep = epi(d_ss, true); lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
+            if (!wdone) lin_wgrad(d_f1, a.ss, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
             if constexpr (std::is_same<T, h16_t>::value) hipLaunchKernelGGL(spatial_softmax_bwd64_kernel, dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, dact3);
             else hipLaunchKernelGGL((spatial_softmax_bwd_kernel<T>), dim3(Nf), dim3(256), 0, st, a.a3, a.ssstats, d_ss, H3, H3, 64, dact3);
         } else {
-            { EpiP ep = epi(d_g0, false); ep.mask = a.g0; lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
-            lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
+            if (!tail_done) { EpiP ep = epi(d_g0, false); ep.mask = a.g0; lin_dgrad(d_f1, Nf, e.fc1, ep, dense_out(128)); }
+            if (!wdone) lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
             { EpiP ep = epi(dact3, false); ep.mask = a.a3; lin_dgrad(d_g0, Nf, e.fc7, ep, dense_out(3136)); }
             // dW7 in packed (NHWC) column order -> temp, then permute-accumulate into the torch-layout grad
             lin_wgrad(d_g0, a.a3, 3136, Nf, 128, 3136, dw7_tmp, 3136, e.fc7.db);
@@ -897,9 +964,11 @@ struct Engine : IEngine {
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
         {
             const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
-            enc_fwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr);
+            constexpr bool tail_fused = std::is_same<T, h16_t>::value;
+            enc_fwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr, tail_fused);
             STAGE("enc_static_fwd");
-            enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
+            enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr, tail_fused);
+            if (tail_fused) enc_tail_fwd_both(N);
             STAGE("enc_gripper_fwd");
         }
         // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
@@ -2063,9 +2132,11 @@ struct Engine : IEngine {
         // ---- encoders backward
         {
             const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
-            enc_bwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr);
+            constexpr bool tail_fused = std::is_same<T, h16_t>::value;
+            if (tail_fused) enc_tail_bwd_both(N);
+            enc_bwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr, tail_fused);
             STAGE("enc_static_bwd");
-            enc_bwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr);
+            enc_bwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr, tail_fused);
             flush_unpacks();
             STAGE("enc_gripper_bwd");
         }

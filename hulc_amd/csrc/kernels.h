@@ -219,8 +219,8 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsp
 
 // the same for up to eight convolutions in ONE launch (the encoders' backward deferred its six unpack launches to its end): job = the
 // convolution whose block range holds blockIdx.x; every job owns its own slab region
-struct UnpackJob { const float* part; float* grad; long long slab; int nsplit, O, I, KH, KW, nhwc, blk0; };
-struct UnpackBatch { UnpackJob j[8]; int n; };
+struct UnpackJob { const float* part; float* grad; long long slab; int nsplit, O, I, KH, KW, nhwc, blk0, ysplit; };   // ysplit > 0: this job's slabs over that many grid.y parts only
+struct UnpackBatch { UnpackJob j[12]; int n; };
 __global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
     int k = 0;
     while (k + 1 < ub.n && (int)blockIdx.x >= ub.j[k + 1].blk0) ++k;
@@ -228,7 +228,9 @@ __global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
     const int idx = ((blockIdx.x - J.blk0) * blockDim.x + threadIdx.x) * 4;
     const int total = J.O * J.I * J.KH * J.KW;
     if (idx >= total) return;
-    const int per = (J.nsplit + gridDim.y - 1) / gridDim.y;
+    const int gy = J.ysplit > 0 ? J.ysplit : (int)gridDim.y;
+    if ((int)blockIdx.y >= gy) return;
+    const int per = (J.nsplit + gy - 1) / gy;
     const int z0 = blockIdx.y * per, z1 = min(J.nsplit, z0 + per);
     if (z0 >= z1) return;
     const float* part = J.part;
