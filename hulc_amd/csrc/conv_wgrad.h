@@ -1128,24 +1128,36 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) oldw[j] = store ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4);
     }
-    for (int m0 = mbeg; m0 < mend; m0 += 64) {
-        if (m0 > mbeg) __syncthreads();
-        // stage dY[m0:m0+64][n0:n0+64] and X[m0:m0+64][k0:k0+128] (rows >= mend and columns past the edge -> zeros)
-        for (int i = tid; i < 64 * (TN / 8); i += 256) {
-            const int m = i / (TN / 8), c = i % (TN / 8);
+    // the next 64-row chunk's tiles are requested into registers before the MFMAs of the current one (2 + 4 x 16 bytes per thread)
+    u32x4_t ry[2], rx[4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256, m = i / (TN / 8), c = i % (TN / 8);
             h16_t v[8];
             if (m0 + m < mend && n0 + c * 8 < N) load8_guard<h16_t>(dY + (long long)(m0 + m) * ldy + n0 + c * 8, N - (n0 + c * 8), v);
             else zero8<h16_t>(v);
-            *(lds_u32x4*)(yimg + m * YS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+            ry[u] = *reinterpret_cast<const u32x4_t*>(v);
         }
-        for (int i = tid; i < 64 * (TK / 8); i += 256) {
-            const int m = i / (TK / 8), c = i % (TK / 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 256, m = i / (TK / 8), c = i % (TK / 8);
             h16_t v[8];
             if (m0 + m < mend && k0 + c * 8 < K) load8_guard<h16_t>(X + (long long)(m0 + m) * ldx + k0 + c * 8, K - (k0 + c * 8), v);
             else zero8<h16_t>(v);
-            *(lds_u32x4*)(ximg + m * XS + c * 16) = *reinterpret_cast<const u32x4_t*>(v);
+            rx[u] = *reinterpret_cast<const u32x4_t*>(v);
         }
+    };
+    fetch(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += 64) {
+        if (m0 > mbeg) __syncthreads();
+        // stage dY[m0:m0+64][n0:n0+64] and X[m0:m0+64][k0:k0+128] (rows >= mend and columns past the edge -> zeros)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + u * 256; *(lds_u32x4*)(yimg + (i / (TN / 8)) * YS + (i % (TN / 8)) * 16) = ry[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = tid + u * 256; *(lds_u32x4*)(ximg + (i / (TK / 8)) * XS + (i % (TK / 8)) * 16) = rx[u]; }
         __syncthreads();
+        if (m0 + 64 < mend) fetch(m0 + 64);
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {                        // reduction over m: 2 x 32
             const int mrow = ms * 32 + g * 8 + prow;
@@ -1158,8 +1170,19 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
                 acc[j] = MFMA_16x16x32_H(xf, yf, acc[j], 0, 0, 0);   // D[row = k][col = n]
             }
         }
-        if (db && by == 0 && tid < TN) {
-            for (int m = 0; m < 64; ++m) bsum += h2f(*(__attribute__((address_space(3))) h16_t*)(yimg + m * YS + tid * 2));
+        if (db && by == 0) {                                    // column sums of dY: wave w adds rows 16 w .. 16 w + 15 of column `lane`
+#pragma unroll 16
+            for (int m = 0; m < 16; ++m) bsum += h2f(*(__attribute__((address_space(3))) h16_t*)(yimg + (wave * 16 + m) * YS + lane * 2));
+        }
+    }
+    if (db && by == 0) {                                        // the four waves' partial column sums meet in LDS (the tiles are dead)
+        __syncthreads();
+        *(__attribute__((address_space(3))) float*)(yimg + (wave * 64 + lane) * 4) = bsum;
+        __syncthreads();
+        if (tid < TN) {
+            bsum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bsum += *(__attribute__((address_space(3))) float*)(yimg + (w * 64 + tid) * 4);
         }
     }
     if (vec_ok) {

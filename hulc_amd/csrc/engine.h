@@ -581,6 +581,39 @@ struct Engine : IEngine {
     // grads_fresh: the gradient buffer is all zeros (hulc_zero_grads was the last thing that touched it).  The first backward after it may STORE
     // the weight gradients that have a single whole-tensor contribution instead of reading the zeros back and adding (200 MB of reads per step):
     // 0 + x == x exactly, so the result is bit-identical.  A second backward before the next zero_grads (one pass per modality) accumulates.
+    // deferred weight gradients of the plan-recognition transformer (16-bit fused path): jobs collected by tr_wgrad_add, one launch in tr_wgrads_flush
+    T *trb_c[2] = {nullptr, nullptr}, *trb_a[2] = {nullptr, nullptr}, *trb_d[2] = {nullptr, nullptr}, *trb_b[2] = {nullptr, nullptr};
+    LinBwdBatch tr_wjobs{};
+    int tr_wblocks = 0;
+    void tr_wgrad_add(const T* dY, const T* X, const LinW& L) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            LinBwdJob& J = tr_wjobs.j[tr_wjobs.n++];
+            J.dY = dY; J.X = X; J.dW = L.dW; J.db = L.db; J.ldx = L.K; J.lddw = L.K; J.N = L.N; J.K = L.K; J.nx = cdiv(L.N, 64); J.blk0 = tr_wblocks; J.part = nullptr;
+            tr_wblocks += J.nx * cdiv(L.K, 128);
+        }
+    }
+    void tr_wgrads_flush(int M) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (tr_wjobs.n == 0) return;
+            const int chunk = 256, nz = cdiv(M, chunk);
+            tr_wjobs.M = M; tr_wjobs.store = 0; tr_wjobs.mchunk = chunk;
+            // slabs [nz][N][K] per job out of the convolution slab arena (free here: the encoders' backward has not started), summed by an unpack launch
+            UnpackBatch ub{};
+            int64_t cur = 0; int ublocks = 0;
+            for (int i = 0; i < tr_wjobs.n; ++i) {
+                LinBwdJob& J = tr_wjobs.j[i];
+                const int64_t need = (int64_t)nz * J.N * J.K;
+                if (part_cur + cur + need > this->partcap) { J.part = nullptr; continue; }      // no room: this job adds with atomics
+                J.part = this->part + part_cur + cur; cur += need;
+                UnpackJob& U = ub.j[ub.n++];
+                U.part = J.part; U.grad = J.dW; U.slab = (long long)J.N * J.K; U.nsplit = nz; U.O = J.N; U.I = J.K; U.KH = U.KW = 1; U.nhwc = 0; U.blk0 = ublocks; U.ysplit = 1;
+                ublocks += cdiv(J.N * J.K, 1024);
+            }
+            hipLaunchKernelGGL(lin_bwd_smallm_batched_kernel, dim3(tr_wblocks, nz), dim3(256), 0, st, tr_wjobs);
+            if (ub.n > 0) hipLaunchKernelGGL(unpack_conv_wgrad_batched_kernel, dim3(ublocks, 1), dim3(256), 0, st, ub);
+            tr_wjobs.n = 0; tr_wblocks = 0;
+        }
+    }
     float* dparts = nullptr;                // fused FFN backward: the four hidden-quarter partials of the gradient entering norm1
     bool grads_fresh = false;
     int wacc() const { return grads_fresh ? 0 : 1; }
@@ -2054,16 +2087,32 @@ struct Engine : IEngine {
                 const bool bc = ln_bwd_can_bcast && l == 1;
                 bool ffn_fused = false;
                 if constexpr (std::is_same<T, h16_t>::value) ffn_fused = tr_fused_mode && S <= 32;
+                // 16-bit fused path: every incoming gradient of the layer's four Linear layers stays in its own buffer, and the eight weight / bias
+                // gradients of both layers run as ONE row-split launch after the loop (tr_wgrads_flush) instead of 16 transposes + GEMMs
+                T *b_c = dt_c, *b_a = dt_a, *b_d = dt_c, *b_b = dt_b;
+                bool defer_w = false;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    static const int defer_sw = HULC_SWITCH("HULC_TR_WGRAD_BATCH", 1);
+                    defer_w = ffn_fused && defer_sw;
+                    if (defer_w) {
+                        if (!trb_c[l]) { trb_c[l] = alloc<T>((int64_t)maxN * EMB); trb_a[l] = alloc<T>((int64_t)maxN * FF); trb_d[l] = alloc<T>((int64_t)maxN * EMB); trb_b[l] = alloc<T>((int64_t)maxN * 3 * EMB); }
+                        b_c = trb_c[l]; b_a = trb_a[l]; b_d = trb_d[l]; b_b = trb_b[l];
+                    }
+                }
                 if constexpr (std::is_same<T, h16_t>::value) {
                     if (ffn_fused) {      // LN2 backward + both data-gradient GEMMs of the FFN: one launch (tr_fused.h); the weight gradients read what it wrote
                         if (!dparts) dparts = alloc<float>(4ll * maxN * EMB);
                         TrFfnBwdP q{};
                         q.dx = bc ? dxm : dx; q.bcast = bc ? 1 : 0; q.bdiv = (float)S; q.y2 = y2[l]; q.st2 = st2[l]; q.n2g = tr_n2g[l]; q.dg2 = d_tr_n2g[l]; q.db2 = d_tr_n2b[l];
-                        q.W2t = tr_l2[l].Wt; q.W1t = tr_l1[l].Wt; q.hff = hff[l]; q.dt_c = dt_c; q.dt_a = dt_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
+                        q.W2t = tr_l2[l].Wt; q.W1t = tr_l1[l].Wt; q.hff = hff[l]; q.dt_c = b_c; q.dt_a = b_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
                         q.seed_y = site_seed(4 + 4 * l);
                         launch_tr_ffn_bwd(st, q);
-                        lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
-                        lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
+                        if (defer_w) {
+                            tr_wgrad_add(b_c, hff[l], tr_l2[l]); tr_wgrad_add(b_a, x1t[l], tr_l1[l]);
+                        } else {
+                            lin_wgrad(dt_c, hff[l], FF, N, EMB, FF, tr_l2[l].dW, FF, tr_l2[l].db);
+                            lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
+                        }
                     }
                 }
                 if (!ffn_fused) {
@@ -2075,22 +2124,25 @@ struct Engine : IEngine {
                 { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
                 }
                 // LN1 (after the fused FFN backward its incoming gradient is the sum of the four hidden-quarter partials)
-                ln_bwd(ffn_fused ? dparts : dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, dt_c, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l), 0, 1.f,
+                ln_bwd(ffn_fused ? dparts : dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, b_d, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l), 0, 1.f,
                        ffn_fused ? 4 : 1, (long long)N * EMB);
-                lin_wgrad(dt_c, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
-                { EpiP ep = epi(dt_a, false); lin_dgrad(dt_c, N, tr_out[l], ep, dense_out(EMB)); }
+                if (defer_w) tr_wgrad_add(b_d, ao[l], tr_out[l]);
+                else lin_wgrad(b_d, ao[l], EMB, N, EMB, EMB, tr_out[l].dW, EMB, tr_out[l].db);
+                { EpiP ep = epi(dt_a, false); lin_dgrad(b_d, N, tr_out[l], ep, dense_out(EMB)); }
                 static const bool att32 = (HULC_SWITCH("HULC_ATT32", 1) != 0) && !std::is_same<T, float>::value;
-                if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
-                else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                if (S <= 32 && att32) hipLaunchKernelGGL((attention_bwd32_kernel<T>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, b_b, dp, site_seed(1 + 4 * l));
+                else if (S <= 32) hipLaunchKernelGGL((attention_bwd_kernel<T, 32>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, b_b, dp, site_seed(1 + 4 * l));
                 else if (att32) {
                     static bool attr = false;
                     if (!attr) { hipFuncSetAttribute((const void*)attention_bwd64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_BWD64_LDS); attr = true; }
-                    hipLaunchKernelGGL((attention_bwd64_kernel<T>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
+                    hipLaunchKernelGGL((attention_bwd64_kernel<T>), dim3(B * NH), dim3(256), ATT_BWD64_LDS, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, b_b, dp, site_seed(1 + 4 * l));
                 }
-                else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, dt_b, dp, site_seed(1 + 4 * l));
-                lin_wgrad(dt_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
-                { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_b, N, tr_in[l], ep, dense_out(EMB)); }
+                else hipLaunchKernelGGL((attention_bwd_kernel<T, 64>), dim3(B * NH), dim3(64), 0, st, qkv[l], Pat[l], dt_a, B, S, EMB, NH, b_b, dp, site_seed(1 + 4 * l));
+                if (defer_w) tr_wgrad_add(b_b, xt[l], tr_in[l]);
+                else lin_wgrad(b_b, xt[l], EMB, N, 3 * EMB, EMB, tr_in[l].dW, EMB, tr_in[l].db);
+                { EpiP ep = epi(dx, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(b_b, N, tr_in[l], ep, dense_out(EMB)); }
             }
+            tr_wgrads_flush(N);
             // x0 = dropout(emb + pos): d(emb) += mask*dx ; dpos += sum_b
             {
                 const int bchunk = std::is_same<T, float>::value ? B : 8;       // fp32 (parity) engine: one deterministic pass over the windows

@@ -245,6 +245,13 @@ __global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
     }
     for (; z < z1; ++z) add4(s0, *reinterpret_cast<const float4*>(part + (long long)z * slab + idx));
     const float v[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+    if (gy == 1 && !J.nhwc) {            // this thread is the only writer of its four elements: plain read-add-write
+        float4* g4 = reinterpret_cast<float4*>(J.grad + idx);
+        float4 o = *g4;
+        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+        *g4 = o;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         int dst = idx + e;
