@@ -771,11 +771,28 @@ struct Engine : IEngine {
                             unpack_blocks += cdiv(L.N * L.K, 1024); part_cur += need;
                         }
                     }
+                // + the gripper camera's first Linear (3136 -> 128, dY = d_g0 which the launch above just wrote): its slabs are in the packed (NHWC)
+                // column order of a3 and the unpack launch lands them in the torch layout (the conv weights' permutation with a 7 x 7 "kernel")
+                tail_fc7_done = false;
+                {
+                    const LinW& L = encG.fc7;
+                    const int64_t need = (int64_t)nz * L.N * L.K;
+                    if (slab_ok && L.N == 128 && L.K == 3136 && unpack_jobs.n < 12 && part_cur + need <= this->partcap) {
+                        LinBwdJob& J = bt.j[bt.n++];
+                        J.dY = d_g0; J.X = aG.a3; J.dW = nullptr; J.db = L.db; J.ldx = L.K; J.lddw = L.K; J.N = L.N; J.K = L.K; J.nx = cdiv(L.N, 64); J.blk0 = blk;
+                        blk += J.nx * cdiv(L.K, 128);
+                        J.part = this->part + part_cur;
+                        UnpackJob& U = unpack_jobs.j[unpack_jobs.n++];
+                        U.part = J.part; U.grad = L.dW; U.slab = (long long)L.N * L.K; U.nsplit = nz; U.O = L.N; U.I = 64; U.KH = U.KW = 7; U.nhwc = 1; U.blk0 = unpack_blocks; U.ysplit = 1;
+                        unpack_blocks += cdiv(L.N * L.K, 1024); part_cur += need;
+                        tail_fc7_done = true;
+                    }
+                }
                 hipLaunchKernelGGL(lin_bwd_smallm_batched_kernel, dim3(blk, nz), dim3(256), 0, st, bt);
             }
         }
     }
-    bool tail_wgrad_done = false;
+    bool tail_wgrad_done = false, tail_fc7_done = false;
     Conv1Src wgrad_src;                       // conv1 only: set by enc_bwd before conv_wgrad(e.c1, ...)
     // 16-bit engines: the slab -> gradient reductions of the encoders' convolutions are collected and run as ONE launch (flush_unpacks) after
     // both encoders' backward instead of one ~6-20 us launch behind each of the six weight-gradient kernels
@@ -909,8 +926,10 @@ struct Engine : IEngine {
             if (!wdone) lin_wgrad(d_f1, a.g0, 128, Nf, 512, 128, e.fc1.dW, 128, e.fc1.db);
             { EpiP ep = epi(dact3, false); ep.mask = a.a3; lin_dgrad(d_g0, Nf, e.fc7, ep, dense_out(3136)); }
             // dW7 in packed (NHWC) column order -> temp, then permute-accumulate into the torch-layout grad
-            lin_wgrad(d_g0, a.a3, 3136, Nf, 128, 3136, dw7_tmp, 3136, e.fc7.db);
-            hipLaunchKernelGGL((permute_cols_kernel<float, float>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, dw7_tmp, e.fc7.dW, 128, 64, 49, 1, 1);
+            if (!(wdone && tail_fc7_done)) {
+                lin_wgrad(d_g0, a.a3, 3136, Nf, 128, 3136, dw7_tmp, 3136, e.fc7.db);
+                hipLaunchKernelGGL((permute_cols_kernel<float, float>), dim3(cdiv(128 * 3136, 256)), dim3(256), 0, st, dw7_tmp, e.fc7.dW, 128, 64, 49, 1, 1);
+            }
         }
         conv_wgrad(e.c3, dact3, a.a2, g3, false);
         conv_dgrad(e.c3, dact3, g3, dact2, a.a2, a.m2bits);

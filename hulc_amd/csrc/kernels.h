@@ -261,7 +261,8 @@ __global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
             int kh = t % J.KH, o = t / J.KH;
             dst = ((o * J.I + ci) * J.KH + kh) * J.KW + kw;
         }
-        unsafeAtomicAdd(J.grad + dst, v[e]);
+        if (gy == 1) J.grad[dst] += v[e];          // only writer of the element
+        else unsafeAtomicAdd(J.grad + dst, v[e]);
     }
 }
 
