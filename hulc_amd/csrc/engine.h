@@ -2011,11 +2011,27 @@ struct Engine : IEngine {
             const long long lastBH = (long long)(S - 1) * BH;          // the BPTT's first step (t = S-1) needs no multiplication: written by the GEMM that produces dH
             { EpiP ep = epi(dH1, false); ep.out2 = dZ1 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H1 + lastBH;
               gemm(dense<T>(dheads, SB, NHEAD), dense<T>(wheadsT, HID, NHEAD), dense_out(HID), ep, SB, HID, NHEAD); }
-            lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
             {
                 const HeadPack hp = head_pack();
                 const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
-                hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, dwheads_tmp, dbheads_tmp, HID);
+                bool slabs = false;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    // row-split weight gradient (see tr_wgrads_flush): one slab per 256 rows in the (idle) convolution slab arena, summed by the unpack launch
+                    const int nz = cdiv(SB, 256);
+                    if (SB > 64 && part_cur + (int64_t)nz * NHEAD * HID <= this->partcap) {
+                        LinBwdBatch bt{}; bt.M = SB; bt.store = 0; bt.mchunk = 256; bt.n = 1;
+                        LinBwdJob& J = bt.j[0];
+                        J.dY = dheads; J.X = H1; J.dW = nullptr; J.db = dbheads_tmp; J.ldx = HID; J.lddw = HID; J.N = NHEAD; J.K = HID; J.nx = cdiv(NHEAD, 64); J.blk0 = 0;
+                        J.part = this->part + part_cur;
+                        hipLaunchKernelGGL(lin_bwd_smallm_batched_kernel, dim3(J.nx * cdiv(HID, 128), nz), dim3(256), 0, st, bt);
+                        hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, J.part, dbheads_tmp, HID, nz, (long long)NHEAD * HID);
+                        slabs = true;
+                    }
+                }
+                if (!slabs) {
+                    lin_wgrad(dheads, H1, HID, SB, NHEAD, HID, dwheads_tmp, HID, dbheads_tmp);
+                    hipLaunchKernelGGL(unpack_heads_grad_kernel, dim3(cdiv((long long)rows * HID, 256)), dim3(256), 0, st, hp, dwheads_tmp, dbheads_tmp, HID, 1, 0ll);
+                }
             }
             // layer 1 BPTT
             rnn_bwd(dH1, H1, dZ1, whh1, B, S, 1, false, false, true);

@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(ConvPackBatch d, int b
     wheads[idx] = from_f<T>(hp.w[i][(long long)r * HID + k]);
     if (k == 0) bheads[idx / HID] = hp.b[i][r];
 }
-__global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ dw, const float* __restrict__ db, int HID) {
+__global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ dw, const float* __restrict__ db, int HID, int nslab = 1, long long slab = 0) {
     const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)total_rows * HID) return;
@@ -615,7 +615,9 @@ __global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ 
     const int k = (int)(idx % HID);
     int i = 0;
     while (i < 3 && r >= hp.rows[i]) { r -= hp.rows[i]; ++i; }
-    hp.dw[i][(long long)r * HID + k] += dw[idx];
+    float a = dw[idx];
+    for (int z = 1; z < nslab; ++z) a += dw[(long long)z * slab + idx];      // row-split weight gradient: one slab per row chunk
+    hp.dw[i][(long long)r * HID + k] += a;
     if (k == 0) hp.db[i][r] += db[idx / HID];
 }
 
