@@ -716,6 +716,12 @@ struct Engine : IEngine {
         { EpiP ep = epi(a.f2, true); lin_fwd(a.f1, 512, Nf, e.fc2, ep, 64); }
         ln_fwd(a.f2, 64, Nf, 64, e.lng, e.lnb, emb + col0, EMB, nullptr, 0, a.lnst);
     }
+    // enc_tail.h is written for the reference's tail widths (128 -> 512 -> 64, vision_network.py:46-52 / vision_network_gripper.py:18-27) and EMB = 2 x 64
+    bool enc_tail_fusable() const {
+        if constexpr (!std::is_same<T, h16_t>::value) return false;
+        auto ok = [](const EncW& e) { return e.fc1.K == 128 && e.fc1.N == 512 && e.fc2.K == 512 && e.fc2.N == 64; };
+        return ok(encS) && ok(encG) && EMB == 128;
+    }
     // fc1 + ReLU, fc2 and the LayerNorm of both encoders in one launch (enc_tail.h)
     void enc_tail_fwd_both(int Nf) {
         if constexpr (std::is_same<T, h16_t>::value) {
@@ -1016,7 +1022,7 @@ struct Engine : IEngine {
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
         {
             const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
-            constexpr bool tail_fused = std::is_same<T, h16_t>::value;
+            const bool tail_fused = enc_tail_fusable();
             enc_fwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr, tail_fused);
             STAGE("enc_static_fwd");
             enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr, tail_fused);
@@ -2219,7 +2225,7 @@ struct Engine : IEngine {
         // ---- encoders backward
         {
             const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
-            constexpr bool tail_fused = std::is_same<T, h16_t>::value;
+            const bool tail_fused = enc_tail_fusable();
             if (tail_fused) enc_tail_bwd_both(N);
             enc_bwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr, tail_fused);
             STAGE("enc_static_bwd");
