@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
         const int ih0 = oh0 * 4;
         const int rows = min(XR, IH - ih0);
         __syncthreads();
-        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64, (dbg & 64) != 0);
+        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
         __syncthreads();
         const int RBe = min(R, OH - oh0);
         const int npix = RBe * OW;

@@ -419,7 +419,7 @@ struct Step256 {
     DEVI explicit Step256(int n_) : n(n_), dq(256 / n_), dr(256 % n_) {}
     DEVI void adv(RowCol& p) const { p.c += dr; p.r += dq; if (p.c >= n) { p.c -= n; ++p.r; } }
 };
-DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw, const bool nt = false) {
+DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const int W4 = IW >> 2;                                           // 4-pixel groups per row
     const Step256 sq(W4);
@@ -442,9 +442,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
                 const int c = (int)(((float)e + 0.5f) * inv_per), rem = e - c * per;
                 const int r = (int)(((float)rem + 0.5f) * inv_w4), q4 = rem - r * W4;
                 pk[u] = (c << 20) | (r << 8) | q4;
-                const float* gp = src0 + ((long long)c * IH + r) * IW + q4 * 4;
-                if (nt) { typedef float f32x4nt __attribute__((ext_vector_type(4))); const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(gp)); v[u] = make_float4(a[0], a[1], a[2], a[3]); }
-                else v[u] = *reinterpret_cast<const float4*>(gp);
+                v[u] = *reinterpret_cast<const float4*>(src0 + ((long long)c * IH + r) * IW + q4 * 4);
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
