@@ -341,3 +341,38 @@ def test_512_frames_against_the_numpy_oracle():
                   [(round(e, 4), n) for e, n in topq[:8]])
             assert topq[0][0] < (3.5e-2 if dtype == "fp16" else 5e-2), topq[:5]
         print(f"[512 frames, {dtype}] worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.parametrize("Bb,Ss", [(9, 32), (11, 30), (17, 16)])
+def test_row_split_weight_gradients_at_ragged_row_counts(Bb, Ss):
+    """The token-major Linear layers (encoder tails fc1 / fc2 / fc7, the transformer's eight Linear layers, the decoder heads) take their weight
+    gradients from the row-split slab launches (lin_bwd_smallm_batched_kernel over grid.y + the unpack launch): B*S = 288 / 330 / 272 rows are
+    two 256-row chunks whose second one ends inside a 64-row tile (32 / 10 / 16 rows).  bf16 engine against the fp32 (parity) engine on the
+    same batch, per tensor; the 2048-row benchmark shape only ever exercises whole chunks."""
+    dev = torch.device("cuda:0")
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    mb = synth_batch(Bb, Ss, dev, seed=5)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    mb["plan_idx"] = torch.randint(0, 32, (Bb, 32), device=dev, generator=g, dtype=torch.int32)
+    grads = {}
+    for dtype in ("fp32", "bf16"):
+        eng = StepEngine(dims, Bb, Ss, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=3)
+        eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+        _, grads[dtype] = _step(eng, mb)
+        eng.close()
+    lay, _ = spec.layout(dims)
+    row_split = ("fc1.0.", "fc2.", "conv_model.7.", "self_attn.in_proj", "self_attn.out_proj", ".linear1.", ".linear2.", "mean_fc", "log_scale_fc", "prob_fc", "gripper_fc")
+    worst = {}
+    for name, (off, shape) in lay.items():
+        if not any(s in name for s in row_split) or "rgb_static_encoder.conv_model.7" in name:
+            continue
+        n = int(np.prod(shape))
+        a, b = grads["bf16"][off:off + n].double(), grads["fp32"][off:off + n].double()
+        assert torch.isfinite(a).all(), name
+        worst[name] = ((a - b).norm() / (b.norm() + 1e-30)).item()
+    assert len(worst) >= 30, sorted(worst)
+    print(f"[row split, B*S = {Bb * Ss}] worst tensors:", [(k.split('.')[-3] + '.' + k.split('.')[-2] + '.' + k.split('.')[-1], round(v, 4)) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:4]], "median", round(float(np.median(list(worst.values()))), 4))
+    bad = {k: v for k, v in worst.items() if v > 0.15}
+    assert not bad, bad
+    # a dropped or doubled row chunk would show up as an O(1) error on every one of these tensors; measured: median 1e-2, worst 8e-2 (the static fc1 weight behind the spatial softmax)
+    assert np.median(list(worst.values())) < 0.03, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
