@@ -228,6 +228,15 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
     const int prow = a >> 2;
     const int ccol = (a & 3) * 8;
     const int nt0 = q * C::NTW;
+    // per n-tile LDS offset of its tap / channel group (wave-uniform)
+    int toff[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int nt = __builtin_amdgcn_readfirstlane(nt0) + j;
+        const int tap = nt / C::CGN, cg = nt % C::CGN;
+        const int kh = tap / KW, kw = tap % KW;
+        toff[j] = (kh * IW + kw) * C::XS + cg * 32;
+    }
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     u32x4_t pf[PF];
@@ -278,6 +287,19 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
         // e >= 4 (second tr-read): run 2 + (g>>1), pixel (g&1)*4 + e - 4.  A 32-lane half of one read then covers 8 consecutive
         // pixels of ONE run -> conflict-free with the pitches of WgradCfg.
         const int px = (g & 1) * 4 + prow;
+        // run u = u0 + hh * 2 + (g >> 1) of the band = (row r, 8-pixel run uo of the row).  Its dY pixel is 8 u (OWp = 8 U); its X pixel offset follows
+        // (r, uo) by adds: + step4 per step, + wrapd whenever uo passes U.  (A runtime u / U and u % U per run and step were ~100 VALU instructions
+        // next to the step's 18 MFMAs: conv2 / conv3 weight gradients 372 -> 340 us per step.)
+        const int q4 = 4 / U, r4 = 4 - q4 * U;
+        const int step4 = (q4 * S * IW + r4 * 8 * S) * C::XS, wrapd = (S * IW - U * 8 * S) * C::XS;
+        int uo[2], pbv[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int u = hh * 2 + (g >> 1), r = u / U;
+            uo[hh] = u - r * U;
+            pbv[hh] = ((r * S) * IW + (uo[hh] * 8 + px) * S) * C::XS + ccol;
+        }
+        const int abase = px * C::DYS + ccol + h * CTH * 32, pb_idle = (px * S) * C::XS + ccol;
 #pragma unroll 1
         for (int u0 = 0; u0 < units; u0 += 4) {
             lds_char* ab[2];
@@ -286,18 +308,12 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
             for (int hh = 0; hh < 2; ++hh) {
                 const int u = u0 + hh * 2 + (g >> 1);
                 const bool valid = u < units;
-                const int r = valid ? u / U : 0, ow0 = valid ? (u % U) * 8 : 0;
-                const int pixA = valid ? r * OWp + ow0 : R * OWp;      // idle runs read the permanent zero pixels
-                ab[hh] = dyimg + (pixA + px) * C::DYS + ccol + h * CTH * 32;
-                pb[hh] = ((r * S) * IW + (ow0 + px) * S) * C::XS + ccol;
+                ab[hh] = dyimg + (valid ? u * 8 : R * OWp) * C::DYS + abase;      // idle runs read the permanent zero pixels
+                pb[hh] = valid ? pbv[hh] : pb_idle;
+                pbv[hh] += step4; uo[hh] += r4;
+                if (uo[hh] >= U) { uo[hh] -= U; pbv[hh] += wrapd; }
             }
-            auto bfrag = [&](int j) {
-                const int nt = nt0 + j;
-                const int tap = nt / C::CGN, cg = nt % C::CGN;
-                const int kh = tap / KW, kw = tap % KW;
-                const int toff = (kh * IW + kw) * C::XS + cg * 32;
-                return tr_read8(ximg + pb[0] + toff, ximg + pb[1] + toff);
-            };
+            auto bfrag = [&](int j) { return tr_read8(ximg + pb[0] + toff[j], ximg + pb[1] + toff[j]); };
             // B fragments run D n-tiles ahead of their MFMAs; A fragments first
             constexpr int D = 3;
             h16x8_t ring[D];
@@ -772,11 +788,20 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
         item = frame * nbands + band;
         if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
         const int units = R * U;
+        // run u = u0 + g -> (row ur, run uo of the row) advanced by adds (8 runs per step): a runtime division per step stood next to 6 MFMAs
+        int joff[3];                                   // per n-tile: (channel, kernel row) of this lane's B rows + its column half
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int nt = nt0 + j; joff[j] = ((nt >> 2) * XR + (nt & 3) * 2 + (q >> 1)) * XRS + (q & 1) * 8; }
+        const int q8 = 8 / U, r8 = 8 - q8 * U;
+        int ur, uo;
+        { const int u = uh * 4 + g; ur = u / U; uo = u - ur * U; }
 #pragma unroll 1
         for (int u0 = uh * 4; u0 < units; u0 += 8) {
             const int u = u0 + g;
             const bool valid = u < units;
-            const int r = valid ? u / U : 0, ow0 = valid ? (u - (u / U) * U) * 8 : 0;
+            const int r = valid ? ur : 0, ow0 = valid ? uo * 8 : 0;
+            ur += q8; uo += r8;
+            if (uo >= U) { uo -= U; ++ur; }
             const int pixA = valid ? r * OWp + ow0 : R * OWp;
             lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
             h16x8_t af[2];
@@ -784,9 +809,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
             for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int nt = nt0 + j;
-                const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
-                lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
+                lds_char* bbase = ximg + joff[j] + (r * C::S) * XRS + (ow0 + prow) * C::S * 2;
                 const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
@@ -977,11 +1000,20 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
         item = frame * nbands + band;
         if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
         const int units = R * U;
+        // run u = u0 + g -> (row ur, run uo of the row) advanced by adds (8 runs per step): a runtime division per step stood next to 6 MFMAs
+        int joff[3];                                   // per n-tile: (channel, kernel row) of this lane's B rows + its column half
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int nt = nt0 + j; joff[j] = ((nt >> 2) * XR + (nt & 3) * 2 + (q >> 1)) * XRS + (q & 1) * 8; }
+        const int q8 = 8 / U, r8 = 8 - q8 * U;
+        int ur, uo;
+        { const int u = uh * 4 + g; ur = u / U; uo = u - ur * U; }
 #pragma unroll 1
         for (int u0 = uh * 4; u0 < units; u0 += 8) {
             const int u = u0 + g;
             const bool valid = u < units;
-            const int r = valid ? u / U : 0, ow0 = valid ? (u - (u / U) * U) * 8 : 0;
+            const int r = valid ? ur : 0, ow0 = valid ? uo * 8 : 0;
+            ur += q8; uo += r8;
+            if (uo >= U) { uo -= U; ++ur; }
             const int pixA = valid ? r * OWp + ow0 : R * OWp;
             lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
             h16x8_t af[2];
@@ -989,9 +1021,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
             for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int nt = nt0 + j;
-                const int ch = nt >> 2, kh = (nt & 3) * 2 + (q >> 1);
-                lds_char* bbase = ximg + (ch * XR + r * C::S + kh) * XRS + ((ow0 + prow) * C::S + (q & 1) * 4) * 2;
+                lds_char* bbase = ximg + joff[j] + (r * C::S) * XRS + (ow0 + prow) * C::S * 2;
                 const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
