@@ -490,12 +490,15 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + (ct * 16 + li) * 192 + ks * 32 + g * 8);
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
+    // ^ A-operand row m of tile ct carries output channel (m >> 2) * 8 + ct * 4 + (m & 3): with the 16x16 C/D map (row = 4 g + r) lane group g then owns
+    //   the 8 CONSECUTIVE channels 8 g .. 8 g + 7 of its pixel — one 16-byte store per lane and 1 KB contiguous per wave store (two 8-byte stores to
+    //   interleaved 32-byte halves of every pixel before)
     // (c, kh) row of this lane group for each k-step
     int rowsel[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
-    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 4), *reinterpret_cast<const float4*>(bias + 16 + g * 4)};
+    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
     const int nitems = Nf * nbands;
     // frame-wise (fw, experiment knob HULC_C1_FW=1): a workgroup walks the bands of one frame back to back so that the rows two bands share come
     // from L2 — what cut conv1's weight gradient by 25 % measured 0.4 % SLOWER here (4 resident workgroups per CU already re-read those rows
@@ -552,18 +555,18 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
                 const long long opix = ((long long)f * OH + oh0 + rr[mm]) * OW + oww[mm];
                 const long long obase = opix * 32;
                 unsigned bits = 0;                                       // ReLU mask of this lane's 8 channels (what conv2's dgrad needs of a1)
+                unsigned ow[4];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const int cn0 = ct * 16 + g * 4;
+                    const int cn0 = g * 8 + ct * 4;
                     const float v0 = fmaxf(acc[mm][ct][0] + bb[ct].x, 0.f), v1 = fmaxf(acc[mm][ct][1] + bb[ct].y, 0.f);
                     const float v2 = fmaxf(acc[mm][ct][2] + bb[ct].z, 0.f), v3 = fmaxf(acc[mm][ct][3] + bb[ct].w, 0.f);
-                    uint2 o;
-                    o.x = pack2h(v0, v1);
-                    o.y = pack2h(v2, v3);
-                    *reinterpret_cast<uint2*>(out + obase + cn0) = o;
-                    const unsigned nz = ((o.x & 0xffffu) ? 1u : 0u) | ((o.x >> 16) ? 2u : 0u) | ((o.y & 0xffffu) ? 4u : 0u) | ((o.y >> 16) ? 8u : 0u);
+                    const unsigned ox = pack2h(v0, v1), oy = pack2h(v2, v3);
+                    ow[ct * 2] = ox; ow[ct * 2 + 1] = oy;
+                    const unsigned nz = ((ox & 0xffffu) ? 1u : 0u) | ((ox >> 16) ? 2u : 0u) | ((oy & 0xffffu) ? 4u : 0u) | ((oy >> 16) ? 8u : 0u);
                     bits |= nz << cn0;
                 }
+                *reinterpret_cast<uint4*>(out + obase + g * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 if (maskbits) {                                          // the four lanes of a pixel (g = 0..3) are all active here: OR their bytes
                     bits |= __shfl_xor(bits, 16);
                     bits |= __shfl_xor(bits, 32);
