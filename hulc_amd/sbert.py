@@ -59,11 +59,11 @@ def init_params(cfg: SBertConfig, seed: int = 0) -> Dict[str, np.ndarray]:
     out = {}
     for n, shape in param_table(cfg):
         if "LayerNorm.weight" in n:
-            out[n] = (1.0 + 0.1 * prng.normal("sbert." + n, shape, seed)).astype(np.float32)
+            out[n] = (1.0 + 0.1 * prng.normal("sbert." + n, shape, seed=seed)).astype(np.float32)
         elif n.endswith(".bias"):
-            out[n] = (0.02 * prng.normal("sbert." + n, shape, seed)).astype(np.float32)
+            out[n] = (0.02 * prng.normal("sbert." + n, shape, seed=seed)).astype(np.float32)
         else:
-            out[n] = (0.06 * prng.normal("sbert." + n, shape, seed)).astype(np.float32)
+            out[n] = (0.06 * prng.normal("sbert." + n, shape, seed=seed)).astype(np.float32)
     return out
 
 
