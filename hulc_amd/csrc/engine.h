@@ -806,7 +806,8 @@ struct Engine : IEngine {
     int64_t part_cur = 0;
     int unpack_blocks = 0;
     void flush_unpacks() {
-        if (unpack_jobs.n > 0) hipLaunchKernelGGL(unpack_conv_wgrad_batched_kernel, dim3(unpack_blocks, 16), dim3(256), 0, st, unpack_jobs);
+        static const int yparts = HULC_SWITCH("HULC_UNPACK_YB", 8);      // same-box: 4 / 8 / 16 / 32 parts = 60 / 55 / 59 / 86 us (with 8 slab quads in flight per thread)
+        if (unpack_jobs.n > 0) hipLaunchKernelGGL(unpack_conv_wgrad_batched_kernel, dim3(unpack_blocks, yparts), dim3(256), 0, st, unpack_jobs);
         unpack_jobs.n = 0; part_cur = 0; unpack_blocks = 0;
     }
     void conv_wgrad(const ConvW& c, const T* dy, const void* xin, const ConvGeom& g, bool conv1) {

@@ -196,6 +196,13 @@ __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ part, int nsp
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     int z = z0;
+    for (; z + 7 < z1; z += 8) {                    // eight slab quads in flight per thread (four were one L2-miss latency per 4 slabs: 16 slabs = 4 rounds)
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(part + (long long)(z + u) * slab + idx);
+        add4(s0, t[0]); add4(s1, t[1]); add4(s2, t[2]); add4(s3, t[3]);
+        add4(s0, t[4]); add4(s1, t[5]); add4(s2, t[6]); add4(s3, t[7]);
+    }
     for (; z + 3 < z1; z += 4) {
         const float4 a = *reinterpret_cast<const float4*>(part + (long long)z * slab + idx), b = *reinterpret_cast<const float4*>(part + (long long)(z + 1) * slab + idx);
         const float4 c = *reinterpret_cast<const float4*>(part + (long long)(z + 2) * slab + idx), d = *reinterpret_cast<const float4*>(part + (long long)(z + 3) * slab + idx);
@@ -238,6 +245,13 @@ __global__ void unpack_conv_wgrad_batched_kernel(UnpackBatch ub) {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
     int z = z0;
+    for (; z + 7 < z1; z += 8) {                    // eight slab quads in flight per thread (four were one L2-miss latency per 4 slabs: 16 slabs = 4 rounds)
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(part + (long long)(z + u) * slab + idx);
+        add4(s0, t[0]); add4(s1, t[1]); add4(s2, t[2]); add4(s3, t[3]);
+        add4(s0, t[4]); add4(s1, t[5]); add4(s2, t[6]); add4(s3, t[7]);
+    }
     for (; z + 3 < z1; z += 4) {
         const float4 a = *reinterpret_cast<const float4*>(part + (long long)z * slab + idx), b = *reinterpret_cast<const float4*>(part + (long long)(z + 1) * slab + idx);
         const float4 c = *reinterpret_cast<const float4*>(part + (long long)(z + 2) * slab + idx), d = *reinterpret_cast<const float4*>(part + (long long)(z + 3) * slab + idx);
