@@ -527,7 +527,7 @@ struct Engine : IEngine {
             static const bool fused = HULC_SWITCH("HULC_LN_FUSED", 1) != 0;
             if (fused || bcast_rows > 0 || dy_parts > 1) {
                 const int rpb = rows >= 1024 ? 16 : 4;
-                hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
+                hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T>), dim3(cdiv(rows, rpb)), dim3(rpb == 16 ? 1024 : 256), 0, st, dy, lddy, x, ldx, stats, g, rows, n, dxf, ldd, acc, dxt, ldt,
                                    drop_p, drop_seed, rpb, dg, db, bcast_rows, bcast_div, dy_parts, dy_part_stride);
                 return;
             }

@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 // reduced over the 4 waves in LDS and added with one fp32 atomic per column per block.  Replaces layernorm_bwd_kernel +
 // layernorm_param_grad_kernel (+ dropout_apply_kernel in the transformer): 7 + 7 + 4 launches of ~5 us per step become 7.
 template <typename T>
-__global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+__global__ void __launch_bounds__(1024) layernorm_bwd_fused_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                                   long long ldx, const float* __restrict__ stats, const float* __restrict__ g,
                                                                   int rows, int n, float* __restrict__ dx_f32, long long ldd, int accumulate,
                                                                   T* __restrict__ dx_t, long long ldt, float drop_p, unsigned long long seed,
@@ -705,12 +705,13 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
     // dy_parts > 1: the incoming gradient is the sum of dy_parts arrays dy + i * dy_part_stride (the fused FFN backward's four partials)
     // dy_rowdiv > 0: the incoming gradient is a per-WINDOW vector broadcast over the window's dy_rowdiv rows and divided by dy_div
     // (the mean over S in front of plan_recognition.fc: bcast_over_s_kernel's job, read here instead of materialised)
-    __shared__ float red[4][256];
+    __shared__ float red[16][256];          // blockDim.x = 256 (4 waves) or 1024 (16 waves: a row per wave of a 16-row block — the rows' load -> reduce -> store chains run side by side)
+    const int nwv = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     const float g0 = lane < n ? g[lane] : 0.f, g1 = lane + 64 < n ? g[lane + 64] : 0.f;
     float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
-    for (int row = r0 + wave; row < r1; row += 4) {
+    for (int row = r0 + wave; row < r1; row += nwv) {
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
         const float* xr = x + (long long)row * ldx;
         const float* dr = dy + (long long)(dy_rowdiv > 0 ? row / dy_rowdiv : row) * lddy;
@@ -740,7 +741,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_fused_kernel(const float* _
     red[wave][lane] = sg0; red[wave][64 + lane] = sg1; red[wave][128 + lane] = sb0; red[wave][192 + lane] = sb1;
     __syncthreads();
     const int t = threadIdx.x, col = t & 127;
-    if (col < n) unsafeAtomicAdd((t < 128 ? dg : db) + col, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+    if (t < 256 && col < n) {
+        float a = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        for (int w = 4; w < nwv; w += 4) a += (red[w][t] + red[w + 1][t]) + (red[w + 2][t] + red[w + 3][t]);
+        unsafeAtomicAdd((t < 128 ? dg : db) + col, a);
+    }
 }
 // partial sums for dgamma[c] = sum_r dy*xhat and dbeta[c] = sum_r dy over a row chunk (grid.y); part = [2][nsplit][n]
 __global__ void __launch_bounds__(256) layernorm_param_grad_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
