@@ -478,10 +478,12 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 template <int MINW>
 __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias,
                                                            h16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
-                                                           unsigned* __restrict__ maskbits) {
+                                                           unsigned* __restrict__ maskbits, float* __restrict__ zero8a = nullptr, float* __restrict__ zero8b = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* ximg = (lds_char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the step's loss accumulators (8 floats each) are cleared by the forward's FIRST kernel instead of by two 32-byte memsets (~5 us of launch each)
+    if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
     const int g = lane >> 4, li = lane & 15;
     const int XR = (R - 1) * 4 + 8;
     const int XRS = IW * 2 + 16;
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
     }
 }
 static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16_t* W, const float* bias, h16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
-                                    unsigned* maskbits = nullptr) {
+                                    unsigned* maskbits = nullptr, float* zero8a = nullptr, float* zero8b = nullptr) {
     // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
     //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
     auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
@@ -597,8 +599,8 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
         attr_set = true;
     }
     const int items = Nf * nbands;
-    if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
-    else hipLaunchKernelGGL(conv1_fwd_kernel<2>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits);
+    if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
+    else hipLaunchKernelGGL(conv1_fwd_kernel<2>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
 }
 
 }  // namespace HULC_NS

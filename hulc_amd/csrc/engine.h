@@ -670,7 +670,8 @@ struct Engine : IEngine {
             if constexpr (std::is_same<T, h16_t>::value) {
                 const double px = (double)nf * g1.OH * g1.OW;
                 TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)nf * 3 * e.IH * e.IH * (sh.u8 ? 1 : 4) + px * 32 * 2);
-                launch_conv1_fwd(st, sh, e.c1.Wf, e.c1.b32, a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr);
+                launch_conv1_fwd(st, sh, e.c1.Wf, e.c1.b32, a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr, pend_zero[0], pend_zero[1]);
+                pend_zero[0] = pend_zero[1] = nullptr;
             } else {
                 const float* x = conv1_f32(sh, e.gripper, nf, e.IH, foff);
                 Conv1Loader<T> l{x, gh};
@@ -799,6 +800,7 @@ struct Engine : IEngine {
         }
     }
     bool tail_wgrad_done = false, tail_fc7_done = false;
+    float* pend_zero[2] = {nullptr, nullptr};   // loss accumulators the next conv1 forward launch clears (16-bit engines)
     Conv1Src wgrad_src;                       // conv1 only: set by enc_bwd before conv_wgrad(e.c1, ...)
     // 16-bit engines: the slab -> gradient reductions of the encoders' convolutions are collected and run as ONE launch (flush_unpacks) after
     // both encoders' backward instead of one ~6-20 us launch behind each of the six weight-gradient kernels
@@ -1200,9 +1202,14 @@ struct Engine : IEngine {
         const float dp = cfg.dropout_p;
         const int Bm = pair ? pairBv : B;                    // windows per modality: the reference's means (and so the gradient scales) are per modality
         const float* kl_src = nullptr; int kl_n = 0;
-        HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
-        if (pair) HIP_CHECK(hipMemsetAsync(losses2, 0, 8 * sizeof(float), st));
+        if constexpr (std::is_same<T, h16_t>::value) {      // cleared by the first conv1 launch of trunk_fwd (nothing accumulates a loss before the encoders are done)
+            pend_zero[0] = losses; pend_zero[1] = pair ? losses2 : nullptr;
+        } else {
+            HIP_CHECK(hipMemsetAsync(losses, 0, 8 * sizeof(float), st));
+            if (pair) HIP_CHECK(hipMemsetAsync(losses2, 0, 8 * sizeof(float), st));
+        }
         trunk_fwd(b, dp);
+        if (pend_zero[0]) { hulc_set_error("forward: the loss accumulators were not cleared (no conv1 launch took them)"); return 1; }
         if (mcil) {
             if (gru) bigru_fwd(B, S); else birnn_fwd(B, S);
             const int n = PLAN / 2;
