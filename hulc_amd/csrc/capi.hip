@@ -137,6 +137,10 @@ int hulc_sbert_encode(hulc_sbert* ctx, const int32_t* ids, const int32_t* mask, 
     return ctx->encode(ids, mask, B, L, out);
 }
 int hulc_adam_step(hulc_ctx* ctx, float lr, float b1, float b2, float eps, int64_t step, float gs) { return ctx->e->adam(lr, b1, b2, eps, step, gs); }
+int hulc_optimizer_step(hulc_ctx* ctx, const hulc_optim* opt) {
+    if (!ctx || !opt) { hulc_set_error("hulc_optimizer_step: null argument"); return 1; }
+    return ctx->e->optim(*opt);
+}
 int hulc_comm_unique_id(void* out, int64_t cap) {
     if (!out || cap < 128) { hulc_set_error("hulc_comm_unique_id: need a 128-byte buffer"); return 1; }
     if (!GradComm::load_api()) return 1;
@@ -164,6 +168,10 @@ int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes) {
     if (n_collectives) *n_collectives = ctx->e->comm->n_collectives;
     if (bytes) *bytes = ctx->e->comm->bytes_reduced;
     return 0;
+}
+int hulc_comm_timeline(hulc_ctx* ctx, double* out, int32_t cap_buckets, double* backward_us) {
+    if (!ctx || !ctx->e->comm || !out) { hulc_set_error("hulc_comm_timeline: no communicator / null buffer"); return -1; }
+    return ctx->e->comm->timeline(out, cap_buckets, backward_us, ctx->e->st);
 }
 int hulc_allreduce_grads(hulc_ctx* ctx, int32_t bucket_dtype) {
     if (!ctx) { hulc_set_error("hulc_allreduce_grads: null context"); return 1; }
@@ -194,6 +202,13 @@ int hulc_set_dropout(hulc_ctx* ctx, float p) {
 int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value) {
     if (!ctx) { hulc_set_error("hulc_set_option: null context"); return 1; }
     return ctx->e->set_option(name, (long long)value);
+}
+int hulc_get_option(hulc_ctx* ctx, const char* name, int64_t* value) {
+    if (!ctx || !value) { hulc_set_error("hulc_get_option: null argument"); return 1; }
+    long long v = 0;
+    const int rc = ctx->e->get_option(name, &v);
+    *value = (int64_t)v;
+    return rc;
 }
 int hulc_timers_enable(hulc_ctx* ctx, int32_t on, const char* only_class) { ctx->e->set_timing(on != 0, only_class); return 0; }
 int hulc_timers_read(hulc_ctx* ctx, char* json_out, int64_t cap, int32_t reset) { return ctx->e->timers_read(json_out, cap, reset != 0); }
@@ -268,7 +283,7 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
                      int32_t OUTH, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvTileP p{}; p.img = (const h16_t*)img; p.IMH = p.IMW = IMH; p.w = (const h16_t*)w; p.out = (h16_t*)out; p.OUTH = p.OUTW = OUTH;
-    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & 30; p.Nf = Nf;
+    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & (30 | 64 | 128); p.Nf = Nf;
     // modes 7..9 = the production forms: 7 = mode 1 that also EMITS the ReLU bitmask of its output into `mask` (unsigned[Nf][OUTH][OUTW][2]);
     // 8 / 9 = modes 2 / 3 with `mask` = ReLU bitmask words (2 / 1 per output pixel) staged through LDS.  relu bit 5 (32): dynamic work claiming.
     if (mode == 7) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 1; }
@@ -289,7 +304,33 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
         if (!zp) { if (hipMalloc(&zp, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; } hipMemset(zp, 0, 256); }
         p.zeros = (const h16_t*)zp;
     }
-    if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
+    // modes 20 / 21 / 27 / 22 / 28 / 23 / 29: modes 10 .. 19 in the form with two 256-thread workgroups per CU (conv_reg.h, NWV = 4)
+    if (mode == 27) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 21; }
+    if (mode == 28) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 22; }
+    if (mode == 29) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 23; }
+    if (mode == 22 || mode == 23) {
+        static void* zp2 = nullptr;
+        if (!zp2) { if (hipMalloc(&zp2, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; } hipMemset(zp2, 0, 256); }
+        p.zeros = (const h16_t*)zp2;
+    }
+    // modes 30 .. 39: the two-workgroup form with TWO (smaller) band buffers per workgroup
+    if (mode == 37) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 31; }
+    if (mode == 38) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 32; }
+    if (mode == 39) { p.mask = nullptr; p.maskbits = (const unsigned*)mask; mode = 33; }
+    if (mode == 32 || mode == 33) {
+        static void* zp3 = nullptr;
+        if (!zp3) { if (hipMalloc(&zp3, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; } hipMemset(zp3, 0, 256); }
+        p.zeros = (const h16_t*)zp3;
+    }
+    if (mode == 30) ok = launch_conv_reg<64, 3, 3, 1, false, 1, 4, 2>(st, p);
+    else if (mode == 31) ok = launch_conv_reg<32, 4, 4, 2, false, 1, 4, 2>(st, p);
+    else if (mode == 32) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4, 2>(st, p);
+    else if (mode == 33) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4, 2>(st, p);
+    else if (mode == 20) ok = launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p);
+    else if (mode == 21) ok = launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p);
+    else if (mode == 22) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p);
+    else if (mode == 23) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p);
+    else if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
     else if (mode == 11) ok = launch_conv_reg_fwd<32, 4, 4, 2>(st, p);
     else if (mode == 12) ok = launch_conv_reg<64, 3, 3, 1, true>(st, p);
     else if (mode == 13) ok = launch_conv_reg<64, 2, 2, 1, true, 2>(st, p);

@@ -54,6 +54,45 @@ struct GradComm {
     std::vector<hipEvent_t> ev; size_t ev_used = 0;
     void* stage = nullptr; int64_t stage_elems = 0;            // bf16 staging buffer (bf16 bucket mode)
     long long n_collectives = 0; double bytes_reduced = 0;     // statistics (tests / bench JSON)
+    // "comm_timing" (hulc_set_option): timing events around every bucket's collective of the LAST hulc_backward_allreduce, on the collectives'
+    // stream, plus the begin / end of that backward on the engine stream -> hulc_comm_timeline: how much of each bucket hid under the backward
+    struct Span { hipEvent_t t0 = nullptr, t1 = nullptr; double bytes = 0; bool used = false; };
+    Span span[8];
+    hipEvent_t bwd_t0 = nullptr, bwd_t1 = nullptr;
+    int n_span = 0;
+    bool timeline_valid = false;
+    void span_begin(int i, double bytes) {
+        if (i < 0 || i >= 8) return;
+        Span& s = span[i];
+        if (!s.t0) { hipEventCreate(&s.t0); hipEventCreate(&s.t1); }
+        s.bytes = bytes; s.used = true;
+        hipEventRecord(s.t0, cs);
+        if (i + 1 > n_span) n_span = i + 1;
+    }
+    void span_end(int i) { if (i >= 0 && i < 8 && span[i].used) hipEventRecord(span[i].t1, cs); }
+    void bwd_mark(bool begin, hipStream_t st) {
+        if (!bwd_t0) { hipEventCreate(&bwd_t0); hipEventCreate(&bwd_t1); }
+        if (begin) { for (Span& s : span) s.used = false; n_span = 0; timeline_valid = false; hipEventRecord(bwd_t0, st); }
+        else { hipEventRecord(bwd_t1, st); timeline_valid = true; }
+    }
+    // out[4 i .. 4 i + 3] = {collective start, collective end (us, relative to the END of the backward on the engine stream: negative = hidden
+    // under it), bytes on the wire per rank, 0}; *bwd_us = duration of the backward.  Synchronises both streams.  Returns the bucket count, < 0 on error
+    int timeline(double* out, int cap, double* bwd_us, hipStream_t st) {
+        if (!timeline_valid) { hulc_set_error("hulc_comm_timeline: no timed hulc_backward_allreduce yet (hulc_set_option comm_timing 1)"); return -1; }
+        hipStreamSynchronize(cs); hipStreamSynchronize(st);
+        float ms = 0;
+        hipEventElapsedTime(&ms, bwd_t0, bwd_t1);
+        if (bwd_us) *bwd_us = ms * 1e3;
+        int n = 0;
+        for (int i = 0; i < n_span && n < cap; ++i) {
+            if (!span[i].used) continue;
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, bwd_t1, span[i].t0); hipEventElapsedTime(&b, bwd_t1, span[i].t1);
+            out[4 * n] = a * 1e3; out[4 * n + 1] = b * 1e3; out[4 * n + 2] = span[i].bytes; out[4 * n + 3] = (double)i;
+            ++n;
+        }
+        return n;
+    }
 
     // everything that can fail on ONE rank only (RCCL not loadable, no stream): done before any rank enters the blocking ncclCommInitRank, so
     // the host can agree on the outcome first (hulc_comm_prepare -> all ranks vote -> hulc_comm_init) instead of deadlocking the healthy ranks
@@ -76,6 +115,8 @@ struct GradComm {
     ~GradComm() {
         if (comm) { hipStreamSynchronize(cs); api().destroy(comm); }
         for (hipEvent_t e : ev) hipEventDestroy(e);
+        for (Span& s : span) { if (s.t0) hipEventDestroy(s.t0); if (s.t1) hipEventDestroy(s.t1); }
+        if (bwd_t0) { hipEventDestroy(bwd_t0); hipEventDestroy(bwd_t1); }
         if (cs) hipStreamDestroy(cs);
         if (stage) hipFree(stage);
     }

@@ -40,9 +40,10 @@ struct ConvRegCfg {
     static constexpr int XS = XSS * 16;
     static constexpr int K = TA * TB * CK, NS = K / 16, KS = CK / 16;
     static constexpr int NPL = SI * SI;                        // parity planes
-    static constexpr int PF = 10;                              // DMA rounds per band per thread (512 threads x 16 B each)
+    static constexpr int PIECES = 80;                          // 1 KB DMA pieces per band at most (80 / waves rounds per wave)
     static constexpr size_t band_bytes(int PLR, int PLC) { return ((size_t)NPL * PLR * PLC * XS + 1023) / 1024 * 1024; }   // whole 1 KB DMA pieces
-    static constexpr size_t lds_bytes(int PLR, int PLC) { return 2 * band_bytes(PLR, PLC) + 256; }
+    // nbuf band buffers + bias[64] + (data-gradient form) nbuf regions of `maskb` bytes: the ReLU bit words of a band's output pixels
+    static constexpr size_t lds_bytes(int PLR, int PLC, int nbuf = 2, size_t maskb = 0) { return nbuf * (band_bytes(PLR, PLC) + maskb) + 256; }
 };
 
 // p.LR = staged rows of a band, p.RB = output rows of a band, p.LW = staged width (REV: IMW + 2 (TB - 1)), p.LP = plane columns (PLC),
@@ -56,12 +57,21 @@ struct ConvRegCfg {
 //   OS = 2 (conv2, 4x4 stride 2): one such stride-1 correlation per output parity class (ph, pw) with TA = TB = 2 taps, 32 output channels and
 //   its own weight slab W[(ph,pw)][cn][(ta,tb,ck)]; out[i*2+ph][j*2+pw][cn].  The eight waves are 4 classes x 2 pixel halves (a wave holds its
 //   class's 32 x 256 weights: 64 VGPRs) instead of 2 channel halves x 4 pixel quarters.
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1>
-__global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
+//
+// NWV = 8 (round 3): ONE 512-thread workgroup per CU, two band buffers, the next band's DMA under the current band's MFMAs.  All eight waves pass
+//   through barrier -> multiply -> epilogue together, so the phases ADD (profiles/r03_conv_reg_ablation.txt: full = DMA + MFMA + epilogue).
+// NWV = 4 (round 4): TWO co-resident 256-thread workgroups per CU (<= 256 VGPRs per wave, <= 80 KB of LDS each), each with ONE
+//   band buffer: load band -> barrier -> multiply + epilogue -> barrier.  The two workgroups of a CU are independent, so they fall out of
+//   phase: while one waits for its DMA or sits in its epilogue stores, the other one's waves own the matrix pipes (a SIMD hosts one wave of
+//   each) — the overlap the single lockstep workgroup could not produce.  A wave takes twice the tiles per band (half the barriers per tile).
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0>
+__global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     static_assert(!REV || SI == 1, "the data-gradient forms are stride-1 correlations (per parity class for OS = 2)");
     static_assert(OS == 1 || REV, "output parity classes only exist in the data-gradient form");
-    constexpr int NCLS = OS * OS, CN = NCLS == 1 ? 64 : 32, PPARTS = NCLS == 1 ? 4 : 2, WPP = CN / 32;
+    static_assert(NWV == 8 || NWV == 4, "8 waves (one workgroup per CU, two band buffers) or 4 (two workgroups per CU, one buffer each)");
+    constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), PF = C::PIECES / NWV;      // band buffers of a workgroup (NWV = 4: 1, or 2 with smaller bands)
+    constexpr int NCLS = OS * OS, CN = NCLS == 1 ? 64 : 32, PPARTS = NCLS == 1 ? NWV / 2 : NWV / 4, WPP = CN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, lj = lane & 31;
@@ -70,7 +80,8 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     const int PLR = p.VPI, PLC = p.LP, plane_px = PLR * PLC;
     const size_t bbytes = C::band_bytes(PLR, PLC);
     lds_char* const lbase = (lds_char*)smem;
-    lds_char* const bl = lbase + 2 * bbytes;                   // bias[64] fp32
+    lds_char* const bl = lbase + NBUF * bbytes;                // bias[64] fp32
+    lds_char* const ml = bl + 256;                             // REV + maskbits: NBUF regions of p.MB bytes — the band's ReLU bit words (round 4)
     if (tid < 64) *(__attribute__((address_space(3))) float*)(bl + tid * 4) = p.bias ? p.bias[tid] : 0.f;
     // ---- weights -> registers (once).  MFMA row i of this wave's A operand carries channel chw*32 + 16*((i>>2)&1) + 4*(i>>3) + (i&3):
     // with the 32x32 C/D map (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) lane half h then owns channels chw*32 + 16h + reg, reg = 0..15
@@ -87,7 +98,7 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     // (image col * CH + chunk)
     const int multi = p.FPB > 1;
     const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    const int npieces = (int)(bbytes / 1024), nrounds = (npieces + 7) / 8;      // 1 KB pieces of a band; piece k*8 + wave is this wave's in round k
+    const int npieces = (int)(bbytes / 1024), nrounds = (npieces + NWV - 1) / NWV;      // 1 KB pieces of a band; piece k*NWV + wave is this wave's in round k
     const float invX = 1.f / (float)C::XSS, invPP = 1.f / (float)plane_px, invPLCd = 1.f / (float)PLC;
     // slot q of a band -> bit 31 = column inside the image, bits 20..30 staged row of the band, bits 0..19 (image col * CH + chunk).  Recomputed per
     // band (a dozen VALU operations per 16-byte piece) rather than kept in registers: the weights need them
@@ -116,9 +127,9 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
         const h16_t* src0 = p.img + (long long)f * p.IMH * rowel;
         lds_char* dst = lbase + bi * bbytes + wave * 1024;
 #pragma unroll
-        for (int k = 0; k < C::PF; ++k) {
-            if (k >= nrounds || k * 8 + wave >= npieces) break;     // wave-uniform
-            int q = (k * 8 + wave) * 64 + lane;
+        for (int k = 0; k < PF; ++k) {
+            if (k >= nrounds || k * NWV + wave >= npieces) break;     // wave-uniform
+            int q = (k * NWV + wave) * 64 + lane;
             asm volatile("" : "+v"(q));                             // opaque: keeps the (band-invariant) decode from being hoisted back into ten live registers
             const unsigned pkk = slot_src(q);
             const int sr = r0 + (int)((pkk >> 20) & 0x7ffu);        // staged row of the item
@@ -128,7 +139,21 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
                 const bool ok = (pkk >> 31) && r >= 0 && r < p.IMH && ff < nfr;
                 s = ok ? src0 + (long long)(ff * p.IMH + r) * rowel + (int)(pkk & 0xfffffu) * 8 : p.zeros;
             } else s = src0 + (long long)min(sr, rmax) * rowel + (int)(pkk & 0xfffffu) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * NWV * 1024), 16, 0, 0);
+        }
+        if (REV && p.maskbits) {
+            // the ReLU bit words of the item's output pixels (whole rows of one frame, or whole stacked frames: contiguous in memory) ride along as
+            // 256-byte pieces.  The epilogue then reads its words from LDS: a VECTOR load inside the tile loop would share vmcnt with the output
+            // stores, and the compiler waits vmcnt(0) — i.e. for every store issued so far — at each use of a loaded word (measured: conv2's data
+            // gradient spent 120 us in an epilogue whose 315 MB of stores take 50 us when they stream)
+            const int orow0 = multi ? 0 : b * p.RB * OS, nrow = multi ? nfr * p.OUTH : min(p.RB * OS, p.OUTH - orow0);
+            const int nwords = nrow * p.OUTW * WPP;
+            const unsigned* src = p.maskbits + ((long long)f * p.OUTH + orow0) * p.OUTW * WPP;
+            lds_char* mdst = ml + bi * p.MB + wave * 256;
+            for (int k = 0; (k * NWV + wave) * 64 < nwords; ++k) {      // wave-uniform
+                const int w = min((k * NWV + wave) * 64 + lane, nwords - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w), (__attribute__((address_space(3))) void*)(mdst + k * NWV * 256), 4, 0, 0);
+            }
         }
     };
     // per-tap LDS offsets (uniform): plane (ta % SI, tb % SI), shifted by (ta / SI) plane rows and tb / SI columns; REV: the flipped tap
@@ -140,51 +165,72 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
     }
     const float invPLC = 1.f / (float)PLC, invVPO = 1.f / (float)max(p.VPO, 1);
     int item = blockIdx.x, nb = 0;
-    if (item < nitems) dma(item, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NBUF == 2) {
+        if (item < nitems) dma(item, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
+    const bool fastmask = REV && p.maskbits && !p.relu;        // the production data-gradient form: 1-bit ReLU mask words, no activation
     while (item < nitems) {
-        __syncthreads();                                        // every wave's share of this band has landed (each waited for its own DMAs
+        __syncthreads();                                        // NBUF 2: every wave's share of this band has landed (each waited for its own DMAs
                                                                 // before arriving) and every wave is done reading the other buffer
         const int cur = item;
+        if (NBUF == 1) dma(cur, 0);                             // one buffer: every wave is done with the previous band -> load this one (the CU's
+                                                                // OTHER workgroup multiplies meanwhile)
         item += (int)gridDim.x;
         lds_char* const xb = lbase + nb * bbytes;
-        nb ^= 1;
+        if (NBUF == 2) nb ^= 1;
         const int f = multi ? cur * p.FPB : cur / p.nbands, b = multi ? 0 : cur % p.nbands;
         const int i0 = b * p.RB;
-        const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
         const int rows_total = multi ? p.RB : NI0;              // output-row slots of the whole item
         const int RBe = min(p.RB, rows_total - i0);
         const int npi = RBe * PLC, ntiles = (p.dbg & 2) ? 0 : (npi + 31) >> 5, last = npi - PLC + NJ0 - 1;      // dbg bit 1: no compute
-        // the next band streams in under this band's MFMAs.  Waves 0-3 issue their DMA pieces now; waves 4-7 (the second wave of each
-        // SIMD) after their first tile pair when they have two, so that one wave of a SIMD starts multiplying at once while the other
-        // spends its ~0.3 us of DMA issue
         // this wave's tiles: a contiguous, balanced share of the band's tiles (10 tiles over 4 parts = 2 + 3 + 2 + 3, walked as pairs + a single)
         const int tbeg = pq * ntiles / PPARTS, tend = (pq + 1) * ntiles / PPARTS;
-        bool pend = item < nitems;
-        if (pend && (wave < 4 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
+        // output pixels of a tile pair (-1: nothing to store)
+        const int mbase = multi ? f * p.OUTH * p.OUTW : (f * p.OUTH + i0 * OS) * p.OUTW;      // first output pixel whose mask word the band staged
+        const lds_char* const mlb = ml + (NBUF == 2 ? (nb ^ 1) : 0) * p.MB;
+        auto pix = [&](int t0, int (&opx)[2]) {
+            const bool two = t0 + 1 < tend;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int pi = t0 * 32 + mm * 32 + lj;
+                const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
+                const int ocol = j * OS + pw;
+                bool ok = pi < npi && ocol < p.OUTW && (mm == 0 || two);
+                int o;
+                if (multi) {
+                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO, orow = rr * OS + ph;
+                    ok = ok && orow < p.OUTH && f + ff < p.Nf;
+                    o = ((f + ff) * p.OUTH + orow) * p.OUTW + ocol;
+                } else {
+                    const int orow = (i0 + ri) * OS + ph;
+                    ok = ok && orow < p.OUTH;
+                    o = (f * p.OUTH + orow) * p.OUTW + ocol;
+                }
+                opx[mm] = ok ? o : -1;
+            }
+        };
+        if (NBUF == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // NBUF 2: the next band streams in under this band's MFMAs.  Waves 0-3 issue their DMA pieces now; waves 4-7 (the second wave of each
+        // SIMD) after their first tile pair when they have two, so that one wave of a SIMD starts multiplying at once while the other
+        // spends its ~0.3 us of DMA issue
+        bool pend = NBUF == 2 && item < nitems;
+        if (pend && (wave < NWV / 2 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
         bool waited = false;
 #pragma unroll 1
         for (int t0 = tbeg; t0 < tend; t0 += 2) {
             const bool two = t0 + 1 < tend;                     // uniform
             const int pi0 = t0 * 32 + lj, pi1 = pi0 + 32;
-            // output pixels of the two tiles (and, REV, their ReLU mask words — loaded BEFORE the multiply loop)
-            long long opx[2]; bool ok[2]; unsigned mw[2] = {0xffffffffu, 0xffffffffu};
+            int opx[2]; unsigned mw[2] = {0xffffffffu, 0xffffffffu};
+            pix(t0, opx);
+            if (REV && p.maskbits) {                            // LDS reads, issued in front of the multiply loop's own fragment reads
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int pi = mm ? pi1 : pi0;
-                const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
-                const int ocol = j * OS + pw;
-                ok[mm] = pi < npi && ocol < p.OUTW && (mm == 0 || two);
-                if (multi) {
-                    const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO, orow = rr * OS + ph;
-                    ok[mm] = ok[mm] && orow < p.OUTH && f + ff < p.Nf;
-                    opx[mm] = ((long long)(f + ff) * p.OUTH + orow) * p.OUTW + ocol;
-                } else {
-                    const int orow = (i0 + ri) * OS + ph;
-                    ok[mm] = ok[mm] && orow < p.OUTH;
-                    opx[mm] = ((long long)f * p.OUTH + orow) * p.OUTW + ocol;
-                }
-                if (REV && p.maskbits && ok[mm]) mw[mm] = p.maskbits[opx[mm] * WPP + chw];
+                for (int mm = 0; mm < 2; ++mm)
+                    if (opx[mm] >= 0) mw[mm] = *(const __attribute__((address_space(3))) unsigned*)(mlb + ((opx[mm] - mbase) * WPP + chw) * 4);
             }
             lds_char* const x0 = xb + min(pi0, last) * C::XS + h * 16;
             lds_char* const x1 = xb + min(pi1, last) * C::XS + h * 16;
@@ -216,12 +262,40 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
             } else if (two) mloop(std::true_type{});
             else mloop(std::false_type{});
             if (pend) { dma(item, nb); pend = false; }
-            if (t0 + 2 >= tend) {                               // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
+            if (NBUF == 2 && t0 + 2 >= tend) {                  // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // multiply loop ago) and the earlier stores are waited for HERE, so that the
                 waited = true;                                  // stores below stay in flight across the barrier
             }
             if ((p.dbg & 8) && acc0[0] != 12345.678f) continue;   // ablation: no epilogue
             // ---- epilogue: lane = (pixel lj, half h) holds channels chw*32 + 16h + [0, 16)
+            if (REV && fastmask) {
+                // data gradient, production form: out = bit ? acc : 0 -> a sign-extended 1-bit field ANDed onto the fp32 pattern (2 VALU per value)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    if (mm == 1 && !two) break;
+                    const f32x16& a = mm ? acc1 : acc0;
+                    const int mwh = (int)(mw[mm] >> (16 * h));
+                    u32x4_t o[2];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m0 = __builtin_amdgcn_sbfe(mwh, 2 * e, 1), m1 = __builtin_amdgcn_sbfe(mwh, 2 * e + 1, 1);
+                        const float v0 = __int_as_float(__float_as_int(a[2 * e]) & m0), v1 = __int_as_float(__float_as_int(a[2 * e + 1]) & m1);
+                        o[e >> 2][e & 3] = pack2h(v0, v1);
+                    }
+                    if (opx[mm] >= 0) {
+                        long long ob = opx[mm];
+#ifdef HULC_AB_SWITCHES
+                        if (p.dbg & 64) ob = min((((long long)cur * NCLS + cls) * ntiles + t0 + mm) * 32 + lj, (long long)p.Nf * p.OUTH * p.OUTW - 1);   // experiment: tile-contiguous output
+#endif
+                        u32x4_t* op = reinterpret_cast<u32x4_t*>(p.out + ob * CN + chw * 32 + 16 * h);
+#ifdef HULC_AB_SWITCHES
+                        if (p.dbg & 128) { __builtin_nontemporal_store(o[0], op); __builtin_nontemporal_store(o[1], op + 1); } else
+#endif
+                        { op[0] = o[0]; op[1] = o[1]; }
+                    }
+                }
+                continue;
+            }
             f32x4 bb[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) bb[e] = REV ? f32x4{0.f, 0.f, 0.f, 0.f} : *(__attribute__((address_space(3))) f32x4*)(bl + (chw * 32 + 16 * h + 4 * e) * 4);
@@ -229,59 +303,65 @@ __global__ void __launch_bounds__(512) conv_reg_kernel(ConvTileP p) {
             for (int mm = 0; mm < 2; ++mm) {
                 if (mm == 1 && !two) break;
                 const f32x16& a = mm ? acc1 : acc0;
-                h16_t* const optr = p.out + opx[mm] * CN + chw * 32 + 16 * h;
+                const bool okm = opx[mm] >= 0;
+                const long long ob = okm ? (long long)opx[mm] : 0ll;
+                h16_t* const optr = p.out + ob * CN + chw * 32 + 16 * h;
                 u32x4_t mk[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
-                if (REV && p.mask && ok[mm]) {                  // 16-bit mask values (per-kernel tests)
-                    const u32x4_t* mp = reinterpret_cast<const u32x4_t*>(p.mask + opx[mm] * CN + chw * 32 + 16 * h);
+                if (REV && p.mask && okm) {                     // 16-bit mask values (per-kernel tests)
+                    const u32x4_t* mp = reinterpret_cast<const u32x4_t*>(p.mask + ob * CN + chw * 32 + 16 * h);
                     mk[0] = mp[0]; mk[1] = mp[1];
                 }
                 u32x4_t o[2];
                 unsigned obits = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float v0 = a[2 * e] + bb[e >> 1][(2 * e) & 3], v1 = a[2 * e + 1] + bb[e >> 1][(2 * e + 1) & 3];
-                    if (!REV || p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                    if (REV) {
+                    float v0 = a[2 * e], v1 = a[2 * e + 1];
+                    if (!REV) { v0 = fmaxf(v0 + bb[e >> 1][(2 * e) & 3], 0.f); v1 = fmaxf(v1 + bb[e >> 1][(2 * e + 1) & 3], 0.f); }
+                    else {
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
                         if (p.maskbits) { v0 = ((mw[mm] >> (16 * h + 2 * e)) & 1u) ? v0 : 0.f; v1 = ((mw[mm] >> (16 * h + 2 * e + 1)) & 1u) ? v1 : 0.f; }
                         else if (p.mask) { const unsigned m = mk[e >> 2][e & 3]; v0 = h2f_lo(m) > 0.f ? v0 : 0.f; v1 = h2f_hi(m) > 0.f ? v1 : 0.f; }
                     }
                     const unsigned w = pack2h(v0, v1);
                     o[e >> 2][e & 3] = w;
-                    obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
+                    if (!REV) obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
                 }
-                if (ok[mm]) {
+                if (okm) {
                     u32x4_t* op = reinterpret_cast<u32x4_t*>(optr);
                     op[0] = o[0]; op[1] = o[1];
                 }
                 if (!REV && p.bits_out) {                       // word chw of the pixel = channels chw*32 .. +31: halves h = 0 / 1 give bits 0..15 / 16..31
                     unsigned w = obits << (16 * h);
                     w |= __shfl_xor(w, 32);
-                    if (ok[mm] && h == 0) p.bits_out[opx[mm] * 2 + chw] = w;
+                    if (okm && h == 0) p.bits_out[ob * 2 + chw] = w;
                 }
             }
         }
         if (pend) dma(item, nb);
-        if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBUF == 2 && !waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1>
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
+    constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), WGPC = NWV == 8 ? 1 : 2;      // band buffers per workgroup, workgroups per CU
     if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
     if (!REV && (p.mask || p.maskbits || !p.relu)) return false;
     const int NI = REV ? (p.OUTH + OS - 1) / OS : p.OUTH;      // output rows to cover (REV: class rows of the largest class)
     if (REV && (!p.zeros || NI > p.IMH + TA)) return false;
-    const size_t cap = 160 * 1024 - 64;
+    const size_t cap = 160 * 1024 / WGPC - 64;
     p.LW = REV ? NI + TB - 1 : p.IMW;
     p.LP = (p.LW + SI - 1) / SI;                                // plane columns = m-index pitch
     p.FPB = 1; p.VPO = 0;
-    auto fits = [&](int LR, int PLR) { return C::lds_bytes(PLR, p.LP) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PF * 8192 && LR < 2048; };
+    // REV: bytes of the ReLU bit words of a band's output rows (whole 256-byte DMA pieces, one extra piece of slack)
+    auto maskb = [&](int out_rows) -> size_t { return (REV && p.maskbits) ? ((size_t)out_rows * p.OUTW * (OS == 1 ? 2 : 1) * 4 + 255) / 256 * 256 + 256 : 0; };
+    auto fits = [&](int LR, int PLR, int out_rows) { return C::lds_bytes(PLR, p.LP, NBUF, maskb(out_rows)) <= cap && C::band_bytes(PLR, p.LP) <= (size_t)C::PIECES * 1024 && LR < 2048; };
     int best_nb = 0;
     for (int nb = 1; nb <= NI; ++nb) {
         const int RB = (NI + nb - 1) / nb, LR = REV ? RB + TA - 1 : (RB - 1) * SI + TA, PLR = (LR + SI - 1) / SI;
-        if (fits(LR, PLR)) { best_nb = nb; break; }
+        if (fits(LR, PLR, std::min(RB * OS, p.OUTH))) { best_nb = nb; break; }
     }
     if (!best_nb) return false;
     p.RB = (NI + best_nb - 1) / best_nb;
@@ -293,9 +373,10 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
         int bestf = 1; double bc = 1e30;
         for (int fpb = 1; fpb <= 32; ++fpb) {
             const int LR = REV ? fpb * vpo + TA - 1 : fpb * p.IMH, PLR = (LR + SI - 1) / SI, RB = REV ? fpb * vpo : (LR - TA) / SI + 1;
-            if (!fits(LR, PLR)) break;
-            const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + (OS == 1 ? 7 : 3)) / (OS == 1 ? 8 : 4);     // a wave pass = 2 tiles; 4 (2) pixel parts
-            const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256);
+            if (!fits(LR, PLR, fpb * p.OUTH)) break;
+            constexpr int per = 2 * (OS == 1 ? NWV / 2 : NWV / 4);                                                // a wave pass = 2 tiles x the pixel parts
+            const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + per - 1) / per;
+            const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256 * WGPC);
             const double c = (double)((items + wgs - 1) / wgs) * (0.35 + rounds);
             if (c < bc - 1e-9) { bc = c; bestf = fpb; }
         }
@@ -304,14 +385,15 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
             p.LR = REV ? bestf * vpo + TA - 1 : bestf * p.IMH; p.VPI = (p.LR + SI - 1) / SI; p.RB = REV ? bestf * vpo : (p.LR - TA) / SI + 1;
         }
     }
-    const size_t lds = C::lds_bytes(p.VPI, p.LP);
+    p.MB = (int)maskb(p.FPB > 1 ? p.FPB * p.OUTH : std::min(p.RB * OS, p.OUTH));
+    const size_t lds = C::lds_bytes(p.VPI, p.LP, NBUF, (size_t)p.MB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS>), dim3(items < 256 ? items : 256), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
     return true;
 }
 template <int CK, int TA, int TB, int SI>

@@ -40,6 +40,7 @@ struct ConvTileP {
                              // straddle two frames are computed and dropped.  Dgrad: the band is a VIRTUAL stack with VPI = IMH + TA - 1 rows per
                              // frame (IMH real rows + the zero rows the full correlation needs between frames), so no computed row is wasted.
     int VPI, VPO;            // rows per frame of the stacked band in window-row space (VPI) and in class-output-row space (VPO)
+    int MB;                  // conv_reg.h (data-gradient form): bytes of one LDS region holding a band's ReLU bit words
     const h16_t* zeros;      // conv_reg.h data-gradient form: >= 16 zero bytes in device memory (source of the staged zero border)
 };
 

@@ -1232,13 +1232,14 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
                 for (int r = 0; r < 4; ++r)
                     if (k + r < K) unsafeAtomicAdd(p + r, acc[j][r]);
             } else if (k + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
-                float4 o = *reinterpret_cast<float4*>(p);
+                // store mode (slabs are never zeroed; first backward after zero_grads): the ragged last k-tile must STORE too, not add to what lies there
+                float4 o = store ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(p);
                 o.x += acc[j][0]; o.y += acc[j][1]; o.z += acc[j][2]; o.w += acc[j][3];
                 *reinterpret_cast<float4*>(p) = o;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (k + r < K) p[r] += acc[j][r];
+                    if (k + r < K) p[r] = store ? acc[j][r] : p[r] + acc[j][r];
             }
         }
     }

@@ -686,8 +686,10 @@ struct Engine : IEngine {
             const double px2 = (double)Nf * e.H2 * e.H2, px3 = (double)Nf * e.H3 * e.H3, px1 = (double)Nf * e.H1 * e.H1;
             TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);      // A/B: bit 0 = conv2 forward, bit 1 = conv3 forward, bit 2 = conv3 data gradient on the weights-in-registers kernel (conv_reg.h)
-            const bool t2 = ((conv_reg & 1) && launch_conv_reg_fwd<32, 4, 4, 2>(st, p2)) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
-            const bool t3 = ((conv_reg & 2) && launch_conv_reg_fwd<64, 3, 3, 1>(st, p3)) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
+            // HULC_CONV_REG_W4 (same bits): the form with two co-resident 256-thread workgroups per CU (conv_reg.h, NWV = 4)
+            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 15);
+            const bool t2 = ((conv_reg & 1) && ((w4 & 1) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
+            const bool t3 = ((conv_reg & 2) && ((w4 & 2) ? launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p3) : launch_conv_reg_fwd<64, 3, 3, 1>(st, p3))) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
             tiled = t2 && t3;
         }
         if (!tiled) {
@@ -870,15 +872,16 @@ struct Engine : IEngine {
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 15);      // bit 2: conv3, bit 3: conv2 data gradient on conv_reg.h
+            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 15);         // same bits: two 256-thread workgroups per CU (NWV = 4)
             if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);      // zero-initialised by alloc(): the staged zero border of the data-gradient form
                 p.zeros = zero_page;
-                ok = ((conv_reg & 4) && maskbits && launch_conv_reg<64, 3, 3, 1, true>(st, p)) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+                ok = ((conv_reg & 4) && maskbits && ((w4 & 4) ? launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p) : launch_conv_reg<64, 3, 3, 1, true>(st, p))) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
             }
             else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);
                 p.zeros = zero_page;
-                ok = ((conv_reg & 8) && maskbits && launch_conv_reg<64, 2, 2, 1, true, 2>(st, p)) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+                ok = ((conv_reg & 8) && maskbits && ((w4 & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p) : launch_conv_reg<64, 2, 2, 1, true, 2>(st, p))) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
             }
             if (ok) return;
         }
@@ -1140,7 +1143,10 @@ struct Engine : IEngine {
     // ---------------------------------------------------------------- forward
     int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) override {
         pair = false;
-        return forward_impl(b, lw, cw, out, on_host);
+        int rc = forward_impl(b, lw, cw, out, on_host);
+        // a persistent recurrence of THIS forward timed out and the stream is drained (losses read back): run it again, one launch per step
+        if (!rc && out && on_host && persist_check("hulc_forward_loss", true)) rc = forward_impl(b, lw, cw, out, on_host);
+        return rc;
     }
     // vis + lang windows of one step as ONE pass over Bv + Bl windows (hulc.py:433-469 runs them one after the other): the encoders, plan
     // networks and the decoder are shared, only the goal encoder (rows [0,Bv): visual, [Bv,B): language) and the CLIP rows differ.  The
@@ -1185,11 +1191,13 @@ struct Engine : IEngine {
         for (int& r : aux_host) r += Bv;
         jb.aux_rows = aux_host.data(); jb.n_aux = lb->aux_rows ? lb->n_aux : 0;
         pair = true; pairBv = Bv; cur2 = *lb;
-        return forward_impl(&jb, lw, cw, out, on_host);
+        int rc = forward_impl(&jb, lw, cw, out, on_host);
+        if (!rc && out && on_host && persist_check("hulc_forward_loss_pair", true)) rc = forward_impl(&jb, lw, cw, out, on_host);
+        return rc;
     }
     int forward_impl(const hulc_batch* b, float lw, float cw, float* out, int on_host) {
         if (!bound) { hulc_set_error("hulc_forward_loss before hulc_bind_params"); return 1; }
-        if (persist_failed("hulc_forward_loss")) return 1;
+        persist_check("hulc_forward_loss", false);
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
             hulc_set_error("batch (B=%d,S=%d) exceeds workspace (max_batch=%d,max_seq=%d,max_window=%d)", b->B, b->S, maxB, maxS, cfg.max_window);
             return 1;
@@ -1307,6 +1315,14 @@ struct Engine : IEngine {
     }
     int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
                  float* pred_pr_out) override {
+        persist_check("hulc_validate", false);
+        int rc = validate_impl(b, nz, out17, plan_pp_out, plan_pr_out, pred_pp_out, pred_pr_out);
+        // validate ends with a stream synchronisation: a timed-out persistent recurrence is visible here -> the metrics are recomputed on the per-step path
+        if (!rc && persist_check("hulc_validate", true)) rc = validate_impl(b, nz, out17, plan_pp_out, plan_pr_out, pred_pp_out, pred_pr_out);
+        return rc;
+    }
+    int validate_impl(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
+                      float* pred_pr_out) {
         if (!bound) { hulc_set_error("hulc_validate before hulc_bind_params"); return 1; }
         const bool hulc = cfg.kind == HULC_KIND_HULC;     // GCBC (gcbc.py:214-246): one decoder pass without a plan, reported in the "pp" slots
         if (b->B < 1 || b->S < 1 || b->B > maxB || b->S > maxS || b->S > cfg.max_window || b->S > 64) {
@@ -1469,17 +1485,30 @@ struct Engine : IEngine {
     }
 
     // ---- a whole recurrence X[q_s] = f(X[q_{s-1}] Wm^T, aux[q_s]), s = 1..S-1, as ONE persistent launch (rnn_persist.h; 16-bit engines, 2048-wide
-    // state).  false = not taken (fp32 engine, option off, shape not covered, or this device failed the first launch's census): the caller runs
-    // one launch per step.  The FIRST launch of a context is followed by a stream synchronisation and a look at the error word; a timeout in
-    // any later launch (the kernel's polls are bounded) is picked up by persist_failed() at the next API call, which reports the step as failed.
+    // state).  false = not taken (fp32 engine, option off, shape not covered, a gradient collective in flight, or this device failed an earlier
+    // launch): the caller runs one launch per step.  The FIRST launch of a context is followed by a stream synchronisation and a look at the
+    // error word.  A timeout in a later launch (the kernel's polls are bounded) never reaches the weights and never fails a step (round 4):
+    //   * the failing kernel also stores the tag of the optimizer step it belongs to into a DEVICE word; adam_kernel / sgd_kernel compare it
+    //     with their own tag and return without touching p / m / v (the step is dropped, exactly like a GradScaler-skipped step);
+    //   * at the API calls that end in a stream synchronisation (forward with losses read back, validate) the host sees the error word right
+    //     there, switches the context to one launch per step and RUNS THE CALL AGAIN — its results are valid;
+    //   * elsewhere (backward) the host notices at the next API call: persistent mode goes off, a warning is printed, `persistent_rnn_fallbacks`
+    //     counts it (hulc_get_option).
     unsigned* rp_flags = nullptr;
     volatile unsigned* rp_err_host = nullptr;
     unsigned* rp_err_dev = nullptr;
+    unsigned* rp_skip = nullptr;          // device word: tag of the optimizer step whose recurrence failed
+    unsigned opt_seq = 0;                 // optimizer calls so far; recurrences launched now belong to step opt_seq + 1
+    long long rp_fallbacks = 0;
     unsigned rp_launches = 1;
     int rp_B = -1;
     bool rp_probed = false, rp_ok = false;
+    // persistent launches need all 256 workgroups co-resident.  While a bucket of hulc_backward_allreduce is in flight RCCL's kernels hold CUs on
+    // the high-priority collectives' stream, so a recurrence that follows an issued bucket (mcil: the plan encoder's BiRNN backward runs after the
+    // decoder bucket has left) takes the launch-per-step path — `persist_under_comm` = 1 lifts that (measure on the target box first)
+    bool comm_in_flight() const { return ar_dtype >= 0 && ar_sent != 0 && !persist_under_comm; }
     bool persist_usable(int B, int S) const {
-        return std::is_same<T, h16_t>::value && persist_mode && HID == RP_HID && S >= 3 && B <= 16 * RP_NG && !(rp_probed && !rp_ok);
+        return std::is_same<T, h16_t>::value && persist_mode && HID == RP_HID && S >= 3 && B <= 16 * RP_NG && !(rp_probed && !rp_ok) && !comm_in_flight();
     }
     bool rnn_persist(T* X, const T* Wm, const T* res, const T* mask, int B, int S, int q0, int dq, int act) {
         if constexpr (!std::is_same<T, h16_t>::value) return false;
@@ -1487,6 +1516,7 @@ struct Engine : IEngine {
             if (!persist_usable(B, S)) return false;
             if (!rp_flags) {
                 rp_flags = alloc<unsigned>(RP_FLAG_WORDS);
+                rp_skip = alloc<unsigned>(64);
                 void* h = nullptr;
                 if (alloc_failed || hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&rp_err_dev, h, 0) != hipSuccess) { rp_probed = true; rp_ok = false; return false; }
                 rp_err_host = (volatile unsigned*)h; *rp_err_host = 0;
@@ -1498,6 +1528,7 @@ struct Engine : IEngine {
             RnnPersistP p{};
             p.X = X; p.W = Wm; p.res = res; p.mask = mask; p.B = B; p.S = S; p.q0 = q0; p.dq = dq; p.act = act;
             p.flags = rp_flags; p.base = rp_launches << 12; p.parity = (int)(rp_launches & 1u); p.err = rp_err_dev; p.stamps = nullptr;
+            p.skip = rp_skip; p.skip_tag = opt_seq + 1;
             ++rp_launches;
             TimerScope ts(this, "rnn_persist", "mfma", 2.0 * B * HID * HID * (S - 1), (double)HID * HID * sizeof(T) + 3.0 * S * B * HID * sizeof(T), 1);
             if (!launch_rnn_persist(st, p)) return false;
@@ -1513,13 +1544,27 @@ struct Engine : IEngine {
             return true;
         }
     }
-    // true (and an error message) if a persistent recurrence of an earlier call timed out: that call's results are invalid
-    bool persist_failed(const char* where) {
+    // true if a persistent recurrence timed out since the last check.  The context then runs one launch per step from here on.
+    // synced: the stream is drained and the caller is about to redo its own work (the skip tag is cleared: the redo makes the step whole again);
+    // otherwise the failed launch belonged to an earlier, asynchronous call — its optimizer step skips itself on the device.
+    bool persist_check(const char* where, bool synced) {
         if (!rp_err_host || *rp_err_host == 0) return false;
-        hulc_set_error("%s: a persistent recurrence launch of the previous step timed out (code %u: the GPU's CUs were not all available — shared with another process?); "
-                       "its results are invalid.  persistent_rnn is now off for this context (hulc_set_option)", where, *rp_err_host);
-        *rp_err_host = 0; rp_ok = false; rp_probed = true;
+        const unsigned code = *rp_err_host;
+        *rp_err_host = 0; rp_ok = false; rp_probed = true; ++rp_fallbacks;
+        fprintf(stderr, "hulc: %s: a persistent recurrence launch timed out (code %u: the GPU's CUs were not all available — shared with another process or a "
+                        "collective?).  %s; persistent_rnn is now off for this context (one launch per time step).\n", where, code,
+                synced ? "The call is run again on the launch-per-step path" : "The optimizer step it belonged to is skipped on the device (weights untouched)");
+        if (synced && rp_skip) hipMemset(rp_skip, 0, sizeof(unsigned));
         return true;
+    }
+    int get_option(const char* name, long long* value) override {
+        if (name && !strcmp(name, "persistent_rnn")) { *value = persist_mode && !(rp_probed && !rp_ok); return 0; }
+        if (name && !strcmp(name, "persistent_rnn_fallbacks")) { *value = rp_fallbacks; return 0; }
+        if (name && !strcmp(name, "fused_transformer")) { *value = tr_fused_mode; return 0; }
+        if (name && !strcmp(name, "persist_under_comm")) { *value = persist_under_comm; return 0; }
+        if (name && !strcmp(name, "comm_timing")) { *value = comm_timing; return 0; }
+        hulc_set_error("hulc_get_option: unknown option '%s'", name ? name : "(null)");
+        return 1;
     }
 
     // H[t] = act(Zx[t] + H[t-1] Whh^T), time-major [S][B][HID].  act 1: ReLU (action decoder), 2: tanh (mcil BiRNN); rev: the
@@ -1902,11 +1947,12 @@ struct Engine : IEngine {
     int ar_dtype = -1;          // >= 0 while a backward with overlapped all-reduce is running: bucket dtype
     unsigned ar_sent = 0;       // bit i: bucket i already issued in this backward
     // SUM all-reduce of G[lo, hi) on the collectives' stream, ordered after everything enqueued on `st` so far
-    int reduce_range(int64_t lo, int64_t hi, int dtype) {
+    int reduce_range(int64_t lo, int64_t hi, int dtype, int span = -1) {
         if (hi <= lo) return 0;
         GradComm& c = *comm;
         c.gate_from(st);
         const size_t n = (size_t)(hi - lo);
+        if (span >= 0) c.span_begin(span, (dtype == HULC_DTYPE_F32 ? 4.0 : 2.0) * n);
         int rc;
         if (dtype == HULC_DTYPE_BF16 || dtype == HULC_DTYPE_F16) {
             // 16-bit wire format: G -> staging (this unit's 16-bit type), all-reduce, widen back.  bf16 keeps fp32's range (no scaling needed);
@@ -1931,6 +1977,7 @@ struct Engine : IEngine {
             c.bytes_reduced += 4.0 * n;
         }
         c.n_collectives++;
+        if (span >= 0) c.span_end(span);
         if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }
         return 0;
     }
@@ -1939,7 +1986,7 @@ struct Engine : IEngine {
         if (ar_dtype < 0 || (ar_sent >> i) & 1u) return 0;
         const std::vector<Bucket> v = bucket_plan();
         ar_sent |= 1u << i;
-        return reduce_range(v[i].lo, v[i].hi, ar_dtype);
+        return reduce_range(v[i].lo, v[i].hi, ar_dtype, comm_timing ? i : -1);
     }
     int check_ar_dtype(int dtype, const char* who) {
         if (!comm) { hulc_set_error("%s: no communicator (hulc_comm_init first)", who); return 1; }
@@ -1975,10 +2022,12 @@ struct Engine : IEngine {
         if (check_ar_dtype(dtype, "hulc_backward_allreduce")) return 1;
         if (!bucket_plan_ok()) { hulc_set_error("hulc_backward_allreduce: the module-group buckets do not partition the gradient buffer (layout changed?)"); return 1; }
         ar_dtype = dtype; ar_sent = 0;
+        if (comm_timing) comm->bwd_mark(true, st);
         int rc = backward(-1);
         if (!rc) for (int i = 0; i < 5 && !rc; ++i) rc = bucket_ready(i);     // whatever no stage hook covered (model kinds without that stage)
         ar_dtype = -1;
         if (rc) return rc;
+        if (comm_timing) comm->bwd_mark(false, st);
         comm->gate_to(st);                 // Adam (or anything enqueued next on the engine stream) runs after the last collective
         return 0;
     }
@@ -1986,7 +2035,7 @@ struct Engine : IEngine {
     int bwd_stage = 0;    // 0: nothing pending; 1: part 0 done, encoders pending
     int backward(int part = -1) override {
         if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
-        if (persist_failed("hulc_backward")) return 1;
+        persist_check("hulc_backward", false);
         if (part == 1 && bwd_stage != 1) { hulc_set_error("hulc_backward_part(1) must follow hulc_backward_part(0)"); return 1; }
         if (part != 1 && bwd_stage != 0) { hulc_set_error("hulc_backward: encoder part of the previous backward still pending"); return 1; }
         const hulc_batch* b = &cur;
@@ -1997,6 +2046,9 @@ struct Engine : IEngine {
         if (part == 1) goto encoders;
         HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
         work_ctr_next = 0;
+        // tests (hulc_set_option debug_poison_partials): the weight-gradient slab arena is never zeroed — every slab element must be WRITTEN before the
+        // unpack launches sum it.  NaN-filling it makes a slab cell that is read-modify-written (the ragged last k-tile of fc7) visible
+        if (poison_partials) HIP_CHECK(hipMemsetAsync(this->part, 0xFF, sizeof(float) * (size_t)this->partcap, st));
         {
         bool have_dseq = false, dseq_cast_done = false;
         // ---- CLIP backward
@@ -2287,16 +2339,24 @@ struct Engine : IEngine {
         return 0;
     }
 
-    int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) override {
-        if (!bound) { hulc_set_error("hulc_adam_step before hulc_bind_params"); return 1; }
-        if (persist_failed("hulc_adam_step")) return 1;
-        const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    int optim(const hulc_optim& o) override {
+        if (!bound) { hulc_set_error("hulc_optimizer_step before hulc_bind_params"); return 1; }
+        persist_check("hulc_optimizer_step", false);
+        const unsigned tag = ++opt_seq;
+        if (o.kind != HULC_OPT_ADAM && o.kind != HULC_OPT_ADAMW && o.kind != HULC_OPT_SGD) { hulc_set_error("hulc_optimizer_step: unknown optimizer kind %d", (int)o.kind); return 1; }
+        if (o.step < 1) { hulc_set_error("hulc_optimizer_step: step counts from 1 (got %lld)", (long long)o.step); return 1; }
+        const float lr = o.lr, b1 = o.beta1, b2 = o.beta2, eps = o.eps, gscale = o.grad_scale;
+        const int64_t step = o.step;
         const double bc1d = 1.0 - pow((double)b1, (double)step), bc2d = 1.0 - pow((double)b2, (double)step);
-        (void)bc1; (void)bc2;
+        h16_t* const shadow = std::is_same<T, float>::value ? (h16_t*)nullptr : (h16_t*)wshadow;
         if (scaler) hipLaunchKernelGGL(nonfinite_check_kernel, dim3(2048), dim3(256), 0, st, G, (long long)numel, scaler);      // after the (host-side) all-reduce: every rank sees the same flag
-        hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale,
-                           std::is_same<T, float>::value ? (h16_t*)nullptr : (h16_t*)wshadow, (const ScalerState*)scaler);
-        if (scaler) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, st, scaler);
+        if (o.kind == HULC_OPT_SGD)
+            hipLaunchKernelGGL(sgd_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, (long long)numel, lr, o.momentum, o.dampening, o.weight_decay, (int)(o.nesterov != 0),
+                               (int)(step == 1), gscale, shadow, (const ScalerState*)scaler, (const unsigned*)rp_skip, tag);
+        else
+            hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale,
+                               shadow, (const ScalerState*)scaler, o.weight_decay, (int)(o.kind == HULC_OPT_ADAMW), (const unsigned*)rp_skip, tag);
+        if (scaler) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, st, scaler, (const unsigned*)rp_skip, tag);
         if (hipGetLastError() != hipSuccess) { hulc_set_error("adam launch failed"); return 1; }
         return prepare_weights(true);
     }

@@ -27,7 +27,11 @@ struct IEngine {
     virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
                              const int32_t* plan_inject, int32_t* plan_out) = 0;
     virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
-    virtual int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) = 0;
+    virtual int optim(const hulc_optim& o) = 0;
+    int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) {
+        hulc_optim o{}; o.kind = HULC_OPT_ADAM; o.lr = lr; o.beta1 = b1; o.beta2 = b2; o.eps = eps; o.step = step; o.grad_scale = gscale;
+        return optim(o);
+    }
     virtual int scaler_enable(float init_scale, float growth, float backoff, int interval) = 0;
     virtual int scaler_get(float* scale, int32_t* tracker, int64_t* skipped, int32_t* last_inf, int64_t* taken) = 0;
     virtual int scaler_set(float scale, int32_t tracker, int64_t taken) = 0;
@@ -64,10 +68,18 @@ struct IEngine {
     // (what a process that SHARES the GPU's CUs with another process must choose: the persistent launch needs all 256 CUs resident)
     // "fused_transformer": 1 (default) = one launch per plan-recognition encoder layer in the forward of the 16-bit engines (tr_fused.h, S <= 32);
     // 0 = the seven unfused launches per layer (what the fp32 engine and S > 32 run) — tests compare the two
-    int persist_mode = 1, tr_fused_mode = 1;
+    // "persist_under_comm": 0 (default) = recurrences that follow an issued all-reduce bucket of hulc_backward_allreduce run one launch per step (RCCL's
+    // kernels hold CUs; a persistent launch needs all of them); 1 = keep them persistent.  "comm_timing": 1 = hulc_backward_allreduce records events around
+    // every bucket's collective and at the end of the backward (hulc_comm_timeline).  "debug_poison_partials": tests only — fills the weight-gradient
+    // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0;
+    virtual int get_option(const char* name, long long* value) = 0;
     int set_option(const char* name, long long value) {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
         if (name && !strcmp(name, "fused_transformer")) { tr_fused_mode = value != 0; return 0; }
+        if (name && !strcmp(name, "persist_under_comm")) { persist_under_comm = value != 0; return 0; }
+        if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
+        if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
         hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
         return 1;
     }

@@ -2019,7 +2019,9 @@ __global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __res
         for (long long j = i; j < n && j < i + 4; ++j) bad |= ((__float_as_uint(g[j]) & 0x7f800000u) == 0x7f800000u);
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ss->found_inf, 1);
 }
-__global__ void scaler_update_kernel(ScalerState* __restrict__ ss) {
+// skip / tag: a persistent recurrence of this step failed (rnn_persist.h) — the optimizer left the weights alone, the scaler state stays as it is
+__global__ void scaler_update_kernel(ScalerState* __restrict__ ss, const unsigned* __restrict__ skip = nullptr, unsigned tag = 0) {
+    if (skip && *skip == tag) { ss->found_inf = 0; return; }
     if (ss->found_inf) { ss->scale *= ss->backoff; ss->growth_tracker = 0; ss->skipped++; }
     else {
         ss->steps++;
@@ -2034,9 +2036,12 @@ __global__ void scaler_update_kernel(ScalerState* __restrict__ ss) {
     ss->found_inf = 0;
 }
 
+// wd != 0: torch.optim.Adam's L2 term (g += wd p; decoupled = 0) or torch.optim.AdamW's decoupled decay (p *= 1 - lr wd before the update)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, h16_t* __restrict__ shadow,
-                            const ScalerState* __restrict__ ss = nullptr) {
+                            const ScalerState* __restrict__ ss = nullptr, float wd = 0.f, int decoupled = 0, const unsigned* __restrict__ skip = nullptr,
+                            unsigned tag = 0) {
+    if (skip && *skip == tag) return;   // a persistent recurrence of this step timed out (rnn_persist.h): its gradients are garbage, the step is dropped
     if (ss) {                           // fp16 mode: unscale; a step with non-finite gradients changes nothing (GradScaler.step skips
         if (ss->found_inf) return;      // optimizer.step(), so Adam's own step count — the bias corrections — only counts the steps taken)
         gscale /= ss->scale;
@@ -2057,7 +2062,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gr = G[e] * gscale;
+            float gr = G[e] * gscale;
+            if (wd != 0.f) {                    // uniform
+                if (decoupled) P[e] *= 1.f - lr * wd;
+                else gr += wd * P[e];
+            }
             Mv[e] = b1 * Mv[e] + (1.f - b1) * gr;
             V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
             P[e] -= (lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
@@ -2071,6 +2080,43 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         }
         __builtin_nontemporal_store(f32x4nt{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f32x4nt*>(m + i));
         __builtin_nontemporal_store(f32x4nt{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4nt*>(v + i));
+    }
+}
+
+// torch.optim.SGD (conf/model/optimizer/sgd.yaml: momentum 0.9) over the flat buffer; buf = the bound first-moment buffer
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n, float lr, float momentum,
+                           float dampening, float wd, int nesterov, int first, float gscale, h16_t* __restrict__ shadow,
+                           const ScalerState* __restrict__ ss = nullptr, const unsigned* __restrict__ skip = nullptr, unsigned tag = 0) {
+    if (skip && *skip == tag) return;
+    if (ss) {
+        if (ss->found_inf) return;
+        gscale /= ss->scale;
+        first = ss->steps == 0;
+    }
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (momentum != 0.f && !first) bb = *reinterpret_cast<const float4*>(buf + i);
+        float* P = &pp.x; float* G = &gg.x; float* Bf = &bb.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gr = G[e] * gscale;
+            if (wd != 0.f) gr += wd * P[e];
+            if (momentum != 0.f) {
+                Bf[e] = first ? gr : momentum * Bf[e] + (1.f - dampening) * gr;
+                gr = nesterov ? gr + momentum * Bf[e] : Bf[e];
+            }
+            P[e] -= lr * gr;
+        }
+        *reinterpret_cast<float4*>(p + i) = pp;
+        if (momentum != 0.f) *reinterpret_cast<float4*>(buf + i) = bb;
+        if (shadow) {
+            uint2 o;
+            o.x = pack2h(pp.x, pp.y);
+            o.y = pack2h(pp.z, pp.w);
+            *reinterpret_cast<uint2*>(shadow + i) = o;
+        }
     }
 }
 

@@ -55,6 +55,8 @@ struct RnnPersistP {
     unsigned base;
     int parity;           // launch parity: census set in use
     unsigned* err;        // device-visible word (the engine maps a pinned host word): 1 = a poll timed out, 2 = an XCD held more than 32 workgroups
+    unsigned* skip;       // device word or null: a failing launch stores `skip_tag` here — the optimizer kernel of the step this recurrence belongs to
+    unsigned skip_tag;    // compares its own tag with the word and leaves the weights untouched (engine.h: persist_check)
     long long* stamps;    // RP_STAMPS builds (tools/rnn_persist_bench.hip): [S][2 waves][8] shader-clock stamps of workgroup 8
 };
 #ifdef RP_STAMPS
@@ -84,7 +86,10 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
         unsigned* const census = p.flags + RP_MAIL_WORDS;
         const unsigned sl = __hip_atomic_fetch_add(census + (p.parity * RP_NG + grp) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sl == 0) __hip_atomic_store(census + ((p.parity ^ 1) * RP_NG + grp) * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's set
-        if (sl >= (unsigned)RP_SLOTS) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (sl >= (unsigned)RP_SLOTS) {
+            __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.skip) __hip_atomic_store(p.skip, p.skip_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         s_slot = sl;
     }
     __syncthreads();
@@ -137,8 +142,20 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
                 unsigned v = want;
                 if (lane < 16) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((int)(v - want) >= 0)) break;
-                if (++spins > (1 << 18)) { dead = true; if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                if (++spins > (1 << 18)) {
+                    dead = true;
+                    if (lane == 0) {
+                        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (p.skip) __hip_atomic_store(p.skip, p.skip_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
             }
+            // compiler barrier: the state loads below may not be hoisted above (or merged across) the poll — the producers' slices are only valid
+            // once their words matched.  No hardware fence: the loads are `sc1` (served by the L2, the coherence point of producer and consumer),
+            // they are issued after the poll's values have returned (the loop exit depends on them), and an agent-scope acquire would add a
+            // ~1.7 us L1 invalidate to each of the 31 steps (MI355X_MICROARCH.md, fence table) for data the L1 never holds
+            asm volatile("" ::: "memory");
         }
         RP_STAMP(1);
         // ---- B fragments: window li, k = 256 wave + 32 ks + 8 gq (sc1: past the L1, which other CUs' stores never refresh; served by the XCD's L2)

@@ -272,6 +272,13 @@ class StepEngine:
         self.adam_t += 1
         L.check(self.lib.hulc_adam_step(self.ctx, lr, b1, b2, eps, self.adam_t, grad_scale))
 
+    def optimizer_step(self, kind="adam", lr=2e-4, b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0, momentum=0.0, dampening=0.0, nesterov=False, grad_scale=1.0):
+        """hulc_optimizer_step: torch.optim.Adam / AdamW / SGD (conf/model/optimizer/*.yaml) over the flat buffers; `adam_t` counts the calls."""
+        self.adam_t += 1
+        o = L.HulcOptim(kind=L.OPTIM[kind], lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=weight_decay, momentum=momentum, dampening=dampening,
+                        nesterov=int(bool(nesterov)), step=self.adam_t, grad_scale=grad_scale)
+        L.check(self.lib.hulc_optimizer_step(self.ctx, C.byref(o)))
+
     # ---- data-parallel gradient all-reduce owned by the library (RCCL over xGMI, include/hulc_hip.h: hulc_comm_*) ---------------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -35,13 +35,20 @@ def _get(cfg, key, default=None):
 
 
 class FusedAdam:
-    """Optimizer handle with the torch.optim surface Lightning touches (step / zero_grad / param_groups / state_dict)."""
+    """Optimizer handle with the torch.optim surface Lightning touches (step / zero_grad / param_groups / state_dict).
 
-    def __init__(self, module: "Hulc", lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
-        if weight_decay:
-            raise NotImplementedError("weight_decay != 0 is not implemented by the fused Adam kernel (reference default is 0)")
-        self.module = module
-        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, params=list(module.parameters()))]
+    `kind` selects what the reference's conf tree can instantiate at hulc.py:239-240: "adam" (torch.optim.Adam, conf/model/optimizer/adam.yaml;
+    weight_decay = L2), "adamw" (torch.optim.AdamW, adamw.yaml: decoupled decay), "sgd" (torch.optim.SGD, sgd.yaml: momentum buffer = the
+    first-moment buffer).  One fused pass over the flat buffers either way (hulc_optimizer_step)."""
+
+    def __init__(self, module: "Hulc", lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, kind: str = "adam",
+                 momentum: float = 0.0, dampening: float = 0.0, nesterov: bool = False):
+        if kind not in ("adam", "adamw", "sgd"):
+            raise NotImplementedError(f"optimizer kind {kind!r}")
+        self.module, self.kind = module, kind
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=float(weight_decay), momentum=float(momentum), dampening=float(dampening),
+                                  nesterov=bool(nesterov), params=list(module.parameters()))]
+        self.param_groups[0]["initial_lr"] = lr
 
     def zero_grad(self, set_to_none: bool = False):
         self.module.engine.zero_grads()
@@ -56,7 +63,11 @@ class FusedAdam:
             else:
                 parallel.allreduce_sum_(self.module.engine.flat_grads)
         self.module._grads_reduced = False
-        self.module.engine.adam_step(lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], grad_scale=1.0 / world)
+        if self.kind == "adam" and not g["weight_decay"]:
+            self.module.engine.adam_step(lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], grad_scale=1.0 / world)
+        else:
+            self.module.engine.optimizer_step(self.kind, lr=g["lr"], b1=g["betas"][0], b2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                                              momentum=g["momentum"], dampening=g["dampening"], nesterov=g["nesterov"], grad_scale=1.0 / world)
         return loss
 
     def state_dict(self):
@@ -86,18 +97,73 @@ class FusedAdam:
                 e.scaler_load(float(st["scale"]), int(st["growth_tracker"]), int(sd["step"]))
 
 
-class ConstantSchedule:
-    """transformers.get_constant_schedule (conf/model/lr_scheduler/constant.yaml:1) == LambdaLR(lambda _: 1.0)."""
+class LambdaSchedule:
+    """torch.optim.lr_scheduler.LambdaLR as transformers' schedule factories build it: lr = initial_lr * f(last_epoch), evaluated once at
+    construction (last_epoch 0) and after every .step().  The learning rate is a per-call argument of hulc_adam_step / hulc_optimizer_step,
+    so a schedule is host-side arithmetic only."""
 
-    def __init__(self, optimizer: FusedAdam):
-        self.optimizer = optimizer
+    def __init__(self, optimizer: FusedAdam, fn):
+        self.optimizer, self.fn = optimizer, fn
+        self.base_lrs = [g.setdefault("initial_lr", g["lr"]) for g in optimizer.param_groups]
         self.last_epoch = 0
+        self._apply()
+
+    def _apply(self):
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = b * self.fn(self.last_epoch)
 
     def step(self):
         self.last_epoch += 1
+        self._apply()
 
     def get_last_lr(self):
         return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lrs": list(self.base_lrs)}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = int(sd["last_epoch"])
+        self.base_lrs = list(sd.get("base_lrs", self.base_lrs))
+        self._apply()
+
+
+class ConstantSchedule(LambdaSchedule):
+    """transformers.get_constant_schedule (conf/model/lr_scheduler/constant.yaml:1) == LambdaLR(lambda _: 1.0)."""
+
+    def __init__(self, optimizer: FusedAdam):
+        super().__init__(optimizer, lambda _step: 1.0)
+
+
+class LinearWarmupSchedule(LambdaSchedule):
+    """transformers.get_linear_schedule_with_warmup (conf/model/lr_scheduler/linear_schedule_with_warmup.yaml): linear 0 -> 1 over the warm-up,
+    then linear 1 -> 0 at num_training_steps."""
+
+    def __init__(self, optimizer: FusedAdam, num_warmup_steps: int, num_training_steps: int):
+        w, n = int(num_warmup_steps), int(num_training_steps)
+
+        def fn(step):
+            if step < w:
+                return float(step) / float(max(1, w))
+            return max(0.0, float(n - step) / float(max(1, n - w)))
+
+        super().__init__(optimizer, fn)
+
+
+class CosineWarmupSchedule(LambdaSchedule):
+    """transformers.get_cosine_schedule_with_warmup (conf/model/lr_scheduler/cosine_schedule_with_warmup.yaml: num_cycles 0.5)."""
+
+    def __init__(self, optimizer: FusedAdam, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5):
+        import math
+        w, n, c = int(num_warmup_steps), int(num_training_steps), float(num_cycles)
+
+        def fn(step):
+            if step < w:
+                return float(step) / float(max(1, w))
+            progress = float(step - w) / float(max(1, n - w))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * c * 2.0 * progress)))
+
+        super().__init__(optimizer, fn)
 
 
 class Hulc(torch.nn.Module):
@@ -329,18 +395,72 @@ class Hulc(torch.nn.Module):
     def on_fit_start(self) -> None:
         """hulc.py:697-737 only builds CLIP-plot metadata from the datamodule (not used for training): no-op here."""
 
+    @property
+    def num_training_steps(self) -> int:
+        """hulc.py:189-216: total optimizer steps inferred from the trainer and its datamodule — (batches per epoch // (accumulation x devices))
+        x max_epochs, capped by max_steps.  This package's Trainer attaches itself as `module.trainer` (with `.datamodule`) before it calls
+        configure_optimizers, like Lightning does."""
+        tr = getattr(self, "trainer", None)
+        if tr is None:
+            raise RuntimeError("num_training_steps needs module.trainer (set by Trainer.fit); pass lr_scheduler.num_training_steps >= 0 otherwise")
+        dm = getattr(tr, "datamodule", None)
+        if hasattr(dm, "steps_per_epoch"):
+            dataset_size = int(dm.steps_per_epoch)
+        else:
+            loaders = dm.train_dataloader()
+            dataset_size = max(len(loaders[k]) for k in loaders) if isinstance(loaders, dict) else len(loaders)
+        ltb = getattr(tr, "limit_train_batches", None)
+        if isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0:
+            dataset_size = ltb
+        elif isinstance(ltb, float):
+            dataset_size = int(dataset_size * ltb)
+        num_devices = max(1, int(getattr(tr, "world", 1)))
+        effective = int(getattr(tr, "accumulate_grad_batches", 1)) * num_devices
+        max_estimated = (dataset_size // effective) * int(tr.max_epochs)
+        if tr.max_steps and 0 < tr.max_steps < max_estimated:
+            return int(tr.max_steps)
+        return max_estimated
+
+    def compute_warmup(self, num_training_steps: int, num_warmup_steps):
+        """hulc.py:218-237: num_training_steps < 0 -> inferred; a float num_warmup_steps is a fraction of the training steps."""
+        if num_training_steps < 0:
+            num_training_steps = self.num_training_steps
+        if isinstance(num_warmup_steps, float):
+            num_warmup_steps *= num_training_steps
+        return int(num_training_steps), int(num_warmup_steps)
+
     def configure_optimizers(self):
-        """hulc.py:239-252: Adam over all parameters + per-step scheduler."""
+        """hulc.py:239-252: the optimizer of conf/model/optimizer/*.yaml over all parameters + the per-step scheduler of conf/model/lr_scheduler/*.yaml."""
         oc = self.optimizer_config
         tgt = str(_get(oc, "_target_", "torch.optim.Adam"))
-        if not tgt.endswith("Adam"):
-            raise NotImplementedError(f"optimizer {tgt}: only torch.optim.Adam (conf/model/optimizer/adam.yaml) has a fused kernel")
-        opt = FusedAdam(self, lr=float(_get(oc, "lr", 2e-4)), betas=tuple(_get(oc, "betas", (0.9, 0.999))), eps=float(_get(oc, "eps", 1e-8)),
-                        weight_decay=float(_get(oc, "weight_decay", 0.0) or 0.0))
-        sc = str(_get(self.lr_scheduler, "_target_", "transformers.get_constant_schedule"))
-        if "constant_schedule" not in sc or "warmup" in sc:
-            raise NotImplementedError(f"lr scheduler {sc}: only the constant schedule (conf/model/lr_scheduler/constant.yaml) is built")
-        return {"optimizer": opt, "lr_scheduler": {"scheduler": ConstantSchedule(opt), "interval": "step", "frequency": 1}}
+        lr, wd = float(_get(oc, "lr", 2e-4)), _get(oc, "weight_decay", None)
+        if tgt.endswith(".AdamW") or tgt == "AdamW":
+            opt = FusedAdam(self, lr=lr, betas=tuple(_get(oc, "betas", (0.9, 0.999))), eps=float(_get(oc, "eps", 1e-8)),
+                            weight_decay=float(1e-2 if wd is None else wd), kind="adamw")          # torch.optim.AdamW's default decay is 1e-2
+        elif tgt.endswith(".Adam") or tgt == "Adam":
+            opt = FusedAdam(self, lr=lr, betas=tuple(_get(oc, "betas", (0.9, 0.999))), eps=float(_get(oc, "eps", 1e-8)), weight_decay=float(wd or 0.0))
+        elif tgt.endswith(".SGD") or tgt == "SGD":
+            opt = FusedAdam(self, lr=lr, weight_decay=float(wd or 0.0), kind="sgd", momentum=float(_get(oc, "momentum", 0.0) or 0.0),
+                            dampening=float(_get(oc, "dampening", 0.0) or 0.0), nesterov=bool(_get(oc, "nesterov", False)))
+        else:
+            raise NotImplementedError(f"optimizer {tgt}: the reference ships torch.optim.Adam / AdamW / SGD (conf/model/optimizer/*.yaml)")
+        ls = self.lr_scheduler
+        sc = str(_get(ls, "_target_", "transformers.get_constant_schedule"))
+        if _get(ls, "num_warmup_steps", None) is not None:
+            n, w = self.compute_warmup(int(_get(ls, "num_training_steps", -1)), _get(ls, "num_warmup_steps", 0))
+            if parallel.rank() == 0:
+                print(f"[hulc_amd] Inferring number of training steps, set to {n}; warm-up steps {w}", flush=True)
+            if "cosine_schedule_with_warmup" in sc:
+                sched = CosineWarmupSchedule(opt, w, n, float(_get(ls, "num_cycles", 0.5)))
+            elif "linear_schedule_with_warmup" in sc:
+                sched = LinearWarmupSchedule(opt, w, n)
+            else:
+                raise NotImplementedError(f"lr scheduler {sc}: the reference ships the constant, linear-warmup and cosine-warmup schedules")
+        elif "constant_schedule" in sc and "warmup" not in sc:
+            sched = ConstantSchedule(opt)
+        else:
+            raise NotImplementedError(f"lr scheduler {sc}: the reference ships the constant, linear-warmup and cosine-warmup schedules")
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
 
     @staticmethod
     def _modality_batch(dataset_batch: Dict[str, Any], is_lang: bool, device) -> Dict[str, Any]:

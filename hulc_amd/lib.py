@@ -36,6 +36,14 @@ class HulcRolloutObs(C.Structure):
     _fields_ = [("rgb_static", C.c_void_p), ("rgb_gripper", C.c_void_p), ("robot_obs_raw", C.c_void_p)]
 
 
+class HulcOptim(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("momentum", C.c_float), ("dampening", C.c_float), ("nesterov", C.c_int32), ("step", C.c_int64), ("grad_scale", C.c_float)]
+
+
+OPTIM = {"adam": 0, "adamw": 1, "sgd": 2}
+
+
 class HulcSbertConfig(C.Structure):
     _fields_ = [("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("intermediate", C.c_int32), ("vocab", C.c_int32),
                 ("max_position", C.c_int32), ("max_sentences", C.c_int32), ("max_tokens", C.c_int32), ("normalize", C.c_int32), ("ln_eps", C.c_float)]
@@ -43,7 +51,7 @@ class HulcSbertConfig(C.Structure):
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_forward_loss", "hulc_forward_loss_pair", "hulc_backward", "hulc_backward_part",
-           "hulc_adam_step", "hulc_comm_unique_id", "hulc_comm_prepare", "hulc_comm_init", "hulc_comm_destroy", "hulc_comm_buckets", "hulc_comm_stats", "hulc_allreduce_grads", "hulc_backward_allreduce", "hulc_scaler_enable", "hulc_scaler_get", "hulc_scaler_set", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_set_option", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny", "hulc_k_attention", "hulc_k_rnn_persist", "hulc_k_rnn_persist_flag_words"]
+           "hulc_adam_step", "hulc_optimizer_step", "hulc_comm_unique_id", "hulc_comm_prepare", "hulc_comm_init", "hulc_comm_destroy", "hulc_comm_buckets", "hulc_comm_stats", "hulc_comm_timeline", "hulc_allreduce_grads", "hulc_backward_allreduce", "hulc_scaler_enable", "hulc_scaler_get", "hulc_scaler_set", "hulc_validate", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_set_option", "hulc_get_option", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv_tile", "hulc_k_skinny", "hulc_k_attention", "hulc_k_rnn_persist", "hulc_k_rnn_persist_flag_words"]
 
 _lib = None
 
@@ -75,12 +83,14 @@ def load():
     lib.hulc_backward.argtypes = [C.c_void_p]
     lib.hulc_backward_part.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_adam_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float]
+    lib.hulc_optimizer_step.argtypes = [C.c_void_p, C.POINTER(HulcOptim)]
     lib.hulc_comm_unique_id.argtypes = [C.c_void_p, C.c_int64]
     lib.hulc_comm_prepare.argtypes = [C.c_void_p]
     lib.hulc_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.hulc_comm_destroy.argtypes = [C.c_void_p]
     lib.hulc_comm_buckets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.hulc_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.hulc_comm_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double)]
     lib.hulc_allreduce_grads.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_backward_allreduce.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_scaler_enable.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32]
@@ -99,6 +109,7 @@ def load():
     lib.hulc_set_dropout.argtypes = [C.c_void_p, C.c_float]
     lib.hulc_timers_enable.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
     lib.hulc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.hulc_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     lib.hulc_k_rnn_persist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.hulc_k_rnn_persist_flag_words.restype = C.c_int32
     lib.hulc_timers_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int32]

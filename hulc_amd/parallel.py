@@ -38,6 +38,10 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 0) -> torch.Tensor:
     """In-place SUM all-reduce of the flat gradient buffer.  bucket_elems=0 -> one collective; otherwise contiguous
     buckets of that many elements issued back to back (async), which lets RCCL pipeline reduce-scatter/all-gather phases."""

@@ -111,13 +111,14 @@ class ModelCheckpoint:
             return
         os.makedirs(os.path.join(trainer.log_dir, self.dirpath), exist_ok=True)
         path = os.path.join(trainer.log_dir, self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt")
-        save_checkpoint(path, module, trainer.optimizer, trainer.current_epoch, trainer.global_step)
+        save_checkpoint(path, module, trainer.optimizer, trainer.current_epoch, trainer.global_step, getattr(trainer, "lr_scheduler", None))
 
 
-def save_checkpoint(path, module, optimizer, epoch, global_step):
+def save_checkpoint(path, module, optimizer, epoch, global_step, lr_scheduler=None):
     """Lightning-style checkpoint dict; `state_dict` keys are the reference's."""
     torch.save({"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in module.state_dict().items()},
                 "optimizer_states": [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()}],
+                "lr_schedulers": [lr_scheduler.state_dict()] if lr_scheduler is not None and hasattr(lr_scheduler, "state_dict") else [],
                 "hyper_parameters": {"kind": module.kind, "use_clip_auxiliary_loss": module.use_clip_auxiliary_loss, "precision": module.precision,
                                      "rnn_type": module.dims.rnn_type, "max_window": module.dims.max_window}}, path)
 
@@ -131,8 +132,11 @@ def get_last_checkpoint(log_dir: str) -> Optional[str]:
 # ---------------------------------------------------------------------------------------------------------------------
 class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_dir: str = "./runs", callbacks: Optional[List] = None,
-                 log_every: int = 10, limit_val_batches: Optional[int] = None, check_val_every_n_epoch: int = 1, **_unused):
+                 log_every: int = 10, limit_val_batches: Optional[int] = None, check_val_every_n_epoch: int = 1, limit_train_batches=None,
+                 accumulate_grad_batches: int = 1, **_unused):
         self.max_epochs, self.max_steps, self.log_dir = int(max_epochs), int(max_steps), log_dir
+        self.limit_train_batches, self.accumulate_grad_batches = limit_train_batches, max(1, int(accumulate_grad_batches or 1))
+        self.datamodule = None
         self.limit_val_batches, self.check_val_every_n_epoch = limit_val_batches, max(1, int(check_val_every_n_epoch or 1))
         self.val_history: List[Dict[str, float]] = []
         self.callbacks = callbacks or []
@@ -166,8 +170,11 @@ class Trainer:
 
     def fit(self, module, datamodule, ckpt_path: Optional[str] = None):
         self.rank, self.world, self.local = parallel.init_from_env()
+        self.datamodule = datamodule
+        module.trainer = self                      # Lightning attaches the trainer before configure_optimizers (Hulc.num_training_steps reads it)
         oc = module.configure_optimizers()
         self.optimizer, sched = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        self.lr_scheduler = sched
         if ckpt_path:
             ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
             hp = ck.get("hyper_parameters") or {}
@@ -178,6 +185,8 @@ class Trainer:
                 print(f"[hulc_amd] resuming from {ckpt_path} (epoch {ck.get('epoch')}, global_step {ck.get('global_step')})", flush=True)
             module.load_state_dict(ck["state_dict"])
             self.optimizer.load_state_dict({k: (v.to(module.device) if torch.is_tensor(v) else v) for k, v in ck["optimizer_states"][0].items()})
+            if ck.get("lr_schedulers") and hasattr(sched, "load_state_dict"):
+                sched.load_state_dict(ck["lr_schedulers"][0])
             self.current_epoch, self.global_step = ck["epoch"] + 1, ck["global_step"]
             module.global_step = self.global_step
         module.on_fit_start()

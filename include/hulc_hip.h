@@ -121,6 +121,23 @@ int hulc_backward(hulc_ctx* ctx);
 int hulc_backward_part(hulc_ctx* ctx, int32_t part);
 /* Adam over the whole flat buffer; grad_scale (e.g. 1/world_size) is folded in. step counts from 1. */
 int hulc_adam_step(hulc_ctx* ctx, float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale);
+/* The other optimizers the reference's conf tree ships (conf/model/optimizer/{adam,adamw,sgd}.yaml, instantiated by
+ * hulc/models/hulc.py:239-240), same single pass over the flat buffers and the same fp16 loss-scaler handling as hulc_adam_step:
+ *   HULC_OPT_ADAM   torch.optim.Adam   (weight_decay = L2: g += wd * p)         — hulc_adam_step == this with weight_decay 0
+ *   HULC_OPT_ADAMW  torch.optim.AdamW  (decoupled: p *= 1 - lr * wd, then Adam)
+ *   HULC_OPT_SGD    torch.optim.SGD    (g += wd * p; buf = momentum * buf + (1 - dampening) * g, buf = g on step 1; nesterov: g + momentum * buf);
+ *                   the momentum buffer is the bound `adam_m` buffer, `adam_v` is untouched.
+ * lr is a per-call argument: the warm-up schedules (conf/model/lr_scheduler/*.yaml, hulc.py:218-252) are host-side arithmetic. */
+enum { HULC_OPT_ADAM = 0, HULC_OPT_ADAMW = 1, HULC_OPT_SGD = 2 };
+typedef struct hulc_optim {
+    int32_t kind;
+    float lr, beta1, beta2, eps, weight_decay;
+    float momentum, dampening;
+    int32_t nesterov;
+    int64_t step;                /* counts from 1 */
+    float grad_scale;            /* e.g. 1 / world_size */
+} hulc_optim;
+int hulc_optimizer_step(hulc_ctx* ctx, const hulc_optim* opt);
 
 /* ---- Data-parallel gradient all-reduce, owned by the library (replaces Lightning's DDPStrategy, hulc/training.py:64-69: mean of the
  * per-rank gradients; the 1/world factor is hulc_adam_step's grad_scale).  RCCL over xGMI on a private high-priority stream, ordered
@@ -144,6 +161,11 @@ int hulc_comm_init(hulc_ctx* ctx, const void* unique_id_host, int32_t rank, int3
 int hulc_comm_destroy(hulc_ctx* ctx);
 int hulc_comm_buckets(hulc_ctx* ctx, int64_t* lo, int64_t* hi, int32_t cap);      /* returns the number of buckets, < 0 on error */
 int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes_on_wire_per_rank);
+/* With hulc_set_option(ctx, "comm_timing", 1): the LAST hulc_backward_allreduce's buckets as seen by events on the collectives' stream.
+ * out[4 i .. 4 i + 3] = {start_us, end_us of bucket i's collective relative to the END of the backward on the context's stream (negative =
+ * that much of it ran hidden under the backward), bytes on the wire per rank, bucket index}; *backward_us = the backward's own duration.
+ * Synchronises both streams.  Returns the number of buckets written (<= cap_buckets), < 0 on error. */
+int hulc_comm_timeline(hulc_ctx* ctx, double* out, int32_t cap_buckets, double* backward_us);
 int hulc_allreduce_grads(hulc_ctx* ctx, int32_t bucket_dtype);
 int hulc_backward_allreduce(hulc_ctx* ctx, int32_t bucket_dtype);
 
@@ -240,6 +262,12 @@ int hulc_set_dropout(hulc_ctx* ctx, float p);
  * several processes share one GPU).  "fused_transformer" (default 1): one launch per plan-recognition encoder layer in the forward of the
  * 16-bit engines (csrc/tr_fused.h; plan_recognition_net.py:98-117), 0 = the unfused kernels.  Returns non-zero for an unknown name. */
 int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value);
+/* Reads an option back.  Besides the settable names: "persistent_rnn" reports the EFFECTIVE state (0 once a persistent launch failed its census or
+ * timed out — the context then runs one launch per time step; a failed launch never reaches the weights: its optimizer step skips itself on the
+ * device, and calls that end in a synchronisation are run again), "persistent_rnn_fallbacks" counts such events.  More settable names:
+ * "persist_under_comm" (default 0: recurrences that follow an issued bucket of hulc_backward_allreduce run one launch per step, because RCCL's
+ * kernels hold CUs), "comm_timing" (hulc_comm_timeline), "debug_poison_partials" (tests). */
+int hulc_get_option(hulc_ctx* ctx, const char* name, int64_t* value);
 
 /* HIP-event timers around the launches of each kernel class, recorded on the context's stream (bench.py's roofline leg).
  * hulc_timers_read synchronises and writes a JSON object {"class": {"bound","launches","ms","flops","bytes"}} (algorithmic

@@ -35,14 +35,15 @@ def test_ctypes_struct_layout_matches_header(tmp_path):
     assert lib.HulcConfig.seed.offset == 48
     src = tmp_path / "layout.c"
     fields = {"hulc_batch": [f[0] for f in lib.HulcBatch._fields_], "hulc_val_noise": [f[0] for f in lib.HulcValNoise._fields_],
-              "hulc_rollout_obs": [f[0] for f in lib.HulcRolloutObs._fields_], "hulc_config": [f[0] for f in lib.HulcConfig._fields_]}
+              "hulc_rollout_obs": [f[0] for f in lib.HulcRolloutObs._fields_], "hulc_config": [f[0] for f in lib.HulcConfig._fields_],
+              "hulc_optim": [f[0] for f in lib.HulcOptim._fields_]}
     body = "".join(f'printf("{st} %zu\\n", sizeof({st}));' + "".join(f'printf("{st}.{fl} %zu\\n", offsetof({st}, {fl}));' for fl in fls)
                    for st, fls in fields.items())
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hulc_hip.h"\nint main(void) {' + body + "return 0; }\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    mirrors = {"hulc_batch": lib.HulcBatch, "hulc_val_noise": lib.HulcValNoise, "hulc_rollout_obs": lib.HulcRolloutObs, "hulc_config": lib.HulcConfig}
+    mirrors = {"hulc_batch": lib.HulcBatch, "hulc_val_noise": lib.HulcValNoise, "hulc_rollout_obs": lib.HulcRolloutObs, "hulc_config": lib.HulcConfig, "hulc_optim": lib.HulcOptim}
     for st, cls in mirrors.items():
         assert ctypes.sizeof(cls) == int(out[st]), st
         for fl in fields[st]:

@@ -376,3 +376,36 @@ def test_row_split_weight_gradients_at_ragged_row_counts(Bb, Ss):
     assert not bad, bad
     # a dropped or doubled row chunk would show up as an O(1) error on every one of these tensors; measured: median 1e-2, worst 8e-2 (the static fc1 weight behind the spatial softmax)
     assert np.median(list(worst.values())) < 0.03, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("dtype,Bb,Ss", [("bf16", 9, 32), ("fp16", 4, 8), ("bf16", 64, 32)])
+def test_weight_gradient_slabs_are_written_before_they_are_summed(dtype, Bb, Ss):
+    """the slab arena of the row-split weight gradients is never zeroed, so a slab cell that is added to instead of stored
+    picks up whatever an earlier launch left there — the gripper fc7 job's ragged last k-tile (K = 3136 = 24 x 128 + 64) did.  The arena is
+    NaN-filled before the backward (debug_poison_partials): every gradient must stay finite and equal the unpoisoned run (same atomics-free
+    slab sums: exact for the slab-reduced tensors; the atomically reduced ones to rounding)."""
+    dev = torch.device("cuda:0")
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    mb = synth_batch(Bb, Ss, dev, seed=7)
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    mb["plan_idx"] = torch.randint(0, 32, (Bb, 32), device=dev, generator=g, dtype=torch.int32)
+    eng = StepEngine(dims, Bb, Ss, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=3)
+    eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+    _, g0 = _step(eng, mb)
+    g0 = g0.clone()
+    eng.set_option("debug_poison_partials", 1)
+    _, g1 = _step(eng, mb)
+    eng.set_option("debug_poison_partials", 0)
+    assert torch.isfinite(g1).all(), "a weight-gradient slab was read before it was written"
+    lay, _ = spec.layout(dims)
+    for name, (off, shape) in lay.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        a, b = g1[off:off + n].double(), g0[off:off + n].double()
+        err = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        assert err < 2e-3, (name, err)
+        if "rgb_gripper_encoder.conv_model.7.weight" in name:          # per column block of 64: the ragged tile is the last one
+            A, Bm = a.view(128, 3136), b.view(128, 3136)
+            for c0 in range(0, 3136, 64):
+                e = ((A[:, c0:c0 + 64] - Bm[:, c0:c0 + 64]).norm() / (Bm[:, c0:c0 + 64].norm() + 1e-30)).item()
+                assert e < 2e-3, (name, c0, e)
+    eng.close()

@@ -232,7 +232,11 @@ def test_attention_kernels(variant, S, drop_p):
 # Shapes: both cameras (static 23 / 49, gripper 9 / 20 with stacked frames), Nf not a multiple of the stack, > 256 frames (several items per workgroup)
 @pytest.mark.parametrize("IH,CI,KH,S,mode,Nf", [(23, 64, 3, 1, 10, 1), (23, 64, 3, 1, 10, 7), (23, 64, 3, 1, 10, 530), (9, 64, 3, 1, 10, 1), (9, 64, 3, 1, 10, 7), (9, 64, 3, 1, 10, 1501),
                                                 (49, 32, 4, 2, 11, 1), (49, 32, 4, 2, 11, 7), (49, 32, 4, 2, 11, 300), (20, 32, 4, 2, 11, 1), (20, 32, 4, 2, 11, 7), (20, 32, 4, 2, 11, 1027),
-                                                (49, 32, 4, 2, 17, 5), (20, 32, 4, 2, 17, 1027), (31, 64, 3, 1, 10, 3), (30, 32, 4, 2, 11, 3)])
+                                                (49, 32, 4, 2, 17, 5), (20, 32, 4, 2, 17, 1027), (31, 64, 3, 1, 10, 3), (30, 32, 4, 2, 11, 3),
+                                                # modes 20 / 21 / 27: the same kernels as two 256-thread workgroups per CU (round 4; > 512 frames = several items per workgroup)
+                                                (23, 64, 3, 1, 20, 1), (23, 64, 3, 1, 20, 7), (23, 64, 3, 1, 20, 1100), (9, 64, 3, 1, 20, 1), (9, 64, 3, 1, 20, 7), (9, 64, 3, 1, 20, 2051),
+                                                (49, 32, 4, 2, 21, 1), (49, 32, 4, 2, 21, 7), (49, 32, 4, 2, 21, 600), (20, 32, 4, 2, 21, 1), (20, 32, 4, 2, 21, 7), (20, 32, 4, 2, 21, 1027),
+                                                (49, 32, 4, 2, 27, 5), (20, 32, 4, 2, 27, 2051), (31, 64, 3, 1, 20, 3), (30, 32, 4, 2, 21, 3)])
 def test_conv_reg_fwd(IH, CI, KH, S, mode, Nf):
     L, lib = _lib()
     rng = np.random.default_rng(IH * 10 + Nf)
@@ -242,7 +246,7 @@ def test_conv_reg_fwd(IH, CI, KH, S, mode, Nf):
     b = rng.standard_normal(64).astype(np.float32)
     wf = bf(Wb.transpose(0, 2, 3, 1).reshape(64, -1))
     out = torch.full((Nf, OH, OH, 64), 7.0, device="cuda", dtype=torch.bfloat16)       # every output must be overwritten
-    bits = torch.full((Nf, OH, OH, 2), -1, device="cuda", dtype=torch.int32) if mode == 17 else None
+    bits = torch.full((Nf, OH, OH, 2), -1, device="cuda", dtype=torch.int32) if mode in (17, 27) else None
     L.check(lib.hulc_k_conv_tile(mode, X.data_ptr(), wf.data_ptr(), torch.from_numpy(b).cuda().data_ptr(), bits.data_ptr() if bits is not None else None,
                                  out.data_ptr(), Nf, IH, OH, 1, None))
     torch.cuda.synchronize()
@@ -258,7 +262,8 @@ def test_conv_reg_fwd(IH, CI, KH, S, mode, Nf):
 
 # conv3's data gradient on the weights-in-registers kernel (conv_reg.h, REV form): mode 12 = 16-bit mask values, 18 = the production ReLU bitmask.
 # IH = the layer INPUT size (output of the gradient); 23 / 9 = the two cameras, 31 = two bands per frame; stacked frames with a short last stack
-@pytest.mark.parametrize("IH,Nf,mode", [(23, 1, 12), (23, 7, 12), (23, 530, 18), (9, 1, 12), (9, 7, 18), (9, 1501, 18), (31, 3, 12), (31, 5, 18)])
+@pytest.mark.parametrize("IH,Nf,mode", [(23, 1, 12), (23, 7, 12), (23, 530, 18), (9, 1, 12), (9, 7, 18), (9, 1501, 18), (31, 3, 12), (31, 5, 18),
+                                        (23, 1, 22), (23, 7, 22), (23, 1100, 28), (9, 1, 22), (9, 7, 28), (9, 2051, 28), (31, 3, 22), (31, 5, 28)])    # 22 / 28: two workgroups per CU
 def test_conv_reg_dgrad3(IH, Nf, mode):
     L, lib = _lib()
     rng = np.random.default_rng(IH * 7 + Nf)
@@ -271,7 +276,7 @@ def test_conv_reg_dgrad3(IH, Nf, mode):
             wd[0, :, kh, kw, :] = Wb[:, :, kh, kw].T
     maskv = rng.standard_normal((Nf, IH, IH, 64))
     dx = torch.full((Nf, IH, IH, 64), 7.0, device="cuda", dtype=torch.bfloat16)      # every pixel must be overwritten
-    if mode == 12:
+    if mode in (12, 22):
         m = bf(maskv)
     else:                                                                             # bit c%32 of word c/32 = (channel c > 0)
         bits = (maskv > 0).reshape(Nf, IH, IH, 2, 32).astype(np.int64)
@@ -279,13 +284,14 @@ def test_conv_reg_dgrad3(IH, Nf, mode):
         m = torch.from_numpy(np.ascontiguousarray(words)).cuda()
     L.check(lib.hulc_k_conv_tile(mode, dY.data_ptr(), bf(wd.reshape(64, -1)).data_ptr(), None, m.data_ptr(), dx.data_ptr(), Nf, OH, IH, 0, None))
     torch.cuda.synchronize()
-    ref = conv_dgrad_ref(f64(dY), Wb, 1, IH) * (maskv > 0 if mode == 18 else f64(m) > 0)
+    ref = conv_dgrad_ref(f64(dY), Wb, 1, IH) * (maskv > 0 if mode in (18, 28) else f64(m) > 0)
     err = np.abs(f64(dx) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
     assert err.max() < 6e-3, (err.max(), int(err.argmax()))
 
 
 # conv2's data gradient (4x4 stride 2 -> four parity classes of 2x2-tap correlations) on conv_reg.h: mode 13 = 16-bit mask, 19 = ReLU bitmask (1 word / pixel)
-@pytest.mark.parametrize("IH,Nf,mode", [(49, 1, 13), (49, 5, 19), (49, 300, 19), (20, 1, 13), (20, 7, 19), (20, 1027, 19), (30, 3, 13), (33, 2, 19)])
+@pytest.mark.parametrize("IH,Nf,mode", [(49, 1, 13), (49, 5, 19), (49, 300, 19), (20, 1, 13), (20, 7, 19), (20, 1027, 19), (30, 3, 13), (33, 2, 19),
+                                        (49, 1, 23), (49, 5, 29), (49, 600, 29), (20, 1, 23), (20, 7, 29), (20, 2051, 29), (30, 3, 23), (33, 2, 29)])    # 23 / 29: two workgroups per CU
 def test_conv_reg_dgrad2(IH, Nf, mode):
     L, lib = _lib()
     rng = np.random.default_rng(IH * 3 + Nf)
@@ -298,7 +304,7 @@ def test_conv_reg_dgrad2(IH, Nf, mode):
             wd[(kh % 2) * 2 + kw % 2, :, kh // 2, kw // 2, :] = Wb[:, :, kh, kw].T
     maskv = rng.standard_normal((Nf, IH, IH, 32))
     dx = torch.full((Nf, IH, IH, 32), 7.0, device="cuda", dtype=torch.bfloat16)
-    if mode == 13:
+    if mode in (13, 23):
         m = bf(maskv)
     else:
         bits = (maskv > 0).astype(np.int64)
@@ -306,7 +312,7 @@ def test_conv_reg_dgrad2(IH, Nf, mode):
         m = torch.from_numpy(np.ascontiguousarray(words)).cuda()
     L.check(lib.hulc_k_conv_tile(mode, dY.data_ptr(), bf(wd.reshape(4 * 32, -1)).data_ptr(), None, m.data_ptr(), dx.data_ptr(), Nf, OH, IH, 0, None))
     torch.cuda.synchronize()
-    ref = conv_dgrad_ref(f64(dY), Wb, 2, IH) * (maskv > 0 if mode == 19 else f64(m) > 0)
+    ref = conv_dgrad_ref(f64(dY), Wb, 2, IH) * (maskv > 0 if mode in (19, 29) else f64(m) > 0)
     err = np.abs(f64(dx) - ref).reshape(Nf, -1).max(1) / np.abs(ref).max()
     assert err.max() < 6e-3, (err.max(), int(err.argmax()))
 

@@ -111,7 +111,14 @@ w("model/action_decoder/hulc_default.yaml", dict(
     latent_goal_features="${model.visual_goal.latent_goal_features}", plan_features="???", perceptual_features="???"),
   H.format("action_decoder/hulc_default.yaml"))
 w("model/optimizer/adam.yaml", dict(_target_="torch.optim.Adam", lr="${training.lr}"), H.format("optimizer/adam.yaml"))
+w("model/optimizer/adamw.yaml", dict(_target_="torch.optim.AdamW", lr="${training.lr}", weight_decay=1.0e-6), H.format("optimizer/adamw.yaml"))
+w("model/optimizer/sgd.yaml", dict(_target_="torch.optim.SGD", lr="${training.lr}", momentum=0.9), H.format("optimizer/sgd.yaml"))
 w("model/lr_scheduler/constant.yaml", dict(_target_="transformers.get_constant_schedule"), H.format("lr_scheduler/constant.yaml"))
+# num_training_steps -1 = inferred from the trainer / datamodule (Hulc.num_training_steps); a float num_warmup_steps = fraction of the training steps
+w("model/lr_scheduler/cosine_schedule_with_warmup.yaml", dict(_target_="transformers.get_cosine_schedule_with_warmup", num_training_steps=-1,
+                                                               num_warmup_steps=0.1, num_cycles=0.5), H.format("lr_scheduler/cosine_schedule_with_warmup.yaml"))
+w("model/lr_scheduler/linear_schedule_with_warmup.yaml", dict(_target_="transformers.get_linear_schedule_with_warmup", num_training_steps=-1,
+                                                               num_warmup_steps=0.1), H.format("lr_scheduler/linear_schedule_with_warmup.yaml"))
 w("model/proj_vis_lang/default.yaml", dict(_target_="hulc.models.auxiliary_loss_networks.proj_vis_lang.ProjVisLang",
                                           im_dim="${model.plan_recognition.fc_hidden_size}", lang_dim="${model.language_goal.latent_goal_features}",
                                           output_dim="${model.language_goal.latent_goal_features}", proj_lang=True), H.format("proj_vis_lang/default.yaml"))
