@@ -32,6 +32,17 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_WINDOW_S32 = 13.02e9   # fwd+bwd algorithmic FLOPs per window at S=32
 
+# GEMM groups of the step (SURVEY §8(d) "per-group MFMA utilisation", north_star "MFMA utilisation against gfx950 peak"): the engine's HIP-event
+# kernel classes (csrc/engine.h TimerScope names) that make up each group.  `roofline` is taken on the heaviest GROUP (a group's classes are
+# timed together), not on whichever single class happens to be a few microseconds ahead in the survey pass.
+MFMA_GROUPS = {
+    "conv": ["conv_tile_fwd", "conv_tile_dgrad", "conv_wgrad_tr"],        # conv2 / conv3 forward, data and weight gradients (MFMA-bound by design)
+    "conv1": ["conv1_fwd", "conv1_wgrad"],                                # first-layer convolutions on the fp32 / uint8 boundary frames (HBM-bound)
+    "rnn_recurrent": ["rnn_persist", "rnn_step_gemm", "gru_step"],        # the recurrences' dependent M = B GEMMs
+    "rnn_batched": ["gemm_128x128"],                                      # the hoisted input projections / 2048^2 weight gradients (128 x 128 tiles)
+    "transformer_mlp": ["transformer_fused", "skinny_gemm_m64", "skinny_gemm_rows", "gemm_64x64_splitk"],
+}
+
 
 def synth_batch(B, S, dev, seed, lang=False, ingest="fp32"):
     g = torch.Generator(device=dev)
@@ -318,9 +329,16 @@ def main():
     for i in range(2):
         step(args.warmup + i)
     survey = eng.timers_read(reset=True)
-    dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0] if survey else ""
-    # timed region: events only around the dominant class (on the engine's stream), so the timers do not perturb the step
-    eng.timers_enable(True, dominant)
+
+    def group_sum(tm, classes):
+        rows = [tm[c] for c in classes if c in tm]
+        return dict(ms=sum(r["ms"] for r in rows), flops=sum(r["flops"] for r in rows), bytes=sum(r["bytes"] for r in rows),
+                    launches=sum(r["launches"] for r in rows), classes=[c for c in classes if c in tm], bounds=sorted({r["bound"] for r in rows})) if rows else None
+    groups = {g: group_sum(survey, cl) for g, cl in MFMA_GROUPS.items()}
+    groups = {g: v for g, v in groups.items() if v}
+    dom_group = max(groups.items(), key=lambda kv: kv[1]["ms"])[0] if groups else ""
+    # timed region: events only around the classes of the dominant GROUP (on the engine's stream), so the timers do not perturb the rest of the step
+    eng.timers_enable(True, ",".join(groups[dom_group]["classes"]) if dom_group else "")
     sc0 = eng.scaler_state() if args.dtype == "fp16" else None
     # one event per step boundary on the engine's stream (= torch's current stream): per-step device times for median / p10 / p90 next to the
     # wall-clock mean the contract's `ms_per_step` is (an event record costs no synchronisation and ~1 us of stream time)
@@ -345,12 +363,23 @@ def main():
 
     timers = eng.timers_read(reset=True)
     eng.timers_enable(False)
+    # N > 1: one more (untimed) step with events around every bucket's collective: when each bucket was issued / finished relative to the END of
+    # the backward on the engine stream (negative = hidden under the backward), per rank 0
+    comm_tl = None
+    if lib_comm:
+        eng.set_option("comm_timing", 1)
+        step(args.warmup + args.steps)
+        comm_tl = eng.comm_timeline()
+        eng.set_option("comm_timing", 0)
 
     def roofline(tm):
-        """Dominant kernel class by measured device time; achieved = algorithmic FLOPs (or bytes) / measured time."""
-        if not tm:
+        """The dominant GEMM group (all of its kernel classes, timed live by HIP events inside the timed region); achieved = the group's
+        algorithmic FLOPs (or bytes) / its measured device time.  `classes` breaks it down per kernel class."""
+        if not tm or not dom_group:
             return None
-        name, t = max(tm.items(), key=lambda kv: kv[1]["ms"])
+        t = group_sum(tm, MFMA_GROUPS[dom_group])
+        t["bound"] = "mfma" if "mfma" in t["bounds"] else "hbm"
+        name = dom_group
         sec = t["ms"] * 1e-3
         if t["bound"] == "mfma":
             ach, peak, unit = t["flops"] / sec / 1e12, MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "fp16") else 157.3, "TFLOP/s"
@@ -365,11 +394,16 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         if cands and args.dtype == "bf16" and not args.lang and args.model == "hulc" and S == 32:
             try:
-                traffic = json.load(open(cands[-1])).get(name)
+                tj = json.load(open(cands[-1]))
+                # bytes per launch, averaged over the group's launches (PMC bytes per launch of each class x its launches per step)
+                tb = [(tj.get(c), tm[c]["launches"]) for c in t["classes"]]
+                traffic = None if any(b is None for b, _ in tb) else sum(b * n for b, n in tb) / max(1, sum(n for _, n in tb))
                 traffic_source = os.path.relpath(cands[-1], ROOT)
             except Exception:
                 traffic = None
-        return {"kernel": name, "bound": t["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+        per_class = {c: {"ms_per_step": round(tm[c]["ms"] / args.steps, 4), "launches_per_step": tm[c]["launches"] / args.steps,
+                         "achieved": round((tm[c]["flops"] / 1e12 if t["bound"] == "mfma" else tm[c]["bytes"] / 1e9) / max(tm[c]["ms"] * 1e-3, 1e-12), 2)} for c in t["classes"]}
+        return {"kernel": name + " = " + " + ".join(t["classes"]), "classes": per_class, "bound": t["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": t["launches"] / args.steps, "avg_launch_us": round(t["ms"] * 1e3 / max(1, t["launches"]), 2),
                 "ms_per_step": round(t["ms"] / args.steps, 4),
                 "per_launch": {"algorithmic_flops": t["flops"] / max(1, t["launches"]), "algorithmic_bytes": t["bytes"] / max(1, t["launches"])}}
@@ -417,9 +451,13 @@ def main():
                         "min": round(float(per_step.min()), 4), "max": round(float(per_step.max()), 4), "windows_per_s_at_median": round(B * world / (float(np.median(per_step)) * 1e-3), 1)},
             "roofline_step": None if mcil else step_roofline(),
             "roofline": rl,
+            # per GEMM group (survey pass: HIP events around every class, 2 steps): algorithmic TFLOP/s and the fraction of the dense MFMA peak
+            "mfma_groups": {g: {"ms_per_step": round(v["ms"] / 2, 4), "launches_per_step": v["launches"] / 2, "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                "mfma_frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / (MFMA_BF16_PEAK_TFLOPS if args.dtype != "fp32" else 157.3), 4),
+                                "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1), "classes": v["classes"]} for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])},
             "allreduce": None if world == 1 else ({"path": "libhulc_hip RCCL (hulc_backward_allreduce)", "rccl_ranks": world, "bucket_dtype": args.bucket, "buckets": eng.comm_buckets(),
                                                   "bucket_bytes": [(hi - lo) * (4 if args.bucket == "fp32" else 2) for lo, hi in eng.comm_buckets()],
-                                                  "selfcheck": selfcheck, **eng.comm_stats()} if lib_comm else
+                                                  "selfcheck": selfcheck, "timeline": comm_tl, **eng.comm_stats()} if lib_comm else
                                                  {"path": "torch.distributed nccl (HULC_DP_COMM=%s)" % parallel.comm_mode(), "bucket_dtype": "fp32"}),
             "kernel_classes": kernel_classes,
             # fp16: GradScaler state after the timed steps; skipped_in_timed_region counts optimizer steps the scaler skipped (inf/nan) inside it

@@ -1083,6 +1083,8 @@ struct Engine : IEngine {
                     q.qkv = qkv[l]; q.Pat = Pat[l]; q.ao = ao[l]; q.y1 = y1[l]; q.st1 = st1[l]; q.x1t = x1t[l]; q.x1f = x1f[l]; q.hff = hff[l]; q.y2 = y2[l];
                     q.B = B; q.S = S; q.dp = dp;
                     q.seed_att = site_seed(1 + 4 * l); q.seed_o = site_seed(2 + 4 * l); q.seed_h = site_seed(3 + 4 * l); q.seed_y = site_seed(4 + 4 * l);
+                    // per token: QKV 3 x 128 x 128, out projection 128 x 128, FFN 2 x 128 x 2048, attention 2 x S x 128 MACs
+                    TimerScope ts(this, "transformer_fused", "mfma", 2.0 * N * (4.0 * EMB * EMB + 2.0 * EMB * FF + 2.0 * S * EMB), (double)N * (4 * EMB + FF) * sizeof(T));
                     launch_tr_layer_fwd(st, q);
                 }
                 ln_fwd(y2[1], EMB, N, EMB, tr_n2g[1], tr_n2b[1], xt[2], EMB, xf[2], EMB, st2[1]);
@@ -1529,6 +1531,7 @@ struct Engine : IEngine {
             p.X = X; p.W = Wm; p.res = res; p.mask = mask; p.B = B; p.S = S; p.q0 = q0; p.dq = dq; p.act = act;
             p.flags = rp_flags; p.base = rp_launches << 12; p.parity = (int)(rp_launches & 1u); p.err = rp_err_dev; p.stamps = nullptr;
             p.skip = rp_skip; p.skip_tag = opt_seq + 1;
+            if (rp_probed && persist_fault > 0) { p.fault = 1; --persist_fault; }
             ++rp_launches;
             TimerScope ts(this, "rnn_persist", "mfma", 2.0 * B * HID * HID * (S - 1), (double)HID * HID * sizeof(T) + 3.0 * S * B * HID * sizeof(T), 1);
             if (!launch_rnn_persist(st, p)) return false;
@@ -2207,7 +2210,10 @@ struct Engine : IEngine {
                         q.dx = bc ? dxm : dx; q.bcast = bc ? 1 : 0; q.bdiv = (float)S; q.y2 = y2[l]; q.st2 = st2[l]; q.n2g = tr_n2g[l]; q.dg2 = d_tr_n2g[l]; q.db2 = d_tr_n2b[l];
                         q.W2t = tr_l2[l].Wt; q.W1t = tr_l1[l].Wt; q.hff = hff[l]; q.dt_c = b_c; q.dt_a = b_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
                         q.seed_y = site_seed(4 + 4 * l);
-                        launch_tr_ffn_bwd(st, q);
+                        {
+                            TimerScope ts(this, "transformer_fused", "mfma", 2.0 * N * (2.0 * EMB * FF), (double)N * (2 * EMB + FF) * sizeof(T));
+                            launch_tr_ffn_bwd(st, q);
+                        }
                         if (defer_w) {
                             tr_wgrad_add(b_c, hff[l], tr_l2[l]); tr_wgrad_add(b_a, x1t[l], tr_l1[l]);
                         } else {

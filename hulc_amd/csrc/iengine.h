@@ -62,7 +62,7 @@ struct IEngine {
     virtual int64_t workspace_bytes() const = 0;
     virtual void set_kl_beta(float b) = 0;
     virtual void set_dropout(float p) = 0;
-    void set_timing(bool on, const char* filter) { timing = on; timing_filter = filter ? filter : ""; }
+    void set_timing(bool on, const char* filter) { timing = on; timing_filter = (filter && *filter) ? std::string(",") + filter + "," : std::string(); }
     // runtime options (hulc_set_option).  "persistent_rnn": 1 (default) = the 2048-wide recurrences of the 16-bit engines run as one
     // persistent launch each (rnn_persist.h) after a first launch has verified the XCD census on this device; 0 = one launch per time step
     // (what a process that SHARES the GPU's CUs with another process must choose: the persistent launch needs all 256 CUs resident)
@@ -72,7 +72,7 @@ struct IEngine {
     // kernels hold CUs; a persistent launch needs all of them); 1 = keep them persistent.  "comm_timing": 1 = hulc_backward_allreduce records events around
     // every bucket's collective and at the end of the backward (hulc_comm_timeline).  "debug_poison_partials": tests only — fills the weight-gradient
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0;
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0;
     virtual int get_option(const char* name, long long* value) = 0;
     int set_option(const char* name, long long value) {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
@@ -80,6 +80,7 @@ struct IEngine {
         if (name && !strcmp(name, "persist_under_comm")) { persist_under_comm = value != 0; return 0; }
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
+        if (name && !strcmp(name, "debug_persist_fault")) { persist_fault = (int)value; return 0; }      // tests: the next `value` persistent launches (after the probed first one) lose a producer
         hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
         return 1;
     }
@@ -88,13 +89,13 @@ struct IEngine {
     struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };
     std::map<std::string, KTimer> timers;
     bool timing = false;
-    std::string timing_filter;      // empty = every class; else only this class (keeps event overhead out of the timed region)
+    std::string timing_filter;      // empty = every class; else ",a,b,": only the listed classes (keeps event overhead out of the timed region)
     int timer_depth = 0;            // a group scope (e.g. the S recurrent steps) suppresses the per-launch scopes inside it
     struct TimerScope {
         IEngine* e; IEngine::KTimer* t;
         TimerScope(IEngine* e_, const char* name, const char* bound, double flops, double bytes, int nlaunch = 1) : e(e_), t(nullptr) {
             if (!e->timing || e->timer_depth > 0) return;
-            if (!e->timing_filter.empty() && e->timing_filter != name) return;
+            if (!e->timing_filter.empty() && e->timing_filter.find(std::string(",") + name + ",") == std::string::npos) return;
             e->timer_depth++;
             t = &e->timers[name];
             if (t->name.empty()) { t->name = name; t->bound = bound; }

@@ -57,6 +57,7 @@ struct RnnPersistP {
     unsigned* err;        // device-visible word (the engine maps a pinned host word): 1 = a poll timed out, 2 = an XCD held more than 32 workgroups
     unsigned* skip;       // device word or null: a failing launch stores `skip_tag` here — the optimizer kernel of the step this recurrence belongs to
     unsigned skip_tag;    // compares its own tag with the word and leaves the weights untouched (engine.h: persist_check)
+    int fault;            // tests (hulc_set_option debug_persist_fault): slot 0 of every XCD leaves at once — its consumers' bounded polls time out
     long long* stamps;    // RP_STAMPS builds (tools/rnn_persist_bench.hip): [S][2 waves][8] shader-clock stamps of workgroup 8
 };
 #ifdef RP_STAMPS
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     __syncthreads();
     const int slot = (int)s_slot;
     if (slot >= RP_SLOTS) return;                     // an over-populated XCD: the launch is reported failed
+    if (p.fault && slot == 0) return;                 // injected fault (tests): a producer that never posts
     const int t0 = grp * p.wpx;
     const int nwin = min(p.wpx, p.B - t0);
     if (nwin <= 0) return;

@@ -314,6 +314,23 @@ class StepEngine:
         L.check(self.lib.hulc_comm_stats(self.ctx, C.byref(n), C.byref(b)))
         return dict(collectives=n.value, bytes=b.value)
 
+    def comm_timeline(self) -> Dict:
+        """hulc_comm_timeline (after a hulc_backward_allreduce with set_option('comm_timing', 1)): per bucket, when its collective started / ended
+        relative to the END of the backward on the engine stream (us; negative = hidden under the backward), and the backward's own duration."""
+        out = (C.c_double * 32)()
+        bwd = C.c_double()
+        n = self.lib.hulc_comm_timeline(self.ctx, out, 8, C.byref(bwd))
+        if n < 0:
+            L.check(1)
+        b = [dict(bucket=int(out[4 * i + 3]), issued_at_us=round(out[4 * i], 1), done_at_us=round(out[4 * i + 1], 1), bytes=int(out[4 * i + 2])) for i in range(n)]
+        exposed = max([x["done_at_us"] for x in b] + [0.0])
+        return dict(backward_us=round(bwd.value, 1), buckets=b, exposed_after_backward_us=round(exposed, 1))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        L.check(self.lib.hulc_get_option(self.ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def allreduce_grads(self, bucket_dtype: str = "fp32"):
         """One SUM all-reduce of the whole gradient buffer (after backward()); stream-ordered, no host sync."""
         L.check(self.lib.hulc_allreduce_grads(self.ctx, L.DTYPE[bucket_dtype]))
