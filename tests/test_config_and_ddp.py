@@ -227,3 +227,36 @@ def test_resume_true_reenters_newest_run_with_checkpoint(tmp_path):
     assert training.resolve_log_dir(pat, resume=False) not in [str(tmp_path / "runs" / n) for n in ("2026-01-01/10-00-00", "2026-01-02/09-30-00")]
     explicit = str(tmp_path / "runs" / "2026-01-01/10-00-00")
     assert training.resolve_log_dir(explicit, resume=False) == explicit
+
+
+def test_resume_skips_runs_of_another_configuration(tmp_path, capsys):
+    """`resume=true` used to re-enter the newest run directory that held ANY checkpoint.  A run directory now records the
+    configuration fingerprint it was started with (model / loss / training / datamodule groups, seed, precision); resume only re-enters a run
+    whose fingerprint matches, reports the ones it skips, and an explicit log_dir of another configuration is refused by `train`."""
+    import json
+    import os
+    import time
+    from hulc_amd import config, training
+    conf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf")
+    cfg_hulc = config.compose(conf, "config", [])
+    cfg_gcbc = config.compose(conf, "config", ["model=gcbc"])
+    fp_h, fp_g = training.config_fingerprint(cfg_hulc), training.config_fingerprint(cfg_gcbc)
+    assert fp_h != fp_g and fp_h == training.config_fingerprint(config.compose(conf, "config", ["trainer.max_epochs=7", "resume=true"]))   # bookkeeping keys do not count
+    pat = str(tmp_path / "runs" / "{now}")
+    for name, fp in (("2026-01-01/10-00-00", fp_h), ("2026-01-02/09-30-00", fp_g)):
+        d = tmp_path / "runs" / name / "saved_models"
+        d.mkdir(parents=True)
+        (d / "epoch=0.ckpt").write_bytes(b"x")
+        json.dump(fp, open(tmp_path / "runs" / name / training.RUN_CONFIG, "w"))
+        time.sleep(0.02)
+    # the newest run is a GCBC run: a HULC job must skip it and continue the older HULC run
+    assert training.resolve_log_dir(pat, resume=True, fp=fp_h) == str(tmp_path / "runs" / "2026-01-01/10-00-00")
+    assert "different configuration" in capsys.readouterr().out
+    assert training.resolve_log_dir(pat, resume=True, fp=fp_g) == str(tmp_path / "runs" / "2026-01-02/09-30-00")
+    ok, why = training.run_config_matches(str(tmp_path / "runs" / "2026-01-02/09-30-00"), fp_h)
+    assert not ok and "model" in why
+    # a run directory without a recorded fingerprint (older runs) is still resumable
+    d = tmp_path / "runs" / "2026-01-03/08-00-00" / "saved_models"
+    d.mkdir(parents=True)
+    (d / "epoch=0.ckpt").write_bytes(b"x")
+    assert training.resolve_log_dir(pat, resume=True, fp=fp_h) == str(tmp_path / "runs" / "2026-01-03/08-00-00")

@@ -7,7 +7,7 @@
 #   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
 #   5. the probes behind DESIGN.md's numbers: tools/bin/ct_stamps (conv tile phases), tools/bin/gridbar2 (XCD barrier + sc1 publish),
 #      tools/bin/rnn_persist_bench_st (the persistent recurrence alone: check against a CPU recurrence, us per step, phase stamps)
-T=${1:-r03}
+T=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$T
@@ -39,7 +39,9 @@ b mcil_gru --model mcil_gru
 b fp32 --dtype fp32 --steps 20                # the parity engine's throughput (v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 rate)
 b u8_h2d --ingest u8 --h2d 1                  # every step's uint8 frames copied from PINNED HOST memory (SURVEY 8(d)'s PCIe-inclusive row)
 python tools/time_conv_reg.py > $O/conv_reg_vs_tile.txt 2>/dev/null
-ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -3 > $O/conv_reg_ablation.txt
+ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -12 > $O/conv_reg_ablation.txt
+test -x tools/bin/storebench && timeout 120 tools/bin/storebench > $O/storebench.txt 2>&1
+test -x tools/bin/mixbench && timeout 120 tools/bin/mixbench > $O/mixbench.txt 2>&1
 python tools/step_timeline.py $O/stats "" 400 > $O/step_timeline.txt 2>&1
 test -x tools/bin/rnn_persist_bench_st || { mkdir -p tools/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -DRP_STAMPS tools/rnn_persist_bench.hip -o tools/bin/rnn_persist_bench_st; }
 ( timeout 120 tools/bin/rnn_persist_bench_st 64 32; timeout 120 tools/bin/rnn_persist_bench_st 128 32 | tail -5; timeout 120 tools/bin/rnn_persist_bench_st 32 64 | tail -5 ) > $O/rnn_persist_stamps.txt 2>&1

@@ -45,8 +45,8 @@ if os.environ.get("ABLATE"):
                           ("conv2 dgrad w4x2", 39, (o2, wd2, b64, bits1, x2, H2, H1))):
         if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
             continue
-        if mode % 10 >= 8:       # the data-gradient forms: epilogue / store experiments (AB build)
+        if mode % 10 >= 8 and os.environ.get("STORE_EXP"):       # the data-gradient forms: epilogue / store experiments (needs the AB build: HULC_BUILD_AB=1)
             r = {k: run(mode, *a, d) for k, d in (("epilogue-only", 20), ("epi-only-compact", 20 | 64), ("epi-only-nt", 20 | 128), ("full-compact", 64), ("full-nt", 128))}
             print(name, {k: round(v, 1) for k, v in r.items()})
-        r = {k: run(mode, *a, d | (1 if mode % 10 < 8 else 0)) for k, d in (("full", 0), ("no-dma", 4), ("no-compute", 2), ("no-epilogue", 8), ("no-mfma", 16), ("no-mfma-no-epi", 24), ("no-dma-no-epi", 12), ("dma-only", 2), ("nothing", 6))}
+        r = {k: run(mode, *a, d | (1 if mode % 10 < 8 else 0)) for k, d in (("full", 0), ("no-dma", 4), ("no-compute", 2), ("no-epilogue", 8), ("no-mfma", 16), ("no-mfma-no-epi", 24), ("no-dma-no-epi", 12), ("epilogue-only", 20), ("dma-only", 2), ("nothing", 6))}
         print(name, {k: round(v, 1) for k, v in r.items()})
