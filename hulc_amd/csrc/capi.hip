@@ -266,8 +266,10 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     const int CO = which == 1 ? 32 : 64;
     if (hipMalloc(&part, sizeof(float) * 512ll * 64 * KC) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; }
     int ns;
-    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
-    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
+    static h16_t* zp = nullptr;                   // zero page of the LDS-DMA kernel (pad slots, columns / rows beyond the frame)
+    if (!zp) { if (hipMalloc(&zp, 256) != hipSuccess) { hulc_set_error("hulc_k_conv_wgrad: hipMalloc failed"); return 1; } hipMemset(zp, 0, 256); }
+    if (which == 3) { const int OH = IH - 2; ns = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512, nullptr, zp); }
+    else if (which == 2) { const int OH = (IH - 4) / 2 + 1; ns = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)X, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512, nullptr, zp); }
     else if (which == 1) { const int OH = (IH - 8) / 4 + 1; ns = launch_conv1_wgrad_tr(st, Conv1Src{X, nullptr, 0, 0}, (const h16_t*)dY, part, bias_tmp, Nf, IH, IH, OH, OH, 512); }
     else { hipFree(part); hulc_set_error("hulc_k_conv_wgrad: which must be 1, 2 or 3"); return 1; }
     hipMemsetAsync(out, 0, sizeof(float) * CO * KC, st);

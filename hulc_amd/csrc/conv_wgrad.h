@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const h16_t* __re
 //   * whole-frame bands where the frame fits (conv3: 152 KB of LDS), balanced bands otherwise (no 1-row tail band).
 // Chunk k of a thread is (dY or X, LDS offset, global offset) packed in one register; loads are unconditional (clamped).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CI, int CO, int KH, int KW, int S, int NWV>
+template <int CI, int CO, int KH, int KW, int S, int NWV, int D = 3>
 __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                             float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                             int* __restrict__ work_ctr, int FPB) {
@@ -315,7 +315,6 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
             }
             auto bfrag = [&](int j) { return tr_read8(ximg + pb[0] + toff[j], ximg + pb[1] + toff[j]); };
             // B fragments run D n-tiles ahead of their MFMAs; A fragments first
-            constexpr int D = 3;
             h16x8_t ring[D];
             h16x8_t af[CTH];
 #pragma unroll
@@ -355,11 +354,244 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (round 4): the v2 multiply loop fed by LDS-DMA into TWO band buffers.
+//   v2 stages a band through 16 prefetch registers per thread and a commit phase (ds_write_b128 + the bias sums), behind two barriers per band;
+//   measured on 2048 static-camera frames (experiment build, rocprofv3): whole kernel 129 / 137 us (conv3 / conv2), without the MFMA loop 71 / 96,
+//   without the global loads 101 / 100, with neither 37 / 42 — per band: 2.5 us of commit + barriers, ~3.5 us of load latency that the MFMA loop of
+//   ONE resident band cannot cover (the next band's registers are only free after the commit), ~8 us of multiply loop.
+//   Here a band = X rows + dY rows of R output rows as ONE contiguous LDS image (same pitches, same tr-read fragments as v2), filled by
+//   global_load_lds_dwordx4 in 1 KB pieces (8 waves x 64 lanes x 16 B; a lane decodes its 16-byte slot -> (pixel, chunk) -> global address; pad
+//   slots, dY columns >= OW, rows beyond the frame and the trailing zero pixels come from a zero page), the NEXT band's DMA is issued right after the
+//   band barrier into the other buffer and lands under the multiply loop; no staging registers (64 VGPRs back), no commit, ONE barrier per band.  The
+//   bias gradient (column sums of dY) is read back from LDS (3 x 16 B per thread and band).  Bands are smaller (two must fit: R = 7 rows for
+//   conv3, 6 for conv2), which costs 6 - 11 % more multiply steps (partially filled last step of a band).
+// Static-camera shapes only; small frames keep v2's stacked bands.
+// ---------------------------------------------------------------------------------------------------------------------
+DEVI int wg_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KB at the wave-uniform LDS address `dst`), issued as inline assembly.  Reason: the tr-read builtin
+// (ds_read_b64_tr_b16) carries no memory operand, so LLVM's waitcnt pass must assume it may read what a pending
+// __builtin_amdgcn_global_load_lds is still writing and puts `s_waitcnt vmcnt(0)` in front of the first tr-read after the DMA — the multiply
+// loop then waits for the whole next band (measured: whole = DMA + MFMA exactly).  Hidden from the pass, the DMA is ordered by this kernel's
+// own `s_waitcnt vmcnt(0)` + barrier only.  (Compiler-inserted vmcnt waits stay safe: unknown extra operations can only make them wait longer.)
+DEVI void wg_lds_dma16(const void* src, lds_char* dst) {
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
+}
+template <int CI, int CO, int KH, int KW, int S>
+__global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
+                                                             float* __restrict__ bias_part, const h16_t* __restrict__ zeros, int Nf, int IH, int IW, int OH, int OW,
+                                                             int R, int nbands, int dbg, int* __restrict__ work_ctr) {
+    using C = WgradCfg<CI, CO, KH, KW, S>;
+    constexpr int NWV = 8, NTH = NWV * 64, CTH = C::CT / (NWV / 4), CHY = CO / 8, CHX = CI / 8, XSS = C::XS / 16, YSS = C::DYS / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * S + KH;
+    const int xpix = XR * IW + 8 * S + KW;
+    const int dypix = R * OWp + 8;
+    const int xslots = xpix * XSS, yslots = dypix * YSS;
+    const int bbytes = ((xslots + yslots) * 16 + 1023) & ~1023;      // one band buffer: [X image | dY image], whole 1 KB DMA pieces
+    const int npieces = bbytes >> 10;
+    lds_char* const lbase = (lds_char*)smem;
+    const int nitems = Nf * nbands;
+    const float invXSS = 1.f / (float)XSS, invYSS = 1.f / (float)YSS, invIW = 1.f / (float)IW, invOWp = 1.f / (float)OWp, invOW = 1.f / (float)OW;
+    // a lane's slot of piece k is the same (pixel, chunk) in every band: decoded ONCE into pk[k] — bit 31: X image, bit 30: a real chunk of a
+    // pixel that can lie inside the frame, bits 24..29: its band row, bits 0..23: element offset / 8 from the band's first row — so that issuing a
+    // band costs a handful of VALU operations per piece (decoding per band made the issue phase 1.6 us of a 4.3 us band)
+    constexpr int PFM = 10;
+    unsigned pk[PFM];
+#pragma unroll
+    for (int k = 0; k < PFM; ++k) {
+        int q = (k * NWV + wave) * 64 + lane;
+        unsigned v = 0;
+        if (q < xslots) {
+            const int px = wg_fdiv(q, invXSS), ch = q - px * XSS;
+            const int r = wg_fdiv(px, invIW), c = px - r * IW;
+            if (ch < CHX && r < XR) v = 0xC0000000u | ((unsigned)r << 24) | (unsigned)(((r * IW + c) * CI + ch * 8) >> 3);
+        } else {
+            q -= xslots;
+            const int px = wg_fdiv(q, invYSS), ch = q - px * YSS;
+            const int r = wg_fdiv(px, invOWp), c = px - r * OWp;
+            if (ch < CHY && r < R && c < OW) v = 0x40000000u | ((unsigned)r << 24) | (unsigned)(((r * OW + c) * CO + ch * 8) >> 3);
+        }
+        pk[k] = v;
+    }
+    auto dma = [&](int item, int buf) {
+        if (dbg & 2) return;
+        const int f = item / nbands, oh0 = (item - f * nbands) * R, ih0 = oh0 * S;
+        const int yrows = min(R, OH - oh0), xrows = min(XR, IH - ih0);
+        const h16_t* xsrc = X + ((long long)f * IH + ih0) * IW * CI;
+        const h16_t* ysrc = dY + ((long long)f * OH + oh0) * OW * CO;
+        lds_char* dst = lbase + buf * bbytes + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < PFM; ++k) {
+            if (k * NWV + wave >= npieces) break;                     // wave-uniform
+            const unsigned v = pk[k];
+            const bool isx = (v >> 31) != 0;
+            const int r = (int)((v >> 24) & 63u);
+            const bool ok = ((v >> 30) & 1u) && r < (isx ? xrows : yrows);
+            const h16_t* src = ok ? (isx ? xsrc : ysrc) + (long long)(v & 0xffffffu) * 8 : zeros;
+            wg_lds_dma16(src, dst + k * NWV * 1024);
+        }
+    };
+    const int q = wave & 3, h = wave >> 2;
+    f32x4 acc[C::NTW][CTH];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < CTH; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2;
+    const int ccol = (a & 3) * 8;
+    const int nt0 = q * C::NTW;
+    int toff[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int nt = __builtin_amdgcn_readfirstlane(nt0) + j;
+        const int tap = nt / C::CGN, cg = nt % C::CGN;
+        const int kh = tap / KW, kw = tap % KW;
+        toff[j] = (kh * IW + kw) * C::XS + cg * 32;
+    }
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __shared__ int s_next[2];
+    int item = blockIdx.x, iter = 0, nb = 0;
+    if (item < nitems) dma(item, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int px = (g & 1) * 4 + prow;
+    const int q4 = 4 / U, r4 = 4 - q4 * U;
+    const int step4 = (q4 * S * IW + r4 * 8 * S) * C::XS, wrapd = (S * IW - U * 8 * S) * C::XS;
+    while (item < nitems) {
+        if (work_ctr && tid == 0) s_next[iter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);   // dynamic claim (see ConvTileP::work_ctr)
+        __syncthreads();                               // this band has landed (every wave waited for its own pieces) and nobody reads the other buffer any more
+        const int cur = item;
+        item = work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
+        ++iter;
+        lds_char* const ximg = lbase + nb * bbytes;
+        lds_char* const dyimg = ximg + xslots * 16;
+        nb ^= 1;
+        // the next band streams in under the bias sums and the MFMAs below.  Waves 0-3 issue their pieces now, waves 4-7 (the second wave of each
+        // SIMD) after their first multiply step, so that one wave per SIMD multiplies while the other spends its issue time
+        bool pend = item < nitems;
+        if (pend && wave < 4) { dma(item, nb); pend = false; }
+        {                                              // bias gradient: column sums of the band's real dY pixels, from LDS
+            const int f = cur / nbands, oh0 = (cur - f * nbands) * R;
+            const int nchunk = min(R, OH - oh0) * OW * CHY;
+            for (int i = tid; i < nchunk; i += NTH) {  // i % CHY == tid % CHY: a thread keeps one channel group
+                const int pix = i / CHY, r = wg_fdiv(pix, invOW), c = pix - r * OW;
+                const u32x4_t v = *(lds_u32x4*)(dyimg + (r * OWp + c) * C::DYS + (tid % CHY) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
+            }
+        }
+        const int units = (dbg & 1) ? 0 : R * U;
+        int uo[2], pbv[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int u = hh * 2 + (g >> 1), r = u / U;
+            uo[hh] = u - r * U;
+            pbv[hh] = ((r * S) * IW + (uo[hh] * 8 + px) * S) * C::XS + ccol;
+        }
+        const int abase = px * C::DYS + ccol + h * CTH * 32, pb_idle = (px * S) * C::XS + ccol;
+        // (measured and not kept: all fragments of step s + 1 requested before the MFMAs of step s, two register sets — 94 vs 97 us for the multiply
+        //  phase alone, 239 VGPRs; and with ONE B-fragment read per step instead of nine the phase still takes 94 us: the loop is not waiting on LDS)
+        auto mstep = [&](const int u0) {
+            lds_char* ab[2];
+            int pb[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int u = u0 + hh * 2 + (g >> 1);
+                const bool valid = u < units;
+                ab[hh] = dyimg + (valid ? u * 8 : R * OWp) * C::DYS + abase;      // idle runs read the zero pixels behind the band
+                pb[hh] = valid ? pbv[hh] : pb_idle;
+                pbv[hh] += step4; uo[hh] += r4;
+                if (uo[hh] >= U) { uo[hh] -= U; pbv[hh] += wrapd; }
+            }
+            auto bfrag = [&](int j) { return tr_read8(ximg + pb[0] + toff[j], ximg + pb[1] + toff[j]); };
+            constexpr int D = 3;
+            h16x8_t ring[D];
+            h16x8_t af[CTH];
+#pragma unroll
+            for (int c = 0; c < CTH; ++c) af[c] = tr_read8(ab[0] + c * 32, ab[1] + c * 32);
+#pragma unroll
+            for (int j = 0; j < D && j < C::NTW; ++j) ring[j] = bfrag(j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j) {
+                const h16x8_t bf = ring[j % D];
+#pragma unroll
+                for (int c = 0; c < CTH; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
+                if (j + D < C::NTW) ring[j % D] = bfrag(j + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (units > 0) mstep(0);                       // first step peeled: the second wave of a SIMD issues its DMA pieces behind it, and the loop body stays free of that code
+        if (pend) { dma(item, nb); pend = false; }
+#pragma unroll 1
+        for (int u0 = 4; u0 < units; u0 += 4) mstep(u0);
+        if (pend) dma(item, nb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next band have landed
+    }
+    constexpr int KC = KH * KW * CI;
+    float* out = part + (long long)blockIdx.x * CO * KC;
+    if (!(dbg & 4) || acc[0][0][0] == 12345.678f)
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j)
+#pragma unroll
+        for (int c = 0; c < CTH; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float s = 0.f;
+        for (int t = cgrp; t < NTH; t += CHY) s += red[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, s);
+    }
+}
+// band height for v3: among the heights of which two bands fit the LDS, the one with the fewest multiply steps per frame — a band of r rows is
+// ceil(r U / 4) steps of four 8-pixel runs (U = OWp / 8 runs per row; a partially filled last step multiplies zeros) plus about one step's worth of
+// barrier / issue overhead.  conv3 (21 rows, U = 3): 8 + 8 + 5 rows = 6 + 6 + 4 steps; conv2 (23 rows): 6 + 6 + 6 + 5.  0 = shape not covered
+template <int CI, int CO, int KH, int KW, int S>
+static inline int conv_wgrad_dma_rows(int IH, int IW, int OH, int OW, int* nbands_out, size_t* lds_out) {
+    using C = WgradCfg<CI, CO, KH, KW, S>;
+    const int OWp = (OW + 7) / 8 * 8, U = OWp / 8;
+    int bestR = 0, bestc = 1 << 30;
+    for (int R = OH; R >= 1; --R) {
+        const int XR = (R - 1) * S + KH;
+        const size_t band = (((size_t)(XR * IW + 8 * S + KW) * C::XS + (size_t)(R * OWp + 8) * C::DYS) + 1023) / 1024 * 1024;
+        const size_t lds = std::max<size_t>(2 * band, 512 * 8 * sizeof(float));
+        if (lds > 160 * 1024 - 128 || band > 80 * 1024 || R > 63) continue;      // <= 10 pieces per wave (pk[] in registers), 6 bits of band row in pk
+        const int nb = (OH + R - 1) / R, last = OH - (nb - 1) * R;
+        const int cost = (nb - 1) * ((R * U + 3) / 4 + 1) + (last * U + 3) / 4 + 1;
+        if (cost < bestc) { bestc = cost; bestR = R; *nbands_out = nb; *lds_out = lds; }
+    }
+    return bestR;
+}
+
 template <int CI, int CO, int KH, int KW, int S>
 static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
-                                       int OW, int max_blocks, int* work_ctr = nullptr) {
+                                       int OW, int max_blocks, int* work_ctr = nullptr, const h16_t* zeros = nullptr) {
     using C = WgradCfg<CI, CO, KH, KW, S>;
     static const bool v1 = HULC_SWITCH("HULC_WGRAD_V1", 0) != 0;
+    static const bool v3 = HULC_SWITCH("HULC_WGRAD_DMA", 1) != 0;
+    // v3 (LDS-DMA, two band buffers): frames large enough that v2 would not stack them (>= 2 bands of multiply work per frame)
+    if (!v1 && v3 && zeros && OH * OW >= 256 && Nf >= 2) {
+        int nb = 0; size_t lds = 0;
+        const int R = conv_wgrad_dma_rows<CI, CO, KH, KW, S>(IH, IW, OH, OW, &nb, &lds);
+        if (R > 0 && (long long)Nf * IH * IW * CI < (1ll << 31)) {
+            static bool attr3 = false;
+            if (!attr3) { hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<CI, CO, KH, KW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr3 = true; }
+            const int grid = std::min(std::min(Nf * nb, 256), max_blocks);
+            static const int dbg3 = HULC_SWITCH("HULC_WGRAD_DBG", 0);
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(512), lds, st, X, dY, part, bias_part, zeros, Nf, IH, IW, OH, OW, R, nb, dbg3, work_ctr);
+            return grid;
+        }
+    }
     constexpr int NWV = 8;                                   // 16 waves (one co-tile each, 4 waves per SIMD) measured slower: 0.43 vs 0.40 ms/step
     if (!v1) {
         // fewest balanced bands whose chunks fit the 16 x 512 prefetch slots and whose images fit in 160 KB (16 KB kept for the bias reduction)
@@ -391,6 +623,17 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
             const int items = fpb > 1 ? (Nf + fpb - 1) / fpb : Nf * nb;
             const int grid = std::min(std::min(items, 256), max_blocks);
             static const int dbg = HULC_SWITCH("HULC_WGRAD_DBG", 0);   // bench ablation only
+#ifdef HULC_AB_SWITCHES
+            static const int dsel = HULC_SWITCH("HULC_WGRAD_D", 3);      // experiment: depth of the B-fragment ring
+            if (dsel == 6 || dsel == 8) {
+                static bool a2 = false;
+                if (!a2) { hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                           hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); a2 = true; }
+                if (dsel == 6) hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 6>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
+                else hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 8>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
+                return grid;
+            }
+#endif
             hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
             return grid;
         }

@@ -827,9 +827,9 @@ struct Engine : IEngine {
             if (conv1)
                 nsplit = launch_conv1_wgrad_tr(st, wgrad_src, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 1024, next_ctr());
             else if (!conv1 && c.I == 64 && c.KH == 3)
-                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
+                nsplit = launch_conv_wgrad_tr<64, 64, 3, 3, 1>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr(), wgrad_zero_page());
             else if (!conv1 && c.I == 32 && c.KH == 4)
-                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr());
+                nsplit = launch_conv_wgrad_tr<32, 64, 4, 4, 2>(st, (const h16_t*)xin, dy, part, c.db, g.Nf, g.IH, g.IW, g.OH, g.OW, 512, next_ctr(), wgrad_zero_page());
         }
         bool bias_done = false;
         if (nsplit > 0) bias_done = true;     // the tr kernels added the bias gradient themselves (atomics)
@@ -865,6 +865,10 @@ struct Engine : IEngine {
         if (!bias_done) colsum(dy, c.O, (int)npix, c.O, c.db);
     }
     h16_t* zero_page = nullptr;
+    const h16_t* wgrad_zero_page() {
+        if constexpr (std::is_same<T, h16_t>::value) { if (!zero_page) zero_page = alloc<h16_t>(128); }     // zero-initialised by alloc()
+        return zero_page;
+    }
     void conv_dgrad(const ConvW& c, const T* dy, const ConvGeom& g, T* dx, const T* mask, const unsigned* maskbits = nullptr) {
         if constexpr (std::is_same<T, h16_t>::value) {
             ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = maskbits ? nullptr : mask; p.maskbits = maskbits; p.Nf = g.Nf; p.work_ctr = next_ctr();

@@ -112,7 +112,7 @@ def test_conv1_fwd_and_wgrad_from_fp32_nchw(IH):
     assert np.abs(g.cpu().numpy() - refw.reshape(32, -1)).max() / np.abs(refw).max() < 1e-4      # fp32 accumulate: tight
 
 
-@pytest.mark.parametrize("which,IH,CI,KH,S", [(3, 23, 64, 3, 1), (3, 9, 64, 3, 1), (2, 49, 32, 4, 2), (2, 20, 32, 4, 2)])
+@pytest.mark.parametrize("which,IH,CI,KH,S", [(3, 23, 64, 3, 1), (3, 9, 64, 3, 1), (2, 49, 32, 4, 2), (2, 20, 32, 4, 2), (3, 31, 64, 3, 1), (2, 57, 32, 4, 2), (3, 18, 64, 3, 1)])      # 23 / 49 / 31 / 57 / 18: the LDS-DMA kernel (2 - 5 bands per frame, OWp = 24 / 32 / 16)
 def test_conv_wgrad_tr(which, IH, CI, KH, S):
     L, lib = _lib()
     rng = np.random.default_rng(which * 100 + IH)
