@@ -163,3 +163,29 @@ def test_library_rccl_selftest_on_two_gpus():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
     assert "DP_SELFTEST_OK" in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--lang", "1"], ["--model", "mcil", "--bucket", "bf16"]])
+def test_bench_multi_gpu_code_path_rehearsal_on_one_gpu(extra):
+    """The N > 1 branch of bench.py — library communicator, the self-check of the bucketed SUM against a flat torch.distributed all-reduce,
+    hulc_backward_allreduce inside the timed loop, the bucket timeline in the JSON — has no multi-GPU box to run on before the driver's.
+    `--force-comm 1` runs exactly that code with a 1-rank process group and a 1-rank RCCL communicator; the line must parse, carry the
+    `allreduce` object with five timed buckets that partition the buffer, and keep roofline / mfma_groups."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 200))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-comm", "1", "--steps", "4", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline", "--batch", "16"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1].startswith('{"metric"'), lines[-3:]          # the JSON line is the LAST line of stdout (the driver's contract)
+    d = json.loads(lines[-1])
+    ar = d["allreduce"]
+    assert ar and "REHEARSAL" in ar["path"] and ar["collectives"] >= 5 * 4
+    sc = ar["selfcheck"]
+    assert sc["rel_l2_whole_buffer"] <= 2e-2 and sc["rel_l2_bucketed_overlapped"] <= sc["tolerance"]
+    tl = ar["timeline"]
+    assert tl["backward_us"] > 0 and len(tl["buckets"]) >= 4
+    assert sum(b["bytes"] for b in tl["buckets"]) == sum(ar["bucket_bytes"])
+    assert tl["buckets"][0]["issued_at_us"] < 0 <= tl["exposed_after_backward_us"]
+    assert d["n_gpus"] == 1 and d["roofline"] and d["mfma_groups"] and d["value"] > 0
