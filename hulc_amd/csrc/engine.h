@@ -1516,10 +1516,13 @@ struct Engine : IEngine {
     bool persist_usable(int B, int S) const {
         return std::is_same<T, h16_t>::value && persist_mode && HID == RP_HID && S >= 3 && B <= 16 * RP_NG && !(rp_probed && !rp_ok) && !comm_in_flight();
     }
-    bool rnn_persist(T* X, const T* Wm, const T* res, const T* mask, int B, int S, int q0, int dq, int act) {
+    // X2 != null: a second, independent recurrence of the same shape in the same launch (rnn_persist.h: dual) — 4 XCDs each, B <= 64
+    bool rnn_persist(T* X, const T* Wm, const T* res, const T* mask, int B, int S, int q0, int dq, int act,
+                     T* X2 = nullptr, const T* Wm2 = nullptr, const T* res2 = nullptr, const T* mask2 = nullptr, int q02 = 0, int dq2 = 0) {
         if constexpr (!std::is_same<T, h16_t>::value) return false;
         else {
             if (!persist_usable(B, S)) return false;
+            if (X2 && B > 16 * (RP_NG / 2)) return false;
             if (!rp_flags) {
                 rp_flags = alloc<unsigned>(RP_FLAG_WORDS);
                 rp_skip = alloc<unsigned>(64);
@@ -1527,17 +1530,19 @@ struct Engine : IEngine {
                 if (alloc_failed || hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&rp_err_dev, h, 0) != hipSuccess) { rp_probed = true; rp_ok = false; return false; }
                 rp_err_host = (volatile unsigned*)h; *rp_err_host = 0;
             }
-            if (B != rp_B || rp_launches >= (1u << 19)) {     // another set of active groups, or the step counters near their wrap: restart the counters from a clean slate
+            const int bkey = X2 ? -B : B;                      // a dual launch uses another window -> XCD assignment
+            if (bkey != rp_B || rp_launches >= (1u << 19)) {   // another set of active groups, or the step counters near their wrap: restart the counters from a clean slate
                 hipMemsetAsync(rp_flags, 0, sizeof(unsigned) * RP_FLAG_WORDS, st);
-                rp_launches = 1; rp_B = B;
+                rp_launches = 1; rp_B = bkey;
             }
             RnnPersistP p{};
             p.X = X; p.W = Wm; p.res = res; p.mask = mask; p.B = B; p.S = S; p.q0 = q0; p.dq = dq; p.act = act;
+            if (X2) { p.dual = 1; p.X2 = X2; p.W2 = Wm2; p.res2 = res2; p.mask2 = mask2; p.q02 = q02; p.dq2 = dq2; }
             p.flags = rp_flags; p.base = rp_launches << 12; p.parity = (int)(rp_launches & 1u); p.err = rp_err_dev; p.stamps = nullptr;
             p.skip = rp_skip; p.skip_tag = opt_seq + 1;
             if (rp_probed && persist_fault > 0) { p.fault = 1; --persist_fault; }
             ++rp_launches;
-            TimerScope ts(this, "rnn_persist", "mfma", 2.0 * B * HID * HID * (S - 1), (double)HID * HID * sizeof(T) + 3.0 * S * B * HID * sizeof(T), 1);
+            TimerScope ts(this, "rnn_persist", "mfma", (X2 ? 2.0 : 1.0) * 2.0 * B * HID * HID * (S - 1), (X2 ? 2.0 : 1.0) * ((double)HID * HID * sizeof(T) + 3.0 * S * B * HID * sizeof(T)), 1);
             if (!launch_rnn_persist(st, p)) return false;
             if (!rp_probed) {
                 hipStreamSynchronize(st);
@@ -1628,6 +1633,17 @@ struct Engine : IEngine {
             }
             return;
         }
+        if constexpr (std::is_same<T, h16_t>::value) {
+            // both directions as ONE persistent launch, four XCDs each (rnn_persist.h: dual)
+            static const bool dualp = HULC_SWITCH("HULC_PERSIST_DUAL", 1) != 0;
+            if (dualp && persist_usable(B, S) && B <= 16 * (RP_NG / 2)) {
+                auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
+                for (int d = 0; d < 2; ++d) hipLaunchKernelGGL((relu_copy_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, Zx[d] + at(d, 0), H[d] + at(d, 0), BH, act);
+                if (rnn_persist(H[0], whh[0]->W, Zx[0], nullptr, B, S, 0, 1, act, H[1], whh[1]->W, Zx[1], nullptr, S - 1, -1)) return;
+                for (int d = 0; d < 2; ++d) rnn_fwd(Zx[d], H[d], *whh[d], B, S, nullptr, act, d == 1, true);      // not taken: sequential chains (first step done)
+                return;
+            }
+        }
         for (int d = 0; d < 2; ++d) rnn_fwd(Zx[d], H[d], *whh[d], B, S, nullptr, act, d == 1);
     }
     void rnn_bwd2(T* const dH[2], T* const H[2], T* const dZ[2], const LinW* const whh[2], int B, int S, int act) {
@@ -1650,6 +1666,17 @@ struct Engine : IEngine {
                 for (int d = 0; d < 2; ++d) gemm(dense<T>(dZ[d] + at(d, i + 1), B, HID), dense<T>(whh[d]->Wt, HID, HID), dense_out(HID), ep[d], B, HID, HID);
             }
             return;
+        }
+        if constexpr (std::is_same<T, h16_t>::value) {
+            static const bool dualp = HULC_SWITCH("HULC_PERSIST_DUAL", 1) != 0;
+            if (dualp && persist_usable(B, S) && B <= 16 * (RP_NG / 2)) {
+                auto at = [&](int d, int i) { return (long long)(d ? S - 1 - i : i) * BH; };
+                for (int d = 0; d < 2; ++d)
+                    hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(cdiv(BH, 256)), dim3(256), 0, st, dH[d] + at(d, S - 1), H[d] + at(d, S - 1), dZ[d] + at(d, S - 1), BH, act);
+                if (rnn_persist(dZ[0], whh[0]->Wt, dH[0], H[0], B, S, S - 1, -1, act, dZ[1], whh[1]->Wt, dH[1], H[1], 0, 1)) return;
+                for (int d = 0; d < 2; ++d) rnn_bwd(dH[d], H[d], dZ[d], *whh[d], B, S, act, d == 1, false, true);
+                return;
+            }
         }
         for (int d = 0; d < 2; ++d) rnn_bwd(dH[d], H[d], dZ[d], *whh[d], B, S, act, d == 1, false);
     }

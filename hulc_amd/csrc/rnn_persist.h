@@ -58,6 +58,11 @@ struct RnnPersistP {
     unsigned* skip;       // device word or null: a failing launch stores `skip_tag` here — the optimizer kernel of the step this recurrence belongs to
     unsigned skip_tag;    // compares its own tag with the word and leaves the weights untouched (engine.h: persist_check)
     int fault;            // tests (hulc_set_option debug_persist_fault): slot 0 of every XCD leaves at once — its consumers' bounded polls time out
+    // dual (round 4): TWO independent recurrences of the same shape in one launch — the two directions of a bidirectional layer (mcil's plan encoder,
+    // plan_recognition_net.py:27-33).  XCDs 0-3 advance problem 0, XCDs 4-7 problem 1, each XCD ceil(B / 4) <= 16 windows: the MFMA tile's 16 token
+    // columns are filled (8 of them are padding at B = 64 over eight XCDs) and both chains finish in the time of ~1.2
+    int dual;
+    h16_t* X2; const h16_t* W2; const h16_t* res2; const h16_t* mask2; int q02, dq2;
     long long* stamps;    // RP_STAMPS builds (tools/rnn_persist_bench.hip): [S][2 waves][8] shader-clock stamps of workgroup 8
 };
 #ifdef RP_STAMPS
@@ -97,11 +102,17 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     const int slot = (int)s_slot;
     if (slot >= RP_SLOTS) return;                     // an over-populated XCD: the launch is reported failed
     if (p.fault && slot == 0) return;                 // injected fault (tests): a producer that never posts
-    const int t0 = grp * p.wpx;
+    const bool second = p.dual && (grp >> 2);            // which of the two problems this XCD works on
+    const int t0 = (p.dual ? (grp & 3) : grp) * p.wpx;
     const int nwin = min(p.wpx, p.B - t0);
     if (nwin <= 0) return;
     const long long BH = (long long)p.B * RP_HID;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, 0x7fffffff, 0x00020000);
+    h16_t* const pX = second ? p.X2 : p.X;
+    const h16_t* const pW = second ? p.W2 : p.W;
+    const h16_t* const pres = second ? p.res2 : p.res;
+    const h16_t* const pmask = second ? p.mask2 : p.mask;
+    const int pq0 = second ? p.q02 : p.q0, pdq = second ? p.dq2 : p.dq;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)pX, 0, 0x7fffffff, 0x00020000);
 
     // ---- the weight slice, once: rows 64 slot + 16 ct + li, k = 256 wave + 32 ks + 8 gq
     h16x8_t wf[4][RP_KS];
@@ -109,7 +120,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int ks = 0; ks < RP_KS; ++ks)
-            wf[ct][ks] = *reinterpret_cast<const h16x8_t*>(p.W + (long long)(RP_COLS * slot + 16 * ct + li) * RP_HID + RP_KW * wave + 32 * ks + 8 * gq);
+            wf[ct][ks] = *reinterpret_cast<const h16x8_t*>(pW + (long long)(RP_COLS * slot + 16 * ct + li) * RP_HID + RP_KW * wave + 32 * ks + 8 * gq);
     // mailbox[group][consumer slot][producer slot][reducer wave]: each of a producer's four reducer waves posts its own word as soon as ITS part of
     // the slice is in the L2 (no arrival count among them), into the 32 consumers' mailboxes (one lane per consumer); a consumer wave samples
     // only the 16 words of the four producers whose features are its k-range — it does not wait for the slowest of all 32
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     const int tk = lane >> 5, c4 = (lane >> 1) & 15, ph = lane & 1;
 
     for (int s = 1; s < p.S; ++s) {
-        const long long qp = (long long)(p.q0 + (s - 1) * p.dq) * BH, qc = (long long)(p.q0 + s * p.dq) * BH;
+        const long long qp = (long long)(pq0 + (s - 1) * pdq) * BH, qc = (long long)(pq0 + s * pdq) * BH;
         RP_STAMP(0);
         // epilogue operands of this step: independent of the recurrence, requested before the wait (the lanes that will store: 8 features each)
         rp_u32x4 rv[NIT], mv[NIT];
@@ -131,8 +142,8 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
                 rv[it] = rp_u32x4{0u, 0u, 0u, 0u}; mv[it] = rp_u32x4{0u, 0u, 0u, 0u};
                 if (tok < nwin && (lane & 3) == 0) {
                     const long long o = qc + (long long)(t0 + tok) * RP_HID + RP_COLS * slot + 4 * c4;
-                    if (RES) rv[it] = *reinterpret_cast<const rp_u32x4*>(p.res + o);
-                    if (MODE >= 2) mv[it] = *reinterpret_cast<const rp_u32x4*>(p.mask + o);
+                    if (RES) rv[it] = *reinterpret_cast<const rp_u32x4*>(pres + o);
+                    if (MODE >= 2) mv[it] = *reinterpret_cast<const rp_u32x4*>(pmask + o);
                 }
             }
         }
@@ -244,9 +255,11 @@ static inline void rnn_persist_go(hipStream_t st, const RnnPersistP& p) {
 }
 static inline bool launch_rnn_persist(hipStream_t st, RnnPersistP p) {
     if (p.B < 1 || p.S < 2 || (p.act != 1 && p.act != 2)) return false;
-    p.wpx = (p.B + RP_NG - 1) / RP_NG;
+    const int ngrp = p.dual ? RP_NG / 2 : RP_NG;          // XCDs per problem
+    p.wpx = (p.B + ngrp - 1) / ngrp;
     if (p.wpx > 16 || (long long)p.S * p.B * RP_HID * 2 >= (1ll << 31)) return false;
     if (!p.mask && !p.res) return false;                 // a forward recurrence always has its input projection
+    if (p.dual && (!p.X2 || !p.W2 || (p.res != nullptr) != (p.res2 != nullptr) || (p.mask != nullptr) != (p.mask2 != nullptr))) return false;
     const int mode = (p.mask ? 2 : 0) + (p.act == 2 ? 1 : 0);
     const bool big = p.wpx > 8;
 #define RP_GO(M, R) do { if (big) rnn_persist_go<16, M, R>(st, p); else rnn_persist_go<8, M, R>(st, p); } while (0)

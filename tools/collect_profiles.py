@@ -12,7 +12,7 @@ copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.cs
           "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt", "conv_reg_vs_tile.txt": "conv_reg_vs_tile.txt", "conv_reg_ablation.txt": "conv_reg_ablation.txt",
           "step_timeline.txt": "step_timeline.txt", "rnn_persist_stamps.txt": "rnn_persist_stamps.txt",
           "storebench.txt": "storebench_write_patterns.txt", "mixbench.txt": "mixbench_conv1_traffic_shape.txt"}
-for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d"):
+for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d", "rehearsal"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
     if os.path.exists(os.path.join(O, src)):

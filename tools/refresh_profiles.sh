@@ -37,6 +37,7 @@ b vislang_seq --lang 1 --pair 0
 b mcil --model mcil
 b mcil_gru --model mcil_gru
 b fp32 --dtype fp32 --steps 20                # the parity engine's throughput (v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 rate)
+MASTER_PORT=29877 b rehearsal --force-comm 1          # 1-GPU rehearsal of the N > 1 code path: allreduce.selfcheck + allreduce.timeline (issue times of the five buckets)
 b u8_h2d --ingest u8 --h2d 1                  # every step's uint8 frames copied from PINNED HOST memory (SURVEY 8(d)'s PCIe-inclusive row)
 python tools/time_conv_reg.py > $O/conv_reg_vs_tile.txt 2>/dev/null
 ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -12 > $O/conv_reg_ablation.txt
