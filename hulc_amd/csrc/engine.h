@@ -687,7 +687,7 @@ struct Engine : IEngine {
             TimerScope ts(this, "conv_tile_fwd", "mfma", 2.0 * px2 * 64 * 512 + 2.0 * px3 * 64 * 576, (px1 * 32 + 2 * px2 * 64 + px3 * 64) * 2);
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);      // A/B: bit 0 = conv2 forward, bit 1 = conv3 forward, bit 2 = conv3 data gradient on the weights-in-registers kernel (conv_reg.h)
             // HULC_CONV_REG_W4 (same bits): the form with two co-resident 256-thread workgroups per CU (conv_reg.h, NWV = 4)
-            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 15);
+            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 11);          // in the step: conv2 fwd 84.0 vs 85.4 us, conv3 fwd 54.7 vs 56.5, conv2 dgrad 79.8 vs 87.9 (launch pairs' average, two-workgroup form first)
             const bool t2 = ((conv_reg & 1) && ((w4 & 1) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
             const bool t3 = ((conv_reg & 2) && ((w4 & 2) ? launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p3) : launch_conv_reg_fwd<64, 3, 3, 1>(st, p3))) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
             tiled = t2 && t3;
@@ -876,7 +876,8 @@ struct Engine : IEngine {
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
             TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 15);      // bit 2: conv3, bit 3: conv2 data gradient on conv_reg.h
-            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 15);         // same bits: two 256-thread workgroups per CU (NWV = 4)
+            static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 11);         // same bits: two 256-thread workgroups per CU (NWV = 4).  conv3's data gradient (bit 2) stays on the one-workgroup form:
+                                                                               // 144 weight registers + the zero-border decode spill 16 registers at 256 VGPRs (90.3 vs 83.5 us in the step, 3.470 vs 3.448 ms/step)
             if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);      // zero-initialised by alloc(): the staged zero border of the data-gradient form
                 p.zeros = zero_page;
