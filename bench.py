@@ -201,6 +201,8 @@ def main():
     # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  HULC_DP_COMM=capi (the default)
     # makes a communicator that cannot be brought up an ERROR on every rank — a run that quietly measured torch.distributed all-reduces
     # would be Lightning-DDP-shaped, not the product; HULC_DP_COMM=torch / auto select that path explicitly.
+    if world > 1:
+        parallel.configure_shared_gpu(eng)              # ranks sharing a device (never the driver's layout: one rank per GPU) switch the persistent recurrences off
     lib_comm = parallel.setup_comm(eng, args.bucket) if world > 1 else False
     if args.force_comm and world == 1:
         eng.comm_init(eng.comm_unique_id(), 0, 1)

@@ -489,6 +489,7 @@ class Hulc(torch.nn.Module):
         eng = self.engine
         if not self._comm_tried and parallel.world_size() > 1:      # first step of a multi-GPU run: the library's own RCCL communicator
             self._comm_tried = True
+            parallel.configure_shared_gpu(eng)                      # several ranks on one device: no persistent recurrences
             parallel.setup_comm(eng, os.environ.get("HULC_BUCKET_DTYPE", "fp32"))
         eng.zero_grads()
         nmod = len(batch)

@@ -166,6 +166,31 @@ def setup_comm(engine, bucket_dtype: str = "fp32") -> bool:
     return True
 
 
+def shared_device_ranks(device) -> int:
+    """How many ranks of this job run on the SAME physical GPU as this one (1 = exclusive).  Ranks are matched by host name and the device's
+    PCI bus id / UUID, not by LOCAL_RANK (two ranks may both have been given cuda:0)."""
+    if world_size() == 1 or not torch.cuda.is_available():
+        return 1
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    key = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) or str(torch.device(device).index))
+    keys = [None] * world_size()
+    dist.all_gather_object(keys, key)
+    return sum(1 for k in keys if k == key)
+
+
+def configure_shared_gpu(engine) -> int:
+    """the persistent recurrences (csrc/rnn_persist.h) need all 256 CUs of the GPU resident at once.  When several ranks share one
+    device that cannot hold, so `persistent_rnn` is switched off up front (one launch per time step) instead of waiting for a bounded poll to
+    time out and the library to fall back by itself.  Returns the number of ranks on this rank's GPU."""
+    n = shared_device_ranks(engine.device)
+    if n > 1:
+        engine.set_option("persistent_rnn", 0)
+        if rank() == 0:
+            print(f"[hulc_amd] {n} ranks share one GPU: persistent_rnn off (one launch per time step)", flush=True)
+    return n
+
+
 def check_bucket_plan(buckets, numel: int) -> None:
     """The buckets of hulc_backward_allreduce must partition [0, numel): disjoint, gap-free, every element reduced exactly once."""
     t = sorted(buckets)

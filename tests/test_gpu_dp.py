@@ -100,6 +100,8 @@ def _module_worker(rank, world, port, out):
     opt.step()
     torch.cuda.synchronize()
     w = dict(model.named_parameters())["action_decoder.mean_fc.weight"].detach().cpu().numpy().copy()
+    # two ranks on one GPU: the module switched the persistent recurrences off up front (parallel.configure_shared_gpu)
+    assert parallel.shared_device_ranks(model.engine.device) == 2 and model.engine.get_option("persistent_rnn") == 0
     out[rank] = (loss, model.logged["train/lang_clip_loss"], bool(getattr(model.engine, "has_comm", False)), w)
     dist.destroy_process_group()
 
