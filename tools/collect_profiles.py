@@ -16,6 +16,11 @@ for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "visla
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
     if os.path.exists(os.path.join(O, src)):
+        if src.startswith("bench_n1") and src.endswith(".json"):      # keep the JSON line only (a run that brings RCCL up prints its version banner first)
+            lines = [l for l in open(os.path.join(O, src)).read().splitlines() if l.startswith('{"metric"')]
+            if lines:
+                open(P(f"{T}_{dst}"), "w").write(lines[-1] + "\n")
+            continue
         shutil.copy(os.path.join(O, src), P(f"{T}_{dst}"))
 J = lambda k: json.load(open(P(f"{T}_bench_n1{k}.json")))
 d = J("")
