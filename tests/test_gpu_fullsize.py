@@ -272,18 +272,10 @@ def test_512_frames_against_the_numpy_oracle():
     P = spec.init_all(dims, seed=21, ln_jitter=True)
     mb = synthetic.make_batch(Bt, 0, St, seed=21, edge_frac=0.05, aux_mask="all")["vis"]
     def oracle_eval(mode=None, grad_scale=1.0):
-        O.set_operand_rounding(mode, grad_scale)
-        try:
-            G, loss, embs = None, 0.0, []
-            for c in range(Bt // CH):
-                chunk = {"vis": {k: v[c * CH:(c + 1) * CH] for k, v in mb.items()}}
-                l, g, caches = O.training_step(P, dims, chunk, keep_cache=True)
-                loss += float(l["total"]) / (Bt // CH)
-                embs.append(caches["vis"]["emb"])
-                G = g if G is None else {n: G[n] + g[n] for n in g}
-            return {n: v / (Bt // CH) for n, v in G.items()}, loss, np.concatenate(embs, 0)
-        finally:
-            O.set_operand_rounding(None)
+        # the same seeded parameters / batch, evaluated chunk-wise by spawned worker processes (tests/oracle_pool.py; sequentially the three modes
+        # of this test took 125 s of the suite)
+        from oracle_pool import oracle_batch
+        return oracle_batch(21, "hulc", 32, Bt, St, CH, mode, grad_scale)
 
     G, loss, emb_o = oracle_eval()
     dev_mb = {k: torch.from_numpy(v.astype(np.int32) if k == "plan_idx" else v).cuda() for k, v in mb.items()}
