@@ -139,3 +139,45 @@ def test_fused_optimizers_match_torch(kind, kw):
     if kind == "sgd" and kw.get("momentum"):
         mb = ref.state[p_ref]["momentum_buffer"]
         assert (eng.adam_m.double() - mb).abs().max().item() < 1e-4 * mb.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,kw", [("adamw", dict(weight_decay=0.05)), ("sgd", dict(momentum=0.9, weight_decay=1e-3))])
+def test_fused_optimizers_under_the_fp16_loss_scaler(kind, kw):
+    """hulc_optimizer_step in an fp16 context: gradients arrive multiplied by the loss scale, a step with a non-finite gradient is skipped
+    (parameters and moments bit-unchanged, scale halves), and the steps that are taken match torch's optimizer on the unscaled gradients — the
+    GradScaler contract, for the optimizers beyond Adam (SGD's `first step` = the first TAKEN step)."""
+    from hulc_amd import spec
+    from hulc_amd.engine import StepEngine
+    dims = spec.ModelDims(kind="gcbc", max_window=16, use_clip=False)
+    eng = StepEngine(dims, 2, 4, dtype="fp16", dropout_p=0.0)
+    eng.load_numpy(spec.init_all(dims, seed=3))
+    scale0 = 1024.0
+    eng.scaler_enable(init_scale=scale0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    p_ref = torch.nn.Parameter(eng.flat_params.detach().clone().double())
+    ref = (torch.optim.AdamW if kind == "adamw" else torch.optim.SGD)([p_ref], lr=1e-3, **kw)
+    fake = types.SimpleNamespace(parameters=lambda: [], engine=eng, _grads_reduced=True)
+    opt = H.FusedAdam(fake, lr=1e-3, kind=kind, **kw)
+    scale = scale0
+    for step in range(6):
+        grad = torch.randn(eng.numel, device="cuda", generator=g) * 0.1
+        overflow = step in (0, 3)                      # incl. the very first step: SGD's momentum buffer must start at the first TAKEN step
+        eng.flat_grads.copy_(grad * scale)
+        if overflow:
+            eng.flat_grads[12345] = float("inf")
+        before = (eng.flat_params.clone(), eng.adam_m.clone())
+        opt.step()
+        torch.cuda.synchronize()
+        st = eng.scaler_state()
+        if overflow:
+            assert torch.equal(before[0], eng.flat_params) and torch.equal(before[1], eng.adam_m)
+            scale *= 0.5
+            assert st["scale"] == scale and st["last_found_inf"] == 1
+        else:
+            p_ref.grad = grad.double()
+            ref.step()
+            assert st["scale"] == scale and st["last_found_inf"] == 0
+    err = (eng.flat_params.double() - p_ref.detach()).abs().max().item()
+    assert err < 5e-6, (kind, err)
+    assert eng.scaler_state()["skipped_steps"] == 2 and eng.scaler_state()["taken_steps"] == 4
