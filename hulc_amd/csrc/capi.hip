@@ -79,6 +79,14 @@ int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* 
     if (!batch) { hulc_set_error("hulc_validate: null batch"); return 1; }
     return ctx->e->validate(batch, noise, out_host, plan_idx_pp_out, plan_idx_pr_out, pred_pp_out, pred_pr_out);
 }
+int hulc_clip_gt_encode(hulc_ctx* ctx, const float* lang_emb, int32_t m, int32_t slot) {
+    if (!ctx) { hulc_set_error("hulc_clip_gt_encode: null context"); return 1; }
+    return ctx->e->clip_gt_encode(lang_emb, m, slot);
+}
+int hulc_clip_gt_scores(hulc_ctx* ctx, int32_t slot, float* scores_host, int64_t cap_floats, int32_t* n_out, int32_t* m_out) {
+    if (!ctx) { hulc_set_error("hulc_clip_gt_scores: null context"); return 1; }
+    return ctx->e->clip_gt_scores(slot, scores_host, cap_floats, n_out, m_out);
+}
 int hulc_rollout_reset(hulc_ctx* ctx) { return ctx->e->rollout_reset(); }
 int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* goal_rgb_static, const float* goal_rgb_gripper, const float* goal_lang,
                       const int32_t* plan_idx_inject, int32_t* plan_idx_out) {

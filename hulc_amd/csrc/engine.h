@@ -1211,7 +1211,7 @@ struct Engine : IEngine {
         }
         if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
         if (b->actions_absolute && !(b->max_rel_pos > 0.f && b->max_rel_orn > 0.f)) { hulc_set_error("actions_absolute needs max_rel_pos > 0 and max_rel_orn > 0 (RelativeActions, transforms.py:35-37)"); return 1; }
-        cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false;
+        cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false; val_clip_n = 0;
         const int B = b->B, S = b->S, N = B * S, SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         const float dp = cfg.dropout_p;
@@ -1342,7 +1342,7 @@ struct Engine : IEngine {
         if (alloc_failed) { hulc_set_error("hulc_validate: workspace allocation failed"); return 1; }
         static const hulc_val_noise none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (!nz) nz = &none;
-        cur = *b; have_fwd = false; pair = false;
+        cur = *b; have_fwd = false; pair = false; val_clip_n = 0;
         const int B = b->B, S = b->S, SB = S * B;
         HIP_CHECK(hipMemsetAsync(valm, 0, 32 * sizeof(float), st));
         trunk_fwd(b, 0.f);
@@ -1391,6 +1391,7 @@ struct Engine : IEngine {
             { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(g_m, GOAL, n, cl_la0, ep, 128); }
             { EpiP ep = epi(txt, true); lin_fwd(la1, 128, n, cl_la2, ep, GOAL); }
             hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(64), 0, st, img, txt, n, GOAL, logit_scale, 0.f, valm + 3, dimg, dtxt, valm + 31);
+            val_clip_n = n;
         }
         STAGE("validate");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in validate"); return 1; }
@@ -1406,6 +1407,60 @@ struct Engine : IEngine {
             for (int i = 0; i < 6; ++i) { out17[5 + i] = h[8 + i]; out17[11 + i] = h[16 + i]; }
             out17[17] = h[3];
         }
+        return 0;
+    }
+
+    // ---------------------------------------------------------------- CLIP ground-truth metric (hulc.py:967-974, 980-1043)
+    // encode: language_goal(lang_emb) then proj_vis_lang.mlp_lang, kept as fp32 (m, GOAL) in `slot` (0: training instructions, 1: validation
+    // instructions) until the next encode of that slot.  scores: exp(logit_scale) * normalised image projections of the masked rows of the LAST
+    // hulc_validate (lang modality) times the normalised slot rows -> (n, m) on the host.  Both overwrite goal-encoder activations: not between a
+    // forward and its backward.
+    int val_clip_n = 0;
+    float* gt_txt[2] = {nullptr, nullptr}; int gt_m[2] = {0, 0}, gt_cap[2] = {0, 0};
+    float *gt_in = nullptr, *gt_out = nullptr; int64_t gt_in_cap = 0, gt_out_cap = 0;
+    template <typename U> bool gt_grow(U*& p, int64_t& cap, int64_t n) {
+        if (n <= cap) return true;
+        void* q = nullptr;
+        if (hipMalloc(&q, n * sizeof(U) + 256) != hipSuccess) return false;
+        allocs.push_back(q);       // the old block stays until the engine goes: kernels in flight may still read it
+        p = (U*)q; cap = n;
+        return true;
+    }
+    int clip_gt_encode(const float* lang_emb, int m, int slot) override {
+        if (!bound) { hulc_set_error("hulc_clip_gt_encode before hulc_bind_params"); return 1; }
+        if (!cfg.use_clip || cfg.kind != HULC_KIND_HULC) { hulc_set_error("hulc_clip_gt_encode: the context has no CLIP head (use_clip_auxiliary_loss, hulc.py:703)"); return 1; }
+        if (have_fwd) { hulc_set_error("hulc_clip_gt_encode between a forward and its backward"); return 1; }
+        if (slot < 0 || slot > 1 || m < 1 || !lang_emb) { hulc_set_error("hulc_clip_gt_encode: slot %d, m %d", slot, m); return 1; }
+        int64_t capi = gt_cap[slot];
+        if (!gt_grow(gt_txt[slot], capi, (int64_t)m * GOAL) || !gt_grow(gt_in, gt_in_cap, (int64_t)m * LANG)) { hulc_set_error("hulc_clip_gt_encode: allocation failed"); return 1; }
+        gt_cap[slot] = (int)capi;
+        HIP_CHECK(hipMemcpyAsync(gt_in, lang_emb, sizeof(float) * (int64_t)m * LANG, hipMemcpyDefault, st));
+        T* acts[2] = {gl1, gl2};
+        for (int r0 = 0; r0 < m; r0 += maxB) {
+            const int rows = std::min(maxB, m - r0);
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(rows * LANG, 256)), dim3(256), 0, st, gt_in + (int64_t)r0 * LANG, lang_t, (long long)rows * LANG);
+            mlp_fwd(lang_t, LANG, rows, lg, 3, acts, gl3, nullptr);
+            ln_fwd(gl3, GOAL, rows, GOAL, ln_lg_g, ln_lg_b, goal_t, GOAL, nullptr, 0, goal_st);
+            { EpiP ep = epi(la1, false); ep.relu = 1; lin_fwd(goal_t, GOAL, rows, cl_la0, ep, 128); }
+            { EpiP ep = epi(gt_txt[slot] + (int64_t)r0 * GOAL, true); lin_fwd(la1, 128, rows, cl_la2, ep, GOAL); }
+        }
+        gt_m[slot] = m;
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in hulc_clip_gt_encode"); return 1; }
+        HIP_CHECK(hipStreamSynchronize(st));          // lang_emb may be a host buffer the caller frees
+        return 0;
+    }
+    int clip_gt_scores(int slot, float* out_host, int64_t cap, int32_t* n_out, int32_t* m_out) override {
+        if (slot < 0 || slot > 1 || gt_m[slot] < 1) { hulc_set_error("hulc_clip_gt_scores: slot %d holds no encoded instructions", slot); return 1; }
+        if (val_clip_n < 1) { hulc_set_error("hulc_clip_gt_scores: the last hulc_validate had no masked lang rows (hulc.py:988-989 returns early)"); return 1; }
+        const int n = val_clip_n, m = gt_m[slot];
+        if (n_out) *n_out = n;
+        if (m_out) *m_out = m;
+        if (!out_host || cap < (int64_t)n * m) { hulc_set_error("hulc_clip_gt_scores: buffer of %lld floats, need %lld", (long long)cap, (long long)n * m); return 1; }
+        if (!gt_grow(gt_out, gt_out_cap, (int64_t)n * m)) { hulc_set_error("hulc_clip_gt_scores: allocation failed"); return 1; }
+        hipLaunchKernelGGL(clip_gt_scores_kernel, dim3(cdiv(m, 64), n), dim3(64), 0, st, img, gt_txt[slot], n, m, GOAL, logit_scale, gt_out);
+        if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in hulc_clip_gt_scores"); return 1; }
+        HIP_CHECK(hipMemcpyAsync(out_host, gt_out, sizeof(float) * (int64_t)n * m, hipMemcpyDefault, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         return 0;
     }
 

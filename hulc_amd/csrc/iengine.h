@@ -23,6 +23,8 @@ struct IEngine {
     virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)
     virtual int validate(const hulc_batch* b, const hulc_val_noise* nz, float* out17, int32_t* plan_pp_out, int32_t* plan_pr_out, float* pred_pp_out,
                          float* pred_pr_out) = 0;
+    virtual int clip_gt_encode(const float* lang_emb, int m, int slot) = 0;
+    virtual int clip_gt_scores(int slot, float* out_host, int64_t cap, int32_t* n_out, int32_t* m_out) = 0;
     virtual int rollout_reset() = 0;
     virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
                              const int32_t* plan_inject, int32_t* plan_out) = 0;

@@ -1819,6 +1819,21 @@ __global__ void __launch_bounds__(256) sum_rows_pair_kernel(const float* __restr
 }
 
 // =========================================================================================================
+// CLIP ground-truth scores (hulc.py:1024-1029): out[i][j] = exp(logit_scale) * <img_i / |img_i|, txt_j / |txt_j|>; grid (ceil(m/64), n)
+// =========================================================================================================
+__global__ void __launch_bounds__(64) clip_gt_scores_kernel(const float* __restrict__ img, const float* __restrict__ txt, int n, int m, int D,
+                                                            const float* __restrict__ logit_scale, float* __restrict__ out) {
+    const int i = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n || j >= m) return;
+    float a = 0.f, b = 0.f;
+    for (int d = 0; d < D; ++d) { a += img[i * D + d] * img[i * D + d]; b += txt[(long long)j * D + d] * txt[(long long)j * D + d]; }
+    const float na = sqrtf(a), nb = sqrtf(b), s = __expf(logit_scale[0]);
+    float c = 0.f;
+    for (int d = 0; d < D; ++d) c += (s * (img[i * D + d] / na)) * (txt[(long long)j * D + d] / nb);
+    out[(long long)i * m + j] = c;
+}
+
+// =========================================================================================================
 // CLIP-style auxiliary loss (hulc.py:679-695) on n <= 64 rows of 32-d projections; single block of 64 threads
 // writes loss, d img, d txt (already times `w`), d logit_scale (accumulated)
 // =========================================================================================================

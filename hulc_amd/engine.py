@@ -202,6 +202,28 @@ class StepEngine:
             res.update(pred_pp=pred_pp, pred_pr=pred_pr)
         return res
 
+    def clip_gt_encode(self, lang_emb, slot: int) -> None:
+        """encoded_lang_{train,val} of Hulc.on_validation_epoch_start (hulc.py:967-974) kept on the device: slot 0 = training instructions,
+        1 = validation instructions.  lang_emb: (m,384) fp32, numpy or tensor."""
+        keep = []
+        if isinstance(lang_emb, torch.Tensor):
+            lang_emb = lang_emb.to(dtype=torch.float32).contiguous()
+        p = self._dev_or_host_ptr(lang_emb, keep, np.float32)
+        m = int(lang_emb.shape[0])
+        if lang_emb.ndim != 2 or lang_emb.shape[1] != 384:
+            raise ValueError(f"lang_emb must be (m,384), got {tuple(lang_emb.shape)}")
+        L.check(self.lib.hulc_clip_gt_encode(self.ctx, p, m, int(slot)))
+
+    def clip_gt_scores(self, slot: int) -> np.ndarray:
+        """logits_per_image (n,m) of Hulc._clip_groundtruth_loss (hulc.py:1024-1029) for the masked rows of the last lang `validate`."""
+        n, m = C.c_int32(0), C.c_int32(0)
+        self.lib.hulc_clip_gt_scores(self.ctx, int(slot), None, 0, C.byref(n), C.byref(m))       # shape query: fails on purpose, fills n and m
+        if n.value < 1 or m.value < 1:
+            L.check(1)
+        out = np.empty((n.value, m.value), np.float32)
+        L.check(self.lib.hulc_clip_gt_scores(self.ctx, int(slot), out.ctypes.data, out.size, C.byref(n), C.byref(m)))
+        return out
+
     def rollout_reset(self):
         L.check(self.lib.hulc_rollout_reset(self.ctx))
 

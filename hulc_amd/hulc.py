@@ -260,6 +260,8 @@ class Hulc(torch.nn.Module):
         self.kl_beta = float(kl_beta)
         self.kl_balancing_mix = float(kl_balancing_mix)
         self.replan_freq = replan_freq
+        self.val_instructions = dict(val_instructions) if val_instructions else {}      # task -> [instruction] (conf/annotations/new_playtable_validation.yaml)
+        self._clip_gt = None
         self.modality_scope = "vis"
         self.optimizer_config = optimizer
         self.lr_scheduler = lr_scheduler
@@ -393,7 +395,87 @@ class Hulc(torch.nn.Module):
         self.engine.set_kl_beta(self.kl_beta)
 
     def on_fit_start(self) -> None:
-        """hulc.py:697-737 only builds CLIP-plot metadata from the datamodule (not used for training): no-op here."""
+        """hulc.py:697-737: preprocessing for the CLIP ground-truth metrics (`lang_gt/*`, validation only, never used for training).  Reads
+        <train>/lang_annotations/auto_lang_ann.npy (instructions, tasks, embeddings), <val>/.../auto_lang_ann.npy (task of every annotated
+        validation episode) and <val>/.../embeddings.npy (one embedding per validation task) through the datamodule's lang datasets.
+        The reference orders the unique instructions and the task ids by Python set iteration; here first occurrence decides — every logged
+        metric is invariant to that order.  A datamodule without `train_datasets` (SyntheticDataModule) has no annotations: the metrics are
+        then not logged."""
+        self._clip_gt = None
+        if not self.use_clip_auxiliary_loss:
+            return
+        dm = getattr(getattr(self, "trainer", None), "datamodule", None)
+        if dm is None or not hasattr(dm, "train_datasets"):
+            return
+        import pathlib
+        train_dataset, val_dataset = dm.train_datasets["lang"], dm.val_datasets["lang"]
+        load = lambda ds, f: np.load(pathlib.Path(ds.abs_datasets_dir) / ds.lang_folder / f, allow_pickle=True).item()
+        lang_data_train = load(train_dataset, "auto_lang_ann.npy")
+        lang_data_val = load(val_dataset, "auto_lang_ann.npy")
+        lang_embeddings_val = load(val_dataset, "embeddings.npy")
+        ann = list(lang_data_train["language"]["ann"])
+        first: Dict[str, int] = {}
+        for i, a in enumerate(ann):
+            first.setdefault(a, i)
+        train_lang_ids = list(first.values())                                            # one row per distinct instruction (hulc.py:714-717)
+        emb = np.asarray(lang_data_train["language"]["emb"])[train_lang_ids]
+        train_lang_emb = emb.reshape(len(train_lang_ids), -1).astype(np.float32)         # (m,1,384) -> (m,384) (.squeeze(), :719)
+        train_lang_tasks = [lang_data_train["language"]["task"][i] for i in train_lang_ids]
+        task_to_id: Dict[str, int] = {}
+        for t in train_lang_tasks:
+            task_to_id.setdefault(t, len(task_to_id))
+        val_lang_tasks, val_lang_emb = [], []
+        for val_task in (self.val_instructions or {}):                                   # hulc.py:729-735
+            if val_task not in task_to_id:
+                continue
+            val_lang_tasks.append(val_task)
+            val_lang_emb.append(np.asarray(lang_embeddings_val[val_task]["emb"][0], np.float32).reshape(1, -1))
+        if not val_lang_emb:
+            raise RuntimeError("on_fit_start: no task of model.val_instructions appears in the training annotations (the reference fails in torch.cat, hulc.py:736)")
+        self._clip_gt = dict(train_emb=train_lang_emb, val_emb=np.concatenate(val_lang_emb).astype(np.float32),
+                             train_task_ids=np.array([task_to_id[t] for t in train_lang_tasks]), val_task_ids=np.array([task_to_id[t] for t in val_lang_tasks]),
+                             task_to_id=task_to_id, val_tasks=list(lang_data_val["language"]["task"]), lang_lookup=val_dataset.lang_lookup, encoded=False)
+
+    def on_validation_epoch_start(self) -> None:
+        """hulc.py:967-974: encoded_lang_train / encoded_lang_val = language_goal(instruction embeddings) with the current weights; kept on the
+        device together with their proj_vis_lang projection (include/hulc_hip.h hulc_clip_gt_encode)."""
+        gt = getattr(self, "_clip_gt", None)
+        if gt is None:
+            return
+        self.engine.clip_gt_encode(gt["train_emb"], 0)
+        self.engine.clip_gt_encode(gt["val_emb"], 1)
+        gt["encoded"] = True
+
+    @staticmethod
+    def _clip_groundtruth_loss(logits: np.ndarray, task_ids: np.ndarray, gt_tasks: np.ndarray):
+        """hulc.py:1031-1043 on the (n,m) logits_per_image the engine returns: per-row min-max normalised scores, sum over the instructions
+        of the ground-truth task minus sum over the others, mean over rows; success rate of the arg-max instruction's task."""
+        scores = logits.astype(np.float32) - logits.min(1, keepdims=True)
+        scores = scores / (scores.max(1, keepdims=True) - scores.min(1, keepdims=True))
+        pos = task_ids[None, :] == gt_tasks[:, None]
+        loss = np.float32(np.mean(np.where(pos, scores, 0).sum(1, dtype=np.float32) - np.where(pos, 0, scores).sum(1, dtype=np.float32)))
+        sr = float(np.mean(task_ids[np.argmax(scores, 1)] == gt_tasks))
+        return float(loss), sr
+
+    def clip_groundtruth(self, idx, use_for_aux_loss) -> None:
+        """hulc.py:980-1005: CLIP ground-truth metric of the lang batch the engine validated last.  idx: episode indices of the batch;
+        use_for_aux_loss: bool mask (None = every row, like the reference's None check)."""
+        gt = getattr(self, "_clip_gt", None)
+        if gt is None:
+            return
+        idx = np.asarray(idx.cpu() if torch.is_tensor(idx) else idx).reshape(-1)
+        mask = np.ones(len(idx), bool) if use_for_aux_loss is None else np.asarray(use_for_aux_loss.cpu() if torch.is_tensor(use_for_aux_loss) else use_for_aux_loss, bool).reshape(-1)
+        if not mask.any():
+            return
+        if not gt["encoded"]:
+            raise RuntimeError("clip_groundtruth before on_validation_epoch_start (the reference fails on self.encoded_lang_train, hulc.py:996)")
+        gt_tasks = np.array([gt["task_to_id"][gt["val_tasks"][gt["lang_lookup"][int(i)]]] for i in idx])[mask]
+        train_score, train_sr = self._clip_groundtruth_loss(self.engine.clip_gt_scores(0), gt["train_task_ids"], gt_tasks)
+        val_score, val_sr = self._clip_groundtruth_loss(self.engine.clip_gt_scores(1), gt["val_task_ids"], gt_tasks)
+        self.log("lang_gt/train_gt", train_score, sync_dist=True)
+        self.log("lang_gt/val_gt", val_score, sync_dist=True)
+        self.log("lang_gt/train_sr", train_sr, sync_dist=True)
+        self.log("lang_gt/val_sr", val_sr, sync_dist=True)
 
     @property
     def num_training_steps(self) -> int:
@@ -571,6 +653,7 @@ class Hulc(torch.nn.Module):
             self.log(f"val_orn_mae/{sc}_orn_mae_pp", float(mae_pp[3:6].mean()), sync_dist=True)
             if is_lang and self.use_clip_auxiliary_loss:
                 self.log("val/val_pred_clip_loss", r["val_pred_clip_loss"], sync_dist=True)       # hulc.py:804-808
+                self.clip_groundtruth(dataset_batch.get("idx"), dataset_batch.get("use_for_aux_lang_loss"))
             self.log(f"val_kl/{sc}_kl_loss", r["kl_loss"], sync_dist=True)
             self.log(f"val_act/{sc}_act_loss_pp", r["action_loss_pp"], sync_dist=True)
             self.log(f"val_act/{sc}_act_loss_pr", r["action_loss_pr"], sync_dist=True)

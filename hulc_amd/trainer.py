@@ -153,18 +153,24 @@ class Trainer:
         if not hasattr(datamodule, "val_dataloader"):
             return {}
         module.eval()
+        if hasattr(module, "on_validation_epoch_start"):
+            module.on_validation_epoch_start()
         sums: Dict[str, float] = {}
+        counts: Dict[str, int] = {}
         n = 0
         for bi, batch in enumerate(datamodule.val_dataloader(self.rank)):
             if self.limit_val_batches is not None and bi >= self.limit_val_batches:
                 break
+            for k in [k for k in module.logged if k.startswith("lang_gt/")]:
+                del module.logged[k]                 # logged only by batches with masked lang rows (hulc.py:988-989): mean over those batches
             module.validation_step(batch, bi)
             for k, v in module.logged.items():
-                if k.startswith("val"):
+                if k.startswith("val") or k.startswith("lang_gt/"):
                     sums[k] = sums.get(k, 0.0) + float(v)
+                    counts[k] = counts.get(k, 0) + 1
             n += 1
         module.train()
-        out = {k: parallel.mean_scalar(v / max(n, 1), device=module.device) for k, v in sums.items()}
+        out = {k: parallel.mean_scalar(v / max(counts[k], 1), device=module.device) for k, v in sums.items()}
         self.val_history.append(out)
         return out
 

@@ -211,6 +211,20 @@ typedef struct hulc_val_noise {
 int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* noise, float* out_host, int32_t* plan_idx_pp_out,
                   int32_t* plan_idx_pr_out, float* pred_pp_out, float* pred_pr_out);
 
+/* ---- CLIP ground-truth validation metric (Hulc.on_validation_epoch_start, hulc/models/hulc.py:967-974, and the device part of
+ * Hulc._clip_groundtruth_loss, :1024-1029).  hulc_clip_gt_encode runs language_goal (goal_encoders.py:64-69) and proj_vis_lang.mlp_lang
+ * (proj_vis_lang.py) on m instruction embeddings (m,384) fp32, host or device, and keeps the (m,32) projections in `slot`
+ * (HULC_GT_TRAIN = encoded_lang_train, HULC_GT_VAL = encoded_lang_val) until the slot is encoded again; call it at the start of every
+ * validation epoch (the weights have moved).  hulc_clip_gt_scores returns logits_per_image (n,m) row-major on the host:
+ * exp(logit_scale) * <image projection of masked row i of the LAST hulc_validate (lang batch, use_for_aux rows in aux_rows order),
+ * projection j of the slot>, both L2-normalised.  It fails when that validate had no masked rows (the reference returns early, :988-989)
+ * or the context has no CLIP head.  The per-row min-max normalisation and the task bookkeeping (:1031-1043) are host logic
+ * (hulc_amd/hulc.py Hulc.clip_groundtruth).  *n_out / *m_out (optional) receive the shape even when the buffer is too small. */
+#define HULC_GT_TRAIN 0
+#define HULC_GT_VAL 1
+int hulc_clip_gt_encode(hulc_ctx* ctx, const float* lang_emb, int32_t m, int32_t slot);
+int hulc_clip_gt_scores(hulc_ctx* ctx, int32_t slot, float* scores_host, int64_t cap_floats, int32_t* n_out, int32_t* m_out);
+
 /* ---- Rollout (Hulc.reset / step, hulc/models/hulc.py:843-957; stateful LogisticDecoderRNN.act, logistic_decoder_rnn.py:102-116).
  * hulc_rollout_plan  = get_pp_plan_vision (:905-927: obs and goal frame encoded as one 2-frame window) or get_pp_plan_lang
  *                      (:929-948): latent goal + a plan sampled from the plan proposal; clears the decoder's hidden state.

@@ -1021,6 +1021,54 @@ def clip_loss(P, seq_feat, goal, mask):
     return loss, cache
 
 
+def clip_gt_setup(train_ann, train_task, train_emb, val_instr_tasks, val_emb):
+    """Hulc.on_fit_start (hulc.py:697-737) on in-memory annotation data.  train_ann / train_task: per training annotation; train_emb (N,1,384);
+    val_instr_tasks: the keys of model.val_instructions in order, val_emb (K,1,384) their embeddings.  The reference orders distinct
+    instructions / task ids by set iteration; first occurrence is used here (the metrics do not depend on the order)."""
+    first = {}
+    for i, a in enumerate(train_ann):
+        first.setdefault(str(a), i)
+    ids = list(first.values())
+    tasks = [str(train_task[i]) for i in ids]
+    task_to_id = {}
+    for t in tasks:
+        task_to_id.setdefault(t, len(task_to_id))
+    keep = [k for k, t in enumerate(val_instr_tasks) if str(t) in task_to_id]            # hulc.py:730-731
+    return dict(train_emb=np.asarray(train_emb)[ids].reshape(len(ids), -1).astype(F32), train_task_ids=np.array([task_to_id[t] for t in tasks]),
+                val_emb=np.asarray(val_emb)[keep].reshape(len(keep), -1).astype(F32), val_task_ids=np.array([task_to_id[str(val_instr_tasks[k])] for k in keep]),
+                task_to_id=task_to_id)
+
+
+def clip_gt_loss(P, seq_feat_masked, encoded_lang, task_ids, gt_tasks):
+    """Hulc._clip_groundtruth_loss (hulc.py:1007-1043)."""
+    img, _ = mlp_fwd(P, ["proj_vis_lang.mlp_im.0", "proj_vis_lang.mlp_im.2"], seq_feat_masked, False)
+    txt, _ = mlp_fwd(P, ["proj_vis_lang.mlp_lang.0", "proj_vis_lang.mlp_lang.2"], encoded_lang, False)
+    i_n = img / np.linalg.norm(img, axis=-1, keepdims=True)
+    t_n = txt / np.linalg.norm(txt, axis=-1, keepdims=True)
+    logits = (np.exp(P["logit_scale"]) * i_n) @ t_n.T
+    scores = logits - logits.min(1, keepdims=True)
+    scores = scores / (scores.max(1, keepdims=True) - scores.min(1, keepdims=True))
+    loss = []
+    for score, gt in zip(scores, gt_tasks):
+        loss.append(score[task_ids == gt].sum(dtype=F32) - score[task_ids != gt].sum(dtype=F32))
+    sr = float(np.mean(task_ids[np.argmax(scores, 1)] == gt_tasks))
+    return F32(np.mean(loss)), sr, logits.astype(F32)
+
+
+def clip_groundtruth(P, setup, seq_feat, mask, gt_tasks_all):
+    """Hulc.on_validation_epoch_start + clip_groundtruth (hulc.py:967-974, 980-1005): the four `lang_gt/*` values, or None when no row is masked in."""
+    mask = np.asarray(mask, bool)
+    if not mask.any():
+        return None
+    gt = np.asarray(gt_tasks_all)[mask]
+    sf = seq_feat[mask]
+    out = {}
+    for tag in ("train", "val"):
+        enc = goal_encode(P, setup[f"{tag}_emb"], True)
+        out[f"lang_gt/{tag}_gt"], out[f"lang_gt/{tag}_sr"], out[f"logits_{tag}"] = clip_gt_loss(P, sf, enc, setup[f"{tag}_task_ids"], gt)
+    return out
+
+
 def clip_loss_bwd(P, G, c, scale, B):
     dlog = c["dlog"] * F32(scale)
     s = c["s"]
