@@ -470,53 +470,9 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 8>(st, p);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// conv1 forward (8x8 stride 4, 3 -> 32, + bias + ReLU) straight from the fp32 NCHW boundary frames.
-// The band of input rows is converted to bf16 while staged ([c][row][iw] image, each input byte read from HBM once instead
-// of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
-// x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int MINW>
-__global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias,
-                                                           h16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
-                                                           unsigned* __restrict__ maskbits, float* __restrict__ zero8a = nullptr, float* __restrict__ zero8b = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    lds_char* ximg = (lds_char*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the step's loss accumulators (8 floats each) are cleared by the forward's FIRST kernel instead of by two 32-byte memsets (~5 us of launch each)
-    if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
-    const int g = lane >> 4, li = lane & 15;
-    const int XR = (R - 1) * 4 + 8;
-    const int XRS = IW * 2 + 16;
-    const int W4 = IW >> 2;
-    h16x8_t wf[6][2];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
-    // ^ A-operand row m of tile ct carries output channel (m >> 2) * 8 + ct * 4 + (m & 3): with the 16x16 C/D map (row = 4 g + r) lane group g then owns
-    //   the 8 CONSECUTIVE channels 8 g .. 8 g + 7 of its pixel — one 16-byte store per lane and 1 KB contiguous per wave store (two 8-byte stores to
-    //   interleaved 32-byte halves of every pixel before)
-    // (c, kh) row of this lane group for each k-step
-    int rowsel[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
-    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
-    const int nitems = Nf * nbands;
-    // frame-wise (fw, experiment knob HULC_C1_FW=1): a workgroup walks the bands of one frame back to back so that the rows two bands share come
-    // from L2 — what cut conv1's weight gradient by 25 % measured 0.4 % SLOWER here (4 resident workgroups per CU already re-read those rows
-    // from the XCD's L2 within microseconds; the frame-wise order only removes the interleaving of their phases): default item-wise
-    const bool fw = Nf >= (int)gridDim.x && !(dbg & 32);
-    for (int it = blockIdx.x; fw ? (it < Nf) : (it < nitems); it += gridDim.x)
-    for (int bnd = 0; bnd < (fw ? nbands : 1); ++bnd) {
-        const int item = fw ? it * nbands + bnd : it;
-        const int f = item / nbands, b = item % nbands;
-        const int oh0 = b * R;
-        const int ih0 = oh0 * 4;
-        const int rows = min(XR, IH - ih0);
-        __syncthreads();
-        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
-        __syncthreads();
+// the multiply + epilogue of one staged band (shared by the fp32 / register-staged kernel and the uint8 LDS-DMA kernel below)
+DEVI void conv1_fwd_band_tiles(lds_char* ximg, const h16x8_t (&wf)[6][2], const int (&rowsel)[6], const float4 (&bb)[2], h16_t* __restrict__ out,
+                               unsigned* __restrict__ maskbits, int f, int oh0, int R, int OH, int OW, int XRS, int dbg, int wave, int g, int li) {
         const int RBe = min(R, OH - oh0);
         const int npix = RBe * OW;
         const int ntm = (dbg & 2) ? 0 : (npix + 15) >> 4;
@@ -577,13 +533,184 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
                 }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 forward (8x8 stride 4, 3 -> 32, + bias + ReLU) straight from the fp32 NCHW boundary frames.
+// The band of input rows is converted to bf16 while staged ([c][row][iw] image, each input byte read from HBM once instead
+// of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
+// x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           h16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
+                                                           unsigned* __restrict__ maskbits, float* __restrict__ zero8a = nullptr, float* __restrict__ zero8b = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    lds_char* ximg = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the step's loss accumulators (8 floats each) are cleared by the forward's FIRST kernel instead of by two 32-byte memsets (~5 us of launch each)
+    if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
+    const int g = lane >> 4, li = lane & 15;
+    const int XR = (R - 1) * 4 + 8;
+    const int XRS = IW * 2 + 16;
+    const int W4 = IW >> 2;
+    h16x8_t wf[6][2];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
+    // ^ A-operand row m of tile ct carries output channel (m >> 2) * 8 + ct * 4 + (m & 3): with the 16x16 C/D map (row = 4 g + r) lane group g then owns
+    //   the 8 CONSECUTIVE channels 8 g .. 8 g + 7 of its pixel — one 16-byte store per lane and 1 KB contiguous per wave store (two 8-byte stores to
+    //   interleaved 32-byte halves of every pixel before)
+    // (c, kh) row of this lane group for each k-step
+    int rowsel[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
+    const int nitems = Nf * nbands;
+    // frame-wise (fw, experiment knob HULC_C1_FW=1): a workgroup walks the bands of one frame back to back so that the rows two bands share come
+    // from L2 — what cut conv1's weight gradient by 25 % measured 0.4 % SLOWER here (4 resident workgroups per CU already re-read those rows
+    // from the XCD's L2 within microseconds; the frame-wise order only removes the interleaving of their phases): default item-wise
+    const bool fw = Nf >= (int)gridDim.x && !(dbg & 32);
+    for (int it = blockIdx.x; fw ? (it < Nf) : (it < nitems); it += gridDim.x)
+    for (int bnd = 0; bnd < (fw ? nbands : 1); ++bnd) {
+        const int item = fw ? it * nbands + bnd : it;
+        const int f = item / nbands, b = item % nbands;
+        const int oh0 = b * R;
+        const int ih0 = oh0 * 4;
+        const int rows = min(XR, IH - ih0);
+        __syncthreads();
+        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
+        __syncthreads();
+        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li);
+    }
+}
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 forward for the uint8 (.., H, W, C) boundary with the NEXT band's raw rows copied global -> LDS by the DMA path (no registers, nothing
+// waits for them) while the current band is multiplied.  conv1_fwd_kernel's uint8 branch loads, waits, converts, multiplies per band and relies on
+// the other three resident workgroups to cover the load latency: 216 us for the static camera against ~105 us of HBM time (561 MB).
+//   * raw layout = conv1_stage_band's: row r at raw + r * RP behind a margin of LM bytes, i.e. 16-byte slots [3 margin | 38 data | 3 margin];
+//     slot 3 + c of a row receives source bytes [16 c, 16 c + 16) of the (row-clamped, RandomShiftsAug replicate pad) source row — the last
+//     data slot carries 8 bytes of the following row, which nothing reads; at the very end of the frame buffer that lane is switched off and
+//     the 8 bytes are patched by one thread.  global_load_lds_dwordx4 accepts 4-byte-aligned sources and writes lane i at M0 + 16 i
+//     (tools/dma96_probe.hip; dwordx3 strides 16 too), inactive lanes write nothing.
+//   * the replicated column margins (needed only when the frame's column shift is not zero) come from the two edge pixels of every row, loaded
+//     into one register at prefetch time and written before the barrier that publishes the raw rows.
+// Measured on 2048 static-camera frames (tools/time_conv1_fwd.py): 205 -> 177 us (212 -> 182 with shifts); DMA alone 48 us, + conversion 87, + multiply
+// 130.  The same structure with 8 waves, two workgroups per CU and 9-row bands: 177 us — no better; for the fp32 boundary (raw fp32 band through
+// the DMA path, LDS -> LDS conversion): 283 against conv1_fwd_kernel's 270 us, both at the mixed read/write streaming floor of ~245 us (tools/mixbench.hip).
+// ---------------------------------------------------------------------------------------------------------------------
+DEVI void c1_lds_dma16(const void* src, lds_char* dst) {
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
+}
+__global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias, h16_t* __restrict__ out,
+                                                                 int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg, unsigned* __restrict__ maskbits,
+                                                                 float* __restrict__ zero8a, float* __restrict__ zero8b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    lds_char* ximg = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
+    const int g = lane >> 4, li = lane & 15;
+    const int XR = (R - 1) * 4 + 8;
+    const int XRS = IW * 2 + 16;
+    const int W4 = IW >> 2;
+    lds_char* raw = ximg + 3 * XR * XRS + 64;
+    const int RB = IW * 3, RP = conv1_raw_pitch16(IW);
+    constexpr int LM = CONV1_RAW_MARGIN * 3;
+    const int SPR = RP >> 4, DS = (RB + 15) >> 4;                 // 16-byte slots per raw row, data slots per row (the last one may be partial)
+    const int tailb = RB & 15;                                    // bytes of the last data slot that belong to the row (0: all 16)
+    h16x8_t wf[6][2];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
+    int rowsel[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X.X);
+    const long long total = (long long)Nf * IH * RB;              // bytes of the frame buffer
+    const int nitems = Nf * nbands;
+    const float inv_spr = 1.f / (float)SPR;
+    unsigned pe = 0;                                              // edge pixel of (row tid >> 1, side tid & 1) of the band in flight
+    int pdx = 0, prows = 0;
+    auto prefetch = [&](int item) {
+        const int f = item / nbands, ih0 = (item % nbands) * R * 4;
+        const int rows = min(XR, IH - ih0);
+        int dy = 0;
+        pdx = 0; prows = rows;
+        if (X.shift) { pdx = X.shift[2 * f] - X.pad; dy = X.shift[2 * f + 1] - X.pad; }
+        const long long fb = (long long)f * IH * RB;
+        const int nslot = rows * SPR;
+        for (int n0 = wave * 64; n0 < nslot; n0 += 256) {
+            const int n = n0 + lane;
+            const int r = (int)(((float)n + 0.5f) * inv_spr), sl = n - r * SPR;       // exact for n < 2^22 / SPR
+            const int c = sl - (LM >> 4);
+            const long long so = fb + (long long)min(max(ih0 + r + dy, 0), IH - 1) * RB + c * 16;
+            if (n < nslot && c >= 0 && c < DS && so + 16 <= total) c1_lds_dma16(Xb + so, raw + n0 * 16);
+        }
+        if (tailb && fb + (long long)IH * RB == total && tid == 255) {                // the frame buffer's last row may be part of this band: its partial last slot
+            for (int r = 0; r < rows; ++r)
+                if (min(max(ih0 + r + dy, 0), IH - 1) == IH - 1) {
+                    const unsigned char* sp = Xb + total - tailb;
+                    for (int k = 0; k < tailb; k += 4) *(__attribute__((address_space(3))) unsigned*)(raw + r * RP + LM + (DS - 1) * 16 + k) = *reinterpret_cast<const unsigned*>(sp + k);
+                }
+        }
+        if (pdx != 0 && tid < 2 * rows) {
+            const int rr = tid >> 1, side = tid & 1;
+            pe = *reinterpret_cast<const unsigned*>(Xb + fb + (long long)min(max(ih0 + rr + dy, 0), IH - 1) * RB + (side ? RB - 4 : 0));
+        }
+    };
+    int item = blockIdx.x;
+    if (item < nitems) prefetch(item);
+    const Step256 sq(W4);
+    const RowCol q0{tid / W4, tid % W4};
+    for (; item < nitems; item += gridDim.x) {
+        const int f = item / nbands, b = item % nbands;
+        const int oh0 = b * R;
+        const int rows = prows, dx = pdx;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this band's raw rows (and edge pixels) have landed
+        if (dx != 0 && tid < 2 * rows) {                          // replicate margins (F.pad(..., "replicate"))
+            const int rr = tid >> 1, side = tid & 1;
+            const unsigned px = side ? (pe >> 8) : (pe & 0xffffffu);
+            lds_char* dst = raw + rr * RP + (side ? LM + RB : 0);
+            for (int k = 0; k < CONV1_RAW_MARGIN; ++k) {
+                dst[k * 3 + 0] = (char)(px & 0xff); dst[k * 3 + 1] = (char)((px >> 8) & 0xff); dst[k * 3 + 2] = (char)((px >> 16) & 0xff);
+            }
+        }
+        __syncthreads();                                          // raw complete for every wave; the previous band's multiply is over (ximg free)
+        if (!(dbg & 4)) {
+            const float sc = 2.f / 255.f;
+            for (RowCol p = q0; p.r < rows; sq.adv(p)) {
+                const int o = p.r * RP + LM + (p.c * 4 + dx) * 3;
+                const int sh = o & 3;
+                const __attribute__((address_space(3))) unsigned* wp = (const __attribute__((address_space(3))) unsigned*)(raw + (o & ~3));
+                const unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
+                float v[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    u32x2_t ov;
+                    ov[0] = pack2h(v[c], v[3 + c]);
+                    ov[1] = pack2h(v[6 + c], v[9 + c]);
+                    *(__attribute__((address_space(3))) u32x2_t*)(ximg + (c * XR + p.r) * XRS + p.c * 8) = ov;
+                }
+            }
+        }
+        __syncthreads();                                          // ximg complete, raw consumed
+        if (item + (int)gridDim.x < nitems) prefetch(item + (int)gridDim.x);         // lands during the multiply below
+        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li);
     }
 }
 static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16_t* W, const float* bias, h16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,
                                     unsigned* maskbits = nullptr, float* zero8a = nullptr, float* zero8b = nullptr) {
     // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
     //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
-    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch(IW) + 16 : 0); };   // + raw uint8 rows
+    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch16(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = HULC_SWITCH("HULC_C1_LDS", 39);   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = HULC_SWITCH("HULC_C1_WG", 1024);
     int R = OH;
@@ -600,6 +727,13 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
         attr_set = true;
     }
     const int items = Nf * nbands;
+    static const int u8dma = HULC_SWITCH("HULC_C1_U8DMA", 1);
+    if (X.u8 && u8dma && (IW * 3) % 4 == 0 && ((uintptr_t)X.X & 3) == 0) {
+        static bool a2 = false;
+        if (!a2) { hipFuncSetAttribute((const void*)conv1_fwd_u8dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
+        hipLaunchKernelGGL(conv1_fwd_u8dma_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
+        return;
+    }
     if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
     else hipLaunchKernelGGL(conv1_fwd_kernel<2>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
 }

@@ -663,6 +663,7 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
 //     4x fewer input bytes and no fp32 copy of the frames ever exists.
 // ---------------------------------------------------------------------------------------------------------------------
 #define CONV1_RAW_MARGIN 16          // replicated edge pixels each side of a raw uint8 row (>= the largest RandomShiftsAug pad; 48 bytes)
+static inline __host__ __device__ int conv1_raw_pitch16(int IW) { return (((IW + 2 * CONV1_RAW_MARGIN) * 3 + 8 + 7) & ~7) + 15 & ~15; }   // the same rounded to the LDS-DMA path's 16-byte slots
 static inline __host__ __device__ int conv1_raw_pitch(int IW) { return ((IW + 2 * CONV1_RAW_MARGIN) * 3 + 8 + 7) & ~7; }   // bytes per raw row (+8: the 16-byte read window)
 struct Conv1Src {
     const void* X;         // fp32 NCHW (u8 == 0) or uint8 NHWC (u8 == 1)
