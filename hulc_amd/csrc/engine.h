@@ -1455,6 +1455,7 @@ struct Engine : IEngine {
         const int n = val_clip_n, m = gt_m[slot];
         if (n_out) *n_out = n;
         if (m_out) *m_out = m;
+        if (!out_host && cap == 0) return 0;                                   // shape query
         if (!out_host || cap < (int64_t)n * m) { hulc_set_error("hulc_clip_gt_scores: buffer of %lld floats, need %lld", (long long)cap, (long long)n * m); return 1; }
         if (!gt_grow(gt_out, gt_out_cap, (int64_t)n * m)) { hulc_set_error("hulc_clip_gt_scores: allocation failed"); return 1; }
         hipLaunchKernelGGL(clip_gt_scores_kernel, dim3(cdiv(m, 64), n), dim3(64), 0, st, img, gt_txt[slot], n, m, GOAL, logit_scale, gt_out);

@@ -217,9 +217,7 @@ class StepEngine:
     def clip_gt_scores(self, slot: int) -> np.ndarray:
         """logits_per_image (n,m) of Hulc._clip_groundtruth_loss (hulc.py:1024-1029) for the masked rows of the last lang `validate`."""
         n, m = C.c_int32(0), C.c_int32(0)
-        self.lib.hulc_clip_gt_scores(self.ctx, int(slot), None, 0, C.byref(n), C.byref(m))       # shape query: fails on purpose, fills n and m
-        if n.value < 1 or m.value < 1:
-            L.check(1)
+        L.check(self.lib.hulc_clip_gt_scores(self.ctx, int(slot), None, 0, C.byref(n), C.byref(m)))       # shape query
         out = np.empty((n.value, m.value), np.float32)
         L.check(self.lib.hulc_clip_gt_scores(self.ctx, int(slot), out.ctypes.data, out.size, C.byref(n), C.byref(m)))
         return out

@@ -219,7 +219,7 @@ int hulc_validate(hulc_ctx* ctx, const hulc_batch* batch, const hulc_val_noise* 
  * exp(logit_scale) * <image projection of masked row i of the LAST hulc_validate (lang batch, use_for_aux rows in aux_rows order),
  * projection j of the slot>, both L2-normalised.  It fails when that validate had no masked rows (the reference returns early, :988-989)
  * or the context has no CLIP head.  The per-row min-max normalisation and the task bookkeeping (:1031-1043) are host logic
- * (hulc_amd/hulc.py Hulc.clip_groundtruth).  *n_out / *m_out (optional) receive the shape even when the buffer is too small. */
+ * (hulc_amd/hulc.py Hulc.clip_groundtruth).  scores_host == NULL with cap_floats == 0 is a shape query: *n_out / *m_out are filled and 0 is returned (they are also filled when the buffer is too small). */
 #define HULC_GT_TRAIN 0
 #define HULC_GT_VAL 1
 int hulc_clip_gt_encode(hulc_ctx* ctx, const float* lang_emb, int32_t m, int32_t slot);
