@@ -105,7 +105,7 @@ struct Engine : IEngine {
     int* pidx; int* pidx_in;
     T *xt[3], *qkv[2], *ao[2], *x1t[2], *hff[2];
     float *xf[3], *Pat[2], *y1[2], *st1[2], *x1f[2], *y2[2], *st2[2];
-    float* zero_arena = nullptr; int64_t zero_n = 0;
+    float* zero_arena = nullptr; int64_t zero_n = 0; bool arena_clean = false;   // arena_clean: the forward's last launch has cleared it (only a backward writes it)
     int* work_ctrs = nullptr; int work_ctr_next = 0;
     int* next_ctr() { return work_ctrs ? work_ctrs + (work_ctr_next++ & 63) : nullptr; }
     float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
@@ -1029,6 +1029,7 @@ struct Engine : IEngine {
     void trunk_fwd(const hulc_batch* b, float dp) {
         const int B = b->B, S = b->S, N = B * S;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
+        bool ppx_packed = false;
         (void)dp;
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
         {
@@ -1052,18 +1053,25 @@ struct Engine : IEngine {
             ln_fwd(gl3 + Bv * GOAL, GOAL, Bl, GOAL, ln_lg_g, ln_lg_b, goal_t + Bv * GOAL, GOAL, nullptr, 0, goal_st + 2 * Bv);
         } else {
             T* acts[2] = {gl1, gl2};
+            // hulc / mcil: the LayerNorm launch also packs the plan proposal's input rows [emb[:,0,:] | goal] (goal_ln_concat_kernel)
+            auto goal_ln = [&](const float* g_, const float* b_) {
+                if (hulc || mcil) {
+                    hipLaunchKernelGGL((goal_ln_concat_kernel<T>), dim3(cdiv(B, 4) + cdiv(B * EMB, 256)), dim3(256), 0, st, gl3, B, GOAL, g_, b_, goal_t, goal_st, emb, (long long)S * EMB, EMB, ppx);
+                    ppx_packed = true;
+                } else ln_fwd(gl3, GOAL, B, GOAL, g_, b_, goal_t, GOAL, nullptr, 0, goal_st);
+            };
             if (b->is_lang) {
                 hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * LANG, 256)), dim3(256), 0, st, b->lang, lang_t, (long long)B * LANG);
                 mlp_fwd(lang_t, LANG, B, lg, 3, acts, gl3, nullptr);
-                ln_fwd(gl3, GOAL, B, GOAL, ln_lg_g, ln_lg_b, goal_t, GOAL, nullptr, 0, goal_st);
+                goal_ln(ln_lg_g, ln_lg_b);
             } else {
                 mlp_fwd(emb + (long long)(S - 1) * EMB, (long long)S * EMB, B, vg, 3, acts, gl3, nullptr);
-                ln_fwd(gl3, GOAL, B, GOAL, ln_vg_g, ln_vg_b, goal_t, GOAL, nullptr, 0, goal_st);
+                goal_ln(ln_vg_g, ln_vg_b);
             }
         }
         // ---- plan proposal (plan_proposal_net.py:42-47)
         if (hulc || mcil) {
-            hipLaunchKernelGGL((concat_pp_kernel<T>), dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, emb, (long long)S * EMB, EMB, goal_t, GOAL, B, ppx);
+            if (!ppx_packed) hipLaunchKernelGGL((concat_pp_kernel<T>), dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, emb, (long long)S * EMB, EMB, goal_t, GOAL, B, ppx);
             mlp_fwd(ppx, EMB + GOAL, B, pp, 5, ppa, pp_logits, nullptr);
         }
         STAGE("goal+pp_fwd");
@@ -1092,7 +1100,8 @@ struct Engine : IEngine {
                     TimerScope ts(this, "transformer_fused", "mfma", 2.0 * N * (4.0 * EMB * EMB + 2.0 * EMB * FF + 2.0 * S * EMB), (double)N * (4 * EMB + FF) * sizeof(T));
                     launch_tr_layer_fwd(st, q);
                 }
-                ln_fwd(y2[1], EMB, N, EMB, tr_n2g[1], tr_n2b[1], xt[2], EMB, xf[2], EMB, st2[1]);
+                // the last norm2 and the mean over the window in one launch (the normalised rows are kept for tests only)
+                hipLaunchKernelGGL((layernorm_mean_kernel<T>), dim3(B), dim3(256), 0, st, y2[1], S, EMB, tr_n2g[1], tr_n2b[1], st2[1], xm, xf[2]);
             }
         }
         for (int l = 0; l < 2 && !fused; ++l) {
@@ -1113,7 +1122,7 @@ struct Engine : IEngine {
             ln_fwd(y2[l], EMB, N, EMB, tr_n2g[l], tr_n2b[l], xt[l + 1], EMB, xf[l + 1], EMB, st2[l]);
         }
         // mean over S commutes with the affine fc (:113-114): seq_feat = fc(mean_t x)
-        hipLaunchKernelGGL((mean_over_s_kernel<T>), dim3(cdiv(B * EMB, 256)), dim3(256), 0, st, xf[2], B, S, EMB, xm);
+        if (!fused) hipLaunchKernelGGL((mean_over_s_kernel<T>), dim3(cdiv(B * EMB, 256)), dim3(256), 0, st, xf[2], B, S, EMB, xm);
         { EpiP ep = epi(seqf, true); ep.out2 = seqf_t; ep.out2_lo = 0; ep.out2_hi = (long long)B * FCH;      // the 16-bit copy the next GEMM reads: a second store of the epilogue
           lin_fwd(xm, EMB, B, pr_fc, ep, FCH); }
         { EpiP ep = epi(pr_logits, true); lin_fwd(seqf_t, FCH, B, pr_fs, ep, PLAN); }
@@ -1124,6 +1133,9 @@ struct Engine : IEngine {
     void dec_fwd(const int* plan_idx, int B, int S, const T* h0_0, const T* h0_1) {
         const int SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
+        // 16-bit engines (hulc / gcbc): the goal term of the time-invariant decoder input is added inside the plan-gather launch; the fp32 (parity)
+        // engine and mcil (whose plan term is a GEMM already) keep the K = 32 GEMM and its summation order
+        const bool cb_fused = !mcil && !std::is_same<T, float>::value;
             // time-major copy of the gripper half of emb: embg[t*B+b][0:64] = emb[b][t][64:128]
             if (mcil) {      // continuous plan (B,256): a GEMM against the plan columns of W_ih0 instead of the one-hot column gather
                 hipLaunchKernelGGL((gather_embg_kernel<T>), dim3(cdiv(SB * DE, 256)), dim3(256), 0, st, emb, embg, B, S, DE);
@@ -1131,8 +1143,8 @@ struct Engine : IEngine {
                 gemm(dense<T>(plan_t, B, dec_plan), dense<T>(wih0, HID, KIN), dense_out(HID), ep, B, HID, dec_plan);
             } else      // the one-hot plan gather and the time-major embedding copy are independent: one launch
             hipLaunchKernelGGL((plan_gather_t_kernel<T>), dim3(cdiv(B * HID, 256) + cdiv(SB * DE, 256)), dim3(256), 0, st, wih0T, plan_idx, B, hulc ? NCAT : 0, NCLS, HID, bih0,
-                               bhh0, Cplan, emb, embg, S, DE);
-            { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
+                               bhh0, Cplan, emb, embg, S, DE, goal_t, GOAL, dec_plan + DE, cb_fused ? Cb : (T*)nullptr);
+            if (!cb_fused) { EpiP ep = epi(Cb, false); ep.res = Cplan; ep.res_f32 = 1; ep.res_ld = HID;
               gemm(dense<T>(goal_t, B, GOAL), dense<T>(wih0 + dec_plan + DE, HID, KIN), dense_out(HID), ep, B, HID, GOAL); }
             const long long BH = (long long)B * HID;
             { EpiP ep = epi(Zx0, false); ep.res = Cb; ep.res_ld = HID; ep.res_rowmod = B;
@@ -1285,7 +1297,11 @@ struct Engine : IEngine {
         have_fwd = true;
         // [total_mod, kl, action, clip]; a device `out` is written by the kernels themselves
         float* const dev_out = (out && !on_host) ? out : nullptr;
-        if (!pair) hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, kl_src, kl_n, cfg.kl_beta / Bm, losses, dev_out);
+        if (!pair) {     // + the backward's zero arena (4 MB), cleared by 255 more blocks of the same launch instead of a memset at the head of the backward
+            hipLaunchKernelGGL(finish_losses_kernel, dim3(256), dim3(256), 0, st, rowloss, SB * 8, 1.f / SB, kl_src, kl_n, cfg.kl_beta / Bm, losses, dev_out,
+                               reinterpret_cast<float4*>(zero_arena), (long long)(zero_n / 4));
+            arena_clean = true;
+        }
         else if (out) {
             hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses, dev_out);
             hipLaunchKernelGGL(pack_losses_kernel, dim3(1), dim3(1), 0, st, losses2, dev_out ? dev_out + 4 : (float*)nullptr);
@@ -2135,7 +2151,8 @@ struct Engine : IEngine {
         const float dp = cfg.dropout_p;
         const long long BH = (long long)B * HID;
         if (part == 1) goto encoders;
-        HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
+        if (!arena_clean) HIP_CHECK(hipMemsetAsync(zero_arena, 0, sizeof(float) * zero_n, st));   // demb, dgoal, dseqf, heads / fc7 gradient temporaries, work counters
+        arena_clean = false;
         work_ctr_next = 0;
         // tests (hulc_set_option debug_poison_partials): the weight-gradient slab arena is never zeroed — every slab element must be WRITTEN before the
         // unpack launches sum it.  NaN-filling it makes a slab cell that is read-modify-written (the ragged last k-tile of fc7) visible
@@ -2244,8 +2261,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((st_softmax_bwd_kernel<T>), dim3(B * NCAT), dim3(64), 0, st, probs, dplan, dpr_kl, NCLS, dprl, dprl_t, dpp_kl, dppl_t);
             DenseOut om = dense_out(EMB + GOAL);
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
-            copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
-            copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            hipLaunchKernelGGL(pp_input_bwd_kernel, dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, dppx, B, EMB, GOAL, demb, (long long)S * EMB, dgoal);
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             // fc_state of plan recognition
             lin_wgrad(dprl_t, seqf_t, FCH, B, PLAN, FCH, pr_fs.dW, FCH, pr_fs.db);
@@ -2262,8 +2278,7 @@ struct Engine : IEngine {
             hipLaunchKernelGGL((cast_kernel<float, T>), dim3(cdiv(B * PLAN, 256)), dim3(256), 0, st, dpp_kl, dppl_t, (long long)B * PLAN);
             DenseOut om = dense_out(EMB + GOAL);
             mlp_bwd(dppl_t, ppx, EMB + GOAL, B, pp, 5, ppa, dt_a, dt_a + (long long)B * HID, dppx, &om, 0);
-            copy2d<float, float>(dppx, EMB + GOAL, demb, (long long)S * EMB, B, EMB, 1);
-            copy2d<float, float>(dppx + EMB, EMB + GOAL, dgoal, GOAL, B, GOAL, 1);
+            hipLaunchKernelGGL(pp_input_bwd_kernel, dim3(cdiv(B * (EMB + GOAL), 256)), dim3(256), 0, st, dppx, B, EMB, GOAL, demb, (long long)S * EMB, dgoal);
             if (bucket_ready(1)) return 1;   // plan_proposal.* final
             if (gru) bigru_bwd(dprl_t, B, S); else birnn_bwd(dprl_t, B, S);
         }

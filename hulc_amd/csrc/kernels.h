@@ -318,6 +318,15 @@ __global__ void copy2d_kernel(const TS* __restrict__ src, long long lds_, TD* __
     *o = from_f<TD>(accumulate ? to_f<TD>(*o) + v : v);
 }
 
+// the plan proposal's input gradient [B][E + G] added onto its two sources in one launch: columns [0, E) -> d emb[:, 0, :] (row stride ld_e), [E, E + G) -> d goal
+__global__ void pp_input_bwd_kernel(const float* __restrict__ dppx, int B, int E, int G, float* __restrict__ demb, long long ld_e, float* __restrict__ dgoal) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * (E + G)) return;
+    const int r = idx / (E + G), c = idx - r * (E + G);
+    float* o = c < E ? demb + (long long)r * ld_e + c : dgoal + (long long)r * G + (c - E);
+    *o += dppx[idx];
+}
+
 // =========================================================================================================
 // column sums (bias grads): out[n] (+)= scale * sum_m X[m][n]; two-stage when rows are split
 // =========================================================================================================
@@ -1204,6 +1213,29 @@ __global__ void mean_over_s_kernel(const float* __restrict__ x, int B, int S, in
     for (int t = 0; t < S; ++t) s += x[((long long)b * S + t) * D + d];      // eight independent loads in flight (the sum order is unchanged)
     out[idx] = from_f<T>(s / S);
 }
+// LayerNorm of the S rows of window b followed by their mean over S (the plan-recognition transformer's last norm2 + the mean that feeds fc,
+// plan_recognition_net.py:110-114): one block per window, a wave per row (4 rows at a time); stats [rows][2] kept for the backward, n <= 128.
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_mean_kernel(const float* __restrict__ x, int S, int n, const float* __restrict__ g, const float* __restrict__ bta,
+                                                             float* __restrict__ stats, T* __restrict__ out, float* __restrict__ yout) {
+    __shared__ float part[4][128];
+    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = w; t < S; t += 4) {
+        const long long row = (long long)b * S + t;
+        const float* xr = x + row * n;
+        const float v0 = lane < n ? xr[lane] : 0.f, v1 = lane + 64 < n ? xr[lane + 64] : 0.f;
+        const float mean = wave_sum(v0 + v1) / n;
+        const float d0 = lane < n ? v0 - mean : 0.f, d1 = lane + 64 < n ? v1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / n + 1e-5f);
+        if (lane < n) { const float y = d0 * rstd * g[lane] + bta[lane]; a0 += y; yout[row * n + lane] = y; }
+        if (lane + 64 < n) { const float y = d1 * rstd * g[lane + 64] + bta[lane + 64]; a1 += y; yout[row * n + lane + 64] = y; }
+        if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    }
+    part[w][lane] = a0; part[w][lane + 64] = a1;
+    __syncthreads();
+    if (threadIdx.x < n) out[(long long)b * n + threadIdx.x] = from_f<T>((((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / S);
+}
 // dx[b][t][d] = dxm[b][d] / S
 __global__ void bcast_over_s_kernel(const float* __restrict__ dxm, int B, int S, int D, float* __restrict__ dx) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1409,7 +1441,10 @@ __global__ void __launch_bounds__(64) st_softmax_bwd_kernel(const float* __restr
 template <typename T>
 __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
                                      const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out,
-                                     const T* __restrict__ emb = nullptr, T* __restrict__ embg = nullptr, int S = 0, int W = 0) {
+                                     const T* __restrict__ emb = nullptr, T* __restrict__ embg = nullptr, int S = 0, int W = 0,
+                                     const T* __restrict__ goal = nullptr, int G = 0, int grow0 = 0, T* __restrict__ cb = nullptr) {
+    // cb (optional): the decoder's whole time-invariant input term in one launch — Cb[b][i] = Cplan[b][i] + sum_k goal[b][k] WihT[grow0 + k][i]
+    // (the K = 32 GEMM that used to follow this launch)
     // blocks past the B * H / blockDim of the plan gather carry the (independent) time-major copy of the embedding's last W columns
     // (gather_embg_kernel's job: embg[(t*B+b)*W + c] = emb[(b*S+t)*128 + (128-W) + c]) — one launch instead of two
     const int nb_plan = (B * H + blockDim.x - 1) / blockDim.x;
@@ -1439,6 +1474,11 @@ __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, con
     } else
         for (int c = 0; c < NCAT; ++c) s += to_f<T>(w_t[(long long)(c * NCLS + sidx[c]) * H + i]);
     out[gid] = s;
+    if (cb) {
+        float a = 0.f;
+        for (int k = 0; k < G; ++k) a += to_f<T>(goal[b * G + k]) * to_f<T>(w_t[(long long)(grow0 + k) * H + i]);
+        cb[gid] = from_f<T>(s + a);
+    }
 }
 // dW_ih[i][cat*NCLS + cls] += sum_{b: idx[b][cat] == cls} dC[b][i], b-ordered.  Block (cat, 64-wide i tile): the [NCLS][64] tile is
 // accumulated in LDS with coalesced dC reads, then added to dW with NCLS consecutive floats per row (128-byte segments).
@@ -1496,6 +1536,31 @@ __global__ void sum_over_t_kernel(const T* __restrict__ x, int S, long long BH, 
 #pragma unroll 8
     for (int t = 0; t < S; ++t) s += to_f<T>(x[(long long)t * BH + i]);
     out[i] = from_f<T>(s);
+}
+// The goal encoder's LayerNorm (n <= 64 features) and the plan proposal's input rows [emb[:,0,:] | goal] in one launch: blocks [0, ceil(rows / 4))
+// normalise (goal rows to `goal` and to the goal columns of `ppx`), the remaining blocks copy the embedding columns.
+template <typename T>
+__global__ void __launch_bounds__(256) goal_ln_concat_kernel(const float* __restrict__ x, int rows, int n, const float* __restrict__ g, const float* __restrict__ b,
+                                                             T* __restrict__ goal, float* __restrict__ stats, const T* __restrict__ emb, long long ld_emb_b, int E,
+                                                             T* __restrict__ ppx) {
+    const int nln = (rows + 3) >> 2;
+    if ((int)blockIdx.x >= nln) {
+        const int idx = ((int)blockIdx.x - nln) * 256 + threadIdx.x;
+        if (idx < rows * E) { const int r = idx / E, c = idx - r * E; ppx[(long long)r * (E + n) + c] = emb[(long long)r * ld_emb_b + c]; }
+        return;
+    }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float v = lane < n ? x[(long long)row * n + lane] : 0.f;
+    const float mean = wave_sum(v) / n;
+    const float d = lane < n ? v - mean : 0.f;
+    const float rstd = rsqrtf(wave_sum(d * d) / n + 1e-5f);
+    if (lane < n) {
+        const T y = from_f<T>(d * rstd * g[lane] + b[lane]);
+        goal[(long long)row * n + lane] = y;
+        ppx[(long long)row * (E + n) + E + lane] = y;
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 // pack [emb[:,0,:] | goal] rows for the plan proposal input
 template <typename T>
@@ -1748,8 +1813,13 @@ DEVI float block_sum256(const float* __restrict__ x, int n, float* red) {
 // the end of a one-modality forward in ONE launch (was: two sum_reduce launches, pack_losses, a 16-byte device copy): l[0] = s0 * sum(x0)
 // (action loss), l[1] = s1 * sum(x1) (KL; x1 == null keeps l[1]), l[4..7] = [action + kl, kl, action, clip], optionally copied to a DEVICE out[4].
 // Same summation order as sum_reduce_kernel.
+// Blocks 1 .. gridDim.x-1 (optional) clear the backward's zero arena [zp, zp + nz4) — the memset the backward would otherwise start with.
 __global__ void __launch_bounds__(256) finish_losses_kernel(const float* __restrict__ x0, int n0, float s0, const float* __restrict__ x1, int n1, float s1,
-                                                            float* __restrict__ l, float* __restrict__ out) {
+                                                            float* __restrict__ l, float* __restrict__ out, float4* __restrict__ zp = nullptr, long long nz4 = 0) {
+    if (blockIdx.x > 0) {
+        for (long long i = (long long)(blockIdx.x - 1) * 256 + threadIdx.x; i < nz4; i += (long long)(gridDim.x - 1) * 256) zp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     __shared__ float red[256];
     const float a = block_sum256(x0, n0, red) * s0;
     float k = 0.f;
