@@ -21,7 +21,9 @@ struct EncTailCam {
     h16_t* f1; float* f2; float* lnst;      // saved: [Nf][512], [Nf][64], [Nf][2]
     int col0;                        // column of this camera's 64 features in the embedding
 };
-struct EncTailP { EncTailCam cam[2]; h16_t* emb; int Nf, ldemb; };
+// pos != null: the plan-recognition transformer's input is produced here too (posadd_kernel's job, plan_recognition_net.py:96-103):
+// x0 = dropout(emb + pos[t]) as fp32 `xf` and 16-bit `xt`, and the two FFN accumulators z0 / z1 of the fused layers start at zero
+struct EncTailP { EncTailCam cam[2]; h16_t* emb; int Nf, ldemb; const float* pos; float *xf, *z0, *z1; h16_t* xt; int S; float drop_p; unsigned long long seed; };
 
 constexpr int ET_XP = 128 * 2 + 16, ET_HP = 512 * 2 + 32;
 constexpr size_t ET_LDS = 16 * ET_XP + 16 * ET_HP + 2 * 16 * 65 * 4;
@@ -108,8 +110,17 @@ __global__ void __launch_bounds__(512) enc_tail_fwd_kernel(EncTailP p) {
         const float d = y - mean;
         const float var = wave_sum(d * d) / 64;
         const float rstd = rsqrtf(var + 1e-5f);
-        p.emb[row * p.ldemb + c.col0 + lane] = f2h(d * rstd * lg + lb);
+        const h16_t e16 = f2h(d * rstd * lg + lb);
+        p.emb[row * p.ldemb + c.col0 + lane] = e16;
         if (lane == 0) { c.lnst[2 * row] = mean; c.lnst[2 * row + 1] = rstd; }
+        if (p.pos) {
+            const long long idx = row * p.ldemb + c.col0 + lane;
+            const int t = (int)(row % p.S);
+            float v = to_f<h16_t>(e16) + p.pos[t * p.ldemb + c.col0 + lane];
+            if (p.drop_p > 0.f) v = hash_uniform(p.seed, idx) < p.drop_p ? 0.f : v / (1.f - p.drop_p);
+            p.xf[idx] = v; p.xt[idx] = from_f<h16_t>(v);
+            p.z0[idx] = 0.f; p.z1[idx] = 0.f;
+        }
     }
 }
 static inline void launch_enc_tail_fwd(hipStream_t st, const EncTailP& p) {

@@ -726,9 +726,12 @@ struct Engine : IEngine {
         return ok(encS) && ok(encG) && EMB == 128;
     }
     // fc1 + ReLU, fc2 and the LayerNorm of both encoders in one launch (enc_tail.h)
-    void enc_tail_fwd_both(int Nf) {
+    // with_x0: the same launch also writes the plan-recognition transformer's input (enc_tail.h) — pr_fwd then skips its posadd launch
+    bool x0_done = false;
+    void enc_tail_fwd_both(int Nf, bool with_x0 = false, int S = 1, float dp = 0.f) {
         if constexpr (std::is_same<T, h16_t>::value) {
             EncTailP q{};
+            if (with_x0) { q.pos = pos32; q.xf = xf[0]; q.xt = xt[0]; q.z0 = y2[0]; q.z1 = y2[1]; q.S = S; q.drop_p = dp; q.seed = site_seed(0); x0_done = true; }
             const EncW* ew[2] = {&encS, &encG};
             EncA* ea[2] = {&aS, &aG};
             for (int k = 0; k < 2; ++k) {
@@ -1030,7 +1033,6 @@ struct Engine : IEngine {
         const int B = b->B, S = b->S, N = B * S;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
         bool ppx_packed = false;
-        (void)dp;
         // ---- perceptual encoders (concat_encoders.py:59-109): static -> emb[..., 0:64], gripper -> emb[..., 64:128]
         {
             const Conv1Src s2s = conv1_src(cur2, false), s2g = conv1_src(cur2, true);
@@ -1038,7 +1040,8 @@ struct Engine : IEngine {
             enc_fwd(encS, aS, conv1_src(*b, false), N, 0, pair ? &s2s : nullptr, tail_fused);
             STAGE("enc_static_fwd");
             enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr, tail_fused);
-            if (tail_fused) enc_tail_fwd_both(N);
+            x0_done = false;
+            if (tail_fused) enc_tail_fwd_both(N, !mcil && tr_fused_mode && S <= 32 && EMB == 128, S, dp);
             STAGE("enc_gripper_fwd");
         }
         // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
@@ -1084,8 +1087,10 @@ struct Engine : IEngine {
         if constexpr (std::is_same<T, h16_t>::value) {
             fused = tr_fused_mode && S <= 32;
         }
+        if (!(fused && x0_done))
         hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0),
                            fused ? y2[0] : (float*)nullptr, fused ? y2[1] : (float*)nullptr);
+        x0_done = false;
         if constexpr (std::is_same<T, h16_t>::value) {
             if (fused) {        // one launch per encoder layer (tr_fused.h); norm2 of layer 0 is the first step of layer 1's launch, the last norm2 a LayerNorm launch
                 for (int l = 0; l < 2; ++l) {
@@ -1101,7 +1106,7 @@ struct Engine : IEngine {
                     launch_tr_layer_fwd(st, q);
                 }
                 // the last norm2 and the mean over the window in one launch (the normalised rows are kept for tests only)
-                hipLaunchKernelGGL((layernorm_mean_kernel<T>), dim3(B), dim3(256), 0, st, y2[1], S, EMB, tr_n2g[1], tr_n2b[1], st2[1], xm, xf[2]);
+                hipLaunchKernelGGL((layernorm_mean_kernel<T>), dim3(B), dim3(1024), 0, st, y2[1], S, EMB, tr_n2g[1], tr_n2b[1], st2[1], xm, xf[2]);
             }
         }
         for (int l = 0; l < 2 && !fused; ++l) {

@@ -1214,14 +1214,14 @@ __global__ void mean_over_s_kernel(const float* __restrict__ x, int B, int S, in
     out[idx] = from_f<T>(s / S);
 }
 // LayerNorm of the S rows of window b followed by their mean over S (the plan-recognition transformer's last norm2 + the mean that feeds fc,
-// plan_recognition_net.py:110-114): one block per window, a wave per row (4 rows at a time); stats [rows][2] kept for the backward, n <= 128.
+// plan_recognition_net.py:110-114): one block per window, a wave per row (16 rows at a time); stats [rows][2] kept for the backward, n <= 128.
 template <typename T>
-__global__ void __launch_bounds__(256) layernorm_mean_kernel(const float* __restrict__ x, int S, int n, const float* __restrict__ g, const float* __restrict__ bta,
+__global__ void __launch_bounds__(1024) layernorm_mean_kernel(const float* __restrict__ x, int S, int n, const float* __restrict__ g, const float* __restrict__ bta,
                                                              float* __restrict__ stats, T* __restrict__ out, float* __restrict__ yout) {
-    __shared__ float part[4][128];
+    __shared__ float part[16][128];
     const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float a0 = 0.f, a1 = 0.f;
-    for (int t = w; t < S; t += 4) {
+    for (int t = w; t < S; t += 16) {
         const long long row = (long long)b * S + t;
         const float* xr = x + row * n;
         const float v0 = lane < n ? xr[lane] : 0.f, v1 = lane + 64 < n ? xr[lane + 64] : 0.f;
@@ -1234,7 +1234,12 @@ __global__ void __launch_bounds__(256) layernorm_mean_kernel(const float* __rest
     }
     part[w][lane] = a0; part[w][lane + 64] = a1;
     __syncthreads();
-    if (threadIdx.x < n) out[(long long)b * n + threadIdx.x] = from_f<T>((((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / S);
+    if (threadIdx.x < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][threadIdx.x];
+        out[(long long)b * n + threadIdx.x] = from_f<T>(s / S);
+    }
 }
 // dx[b][t][d] = dxm[b][d] / S
 __global__ void bcast_over_s_kernel(const float* __restrict__ dxm, int B, int S, int D, float* __restrict__ dx) {
@@ -1476,7 +1481,14 @@ __global__ void plan_gather_t_kernel(const T* __restrict__ w_t /*[KIN][H]*/, con
     out[gid] = s;
     if (cb) {
         float a = 0.f;
-        for (int k = 0; k < G; ++k) a += to_f<T>(goal[b * G + k]) * to_f<T>(w_t[(long long)(grow0 + k) * H + i]);
+        if (G == 32) {           // 32 independent loads in flight, like the plan rows above
+            float w[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) w[k] = to_f<T>(w_t[(long long)(grow0 + k) * H + i]);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a += to_f<T>(goal[b * 32 + k]) * w[k];
+        } else
+            for (int k = 0; k < G; ++k) a += to_f<T>(goal[b * G + k]) * to_f<T>(w_t[(long long)(grow0 + k) * H + i]);
         cb[gid] = from_f<T>(s + a);
     }
 }

@@ -205,7 +205,10 @@ def test_library_rccl_allreduce_world1_and_bucket_plan():
             if dtype == "fp32":
                 assert torch.equal(eng.flat_grads, g_ref)                                          # fp32 engine is deterministic: bit-identical
             else:
-                assert torch.allclose(eng.flat_grads, g_ref, rtol=1e-3, atol=1e-6)                 # bf16 engine: atomics reorder sums
+                # bf16 engine: atomics reorder sums, and now and then (2 of 30 evaluations, tools/det_probe.py) one reordered sum crosses a 16-bit
+                # rounding boundary and moves everything downstream of it by ~1e-3 of the tensor's scale; a lost or doubled bucket is an O(0.3) error
+                rel = ((eng.flat_grads - g_ref).double().norm() / g_ref.double().norm()).item()
+                assert rel < 2e-2, rel
         else:
             rel = ((eng.flat_grads - g_ref).double().norm() / g_ref.double().norm()).item()
             assert 1e-5 < rel < 4e-3, rel                                                          # went through bf16 on the wire
