@@ -192,7 +192,7 @@ struct Engine : IEngine {
             named["demb"] = Named{demb, N * EMB, 0}; named["dgoal"] = Named{dgoal, B * GOAL, 0}; named["dseq_feat"] = Named{dseqf, B * FCH, 0};
         }
         dplan = alloc<float>(B * PLAN, "dplan"); dprl = alloc<float>(B * PLAN, "dpr_logits"); dppx = alloc<float>(B * (EMB + GOAL));
-        dxa = alloc<float>(N * EMB); dxb = alloc<float>(N * EMB); dy_f = alloc<float>(N * EMB); dxm = alloc<float>(B * EMB);
+        dxa = alloc<float>(N * EMB, "tr_dx"); dxb = alloc<float>(N * EMB); dy_f = alloc<float>(N * EMB, "tr_dy1"); dxm = alloc<float>(B * EMB);
         dprl_t = alloc<T>(B * PLAN); dppl_t = alloc<T>(B * PLAN); dseq_t = alloc<T>(B * FCH);
         dt_a = alloc<T>(std::max<int64_t>(N * FF, 2 * B * HID)); dt_b = alloc<T>(N * 3 * EMB); dt_c = alloc<T>(N * EMB); dgl3_t = alloc<T>(B * GOAL);
         tcap = std::max<int64_t>(3136 * ((N + 7) / 8 * 8), std::max<int64_t>((gru ? 3 : 1) * HID * ((SB + 7) / 8 * 8), FCH * ((B + 7) / 8 * 8))) + 4096;
@@ -2307,7 +2307,7 @@ struct Engine : IEngine {
                     static const int defer_sw = HULC_SWITCH("HULC_TR_WGRAD_BATCH", 1);
                     defer_w = ffn_fused && defer_sw;
                     if (defer_w) {
-                        if (!trb_c[l]) { trb_c[l] = alloc<T>((int64_t)maxN * EMB); trb_a[l] = alloc<T>((int64_t)maxN * FF); trb_d[l] = alloc<T>((int64_t)maxN * EMB); trb_b[l] = alloc<T>((int64_t)maxN * 3 * EMB); }
+                        if (!trb_c[l]) { trb_c[l] = alloc<T>((int64_t)maxN * EMB); trb_a[l] = alloc<T>((int64_t)maxN * FF); trb_d[l] = alloc<T>((int64_t)maxN * EMB, l ? "tr_bd1" : "tr_bd0"); trb_b[l] = alloc<T>((int64_t)maxN * 3 * EMB, l ? "tr_bb1" : "tr_bb0"); }
                         b_c = trb_c[l]; b_a = trb_a[l]; b_d = trb_d[l]; b_b = trb_b[l];
                     }
                 }
@@ -2337,6 +2337,24 @@ struct Engine : IEngine {
                 { EpiP ep = epi(dt_a, false); ep.mask = hff[l]; ep.alpha = dp > 0.f ? 1.f / (1.f - dp) : 1.f; lin_dgrad(dt_c, N, tr_l2[l], ep, dense_out(FF)); }
                 lin_wgrad(dt_a, x1t[l], EMB, N, FF, EMB, tr_l1[l].dW, EMB, tr_l1[l].db);
                 { EpiP ep = epi(dnext, true); ep.res = dy_f; ep.res_f32 = 1; ep.res_ld = EMB; lin_dgrad(dt_a, N, tr_l1[l], ep, dense_out(EMB)); }
+                }
+                // 16-bit fused path: LN1 backward, out_proj data gradient, attention backward and in_proj data gradient of a window in one launch (tr_fused.h)
+                bool attn_fused = false;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    static const int sw = HULC_SWITCH("HULC_TR_ATTN_BWD", 1);
+                    attn_fused = ffn_fused && defer_w && sw && EMB == 128 && NH == 8;
+                    if (attn_fused) {
+                        TrAttnBwdP q{};
+                        q.parts = dparts; q.part_stride = (long long)N * EMB; q.nparts = 4; q.y1 = y1[l]; q.st1 = st1[l]; q.n1g = tr_n1g[l]; q.dg1 = d_tr_n1g[l]; q.db1 = d_tr_n1b[l];
+                        q.Wot = tr_out[l].Wt; q.Wint = tr_in[l].Wt; q.qkv = qkv[l]; q.Pat = Pat[l]; q.b_d = b_d; q.b_b = b_b; q.dy_f = dy_f; q.dx = dx;
+                        q.B = B; q.S = S; q.dp = dp; q.seed_o = site_seed(2 + 4 * l); q.seed_att = site_seed(1 + 4 * l);
+                        static const int tra_dbg = HULC_SWITCH("HULC_TRA_DBG", 0);
+                        q.dbg = tra_dbg;
+                        launch_tr_attn_bwd(st, q);
+                        tr_wgrad_add(b_d, ao[l], tr_out[l]);
+                        tr_wgrad_add(b_b, xt[l], tr_in[l]);
+                        continue;
+                    }
                 }
                 // LN1 (after the fused FFN backward its incoming gradient is the sum of the four hidden-quarter partials)
                 ln_bwd(ffn_fused ? dparts : dnext, EMB, y1[l], EMB, st1[l], tr_n1g[l], N, EMB, dy_f, EMB, 0, b_d, EMB, d_tr_n1g[l], d_tr_n1b[l], dp, site_seed(2 + 4 * l), 0, 1.f,

@@ -534,6 +534,240 @@ __global__ void __launch_bounds__(512) tr_ffn_bwd_kernel(TrFfnBwdP p) {
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The attention half of a layer's BACKWARD as one launch (was LayerNorm backward 9 us + out_proj data gradient 6.6 + attention backward 15 +
+// in_proj data gradient 8 per layer, each a latency chain over 2048 x 128 values): one workgroup per WINDOW, wave = head.
+//   P0  dy1 = LN1_bwd(sum of the incoming partials; y1, stats1, g1)  -> dy_f (fp32, global: re-read as the residual in P3), norm1 parameter
+//       gradients (atomics);  b_d = T(dropout_o(dy1))  -> LDS + global (operand of out_proj's weight gradient)
+//   P1  dao = b_d W_o: wave w computes the 16 features of head w -> that head's dO rows in LDS (16 bit, as the unfused path rounds them)
+//   P2  attention backward of head w (attention_bwd32_kernel's arithmetic: two lanes per query row)  -> b_b = d qkv (16 bit) in LDS + global
+//       (operand of in_proj's weight gradient)
+//   P3  dx = b_b W_in + dy1  -> fp32, global: the layer's input gradient
+// Measured (rocprofv3, B = 64 x S = 32): 33 us per layer against 9.1 + 6.6 + 15.2 + 8.2 = 39 us and three launch gaps; phases switched off (experiment
+// build, HULC_TRA_DBG): without P0 28 us, without P3 31.8, everything off (weight / qkv loads, barriers) 8.6 — the attention chain of P2 is the
+// long pole.  Tried: 16 waves (two rows per wave in P0, one MFMA tile per wave, four lanes per query row): 35 - 38 us, slower; loads of P0 hoisted
+// over its four rows and the saved probabilities requested before P1: no change.
+// S <= 32, 8 heads of 16.  LDS: b_d 9 KB + d qkv 25 KB + 8 x (q, k, v, dO 16 bit 4.5 KB + dS, dropped P fp32 8.3 KB) + 8 KB of reduction space.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct TrAttnBwdP {
+    const float* parts; long long part_stride; int nparts;    // incoming gradient of norm1's output: the sum of nparts arrays [N][128]
+    const float *y1, *st1, *n1g;                 // LN1 input, (mean, rstd) per row, gamma
+    float *dg1, *db1;                            // norm1 parameter gradients (atomics)
+    const h16_t *Wot, *Wint;                     // [128][128] = out_proj.weight^T, [128][384] = in_proj_weight^T
+    const h16_t* qkv; const float* Pat;          // saved [N][384] and attention probabilities [B * 8][S][S]
+    h16_t *b_d, *b_b;                            // [N][128], [N][384] 16-bit gradient operands (written)
+    float *dy_f, *dx;                            // [N][128] fp32
+    int B, S;
+    float dp; unsigned long long seed_o, seed_att;
+    int dbg;                                     // experiment builds: phases switched off (1: P0, 2: P2, 4: P1, 8: P3)
+};
+constexpr int TRA_HP = 48;                                          // bytes per row of a head's [32][16] 16-bit operand: two 16-byte reads per row
+constexpr int TRA_HEADB = 4 * 32 * TRA_HP + 2 * 32 * 33 * 4;        // q, k, v, dO + dS, dropped P
+constexpr size_t TRA_LDS = 32 * TRF_XP + 32 * TRF_QP + 8 * 256 * 4 + 8 * TRA_HEADB;
+
+__global__ void __launch_bounds__(512) tr_attn_bwd_kernel(TrAttnBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) h16_t lds_h16;
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    lds_char* const bdb = (lds_char*)smem;                     // [32][XP] 16 bit: b_d
+    lds_char* const dqb = bdb + 32 * TRF_XP;                   // [32][QP] 16 bit: d qkv
+    lds_char* const red = dqb + 32 * TRF_QP;                   // [8 waves][256] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    lds_char* const hb = red + 8 * 256 * 4 + wave * TRA_HEADB; // this wave's head
+    lds_char* const qh = hb, * const kh = hb + 32 * TRA_HP, * const vh = hb + 2 * 32 * TRA_HP, * const doh = hb + 3 * 32 * TRA_HP;
+    lds_char* const dSb = hb + 4 * 32 * TRA_HP;                // [32][33] fp32
+    lds_char* const Pdb = dSb + 32 * 33 * 4;
+    const int w = blockIdx.x, S = p.S;
+    const long long row0 = (long long)w * S;
+    const bool mt1 = true;        // both 16-row tiles always (rows past S are zero).  With the second tile's MFMAs under `S > 16`, as in the kernels above,
+    // S <= 16 produced wrong d k / d v (transposed dS / P reads) while S >= 17 was exact — not understood; tools/tr_bwd_probe.py + tr_bwd_cmp.py (experiment build, HULC_TR_ATTN_BWD=0 / 1) reproduce it
+
+    // out_proj^T fragments (rows = the 16 features of head `wave`, 4 k-steps over the 128 columns of b_d): requested first
+    h16x8_t wo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(p.Wot + (long long)(wave * 16 + li) * TRF_D + ks * 32 + g * 8);
+
+    // ---- P0: LayerNorm backward (wave = 4 rows, lane = columns lane and lane + 64), layernorm_bwd_fused_kernel's arithmetic
+    {
+        const float g0 = p.n1g[lane], g1 = p.n1g[lane + 64];
+        float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            float t0 = 0.f, t1 = 0.f;
+            if (r < S && !(p.dbg & 1)) {
+                const long long row = row0 + r;
+                const float mean = p.st1[2 * row], rstd = p.st1[2 * row + 1];
+                const float* xr = p.y1 + row * TRF_D;
+                const float* dr = p.parts + row * TRF_D;
+                const float xh0 = (xr[lane] - mean) * rstd, xh1 = (xr[lane + 64] - mean) * rstd;
+                float d0 = dr[lane], d1 = dr[lane + 64];
+                for (int pp = 1; pp < p.nparts; ++pp) { d0 += dr[pp * p.part_stride + lane]; d1 += dr[pp * p.part_stride + lane + 64]; }
+                sg0 += d0 * xh0; sb0 += d0; sg1 += d1 * xh1; sb1 += d1;
+                const float q0 = d0 * g0, q1 = d1 * g1;
+                const float m1 = wave_sum(q0 + q1) / TRF_D;
+                const float m2 = wave_sum(q0 * xh0 + q1 * xh1) / TRF_D;
+                const float o0 = rstd * (q0 - m1 - xh0 * m2), o1 = rstd * (q1 - m1 - xh1 * m2);
+                p.dy_f[row * TRF_D + lane] = o0; p.dy_f[row * TRF_D + lane + 64] = o1;
+                t0 = o0; t1 = o1;
+                if (p.dp > 0.f) {
+                    t0 = hash_uniform(p.seed_o, (unsigned long long)(row * TRF_D + lane)) < p.dp ? 0.f : t0 / (1.f - p.dp);
+                    t1 = hash_uniform(p.seed_o, (unsigned long long)(row * TRF_D + lane + 64)) < p.dp ? 0.f : t1 / (1.f - p.dp);
+                }
+                p.b_d[row * TRF_D + lane] = f2h(t0); p.b_d[row * TRF_D + lane + 64] = f2h(t1);
+            }
+            *(lds_h16*)(bdb + r * TRF_XP + lane * 2) = f2h(t0); *(lds_h16*)(bdb + r * TRF_XP + (lane + 64) * 2) = f2h(t1);
+        }
+        *(lds_f32*)(red + (wave * 256 + lane) * 4) = sg0; *(lds_f32*)(red + (wave * 256 + 64 + lane) * 4) = sg1;
+        *(lds_f32*)(red + (wave * 256 + 128 + lane) * 4) = sb0; *(lds_f32*)(red + (wave * 256 + 192 + lane) * 4) = sb1;
+    }
+    // this head's q (pre-scaled by 1/4: exact), k, v rows and the in_proj^T fragments of P3: independent of everything above
+    const int ai = lane & 31, hf = lane >> 5;
+    if (ai < S) {
+        const h16_t* r = p.qkv + (row0 + ai) * 3 * TRF_D + wave * TRF_HD;
+        h16_t a0[16], a1[16];
+        if (hf == 0) {
+            load8<h16_t>(r, *reinterpret_cast<h16_t(*)[8]>(a0)); load8<h16_t>(r + 8, *reinterpret_cast<h16_t(*)[8]>(a0 + 8));
+            load8<h16_t>(r + TRF_D, *reinterpret_cast<h16_t(*)[8]>(a1)); load8<h16_t>(r + TRF_D + 8, *reinterpret_cast<h16_t(*)[8]>(a1 + 8));
+#pragma unroll
+            for (int d = 0; d < 16; ++d) { *(lds_h16*)(qh + ai * TRA_HP + d * 2) = f2h(h2f(a0[d]) * 0.25f); *(lds_h16*)(kh + ai * TRA_HP + d * 2) = a1[d]; }
+        } else {
+            load8<h16_t>(r + 2 * TRF_D, *reinterpret_cast<h16_t(*)[8]>(a0)); load8<h16_t>(r + 2 * TRF_D + 8, *reinterpret_cast<h16_t(*)[8]>(a0 + 8));
+#pragma unroll
+            for (int d = 0; d < 16; ++d) *(lds_h16*)(vh + ai * TRA_HP + d * 2) = a0[d];
+        }
+    }
+    h16x8_t wi[12];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) wi[ks] = *reinterpret_cast<const h16x8_t*>(p.Wint + (long long)(wave * 16 + li) * (3 * TRF_D) + ks * 32 + g * 8);
+    __syncthreads();
+    if (tid < 256) {          // norm1 parameter gradients: 8 wave partials per column -> one atomic each
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) sum += *(lds_f32*)(red + (ww * 256 + tid) * 4);
+        unsafeAtomicAdd((tid < 128 ? p.dg1 : p.db1) + (tid & 127), sum);
+    }
+
+    // ---- P1: dao[:, head] = b_d W_o[:, head]  -> dO of this head (16 bit)
+    if (!(p.dbg & 4)) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(bdb + li * TRF_XP + ks * 64 + g * 16);
+            acc[0] = MFMA_16x16x32_H(wo[ks], b0, acc[0], 0, 0, 0);
+            if (mt1) {
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(bdb + (16 + li) * TRF_XP + ks * 64 + g * 16);
+                acc[1] = MFMA_16x16x32_H(wo[ks], b1, acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *(lds_h16*)(doh + m * TRA_HP + (g * 4 + r) * 2) = f2h(acc[mt][r]);
+        }
+    }
+    __syncthreads();
+
+    // ---- P2: attention backward of head `wave` (lane = query row ai, half hf of the keys)
+    auto row16 = [](lds_char* base, int i, float (&x)[16]) {      // a head's 16 values of row i: two 16-byte LDS reads, unpacked
+        const u32x4_t a = *(lds_u32x4*)(base + i * TRA_HP), b = *(lds_u32x4*)(base + i * TRA_HP + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[2 * e] = h2f_lo(a[e]); x[2 * e + 1] = h2f_hi(a[e]); x[8 + 2 * e] = h2f_lo(b[e]); x[8 + 2 * e + 1] = h2f_hi(b[e]); }
+    };
+    constexpr int HJ = 16;
+    if (ai < S && !(p.dbg & 2)) {
+        const float* Pr = p.Pat + (((long long)w * TRF_NH + wave) * S + ai) * S;
+        float dot = 0.f;
+        float dpv[HJ], pv[HJ];
+        float dOi[16];
+        row16(doh, ai, dOi);
+#pragma unroll
+        for (int jj = 0; jj < HJ; ++jj) {
+            const int j = hf * HJ + jj;
+            dpv[jj] = 0.f; pv[jj] = 0.f;
+            if (j < S) {
+                float dpj = 0.f, vj[16];
+                row16(vh, j, vj);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) dpj += dOi[d] * vj[d];
+                const float pr = Pr[j];
+                float keep = 1.f;
+                if (p.dp > 0.f) keep = hash_uniform(p.seed_att, (((long long)w * TRF_NH + wave) * S + ai) * S + j) < p.dp ? 0.f : 1.f / (1.f - p.dp);
+                *(lds_f32*)(Pdb + (ai * 33 + j) * 4) = pr * keep;
+                dpj *= keep;
+                dpv[jj] = dpj; pv[jj] = pr;
+                dot += dpj * pr;
+            }
+        }
+        dot += __shfl_xor(dot, 32);
+#pragma unroll
+        for (int jj = 0; jj < HJ; ++jj) if (hf * HJ + jj < S) *(lds_f32*)(dSb + (ai * 33 + hf * HJ + jj) * 4) = pv[jj] * (dpv[jj] - dot);
+    }
+    __syncthreads();
+    if (ai < S && !(p.dbg & 2)) {
+        float dq[16], dk[16], dv[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { dq[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+        for (int jj = 0; jj < HJ; ++jj) {
+            const int j = hf * HJ + jj;
+            if (j >= S) break;
+            const float s_ij = *(lds_f32*)(dSb + (ai * 33 + j) * 4), s_ji = *(lds_f32*)(dSb + (j * 33 + ai) * 4), p_ji = *(lds_f32*)(Pdb + (j * 33 + ai) * 4);
+            float kj[16], qj[16], oj[16];
+            row16(kh, j, kj); row16(qh, j, qj); row16(doh, j, oj);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                dq[d] += s_ij * kj[d];
+                dk[d] += s_ji * qj[d];          // q already carries the 1/sqrt(hd) scale
+                dv[d] += p_ji * oj[d];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { dq[d] += __shfl_xor(dq[d], 32); dk[d] += __shfl_xor(dk[d], 32); dv[d] += __shfl_xor(dv[d], 32); }
+        Vec8<h16_t> oq, ok, ov;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            oq.v[d] = f2h((hf ? dq[8 + d] : dq[d]) * 0.25f); ok.v[d] = f2h(hf ? dk[8 + d] : dk[d]); ov.v[d] = f2h(hf ? dv[8 + d] : dv[d]);
+        }
+        h16_t* o = p.b_b + (row0 + ai) * 3 * TRF_D + wave * TRF_HD + hf * 8;
+        *reinterpret_cast<Vec8<h16_t>*>(o) = oq; *reinterpret_cast<Vec8<h16_t>*>(o + TRF_D) = ok; *reinterpret_cast<Vec8<h16_t>*>(o + 2 * TRF_D) = ov;
+        lds_char* lo = dqb + ai * TRF_QP + (wave * TRF_HD + hf * 8) * 2;
+        *(lds_u32x4*)(lo) = __builtin_bit_cast(u32x4_t, oq);
+        *(lds_u32x4*)(lo + TRF_D * 2) = __builtin_bit_cast(u32x4_t, ok);
+        *(lds_u32x4*)(lo + 2 * TRF_D * 2) = __builtin_bit_cast(u32x4_t, ov);
+    }
+    __syncthreads();
+
+    // ---- P3: dx = d qkv W_in + dy1 (features wave * 16 .. + 15)
+    if (!(p.dbg & 8)) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(dqb + li * TRF_QP + ks * 64 + g * 16);
+            acc[0] = MFMA_16x16x32_H(wi[ks], b0, acc[0], 0, 0, 0);
+            if (mt1) {
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(dqb + (16 + li) * TRF_QP + ks * 64 + g * 16);
+                acc[1] = MFMA_16x16x32_H(wi[ks], b1, acc[1], 0, 0, 0);
+            }
+        }
+        const int n = wave * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = mt * 16 + li;
+            if (m >= S) continue;
+            const f32x4 res = *reinterpret_cast<const f32x4*>(p.dy_f + (row0 + m) * TRF_D + n);      // written in P0 by this workgroup (two barriers ago)
+            *reinterpret_cast<f32x4*>(p.dx + (row0 + m) * TRF_D + n) = acc[mt] + res;
+        }
+    }
+}
+static inline void launch_tr_attn_bwd(hipStream_t st, const TrAttnBwdP& p) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)tr_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRA_LDS); attr_set = true; }
+    hipLaunchKernelGGL(tr_attn_bwd_kernel, dim3(p.B), dim3(512), TRA_LDS, st, p);
+}
+
 static inline void launch_tr_ffn_bwd(hipStream_t st, const TrFfnBwdP& p) {
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)tr_ffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRB_LDS); attr_set = true; }
