@@ -1,4 +1,5 @@
-"""Debug helper (experiment build): dumps the plan-recognition transformer backward intermediates (tr_dx, tr_dy1, tr_bd*, tr_bb*) of one synthetic\nstep to an .npz; run once with HULC_TR_ATTN_BWD=0 and once with 1, then tools/tr_bwd_cmp.py a.npz b.npz.   python tools/tr_bwd_probe.py out.npz B S"""
+"""Debug helper (experiment build): dumps the plan-recognition transformer backward intermediates (tr_dx, tr_dy1, tr_bd*, tr_bb*) of one synthetic
+step to an .npz; run once with HULC_TR_ATTN_BWD=0 and once with 1, then tools/tr_bwd_cmp.py a.npz b.npz.   python tools/tr_bwd_probe.py out.npz B S"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
