@@ -40,6 +40,10 @@ namespace HULC_NS {
 
 constexpr int RP_HID = 2048, RP_NG = 8, RP_SLOTS = 32, RP_COLS = 64, RP_NW = 8, RP_KW = 256, RP_KS = RP_KW / 32;
 constexpr int RP_TPITCH = RP_COLS * 4 + 16;          // LDS pitch of one window's 64 fp32 partial sums: 17 slots -> conflict-free 16-byte writes
+constexpr int RP_XPITCH = RP_KW * 2 + 16;         // LDS pitch of one window's 512-byte k-range in a wave's staging image (RP_COAL)
+#ifndef RP_COAL
+#define RP_COAL 1
+#endif
 constexpr int RP_MAIL_WORDS = RP_NG * RP_SLOTS * RP_SLOTS * 4;        // mailbox[group][consumer][producer][reducer wave]: 512 bytes per consumer workgroup
 constexpr int RP_FLAG_WORDS = RP_MAIL_WORDS + 2 * RP_NG * 32;     // mailbox[group][consumer][producer]: one 128-byte line per consumer workgroup
 
@@ -173,6 +177,31 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
         RP_STAMP(1);
         // ---- B fragments: window li, k = 256 wave + 32 ks + 8 gq (sc1: past the L1, which other CUs' stores never refresh; served by the XCD's L2)
         h16x8_t bf[RP_KS];
+#if RP_COAL
+        {
+            // The MFMA layout puts 16 different windows (4 KB apart) on 16 adjacent lanes: read that way, every lane's 16 bytes are their own
+            // line lookup in the CU's L1 / texture path (2048 per CU and step) and their own request at the L2.  Instead the wave reads its
+            // 512-byte k-range of a window with 32 adjacent lanes (four whole 128-byte lines, two windows per instruction) and turns the tile
+            // into fragments through a wave-private LDS image (pitch 528 bytes: the 16 windows of a ds_read_b128 fall into distinct banks).
+            lds_c* const xs = (lds_c*)smem + 2 * BUF + wave * (TOK * RP_XPITCH);
+            const int hw = lane >> 5, ch = lane & 31;
+            const unsigned off = (unsigned)((qp + (long long)(t0 + hw) * RP_HID + RP_KW * wave + 8 * ch) * 2);
+            rp_u32x4 stg[TOK / 2];
+#pragma unroll
+            for (int i = 0; i < TOK / 2; ++i) {
+                stg[i] = rp_u32x4{0u, 0u, 0u, 0u};
+                if (2 * i + hw < nwin) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + (unsigned)(2 * i) * (RP_HID * 2), 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TOK / 2; ++i) *(__attribute__((address_space(3))) rp_u32x4*)(xs + (2 * i + hw) * RP_XPITCH + 16 * ch) = stg[i];
+            const lds_c* const xr_l = xs + (li & (TOK - 1)) * RP_XPITCH + 16 * gq;
+#pragma unroll
+            for (int ks = 0; ks < RP_KS; ++ks) {
+                rp_u32x4 v = *(const __attribute__((address_space(3))) rp_u32x4*)(xr_l + 64 * ks);
+                bf[ks] = *reinterpret_cast<h16x8_t*>(&v);
+            }
+        }
+#else
         {
             const unsigned off = (unsigned)((qp + (long long)(t0 + li) * RP_HID + RP_KW * wave + 8 * gq) * 2);
 #pragma unroll
@@ -182,6 +211,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
                 bf[ks] = *reinterpret_cast<h16x8_t*>(&v);
             }
         }
+#endif
 #ifdef RP_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -244,7 +274,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
     }
 }
 
-static inline size_t rnn_persist_lds(int tok) { return (size_t)2 * RP_NW * (tok * RP_TPITCH + 32); }
+static inline size_t rnn_persist_lds(int tok) { return (size_t)2 * RP_NW * (tok * RP_TPITCH + 32) + (RP_COAL ? (size_t)RP_NW * tok * RP_XPITCH : 0); }
 
 // false: shape not covered (the caller keeps the launch-per-step path).  X must lie below 2 GB from its base (buffer offsets are 32 bit).
 template <int TOK, int MODE, bool RES>
