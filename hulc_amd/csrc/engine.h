@@ -66,6 +66,7 @@ struct Engine : IEngine {
     struct LinW {
         const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
         T* W = nullptr; T* Wt = nullptr; int N = 0, K = 0; bool own_w = false;
+        T* Wfr = nullptr; T* Wtfr = nullptr;      // fragment-ordered copies of W / Wt (gemm.h: frag_pack_kernel), GRU recurrent weights only
     };
     struct ConvW {
         const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
@@ -241,6 +242,7 @@ struct Engine : IEngine {
         if (!L.Wt) L.Wt = alloc<T>((int64_t)N * K);
         add_tr(L.W32, L.W, L.Wt, N, K);
     }
+    static bool frag_weights() { static const bool on = HULC_SWITCH("HULC_FRAG_W", 1) != 0; return on; }
     static constexpr int TRT = std::is_same<T, float>::value ? 32 : 64;     // transpose tile (bf16: 64x64, 16-byte accesses)
     void add_tr(const float* w32, const T* w, T* wt, int R, int C) {
         TrDesc d; d.src = std::is_same<T, float>::value ? (const void*)w32 : (const void*)w; d.dst = wt; d.lds = C; d.ldt = R; d.R = R; d.C = C;
@@ -306,6 +308,13 @@ struct Engine : IEngine {
                         const std::string bp = pr + "birnn_model.";
                         bind_lin(bw_ih[l][d], bp + "weight_ih" + sfx, (gru ? 3 : 1) * HID, l ? 2 * HID : EMB, false);
                         bind_lin(bw_hh[l][d], bp + "weight_hh" + sfx, (gru ? 3 : 1) * HID, HID, false);
+                        if constexpr (std::is_same<T, h16_t>::value) {
+                            if (gru && frag_weights()) {
+                                LinW& L = bw_hh[l][d];
+                                if (!L.Wfr) L.Wfr = alloc<T>((int64_t)L.N * L.K);
+                                if (!L.Wtfr) L.Wtfr = alloc<T>((int64_t)L.N * L.K);
+                            }
+                        }
                         bb_ih[l][d] = pw(bp + "bias_ih" + sfx); bb_hh[l][d] = pw(bp + "bias_hh" + sfx);
                         dbb_ih[l][d] = gw(bp + "bias_ih" + sfx); dbb_hh[l][d] = gw(bp + "bias_hh" + sfx);
                     }
@@ -574,6 +583,20 @@ struct Engine : IEngine {
         // ... then every transposed copy — the Linear weights, the permuted fc7 and the packed heads — in ONE batched launch
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (gru && bw_hh[0][0].Wfr) {       // fragment-ordered copies of the GRU's recurrent weights: W_hh [3H][H] (forward step) and its transpose [H][3H] (BPTT step)
+                FragPackBatch fb{};
+                int blk = 0;
+                for (int l = 0; l < 2; ++l)
+                    for (int d = 0; d < 2; ++d) {
+                        const LinW& L = bw_hh[l][d];
+                        fb.src[fb.n] = L.W; fb.dst[fb.n] = L.Wfr; fb.N[fb.n] = L.N; fb.K[fb.n] = L.K; fb.blk0[fb.n] = blk; blk += (L.N / 16) * (L.K / 256); ++fb.n;
+                        fb.src[fb.n] = L.Wt; fb.dst[fb.n] = L.Wtfr; fb.N[fb.n] = L.K; fb.K[fb.n] = L.N; fb.blk0[fb.n] = blk; blk += (L.K / 16) * (L.N / 256); ++fb.n;
+                    }
+                fb.blk0[fb.n] = blk;
+                hipLaunchKernelGGL(frag_pack_kernel, dim3(blk), dim3(256), 0, st, fb);
+            }
+        }
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
         return 0;
@@ -1799,8 +1822,8 @@ struct Engine : IEngine {
                 static const bool fused = HULC_SWITCH("HULC_GRU_FUSED", 1) != 0;
                 if (i && fused) {
                     TimerScope ts(this, "gru_step", "hbm", 2.0 * B * 3 * HID * HID, ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
-                    const GruStepP q{hp, whh.W, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH};
-                    if (launch_gru_step(st, &q, 1, B, HID)) continue;
+                    const GruStepP q{hp, whh.Wfr ? whh.Wfr : whh.W, g.Zx + t * 3 * BH, bhh, g.H + t * BH, g.R + t * BH, g.Z + t * BH, g.N + t * BH, g.GN + t * BH};
+                    if (launch_gru_step(st, &q, 1, B, HID, whh.Wfr != nullptr)) continue;
                 }
             }
             if (i) { EpiP ep = epi(gGf, true); ep.bias = bhh; gemm(dense<T>(hp, B, HID), dense<T>(whh.W, 3 * HID, HID), dense_out(3 * HID), ep, B, 3 * HID, HID); }
@@ -1831,7 +1854,7 @@ struct Engine : IEngine {
                     gbp.Hprev = i - 1 ? g.H + at(i - 2) * BH : nullptr;
                     gbp.dzx = g.dZx + tp * 3 * BH; gbp.dg = g.dG + tp * 3 * BH; gbp.direct = gcarB; gbp.direct_in = gcarB;     // each thread reads its 4 direct[t] values before it writes direct[t-1] over them
                     EpiP ep = epi(gcarA, false);
-                    if (launch_skinny_lds_kchunk(st, g.dG + t * 3 * BH, 3 * HID, whh.Wt, 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp)) { fused_prev = true; continue; }
+                    if (launch_skinny_lds_kchunk(st, g.dG + t * 3 * BH, 3 * HID, whh.Wtfr ? whh.Wtfr : whh.Wt, whh.Wtfr ? 0 : 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp)) { fused_prev = true; continue; }
                 }
             }
             { EpiP ep = epi(gcarA, false); ep.res = gcarB; ep.res_ld = HID;
@@ -1851,11 +1874,11 @@ struct Engine : IEngine {
                         GruStepP q[2];
                         for (int d = 0; d < 2; ++d) {
                             const long long t = at(d, i);
-                            q[d] = GruStepP{g[d]->H + at(d, i - 1) * BH, whh[d]->W, g[d]->Zx + t * 3 * BH, bhh[d], g[d]->H + t * BH, g[d]->R + t * BH, g[d]->Z + t * BH,
+                            q[d] = GruStepP{g[d]->H + at(d, i - 1) * BH, whh[d]->Wfr ? whh[d]->Wfr : whh[d]->W, g[d]->Zx + t * 3 * BH, bhh[d], g[d]->H + t * BH, g[d]->R + t * BH, g[d]->Z + t * BH,
                                             g[d]->N + t * BH, g[d]->GN + t * BH};
                         }
                         TimerScope ts(this, "gru_step", "hbm", 4.0 * B * 3 * HID * HID, 2 * ((double)3 * HID * HID + 9.0 * B * HID) * sizeof(T));
-                        if (launch_gru_step(st, q, 2, B, HID)) continue;
+                        if (launch_gru_step(st, q, 2, B, HID, whh[0]->Wfr != nullptr)) continue;
                     }
                 }
                 for (int d = 0; d < 2; ++d) {
@@ -1896,8 +1919,9 @@ struct Engine : IEngine {
                         gbp[d].dzx = g[d]->dZx + tp * 3 * BH; gbp[d].dg = g[d]->dG + tp * 3 * BH; gbp[d].direct = carry[d]; gbp[d].direct_in = carry[d];
                     }
                     EpiP ep = epi(gcarA, false);
-                    KChunk2 p2; p2.A = g[1]->dG + at(1, i) * 3 * BH; p2.W = whh[1]->Wt; p2.ep = ep; p2.gb = gbp[1];
-                    ok = launch_skinny_lds_kchunk(st, g[0]->dG + at(0, i) * 3 * BH, 3 * HID, whh[0]->Wt, 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp[0], &p2);
+                    const bool fr = whh[0]->Wtfr != nullptr;
+                    KChunk2 p2; p2.A = g[1]->dG + at(1, i) * 3 * BH; p2.W = fr ? whh[1]->Wtfr : whh[1]->Wt; p2.ep = ep; p2.gb = gbp[1];
+                    ok = launch_skinny_lds_kchunk(st, g[0]->dG + at(0, i) * 3 * BH, 3 * HID, fr ? whh[0]->Wtfr : whh[0]->Wt, fr ? 0 : 3 * HID, B, HID, 3 * HID, dense_out(HID), ep, gbp[0], &p2);
                 }
                 if (ok) return;
                 hulc_set_error("gru_recur_bwd2: dual launch rejected mid-chain");      // shapes are checked identically every step: cannot happen after the first

@@ -797,6 +797,37 @@ __device__ unsigned long long g_stamps[512 * 64];
 #else
 #define KSTAMP(n)
 #endif
+// Fragment-ordered weight copy (round 4).  A 16-bit W[N][K] read as MFMA fragments puts 16 different rows (K x 2 bytes apart) on 16 adjacent lanes:
+// every lane's 16 bytes are a line lookup of their own in the texture path (tools/loadbench.hip: 192 KB per CU in 7.4 us fragment-shaped, 4.3 us as
+// whole lines).  The recurrent GRU steps pull 192 KB of W per workgroup that way, 60 % of their bytes.  The copy stores each (16-row tile, 32-k step)
+// as ONE 1 KB block in lane order — lane (g, i) at byte 16 (16 g + i) holds W[16 nb + i][32 ks + 8 g .. + 7], blocks ordered [nb][ks] — so that a
+// fragment load is a contiguous 1 KB wave instruction.  Kernels take it with ldw == 0 (skinny_wfrag_ptr).  N % 16 == 0, K % 256 == 0.
+struct FragPackBatch { const h16_t* src[8]; h16_t* dst[8]; int N[8], K[8]; int blk0[9]; int n; };
+__global__ void __launch_bounds__(256) frag_pack_kernel(FragPackBatch b) {
+    __shared__ uint4 tile[16][33];
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+    const int K = b.K[j], kt_n = K >> 8, blk = (int)blockIdx.x - b.blk0[j], nb = blk / kt_n, kt = blk % kt_n, t = threadIdx.x;
+    const h16_t* __restrict__ src = b.src[j];
+    h16_t* __restrict__ dst = b.dst[j];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int idx = t + 256 * r, row = idx >> 5, ch = idx & 31;
+        tile[row][ch] = *reinterpret_cast<const uint4*>(src + (long long)(nb * 16 + row) * K + kt * 256 + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int idx = t + 256 * r, ksl = idx >> 6, lane = idx & 63, g = lane >> 4, i = lane & 15;
+        *reinterpret_cast<uint4*>(dst + (((long long)nb * (K >> 5) + kt * 8 + ksl) * 64 + lane) * 8) = tile[i][ksl * 4 + g];
+    }
+}
+// first fragment of lane (g, i) for output tile n0 at k offset kb; consecutive k-steps are `*wstep` elements apart
+DEVI const h16_t* skinny_wfrag_ptr(const h16_t* W, long long ldw, int n0, int Nclamp, int K, int kb, int lane, int* wstep) {
+    if (ldw == 0) { *wstep = 512; return W + ((long long)(n0 >> 4) * (K >> 5) + (kb >> 5)) * 512 + lane * 8; }
+    *wstep = 32;
+    return W + (long long)min(n0 + (lane & 15), Nclamp) * ldw + kb + (lane >> 4) * 8;
+}
 static bool skinny_use_lds = true;
 static bool gemm_use_glds = true;   // tests / tools can force the register-fragment kernel
 // skinny GEMM, A through LDS (K % 512 == 0, MT*16 rows x K bf16 <= 128 KB): the A rows — 2/3 of the bytes a workgroup pulls, and
@@ -922,9 +953,10 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
     h16x8_t b[3][KQ32];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
-        const h16_t* wp = W + (long long)(gate * H + n0 + i) * ldw + kb + g * 8;
+        int wstep;
+        const h16_t* wp = skinny_wfrag_ptr(W, ldw, gate * H + n0, 3 * H - 1, H, kb, lane, &wstep);      // ldw == 0: fragment-ordered copy (frag_pack_kernel)
 #pragma unroll
-        for (int u = 0; u < KQ32; ++u) b[gate][u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
+        for (int u = 0; u < KQ32; ++u) b[gate][u] = *reinterpret_cast<const h16x8_t*>(wp + u * wstep);
     }
     // epilogue operands of this thread's 4 hidden units (threads < MT*64), fetched under the operand stream
     const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
@@ -1000,14 +1032,14 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
 }
 // returns false when the shape is not covered (the caller then runs the GEMM + gate kernel pair)
 // nprob = 2: q[1] is a second independent recurrence (the other direction of the BiGRU) advanced by the same launch
-static inline bool launch_gru_step(hipStream_t st, const GruStepP* q, int nprob, int M, int H) {
+static inline bool launch_gru_step(hipStream_t st, const GruStepP* q, int nprob, int M, int H, bool wfrag = false) {
     for (int k = 0; k < nprob; ++k)
         if (H != 2048 || M < 1 || ((uintptr_t)q[k].A % 128) != 0 || ((uintptr_t)q[k].W % 16) != 0) return false;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)gru_step_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     dim3 grid(H / 16, (M + 31) / 32, nprob);
     // LDS: the A region (16 waves x 2 x 2 x 2 KB = 128 KB) is reused for the 16 x 2 x 3 K-partials (96 KB)
-    hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, q[0], q[nprob - 1], (long long)H, (long long)H, M, H);
+    hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, q[0], q[nprob - 1], (long long)H, wfrag ? 0ll : (long long)H, M, H);
     return true;
 }
 
@@ -1051,11 +1083,13 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
                                                  (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
         }
     };
-    const h16_t* wp = W + (long long)min(n0 + i, N - 1) * ldw + kb + g * 8;
+    int wstep;
+    const h16_t* wp = skinny_wfrag_ptr(W, ldw, n0, N - 1, K, kb, lane, &wstep);      // ldw == 0: fragment-ordered copy (frag_pack_kernel)
+    const long long wchunk = (long long)(KCH / 32) * wstep;                                // elements between two K chunks
     dma_chunk(0);
     h16x8_t b[KQ32];
 #pragma unroll
-    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + u * 32);
+    for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + u * wstep);
     const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
     const bool ethread = tid < MT * 64 && erow < M;
     const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
@@ -1092,7 +1126,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
         if (ch + 1 < nch) {                                         // next chunk in flight under this chunk's MFMAs
             dma_chunk(ch + 1);
 #pragma unroll
-            for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + (long long)(ch + 1) * KCH + u * 32);
+            for (int u = 0; u < KQ32; ++u) b[u] = *reinterpret_cast<const h16x8_t*>(wp + (ch + 1) * wchunk + u * wstep);
         }
 #pragma unroll
         for (int u = 0; u < KQ32; ++u)
