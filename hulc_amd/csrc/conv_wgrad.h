@@ -1396,11 +1396,19 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
     const bool atomic_b = gz > 1;
     const bool atomic = atomic_b && !slabs;
     const int n = n0 + wave * 16 + a;
-    const bool vec_ok = !atomic && n < N && (lddw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) && k0 + TK <= K;
+    // Whole-tile output path (wave-uniform condition): the accumulators leave in ROW shape, not in fragment shape.  A fragment-shaped store puts 16
+    // different dW rows on 16 adjacent lanes — 64 separate 16-byte accesses per wave instruction, 64 contiguous bytes per row; the launches that
+    // write the M <= 64 Linear layers' fp32 gradients ran at ~3 TB/s that way.  Each wave turns its 16 x 128 tile through a private LDS image (the
+    // operand images are dead by then) so that an instruction writes 4 rows x 256 contiguous bytes; the old values are read in the same shape.
+    const bool vec_ok = !atomic && (lddw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) && k0 + TK <= K;
+    const int orow = lane >> 4, ocol = (lane & 15) * 4;          // output shape: row 4 it + orow of the wave's 16, columns 64 h + ocol .. + 3
     float4 oldw[8];
     if (vec_ok) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oldw[j] = store ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4);
+        for (int j = 0; j < 8; ++j) {
+            const int nr = n0 + wave * 16 + (j & 3) * 4 + orow;
+            oldw[j] = (store || nr >= N) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dW + (long long)nr * lddw + k0 + (j >> 2) * 64 + ocol);
+        }
     }
     // the next 64-row chunk's tiles are requested into registers before the MFMAs of the current one (2 + 4 x 16 bytes per thread)
     u32x4_t ry[2], rx[4];
@@ -1460,11 +1468,21 @@ DEVI void lin_bwd_smallm_body(const h16_t* __restrict__ dY, long long ldy, const
         }
     }
     if (vec_ok) {
+        constexpr int OP = 64 * 4 + 16;                          // pitch of one row's 64 fp32 columns in the wave's image
+        __syncthreads();                                         // every wave is past its last read of the operand images (and of the bias sums)
+        lds_char* const tb = (lds_char*)smem + wave * (16 * OP);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float4 o = oldw[j];
-            o.x += acc[j][0]; o.y += acc[j][1]; o.z += acc[j][2]; o.w += acc[j][3];
-            *reinterpret_cast<float4*>(dW + (long long)n * lddw + k0 + j * 16 + g * 4) = o;
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *(__attribute__((address_space(3))) f32x4*)(tb + a * OP + jj * 64 + g * 16) = acc[h * 4 + jj];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const f32x4 v = *(__attribute__((address_space(3))) f32x4*)(tb + (it * 4 + orow) * OP + ocol * 4);
+                const int nr = n0 + wave * 16 + it * 4 + orow;
+                float4 o = oldw[h * 4 + it];
+                o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                if (nr < N) *reinterpret_cast<float4*>(dW + (long long)nr * lddw + k0 + h * 64 + ocol) = o;
+            }
         }
     } else if (n < N) {
 #pragma unroll

@@ -66,7 +66,7 @@ struct Engine : IEngine {
     struct LinW {
         const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
         T* W = nullptr; T* Wt = nullptr; int N = 0, K = 0; bool own_w = false;
-        T* Wfr = nullptr; T* Wtfr = nullptr;      // fragment-ordered copies of W / Wt (gemm.h: frag_pack_kernel), GRU recurrent weights only
+        T* Wfr = nullptr; T* Wtfr = nullptr;      // fragment-ordered copies of W / Wt (add_frag; gemm.h: frag_pack_kernel)
     };
     struct ConvW {
         const float* W32 = nullptr; const float* b32 = nullptr; float* dW = nullptr; float* db = nullptr;
@@ -242,6 +242,21 @@ struct Engine : IEngine {
         if (!L.Wt) L.Wt = alloc<T>((int64_t)N * K);
         add_tr(L.W32, L.W, L.Wt, N, K);
     }
+    // fragment-ordered weight copies (gemm.h: frag_pack_kernel): the recurrent weights of the GRU plan encoder and the plan-recognition transformer's
+    // weights, whose kernels read MFMA fragments straight from global memory.  Jobs are collected at bind time, one batched launch in prepare_weights
+    FragPackBatch fragbatch{};
+    int frag_blocks = 0;
+    void add_frag(LinW& L) {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (!L.Wfr) L.Wfr = alloc<T>((int64_t)L.N * L.K);
+            if (!L.Wtfr) L.Wtfr = alloc<T>((int64_t)L.N * L.K);
+            if (fragbatch.n + 2 > FRAG_PACK_MAX) return;
+            FragPackBatch& fb = fragbatch;
+            fb.src[fb.n] = L.W; fb.dst[fb.n] = L.Wfr; fb.N[fb.n] = L.N; fb.K[fb.n] = L.K; fb.blk0[fb.n] = frag_blocks; frag_blocks += frag_pack_blocks(L.N, L.K); ++fb.n;
+            fb.src[fb.n] = L.Wt; fb.dst[fb.n] = L.Wtfr; fb.N[fb.n] = L.K; fb.K[fb.n] = L.N; fb.blk0[fb.n] = frag_blocks; frag_blocks += frag_pack_blocks(L.K, L.N); ++fb.n;
+            fb.blk0[fb.n] = frag_blocks;
+        }
+    }
     static bool frag_weights() { static const bool on = HULC_SWITCH("HULC_FRAG_W", 1) != 0; return on; }
     static constexpr int TRT = std::is_same<T, float>::value ? 32 : 64;     // transpose tile (bf16: 64x64, 16-byte accesses)
     void add_tr(const float* w32, const T* w, T* wt, int R, int C) {
@@ -281,7 +296,7 @@ struct Engine : IEngine {
     int bind(float* p, float* g, float* m, float* v, int64_t n_, int n, const char* const* names, const int64_t* offs,
              const int64_t* numels) override {
         P = p; G = g; AM = m; AV = v; numel = n_;
-        tab.clear(); trdesc.clear(); tr_blocks = 0;
+        tab.clear(); trdesc.clear(); tr_blocks = 0; fragbatch = FragPackBatch{}; frag_blocks = 0;
         if (!std::is_same<T, float>::value && !wshadow) wshadow = alloc<T>(numel);
         for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
         tab_order.assign(tab.begin(), tab.end());
@@ -308,13 +323,7 @@ struct Engine : IEngine {
                         const std::string bp = pr + "birnn_model.";
                         bind_lin(bw_ih[l][d], bp + "weight_ih" + sfx, (gru ? 3 : 1) * HID, l ? 2 * HID : EMB, false);
                         bind_lin(bw_hh[l][d], bp + "weight_hh" + sfx, (gru ? 3 : 1) * HID, HID, false);
-                        if constexpr (std::is_same<T, h16_t>::value) {
-                            if (gru && frag_weights()) {
-                                LinW& L = bw_hh[l][d];
-                                if (!L.Wfr) L.Wfr = alloc<T>((int64_t)L.N * L.K);
-                                if (!L.Wtfr) L.Wtfr = alloc<T>((int64_t)L.N * L.K);
-                            }
-                        }
+                        if (gru && frag_weights()) add_frag(bw_hh[l][d]);
                         bb_ih[l][d] = pw(bp + "bias_ih" + sfx); bb_hh[l][d] = pw(bp + "bias_hh" + sfx);
                         dbb_ih[l][d] = gw(bp + "bias_ih" + sfx); dbb_hh[l][d] = gw(bp + "bias_hh" + sfx);
                     }
@@ -331,6 +340,7 @@ struct Engine : IEngine {
                 bind_lin(tr_out[l], L + "self_attn.out_proj", EMB, EMB);
                 bind_lin(tr_l1[l], L + "linear1", FF, EMB);
                 bind_lin(tr_l2[l], L + "linear2", EMB, FF);
+                for (LinW* w : {&tr_in[l], &tr_out[l], &tr_l1[l], &tr_l2[l]}) add_frag(*w);      // the fused layer kernels (tr_fused.h) read these
                 tr_n1g[l] = pw(L + "norm1.weight"); tr_n1b[l] = pw(L + "norm1.bias"); d_tr_n1g[l] = gw(L + "norm1.weight"); d_tr_n1b[l] = gw(L + "norm1.bias");
                 tr_n2g[l] = pw(L + "norm2.weight"); tr_n2b[l] = pw(L + "norm2.bias"); d_tr_n2g[l] = gw(L + "norm2.weight"); d_tr_n2b[l] = gw(L + "norm2.bias");
             }
@@ -584,18 +594,7 @@ struct Engine : IEngine {
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
         if constexpr (std::is_same<T, h16_t>::value) {
-            if (gru && bw_hh[0][0].Wfr) {       // fragment-ordered copies of the GRU's recurrent weights: W_hh [3H][H] (forward step) and its transpose [H][3H] (BPTT step)
-                FragPackBatch fb{};
-                int blk = 0;
-                for (int l = 0; l < 2; ++l)
-                    for (int d = 0; d < 2; ++d) {
-                        const LinW& L = bw_hh[l][d];
-                        fb.src[fb.n] = L.W; fb.dst[fb.n] = L.Wfr; fb.N[fb.n] = L.N; fb.K[fb.n] = L.K; fb.blk0[fb.n] = blk; blk += (L.N / 16) * (L.K / 256); ++fb.n;
-                        fb.src[fb.n] = L.Wt; fb.dst[fb.n] = L.Wtfr; fb.N[fb.n] = L.K; fb.K[fb.n] = L.N; fb.blk0[fb.n] = blk; blk += (L.K / 16) * (L.N / 256); ++fb.n;
-                    }
-                fb.blk0[fb.n] = blk;
-                hipLaunchKernelGGL(frag_pack_kernel, dim3(blk), dim3(256), 0, st, fb);
-            }
+            if (fragbatch.n) hipLaunchKernelGGL(frag_pack_kernel, dim3(frag_blocks), dim3(256), 0, st, fragbatch);
         }
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }
@@ -1119,7 +1118,7 @@ struct Engine : IEngine {
                 for (int l = 0; l < 2; ++l) {
                     TrLayerP q{};
                     q.xin = l ? y2[0] : xf[0]; q.ln_in = l; q.ln_g = tr_n2g[0]; q.ln_b = tr_n2b[0]; q.xf_out = xf[1]; q.xt_out = xt[1]; q.st_out = st2[0];
-                    q.Wqkv = tr_in[l].W; q.Wo = tr_out[l].W; q.W1 = tr_l1[l].W; q.W2 = tr_l2[l].W;
+                    q.Wqkv = tr_in[l].Wfr; q.Wo = tr_out[l].Wfr; q.W1 = tr_l1[l].Wfr; q.W2 = tr_l2[l].Wfr;
                     q.bqkv = tr_in[l].b32; q.bo = tr_out[l].b32; q.b1 = tr_l1[l].b32; q.b2 = tr_l2[l].b32; q.n1g = tr_n1g[l]; q.n1b = tr_n1b[l];
                     q.qkv = qkv[l]; q.Pat = Pat[l]; q.ao = ao[l]; q.y1 = y1[l]; q.st1 = st1[l]; q.x1t = x1t[l]; q.x1f = x1f[l]; q.hff = hff[l]; q.y2 = y2[l];
                     q.B = B; q.S = S; q.dp = dp;
@@ -2340,7 +2339,7 @@ struct Engine : IEngine {
                         if (!dparts) dparts = alloc<float>(4ll * maxN * EMB);
                         TrFfnBwdP q{};
                         q.dx = bc ? dxm : dx; q.bcast = bc ? 1 : 0; q.bdiv = (float)S; q.y2 = y2[l]; q.st2 = st2[l]; q.n2g = tr_n2g[l]; q.dg2 = d_tr_n2g[l]; q.db2 = d_tr_n2b[l];
-                        q.W2t = tr_l2[l].Wt; q.W1t = tr_l1[l].Wt; q.hff = hff[l]; q.dt_c = b_c; q.dt_a = b_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
+                        q.W2t = tr_l2[l].Wtfr; q.W1t = tr_l1[l].Wtfr; q.hff = hff[l]; q.dt_c = b_c; q.dt_a = b_a; q.part = dparts; q.B = B; q.S = S; q.N = N; q.dp = dp;
                         q.seed_y = site_seed(4 + 4 * l);
                         {
                             TimerScope ts(this, "transformer_fused", "mfma", 2.0 * N * (2.0 * EMB * FF), (double)N * (2 * EMB + FF) * sizeof(T));
@@ -2370,7 +2369,7 @@ struct Engine : IEngine {
                     if (attn_fused) {
                         TrAttnBwdP q{};
                         q.parts = dparts; q.part_stride = (long long)N * EMB; q.nparts = 4; q.y1 = y1[l]; q.st1 = st1[l]; q.n1g = tr_n1g[l]; q.dg1 = d_tr_n1g[l]; q.db1 = d_tr_n1b[l];
-                        q.Wot = tr_out[l].Wt; q.Wint = tr_in[l].Wt; q.qkv = qkv[l]; q.Pat = Pat[l]; q.b_d = b_d; q.b_b = b_b; q.dy_f = dy_f; q.dx = dx;
+                        q.Wot = tr_out[l].Wtfr; q.Wint = tr_in[l].Wtfr; q.qkv = qkv[l]; q.Pat = Pat[l]; q.b_d = b_d; q.b_b = b_b; q.dy_f = dy_f; q.dx = dx;
                         q.B = B; q.S = S; q.dp = dp; q.seed_o = site_seed(2 + 4 * l); q.seed_att = site_seed(1 + 4 * l);
                         static const int tra_dbg = HULC_SWITCH("HULC_TRA_DBG", 0);
                         q.dbg = tra_dbg;

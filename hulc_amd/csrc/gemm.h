@@ -802,26 +802,31 @@ __device__ unsigned long long g_stamps[512 * 64];
 // whole lines).  The recurrent GRU steps pull 192 KB of W per workgroup that way, 60 % of their bytes.  The copy stores each (16-row tile, 32-k step)
 // as ONE 1 KB block in lane order — lane (g, i) at byte 16 (16 g + i) holds W[16 nb + i][32 ks + 8 g .. + 7], blocks ordered [nb][ks] — so that a
 // fragment load is a contiguous 1 KB wave instruction.  Kernels take it with ldw == 0 (skinny_wfrag_ptr).  N % 16 == 0, K % 256 == 0.
-struct FragPackBatch { const h16_t* src[8]; h16_t* dst[8]; int N[8], K[8]; int blk0[9]; int n; };
+constexpr int FRAG_PACK_MAX = 24;
+struct FragPackBatch { const h16_t* src[FRAG_PACK_MAX]; h16_t* dst[FRAG_PACK_MAX]; int N[FRAG_PACK_MAX], K[FRAG_PACK_MAX]; int blk0[FRAG_PACK_MAX + 1]; int n; };
+static inline int frag_pack_blocks(int N, int K) { return (N / 16) * (K / ((K % 256) == 0 ? 256 : 128)); }       // N % 16 == 0, K % 128 == 0
 __global__ void __launch_bounds__(256) frag_pack_kernel(FragPackBatch b) {
     __shared__ uint4 tile[16][33];
     int j = 0;
     while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
-    const int K = b.K[j], kt_n = K >> 8, blk = (int)blockIdx.x - b.blk0[j], nb = blk / kt_n, kt = blk % kt_n, t = threadIdx.x;
+    const int K = b.K[j], KT = (K % 256) == 0 ? 256 : 128, CPR = KT >> 3;          // a block repacks 16 rows x KT columns: CPR 16-byte chunks per row
+    const int kt_n = K / KT, blk = (int)blockIdx.x - b.blk0[j], nb = blk / kt_n, kt = blk % kt_n, t = threadIdx.x;
     const h16_t* __restrict__ src = b.src[j];
     h16_t* __restrict__ dst = b.dst[j];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int idx = t + 256 * r, row = idx >> 5, ch = idx & 31;
-        tile[row][ch] = *reinterpret_cast<const uint4*>(src + (long long)(nb * 16 + row) * K + kt * 256 + ch * 8);
+        const int idx = t + 256 * r, row = idx / CPR, ch = idx % CPR;
+        if (idx < 16 * CPR) tile[row][ch] = *reinterpret_cast<const uint4*>(src + (long long)(nb * 16 + row) * K + kt * KT + ch * 8);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int idx = t + 256 * r, ksl = idx >> 6, lane = idx & 63, g = lane >> 4, i = lane & 15;
-        *reinterpret_cast<uint4*>(dst + (((long long)nb * (K >> 5) + kt * 8 + ksl) * 64 + lane) * 8) = tile[i][ksl * 4 + g];
+        if (idx < 16 * CPR) *reinterpret_cast<uint4*>(dst + (((long long)nb * (K >> 5) + kt * (KT >> 5) + ksl) * 64 + lane) * 8) = tile[i][ksl * 4 + g];
     }
 }
+// fragment-ordered W[N][K]: the block of row tile row0 / 16 and k-step k0 / 32, this lane's 16 bytes; consecutive k-steps are 512 elements apart
+DEVI const h16_t* wfrag_ptr(const h16_t* Wf, int row0, int K, int k0, int lane) { return Wf + (((long long)(row0 >> 4) * (K >> 5) + (k0 >> 5)) * 64 + lane) * 8; }
 // first fragment of lane (g, i) for output tile n0 at k offset kb; consecutive k-steps are `*wstep` elements apart
 DEVI const h16_t* skinny_wfrag_ptr(const h16_t* W, long long ldw, int n0, int Nclamp, int K, int kb, int lane, int* wstep) {
     if (ldw == 0) { *wstep = 512; return W + ((long long)(n0 >> 4) * (K >> 5) + (kb >> 5)) * 512 + lane * 8; }

@@ -35,7 +35,7 @@ struct TrLayerP {
     int ln_in;
     const float *ln_g, *ln_b;         // ln_in: norm2 of the previous layer
     float* xf_out; h16_t* xt_out; float* st_out;      // ln_in: the normalised input is saved (fp32, 16 bit, mean / rstd) — quarter 0 writes
-    const h16_t *Wqkv, *Wo, *W1, *W2; // [384][128], [128][128], [2048][128], [128][2048]
+    const h16_t *Wqkv, *Wo, *W1, *W2; // [384][128], [128][128], [2048][128], [128][2048], FRAGMENT-ORDERED copies (gemm.h: frag_pack_kernel / wfrag_ptr)
     const float *bqkv, *bo, *b1, *b2, *n1g, *n1b;
     h16_t* qkv; float* Pat; h16_t* ao; float* y1; float* st1; h16_t* x1t; float* x1f; h16_t* hff; float* y2;
     int B, S;
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wq[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.Wqkv + (long long)((3 * wave + nt) * 16 + li) * TRF_D + ks * 32 + g * 8);
+        for (int ks = 0; ks < 4; ++ks) wq[nt][ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.Wqkv, (3 * wave + nt) * 16, TRF_D, 0, lane) + ks * 512);
 
     // every small parameter the later phases need (biases, LayerNorm affine): requested NOW — a dependent global load in front of each
     // phase's epilogue cost an exposed L2 round trip (~1 us) per phase (tools/tr_fused_bench.hip stamps: 3 - 8 us per phase for a few
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     // weight fragments of the later phases: they depend on nothing computed here, so they travel while QKV / attention / LN1 run
     h16x8_t wo[4], w1[4][4], w2[16];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(p.Wo + (long long)(wave * 16 + li) * TRF_D + ks * 32 + g * 8);
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.Wo, wave * 16, TRF_D, 0, lane) + ks * 512);
 
     TRF_STAMP(1);
     // ---- phase 1: qkv = x Wqkv^T + b  -> qb (LDS) [+ global]
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.W1 + (long long)(hq * TRF_HQ + wave * 64 + nt * 16 + li) * TRF_D + ks * 32 + g * 8);
+            w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W1, hq * TRF_HQ + wave * 64 + nt * 16, TRF_D, 0, lane) + ks * 512);
     __syncthreads();
 
     TRF_STAMP(2);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     // W2 fragments of phase 6: requested only now — together with the attention's working set they exceeded the 256 registers of a wave
     // (28 spilled: a spilled prefetch register turns the asynchronous load into load-wait-store at its issue point)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) w2[ks] = *reinterpret_cast<const h16x8_t*>(p.W2 + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
+    for (int ks = 0; ks < 16; ++ks) w2[ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W2, wave * 16, TRF_FF, hq * TRF_HQ, lane) + ks * 512);
     TRF_STAMP(3);
     // ---- phase 3: y1 = x + drop(ao Wo^T + bo)  (in place in xf) [+ global]
     {
@@ -382,7 +382,7 @@ struct TrFfnBwdP {
     const float* dx; int bcast; float bdiv;      // incoming gradient [N][128] fp32, or (bcast) one row per window divided by bdiv
     const float *y2, *st2, *n2g;                 // LN2 input, (mean, rstd) per row, gamma
     float *dg2, *db2;                            // norm2 parameter gradients (atomics, quarter 0)
-    const h16_t *W2t, *W1t;                      // [2048][128] = linear2.weight^T, [128][2048] = linear1.weight^T
+    const h16_t *W2t, *W1t;                      // [2048][128] = linear2.weight^T, [128][2048] = linear1.weight^T, fragment-ordered copies
     const h16_t* hff;                            // [N][2048] saved hidden (post ReLU + dropout)
     h16_t *dt_c, *dt_a;                          // [N][128], [N][2048] 16-bit gradient operands (written)
     float* part;                                 // [4][N][128]
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(512) tr_ffn_bwd_kernel(TrFfnBwdP p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            w2[nt][ks] = *reinterpret_cast<const h16x8_t*>(p.W2t + (long long)(hq * TRF_HQ + wave * 64 + nt * 16 + li) * TRF_D + ks * 32 + g * 8);
+            w2[nt][ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W2t, hq * TRF_HQ + wave * 64 + nt * 16, TRF_D, 0, lane) + ks * 512);
 
     // ---- P0: LayerNorm backward of the rows of this window (wave = 4 rows, lane = columns lane and lane + 64)
     {
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(512) tr_ffn_bwd_kernel(TrFfnBwdP p) {
         }
     h16x8_t w1[16];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) w1[ks] = *reinterpret_cast<const h16x8_t*>(p.W1t + (long long)(wave * 16 + li) * TRF_FF + hq * TRF_HQ + ks * 32 + g * 8);
+    for (int ks = 0; ks < 16; ++ks) w1[ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W1t, wave * 16, TRF_FF, hq * TRF_HQ, lane) + ks * 512);
     __syncthreads();
     if (lead && tid < 256) {          // norm2 parameter gradients: 8 wave partials per column -> one atomic each (columns 0..127 dgamma, 128..255 dbeta)
         float sum = 0.f;
@@ -553,7 +553,7 @@ struct TrAttnBwdP {
     const float* parts; long long part_stride; int nparts;    // incoming gradient of norm1's output: the sum of nparts arrays [N][128]
     const float *y1, *st1, *n1g;                 // LN1 input, (mean, rstd) per row, gamma
     float *dg1, *db1;                            // norm1 parameter gradients (atomics)
-    const h16_t *Wot, *Wint;                     // [128][128] = out_proj.weight^T, [128][384] = in_proj_weight^T
+    const h16_t *Wot, *Wint;                     // [128][128] = out_proj.weight^T, [128][384] = in_proj_weight^T, fragment-ordered copies
     const h16_t* qkv; const float* Pat;          // saved [N][384] and attention probabilities [B * 8][S][S]
     h16_t *b_d, *b_b;                            // [N][128], [N][384] 16-bit gradient operands (written)
     float *dy_f, *dx;                            // [N][128] fp32
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(512) tr_attn_bwd_kernel(TrAttnBwdP p) {
     // out_proj^T fragments (rows = the 16 features of head `wave`, 4 k-steps over the 128 columns of b_d): requested first
     h16x8_t wo[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(p.Wot + (long long)(wave * 16 + li) * TRF_D + ks * 32 + g * 8);
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.Wot, wave * 16, TRF_D, 0, lane) + ks * 512);
 
     // ---- P0: LayerNorm backward (wave = 4 rows, lane = columns lane and lane + 64), layernorm_bwd_fused_kernel's arithmetic
     {
@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(512) tr_attn_bwd_kernel(TrAttnBwdP p) {
     }
     h16x8_t wi[12];
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) wi[ks] = *reinterpret_cast<const h16x8_t*>(p.Wint + (long long)(wave * 16 + li) * (3 * TRF_D) + ks * 32 + g * 8);
+    for (int ks = 0; ks < 12; ++ks) wi[ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.Wint, wave * 16, 3 * TRF_D, 0, lane) + ks * 512);
     __syncthreads();
     if (tid < 256) {          // norm1 parameter gradients: 8 wave partials per column -> one atomic each
         float sum = 0.f;
