@@ -17,7 +17,8 @@
 //   * the 64 x 2048 slice of the weight matrix (256 KB) is loaded ONCE into the CU's vector registers as MFMA A-fragments (wave w of 8 holds
 //     k in [256 w, 256 w + 256) of all 64 features: 32 x 16 B per lane = 128 VGPRs) and stays there for the whole launch: a step reads no
 //     weight byte at all;
-//   * per step a wave loads the B-fragments of its k-range of the previous state (wpx windows x 512 B), issues 32 MFMAs (16x16x32; the token
+//   * per step a wave loads its k-range of the previous state (wpx windows x 512 B, as whole 128-byte lines, turned into B-fragments through a
+//     wave-private LDS image), issues 32 MFMAs (16x16x32; the token
 //     dimension of the tile is the group's <= 16 windows), the 8 k-partials meet in LDS (double-buffered by step parity: ONE workgroup
 //     barrier per step), four reducer waves (one per SIMD) sum them, apply the step's epilogue (residual, ReLU / tanh or their derivative
 //     masks) and store the 64-feature slice of the new state;
@@ -27,7 +28,7 @@
 //     workgroup's own mailbox with `sc1` loads (they bypass the L1, which another CU's stores never refresh, and are served by the L2 — the mailbox lines are
 //     rewritten every step and stay dirty-resident there) and then reads the state with `sc1` loads.  Measured alternatives (B = 64, S = 32,
 //     per step): write-through `sc1` stores + flags through memory, the placement-independent form, 5.6 - 9.3 us (no better than a launch
-//     per step: 4.2 us back to back); this form 2.6 - 3.2 us; the state as its own ready flag (slices pre-filled with a reserved NaN pattern,
+//     per step: 4.2 us back to back); this form 2.6 - 3.2 us (2.3 - 2.4 us since the state is read as whole lines, RP_COAL below); the state as its own ready flag (slices pre-filled with a reserved NaN pattern,
 //     consumers re-reading until it is gone: one hop less on paper) 3.6 - 4.7 us — polling lines that are NOT being rewritten costs a memory
 //     round trip per sample, and sampling the payload itself saturates the L2.  There is no grid-wide barrier and no cross-XCD traffic;
 //   * every poll loop is bounded; a timeout (workgroups not co-resident: somebody else holds CUs; XCD population not 32) raises `err`.
@@ -44,6 +45,10 @@ constexpr int RP_XPITCH = RP_KW * 2 + 16;         // LDS pitch of one window's 5
 #ifndef RP_COAL
 #define RP_COAL 1
 #endif
+#ifndef RP_TAG
+#define RP_TAG (RP_COAL)      // the state is its own ready flag from the third step on (see the kernel); needs the whole-line read
+#endif
+constexpr unsigned RP_SENT = 0xFFFFFFFFu;     // two 16-bit NaNs no arithmetic of the epilogue produces (a computed NaN is the canonical quiet one)
 constexpr int RP_MAIL_WORDS = RP_NG * RP_SLOTS * RP_SLOTS * 4;        // mailbox[group][consumer][producer][reducer wave]: 512 bytes per consumer workgroup
 constexpr int RP_FLAG_WORDS = RP_MAIL_WORDS + 2 * RP_NG * 32;     // mailbox[group][consumer][producer]: one 128-byte line per consumer workgroup
 
@@ -125,6 +130,22 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
 #pragma unroll
         for (int ks = 0; ks < RP_KS; ++ks)
             wf[ct][ks] = *reinterpret_cast<const h16x8_t*>(pW + (long long)(RP_COLS * slot + 16 * ct + li) * RP_HID + RP_KW * wave + 32 * ks + 8 * gq);
+#if RP_TAG
+    // Steps >= 3 hand the state over WITHOUT flags: every 16-byte piece of a slice is written by one store of one producer lane and read by one
+    // load of one consumer lane, so a piece is either the pattern it was pre-filled with or the new values.  The reducer waves pre-fill the slices this
+    // workgroup will write in steps 2 .. S-1 here, and their own `vmcnt(0)` in front of the step-1 flag covers these stores too: a consumer that has
+    // seen the step-1 words of its four producers (the flag protocol, kept for the first hand-off) knows their later slices hold the pattern, not
+    // the values of an earlier launch.  What it saves per step: the producers' store drain and the flag's own L2 round trip in front of the state read.
+    if (wave < 4) {
+        const rp_u32x4 sent = rp_u32x4{RP_SENT, RP_SENT, RP_SENT, RP_SENT};
+        const int per = nwin * 8;                     // 16-byte pieces of one step's slice
+        for (int idx = tid; idx < (p.S - 2) * per; idx += 4 * 64) {
+            const int s2 = 2 + idx / per, r = idx % per;
+            const long long o = (long long)(pq0 + s2 * pdq) * BH + (long long)(t0 + (r >> 3)) * RP_HID + RP_COLS * slot + 8 * (r & 7);
+            __builtin_amdgcn_raw_buffer_store_b128(sent, xr, (unsigned)(o * 2), 0, 0);
+        }
+    }
+#endif
     // mailbox[group][consumer slot][producer slot][reducer wave]: each of a producer's four reducer waves posts its own word as soon as ITS part of
     // the slice is in the L2 (no arrival count among them), into the 32 consumers' mailboxes (one lane per consumer); a consumer wave samples
     // only the 16 words of the four producers whose features are its k-range — it does not wait for the slowest of all 32
@@ -151,7 +172,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
                 }
             }
         }
-        if (s > 1 && !dead) {
+        if (s > 1 && (!RP_TAG || s == 2) && !dead) {
             // wait for the four producers of this wave's k-range (lane = producer * 4 + reducer wave); the first step's input comes from an earlier launch
             const unsigned want = p.base + (unsigned)(s - 1);
             int spins = 0;
@@ -187,11 +208,35 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
             const int hw = lane >> 5, ch = lane & 31;
             const unsigned off = (unsigned)((qp + (long long)(t0 + hw) * RP_HID + RP_KW * wave + 8 * ch) * 2);
             rp_u32x4 stg[TOK / 2];
+#if RP_TAG
+            for (int spins = 0;;) {
+                bool ready = true;
+#pragma unroll
+                for (int i = 0; i < TOK / 2; ++i) {
+                    stg[i] = rp_u32x4{0u, 0u, 0u, 0u};
+                    if (2 * i + hw < nwin) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + (unsigned)(2 * i) * (RP_HID * 2), 0, 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TOK / 2; ++i) ready = ready && stg[i][0] != RP_SENT && stg[i][3] != RP_SENT;
+                if (s < 3 || dead || __all(ready)) break;
+                if (++spins > (1 << 16)) {
+                    dead = true;
+                    if (lane == 0) {
+                        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (p.skip) __hip_atomic_store(p.skip, p.skip_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            RP_STAMP(1);
+#else
 #pragma unroll
             for (int i = 0; i < TOK / 2; ++i) {
                 stg[i] = rp_u32x4{0u, 0u, 0u, 0u};
                 if (2 * i + hw < nwin) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + (unsigned)(2 * i) * (RP_HID * 2), 0, 16);
             }
+#endif
 #pragma unroll
             for (int i = 0; i < TOK / 2; ++i) *(__attribute__((address_space(3))) rp_u32x4*)(xs + (2 * i + hw) * RP_XPITCH + 16 * ch) = stg[i];
             const lds_c* const xr_l = xs + (li & (TOK - 1)) * RP_XPITCH + 16 * gq;
@@ -266,10 +311,12 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
                 }
             }
             RP_STAMP(5);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the slice is in the L2
-            RP_STAMP(6);
-            if (lane < RP_SLOTS)      // this reducer wave's part of the slice is in the L2 -> its word in every consumer's mailbox
-                __hip_atomic_store(p.flags + (((grp * RP_SLOTS + lane) * RP_SLOTS + slot) * 4 + wave), p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!RP_TAG || s == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the slice (and, RP_TAG, of the pre-fill) is in the L2
+                RP_STAMP(6);
+                if (lane < RP_SLOTS)      // this reducer wave's part of the slice is in the L2 -> its word in every consumer's mailbox
+                    __hip_atomic_store(p.flags + (((grp * RP_SLOTS + lane) * RP_SLOTS + slot) * 4 + wave), p.base + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
 }
