@@ -28,9 +28,13 @@
 //     workgroup's own mailbox with `sc1` loads (they bypass the L1, which another CU's stores never refresh, and are served by the L2 — the mailbox lines are
 //     rewritten every step and stay dirty-resident there) and then reads the state with `sc1` loads.  Measured alternatives (B = 64, S = 32,
 //     per step): write-through `sc1` stores + flags through memory, the placement-independent form, 5.6 - 9.3 us (no better than a launch
-//     per step: 4.2 us back to back); this form 2.6 - 3.2 us (2.3 - 2.4 us since the state is read as whole lines, RP_COAL below); the state as its own ready flag (slices pre-filled with a reserved NaN pattern,
-//     consumers re-reading until it is gone: one hop less on paper) 3.6 - 4.7 us — polling lines that are NOT being rewritten costs a memory
-//     round trip per sample, and sampling the payload itself saturates the L2.  There is no grid-wide barrier and no cross-XCD traffic;
+//     per step: 4.2 us back to back); this form 2.6 - 3.2 us with the state read fragment-shaped (round 3), where the state as its own ready flag
+//     (slices pre-filled with a reserved NaN pattern, consumers re-reading until it is gone: one hop less) cost 3.6 - 4.7 us — a fragment-shaped
+//     sweep is 2048 line lookups per CU and sampling the payload that way saturated the L2.  Round 4: the state is read as whole lines (RP_COAL,
+//     2.36 us per step with flags), which makes a sweep cheap enough that the SECOND form wins: from the third step on (RP_TAG) the producers
+//     neither drain their stores nor post flags, consumers sweep the slices until no 16-byte piece shows the pattern (2.24 us per step at B = 64,
+//     2.06 at B = 37).  The first hand-off of a launch keeps the flags: it is what proves that a producer's pre-fill of its later slices has landed
+//     (see the kernel).  There is no grid-wide barrier and no cross-XCD traffic;
 //   * every poll loop is bounded; a timeout (workgroups not co-resident: somebody else holds CUs; XCD population not 32) raises `err`.
 // Mailbox words never need zeroing: a launch publishes base + s with a base the host advances by 4096 per launch.  The census counters are
 // double-buffered by launch parity: a launch counts in one set and clears the other.
