@@ -480,6 +480,53 @@ __global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const h16_t*
 #pragma unroll
     for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; s[e] = 0.f; ax[e] = 0.f; ay[e] = 0.f; }
     const float sh = 2.f / (H - 1), sw = 2.f / (W - 1);
+    constexpr int SSM_NIT = 7;                    // 64-position rounds held in registers: 448 >= the 21 x 21 map of the static camera
+    if (HW <= SSM_NIT * 64) {
+        // Two passes over registers instead of the online form below: the whole map of this thread (<= 14 positions x 8 channels, 56 VGPRs) is requested
+        // up front, pass 1 takes the thread's maximum, pass 2 one exponential per value — the online form pays a compare, a conditional rescale and
+        // two exponentials per value and was VALU-bound (36 us for the 115 MB of the static camera's maps, 21 us of HBM time)
+#ifdef HULC_HALF_F16
+        constexpr unsigned NEG_INF2 = 0xFC00FC00u;
+#else
+        constexpr unsigned NEG_INF2 = 0xFF80FF80u;
+#endif
+        uint4 raw[SSM_NIT][2];
+#pragma unroll
+        for (int it = 0; it < SSM_NIT; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = pg + it * 64 + u * 32;
+                raw[it][u] = uint4{NEG_INF2, NEG_INF2, NEG_INF2, NEG_INF2};
+                if (q < HW) raw[it][u] = *reinterpret_cast<const uint4*>(p + (long long)q * 64);
+            }
+#pragma unroll
+        for (int it = 0; it < SSM_NIT; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned wd[4] = {raw[it][u].x, raw[it][u].y, raw[it][u].z, raw[it][u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (e & 1) ? h2f_hi(wd[e >> 1]) : h2f_lo(wd[e >> 1]));
+            }
+        float mu[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mu[e] = m[e] == -INFINITY ? 0.f : m[e];      // a thread without a position: exp(-inf - 0) = 0, its maximum stays -inf for the merge
+        int h = pg / W, w = pg - h * W;
+#pragma unroll
+        for (int it = 0; it < SSM_NIT; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float lx = -1.f + sh * h, ly = -1.f + sw * w;
+                const unsigned wd[4] = {raw[it][u].x, raw[it][u].y, raw[it][u].z, raw[it][u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (e & 1) ? h2f_hi(wd[e >> 1]) : h2f_lo(wd[e >> 1]);
+                    const float ex = __expf(v - mu[e]);
+                    s[e] += ex; ax[e] += ex * lx; ay[e] += ex * ly;
+                }
+                w += 32;                                                           // next position of this thread: q + 32
+                while (w >= W) { w -= W; ++h; }
+            }
+    } else
     for (int q0 = pg; q0 < HW; q0 += 64) {
         uint4 raw[2];
 #pragma unroll
@@ -507,16 +554,34 @@ __global__ void __launch_bounds__(256) spatial_softmax_fwd64_kernel(const h16_t*
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sm[pg][cg * 8 + e] = m[e]; ss[pg][cg * 8 + e] = s[e]; sx[pg][cg * 8 + e] = ax[e]; sy[pg][cg * 8 + e] = ay[e]; }
     __syncthreads();
+    // merge of the 32 position groups in two levels: all four waves merge 8 groups each, one wave the four results (a single wave walking all
+    // 32 was a ~1.5 us serial tail per frame with the other three waves idle)
+    __shared__ float t2[4][4][64];
+    {
+        const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+        float M = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) M = fmaxf(M, sm[part * 8 + k][c]);
+        float S = 0.f, X = 0.f, Y = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float mk = sm[part * 8 + k][c];
+            const float sc = (mk == -INFINITY) ? 0.f : __expf(mk - M);
+            S += ss[part * 8 + k][c] * sc; X += sx[part * 8 + k][c] * sc; Y += sy[part * 8 + k][c] * sc;
+        }
+        t2[0][part][c] = M; t2[1][part][c] = S; t2[2][part][c] = X; t2[3][part][c] = Y;
+    }
+    __syncthreads();
     if (threadIdx.x < 64) {
         const int c = threadIdx.x;
         float M = -INFINITY;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) M = fmaxf(M, sm[k][c]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M = fmaxf(M, t2[0][k][c]);
         float S = 0.f, X = 0.f, Y = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float sc = (sm[k][c] == -INFINITY) ? 0.f : __expf(sm[k][c] - M);
-            S += ss[k][c] * sc; X += sx[k][c] * sc; Y += sy[k][c] * sc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sc = (t2[0][k][c] == -INFINITY) ? 0.f : __expf(t2[0][k][c] - M);
+            S += t2[1][k][c] * sc; X += t2[2][k][c] * sc; Y += t2[3][k][c] * sc;
         }
         const float inv = 1.f / S;
         const float ex = X * inv, ey = Y * inv;

@@ -45,7 +45,10 @@ namespace HULC_NS {
 
 constexpr int RP_HID = 2048, RP_NG = 8, RP_SLOTS = 32, RP_COLS = 64, RP_NW = 8, RP_KW = 256, RP_KS = RP_KW / 32;
 constexpr int RP_TPITCH = RP_COLS * 4 + 16;          // LDS pitch of one window's 64 fp32 partial sums: 17 slots -> conflict-free 16-byte writes
-constexpr int RP_XPITCH = RP_KW * 2 + 16;         // LDS pitch of one window's 512-byte k-range in a wave's staging image (RP_COAL)
+// LDS pitch of one window's 512-byte k-range in a wave's staging image (RP_COAL): 34 slots of 16 bytes = 2 (mod 16).  ds_read_b128 is served in groups
+// of 16 lanes that mix two gq values ({0-3, 12-15 | 20-27}, ...): with slot(li, gq) = 2 li + gq the rows of one gq take the even slots and the other's the
+// odd ones — conflict-free; 33 slots (2-way conflicts between (li, gq) and (li + 1, gq - 1)) showed as SQ_LDS_BANK_CONFLICT 0.23
+constexpr int RP_XPITCH = RP_KW * 2 + 32;
 #ifndef RP_COAL
 #define RP_COAL 1
 #endif
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(RP_NW * 64) rnn_persist_kernel(RnnPersistP p) 
             // The MFMA layout puts 16 different windows (4 KB apart) on 16 adjacent lanes: read that way, every lane's 16 bytes are their own
             // line lookup in the CU's L1 / texture path (2048 per CU and step) and their own request at the L2.  Instead the wave reads its
             // 512-byte k-range of a window with 32 adjacent lanes (four whole 128-byte lines, two windows per instruction) and turns the tile
-            // into fragments through a wave-private LDS image (pitch 528 bytes: the 16 windows of a ds_read_b128 fall into distinct banks).
+            // into fragments through a wave-private LDS image (pitch 544 bytes, see RP_XPITCH).
             lds_c* const xs = (lds_c*)smem + 2 * BUF + wave * (TOK * RP_XPITCH);
             const int hw = lane >> 5, ch = lane & 31;
             const unsigned off = (unsigned)((qp + (long long)(t0 + hw) * RP_HID + RP_KW * wave + 8 * ch) * 2);
