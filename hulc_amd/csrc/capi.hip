@@ -379,6 +379,21 @@ int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N,
         if (!launch_skinny_lds_dual(st, a, w, ep, a + (long long)M * K, w + (long long)N * K, ep2, (long long)K, (long long)K, M, N, K, dense_out(N))) {
             hulc_set_error("hulc_k_skinny: shape not covered by the dual launch"); return 1; }
     }
+    else if (NW == 50 || NW == 51) {      // fragment-ordered weight copies (gemm.h: frag_pack_kernel).  500: W repacked into a scratch copy, then the K-chunked LDS kernel reads
+        // it with ldw == 0 (K = n x 2048, M <= 64: the GRU's BPTT step);  510: the repacked W itself lands in `out` (N x K elements; K % 128 == 0, N % 16 == 0)
+        if ((N % 16) != 0 || (K % 128) != 0) { hulc_set_error("hulc_k_skinny: fragment order needs N %% 16 == 0 and K %% 128 == 0"); return 1; }
+        h16_t* wf = (h16_t*)out;
+        if (NW == 50 && hipMalloc((void**)&wf, (size_t)N * K * sizeof(h16_t)) != hipSuccess) { hulc_set_error("hulc_k_skinny: scratch allocation failed"); return 1; }
+        FragPackBatch fb{};
+        fb.src[0] = w; fb.dst[0] = wf; fb.N[0] = N; fb.K[0] = K; fb.blk0[0] = 0; fb.blk0[1] = frag_pack_blocks(N, K); fb.n = 1;
+        hipLaunchKernelGGL(frag_pack_kernel, dim3(fb.blk0[1]), dim3(256), 0, st, fb);
+        if (NW == 50) {
+            const bool ok = launch_skinny_lds_kchunk(st, a, (long long)K, wf, 0ll, M, N, K, dense_out(N), ep);
+            hipStreamSynchronize(st);
+            hipFree(wf);
+            if (!ok) { hulc_set_error("hulc_k_skinny: shape not covered by the K-chunked kernel"); return 1; }
+        }
+    }
     else { hulc_set_error("hulc_k_skinny: unsupported variant"); return 1; }
 #undef SK
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -309,7 +309,9 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
 int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
                      int32_t OUTH, int32_t relu, void* hip_stream);
 /* skinny GEMM kernel alone (bf16 in / bf16 out), variant = waves*10 + row-tiles-per-workgroup; 300 = the production router; 400 = TWO
- * independent problems in one launch (second one at A + M*K, W + N*K, out + M*N; 32 < M <= 64, K = 2048); asynchronous. */
+ * independent problems in one launch (second one at A + M*K, W + N*K, out + M*N; 32 < M <= 64, K = 2048); 500 = W repacked into the
+ * fragment order first (every 16-row x 32-column block = 1 KB in MFMA lane order) and read that way by the K-chunked kernel (K = n x 2048,
+ * synchronous); 510 = only the repack: `out` receives the N x K fragment-ordered copy.  Asynchronous unless noted. */
 int hulc_k_skinny(const void* A, const void* W, void* out, int32_t M, int32_t N, int32_t K, int32_t variant, void* hip_stream);
 /* one whole recurrence X[q0 + s dq] = f(X[q0 + (s-1) dq] W^T, res, mask), s = 1..S-1, as ONE persistent launch (bf16; csrc/rnn_persist.h).
  * X, res, mask: [S][B][2048]; W [2048][2048]; mask == NULL: act 1 ReLU / 2 tanh of (product + res); mask given: (product + res) * (mask > 0)

@@ -144,6 +144,36 @@ def test_skinny_gemm(M, N, K, variant):
     assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3
 
 
+@pytest.mark.parametrize("N,K", [(384, 128), (128, 384), (2048, 128), (128, 2048), (96, 6144)])
+def test_fragment_ordered_weight_copy_layout(N, K):
+    """frag_pack_kernel: block (row tile nb, k-step ks) = 1 KB, lane (g, i) at byte 16 (16 g + i) holds W[16 nb + i][32 ks + 8 g .. + 7] — what a
+    wave's MFMA fragment load of the GRU step / fused transformer kernels expects as one contiguous instruction (both tile widths of the kernel)."""
+    L, lib = _lib()
+    rng = np.random.default_rng(N + K)
+    W = bf(rng.standard_normal((N, K)))
+    out = torch.zeros(N * K, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_skinny(None, W.data_ptr(), out.data_ptr(), 1, N, K, 510, None))
+    torch.cuda.synchronize()
+    w = W.view(torch.int16).cpu().numpy()
+    # [nb][i][ks][g][8] -> [nb][ks][g][i][8]
+    want = w.reshape(N // 16, 16, K // 32, 4, 8).transpose(0, 2, 3, 1, 4).reshape(-1)
+    assert np.array_equal(out.view(torch.int16).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 6144), (37, 1024, 4096)])
+def test_skinny_kchunk_reads_fragment_ordered_weights(M, N, K):
+    """The GRU's BPTT-step kernel on a fragment-ordered copy of W (ldw == 0) against fp64."""
+    L, lib = _lib()
+    rng = np.random.default_rng(M + N)
+    A = bf(rng.standard_normal((M, K)))
+    W = bf(rng.standard_normal((N, K)) * 0.05 + np.arange(N)[:, None] * 1e-4)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.hulc_k_skinny(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, 500, None))
+    torch.cuda.synchronize()
+    ref = f64(A) @ f64(W).T
+    assert np.abs(f64(out) - ref).max() / np.abs(ref).max() < 6e-3
+
+
 @pytest.mark.parametrize("M", [40, 64])
 def test_skinny_dual_launch(M):
     """Two independent recurrent-step GEMMs in one launch (grid.z = 2: the paired directions of the bidirectional plan encoders)."""
