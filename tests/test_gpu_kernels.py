@@ -439,6 +439,32 @@ def test_rnn_persist_kernel(B, S):
             assert e.max() < 6e-3, (mode, act, rev, s, float(e.max()), int(e.argmax()))
 
 
+def test_rnn_persist_relaunch_never_consumes_an_earlier_launch_states():
+    """From the third step on the state is its own ready flag (rnn_persist.h, RP_TAG): a slice counts as written once the pre-filled pattern is gone.
+    The SAME state buffer is therefore driven through many launches with alternating inputs — it always holds the previous launch's valid-looking
+    states when a launch starts; every step of every launch must follow from that launch's own previous step, never from what was left there."""
+    L, lib = _lib()
+    H, B, S = 2048, 64, 32
+    rng = np.random.default_rng(7)
+    W = bf(rng.standard_normal((H, H)) * 0.03)
+    flags = torch.zeros(lib.hulc_k_rnn_persist_flag_words(), dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = [bf(rng.standard_normal((S, B, H))) for _ in range(2)]
+    x0 = [bf(np.abs(rng.standard_normal((B, H)))) for _ in range(2)]
+    X = torch.zeros((S, B, H), dtype=torch.bfloat16, device="cuda")
+    Wf = W.float()
+    for launch in range(1, 25):
+        k = launch & 1
+        X[0] = x0[k]
+        L.check(lib.hulc_k_rnn_persist(X.data_ptr(), W.data_ptr(), res[k].data_ptr(), None, B, S, 0, 1, 1, flags.data_ptr(), err.data_ptr(), launch, None))
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0
+        ref = torch.relu(X[:-1].float() @ Wf.T + res[k][1:].float())              # every step from the kernel's own previous state
+        e = (X[1:].float() - ref).abs().amax(dim=(1, 2)) / ref.abs().amax(dim=(1, 2))
+        assert float(e.max()) < 6e-3, (launch, int(e.argmax()) + 1, float(e.max()))
+        assert not bool(torch.isnan(X.float()).any())
+
+
 # the engine's persistent recurrences (action decoder: 2 layers forward + 2 backward) against the same engine with one launch per time step
 # (hulc_set_option persistent_rnn = 0): the two paths sum the 2048 products of a state element in different orders, so states and gradients
 # agree to 16-bit rounding noise, not bit for bit
