@@ -91,22 +91,31 @@ DEVI void transpose_tile64_h16(const TrDesc& D, int b, unsigned short (*tile)[66
         unsafeAtomicAdd(D.cs + c0 + threadIdx.x, sum);
         if (D.cs2) unsafeAtomicAdd(D.cs2 + c0 + threadIdx.x, sum);
     }
+    // read-out: a thread takes TWO adjacent columns of the tile (one 32-bit LDS read per source row instead of two 16-bit ones: the kernel is bound by its
+    // LDS instruction count, 24 -> 16 per thread) and writes their 8-row runs as two 16-byte stores; 8 adjacent lanes still cover 128 contiguous bytes
+    {
+        const int q = threadIdx.x, cp = (q >> 3) * 2, oc = (q & 7) * 8;
+        const int r = r0 + oc;
+        unsigned w[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = threadIdx.x + i * 256, orow = q >> 3, oc = (q & 7) * 8;
-        const int c = c0 + orow, r = r0 + oc;
-        if (c >= D.C) continue;
-        unsigned short v[8];
+        for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const unsigned*>(&tile[oc + e][cp]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tile[oc + e][orow];
-        if (vout && r + 7 < D.R) {
-            *reinterpret_cast<uint4*>(dst + (long long)c * D.ldt + r) = *reinterpret_cast<const uint4*>(v);
-        } else {
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + cp + h;
+            if (c >= D.C) continue;
+            unsigned short v[8];
+            unsigned* vw = reinterpret_cast<unsigned*>(v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (r + e < D.R) dst[(long long)c * D.ldt + r + e] = v[e];
+            for (int e = 0; e < 4; ++e) vw[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], h ? 0x07060302u : 0x05040100u);
+            if (vout && r + 7 < D.R) {
+                *reinterpret_cast<uint4*>(dst + (long long)c * D.ldt + r) = *reinterpret_cast<const uint4*>(v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (r + e < D.R) dst[(long long)c * D.ldt + r + e] = v[e];
         }
     }
+}
 }
 // descriptor of block b: the last one whose first block is <= b.  Bisection: the linear walk made a block of a late matrix wait for up to ~60
 // dependent descriptor loads before it touched its tile
