@@ -150,7 +150,8 @@ def cpu_baseline(S, budget_s=6.0, kind="hulc", rnn_type="rnn"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node = ranks of the job (default: WORLD_SIZE, else 1).  Given without a launcher "
+                                                       "(no WORLD_SIZE in the environment) and > 1, bench.py re-launches itself under torch.distributed.run with that many ranks")
     ap.add_argument("--steps", type=int, default=100)    # ~0.5 s of timed steps: one host-side stall of a few ms no longer moves the mean
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
@@ -177,6 +178,27 @@ def main():
                                                               "timeline run before the first multi-GPU box meets them (tests/test_gpu_dp.py)")
     args = ap.parse_args()
 
+    # --gpus N MEANS N: under a launcher it must equal WORLD_SIZE; without one, N > 1 re-launches this script with one rank per GPU.
+    # A `python bench.py --gpus 8` that quietly ran one rank and printed n_gpus: 1 is the failure this guards against.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}: refusing to report a line whose n_gpus is not what was asked for")
+    if env_world is None and args.gpus > 1:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible on this node")
+        import socket
+        import subprocess
+        with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -93,6 +93,14 @@ int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* g
     if (!obs || !obs->rgb_static || !obs->rgb_gripper) { hulc_set_error("hulc_rollout_plan: null observation"); return 1; }
     return ctx->e->rollout_plan(obs, goal_rgb_static, goal_rgb_gripper, goal_lang, plan_idx_inject, plan_idx_out);
 }
+int hulc_rollout_get_goal(hulc_ctx* ctx, float* latent_goal_out) {
+    if (!latent_goal_out) { hulc_set_error("hulc_rollout_get_goal: null output"); return 1; }
+    return ctx->e->rollout_get_goal(latent_goal_out);
+}
+int hulc_rollout_set_state(hulc_ctx* ctx, const void* plan, const float* latent_goal) {
+    if (!latent_goal) { hulc_set_error("hulc_rollout_set_state: null latent goal"); return 1; }
+    return ctx->e->rollout_set_state(plan, latent_goal);
+}
 int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out_host) {
     if (!obs || !obs->rgb_static || !obs->rgb_gripper || !obs->robot_obs_raw || !action_out_host) { hulc_set_error("hulc_rollout_act: null argument"); return 1; }
     return ctx->e->rollout_act(obs, u_mix, u_act, action_out_host);

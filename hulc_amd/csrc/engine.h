@@ -301,6 +301,10 @@ struct Engine : IEngine {
         for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
         tab_order.assign(tab.begin(), tab.end());
         std::sort(tab_order.begin(), tab_order.end(), [](const std::pair<std::string, Ref>& a, const std::pair<std::string, Ref>& b) { return a.second.off < b.second.off; });
+        // data parallelism: the "this step's gradients are garbage" vote rides in an alignment-padding element of the LAST bucket (see skip_vote_put)
+        skip_pad = -1;
+        for (const auto& kv : tab_order)
+            if (kv.first.compare(0, 19, "perceptual_encoder.") == 0 && kv.second.n % 64 != 0 && kv.second.off + kv.second.n < numel) { skip_pad = kv.second.off + kv.second.n; break; }
         try {
             bind_enc(encS, "perceptual_encoder.rgb_static_encoder.", false, 200);
             bind_enc(encG, "perceptual_encoder.rgb_gripper_encoder.", true, 84);
@@ -642,7 +646,7 @@ struct Engine : IEngine {
     int zero_grads() override {
         if (!bound) { hulc_set_error("hulc_zero_grads before hulc_bind_params"); return 1; }
         HIP_CHECK(hipMemsetAsync(G, 0, numel * sizeof(float), st));
-        grads_fresh = true;
+        grads_fresh = true; bwd_since_opt = false;
         return 0;
     }
 
@@ -1510,7 +1514,7 @@ struct Engine : IEngine {
 
     // ---------------------------------------------------------------- rollout (hulc.py:843-957), B = 1
     int* roll_plan = nullptr; T* roll_plan_c = nullptr; T *roll_goal = nullptr, *roll_h0 = nullptr, *roll_h1 = nullptr;
-    float *roll_fs = nullptr, *roll_fg = nullptr, *roll_ro = nullptr, *roll_pred = nullptr;
+    float *roll_fs = nullptr, *roll_fg = nullptr, *roll_ro = nullptr, *roll_pred = nullptr, *roll_pred_goal = nullptr;
     bool roll_has_h = false, roll_has_plan = false;
     uint64_t roll_counter = 0;
     void roll_alloc() {
@@ -1518,7 +1522,7 @@ struct Engine : IEngine {
         val_alloc();
         roll_plan = alloc<int>(NCAT); roll_plan_c = alloc<T>(PLAN); roll_goal = alloc<T>(GOAL); roll_h0 = alloc<T>(HID); roll_h1 = alloc<T>(HID);
         roll_fs = alloc<float>(2ll * 3 * encS.IH * encS.IH); roll_fg = alloc<float>(2ll * 3 * encG.IH * encG.IH);
-        roll_ro = alloc<float>(16); roll_pred = alloc<float>(8);
+        roll_ro = alloc<float>(16); roll_pred = alloc<float>(8); roll_pred_goal = alloc<float>(GOAL);
     }
     int rollout_reset() override { roll_has_h = false; roll_has_plan = false; roll_counter = 0; return 0; }
     int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang, const int32_t* plan_inject,
@@ -1565,6 +1569,30 @@ struct Engine : IEngine {
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in rollout_plan"); return 1; }
         return 0;
     }
+    // the latent goal / plan of a rollout as VALUES (hulc.py:881-948: predict_with_plan / get_pp_plan_* take and return them)
+    int rollout_get_goal(float* latent_goal_out) override {
+        if (!roll_has_plan) { hulc_set_error("hulc_rollout_get_goal before hulc_rollout_plan"); return 1; }
+        hipLaunchKernelGGL((cast_kernel<T, float>), dim3(1), dim3(64), 0, st, roll_goal, roll_pred_goal, (long long)GOAL);
+        HIP_CHECK(hipMemcpyAsync(latent_goal_out, roll_pred_goal, sizeof(float) * GOAL, hipMemcpyDefault, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    }
+    int rollout_set_state(const void* plan, const float* latent_goal) override {
+        if (!bound) { hulc_set_error("hulc_rollout_set_state before hulc_bind_params"); return 1; }
+        const bool gcbc = cfg.kind == HULC_KIND_GCBC;
+        if (!gcbc && !plan) { hulc_set_error("hulc_rollout_set_state: null plan"); return 1; }
+        roll_alloc();
+        if (alloc_failed) { hulc_set_error("hulc_rollout_set_state: workspace allocation failed"); return 1; }
+        HIP_CHECK(hipMemcpyAsync(roll_pred_goal, latent_goal, sizeof(float) * GOAL, hipMemcpyDefault, st));
+        hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(64), 0, st, roll_pred_goal, roll_goal, (long long)GOAL);
+        if (mcil) {
+            HIP_CHECK(hipMemcpyAsync(plan_f, plan, sizeof(float) * (PLAN / 2), hipMemcpyDefault, st));
+            hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, plan_f, roll_plan_c, (long long)(PLAN / 2));
+        } else if (!gcbc) HIP_CHECK(hipMemcpyAsync(roll_plan, plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        roll_has_plan = true;
+        return 0;
+    }
     int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) override {
         if (!roll_has_plan) { hulc_set_error("hulc_rollout_act before hulc_rollout_plan (Hulc.step replans at rollout_step_counter %% replan_freq == 0)"); return 1; }
         have_fwd = false;
@@ -1605,6 +1633,7 @@ struct Engine : IEngine {
     unsigned* rp_err_dev = nullptr;
     unsigned* rp_skip = nullptr;          // device word: tag of the optimizer step whose recurrence failed
     unsigned opt_seq = 0;                 // optimizer calls so far; recurrences launched now belong to step opt_seq + 1
+    bool bwd_since_opt = false;           // a backward has accumulated into G since the last optimizer step / zero_grads
     long long rp_fallbacks = 0;
     unsigned rp_launches = 1;
     int rp_B = -1;
@@ -1625,7 +1654,7 @@ struct Engine : IEngine {
             if (X2 && B > 16 * (RP_NG / 2)) return false;
             if (!rp_flags) {
                 rp_flags = alloc<unsigned>(RP_FLAG_WORDS);
-                rp_skip = alloc<unsigned>(64);
+                if (!rp_skip) rp_skip = alloc<unsigned>(64);
                 void* h = nullptr;
                 if (alloc_failed || hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&rp_err_dev, h, 0) != hipSuccess) { rp_probed = true; rp_ok = false; return false; }
                 rp_err_host = (volatile unsigned*)h; *rp_err_host = 0;
@@ -1665,8 +1694,14 @@ struct Engine : IEngine {
         *rp_err_host = 0; rp_ok = false; rp_probed = true; ++rp_fallbacks;
         fprintf(stderr, "hulc: %s: a persistent recurrence launch timed out (code %u: the GPU's CUs were not all available — shared with another process or a "
                         "collective?).  %s; persistent_rnn is now off for this context (one launch per time step).\n", where, code,
-                synced ? "The call is run again on the launch-per-step path" : "The optimizer step it belonged to is skipped on the device (weights untouched)");
-        if (synced && rp_skip) hipMemset(rp_skip, 0, sizeof(unsigned));
+                synced ? (bwd_since_opt ? "The call is run again on the launch-per-step path; a backward of this optimizer step ran before it, so the step is skipped on the device"
+                                        : "The call is run again on the launch-per-step path")
+                       : "The optimizer step it belonged to is skipped on the device (weights untouched)");
+        // synced = the caller is about to run its own forward again.  That makes the step whole only if the failed launch was the caller's: the
+        // timeout may also belong to an earlier, still asynchronous BACKWARD of the same optimizer step (fwd(vis), bwd(vis), fwd(lang): the check
+        // at the entry of the second forward cannot see a backward that is still running) — its garbage is already accumulated in G, so the tag
+        // stays and the step is dropped.  Only a step that has no backward behind it yet is cleared.
+        if (synced && rp_skip && !bwd_since_opt) hipMemset(rp_skip, 0, sizeof(unsigned));
         return true;
     }
     int get_option(const char* name, long long* value) override {
@@ -2079,12 +2114,31 @@ struct Engine : IEngine {
         for (int i = 0; i < (int)v.size() && i < cap; ++i) { lo[i] = v[i].lo; hi[i] = v[i].hi; }
         return (int)v.size();
     }
+    // ---- a timed-out persistent recurrence under data parallelism: the failing rank's garbage gradients are SUMMED into every rank's
+    // buffer, so skipping the optimizer step must be a decision of the whole job — not of the one rank whose launch failed (the others would
+    // apply the garbage and the ranks' weights would diverge).  The vote costs no collective of its own: before the last bucket (the perceptual
+    // encoders', whose tensors leave 64-element alignment padding) is reduced, each rank writes 1.0 into ONE padding element of its gradient
+    // buffer if its skip word carries this step's tag, else 0.0; after the SUM a non-zero element means "some rank failed" -> every rank
+    // sets its own skip word (adam / sgd / scaler_update then return without touching p / m / v) and clears the element.
+    int64_t skip_pad = -1;
+    void skip_vote_put(hipStream_t s) {
+        if (skip_pad < 0) return;
+        if (!rp_skip) rp_skip = alloc<unsigned>(64);
+        if (rp_skip) hipLaunchKernelGGL(dp_skip_put_kernel, dim3(1), dim3(1), 0, s, (const unsigned*)rp_skip, opt_seq + 1, G + skip_pad);
+    }
+    void skip_vote_get(hipStream_t s) {
+        if (skip_pad < 0 || !rp_skip) return;
+        hipLaunchKernelGGL(dp_skip_get_kernel, dim3(1), dim3(1), 0, s, G + skip_pad, rp_skip, opt_seq + 1);
+    }
+    void dp_skip_vote(int phase) override { if (phase == 1) skip_vote_put(st); else if (phase == 2) skip_vote_get(st); }
     int ar_dtype = -1;          // >= 0 while a backward with overlapped all-reduce is running: bucket dtype
     unsigned ar_sent = 0;       // bit i: bucket i already issued in this backward
     // SUM all-reduce of G[lo, hi) on the collectives' stream, ordered after everything enqueued on `st` so far
     int reduce_range(int64_t lo, int64_t hi, int dtype, int span = -1) {
         if (hi <= lo) return 0;
         GradComm& c = *comm;
+        const bool vote = skip_pad >= lo && skip_pad < hi;      // the range that carries the job-wide skip vote (the last bucket / the whole buffer)
+        if (vote) skip_vote_put(st);
         c.gate_from(st);
         const size_t n = (size_t)(hi - lo);
         if (span >= 0) c.span_begin(span, (dtype == HULC_DTYPE_F32 ? 4.0 : 2.0) * n);
@@ -2112,6 +2166,7 @@ struct Engine : IEngine {
             c.bytes_reduced += 4.0 * n;
         }
         c.n_collectives++;
+        if (vote) skip_vote_get(c.cs);
         if (span >= 0) c.span_end(span);
         if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }
         return 0;
@@ -2171,6 +2226,7 @@ struct Engine : IEngine {
     int backward(int part = -1) override {
         if (!have_fwd) { hulc_set_error("hulc_backward without a preceding hulc_forward_loss"); return 1; }
         persist_check("hulc_backward", false);
+        bwd_since_opt = true;
         if (part == 1 && bwd_stage != 1) { hulc_set_error("hulc_backward_part(1) must follow hulc_backward_part(0)"); return 1; }
         if (part != 1 && bwd_stage != 0) { hulc_set_error("hulc_backward: encoder part of the previous backward still pending"); return 1; }
         const hulc_batch* b = &cur;
@@ -2497,6 +2553,7 @@ struct Engine : IEngine {
     int optim(const hulc_optim& o) override {
         if (!bound) { hulc_set_error("hulc_optimizer_step before hulc_bind_params"); return 1; }
         persist_check("hulc_optimizer_step", false);
+        bwd_since_opt = false;
         const unsigned tag = ++opt_seq;
         if (o.kind != HULC_OPT_ADAM && o.kind != HULC_OPT_ADAMW && o.kind != HULC_OPT_SGD) { hulc_set_error("hulc_optimizer_step: unknown optimizer kind %d", (int)o.kind); return 1; }
         if (o.step < 1) { hulc_set_error("hulc_optimizer_step: step counts from 1 (got %lld)", (long long)o.step); return 1; }

@@ -29,6 +29,8 @@ struct IEngine {
     virtual int rollout_plan(const hulc_rollout_obs* obs, const float* goal_static, const float* goal_gripper, const float* goal_lang,
                              const int32_t* plan_inject, int32_t* plan_out) = 0;
     virtual int rollout_act(const hulc_rollout_obs* obs, const float* u_mix, const float* u_act, float* action_out) = 0;
+    virtual int rollout_get_goal(float* latent_goal_out) = 0;
+    virtual int rollout_set_state(const void* plan, const float* latent_goal) = 0;
     virtual int optim(const hulc_optim& o) = 0;
     int adam(float lr, float b1, float b2, float eps, int64_t step, float gscale) {
         hulc_optim o{}; o.kind = HULC_OPT_ADAM; o.lr = lr; o.beta1 = b1; o.beta2 = b2; o.eps = eps; o.step = step; o.grad_scale = gscale;
@@ -76,12 +78,16 @@ struct IEngine {
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
     int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0;
     virtual int get_option(const char* name, long long* value) = 0;
+    virtual void dp_skip_vote(int phase) = 0;
     int set_option(const char* name, long long value) {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
         if (name && !strcmp(name, "fused_transformer")) { tr_fused_mode = value != 0; return 0; }
         if (name && !strcmp(name, "persist_under_comm")) { persist_under_comm = value != 0; return 0; }
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
+        // "dp_skip_vote": for a gradient all-reduce done OUTSIDE the library (the torch.distributed fallback): 1 right before the collective that covers the
+        // perceptual-encoder gradients, 2 right after it — the job-wide "a recurrence of this step failed on some rank" vote (engine.h skip_vote_put)
+        if (name && !strcmp(name, "dp_skip_vote")) { dp_skip_vote((int)value); return 0; }
         if (name && !strcmp(name, "debug_persist_fault")) { persist_fault = (int)value; return 0; }      // tests: the next `value` persistent launches (after the probed first one) lose a producer
         hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
         return 1;

@@ -2190,6 +2190,13 @@ __global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __res
         for (long long j = i; j < n && j < i + 4; ++j) bad |= ((__float_as_uint(g[j]) & 0x7f800000u) == 0x7f800000u);
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ss->found_inf, 1);
 }
+// data-parallel skip vote (engine.h skip_vote_put / skip_vote_get): one alignment-padding element of the gradient buffer carries "my recurrence
+// of this step failed" through the gradients' own SUM all-reduce
+__global__ void dp_skip_put_kernel(const unsigned* __restrict__ skip, unsigned tag, float* __restrict__ pad) { *pad = (*skip == tag) ? 1.f : 0.f; }
+__global__ void dp_skip_get_kernel(float* __restrict__ pad, unsigned* __restrict__ skip, unsigned tag) {
+    if (!(*pad == 0.f)) *skip = tag;      // any rank voted (NaN included)
+    *pad = 0.f;
+}
 // skip / tag: a persistent recurrence of this step failed (rnn_persist.h) — the optimizer left the weights alone, the scaler state stays as it is
 __global__ void scaler_update_kernel(ScalerState* __restrict__ ss, const unsigned* __restrict__ skip = nullptr, unsigned tag = 0) {
     if (skip && *skip == tag) { ss->found_inf = 0; return; }

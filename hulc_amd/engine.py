@@ -257,6 +257,25 @@ class StepEngine:
                                           self._dev_or_host_ptr(u_act, keep, np.float32), out))
         return np.array(list(out), np.float32)
 
+    def rollout_get_goal(self) -> np.ndarray:
+        """The (32,) fp32 latent goal the last rollout_plan encoded (second return value of get_pp_plan_vision / get_pp_plan_lang)."""
+        out = np.empty(32, np.float32)
+        L.check(self.lib.hulc_rollout_get_goal(self.ctx, out.ctypes.data))
+        return out
+
+    def rollout_set_state(self, plan, latent_goal) -> None:
+        """Install a caller-held plan ((32,) int32 indices; (256,) fp32 for mcil; None for gcbc) and (32,) latent goal for the next rollout_act calls."""
+        g = np.ascontiguousarray(np.asarray(latent_goal, np.float32).reshape(-1))
+        if g.size != 32:
+            raise ValueError("latent_goal must have 32 elements")
+        p = None
+        if plan is not None:
+            mcil = self.dims.kind == "mcil"
+            p = np.ascontiguousarray(np.asarray(plan, np.float32 if mcil else np.int32).reshape(-1))
+            if p.size != (256 if mcil else 32):
+                raise ValueError("plan must have %d elements" % (256 if mcil else 32))
+        L.check(self.lib.hulc_rollout_set_state(self.ctx, p.ctypes.data if p is not None else None, g.ctypes.data))
+
     def set_kl_beta(self, kl_beta: float):
         L.check(self.lib.hulc_set_kl_beta(self.ctx, float(kl_beta)))
 

@@ -15,6 +15,7 @@ There is no torch/CPU fallback: constructing the module without the HIP library 
 """
 from __future__ import annotations
 
+import logging
 import math
 import os
 from typing import Any, Dict, Iterator, Optional, Tuple
@@ -25,6 +26,7 @@ import torch
 from . import parallel, spec
 from .engine import StepEngine
 
+logger = logging.getLogger(__name__)
 
 def _get(cfg, key, default=None):
     if cfg is None:
@@ -160,7 +162,9 @@ class CosineWarmupSchedule(LambdaSchedule):
         def fn(step):
             if step < w:
                 return float(step) / float(max(1, w))
-            progress = float(step - w) / float(max(1, n - w))
+            # clamped at the end of the curve: a run that steps past num_training_steps (a mis-inferred length) stays at the final
+            # factor instead of climbing the cosine again (identical to transformers' lambda for every step <= num_training_steps)
+            progress = min(1.0, float(step - w) / float(max(1, n - w)))
             return max(0.0, 0.5 * (1.0 + math.cos(math.pi * c * 2.0 * progress)))
 
         super().__init__(optimizer, fn)
@@ -480,24 +484,27 @@ class Hulc(torch.nn.Module):
     @property
     def num_training_steps(self) -> int:
         """hulc.py:189-216: total optimizer steps inferred from the trainer and its datamodule — (batches per epoch // (accumulation x devices))
-        x max_epochs, capped by max_steps.  This package's Trainer attaches itself as `module.trainer` (with `.datamodule`) before it calls
+        x max_epochs, capped by max_steps; = the number of optimizer steps Trainer.fit really takes (it honours limit_train_batches and
+        rejects accumulate_grad_batches > 1).  This package's Trainer attaches itself as `module.trainer` (with `.datamodule`) before it calls
         configure_optimizers, like Lightning does."""
         tr = getattr(self, "trainer", None)
         if tr is None:
             raise RuntimeError("num_training_steps needs module.trainer (set by Trainer.fit); pass lr_scheduler.num_training_steps >= 0 otherwise")
         dm = getattr(tr, "datamodule", None)
+        num_devices = max(1, int(getattr(tr, "world", 1)))
         if hasattr(dm, "steps_per_epoch"):
-            dataset_size = int(dm.steps_per_epoch)
+            # this package's datamodules state their length PER RANK (every rank draws steps_per_epoch batches of its own): not divided by the
+            # number of devices again.  The reference divides because it measures the un-sharded loader (hulc.py:197-199, 209-211)
+            dataset_size, per_rank = int(dm.steps_per_epoch), True
         else:
             loaders = dm.train_dataloader()
-            dataset_size = max(len(loaders[k]) for k in loaders) if isinstance(loaders, dict) else len(loaders)
+            dataset_size, per_rank = (max(len(loaders[k]) for k in loaders) if isinstance(loaders, dict) else len(loaders)), False
         ltb = getattr(tr, "limit_train_batches", None)
         if isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0:
             dataset_size = ltb
         elif isinstance(ltb, float):
             dataset_size = int(dataset_size * ltb)
-        num_devices = max(1, int(getattr(tr, "world", 1)))
-        effective = int(getattr(tr, "accumulate_grad_batches", 1)) * num_devices
+        effective = int(getattr(tr, "accumulate_grad_batches", 1)) * (1 if per_rank else num_devices)
         max_estimated = (dataset_size // effective) * int(tr.max_epochs)
         if tr.max_steps and 0 < tr.max_steps < max_estimated:
             return int(tr.max_steps)
@@ -710,25 +717,74 @@ class Hulc(torch.nn.Module):
     def _rollout_obs(obs: Dict[str, Any]) -> Dict[str, torch.Tensor]:
         return dict(rgb_static=obs["rgb_obs"]["rgb_static"], rgb_gripper=obs["rgb_obs"]["rgb_gripper"], robot_obs_raw=obs.get("robot_obs_raw"))
 
+    def _plan_value(self, plan_dev) -> torch.Tensor:
+        """The engine's plan -> the reference's VALUE: (1, 1024) one-hot of the 32 category indices (distributions.py:37-41), (1, 256) for mcil."""
+        if self.kind == "mcil":
+            return plan_dev.to(torch.float32).reshape(1, -1)
+        return torch.nn.functional.one_hot(plan_dev.long(), 32).to(torch.float32).reshape(1, -1)
+
+    def get_pp_plan_vision(self, obs: dict, goal: dict, noise: Optional[Dict] = None):
+        """hulc.py:905-927: obs + goal frame as one 2-frame window -> visual goal encoder -> plan proposal -> a sampled plan; clears the
+        decoder's hidden state.  Returns (sampled_plan, latent_goal) as values like the reference: (1,1024) one-hot / (1,256), (1,32)."""
+        assert len(obs["rgb_obs"]) == len(goal["rgb_obs"])
+        noise = noise or {}
+        g = dict(rgb_static=goal["rgb_obs"]["rgb_static"], rgb_gripper=goal["rgb_obs"]["rgb_gripper"])
+        plan = self.engine.rollout_plan(self._rollout_obs(obs), g, plan_idx=noise.get("plan") if self.kind == "mcil" else noise.get("plan_idx"))
+        return self._plan_value(plan), torch.from_numpy(self.engine.rollout_get_goal()).reshape(1, -1).to(plan.device)
+
+    def get_pp_plan_lang(self, obs: dict, goal, noise: Optional[Dict] = None):
+        """hulc.py:929-948: `goal` = the embedded language instruction (384-d) -> language goal encoder -> plan proposal -> a sampled plan;
+        clears the decoder's hidden state.  Returns (sampled_plan, latent_goal)."""
+        noise = noise or {}
+        g = torch.as_tensor(goal, dtype=torch.float32).reshape(-1)
+        plan = self.engine.rollout_plan(self._rollout_obs(obs), g, plan_idx=noise.get("plan") if self.kind == "mcil" else noise.get("plan_idx"))
+        return self._plan_value(plan), torch.from_numpy(self.engine.rollout_get_goal()).reshape(1, -1).to(plan.device)
+
+    def predict_with_plan(self, obs: Dict[str, Any], latent_goal: torch.Tensor, sampled_plan: torch.Tensor, noise: Optional[Dict] = None) -> torch.Tensor:
+        """hulc.py:881-903: encode the current frame, one stateful decoder step with the GIVEN latent goal and plan, sample, tcp -> world.
+        The plan and goal are installed as values (hulc_rollout_set_state), so a caller may hold, swap or replay them like with the reference."""
+        noise = noise or {}
+        p = None
+        if self.kind != "gcbc":
+            p = sampled_plan.detach().reshape(-1).cpu()
+            p = p.numpy().astype(np.float32) if self.kind == "mcil" else p.reshape(32, 32).argmax(-1).numpy().astype(np.int32)
+        self.engine.rollout_set_state(p, latent_goal.detach().reshape(-1).cpu().numpy())
+        action = self.engine.rollout_act(self._rollout_obs(obs), u_mix=noise.get("u_mix"), u_act=noise.get("u_act"))
+        return torch.from_numpy(action).reshape(1, 1, 7)
+
     def step(self, obs, goal, noise: Optional[Dict] = None):
         """One step of inference (hulc.py:851-869): replan every replan_freq steps from the plan proposal, then act.
         obs: rgb_obs {rgb_static (1,1,3,200,200), rgb_gripper (1,1,3,84,84)}, robot_obs_raw (1,1,15); goal: a sentence (key of
         load_lang_embeddings) or a dict with rgb_obs goal images.  Returns the (1,1,7) world-frame action."""
-        import numpy as np
         noise = noise or {}
-        o = self._rollout_obs(obs)
         if self.rollout_step_counter % self.replan_freq == 0:
             if isinstance(goal, str):
                 if self.lang_embeddings is None:
                     raise RuntimeError("call load_lang_embeddings() before stepping with a language goal (hulc.py:871)")
-                g = torch.from_numpy(np.asarray(self.lang_embeddings[goal], np.float32)).reshape(-1)
+                embedded_lang = torch.from_numpy(np.asarray(self.lang_embeddings[goal], np.float32)).reshape(-1)
+                self.plan, self.latent_goal = self.get_pp_plan_lang(obs, embedded_lang, noise)
             else:
-                g = dict(rgb_static=goal["rgb_obs"]["rgb_static"], rgb_gripper=goal["rgb_obs"]["rgb_gripper"])
-            self.plan = self.engine.rollout_plan(o, g, plan_idx=noise.get("plan") if self.kind == "mcil" else noise.get("plan_idx"))
-            self.latent_goal = True
-        action = self.engine.rollout_act(o, u_mix=noise.get("u_mix"), u_act=noise.get("u_act"))
+                self.plan, self.latent_goal = self.get_pp_plan_vision(obs, goal, noise)
+        action = self.predict_with_plan(obs, self.latent_goal, self.plan, noise)
         self.rollout_step_counter += 1
-        return torch.from_numpy(action).reshape(1, 1, 7)
+        return action
+
+    # ---- epoch hooks (hulc.py:959-978; rank-zero log lines like the reference's logger.info / log_rank_0) ----------------------
+    @property
+    def current_epoch(self) -> int:
+        return int(getattr(getattr(self, "trainer", None), "current_epoch", 0))
+
+    def on_train_epoch_start(self) -> None:
+        if parallel.rank() == 0:
+            logger.info(f"Start training epoch {self.current_epoch}")
+
+    def on_train_epoch_end(self, unused=None) -> None:
+        if parallel.rank() == 0:
+            logger.info(f"Finished training epoch {self.current_epoch}")
+
+    def on_validation_epoch_end(self) -> None:
+        if parallel.rank() == 0:
+            logger.info(f"Finished validation epoch {self.current_epoch}")
 
 
 class GCBC(Hulc):

@@ -11,7 +11,7 @@ Unused parameters (GCBC's plan_proposal / fc_state) simply contrib
 from __future__ import annotations
 
 import os
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -72,6 +72,24 @@ def mean_scalar(x: float, device=None) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item()) / world_size()
+
+
+def mean_metrics(sums: Dict[str, float], counts: Dict[str, int], device=None) -> Dict[str, float]:
+    """Epoch means of per-batch metrics over ALL ranks' batches.  The key set may differ between ranks (`lang_gt/*` is only logged by batches
+    with masked language rows, hulc.py:988-989): the ranks first agree on the union of their keys (one all_gather_object), then ONE
+    all-reduce carries a (sum, count) pair per key in sorted order — a rank that never logged a key contributes 0 / 0 instead of issuing
+    fewer collectives (a hang) or pairing its k-th metric with another rank's different k-th metric."""
+    if world_size() == 1:
+        return {k: float(v) / max(int(counts.get(k, 0)), 1) for k, v in sums.items()}
+    gathered = [None] * world_size()
+    dist.all_gather_object(gathered, sorted(sums))
+    keys = sorted(set().union(*[set(g) for g in gathered]))
+    if not keys:
+        return {}
+    t = torch.tensor([[float(sums.get(k, 0.0)), float(counts.get(k, 0))] for k in keys], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t.cpu()
+    return {k: float(t[i, 0]) / float(t[i, 1]) for i, k in enumerate(keys) if float(t[i, 1]) > 0}
 
 
 BUCKET_GROUPS = (("action_decoder.", None), ("plan_proposal.",), ("plan_recognition.",), ("visual_goal.", "language_goal."), ("perceptual_encoder.",))
@@ -172,11 +190,38 @@ def shared_device_ranks(device) -> int:
     if world_size() == 1 or not torch.cuda.is_available():
         return 1
     import socket
-    props = torch.cuda.get_device_properties(device)
-    key = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")) or str(torch.device(device).index))
+    ident = device_identity(device)
+    if ident is None:
+        # unknown identity: do NOT conclude that the ranks share a device — with per-rank HIP_VISIBLE_DEVICES isolation every rank sees "cuda:0",
+        # and keying on the index would switch the persistent recurrences off for the whole job (a silent slowdown).  A rank that
+        # really shares its GPU still falls back by itself when a persistent launch times out (csrc/engine.h persist_check).
+        ident = ("unknown", rank())
+    key = (socket.gethostname(), ident)
     keys = [None] * world_size()
     dist.all_gather_object(keys, key)
     return sum(1 for k in keys if k == key)
+
+
+def device_identity(device):
+    """A job-wide identity of the physical GPU behind `device`: its UUID or PCI address from the device properties; else the entry of
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES that the index maps to (the launcher's per-rank isolation); None if
+    nothing identifies it."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return ("uuid", str(uuid))
+    bus = getattr(props, "pci_bus_id", None)
+    if bus is not None and getattr(props, "pci_device_id", None) is not None:
+        return ("pci", int(getattr(props, "pci_domain_id", 0) or 0), int(bus), int(props.pci_device_id))
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis:
+            ids = [v.strip() for v in vis.split(",") if v.strip()]
+            if idx < len(ids):
+                return (var, ids[idx])
+    return None
 
 
 def configure_shared_gpu(engine) -> int:
@@ -212,13 +257,21 @@ def backward_overlapped(engine) -> None:
     if getattr(engine, "has_comm", False):                    # the library's own RCCL communicator: bucketed, reverse-forward order, event-ordered
         engine.backward_allreduce(getattr(engine, "comm_bucket_dtype", "fp32"))
         return
+    # torch.distributed fallback.  The job-wide "a persistent recurrence of this step timed out on some rank" vote rides in a padding element of
+    # the encoder slice (hulc_set_option dp_skip_vote: 1 = write this rank's vote before the collective, 2 = read the SUM after it) so that every
+    # rank drops the optimizer step together — the failing rank's garbage is in everybody's sum
+    vote = getattr(engine, "set_option", None)
     if os.environ.get("HULC_DP_OVERLAP", "1") == "0":        # experiment knob: plain backward, then one all-reduce
         engine.backward()
+        if vote: vote("dp_skip_vote", 1)
         dist.all_reduce(engine.flat_grads, op=dist.ReduceOp.SUM)
+        if vote: vote("dp_skip_vote", 2)
         return
     n_enc = engine.encoder_numel
     engine.backward(0)
     work = dist.all_reduce(engine.flat_grads[n_enc:], op=dist.ReduceOp.SUM, async_op=True)
     engine.backward(1)
+    if vote: vote("dp_skip_vote", 1)
     dist.all_reduce(engine.flat_grads[:n_enc], op=dist.ReduceOp.SUM)
+    if vote: vote("dp_skip_vote", 2)
     work.wait()

@@ -136,6 +136,10 @@ class Trainer:
                  accumulate_grad_batches: int = 1, **_unused):
         self.max_epochs, self.max_steps, self.log_dir = int(max_epochs), int(max_steps), log_dir
         self.limit_train_batches, self.accumulate_grad_batches = limit_train_batches, max(1, int(accumulate_grad_batches or 1))
+        if self.accumulate_grad_batches != 1:
+            # training_step runs forward AND backward and the optimizer steps on every batch; a schedule inferred for fewer optimizer steps than
+            # are taken would reach lr 0 early.  No reference configuration sets it (conf/trainer/*.yaml): rejected, not ignored
+            raise NotImplementedError("accumulate_grad_batches > 1 is not supported by hulc_amd.trainer.Trainer (the reference's confs never set it)")
         self.datamodule = None
         self.limit_val_batches, self.check_val_every_n_epoch = limit_val_batches, max(1, int(check_val_every_n_epoch or 1))
         self.val_history: List[Dict[str, float]] = []
@@ -147,6 +151,15 @@ class Trainer:
         self.optimizer = None
         self.history: List[Dict[str, float]] = []
         self.epoch_history: List[Dict[str, float]] = []
+
+    def _train_batches(self, datamodule) -> float:
+        """Batches of one training epoch after limit_train_batches — the same arithmetic Hulc.num_training_steps uses (hulc.py:201-205)."""
+        ltb = self.limit_train_batches
+        if isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0:
+            return ltb
+        if isinstance(ltb, float) and hasattr(datamodule, "steps_per_epoch"):
+            return int(int(datamodule.steps_per_epoch) * ltb)
+        return float("inf")
 
     def validate(self, module, datamodule) -> Dict[str, float]:
         """Lightning's validation loop for this module: eval mode, validation_step over the val batches, mean of every `val*` metric."""
@@ -170,7 +183,9 @@ class Trainer:
                     counts[k] = counts.get(k, 0) + 1
             n += 1
         module.train()
-        out = {k: parallel.mean_scalar(v / max(counts[k], 1), device=module.device) for k, v in sums.items()}
+        if hasattr(module, "on_validation_epoch_end"):
+            module.on_validation_epoch_end()
+        out = parallel.mean_metrics(sums, counts, device=module.device)
         self.val_history.append(out)
         return out
 
@@ -203,7 +218,11 @@ class Trainer:
             for cb in self.callbacks:
                 if hasattr(cb, "on_train_epoch_start"):
                     cb.on_train_epoch_start(self, module)
-            for batch in datamodule.train_dataloader(self.rank):
+            if hasattr(module, "on_train_epoch_start"):
+                module.on_train_epoch_start()
+            for bi, batch in enumerate(datamodule.train_dataloader(self.rank)):
+                if bi >= self._train_batches(datamodule):                 # Lightning's limit_train_batches (int: batches, float: fraction of the epoch)
+                    break
                 loss = module.training_step(batch, self.global_step)      # forward + loss + backward (grads accumulated)
                 self.optimizer.step()                                      # RCCL all-reduce (mean) + fused Adam
                 sched.step()
@@ -224,6 +243,8 @@ class Trainer:
                 self.epoch_history.append(dict(epoch=self.current_epoch, **em))
                 if self.rank == 0 and em:
                     print(f"[hulc_amd] epoch {self.current_epoch} means: " + ", ".join(f"{k} {v:.4f}" for k, v in sorted(em.items()) if k.startswith("train/")), flush=True)
+            if hasattr(module, "on_train_epoch_end"):
+                module.on_train_epoch_end()
             for cb in self.callbacks:
                 if hasattr(cb, "on_train_epoch_end"):
                     cb.on_train_epoch_end(self, module)

@@ -243,6 +243,14 @@ int hulc_rollout_plan(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* g
                       const int32_t* plan_idx_inject /* (32) or NULL */, int32_t* plan_idx_out /* (32) host or device, optional */);
 int hulc_rollout_act(hulc_ctx* ctx, const hulc_rollout_obs* obs, const float* u_mix /* (6,10) or NULL */,
                      const float* u_act /* (6) or NULL */, float* action_out_host /* (7) */);
+/* The reference's three public inference methods take and return the plan and the latent goal as VALUES (hulc.py:881-948; called by name
+ * from hulc/evaluation/rollouts_interactive.py:158-164): hulc_rollout_get_goal reads the latent goal the last hulc_rollout_plan encoded
+ * ((32) fp32, the second return value of get_pp_plan_vision / get_pp_plan_lang); hulc_rollout_set_state installs a caller-held plan
+ * ((32) int32 category indices, (256) fp32 for HULC_KIND_MCIL, ignored / NULL for HULC_KIND_GCBC) and latent goal ((32) fp32) for the
+ * following hulc_rollout_act calls = the `latent_goal, sampled_plan` arguments of predict_with_plan (:881-903).  Neither touches the
+ * decoder's hidden state.  Pointers may be host or device memory. */
+int hulc_rollout_get_goal(hulc_ctx* ctx, float* latent_goal_out /* (32) */);
+int hulc_rollout_set_state(hulc_ctx* ctx, const void* plan, const float* latent_goal /* (32) */);
 
 /* ---- MiniLM sentence encoder: the reference's SBert (hulc/models/encoders/language_network.py:8-17) =
  * sentence_transformers "all-MiniLM-L6-v2" (conf/model/sbert.yaml:2) = BERT encoder + masked mean pooling + L2 normalisation.

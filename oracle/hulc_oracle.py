@@ -601,6 +601,18 @@ def decoder_loss_bwd(P, G, c, dims, scale):
 # ----------------------------------------------------------------------------------------------------
 # mcil variant (conf/model/mcil.yaml): bidirectional tanh-RNN plan recognition, continuous latent plan
 # ----------------------------------------------------------------------------------------------------
+def _birnn_zx(inp2d, wih, b, l):
+    """The hoisted input projection of one direction of a plan-encoder layer as the engines hold it: fp32 in the plain mode; in the
+    rounding-aware mode a stored 16-bit tensor — layer 1's input is [H0 forward | H0 reverse], projected as two K = 2048 GEMMs of which the
+    first result is stored (16-bit) and re-read as the residual of the second (engine.h birnn_fwd / bigru_fwd)."""
+    if _QMODE is None:
+        return (inp2d @ wih.T + b).astype(F32)
+    if l == 0:
+        return q(mm(inp2d, wih.T) + b)
+    Hn = inp2d.shape[1] // 2
+    return q(q(mm(inp2d[:, :Hn], wih[:, :Hn].T) + b) + mm(inp2d[:, Hn:], wih[:, Hn:].T))
+
+
 def bigru_fwd(P, emb):
     """PlanRecognitionBiRNNNetwork.forward with rnn_type nn.GRU (plan_recognition_net.py:27-42; torch.nn.GRU cell equations):
     r = sig(W_ir x + b_ir + W_hr h + b_hr), z = sig(W_iz x + b_iz + W_hz h + b_hz), n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
@@ -615,17 +627,17 @@ def bigru_fwd(P, emb):
             wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
             bih, bhh = P[f"{pre}bias_ih_l{l}{sfx}"], P[f"{pre}bias_hh_l{l}{sfx}"]
             Hn = whh.shape[1]
-            zx = (inp.reshape(B * S, -1) @ wih.T + bih).reshape(B, S, 3 * Hn)
+            zx = _birnn_zx(inp.reshape(B * S, -1), wih, bih, l).reshape(B, S, 3 * Hn)
             Hs, R, Z, N, GN, HP = (np.zeros((B, S, Hn), F32) for _ in range(6))
             h = np.zeros((B, Hn), F32)
             for t in order:
-                g = (h @ whh.T + bhh).astype(F32)
+                g = (mm(h, whh.T) + bhh).astype(F32)          # fp32 accumulators; the gates are computed on them in the same launch
                 r = sigmoid(zx[:, t, :Hn] + g[:, :Hn]).astype(F32)
                 z = sigmoid(zx[:, t, Hn:2 * Hn] + g[:, Hn:2 * Hn]).astype(F32)
                 n = np.tanh(zx[:, t, 2 * Hn:] + r * g[:, 2 * Hn:]).astype(F32)
                 HP[:, t] = h
-                h = ((1.0 - z) * n + z * h).astype(F32)
-                Hs[:, t], R[:, t], Z[:, t], N[:, t], GN[:, t] = h, r, z, n, g[:, 2 * Hn:]
+                h = q(((1.0 - z) * n + z * h).astype(F32))     # the state is a stored 16-bit tensor; r, z, n, W_hn h + b_hn are kept (16-bit) for the backward
+                Hs[:, t], R[:, t], Z[:, t], N[:, t], GN[:, t] = h, q(r), q(z), q(n), q(g[:, 2 * Hn:])
             c[f"g{l}{sfx}"] = (Hs, R, Z, N, GN, HP)
             outs.append(Hs)
         inp = np.concatenate(outs, -1)
@@ -645,7 +657,7 @@ def bigru_bwd(P, G, c, dstate):
     B, S, _ = emb.shape
     Hn = c["g0"][0].shape[-1]
     dout = np.zeros((B, S, 2 * Hn), F32)
-    dout[:, -1] = dx
+    dout[:, -1] = qg(dx)                                 # d x is a stored 16-bit tensor (as is every dH below)
     for l in (1, 0):
         inp = c["out0"] if l == 1 else emb
         dinp = np.zeros_like(inp)
@@ -663,15 +675,15 @@ def bigru_bwd(P, G, c, dstate):
                 dn = dh * (1.0 - z) * (1.0 - n * n)
                 dz = dh * (hp - n) * z * (1.0 - z)
                 dr = dn * gn * r * (1.0 - r)
-                dZx[:, t] = np.concatenate([dr, dz, dn], -1)
-                dGh[:, t] = np.concatenate([dr, dz, dn * r], -1)
-                carry = dh * z + dGh[:, t] @ whh
-            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dGh.reshape(B * S, -1).T @ HP.reshape(B * S, Hn))
+                dZx[:, t] = qg(np.concatenate([dr, dz, dn], -1))       # both pre-activation gradients are stored 16-bit GEMM operands
+                dGh[:, t] = qg(np.concatenate([dr, dz, dn * r], -1))
+                carry = qg(dh * z) + dGh[:, t] @ q(whh)                # the direct path is stored (16-bit), the GEMM part stays in fp32 accumulators
+            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dGh.reshape(B * S, -1).T @ q(HP.reshape(B * S, Hn)))
             _acc(G, f"{pre}bias_hh_l{l}{sfx}", dGh.reshape(B * S, -1).sum(0))
-            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dZx.reshape(B * S, -1).T @ inp.reshape(B * S, -1))
+            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dZx.reshape(B * S, -1).T @ q(inp.reshape(B * S, -1)))
             _acc(G, f"{pre}bias_ih_l{l}{sfx}", dZx.reshape(B * S, -1).sum(0))
-            dinp += (dZx.reshape(B * S, -1) @ wih).reshape(B, S, -1)
-        dout = dinp.astype(F32)
+            dinp += (dZx.reshape(B * S, -1) @ q(wih)).reshape(B, S, -1)
+        dout = (qg(dinp) if l == 1 else dinp).astype(F32)       # layer 0's output gradient is stored (16-bit); d emb accumulates in fp32
     return dout
 
 
@@ -687,11 +699,11 @@ def birnn_fwd(P, emb):
         for sfx, order in (("", range(S)), ("_reverse", range(S - 1, -1, -1))):
             wih, whh = P[f"{pre}weight_ih_l{l}{sfx}"], P[f"{pre}weight_hh_l{l}{sfx}"]
             b = P[f"{pre}bias_ih_l{l}{sfx}"] + P[f"{pre}bias_hh_l{l}{sfx}"]
-            zx = (inp.reshape(B * S, -1) @ wih.T + b).reshape(B, S, -1)
+            zx = _birnn_zx(inp.reshape(B * S, -1), wih, b, l).reshape(B, S, -1)
             Hs = np.zeros((B, S, whh.shape[0]), F32)
             h = np.zeros((B, whh.shape[0]), F32)
             for t in order:
-                h = np.tanh(zx[:, t] + h @ whh.T).astype(F32)
+                h = q(np.tanh(zx[:, t] + mm(h, whh.T)).astype(F32))
                 Hs[:, t] = h
             c[f"H{l}{sfx}"] = Hs
             outs.append(Hs)
@@ -712,7 +724,7 @@ def birnn_bwd(P, G, c, dstate):
     B, S, _ = emb.shape
     Hn = c["H0"].shape[-1]
     dout = np.zeros((B, S, 2 * Hn), F32)
-    dout[:, -1] = dx
+    dout[:, -1] = qg(dx)                                 # d x is a stored 16-bit tensor (as is every dH below)
     for l in (1, 0):
         inp = c["out0"] if l == 1 else emb
         dinp = np.zeros_like(inp)
@@ -725,18 +737,18 @@ def birnn_bwd(P, G, c, dstate):
             Hprev = np.zeros((B, S, Hn), F32)
             for i in reversed(range(S)):                     # reverse of the processing order
                 t = order[i]
-                dz = (dH[:, t] + carry) * (1.0 - Hs[:, t] ** 2)
+                dz = qg((dH[:, t] + carry) * (1.0 - Hs[:, t] ** 2))
                 dZ[:, t] = dz
-                carry = dz @ whh
+                carry = dz @ q(whh)
                 if i > 0:
                     Hprev[:, t] = Hs[:, order[i - 1]]
             dz2 = dZ.reshape(B * S, Hn)
-            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dz2.T @ Hprev.reshape(B * S, Hn))
-            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dz2.T @ inp.reshape(B * S, -1))
+            _acc(G, f"{pre}weight_hh_l{l}{sfx}", dz2.T @ q(Hprev.reshape(B * S, Hn)))
+            _acc(G, f"{pre}weight_ih_l{l}{sfx}", dz2.T @ q(inp.reshape(B * S, -1)))
             _acc(G, f"{pre}bias_ih_l{l}{sfx}", dz2.sum(0))
             _acc(G, f"{pre}bias_hh_l{l}{sfx}", dz2.sum(0))
-            dinp += (dz2 @ wih).reshape(B, S, -1)
-        dout = dinp.astype(F32)
+            dinp += (dz2 @ q(wih)).reshape(B, S, -1)
+        dout = (qg(dinp) if l == 1 else dinp).astype(F32)       # layer 0's output gradient is stored (16-bit); d emb accumulates in fp32
     return dout              # grad w.r.t. perceptual_emb (B,S,128)
 
 

@@ -106,3 +106,16 @@ def test_synthetic_batch_contract():
     assert set(np.unique(v["actions"][..., 6])) <= {-1.0, 1.0}
     assert l["lang"].shape == (3, 384) and np.allclose(np.linalg.norm(l["lang"], axis=-1), 1, atol=1e-5)
     assert l["use_for_aux"].dtype == bool and "lang" not in v
+
+
+def test_bench_gpus_flag_is_checked_before_anything_runs():
+    """bench.py `--gpus N` means N ranks: more than the node has, or a launcher WORLD_SIZE that disagrees, is an error — not an `n_gpus: 1` line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and '"metric"' not in r.stdout

@@ -260,3 +260,29 @@ def test_resume_skips_runs_of_another_configuration(tmp_path, capsys):
     d.mkdir(parents=True)
     (d / "epoch=0.ckpt").write_bytes(b"x")
     assert training.resolve_log_dir(pat, resume=True, fp=fp_h) == str(tmp_path / "runs" / "2026-01-03/08-00-00")
+
+
+def _metrics_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hulc_amd import parallel
+    # rank 0 saw masked language rows in 2 of its 3 validation batches, rank 1 in none; the ranks' dicts also differ in insertion order
+    if rank == 0:
+        sums, counts = {"val_act/a": 3.0, "lang_gt/train_sr": 1.0, "val_kl/k": 6.0}, {"val_act/a": 3, "lang_gt/train_sr": 2, "val_kl/k": 3}
+    else:
+        sums, counts = {"val_kl/k": 12.0, "val_act/a": 9.0}, {"val_kl/k": 3, "val_act/a": 3}
+    out[rank] = parallel.mean_metrics(sums, counts)
+    dist.destroy_process_group()
+
+
+def test_validation_metric_reduction_with_rank_dependent_key_sets():
+    """ADVICE r4 (trainer.validate): `lang_gt/*` is logged only by batches with masked language rows, so the ranks' key sets and orders differ;
+    the reduction must neither hang nor average different metrics together."""
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_metrics_worker, args=(2, 29900 + os.getpid() % 90, out), nprocs=2, join=True)
+    assert out[0] == out[1] == {"lang_gt/train_sr": 0.5, "val_act/a": 2.0, "val_kl/k": 3.0}
+    from hulc_amd import parallel
+    assert parallel.mean_metrics({"a": 3.0}, {"a": 2}) == {"a": 1.5}          # world 1: no collective

@@ -191,3 +191,23 @@ def test_bench_multi_gpu_code_path_rehearsal_on_one_gpu(extra):
     assert sum(b["bytes"] for b in tl["buckets"]) == sum(ar["bucket_bytes"])
     assert tl["buckets"][0]["issued_at_us"] < 0 <= tl["exposed_after_backward_us"]
     assert d["n_gpus"] == 1 and d["roofline"] and d["mfma_groups"] and d["value"] > 0
+
+
+def test_bench_gpus_flag_means_what_it_says():
+    """`--gpus N` is the number of ranks: without a launcher `--gpus 2` re-launches bench.py under torch.distributed.run with two
+    ranks — on a box with fewer GPUs it must FAIL, never print an `n_gpus: 1` line; under a launcher a WORLD_SIZE that disagrees is an error."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--preroll", "1", "--no-cpu-baseline", "--batch", "8"]
+    n = torch.cuda.device_count()
+    r = subprocess.run(base + ["--gpus", str(n + 1)], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and '"metric"' not in r.stdout, r.stdout[-2000:]
+    assert "GPU(s) are visible" in r.stderr
+    r = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and '"metric"' not in r.stdout and "WORLD_SIZE=1" in r.stderr
+    if n >= 2:              # the self-launch itself, wherever two GPUs exist
+        import json
+        r = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{"metric"')][-1])
+        assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"

@@ -446,3 +446,88 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
     b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
     assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999
+
+
+def _np_to_dev(mb):
+    out = {}
+    for k, v in mb.items():
+        if k == "use_for_aux":
+            out["aux_rows"] = np.nonzero(v)[0].astype(np.int32)
+        else:
+            out[k] = torch.from_numpy(v.astype(np.int32) if k == "plan_idx" else v).cuda()
+    return out
+
+
+def _per_tensor_table(tag, Gg, G, gate):
+    from golden_util import rel_l2
+    errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    top = sorted(((e, n) for n, e in errs.items()), reverse=True)
+    print(f"[{tag}] per-tensor gradient rel-L2 vs the rounding-aware oracle: median {np.median([e for e, _ in top]):.2e}, worst:",
+          [(round(e, 4), n) for e, n in top[:10]])
+    assert top[0][0] < gate, top[:6]
+    a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
+    b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
+    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999
+    return top
+
+
+@pytest.mark.parametrize("rnn_type", ["rnn", "gru"])
+def test_mcil_benchmark_shape_against_the_rounding_aware_oracle(rnn_type):
+    """BASELINE config 4's shape (model=mcil, BiRNN and BiGRU plan encoder, B = 64, S = 32, bf16) against the ORACLE — not the sibling
+    engine: this is the size at which the 16-bit engine runs the kernels that only exist at M > 32 rows (both directions of layer 0 as ONE dual
+    persistent recurrence, the paired-direction `gru_step_lds_kernel`, the GRU gate backward fused into the K-chunked carry GEMM).  The oracle
+    rounds the plan encoder's operands and stored tensors where the engine does (oracle.birnn_* / bigru_*: `q` / `qg`), the N(0,1) draw is
+    injected.  Gates as for the HULC shapes: loss 5e-4, emb 2e-3, every gradient tensor 5e-2."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import rel_l2
+    import oracle_pool
+    case = dict(seed=29, kind="mcil", rnn_type=rnn_type, max_window=32, B=64, S=32, mode="bf16", gscale=1.0)
+    dims = oracle_pool.case_dims(case)
+    mb = oracle_pool.case_batch(case)["vis"]
+    eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3, num_classes=dims.mix_classes)
+    eng.load_numpy(spec.init_all(dims, seed=29, ln_jitter=True))
+    l, _ = _step(eng, _np_to_dev(mb))
+    assert eng.get_option("persistent_rnn") == 1                   # the benchmark's kernels, not a fallback
+    Gg = {n: t.detach().cpu().numpy() for n, t in eng.views(eng.flat_grads).items()}
+    emb = eng.get_tensor("emb", 64 * 32 * 128).reshape(64, 32, 128)
+    eng.close()
+    torch.cuda.empty_cache()
+    G, losses, embs = oracle_pool.oracle_case(case)
+    lo = losses["vis"]
+    print(f"[mcil {rnn_type} B=64 S=32 bf16] loss {l['total_mod']:.6f} vs oracle {lo['total']:.6f}; kl {l['kl']:.3e} vs {lo['kl']:.3e}; emb {rel_l2(emb, embs['vis']):.1e}")
+    assert abs(l["total_mod"] - lo["total"]) <= 5e-4 * abs(lo["total"]), (l, lo)
+    assert abs(l["kl"] - lo["kl"]) <= 2e-3 * abs(lo["kl"]) + 1e-7, (l, lo)
+    assert rel_l2(emb, embs["vis"]) < 2e-3
+    _per_tensor_table(f"mcil {rnn_type} B=64 S=32 bf16", Gg, G, 5e-2)
+
+
+def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle():
+    """BASELINE config 3 (32 vis + 32 lang windows per GPU, CLIP auxiliary loss, S = 32, bf16) through hulc_forward_loss_pair — the
+    ONE pass over 64 windows the bench and Hulc.training_step run — against the oracle's two modality passes: vis in chunks of 4 windows, the
+    language modality in one piece (its contrastive loss couples all 32 rows), weights 1/2, 1/2 and beta = 3 (hulc.py:433-537)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import rel_l2
+    import oracle_pool
+    case = dict(seed=31, kind="hulc", max_window=32, B=32, B_lang=32, S=32, use_clip=True, mode="bf16", gscale=1.0)
+    dims = oracle_pool.case_dims(case)
+    batch = oracle_pool.case_batch(case)
+    eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3)
+    eng.load_numpy(spec.init_all(dims, seed=31, ln_jitter=True))
+    eng.zero_grads()
+    lv, ll = eng.forward_loss_pair(_np_to_dev(batch["vis"]), _np_to_dev(batch["lang"]), 0.5, 3.0, step=0)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert eng.get_option("persistent_rnn") == 1
+    Gg = {n: t.detach().cpu().numpy() for n, t in eng.views(eng.flat_grads).items()}
+    eng.close()
+    torch.cuda.empty_cache()
+    G, losses, _ = oracle_pool.oracle_case(case)
+    print(f"[vis+lang+CLIP 32+32 S=32 bf16] vis {lv} / oracle {losses['vis']}; lang {ll} / oracle {losses['lang']}")
+    for got, sc in ((lv, "vis"), (ll, "lang")):
+        # hulc_forward_loss_pair reports total_mod = kl + action of the modality
+        assert abs(got["total_mod"] - (losses[sc]["kl"] + losses[sc]["action"])) <= 5e-4 * abs(losses[sc]["total"]), (sc, got, losses[sc])
+        assert abs(got["kl"] - losses[sc]["kl"]) <= 2e-3 * abs(losses[sc]["kl"]) + 1e-7, (sc, got, losses[sc])
+    assert abs(ll["clip"] - losses["lang"]["clip"]) <= 2e-3 * abs(losses["lang"]["clip"]), (ll, losses["lang"])
+    _per_tensor_table("vis+lang+CLIP 32+32 S=32 bf16", Gg, G, 5e-2)

@@ -46,7 +46,11 @@ def test_schedules_match_transformers(kind, kw):
     opt = H.FusedAdam(_FakeModule(), lr=lr)
     sched = {"constant": H.ConstantSchedule, "linear": H.LinearWarmupSchedule, "cosine": H.CosineWarmupSchedule}[kind](opt, **kw)
     got = _traj(sched, opt, 60)
-    assert np.allclose(got, np.array(want), rtol=1e-12, atol=0), (got[:10], want[:10])
+    # exact up to num_training_steps; past the end the cosine factor here stays at its final value (transformers' lambda climbs the
+    # cosine again once progress > 1, which a mis-inferred run length would turn into a second warm-up)
+    n_end = kw.get("num_training_steps", 60) if kind == "cosine" else 60
+    assert np.allclose(got[:n_end + 1], np.array(want)[:n_end + 1], rtol=1e-12, atol=0), (got[:10], want[:10])
+    assert np.allclose(got[n_end:], got[n_end], rtol=0, atol=1e-18)
     assert got[0] == (0.0 if kw.get("num_warmup_steps", 0) > 0 else lr)        # LambdaLR applies f(0) at construction
     # state round trip (checkpoint resume keeps the position on the curve)
     opt2 = H.FusedAdam(_FakeModule(), lr=lr)
@@ -59,16 +63,42 @@ def test_compute_warmup_and_training_steps_follow_the_reference():
     m = H.Hulc.__new__(H.Hulc)                     # only the host arithmetic is under test: no engine
     tr = types.SimpleNamespace(datamodule=types.SimpleNamespace(steps_per_epoch=50), limit_train_batches=None, world=2, accumulate_grad_batches=1, max_epochs=4, max_steps=-1)
     object.__setattr__(m, "trainer", tr)
-    assert m.num_training_steps == (50 // 2) * 4              # hulc.py:209-211: (dataset_size // (accumulation x devices)) x max_epochs
+    # a datamodule that states its length PER RANK (steps_per_epoch: what every rank's loader yields) is not divided by the devices again
+    assert m.num_training_steps == 50 * 4
     tr.max_steps = 30
     assert m.num_training_steps == 30                         # hulc.py:213-214
     tr.max_steps = -1
     tr.limit_train_batches = 10
-    assert m.num_training_steps == (10 // 2) * 4              # hulc.py:201-202
+    assert m.num_training_steps == 10 * 4                     # hulc.py:201-202
     tr.limit_train_batches = 0.5
-    assert m.num_training_steps == (25 // 2) * 4              # hulc.py:203-205
-    assert m.compute_warmup(-1, 0.1) == (48, 4)               # hulc.py:229-236: fraction of the inferred steps, truncated
+    assert m.num_training_steps == 25 * 4                     # hulc.py:203-205
+    assert m.compute_warmup(-1, 0.1) == (100, 10)             # hulc.py:229-236: fraction of the inferred steps, truncated
     assert m.compute_warmup(200, 25) == (200, 25)
+    # an un-sharded loader (what the reference measures, hulc.py:197-199): (len // (accumulation x devices)) x max_epochs, hulc.py:209-211
+    class _DM:
+        def train_dataloader(self):
+            return {"vis": list(range(50)), "lang": list(range(37))}
+    tr.datamodule, tr.limit_train_batches = _DM(), None
+    assert m.num_training_steps == (50 // 2) * 4
+    tr.limit_train_batches = 0.5
+    assert m.num_training_steps == (25 // 2) * 4
+
+
+def test_trainer_takes_exactly_the_inferred_number_of_optimizer_steps():
+    """Trainer.fit honours limit_train_batches (and rejects accumulate_grad_batches > 1), so the warm-up schedules built from
+    Hulc.num_training_steps end where the run ends; the cosine factor does not rise again past the end."""
+    from hulc_amd.trainer import Trainer
+    with pytest.raises(NotImplementedError):
+        Trainer(accumulate_grad_batches=2)
+    dm = types.SimpleNamespace(steps_per_epoch=50)
+    assert Trainer(limit_train_batches=7)._train_batches(dm) == 7
+    assert Trainer(limit_train_batches=0.5)._train_batches(dm) == 25
+    assert Trainer()._train_batches(dm) == float("inf")
+    opt = H.FusedAdam(_FakeModule(), lr=1.0)
+    sched = H.CosineWarmupSchedule(opt, 2, 10)
+    for _ in range(25):
+        sched.step()
+    assert opt.param_groups[0]["lr"] == 0.0                   # clamped at the end of the curve (transformers' lambda would be back at 1.0 by step 18)
 
 
 @pytest.mark.parametrize("opt_name,sched_name", [("adamw", "cosine_schedule_with_warmup"), ("sgd", "linear_schedule_with_warmup"), ("adam", "constant")])
