@@ -347,7 +347,7 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     else if (mode == 20) ok = launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p);
     else if (mode == 21) ok = launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p);
     else if (mode == 22) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p);
-    else if (mode == 23) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p);
+    else if (mode == 23) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true>(st, p);      // the production form: slot decode in registers (conv_reg.h PKR)
     else if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
     else if (mode == 11) ok = launch_conv_reg_fwd<32, 4, 4, 2>(st, p);
     else if (mode == 12) ok = launch_conv_reg<64, 3, 3, 1, true>(st, p);

@@ -33,6 +33,13 @@ namespace HULC_NS {
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef HULC_CR_STAMPS     // tools/cr_stamps.hip only: shader-clock stamps of a band's phases, every wave of workgroups 0..15 (never defined in the library build)
+__device__ unsigned long long g_cr_stamps[16 * 8 * 32 * 8];      // [workgroup][wave][band iteration][stamp]
+#define CRSTAMP(n) do { if (lane == 0 && blockIdx.x < 16 && crit < 32) g_cr_stamps[((blockIdx.x * 8 + wave) * 32 + crit) * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CRSTAMP(n)
+#endif
+
 template <int CK, int TA, int TB, int SI>
 struct ConvRegCfg {
     static constexpr int CH = CK / 8;                          // 16-byte chunks per pixel
@@ -64,7 +71,14 @@ struct ConvRegCfg {
 //   band buffer: load band -> barrier -> multiply + epilogue -> barrier.  The two workgroups of a CU are independent, so they fall out of
 //   phase: while one waits for its DMA or sits in its epilogue stores, the other one's waves own the matrix pipes (a SIMD hosts one wave of
 //   each) — the overlap the single lockstep workgroup could not produce.  A wave takes twice the tiles per band (half the barriers per tile).
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0>
+//
+// PKR (round 5): the slot -> (staged row, column, chunk) decode of a wave's DMA rounds is the same for every band.  tools/cr_stamps.hip stamps the
+//   phases of a band: a wave that issues a band's ten DMA rounds spends 3 000 - 7 000 cycles there — not waiting for the memory system but in the
+//   ~50 VALU instructions of that decode per round (three reciprocal divisions, clamps, the 64-bit address), with the matrix pipe idle for that wave.
+//   Where the weights leave registers (conv2: 128 / 64 weight registers) or the allocator finds them (conv3 forward at 8 waves), the decode is done
+//   ONCE per launch (pk[]: 10 registers) and a round costs a row clamp and one multiply-add: conv2 forward 143 -> 135 us, conv3 forward 81 -> 77 us,
+//   conv2 data gradient (2 x 4 waves) 147 -> 140 us on 2048 static frames (profiles/r05_conv_reg_forms.txt).  conv3's data gradient spills with it.
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false>
 __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     static_assert(!REV || SI == 1, "the data-gradient forms are stride-1 correlations (per parity class for OS = 2)");
@@ -119,6 +133,11 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     };
     const int rowel = p.IMW * CK;
     const float invVPI = 1.f / (float)(p.IMH + TA - 1);
+    unsigned pk[PKR ? PF : 1];
+    if (PKR) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) pk[k] = slot_src(min(k * NWV + wave, npieces - 1) * 64 + lane);
+    }
     auto dma = [&](int item, int bi) {
         if (p.dbg & 4) return;                                  // timing ablation (tools/time_conv_reg.py): no loads
         const int f = multi ? item * p.FPB : item / p.nbands, b = multi ? 0 : item % p.nbands;
@@ -129,9 +148,13 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             if (k >= nrounds || k * NWV + wave >= npieces) break;     // wave-uniform
-            int q = (k * NWV + wave) * 64 + lane;
-            asm volatile("" : "+v"(q));                             // opaque: keeps the (band-invariant) decode from being hoisted back into ten live registers
-            const unsigned pkk = slot_src(q);
+            unsigned pkk;
+            if (PKR) pkk = pk[k];
+            else {
+                int q = (k * NWV + wave) * 64 + lane;
+                asm volatile("" : "+v"(q));                         // opaque: keeps the (band-invariant) decode from being hoisted back into ten live registers
+                pkk = slot_src(q);
+            }
             const int sr = r0 + (int)((pkk >> 20) & 0x7ffu);        // staged row of the item
             const h16_t* s;
             if (REV) {        // staged row -> (frame of the stack, image row): rows [0, TA-1) of a frame's IMH + TA - 1 are its zero border
@@ -171,9 +194,17 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     }
     const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
     const bool fastmask = REV && p.maskbits && !p.relu;        // the production data-gradient form: 1-bit ReLU mask words, no activation
+#ifdef HULC_CR_STAMPS
+    int crit = -1;
+#endif
     while (item < nitems) {
+#ifdef HULC_CR_STAMPS
+        ++crit;
+#endif
+        CRSTAMP(0);
         __syncthreads();                                        // NBUF 2: every wave's share of this band has landed (each waited for its own DMAs
                                                                 // before arriving) and every wave is done reading the other buffer
+        CRSTAMP(1);
         const int cur = item;
         if (NBUF == 1) dma(cur, 0);                             // one buffer: every wave is done with the previous band -> load this one (the CU's
                                                                 // OTHER workgroup multiplies meanwhile)
@@ -221,6 +252,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         bool pend = NBUF == 2 && item < nitems;
         if (pend && (wave < NWV / 2 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
         bool waited = false;
+        CRSTAMP(2);
 #pragma unroll 1
         for (int t0 = tbeg; t0 < tend; t0 += 2) {
             const bool two = t0 + 1 < tend;                     // uniform
@@ -261,11 +293,13 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
             if (p.dbg & 16) {                                   // ablation: no multiply loop
             } else if (two) mloop(std::true_type{});
             else mloop(std::false_type{});
+            if (t0 + 2 >= tend) CRSTAMP(3);
             if (pend) { dma(item, nb); pend = false; }
             if (NBUF == 2 && t0 + 2 >= tend) {                  // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // multiply loop ago) and the earlier stores are waited for HERE, so that the
                 waited = true;                                  // stores below stay in flight across the barrier
             }
+            if (t0 + 2 >= tend) CRSTAMP(4);
             if ((p.dbg & 8) && acc0[0] != 12345.678f) continue;   // ablation: no epilogue
             // ---- epilogue: lane = (pixel lj, half h) holds channels chw*32 + 16h + [0, 16)
             if (REV && fastmask) {
@@ -337,13 +371,14 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
                 }
             }
         }
+        CRSTAMP(5);
         if (pend) dma(item, nb);
         if (NBUF == 2 && !waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0>
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), WGPC = NWV == 8 ? 1 : 2;      // band buffers per workgroup, workgroups per CU
@@ -389,14 +424,14 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.VPI, p.LP, NBUF, (size_t)p.MB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
     return true;
 }
 template <int CK, int TA, int TB, int SI>
-static inline bool launch_conv_reg_fwd(hipStream_t st, const ConvTileP& p) { return launch_conv_reg<CK, TA, TB, SI, false>(st, p); }
+static inline bool launch_conv_reg_fwd(hipStream_t st, const ConvTileP& p) { return launch_conv_reg<CK, TA, TB, SI, false, 1, 8, 0, true>(st, p); }
 
 }  // namespace HULC_NS

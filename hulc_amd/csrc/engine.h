@@ -302,6 +302,7 @@ struct Engine : IEngine {
         tab_order.assign(tab.begin(), tab.end());
         std::sort(tab_order.begin(), tab_order.end(), [](const std::pair<std::string, Ref>& a, const std::pair<std::string, Ref>& b) { return a.second.off < b.second.off; });
         // data parallelism: the "this step's gradients are garbage" vote rides in an alignment-padding element of the LAST bucket (see skip_vote_put)
+        lazy.clear();
         skip_pad = -1;
         for (const auto& kv : tab_order)
             if (kv.first.compare(0, 19, "perceptual_encoder.") == 0 && kv.second.n % 64 != 0 && kv.second.off + kv.second.n < numel) { skip_pad = kv.second.off + kv.second.n; break; }
@@ -377,6 +378,12 @@ struct Engine : IEngine {
             hulc_set_error("hulc_bind_params: a required parameter name is missing from the table");
             return 1;
         }
+        // the weight gradients every writer of which can STORE (see LazyG): the M = B MLPs and the decoder's 2048^2 recurrent / layer-1 input weights
+        for (int i = 0; i < 5; ++i) lazy_register(pp[i]);
+        for (int i = 0; i < 3; ++i) { lazy_register(vg[i]); lazy_register(lg[i]); }
+        lazy_register(pr_fs); lazy_register(whh0); lazy_register(whh1); lazy_register(wih1);
+        std::sort(lazy.begin(), lazy.end(), [](const LazyG& a, const LazyG& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < lazy.size(); ++i) if (lazy[i].off + lazy[i].n > lazy[i + 1].off) { lazy.clear(); break; }      // overlapping views: no lazy set
         if (blk2desc_dev) { hipFree(blk2desc_dev); blk2desc_dev = nullptr; }
         {
             std::vector<unsigned short> b2d((size_t)std::max(tr_blocks, 1));
@@ -513,9 +520,10 @@ struct Engine : IEngine {
     void lin_wgrad(const T* dY, const T* X, long long ldx, int M, int N, int K, float* dW, long long lddw, float* db, float* db2 = nullptr) {
         if constexpr (std::is_same<T, h16_t>::value) {
             if (M <= 64) {          // one fused launch: tr-read wgrad + bias grad, no transposed copies
-                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64, grads_fresh ? 1 : 0);
+                hipLaunchKernelGGL(lin_bwd_smallm_kernel, dim3(cdiv(N, 64), cdiv(K, 128)), dim3(256), 0, st, dY, (long long)N, X, ldx, M, N, K, dW, lddw, db, db2, 64, grad_first(dW) ? 1 : 0);
                 return;
             }
+            grad_ensure_zero(dW);      // the paths below accumulate
             static const bool fused_largem = HULC_SWITCH("HULC_LINBWD_LARGEM", 0) != 0;   // measured 0.25 ms/step SLOWER than transposes + NT GEMM (A/B, same box): off
             if (fused_largem && (long long)N * K <= 2048ll * 512) {
                 // token-major layers (M = B*S): the same kernel, rows split over blockIdx.z (~256 workgroups), partials by atomics
@@ -643,9 +651,57 @@ struct Engine : IEngine {
     float* dparts = nullptr;                // fused FFN backward: the four hidden-quarter partials of the gradient entering norm1
     bool grads_fresh = false;
     int wacc() const { return grads_fresh ? 0 : 1; }
+    // ---- lazily zeroed weight gradients (round 5, VERDICT r4 #8 ii; 16-bit engines).  hulc_zero_grads used to memset all 188 MB (24.5 us) although the
+    // first backward STORES the large Linear weight gradients (0 + x == x).  Now the tensors whose every writer can store (`lazy`: the M = B MLPs'
+    // weights through lin_wgrad / mlp_bwd, the decoder's recurrent / layer-1 input weights through their 2048^3 GEMMs) are only MARKED stale by
+    // zero_grads and everything else is zeroed by one multi-range launch.  A stale tensor is made valid by whoever touches it first:
+    //   * a store-capable site asks grad_first(dW): stale -> it stores (and the mark is cleared); not stale -> it accumulates as before;
+    //   * an accumulate-only path calls grad_ensure_zero(dW) first;
+    //   * what is still stale when its all-reduce bucket is issued, at the end of the backward, or when the optimizer / a whole-buffer all-reduce
+    //     runs (a tensor the step never touched: language_goal.* in a vision-only step) is zeroed then (lazy_sweep).
+    // So the buffer the caller sees after hulc_backward is exactly what the full memset produced; between hulc_zero_grads and the next backward the
+    // lazy tensors hold the previous step's values (hulc_set_option "lazy_zero_grads" 0 restores the plain memset).
+    struct LazyG { int64_t off, n; bool stale; };
+    std::vector<LazyG> lazy;
+    void lazy_register(const LinW& L) {
+        if (!std::is_same<T, h16_t>::value || !L.dW || (int64_t)L.N * L.K < 65536) return;
+        const int64_t off = L.dW - G, n = ((int64_t)L.N * L.K + 63) / 64 * 64;
+        for (const LazyG& z : lazy) if (z.off == off) return;
+        if (lazy.size() < 30 && off >= 0 && off + n <= numel) lazy.push_back(LazyG{off, n, false});
+    }
+    int lazy_find(const float* dW) const { const int64_t off = dW - G; for (size_t i = 0; i < lazy.size(); ++i) if (lazy[i].off == off) return (int)i; return -1; }
+    // store-capable writer of dW: true = STORE
+    bool grad_first(const float* dW) {
+        const int i = lazy_find(dW);
+        if (i < 0) return grads_fresh;
+        const bool s = lazy[i].stale;
+        lazy[i].stale = false;
+        return s;
+    }
+    void grad_ensure_zero(const float* dW) {
+        const int i = lazy_find(dW);
+        if (i >= 0 && lazy[i].stale) { hipMemsetAsync(G + lazy[i].off, 0, sizeof(float) * lazy[i].n, st); lazy[i].stale = false; }
+    }
+    void lazy_sweep(int64_t lo, int64_t hi, hipStream_t s) {
+        MultiZero mz{}; int k = 0; long long mx = 0;
+        for (LazyG& z : lazy)
+            if (z.stale && z.off >= lo && z.off + z.n <= hi) { mz.p[k] = G + z.off; mz.n[k] = z.n; mx = std::max<long long>(mx, z.n); ++k; z.stale = false; }
+        if (k) hipLaunchKernelGGL(multi_zero_kernel, dim3((unsigned)std::min<long long>(256, cdiv(mx, 4 * 256 * 8)), k), dim3(256), 0, s, mz);
+    }
     int zero_grads() override {
         if (!bound) { hulc_set_error("hulc_zero_grads before hulc_bind_params"); return 1; }
-        HIP_CHECK(hipMemsetAsync(G, 0, numel * sizeof(float), st));
+        if (lazy.empty() || !lazy_zero_mode) {
+            HIP_CHECK(hipMemsetAsync(G, 0, numel * sizeof(float), st));
+            for (LazyG& z : lazy) z.stale = false;
+        } else {
+            // the complement of the lazy tensors, as <= 31 ranges in one launch
+            MultiZero mz{}; int k = 0; long long mx = 0; int64_t cur = 0;
+            auto add = [&](int64_t lo, int64_t hi) { if (hi > lo) { mz.p[k] = G + lo; mz.n[k] = hi - lo; mx = std::max<long long>(mx, hi - lo); ++k; } };
+            for (LazyG& z : lazy) { add(cur, z.off); cur = z.off + z.n; z.stale = true; }
+            add(cur, numel / 4 * 4);
+            if (numel % 4) HIP_CHECK(hipMemsetAsync(G + numel / 4 * 4, 0, sizeof(float) * (numel % 4), st));
+            if (k) hipLaunchKernelGGL(multi_zero_kernel, dim3((unsigned)std::min<long long>(256, cdiv(mx, 4 * 256 * 8)), k), dim3(256), 0, st, mz);
+        }
         grads_fresh = true; bwd_since_opt = false;
         return 0;
     }
@@ -714,8 +770,13 @@ struct Engine : IEngine {
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 7);      // A/B: bit 0 = conv2 forward, bit 1 = conv3 forward, bit 2 = conv3 data gradient on the weights-in-registers kernel (conv_reg.h)
             // HULC_CONV_REG_W4 (same bits): the form with two co-resident 256-thread workgroups per CU (conv_reg.h, NWV = 4)
             static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 11);          // in the step: conv2 fwd 84.0 vs 85.4 us, conv3 fwd 54.7 vs 56.5, conv2 dgrad 79.8 vs 87.9 (launch pairs' average, two-workgroup form first)
-            const bool t2 = ((conv_reg & 1) && ((w4 & 1) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
-            const bool t3 = ((conv_reg & 2) && ((w4 & 2) ? launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p3) : launch_conv_reg_fwd<64, 3, 3, 1>(st, p3))) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
+            // HULC_CONV_REG_PK (round 5, same bits): large maps (the static camera) take the one-workgroup form with the band-invariant DMA slot decode
+            // held in registers (conv_reg.h: PKR) — standalone on 2048 static frames conv2 forward 135 us against 142 (two workgroups) / 143, conv3
+            // forward 77 against 84 / 81; the gripper camera's stacked small maps stay on the two-workgroup form (30.5 against 34.8 us)
+            static const int pkr = HULC_SWITCH("HULC_CONV_REG_PK", 11);
+            const bool big = e.H2 >= 16;
+            const bool t2 = ((conv_reg & 1) && (((w4 & 1) && !(big && (pkr & 1))) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
+            const bool t3 = ((conv_reg & 2) && (((w4 & 2) && !(big && (pkr & 2))) ? launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p3) : launch_conv_reg_fwd<64, 3, 3, 1>(st, p3))) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
             tiled = t2 && t3;
         }
         if (!tiled) {
@@ -915,7 +976,9 @@ struct Engine : IEngine {
             else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);
                 p.zeros = zero_page;
-                ok = ((conv_reg & 8) && maskbits && ((w4 & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p) : launch_conv_reg<64, 2, 2, 1, true, 2>(st, p))) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
+                static const int pkr = HULC_SWITCH("HULC_CONV_REG_PK", 11);       // bit 3: slot decode in registers (no spill at 64 weight registers): 147 -> 140 us standalone
+                ok = ((conv_reg & 8) && maskbits && ((w4 & 8) ? ((pkr & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true>(st, p) : launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p))
+                                                              : launch_conv_reg<64, 2, 2, 1, true, 2>(st, p))) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
             }
             if (ok) return;
         }
@@ -1012,7 +1075,12 @@ struct Engine : IEngine {
             // M <= 64 (every M = B MLP): the data-gradient chain first, every layer's incoming gradient kept in its own buffer, then the weight /
             // bias gradients of ALL layers in one launch (lin_bwd_smallm_batched_kernel) instead of one ~9 us launch per layer
             if (M <= 64 && n <= 8) {
-                LinBwdBatch bt{}; bt.M = M; bt.store = grads_fresh ? 1 : 0;
+                // one store flag for the whole batch: every layer's weight gradient is in the same state (fresh zeros / stale = first write of the step, or
+                // already written = a second backward before the optimizer); a mixed batch (never seen) zeroes its stale tensors and accumulates
+                bool all_first = true;
+                for (int i = 0; i < n; ++i) { const int z = lazy_find(L[i].dW); all_first = all_first && (z >= 0 ? lazy[z].stale : grads_fresh); }
+                for (int i = 0; i < n; ++i) { if (all_first) grad_first(L[i].dW); else grad_ensure_zero(L[i].dW); }
+                LinBwdBatch bt{}; bt.M = M; bt.store = all_first ? 1 : 0;
                 int blk = 0;
                 for (int i = n - 1; i >= 0; --i) {
                     const T* in = i > 0 ? acts[i - 1] : x;
@@ -2176,6 +2244,7 @@ struct Engine : IEngine {
         if (ar_dtype < 0 || (ar_sent >> i) & 1u) return 0;
         const std::vector<Bucket> v = bucket_plan();
         ar_sent |= 1u << i;
+        lazy_sweep(v[i].lo, v[i].hi, st);    // the bucket is final: a lazily zeroed tensor in it that no writer touched becomes zeros before it goes on the wire
         return reduce_range(v[i].lo, v[i].hi, ar_dtype, comm_timing ? i : -1);
     }
     int check_ar_dtype(int dtype, const char* who) {
@@ -2195,6 +2264,7 @@ struct Engine : IEngine {
         if (check_ar_dtype(dtype, "hulc_allreduce_grads")) return 1;
         if (!bound) { hulc_set_error("hulc_allreduce_grads before hulc_bind_params"); return 1; }
         if (bwd_stage != 0) { hulc_set_error("hulc_allreduce_grads: encoder part of the backward still pending"); return 1; }
+        lazy_sweep(0, numel, st);
         if (reduce_range(0, numel, dtype)) return 1;
         comm->gate_to(st);
         return 0;
@@ -2297,10 +2367,10 @@ struct Engine : IEngine {
                 const int mp = ldpad(SB);
                 constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // 16-bit engines: the dZ transpose adds its column sums (= both bias gradients) on the way
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp, fuse_cs ? dbih1 : nullptr, fuse_cs ? dbhh1 : nullptr);
-                if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = wacc();
+                if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = grad_first(whh1.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
-                { EpiP ep = epi(wih1.dW, true); ep.accumulate = wacc(); gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
+                { EpiP ep = epi(wih1.dW, true); ep.accumulate = grad_first(wih1.dW) ? 0 : 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
                 if (!fuse_cs) colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
             }
             { EpiP ep = epi(dH0, false); ep.out2 = dZ0 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H0 + lastBH;
@@ -2311,7 +2381,7 @@ struct Engine : IEngine {
                 const int mp = ldpad(SB);
                 // the column sums of dZ0 over all (t, b) rows = those of dC = sum_t dZ0: both bias gradients of layer 0 ride on this transpose too
                 transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp, std::is_same<T, h16_t>::value ? dbih0 : nullptr, std::is_same<T, h16_t>::value ? dbhh0 : nullptr);
-                if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = wacc();
+                if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = grad_first(whh0.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
                 { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
@@ -2488,6 +2558,7 @@ struct Engine : IEngine {
         }
         if (bucket_ready(3)) return 1;       // visual_goal.*, language_goal.* final
         if (part == 0) {
+            lazy_sweep(0, numel, st);        // every lazy tensor is final here (none belongs to the encoders): what no writer touched is zeroed now
             if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
             bwd_stage = 1;
             return 0;
@@ -2505,6 +2576,7 @@ struct Engine : IEngine {
             STAGE("enc_gripper_bwd");
         }
         if (bucket_ready(4)) return 1;       // perceptual_encoder.* final
+        lazy_sweep(0, numel, st);
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in backward"); return 1; }
         have_fwd = false;
         bwd_stage = 0;
@@ -2553,6 +2625,7 @@ struct Engine : IEngine {
     int optim(const hulc_optim& o) override {
         if (!bound) { hulc_set_error("hulc_optimizer_step before hulc_bind_params"); return 1; }
         persist_check("hulc_optimizer_step", false);
+        lazy_sweep(0, numel, st);            // an optimizer step without a backward behind hulc_zero_grads: the lazily zeroed tensors become zeros now
         bwd_since_opt = false;
         const unsigned tag = ++opt_seq;
         if (o.kind != HULC_OPT_ADAM && o.kind != HULC_OPT_ADAMW && o.kind != HULC_OPT_SGD) { hulc_set_error("hulc_optimizer_step: unknown optimizer kind %d", (int)o.kind); return 1; }

@@ -76,7 +76,9 @@ struct IEngine {
     // kernels hold CUs; a persistent launch needs all of them); 1 = keep them persistent.  "comm_timing": 1 = hulc_backward_allreduce records events around
     // every bucket's collective and at the end of the backward (hulc_comm_timeline).  "debug_poison_partials": tests only — fills the weight-gradient
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0;
+    // "lazy_zero_grads": 1 (default; 16-bit engines) = hulc_zero_grads only marks the large store-first weight gradients stale instead of zeroing them
+    // (engine.h: LazyG); 0 = the plain memset of the whole buffer.
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
     int set_option(const char* name, long long value) {
@@ -85,6 +87,7 @@ struct IEngine {
         if (name && !strcmp(name, "persist_under_comm")) { persist_under_comm = value != 0; return 0; }
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
+        if (name && !strcmp(name, "lazy_zero_grads")) { lazy_zero_mode = value != 0; return 0; }
         // "dp_skip_vote": for a gradient all-reduce done OUTSIDE the library (the torch.distributed fallback): 1 right before the collective that covers the
         // perceptual-encoder gradients, 2 right after it — the job-wide "a recurrence of this step failed on some rank" vote (engine.h skip_vote_put)
         if (name && !strcmp(name, "dp_skip_vote")) { dp_skip_vote((int)value); return 0; }

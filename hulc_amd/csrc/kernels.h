@@ -1945,6 +1945,16 @@ __global__ void __launch_bounds__(256) sum_reduce_kernel(const float* __restrict
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// up to 32 ranges of a float buffer zeroed in ONE launch (engine.h zero_grads: everything but the lazily stored weight gradients); 16-byte stores,
+// ranges are 64-element aligned (spec.layout pads every tensor).  blockIdx.y = range
+struct MultiZero { float* p[32]; long long n[32]; };
+__global__ void __launch_bounds__(256) multi_zero_kernel(MultiZero mz) {
+    float4* __restrict__ d = reinterpret_cast<float4*>(mz.p[blockIdx.y]);
+    const long long n4 = mz.n[blockIdx.y] >> 2;
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) d[i] = z;
+}
+
 // up to 8 small device-to-device copies in ONE launch (the paired pass joins the two modalities' actions / robot_obs / injected draws: six
 // hipMemcpyAsync of a few KB cost ~5 us each on the engine's stream); 4-byte words, blockIdx.y = segment
 struct MultiCopy { const unsigned* src[8]; unsigned* dst[8]; int words[8]; };

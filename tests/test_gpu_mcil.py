@@ -156,7 +156,7 @@ def test_mcil_fit_loop_descends_validates_and_checkpoints(tmp_path, rnn_type):
     frame = lambda t: dict(rgb_obs=dict(rgb_static=vis["rgb_obs"]["rgb_static"][:1, t:t + 1], rgb_gripper=vis["rgb_obs"]["rgb_gripper"][:1, t:t + 1]),
                            robot_obs_raw=vis["state_info"]["robot_obs"][0, t])
     a = model.step(frame(0), frame(7))
-    assert tuple(a.shape) == (1, 1, 7) and torch.isfinite(a).all() and tuple(model.plan.shape) == (256,)
+    assert tuple(a.shape) == (1, 1, 7) and torch.isfinite(a).all() and tuple(model.plan.shape) == (1, 256)      # the VALUE get_pp_plan_vision returns (hulc.py:905-927): batch of one
     model.engine.close()
 
 

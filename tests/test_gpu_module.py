@@ -153,6 +153,58 @@ def test_module_validation_step_and_rollout_match_reference():
             assert np.abs(a.numpy()[0, 0] - rfx[f"actions_{mode}"][0, t]).max() <= 2e-3, (mode, t)
 
 
+def test_public_inference_methods_drive_a_rollout_like_the_reference_callers():
+    """hulc.py:881-957 as hulc/evaluation/rollouts_interactive.py:158-164 uses them: get_pp_plan_lang / get_pp_plan_vision return
+    (sampled_plan, latent_goal) as VALUES, predict_with_plan(obs, latent_goal, plan) acts on the values it is handed — the reference rollout
+    fixture is reproduced by calling the three methods directly, and a plan / goal installed in between is really the one used."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load_rollout_case
+    from hulc_amd.hulc import Hulc
+    dims, P, frames, nsteps, replan_freq, rfx = load_rollout_case()
+    m = Hulc(precision="fp32", max_batch_size=2, max_seq_len=4, use_clip_auxiliary_loss=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m.eval()
+    obs_at = lambda mb, t: dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, t:t + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, t:t + 1])),
+                                depth_obs={}, robot_obs=torch.zeros(1, 1, 8), robot_obs_raw=torch.from_numpy(mb["robot_obs"][:, t:t + 1]))
+    for mode in ("vis", "lang"):
+        mb = frames[mode]
+        m.reset()
+        plan = goal = None
+        for t in range(nsteps):
+            obs = obs_at(mb, t)
+            nz = dict(plan_idx=rfx[f"plan_idx_{mode}"][t][0], u_mix=rfx[f"u_mix_{mode}"][t][0, 0], u_act=rfx[f"u_act_{mode}"][t][0, 0])
+            if t % replan_freq == 0:
+                if mode == "lang":
+                    plan, goal = m.get_pp_plan_lang(obs, torch.from_numpy(frames["lang"]["lang"][0]), nz)
+                else:
+                    g = dict(rgb_obs=dict(rgb_static=torch.from_numpy(mb["rgb_static"][:, nsteps:nsteps + 1]), rgb_gripper=torch.from_numpy(mb["rgb_gripper"][:, nsteps:nsteps + 1])), depth_obs={})
+                    plan, goal = m.get_pp_plan_vision(obs, g, nz)
+                assert plan.shape == (1, 1024) and goal.shape == (1, 32)
+                assert np.array_equal(plan.reshape(32, 32).argmax(-1).cpu().numpy(), np.asarray(nz["plan_idx"]).reshape(-1))
+                assert float(plan.sum()) == 32.0                                  # one-hot per category (distributions.py:37-41)
+            a = m.predict_with_plan(obs, goal, plan, nz)
+            assert a.shape == (1, 1, 7)
+            assert np.abs(a.numpy()[0, 0] - rfx[f"actions_{mode}"][0, t]).max() <= 2e-3, (mode, t)
+    # the values handed to predict_with_plan are the ones used: another plan / goal changes the action, handing the original back restores it
+    # (same decoder state: reset + replan in between)
+    mb = frames["lang"]
+    obs0 = obs_at(mb, 0)
+    nz = dict(plan_idx=rfx["plan_idx_lang"][0][0], u_mix=rfx["u_mix_lang"][0][0, 0], u_act=rfx["u_act_lang"][0][0, 0])
+    acts = []
+    for variant in range(3):
+        m.reset()
+        plan, goal = m.get_pp_plan_lang(obs0, torch.from_numpy(frames["lang"]["lang"][0]), nz)
+        if variant == 1:
+            plan = torch.roll(plan.reshape(32, 32), 1, dims=1).reshape(1, -1)
+            goal = -goal
+        acts.append(m.predict_with_plan(obs0, goal, plan, nz).numpy())
+    assert np.array_equal(acts[0], acts[2]) and np.abs(acts[0] - acts[1]).max() > 1e-4
+    assert np.abs(acts[0][0, 0] - rfx["actions_lang"][0, 0]).max() <= 2e-3
+    # epoch hooks of the surface (hulc.py:959-978) exist and log on rank zero
+    m.on_train_epoch_start(); m.on_train_epoch_end(); m.on_validation_epoch_end()
+
+
 def test_gcbc_module_rollout_matches_reference():
     """GCBC.reset / step through the module and the C-ABI (hulc_rollout_plan encodes only the goal for HULC_KIND_GCBC) against the
     reference fixture — including the hidden state that the reference's GCBC keeps across reset() (gcbc.py:281-320)."""
