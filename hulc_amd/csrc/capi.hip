@@ -312,6 +312,11 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
         hipMemsetAsync(ctr, 0, 256, st);
         p.work_ctr = ctr;
     }
+    {   // conv_reg.h pipelined-epilogue forms (modes 28 / 29 and what falls back from them): a scratch page for the stores of pixels that must not be written
+        static void* dp = nullptr;
+        if (!dp && hipMalloc(&dp, 8192) != hipSuccess) { hulc_set_error("hulc_k_conv_tile: hipMalloc failed"); return 1; }
+        p.dump = (h16_t*)dp;
+    }
     bool ok = false;
     // modes 10 / 11 / 17: modes 0 / 1 / 7 on the weights-in-registers kernels (conv_reg.h); 12 / 18: modes 2 / 8 (conv3 data gradient, 16-bit mask / bitmask)
     if (mode == 17) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 11; }
@@ -345,9 +350,9 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
     else if (mode == 32) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4, 2>(st, p);
     else if (mode == 33) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4, 2>(st, p);
     else if (mode == 20) ok = launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p);
-    else if (mode == 21) ok = launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p);
-    else if (mode == 22) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p);
-    else if (mode == 23) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true>(st, p);      // the production form: slot decode in registers (conv_reg.h PKR)
+    else if (mode == 21) ok = launch_conv_reg<32, 4, 4, 2, false, 1, 4, 0, true>(st, p);      // the production form for small maps: slot decode in registers (conv_reg.h PKR)
+    else if (mode == 22) ok = launch_conv_reg<64, 3, 3, 1, true, 1, 4, 0, true, 1>(st, p);    // the production forms: PKR + pipelined epilogue (EPI; 16-bit mask values
+    else if (mode == 23) ok = launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true, 1>(st, p);    // = modes 22 / 23 fall back to the pair form inside launch_conv_reg)
     else if (mode == 10) ok = launch_conv_reg_fwd<64, 3, 3, 1>(st, p);
     else if (mode == 11) ok = launch_conv_reg_fwd<32, 4, 4, 2>(st, p);
     else if (mode == 12) ok = launch_conv_reg<64, 3, 3, 1, true>(st, p);

@@ -78,7 +78,17 @@ struct ConvRegCfg {
 //   Where the weights leave registers (conv2: 128 / 64 weight registers) or the allocator finds them (conv3 forward at 8 waves), the decode is done
 //   ONCE per launch (pk[]: 10 registers) and a round costs a row clamp and one multiply-add: conv2 forward 143 -> 135 us, conv3 forward 81 -> 77 us,
 //   conv2 data gradient (2 x 4 waves) 147 -> 140 us on 2048 static frames (profiles/r05_conv_reg_forms.txt).  conv3's data gradient spills with it.
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false>
+//
+// EPI (round 5): the epilogue of a tile rides in the multiply loop of the NEXT tile.  Until now a wave alternated [multiply loop of a tile pair]
+//   [epilogue of the pair: ~110 VALU + 4 - 6 stores] and, with the band barrier putting the waves in lockstep, the epilogues of all eight waves fell
+//   together — the matrix pipes idle, 10 - 17 % of a band (tools/cr_stamps.hip).  Now a wave walks its tiles ONE at a time with two accumulators in
+//   hand: while the 16 / 32 / 36 MFMAs of tile n accumulate (even / odd k-steps into two accumulators), the 16 values of tile n-1 (a third one) are
+//   biased / masked / packed two at a time between the k-steps and stored when a 16-byte word group is complete — no epilogue phase, 48 accumulator
+//   registers instead of 32 but one fragment ring instead of two, the stores spread over the loop instead of a burst behind it.  The code
+//   between the k-steps is branch-free (a wave-uniform branch would split the scheduling region): a pixel that must not be stored (pitch padding,
+//   rows beyond the band, "no previous tile") goes to a 4 KB dump page (p.dump).  Production forms only (forward + ReLU, data gradient with ReLU bit
+//   words); p.dump == nullptr or the test-only epilogues select the round-4 pair form below.
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0>
 __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     static_assert(!REV || SI == 1, "the data-gradient forms are stride-1 correlations (per parity class for OS = 2)");
@@ -194,6 +204,16 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     }
     const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
     const bool fastmask = REV && p.maskbits && !p.relu;        // the production data-gradient form: 1-bit ReLU mask words, no activation
+    // EPI: the tile whose epilogue is pending (accP), its output pixel (-1: none -> dump page) and ReLU bit word
+    f32x16 accP;
+    int popx = -1; unsigned pmw = 0xffffffffu;
+    if (EPI) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accP[r] = 0.f;
+    }
+    if (EPI && !REV) __syncthreads();                           // bias[] in LDS is complete (the drains read it)
+    auto biasE = [&](int c) -> float { return *(const __attribute__((address_space(3))) float*)(bl + (chw * 32 + 16 * h + c) * 4); };
+    h16_t* const dumpp = EPI ? p.dump + lane * 16 : nullptr;     // 32 bytes per lane
 #ifdef HULC_CR_STAMPS
     int crit = -1;
 #endif
@@ -252,9 +272,93 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         bool pend = NBUF == 2 && item < nitems;
         if (pend && (wave < NWV / 2 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
         bool waited = false;
-        CRSTAMP(2);
+        // output pixel of ONE tile (EPI form)
+        auto pix1 = [&](int t, int (&opx)[2]) __attribute__((always_inline)) {
+            const int pi = t * 32 + lj;
+            const int ri = fast_div(pi, invPLC), j = pi - ri * PLC;
+            const int ocol = j * OS + pw;
+            bool ok = pi < npi && ocol < p.OUTW;
+            int o;
+            if (multi) {
+                const int ff = fast_div(ri, invVPO), rr = ri - ff * p.VPO, orow = rr * OS + ph;
+                ok = ok && orow < p.OUTH && f + ff < p.Nf;
+                o = ((f + ff) * p.OUTH + orow) * p.OUTW + ocol;
+            } else {
+                const int orow = (i0 + ri) * OS + ph;
+                ok = ok && orow < p.OUTH;
+                o = (f * p.OUTH + orow) * p.OUTW + ocol;
+            }
+            opx[0] = ok ? o : -1; opx[1] = -1;
+        };
+
+        if (EPI) {
+            // one step = tile t multiplied while the pending tile (accP) drains.  EPI == 2: the k-steps alternate between TWO accumulators (even / odd
+            // steps, summed at the end; consecutive MFMAs on one accumulator with instructions between them are listed at ~43 cycles each in
+            // MI355X_MICROARCH.md) — measured no better than one accumulator here (the second wave of the SIMD fills the gaps) and 16 registers dearer
+            auto do_tile = [&](int t) __attribute__((always_inline)) {
+                const int pi = t * 32 + lj;
+                int opx1[2]; pix1(t, opx1);
+                unsigned mw = 0xffffffffu;
+                if (REV) mw = *(const __attribute__((address_space(3))) unsigned*)(mlb + ((max(opx1[0], mbase) - mbase) * WPP + chw) * 4);      // (a pixel without output reads word 0: never used)
+                lds_char* const x0 = xb + min(pi, last) * C::XS + h * 16;
+                // the pending tile: output pointer (dump page if nothing is to be stored) and the mask half of this lane
+                h16_t* const optr = popx >= 0 ? p.out + (long long)popx * CN + chw * 32 + 16 * h : dumpp;
+                unsigned* const bptr = (!REV && p.bits_out && popx >= 0 && h == 0) ? p.bits_out + (long long)popx * 2 + chw : reinterpret_cast<unsigned*>(dumpp);
+                const int mwh = (int)(pmw >> (16 * h));
+                u32x4_t o = u32x4_t{0u, 0u, 0u, 0u};
+                unsigned obits = 0;
+                f32x16 c0, c1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+                h16x8_t xa[3];
+                auto ld = [&](int s_, int slot) { xa[slot] = *(__attribute__((address_space(3))) h16x8_t*)(x0 + toff[s_ / C::KS] + (s_ % C::KS) * 32); };
+                ld(0, 0);
+                if (C::NS > 1) ld(1, 1);
+#pragma unroll
+                for (int s_ = 0; s_ < C::NS; ++s_) {
+                    if (s_ + 2 < C::NS) ld(s_ + 2, (s_ + 2) % 3);
+                    if (EPI == 2 && (s_ & 1)) c1 = MFMA_32x32x16_H(wf[s_], xa[s_ % 3], c1, 0, 0, 0);
+                    else c0 = MFMA_32x32x16_H(wf[s_], xa[s_ % 3], c0, 0, 0, 0);
+                    const int e = (s_ * 8 + C::NS - 1) / C::NS;   // slice e of the pending tile (values 2e, 2e+1) rides behind step floor(e NS / 8)
+                    if (e < 8 && (e * C::NS) / 8 == s_) {
+                        float v0 = accP[2 * e], v1 = accP[2 * e + 1];
+                        if (REV) {
+                            v0 = __int_as_float(__float_as_int(v0) & __builtin_amdgcn_sbfe(mwh, 2 * e, 1));
+                            v1 = __int_as_float(__float_as_int(v1) & __builtin_amdgcn_sbfe(mwh, 2 * e + 1, 1));
+                        } else {                                    // the two bias values come from LDS (16 registers of bias next to 144 of weights spilled)
+                            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                            const f32x2_ b2 = *(const __attribute__((address_space(3))) f32x2_*)(bl + (chw * 32 + 16 * h + 2 * e) * 4);
+                            v0 = fmaxf(v0 + b2[0], 0.f); v1 = fmaxf(v1 + b2[1], 0.f);
+                        }
+                        const unsigned w = pack2h(v0, v1);
+                        o[e & 3] = w;
+                        if (!REV) obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
+                        if ((e & 3) == 3) reinterpret_cast<u32x4_t*>(optr)[e >> 2] = o;
+                        if (!REV && e == 7) {                       // (no bits_out: bptr is the dump page)
+                            unsigned wb = obits << (16 * h);
+                            wb |= __shfl_xor(wb, 32);
+                            *bptr = wb;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accP[r] = EPI == 2 ? c0[r] + c1[r] : c0[r];
+                popx = opx1[0]; pmw = mw;
+            };
+            CRSTAMP(2);
 #pragma unroll 1
-        for (int t0 = tbeg; t0 < tend; t0 += 2) {
+            for (int t = tbeg; t < tend; ++t) do_tile(t);
+            CRSTAMP(3);
+            if (pend) { dma(item, nb); pend = false; }
+            if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next band's pieces (issued at the band's start) and the stores of the drains
+            waited = true;
+            CRSTAMP(4);
+        }
+
+        if (!EPI) CRSTAMP(2);
+#pragma unroll 1
+        for (int t0 = tbeg; !EPI && t0 < tend; t0 += 2) {
             const bool two = t0 + 1 < tend;                     // uniform
             const int pi0 = t0 * 32 + lj, pi1 = pi0 + 32;
             int opx[2]; unsigned mw[2] = {0xffffffffu, 0xffffffffu};
@@ -375,11 +479,44 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         if (pend) dma(item, nb);
         if (NBUF == 2 && !waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (EPI && popx >= 0) {                                     // the last tile of this wave
+        const f32x16& a = accP;
+        const int mwh = (int)(pmw >> (16 * h));
+        u32x4_t o[2];
+        unsigned obits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v0 = a[2 * e], v1 = a[2 * e + 1];
+            if (REV) {
+                v0 = __int_as_float(__float_as_int(v0) & __builtin_amdgcn_sbfe(mwh, 2 * e, 1));
+                v1 = __int_as_float(__float_as_int(v1) & __builtin_amdgcn_sbfe(mwh, 2 * e + 1, 1));
+            } else { v0 = fmaxf(v0 + biasE(2 * e), 0.f); v1 = fmaxf(v1 + biasE(2 * e + 1), 0.f); }
+            const unsigned w = pack2h(v0, v1);
+            o[e >> 2][e & 3] = w;
+            if (!REV) obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
+        }
+        u32x4_t* op = reinterpret_cast<u32x4_t*>(p.out + (long long)popx * CN + chw * 32 + 16 * h);
+        op[0] = o[0]; op[1] = o[1];
+    }
+    if (EPI && !REV && p.bits_out) {                            // the mask word of that tile (both halves of the wave take part in the shuffle)
+        unsigned obits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v0 = fmaxf(accP[2 * e] + biasE(2 * e), 0.f), v1 = fmaxf(accP[2 * e + 1] + biasE(2 * e + 1), 0.f);
+            const unsigned w = pack2h(v0, v1);
+            obits |= (((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u)) << (2 * e);
+        }
+        unsigned wb = obits << (16 * h);
+        wb |= __shfl_xor(wb, 32);
+        if (popx >= 0 && h == 0) p.bits_out[(long long)popx * 2 + chw] = wb;
+    }
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false>
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
+    if (EPI && (!p.dump || (REV && (!p.maskbits || p.relu || p.mask))))       // the pipelined epilogue covers the production forms only
+        return launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, 0>(st, p);
     using C = ConvRegCfg<CK, TA, TB, SI>;
     constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), WGPC = NWV == 8 ? 1 : 2;      // band buffers per workgroup, workgroups per CU
     if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
@@ -424,11 +561,11 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.VPI, p.LP, NBUF, (size_t)p.MB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
     return true;
 }
 template <int CK, int TA, int TB, int SI>

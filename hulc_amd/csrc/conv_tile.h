@@ -42,6 +42,8 @@ struct ConvTileP {
     int VPI, VPO;            // rows per frame of the stacked band in window-row space (VPI) and in class-output-row space (VPO)
     int MB;                  // conv_reg.h (data-gradient form): bytes of one LDS region holding a band's ReLU bit words
     const h16_t* zeros;      // conv_reg.h data-gradient form: >= 16 zero bytes in device memory (source of the staged zero border)
+    h16_t* dump;             // conv_reg.h pipelined-epilogue form (EPI): >= 4 KB of device scratch that receives the stores of pixels which must not be
+                             // written (the code between the k-steps of the multiply loop is branch-free); never read
 };
 
 // ds_read_b128 is serviced in four fixed 16-lane groups, each mixing lanes of two k-chunk groups g (MI355X_MICROARCH.md §LDS):

@@ -649,6 +649,7 @@ struct Engine : IEngine {
         }
     }
     float* dparts = nullptr;                // fused FFN backward: the four hidden-quarter partials of the gradient entering norm1
+    h16_t* dump_page = nullptr;             // conv_reg.h EPI form: scratch that receives the stores of pixels which must not be written
     bool grads_fresh = false;
     int wacc() const { return grads_fresh ? 0 : 1; }
     // ---- lazily zeroed weight gradients (round 5, VERDICT r4 #8 ii; 16-bit engines).  hulc_zero_grads used to memset all 188 MB (24.5 us) although the
@@ -775,7 +776,7 @@ struct Engine : IEngine {
             // forward 77 against 84 / 81; the gripper camera's stacked small maps stay on the two-workgroup form (30.5 against 34.8 us)
             static const int pkr = HULC_SWITCH("HULC_CONV_REG_PK", 11);
             const bool big = e.H2 >= 16;
-            const bool t2 = ((conv_reg & 1) && (((w4 & 1) && !(big && (pkr & 1))) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
+            const bool t2 = ((conv_reg & 1) && (((w4 & 1) && !(big && (pkr & 1))) ? launch_conv_reg<32, 4, 4, 2, false, 1, 4, 0, true>(st, p2) : launch_conv_reg_fwd<32, 4, 4, 2>(st, p2))) || launch_conv_tile<32, 64, 4, 4, 2, 1, false>(st, p2);
             const bool t3 = ((conv_reg & 2) && (((w4 & 2) && !(big && (pkr & 2))) ? launch_conv_reg<64, 3, 3, 1, false, 1, 4>(st, p3) : launch_conv_reg_fwd<64, 3, 3, 1>(st, p3))) || launch_conv_tile<64, 64, 3, 3, 1, 1, false>(st, p3);
             tiled = t2 && t3;
         }
@@ -971,13 +972,22 @@ struct Engine : IEngine {
             if (c.KH == 3 && c.S == 1 && c.I == 64 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);      // zero-initialised by alloc(): the staged zero border of the data-gradient form
                 p.zeros = zero_page;
-                ok = ((conv_reg & 4) && maskbits && ((w4 & 4) ? launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p) : launch_conv_reg<64, 3, 3, 1, true>(st, p))) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
+                // round 5: the pipelined-epilogue form (conv_reg.h EPI: a tile's epilogue rides in the next tile's multiply loop; one tile at a time also ends
+                // the spills of the pair form at 144 weight registers) on two workgroups per CU: 129 -> 97 us standalone on 2048 static frames, 30.6 -> 28.2 gripper
+                static const int epi = HULC_SWITCH("HULC_CONV_REG_EPI", 12);      // bit 2: conv3, bit 3: conv2 data gradient
+                if (!dump_page) dump_page = alloc<h16_t>(4096);
+                p.dump = dump_page;
+                ok = ((conv_reg & 4) && maskbits && ((epi & 4) ? launch_conv_reg<64, 3, 3, 1, true, 1, 4, 0, true, 1>(st, p)
+                                                       : ((w4 & 4) ? launch_conv_reg<64, 3, 3, 1, true, 1, 4>(st, p) : launch_conv_reg<64, 3, 3, 1, true>(st, p)))) || launch_conv_tile<64, 64, 3, 3, 1, 1, true>(st, p);
             }
             else if (c.KH == 4 && c.S == 2 && c.I == 32 && c.O == 64) {
                 if (!zero_page) zero_page = alloc<h16_t>(128);
                 p.zeros = zero_page;
                 static const int pkr = HULC_SWITCH("HULC_CONV_REG_PK", 11);       // bit 3: slot decode in registers (no spill at 64 weight registers): 147 -> 140 us standalone
-                ok = ((conv_reg & 8) && maskbits && ((w4 & 8) ? ((pkr & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true>(st, p) : launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p))
+                static const int epi = HULC_SWITCH("HULC_CONV_REG_EPI", 12);      // bit 3: pipelined epilogue (142 -> 137 us standalone static, 29.7 -> 28.7 gripper)
+                if (!dump_page) dump_page = alloc<h16_t>(4096);
+                p.dump = dump_page;
+                ok = ((conv_reg & 8) && maskbits && ((w4 & 8) ? ((epi & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true, 1>(st, p) : (pkr & 8) ? launch_conv_reg<64, 2, 2, 1, true, 2, 4, 0, true>(st, p) : launch_conv_reg<64, 2, 2, 1, true, 2, 4>(st, p))
                                                               : launch_conv_reg<64, 2, 2, 1, true, 2>(st, p))) || launch_conv_tile<64, 32, 2, 2, 1, 2, true>(st, p);
             }
             if (ok) return;

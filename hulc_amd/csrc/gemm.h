@@ -940,11 +940,14 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
     typedef __attribute__((address_space(3))) char lchar;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;                              // hidden units n0 .. n0+15 of every gate block
-    const int m0 = blockIdx.y * (MT * 16);
+    // gridDim.y == 1 (round 5): ONE workgroup walks all 32-row blocks of its 16 hidden units.  The W_hh fragments — 60 % of the bytes a workgroup pulls
+    // (192 KB of 320) — are loaded ONCE and stay in registers across the blocks, and the launch is one round of 256 workgroups (x 2 directions) instead
+    // of two (512 workgroups of 1024 threads / 128 KB LDS: one per CU at a time).  gridDim.y > 1: one row block per workgroup (M > 64, tests).
+    const int nrb = gridDim.y == 1 ? (M + MT * 16 - 1) / (MT * 16) : 1;
     const int kq = KQ32 * 32, kb = wave * kq;
     const int g = lane >> 4, i = lane & 15;
     lchar* wbase = (lchar*)sk_smem + wave * (MT * 2 * PCW * 1024);
-    {
+    auto dma_rows = [&](int m0) {
         const int r = lane >> 3, c = (lane & 7) ^ (r & 6);
 #pragma unroll
         for (int rg = 0; rg < MT * 2; ++rg) {
@@ -954,7 +957,8 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
                                                  (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
         }
-    }
+    };
+    dma_rows(gridDim.y == 1 ? 0 : blockIdx.y * (MT * 16));
     h16x8_t b[3][KQ32];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
@@ -963,17 +967,22 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
 #pragma unroll
         for (int u = 0; u < KQ32; ++u) b[gate][u] = *reinterpret_cast<const h16x8_t*>(wp + u * wstep);
     }
+    const int ecol = n0 + g * 4;
+    float4 bv[3];
+    if (tid < MT * 64) {
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) bv[gate] = *reinterpret_cast<const float4*>(bhh + gate * H + ecol);
+    }
+#pragma unroll 1
+    for (int rb = 0; rb < nrb; ++rb) {
+    const int m0 = (gridDim.y == 1 ? rb : blockIdx.y) * (MT * 16);
     // epilogue operands of this thread's 4 hidden units (threads < MT*64), fetched under the operand stream
-    const int erow = m0 + (tid >> 6) * 16 + i, ecol = n0 + g * 4;
+    const int erow = m0 + (tid >> 6) * 16 + i;
     const bool ethread = tid < MT * 64 && erow < M;
     uint2 zxv[3] = {uint2{0u, 0u}, uint2{0u, 0u}, uint2{0u, 0u}}, hpv = uint2{0u, 0u};
-    float4 bv[3];
     if (ethread) {
 #pragma unroll
-        for (int gate = 0; gate < 3; ++gate) {
-            zxv[gate] = *reinterpret_cast<const uint2*>(zx + (long long)erow * 3 * H + gate * H + ecol);
-            bv[gate] = *reinterpret_cast<const float4*>(bhh + gate * H + ecol);
-        }
+        for (int gate = 0; gate < 3; ++gate) zxv[gate] = *reinterpret_cast<const uint2*>(zx + (long long)erow * 3 * H + gate * H + ecol);
         hpv = *reinterpret_cast<const uint2*>(A + (long long)erow * lda + ecol);
     }
     f32x4 acc[MT][3];
@@ -1003,9 +1012,9 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) red[((wave * MT + mt) * 3 + gate) * 64 + lane] = acc[mt][gate];
     __syncthreads();
+    f32x4 gs[3];
     if (ethread) {
         const int mt = tid >> 6, l = tid & 63;
-        f32x4 gs[3];
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) {
             f32x4 v = red[((0 * MT + mt) * 3 + gate) * 64 + l];
@@ -1013,6 +1022,12 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
             for (int w = 1; w < NW; ++w) v += red[((w * MT + mt) * 3 + gate) * 64 + l];
             gs[gate] = v;
         }
+    }
+    if (rb + 1 < nrb) {                                   // the partials are read: the next row block's A rows stream in under the gate arithmetic
+        __syncthreads();
+        dma_rows(m0 + MT * 16);
+    }
+    if (ethread) {
         const float* bb[3] = {&bv[0].x, &bv[1].x, &bv[2].x};
         float hn[4], rr[4], zz[4], nn[4], gn[4];
 #pragma unroll
@@ -1034,6 +1049,7 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
         *reinterpret_cast<uint2*>(n_out + o) = uint2{pack2h(nn[0], nn[1]), pack2h(nn[2], nn[3])};
         *reinterpret_cast<uint2*>(gn_out + o) = uint2{pack2h(gn[0], gn[1]), pack2h(gn[2], gn[3])};
     }
+    }
 }
 // returns false when the shape is not covered (the caller then runs the GEMM + gate kernel pair)
 // nprob = 2: q[1] is a second independent recurrence (the other direction of the BiGRU) advanced by the same launch
@@ -1042,7 +1058,8 @@ static inline bool launch_gru_step(hipStream_t st, const GruStepP* q, int nprob,
         if (H != 2048 || M < 1 || ((uintptr_t)q[k].A % 128) != 0 || ((uintptr_t)q[k].W % 16) != 0) return false;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)gru_step_lds_kernel<2, 4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    dim3 grid(H / 16, (M + 31) / 32, nprob);
+    static const int walk = HULC_SWITCH("HULC_GRU_WALK", 0);      // 1: one workgroup walks the row blocks with W_hh loaded once — measured SLOWER in the step (mcil_gru 7.30 -> 7.47, 7.37 -> 7.63 ms: the row blocks of a workgroup serialise, two rounds of workgroups overlap their loads), kept for the record
+    dim3 grid(H / 16, (walk && M <= 128) ? 1 : (M + 31) / 32, nprob);
     // LDS: the A region (16 waves x 2 x 2 x 2 KB = 128 KB) is reused for the 16 x 2 x 3 K-partials (96 KB)
     hipLaunchKernelGGL((gru_step_lds_kernel<2, 4, 16>), grid, dim3(1024), (size_t)16 * 2 * 2 * 2 * 1024, st, q[0], q[nprob - 1], (long long)H, wfrag ? 0ll : (long long)H, M, H);
     return true;

@@ -28,15 +28,15 @@ template <typename T> static T* dev(const std::vector<T>& h) { T* d; hipMalloc(&
 
 struct Case { const char* name; int kind; int IMH, OUTH; };      // kind 0: conv3 fwd, 1: conv2 fwd, 2: conv3 dgrad, 3: conv2 dgrad
 
-template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD>
+template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD, int EPI = 0>
 static float run_form(ConvTileP p, int reps, bool* ok) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    *ok = launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD>(0, p);
+    *ok = launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
     if (!*ok) return 0.f;
-    for (int i = 0; i < 2; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD>(0, p);
+    for (int i = 0; i < 2; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD>(0, p);
+    for (int i = 0; i < reps; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) { *ok = false; }
@@ -58,7 +58,8 @@ static void bench(const char* name, int Nf, int IMH, int OUTH, bool ablate) {
     unsigned *bits = dev(hbits), *bits_out, *bits_ref;
     hipMalloc(&bits_out, hbits.size() * 4 + 512); hipMalloc(&bits_ref, hbits.size() * 4 + 512);
     void* zp; hipMalloc(&zp, 256); hipMemset(zp, 0, 256);
-    ConvTileP p{}; p.img = img; p.IMH = p.IMW = IMH; p.w = w; p.OUTH = p.OUTW = OUTH; p.Nf = Nf;
+    void* dumpb; hipMalloc(&dumpb, 8192);
+    ConvTileP p{}; p.dump = (h16_t*)dumpb; p.img = img; p.IMH = p.IMW = IMH; p.w = w; p.OUTH = p.OUTW = OUTH; p.Nf = Nf;
     if (REV) { p.maskbits = bits; p.zeros = (const h16_t*)zp; p.relu = 0; } else { p.bias = bias; p.relu = 1; if (SI == 2) p.bits_out = bits_ref; }
     bool ok;
     // reference = the production form of round 4 (8 waves, two buffers, old order; conv3 dgrad ran it too)
@@ -98,22 +99,31 @@ static void bench(const char* name, int Nf, int IMH, int OUTH, bool ablate) {
     printf("%-28s Nf=%d  round-4 form (8 waves, 2 buffers) %.1f us   [direct fp64 sample: worst rel %.2e %s]\n", name, Nf, t_ref, worst, worst < 2e-2 ? "ok" : "MISMATCH");
     auto cmp = [&](const char* form, float t) {
         std::vector<h16_t> h(nout); hipMemcpy(h.data(), out, nout * 2, hipMemcpyDeviceToHost);
-        size_t bad = 0; for (size_t i = 0; i < nout; ++i) bad += h[i] != href[i];
+        size_t bad = 0; double worstd = 0;
+        for (size_t i = 0; i < nout; ++i) if (h[i] != href[i]) { ++bad; worstd = std::max(worstd, std::fabs((double)b2f(h[i]) - b2f(href[i])) / (std::fabs((double)b2f(href[i])) + 0.05)); }
         size_t badb = 0;
         if (!REV && SI == 2) {
             std::vector<unsigned> a(hbits.size()), b(hbits.size());
             hipMemcpy(a.data(), bits_out, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), bits_ref, b.size() * 4, hipMemcpyDeviceToHost);
             for (size_t i = 0; i < a.size(); ++i) badb += a[i] != b[i];
         }
-        printf("    %-44s %7.1f us   %s", form, t, bad || badb ? "DIFFERS" : "bit-identical");
-        if (bad || badb) printf(" (%zu values, %zu mask words)", bad, badb);
+        printf("    %-44s %7.1f us   %s", form, t, bad || badb ? (worstd < 1.6e-2 ? "equal to 16-bit rounding" : "DIFFERS") : "bit-identical");
+        if (bad || badb) printf(" (%zu values off by <= %.1e rel, %zu mask words)", bad, worstd, badb);
         printf("\n");
     };
     p.out = out; if (!REV && SI == 2) p.bits_out = bits_out;
-#define FORM(nwv, nbuf, ord, label) do { hipMemset(out, 0xEE, nout * 2); const float t = run_form<CK, TA, TB, SI, REV, OS, nwv, nbuf, ord>(p, 10, &ok); if (ok) cmp(label, t); else printf("    %-44s not launchable\n", label); } while (0)
+#define FORM(nwv, nbuf, ord, label) FORME(nwv, nbuf, ord, 0, label)
+#define FORME(nwv, nbuf, ord, epi, label) do { hipMemset(out, 0xEE, nout * 2); if (!REV && SI == 2) hipMemset(bits_out, 0xEE, hbits.size() * 4); const float t = run_form<CK, TA, TB, SI, REV, OS, nwv, nbuf, ord, epi>(p, 10, &ok); if (ok) cmp(label, t); else printf("    %-44s not launchable\n", label); } while (0)
     FORM(8, 0, true, "8 waves, 2 buffers, slot decode in registers");
     FORM(4, 0, false, "2 x 4 waves, 1 buffer each");
     FORM(4, 0, true, "2 x 4 waves, 1 buffer, slot decode in registers");
+    FORME(8, 0, false, 1, "8 waves, pipelined epilogue (1 accumulator)");
+    FORME(8, 0, true, 1, "8 waves, pipelined epilogue (1) + slot registers");
+    FORME(4, 0, false, 1, "2 x 4 waves, pipelined epilogue (1)");
+    FORME(4, 0, true, 1, "2 x 4 waves, pipelined epilogue (1) + slot registers");
+    FORME(8, 0, true, 2, "8 waves, pipelined epilogue (2 accumulators) + slot registers");
+    FORME(4, 0, false, 2, "2 x 4 waves, pipelined epilogue (2)");
+    FORME(4, 0, true, 2, "2 x 4 waves, pipelined epilogue (2) + slot registers");
     if (ablate) {
         const int flags[] = {0, 4, 8, 16, 12, 20, 24, 2};
         const char* fn[] = {"full", "no-dma", "no-epilogue", "no-mfma", "mfma-only", "epilogue-only", "dma-only", "no-compute"};
