@@ -647,11 +647,13 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
         // true for every wave and also says every wave has finished multiplying stage kt-1, whose buffer the next DMA overwrites
         const int ahead = min(NST - 2, nk - 1 - kt);
         if constexpr (PW == 4) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -704,6 +706,15 @@ static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<h16_t>& a,
         attr_set = true;
     }
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    // round 5 experiment: a FOUR-stage ring (128 KB of LDS, three k-steps of 64 in flight) — same-box A/B in the step: 3.073 / 3.080 / 3.080 ms (3 stages)
+    // against 3.082 / 3.095 / 3.091 (4), mcil_gru 7.27 / 7.33 against 7.39 / 7.37: the operand stream of a tile is NOT latency-bound; stays at 3
+    static const int nst = HULC_SWITCH("HULC_GLDS_NST", 3);
+    if (nst == 4 && nw == 8) {
+        static bool a4 = false;
+        if (!a4) { hipFuncSetAttribute((const void*)gemm_glds_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); a4 = true; }
+        hipLaunchKernelGGL((gemm_glds_kernel<4, 8>), dim3(tiles_m * tiles_n), dim3(512), 128 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
+        return;
+    }
     if (nw == 4) hipLaunchKernelGGL((gemm_glds_kernel<3, 4>), dim3(tiles_m * tiles_n), dim3(256), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
     else hipLaunchKernelGGL((gemm_glds_kernel<3, 8>), dim3(tiles_m * tiles_n), dim3(512), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
 }
