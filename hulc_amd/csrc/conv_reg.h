@@ -88,14 +88,31 @@ struct ConvRegCfg {
 //   between the k-steps is branch-free (a wave-uniform branch would split the scheduling region): a pixel that must not be stored (pitch padding,
 //   rows beyond the band, "no previous tile") goes to a 4 KB dump page (p.dump).  Production forms only (forward + ReLU, data gradient with ReLU bit
 //   words); p.dump == nullptr or the test-only epilogues select the round-4 pair form below.
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0>
+//
+// LDR = 2 (round 5): two of the eight waves are LOADERS.  tools/cr_stamps.hip: a wave that issues its ten LDS-DMA rounds of the next band sits in the
+//   issue of those instructions for 2 700 - 4 200 cycles even with the slot decode in registers — the CU's vector-memory queue is shallow, and a band
+//   (72 - 77 KB) takes ~7 000 cycles to arrive at the ~10 B/clk a CU gets of the HBM stream, so whoever issues the pieces is blocked for about as long as
+//   they take to arrive.  With every wave issuing its share at the start of a band, that blocked time preceded the multiply phase on all of them (the band's
+//   phases ADD).  Now waves 6 and 7 do nothing but request the next band (all its pieces, blocked in issue most of the time, no weights, no tiles) and the
+//   six compute waves (3 pixel parts x 2 channel halves) never touch the load path: no DMA issue, no vmcnt wait — their output stores are never waited
+//   for — one barrier per band.  A band then costs max(arrival of the next band, 4/3 of the old multiply + epilogue time) instead of their sum.
+//   Forms with one output class only (OS == 1); the loaders keep their 40 rounds' slot decode in registers (PKR) — recomputing it per round made THEM
+//   the bottleneck (conv2 forward 185 us).  MEASURED (2048 static frames, profiles/r05_conv_reg_forms.txt): conv2 forward 132 us against 134 - 137 for
+//   the eight-wave form, conv3 forward 93 against 77 (compute-bound: six waves multiply), conv3 data gradient with EPI 107 against 98 for the
+//   two-workgroup EPI form — all forms of conv2's forward converge at ~1.4 x the mixed read / write streaming time of its 500 MB, so the blocked
+//   issue was not the whole story.  Kept selectable, not the production form.
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0, int LDR = 0>
 __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(ConvTileP p) {
     using C = ConvRegCfg<CK, TA, TB, SI>;
     static_assert(!REV || SI == 1, "the data-gradient forms are stride-1 correlations (per parity class for OS = 2)");
     static_assert(OS == 1 || REV, "output parity classes only exist in the data-gradient form");
     static_assert(NWV == 8 || NWV == 4, "8 waves (one workgroup per CU, two band buffers) or 4 (two workgroups per CU, one buffer each)");
     constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), PF = C::PIECES / NWV;      // band buffers of a workgroup (NWV = 4: 1, or 2 with smaller bands)
-    constexpr int NCLS = OS * OS, CN = NCLS == 1 ? 64 : 32, PPARTS = NCLS == 1 ? NWV / 2 : NWV / 4, WPP = CN / 32;
+    static_assert(LDR == 0 || (LDR == 2 && NWV == 8 && OS == 1), "loader waves: 6 compute + 2 loader waves of a 512-thread workgroup, one output class");
+    constexpr int NCW = NWV - LDR;                              // compute waves
+    constexpr int NLD = LDR ? LDR : NWV;                        // waves that issue a band's DMA pieces, and the rounds each of them needs
+    constexpr int PFL = (C::PIECES + NLD - 1) / NLD;
+    constexpr int NCLS = OS * OS, CN = NCLS == 1 ? 64 : 32, PPARTS = NCLS == 1 ? NCW / 2 : NCW / 4, WPP = CN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, lj = lane & 31;
@@ -110,7 +127,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     // ---- weights -> registers (once).  MFMA row i of this wave's A operand carries channel chw*32 + 16*((i>>2)&1) + 4*(i>>3) + (i&3):
     // with the 32x32 C/D map (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) lane half h then owns channels chw*32 + 16h + reg, reg = 0..15
     h16x8_t wf[C::NS];
-    {
+    if (!LDR || wave < NCW) {
         const int chn = chw * 32 + 16 * ((lj >> 2) & 1) + 4 * (lj >> 3) + (lj & 3);
         const h16_t* wr = p.w + ((long long)cls * CN + chn) * C::K + h * 8;
 #pragma unroll
@@ -122,7 +139,8 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     // (image col * CH + chunk)
     const int multi = p.FPB > 1;
     const int nitems = multi ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    const int npieces = (int)(bbytes / 1024), nrounds = (npieces + NWV - 1) / NWV;      // 1 KB pieces of a band; piece k*NWV + wave is this wave's in round k
+    const int lw = LDR ? wave - NCW : wave;                     // index among the issuing waves
+    const int npieces = (int)(bbytes / 1024), nrounds = (npieces + NLD - 1) / NLD;      // 1 KB pieces of a band; piece k*NLD + lw is this wave's in round k
     const float invX = 1.f / (float)C::XSS, invPP = 1.f / (float)plane_px, invPLCd = 1.f / (float)PLC;
     // slot q of a band -> bit 31 = column inside the image, bits 20..30 staged row of the band, bits 0..19 (image col * CH + chunk).  Recomputed per
     // band (a dozen VALU operations per 16-byte piece) rather than kept in registers: the weights need them
@@ -143,10 +161,10 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     };
     const int rowel = p.IMW * CK;
     const float invVPI = 1.f / (float)(p.IMH + TA - 1);
-    unsigned pk[PKR ? PF : 1];
-    if (PKR) {
+    unsigned pk[PKR ? PFL : 1];
+    if (PKR && (!LDR || wave >= NCW)) {                         // LDR: the loader waves hold their 40 rounds' decode in the registers the compute waves give to weights
 #pragma unroll
-        for (int k = 0; k < PF; ++k) pk[k] = slot_src(min(k * NWV + wave, npieces - 1) * 64 + lane);
+        for (int k = 0; k < PFL; ++k) pk[k] = slot_src(min(k * NLD + lw, npieces - 1) * 64 + lane);
     }
     auto dma = [&](int item, int bi) {
         if (p.dbg & 4) return;                                  // timing ablation (tools/time_conv_reg.py): no loads
@@ -154,14 +172,14 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         const int nfr = multi ? min(p.FPB, p.Nf - f) : 1;
         const int r0 = b * p.RB * SI, rmax = nfr * p.IMH - 1;
         const h16_t* src0 = p.img + (long long)f * p.IMH * rowel;
-        lds_char* dst = lbase + bi * bbytes + wave * 1024;
+        lds_char* dst = lbase + bi * bbytes + lw * 1024;
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            if (k >= nrounds || k * NWV + wave >= npieces) break;     // wave-uniform
+        for (int k = 0; k < PFL; ++k) {
+            if (k >= nrounds || k * NLD + lw >= npieces) break;     // wave-uniform
             unsigned pkk;
             if (PKR) pkk = pk[k];
             else {
-                int q = (k * NWV + wave) * 64 + lane;
+                int q = (k * NLD + lw) * 64 + lane;
                 asm volatile("" : "+v"(q));                         // opaque: keeps the (band-invariant) decode from being hoisted back into ten live registers
                 pkk = slot_src(q);
             }
@@ -172,7 +190,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
                 const bool ok = (pkk >> 31) && r >= 0 && r < p.IMH && ff < nfr;
                 s = ok ? src0 + (long long)(ff * p.IMH + r) * rowel + (int)(pkk & 0xfffffu) * 8 : p.zeros;
             } else s = src0 + (long long)min(sr, rmax) * rowel + (int)(pkk & 0xfffffu) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * NWV * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)(dst + k * NLD * 1024), 16, 0, 0);
         }
         if (REV && p.maskbits) {
             // the ReLU bit words of the item's output pixels (whole rows of one frame, or whole stacked frames: contiguous in memory) ride along as
@@ -182,10 +200,10 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
             const int orow0 = multi ? 0 : b * p.RB * OS, nrow = multi ? nfr * p.OUTH : min(p.RB * OS, p.OUTH - orow0);
             const int nwords = nrow * p.OUTW * WPP;
             const unsigned* src = p.maskbits + ((long long)f * p.OUTH + orow0) * p.OUTW * WPP;
-            lds_char* mdst = ml + bi * p.MB + wave * 256;
-            for (int k = 0; (k * NWV + wave) * 64 < nwords; ++k) {      // wave-uniform
-                const int w = min((k * NWV + wave) * 64 + lane, nwords - 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w), (__attribute__((address_space(3))) void*)(mdst + k * NWV * 256), 4, 0, 0);
+            lds_char* mdst = ml + bi * p.MB + lw * 256;
+            for (int k = 0; (k * NLD + lw) * 64 < nwords; ++k) {      // wave-uniform
+                const int w = min((k * NLD + lw) * 64 + lane, nwords - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w), (__attribute__((address_space(3))) void*)(mdst + k * NLD * 256), 4, 0, 0);
             }
         }
     };
@@ -198,9 +216,19 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
     }
     const float invPLC = 1.f / (float)PLC, invVPO = 1.f / (float)max(p.VPO, 1);
     int item = blockIdx.x, nb = 0;
-    if (NBUF == 2) {
+    if (NBUF == 2 && (!LDR || wave >= NCW)) {
         if (item < nitems) dma(item, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (LDR && wave >= NCW) {                                   // ---- a loader wave: request band i+1 while the compute waves multiply band i
+        static_assert(!(LDR && EPI && !REV), "(the forward EPI form has an extra barrier in front of the band loop)");
+        int it = item, b = 0;
+        while (it < nitems) {
+            __syncthreads();                                    // band `it` has landed (this wave waited for its pieces); the compute waves are done with the other buffer
+            it += (int)gridDim.x; b ^= 1;
+            if (it < nitems) { dma(it, b); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        return;
     }
     const int NI0 = (p.OUTH + OS - 1) / OS, NJ0 = (p.OUTW + OS - 1) / OS;      // output rows / columns of the largest class
     const bool fastmask = REV && p.maskbits && !p.relu;        // the production data-gradient form: 1-bit ReLU mask words, no activation
@@ -269,7 +297,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         // NBUF 2: the next band streams in under this band's MFMAs.  Waves 0-3 issue their DMA pieces now; waves 4-7 (the second wave of each
         // SIMD) after their first tile pair when they have two, so that one wave of a SIMD starts multiplying at once while the other
         // spends its ~0.3 us of DMA issue
-        bool pend = NBUF == 2 && item < nitems;
+        bool pend = NBUF == 2 && !LDR && item < nitems;
         if (pend && (wave < NWV / 2 || tend - tbeg <= 2)) { dma(item, nb); pend = false; }
         bool waited = false;
         // output pixel of ONE tile (EPI form)
@@ -351,7 +379,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
             for (int t = tbeg; t < tend; ++t) do_tile(t);
             CRSTAMP(3);
             if (pend) { dma(item, nb); pend = false; }
-            if (NBUF == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next band's pieces (issued at the band's start) and the stores of the drains
+            if (NBUF == 2 && !LDR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next band's pieces (issued at the band's start) and the stores of the drains
             waited = true;
             CRSTAMP(4);
         }
@@ -399,7 +427,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
             else mloop(std::false_type{});
             if (t0 + 2 >= tend) CRSTAMP(3);
             if (pend) { dma(item, nb); pend = false; }
-            if (NBUF == 2 && t0 + 2 >= tend) {                  // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
+            if (NBUF == 2 && !LDR && t0 + 2 >= tend) {          // last pair of this wave in the band: its DMA pieces of the NEXT band (issued a
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // multiply loop ago) and the earlier stores are waited for HERE, so that the
                 waited = true;                                  // stores below stay in flight across the barrier
             }
@@ -477,7 +505,7 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
         }
         CRSTAMP(5);
         if (pend) dma(item, nb);
-        if (NBUF == 2 && !waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBUF == 2 && !LDR && !waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (EPI && popx >= 0) {                                     // the last tile of this wave
         const f32x16& a = accP;
@@ -513,10 +541,10 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
-template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0>
+template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0, int LDR = 0>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     if (EPI && (!p.dump || (REV && (!p.maskbits || p.relu || p.mask))))       // the pipelined epilogue covers the production forms only
-        return launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, 0>(st, p);
+        return launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, 0, LDR>(st, p);
     using C = ConvRegCfg<CK, TA, TB, SI>;
     constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), WGPC = NWV == 8 ? 1 : 2;      // band buffers per workgroup, workgroups per CU
     if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
@@ -546,7 +574,7 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
         for (int fpb = 1; fpb <= 32; ++fpb) {
             const int LR = REV ? fpb * vpo + TA - 1 : fpb * p.IMH, PLR = (LR + SI - 1) / SI, RB = REV ? fpb * vpo : (LR - TA) / SI + 1;
             if (!fits(LR, PLR, fpb * p.OUTH)) break;
-            constexpr int per = 2 * (OS == 1 ? NWV / 2 : NWV / 4);                                                // a wave pass = 2 tiles x the pixel parts
+            constexpr int per = 2 * (OS == 1 ? (NWV - LDR) / 2 : NWV / 4);                                                // a wave pass = 2 tiles x the pixel parts
             const int tiles = (RB * p.LP + 31) / 32, rounds = (tiles + per - 1) / per;
             const int items = (p.Nf + fpb - 1) / fpb, wgs = std::min(items, 256 * WGPC);
             const double c = (double)((items + wgs - 1) / wgs) * (0.35 + rounds);
@@ -561,11 +589,11 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.VPI, p.LP, NBUF, (size_t)p.MB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI, LDR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;
-    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
+    hipLaunchKernelGGL((conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI, LDR>), dim3(items < 256 * WGPC ? items : 256 * WGPC), dim3(NWV * 64), lds, st, p);
     return true;
 }
 template <int CK, int TA, int TB, int SI>

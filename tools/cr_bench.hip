@@ -28,15 +28,15 @@ template <typename T> static T* dev(const std::vector<T>& h) { T* d; hipMalloc(&
 
 struct Case { const char* name; int kind; int IMH, OUTH; };      // kind 0: conv3 fwd, 1: conv2 fwd, 2: conv3 dgrad, 3: conv2 dgrad
 
-template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD, int EPI = 0>
+template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD, int EPI = 0, int LDR = 0>
 static float run_form(ConvTileP p, int reps, bool* ok) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    *ok = launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
+    *ok = launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI, LDR>(0, p);
     if (!*ok) return 0.f;
-    for (int i = 0; i < 2; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
+    for (int i = 0; i < 2; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI, LDR>(0, p);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
+    for (int i = 0; i < reps; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI, LDR>(0, p);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) { *ok = false; }
@@ -113,6 +113,7 @@ static void bench(const char* name, int Nf, int IMH, int OUTH, bool ablate) {
     };
     p.out = out; if (!REV && SI == 2) p.bits_out = bits_out;
 #define FORM(nwv, nbuf, ord, label) FORME(nwv, nbuf, ord, 0, label)
+#define FORML(epi, label) do { if constexpr (OS == 1) { hipMemset(out, 0xEE, nout * 2); if (!REV && SI == 2) hipMemset(bits_out, 0xEE, hbits.size() * 4); const float t = run_form<CK, TA, TB, SI, REV, OS, 8, 0, true, epi, 2>(p, 10, &ok); if (ok) cmp(label, t); else printf("    %-44s not launchable\n", label); } } while (0)
 #define FORME(nwv, nbuf, ord, epi, label) do { hipMemset(out, 0xEE, nout * 2); if (!REV && SI == 2) hipMemset(bits_out, 0xEE, hbits.size() * 4); const float t = run_form<CK, TA, TB, SI, REV, OS, nwv, nbuf, ord, epi>(p, 10, &ok); if (ok) cmp(label, t); else printf("    %-44s not launchable\n", label); } while (0)
     FORM(8, 0, true, "8 waves, 2 buffers, slot decode in registers");
     FORM(4, 0, false, "2 x 4 waves, 1 buffer each");
@@ -121,9 +122,8 @@ static void bench(const char* name, int Nf, int IMH, int OUTH, bool ablate) {
     FORME(8, 0, true, 1, "8 waves, pipelined epilogue (1) + slot registers");
     FORME(4, 0, false, 1, "2 x 4 waves, pipelined epilogue (1)");
     FORME(4, 0, true, 1, "2 x 4 waves, pipelined epilogue (1) + slot registers");
-    FORME(8, 0, true, 2, "8 waves, pipelined epilogue (2 accumulators) + slot registers");
-    FORME(4, 0, false, 2, "2 x 4 waves, pipelined epilogue (2)");
-    FORME(4, 0, true, 2, "2 x 4 waves, pipelined epilogue (2) + slot registers");
+    FORML(0, "6 compute + 2 LOADER waves");
+    if constexpr (REV) FORML(1, "6 compute + 2 LOADER waves, pipelined epilogue");
     if (ablate) {
         const int flags[] = {0, 4, 8, 16, 12, 20, 24, 2};
         const char* fn[] = {"full", "no-dma", "no-epilogue", "no-mfma", "mfma-only", "epilogue-only", "dma-only", "no-compute"};
