@@ -457,8 +457,9 @@ def rnn_fwd(P, pre, x, h0=None):
         zx = q((mm(inp.reshape(B * S, -1), wih.T) + b).reshape(B, S, -1))     # q: the hoisted input projection is stored (16-bit) and added in the step's epilogue
         H = np.zeros((B, S, whh.shape[0]), F32)
         h = np.zeros((B, whh.shape[0]), F32) if h0 is None else h0[l].astype(F32)
+        whhT = q(whh).T                                  # rounded once, not once per time step (q of a 2048 x 2048 matrix is ~30 ms)
         for t in range(S):
-            h = q(relu(zx[:, t] + mm(h, whh.T)).astype(F32))
+            h = q(relu(zx[:, t] + q(h) @ whhT).astype(F32))
             H[:, t] = h
         c[f"H{l}"] = H
         hn.append(h)
@@ -477,10 +478,11 @@ def rnn_bwd(P, G, pre, c, dH1):
         dZ = np.zeros((B, S, Hn), F32)
         carry = np.zeros((B, Hn), F32)
         dout = qg(dout)                                  # dH of the layer is a stored 16-bit tensor (residual operand of the BPTT step)
+        whh_q = q(whh)
         for t in reversed(range(S)):
             dz = qg((dout[:, t] + carry) * (H[:, t] > 0))
             dZ[:, t] = dz
-            carry = dz @ q(whh)
+            carry = dz @ whh_q
         dz2 = dZ.reshape(B * S, Hn)
         Hprev = np.concatenate([np.zeros((B, 1, Hn), F32), H[:, :-1]], 1).reshape(B * S, Hn)
         _acc(G, f"{pre}weight_hh_l{l}", dz2.T @ q(Hprev))
@@ -630,8 +632,9 @@ def bigru_fwd(P, emb):
             zx = _birnn_zx(inp.reshape(B * S, -1), wih, bih, l).reshape(B, S, 3 * Hn)
             Hs, R, Z, N, GN, HP = (np.zeros((B, S, Hn), F32) for _ in range(6))
             h = np.zeros((B, Hn), F32)
+            whhT = q(whh).T
             for t in order:
-                g = (mm(h, whh.T) + bhh).astype(F32)          # fp32 accumulators; the gates are computed on them in the same launch
+                g = (q(h) @ whhT + bhh).astype(F32)           # fp32 accumulators; the gates are computed on them in the same launch
                 r = sigmoid(zx[:, t, :Hn] + g[:, :Hn]).astype(F32)
                 z = sigmoid(zx[:, t, Hn:2 * Hn] + g[:, Hn:2 * Hn]).astype(F32)
                 n = np.tanh(zx[:, t, 2 * Hn:] + r * g[:, 2 * Hn:]).astype(F32)
@@ -668,6 +671,7 @@ def bigru_bwd(P, G, c, dstate):
             dZx = np.zeros((B, S, 3 * Hn), F32)          # grads of the input-side pre-activations (r | z | n)
             dGh = np.zeros((B, S, 3 * Hn), F32)          # grads of the hidden-side pre-activations (n block scaled by r)
             carry = np.zeros((B, Hn), F32)
+            whh_q = q(whh)
             for i in reversed(range(S)):
                 t = order[i]
                 dh = dH[:, t] + carry
@@ -677,7 +681,7 @@ def bigru_bwd(P, G, c, dstate):
                 dr = dn * gn * r * (1.0 - r)
                 dZx[:, t] = qg(np.concatenate([dr, dz, dn], -1))       # both pre-activation gradients are stored 16-bit GEMM operands
                 dGh[:, t] = qg(np.concatenate([dr, dz, dn * r], -1))
-                carry = qg(dh * z) + dGh[:, t] @ q(whh)                # the direct path is stored (16-bit), the GEMM part stays in fp32 accumulators
+                carry = qg(dh * z) + dGh[:, t] @ whh_q                 # the direct path is stored (16-bit), the GEMM part stays in fp32 accumulators
             _acc(G, f"{pre}weight_hh_l{l}{sfx}", dGh.reshape(B * S, -1).T @ q(HP.reshape(B * S, Hn)))
             _acc(G, f"{pre}bias_hh_l{l}{sfx}", dGh.reshape(B * S, -1).sum(0))
             _acc(G, f"{pre}weight_ih_l{l}{sfx}", dZx.reshape(B * S, -1).T @ q(inp.reshape(B * S, -1)))
@@ -702,8 +706,9 @@ def birnn_fwd(P, emb):
             zx = _birnn_zx(inp.reshape(B * S, -1), wih, b, l).reshape(B, S, -1)
             Hs = np.zeros((B, S, whh.shape[0]), F32)
             h = np.zeros((B, whh.shape[0]), F32)
+            whhT = q(whh).T
             for t in order:
-                h = q(np.tanh(zx[:, t] + mm(h, whh.T)).astype(F32))
+                h = q(np.tanh(zx[:, t] + q(h) @ whhT).astype(F32))
                 Hs[:, t] = h
             c[f"H{l}{sfx}"] = Hs
             outs.append(Hs)
@@ -735,11 +740,12 @@ def birnn_bwd(P, G, c, dstate):
             dZ = np.zeros((B, S, Hn), F32)
             carry = np.zeros((B, Hn), F32)
             Hprev = np.zeros((B, S, Hn), F32)
+            whh_q = q(whh)
             for i in reversed(range(S)):                     # reverse of the processing order
                 t = order[i]
                 dz = qg((dH[:, t] + carry) * (1.0 - Hs[:, t] ** 2))
                 dZ[:, t] = dz
-                carry = dz @ q(whh)
+                carry = dz @ whh_q
                 if i > 0:
                     Hprev[:, t] = Hs[:, order[i - 1]]
             dz2 = dZ.reshape(B * S, Hn)

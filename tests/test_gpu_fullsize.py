@@ -275,7 +275,7 @@ def test_512_frames_against_the_numpy_oracle():
         # the same seeded parameters / batch, evaluated chunk-wise by spawned worker processes (tests/oracle_pool.py; sequentially the three modes
         # of this test took 125 s of the suite)
         from oracle_pool import oracle_batch
-        return oracle_batch(21, "hulc", 32, Bt, St, CH, mode, grad_scale)
+        return oracle_batch(21, "hulc", 32, Bt, St, CH, mode, grad_scale, P=P, mb=mb)
 
     G, loss, emb_o = oracle_eval()
     dev_mb = {k: torch.from_numpy(v.astype(np.int32) if k == "plan_idx" else v).cuda() for k, v in mb.items()}
@@ -435,7 +435,7 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     # the oracle runs in spawned worker processes (tests/oracle_pool.py: the same seeded parameters and batch, chunks of 4 windows spread over the
     # host's cores) — sequentially the 16 chunks take ~4 minutes on 8 cores
     from oracle_pool import oracle_batch
-    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale)
+    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb)
     assert abs(l["total_mod"] - loss) <= 5e-4 * abs(loss), (l, loss)
     assert rel_l2(emb, emb_q) < 2e-3, rel_l2(emb, emb_q)
     errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
@@ -486,14 +486,15 @@ def test_mcil_benchmark_shape_against_the_rounding_aware_oracle(rnn_type):
     dims = oracle_pool.case_dims(case)
     mb = oracle_pool.case_batch(case)["vis"]
     eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3, num_classes=dims.mix_classes)
-    eng.load_numpy(spec.init_all(dims, seed=29, ln_jitter=True))
+    P = spec.init_all(dims, seed=29, ln_jitter=True)
+    eng.load_numpy(P)
     l, _ = _step(eng, _np_to_dev(mb))
     assert eng.get_option("persistent_rnn") == 1                   # the benchmark's kernels, not a fallback
     Gg = {n: t.detach().cpu().numpy() for n, t in eng.views(eng.flat_grads).items()}
     emb = eng.get_tensor("emb", 64 * 32 * 128).reshape(64, 32, 128)
     eng.close()
     torch.cuda.empty_cache()
-    G, losses, embs = oracle_pool.oracle_case(case)
+    G, losses, embs = oracle_pool.oracle_case(case, P=P, batch={"vis": mb})
     lo = losses["vis"]
     print(f"[mcil {rnn_type} B=64 S=32 bf16] loss {l['total_mod']:.6f} vs oracle {lo['total']:.6f}; kl {l['kl']:.3e} vs {lo['kl']:.3e}; emb {rel_l2(emb, embs['vis']):.1e}")
     assert abs(l["total_mod"] - lo["total"]) <= 5e-4 * abs(lo["total"]), (l, lo)
@@ -514,7 +515,8 @@ def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle(
     dims = oracle_pool.case_dims(case)
     batch = oracle_pool.case_batch(case)
     eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3)
-    eng.load_numpy(spec.init_all(dims, seed=31, ln_jitter=True))
+    P = spec.init_all(dims, seed=31, ln_jitter=True)
+    eng.load_numpy(P)
     eng.zero_grads()
     lv, ll = eng.forward_loss_pair(_np_to_dev(batch["vis"]), _np_to_dev(batch["lang"]), 0.5, 3.0, step=0)
     eng.backward()
@@ -523,7 +525,7 @@ def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle(
     Gg = {n: t.detach().cpu().numpy() for n, t in eng.views(eng.flat_grads).items()}
     eng.close()
     torch.cuda.empty_cache()
-    G, losses, _ = oracle_pool.oracle_case(case)
+    G, losses, _ = oracle_pool.oracle_case(case, P=P, batch=batch)
     print(f"[vis+lang+CLIP 32+32 S=32 bf16] vis {lv} / oracle {losses['vis']}; lang {ll} / oracle {losses['lang']}")
     for got, sc in ((lv, "vis"), (ll, "lang")):
         # hulc_forward_loss_pair reports total_mod = kl + action of the modality

@@ -19,10 +19,10 @@ def test_pooled_chunks_equal_one_training_step(case):
     import hulc_oracle as O
     import oracle_pool
     from hulc_amd import spec
-    G, losses, embs = oracle_pool.oracle_case(case, CH=2, workers=2)
     dims = oracle_pool.case_dims(case)
     P = spec.init_all(dims, seed=case["seed"], ln_jitter=True)
     batch = oracle_pool.case_batch(case)
+    G, losses, embs = oracle_pool.oracle_case(case, CH=2, workers=2, P=P if case["kind"] == "mcil" else None, batch=batch if case["kind"] == "mcil" else None)   # both hand-over forms
     L, Gr, caches = O.training_step(P, dims, batch, keep_cache=True)
     tot = sum(losses[s]["kl"] + losses[s]["action"] for s in losses) / len(losses) + 3.0 * sum(losses[s]["clip"] for s in losses)
     assert abs(tot - float(L["total"])) <= 2e-6 * abs(float(L["total"])), (tot, L["total"])
