@@ -474,7 +474,8 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
 
 // the multiply + epilogue of one staged band (shared by the fp32 / register-staged kernel and the uint8 LDS-DMA kernel below)
 DEVI void conv1_fwd_band_tiles(lds_char* ximg, const h16x8_t (&wf)[6][2], const int (&rowsel)[6], const float4 (&bb)[2], h16_t* __restrict__ out,
-                               unsigned* __restrict__ maskbits, int f, int oh0, int R, int OH, int OW, int XRS, int dbg, int wave, int g, int li) {
+                               unsigned* __restrict__ maskbits, int f, int oh0, int R, int OH, int OW, int XRS, int dbg, int wave, int g, int li, float osc = 1.f) {
+        // osc: Conv1Src::fold — the staged operand is the raw byte value, out = relu(osc * acc + bias_fold)
         const int RBe = min(R, OH - oh0);
         const int npix = RBe * OW;
         const int ntm = (dbg & 2) ? 0 : (npix + 15) >> 4;
@@ -520,8 +521,8 @@ DEVI void conv1_fwd_band_tiles(lds_char* ximg, const h16x8_t (&wf)[6][2], const 
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const int cn0 = g * 8 + ct * 4;
-                    const float v0 = fmaxf(acc[mm][ct][0] + bb[ct].x, 0.f), v1 = fmaxf(acc[mm][ct][1] + bb[ct].y, 0.f);
-                    const float v2 = fmaxf(acc[mm][ct][2] + bb[ct].z, 0.f), v3 = fmaxf(acc[mm][ct][3] + bb[ct].w, 0.f);
+                    const float v0 = fmaxf(fmaf(acc[mm][ct][0], osc, bb[ct].x), 0.f), v1 = fmaxf(fmaf(acc[mm][ct][1], osc, bb[ct].y), 0.f);
+                    const float v2 = fmaxf(fmaf(acc[mm][ct][2], osc, bb[ct].z), 0.f), v3 = fmaxf(fmaf(acc[mm][ct][3], osc, bb[ct].w), 0.f);
                     const unsigned ox = pack2h(v0, v1), oy = pack2h(v2, v3);
                     ow[ct * 2] = ox; ow[ct * 2 + 1] = oy;
                     const unsigned nz = ((ox & 0xffffu) ? 1u : 0u) | ((ox >> 16) ? 2u : 0u) | ((oy & 0xffffu) ? 4u : 0u) | ((oy >> 16) ? 8u : 0u);
@@ -584,7 +585,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
         __syncthreads();
         if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
         __syncthreads();
-        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li);
+        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li, (X.u8 && X.fold) ? CONV1_FOLD_SCALE : 1.f);
     }
 }
 // ---------------------------------------------------------------------------------------------------------------------
@@ -684,7 +685,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
         }
         __syncthreads();                                          // raw complete for every wave; the previous band's multiply is over (ximg free)
         if (!(dbg & 4)) {
-            const float sc = 2.f / 255.f;
+            const float sc = X.fold ? 1.f : 2.f / 255.f, of = X.fold ? 0.f : -1.f;      // fold: the exact value of the byte (Conv1Src::fold)
             for (RowCol p = q0; p.r < rows; sq.adv(p)) {
                 const int o = p.r * RP + LM + (p.c * 4 + dx) * 3;
                 const int sh = o & 3;
@@ -693,7 +694,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
                 const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
                 float v[12];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+                for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, of);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     u32x2_t ov;
@@ -705,7 +706,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
         }
         __syncthreads();                                          // ximg complete, raw consumed
         if (item + (int)gridDim.x < nitems) prefetch(item + (int)gridDim.x);         // lands during the multiply below
-        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li);
+        conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li, X.fold ? CONV1_FOLD_SCALE : 1.f);
     }
 }
 static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16_t* W, const float* bias, h16_t* out, int Nf, int IH, int IW, int OH, int OW, int dbg = 0,

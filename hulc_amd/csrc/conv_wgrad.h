@@ -669,7 +669,24 @@ struct Conv1Src {
     const void* X;         // fp32 NCHW (u8 == 0) or uint8 NHWC (u8 == 1)
     const int* shift;      // u8 only: [Nf][2] = (sx, sy) in [0, 2*pad], or null (no augmentation)
     int u8, pad;
+    // fold (round 5; u8 only, 16-bit engines): the affine x = u (2/255) - 1 of ScaleImageTensor + Normalize is taken OUT of the data path.
+    // conv1 has no zero padding (RandomShiftsAug pads by replication), so  conv(W, x) + b = (2/255) conv(W, u) + (b - sum_k W[.,k])  and
+    // dW = dY * x = (2/255) (dY * u) - db (x) 1:  the MFMA operand is the EXACT 16-bit value of the byte (0..255 are representable: one v_cvt_f32_ubyteN
+    // per value instead of extract + convert + fma, and no rounding of the input at all), the scale and the folded bias move into the fp32 epilogue
+    // (bias = bias_fold, computed by conv1_bias_fold_kernel from the 16-bit weights), the weight-gradient kernels scale their slab and subtract their
+    // own bias partial before they write it.  fold == 0: the value x itself is staged (round 2 - 4).
+    int fold;
 };
+#define CONV1_FOLD_SCALE (2.f / 255.f)
+// bias_fold[o] = b[o] - sum_k W16[o][k] over the packed 16-bit conv1 weights [32][192] (what the MFMAs multiply); one wave per output channel
+__global__ void __launch_bounds__(64) conv1_bias_fold_kernel(const h16_t* __restrict__ W, const float* __restrict__ b, float* __restrict__ out) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int k = lane; k < 192; k += 64) s += h2f(W[o * 192 + k]);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) out[o] = b[o] - s;
+}
 DEVI float u8_to_unit(unsigned char b) { return ((float)b / 255.f - 0.5f) / 0.5f; }    // ScaleImageTensor then Normalize(mean .5, std .5)
 // element e = tid + m*256 of a [rows][n] grid, m = 0, 1, ...: (row, col) advanced incrementally — a runtime integer division per
 // element (~35 VALU instructions) made the staging VALU-bound (one division per load AND per store, 3 channels, every band)
@@ -779,7 +796,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
         }
     }
     __syncthreads();
-    const float sc = 2.f / 255.f;
+    const float sc = s.fold ? 1.f : 2.f / 255.f, of = s.fold ? 0.f : -1.f;      // fold: the exact value of the byte (Conv1Src::fold)
     for (RowCol p = q0; p.r < rows; sq.adv(p)) {
         const int o = p.r * RP + LM + (p.c * 4 + dx) * 3;             // |dx| <= pad <= CONV1_RAW_MARGIN: stays inside the margins
         const int sh = o & 3;
@@ -788,7 +805,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
         const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
         float v[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+        for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, of);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             u32x2_t ov;
@@ -1215,7 +1232,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
             }
         __syncthreads();                                          // raw rows complete
         {
-            const float sc = 2.f / 255.f;
+            const float sc = S.fold ? 1.f : 2.f / 255.f, of = S.fold ? 0.f : -1.f;
             for (int e = tid; e < XR * W4; e += 512) {
                 const int r = e / W4, c = e - r * W4;
                 u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
@@ -1227,7 +1244,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
                     const unsigned d[3] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh)};
                     float v[12];
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, -1.f);
+                    for (int k = 0; k < 12; ++k) v[k] = fmaf((float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu), sc, of);
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = pack2h(v[ch], v[3 + ch]); ov[ch][1] = pack2h(v[6 + ch], v[9 + ch]); }
                 }
@@ -1272,7 +1289,21 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
             }
         }
     }
-    // ---- the two unit halves (waves w and w + 4) are summed through LDS, then one slab per workgroup
+    // ---- the bias partial of this workgroup first (Conv1Src::fold needs it for the slab), then the two unit halves (waves w and w + 4) are summed
+    // through LDS and one slab per workgroup is written
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);
+    float* dbw = redf + 6144;                                    // [CO]: this workgroup's bias-gradient partial (24 KB in: behind redf's 16 KB and red's 24 KB)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) redf[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C::CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float sacc = 0.f;
+        for (int t = cgrp; t < 512; t += 4) sacc += redf[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, sacc);
+        dbw[tid] = sacc;
+    }
     __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(smem);
     if (uh == 1) {
@@ -1284,25 +1315,18 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
     __syncthreads();
     if (uh == 0) {
         float* out = part + (long long)blockIdx.x * C::CO * 192;
+        const float fsc = S.fold ? CONV1_FOLD_SCALE : 1.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const f32x4 v = acc[j][c] + red[((wave & 3) * 6 + j * 2 + c) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[(long long)(c * 16 + g * 4 + r) * 192 + (nt0 + j) * 16 + a] = v[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = c * 16 + g * 4 + r;
+                    out[(long long)co * 192 + (nt0 + j) * 16 + a] = S.fold ? fmaf(v[r], fsc, -dbw[co]) : v[r];      // dW = (2/255) (dY * u) - db (x) 1
+                }
             }
-    }
-    __syncthreads();
-    float* redf = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) redf[tid * 8 + e] = bsum[e];
-    __syncthreads();
-    if (tid < C::CO) {
-        const int cgrp = tid >> 3, e = tid & 7;
-        float sacc = 0.f;
-        for (int t = cgrp; t < 512; t += 4) sacc += redf[t * 8 + e];
-        unsafeAtomicAdd(bias_part + tid, sacc);
     }
 }
 
@@ -1360,7 +1384,8 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
         attr_set = true;
     }
     const int grid = Nf < max_blocks ? Nf : max_blocks;
-    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
+    Conv1Src X1 = X; X1.fold = 0;      // this (fallback) kernel writes the plain slab: it stages x itself
+    hipLaunchKernelGGL(conv1_wgrad_tr_kernel, dim3(grid), dim3(256), lds, st, X1, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R);
     return grid;
 }
 

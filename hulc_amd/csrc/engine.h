@@ -583,6 +583,7 @@ struct Engine : IEngine {
     // NHWC-permuted gripper fc and the packed decoder heads
     int prepare_weights(bool shadow_fresh = false) override {
         if (!bound) { hulc_set_error("hulc_prepare_weights before hulc_bind_params"); return 1; }
+        c1_bias_fold_valid = false;
         if constexpr (!std::is_same<T, float>::value) {
             if (!shadow_fresh) hipLaunchKernelGGL((cast_kernel<float, T>), dim3(2048), dim3(256), 0, st, P, wshadow, (long long)numel);
         }
@@ -718,7 +719,26 @@ struct Engine : IEngine {
         s.u8 = b.frames_u8 != 0;
         s.shift = s.u8 ? (gripper ? b.shift_gripper : b.shift_static) : nullptr;
         s.pad = gripper ? b.pad_gripper : b.pad_static;
+        // 16-bit engines: the dataloader's affine is folded out of the uint8 data path (conv_wgrad.h Conv1Src::fold); the fp32 (parity) engine converts
+        // exactly like the reference (ingest_u8_kernel)
+        s.fold = (s.u8 && std::is_same<T, h16_t>::value && u8_fold_mode) ? 1 : 0;
         return s;
+    }
+    // b - sum_k W16 of the two conv1 layers (Conv1Src::fold), recomputed after every weight refresh, only when a uint8 batch asks for it
+    float* c1_bias_fold[2] = {nullptr, nullptr};
+    bool c1_bias_fold_valid = false;
+    const float* conv1_bias(const EncW& e, const Conv1Src& src) {
+        if (!src.fold) return e.c1.b32;
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (!c1_bias_fold[0]) { c1_bias_fold[0] = alloc<float>(64); c1_bias_fold[1] = alloc<float>(64); }
+            if (!c1_bias_fold_valid) {
+                hipLaunchKernelGGL(conv1_bias_fold_kernel, dim3(32), dim3(64), 0, st, encS.c1.Wf, encS.c1.b32, c1_bias_fold[0]);
+                hipLaunchKernelGGL(conv1_bias_fold_kernel, dim3(32), dim3(64), 0, st, encG.c1.Wf, encG.c1.b32, c1_bias_fold[1]);
+                c1_bias_fold_valid = true;
+            }
+            return c1_bias_fold[e.gripper ? 1 : 0];
+        }
+        return e.c1.b32;
     }
     // actions of the current batch: the reference's relative actions, or absolute targets + RelativeActions applied here
     float* act_rel = nullptr;
@@ -753,7 +773,7 @@ struct Engine : IEngine {
             if constexpr (std::is_same<T, h16_t>::value) {
                 const double px = (double)nf * g1.OH * g1.OW;
                 TimerScope ts(this, "conv1_fwd", "hbm", 2.0 * px * 32 * 192, (double)nf * 3 * e.IH * e.IH * (sh.u8 ? 1 : 4) + px * 32 * 2);
-                launch_conv1_fwd(st, sh, e.c1.Wf, e.c1.b32, a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr, pend_zero[0], pend_zero[1]);
+                launch_conv1_fwd(st, sh, e.c1.Wf, conv1_bias(e, sh), a.a1 + poff * 32, nf, e.IH, e.IH, g1.OH, g1.OW, 0, a.m1bits ? a.m1bits + poff : nullptr, pend_zero[0], pend_zero[1]);
                 pend_zero[0] = pend_zero[1] = nullptr;
             } else {
                 const float* x = conv1_f32(sh, e.gripper, nf, e.IH, foff);

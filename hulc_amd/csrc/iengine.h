@@ -78,7 +78,7 @@ struct IEngine {
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
     // "lazy_zero_grads": 1 (default; 16-bit engines) = hulc_zero_grads only marks the large store-first weight gradients stale instead of zeroing them
     // (engine.h: LazyG); 0 = the plain memset of the whole buffer.
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1;
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
     int set_option(const char* name, long long value) {
@@ -88,6 +88,9 @@ struct IEngine {
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
         if (name && !strcmp(name, "lazy_zero_grads")) { lazy_zero_mode = value != 0; return 0; }
+        // "u8_fold": 1 (default; 16-bit engines) = the uint8 ingest path multiplies the exact byte values and applies x = u (2/255) - 1 in conv1's epilogue /
+        // weight-gradient slabs (conv_wgrad.h Conv1Src::fold); 0 = the value x itself is staged (16-bit rounded), as in rounds 2 - 4
+        if (name && !strcmp(name, "u8_fold")) { u8_fold_mode = value != 0; return 0; }
         // "dp_skip_vote": for a gradient all-reduce done OUTSIDE the library (the torch.distributed fallback): 1 right before the collective that covers the
         // perceptual-encoder gradients, 2 right after it — the job-wide "a recurrence of this step failed on some rank" vote (engine.h skip_vote_put)
         if (name && !strcmp(name, "dp_skip_vote")) { dp_skip_vote((int)value); return 0; }

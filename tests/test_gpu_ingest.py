@@ -28,8 +28,29 @@ def _inputs(B, S, seed):
     return fs, fg, sh_s, sh_g
 
 
+def _run(dims, P, B, S, dtype, mb, fold=None):
+    eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=1)
+    if fold is not None:
+        eng.set_option("u8_fold", fold)
+    eng.load_numpy(P)
+    eng.zero_grads()
+    l = eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+    eng.backward()
+    torch.cuda.synchronize()
+    g = eng.flat_grads.clone()
+    views = {n: (off, int(np.prod(sh)) if len(sh) else 1) for n, (off, sh) in eng.layout.items()}
+    eng.close()
+    return l, g, views
+
+
 @pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-6, 2e-5), ("bf16", 2e-4, 3e-3)])
 def test_u8_ingest_step_equals_fp32_boundary(dtype, tol_loss, tol_grad):
+    """uint8 frames + shifts through the fused ingest path == the transformed fp32 NCHW frames through the reference boundary.  fp32 engine: exact
+    conversion (ingest_u8_kernel).  bf16 engine: the path that stages x = u (2/255) - 1 itself (`u8_fold` 0: the same 16-bit rounded operand as the
+    fp32 boundary, tight tolerance) AND the production path with the affine folded out of the data path (Conv1Src::fold: exact byte operands,
+    scale + folded bias in conv1's epilogue, (2/255) S - db in its weight gradient) — which differs from the fp32 boundary by that boundary's own
+    input rounding, so it is held (i) to the boundary within the 16-bit rounding level and (ii) to the fp32 ENGINE at least as closely as the
+    fp32-boundary run of the bf16 engine is."""
     dims, P, batch, fx = load_case("hulc_tiny")
     mb0 = batch["vis"]
     B, S = mb0["actions"].shape[:2]
@@ -38,20 +59,27 @@ def test_u8_ingest_step_equals_fp32_boundary(dtype, tol_loss, tol_grad):
     common = dict(actions=t(mb0["actions"], np.float32), robot_obs=t(mb0["robot_obs"], np.float32), plan_idx=t(mb0["plan_idx"], np.int32))
     ref = dict(common, rgb_static=t(O.ingest_u8(fs, sh_s, 10)), rgb_gripper=t(O.ingest_u8(fg, sh_g, 4)))
     u8 = dict(common, rgb_static=t(fs), rgb_gripper=t(fg), shift_static=t(sh_s), shift_gripper=t(sh_g), pad_static=10, pad_gripper=4)
-    out = []
-    for mb in (ref, u8):
-        eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=1)
-        eng.load_numpy(P)
-        eng.zero_grads()
-        l = eng.forward_loss(mb, False, 1.0, 3.0, step=0)
-        eng.backward()
-        torch.cuda.synchronize()
-        out.append((l, eng.flat_grads.clone()))
-        eng.close()
-    (l0, g0), (l1, g1) = out
+    l0, g0, views = _run(dims, P, B, S, dtype, ref)
+    l1, g1, _ = _run(dims, P, B, S, dtype, u8, fold=0)
     assert abs(l0["total_mod"] - l1["total_mod"]) <= tol_loss * abs(l0["total_mod"]), (l0, l1)
     rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
     assert rel <= tol_grad, rel
+    if dtype == "fp32":
+        return
+    l2, g2, _ = _run(dims, P, B, S, dtype, u8, fold=1)             # the production path
+    lt, gt, _ = _run(dims, P, B, S, "fp32", ref)                   # the parity engine on the reference boundary
+    rel_l = lambda a, b: abs(a["total_mod"] - b["total_mod"]) / abs(b["total_mod"])
+    rel_g = lambda a, b: ((a - b).double().norm() / b.double().norm()).item()
+    print(f"[u8 fold] loss vs fp32 boundary {rel_l(l2, l0):.2e} (no fold {rel_l(l1, l0):.2e}); vs fp32 engine: fold {rel_l(l2, lt):.2e} boundary {rel_l(l0, lt):.2e}; "
+          f"gradient vs fp32 engine: fold {rel_g(g2, gt):.3e} boundary {rel_g(g0, gt):.3e}, fold vs boundary {rel_g(g2, g0):.3e}")
+    assert rel_l(l2, l0) <= 3e-3 and rel_g(g2, g0) <= 5e-2
+    assert rel_l(l2, lt) <= max(2.0 * rel_l(l0, lt), 1e-3)
+    assert rel_g(g2, gt) <= 1.15 * rel_g(g0, gt) + 1e-3
+    # the first-layer tensors — the only ones the fold computes differently — one by one against the fp32 engine
+    for n, (off, k) in views.items():
+        if "conv_model.0." in n:
+            e_fold = rel_g(g2[off:off + k], gt[off:off + k]); e_ref = rel_g(g0[off:off + k], gt[off:off + k])
+            assert e_fold <= 1.5 * e_ref + 5e-3, (n, e_fold, e_ref)
 
 
 def test_u8_ingest_validation_without_augmentation():
