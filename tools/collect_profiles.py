@@ -11,7 +11,8 @@ copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.cs
           "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
           "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt", "conv_reg_vs_tile.txt": "conv_reg_vs_tile.txt", "conv_reg_ablation.txt": "conv_reg_ablation.txt",
           "step_timeline.txt": "step_timeline.txt", "rnn_persist_stamps.txt": "rnn_persist_stamps.txt",
-          "storebench.txt": "storebench_write_patterns.txt", "mixbench.txt": "mixbench_conv1_traffic_shape.txt"}
+          "storebench.txt": "storebench_write_patterns.txt", "mixbench.txt": "mixbench_conv1_traffic_shape.txt",
+          "cr_bench.txt": "conv_reg_forms.txt", "cr_stamps.txt": "conv_reg_phase_stamps.txt", "vmcnt_probe.txt": "vmcnt_order_probe.txt"}
 for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d", "rehearsal"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():

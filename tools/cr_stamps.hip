@@ -20,7 +20,7 @@ static std::vector<h16_t> rnd16(size_t n, float scale, unsigned s) {
 }
 template <typename T> static T* dev(const std::vector<T>& h) { T* d; hipMalloc(&d, h.size() * sizeof(T) + 512); hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice); return d; }
 
-template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD>
+template <int CK, int TA, int TB, int SI, bool REV, int OS, int NWV, int NBUF, bool ORD, int EPI = 0>
 static void run(const char* name, int Nf, int IMH, int OUTH) {
     constexpr int CN = OS == 1 ? 64 : 32, K = TA * TB * CK, NCLS = OS * OS;
     const size_t nimg = (size_t)Nf * IMH * IMH * CK, nout = (size_t)Nf * OUTH * OUTH * CN;
@@ -28,15 +28,16 @@ static void run(const char* name, int Nf, int IMH, int OUTH) {
     std::vector<float> hb(64, 0.01f); float* bias = dev(hb);
     std::vector<unsigned> hbits((size_t)Nf * OUTH * OUTH * 2, 0x5a5a5a5au); unsigned* bits = dev(hbits);
     void* zp; hipMalloc(&zp, 256); hipMemset(zp, 0, 256);
-    ConvTileP p{}; p.img = img; p.IMH = p.IMW = IMH; p.w = w; p.out = out; p.OUTH = p.OUTW = OUTH; p.Nf = Nf;
+    void* dumpb; hipMalloc(&dumpb, 8192);
+    ConvTileP p{}; p.dump = (h16_t*)dumpb; p.img = img; p.IMH = p.IMW = IMH; p.w = w; p.out = out; p.OUTH = p.OUTW = OUTH; p.Nf = Nf;
     if (REV) { p.maskbits = bits; p.zeros = (const h16_t*)zp; } else { p.bias = bias; p.relu = 1; if (SI == 2) p.bits_out = bits; }
-    for (int i = 0; i < 3; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD>(0, p);
+    for (int i = 0; i < 3; ++i) launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
     hipDeviceSynchronize();
     std::vector<unsigned long long> z(16 * 8 * 32 * 8, 0ull);
     hipMemcpyToSymbol(HIP_SYMBOL(g_cr_stamps), z.data(), z.size() * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD>(0, p);
+    launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF, ORD, EPI>(0, p);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_cr_stamps), z.size() * 8);
@@ -74,5 +75,8 @@ int main() {
     run<64, 3, 3, 1, true, 1, 8, 0, false>("conv3 dgrad, 8 waves (r4 product)", Nf, 21, 23);
     run<64, 2, 2, 1, true, 2, 8, 0, false>("conv2 dgrad, 8 waves", Nf, 23, 49);
     run<64, 2, 2, 1, true, 2, 4, 0, false>("conv2 dgrad, 2 x 4 waves (r4 product)", Nf, 23, 49);
+    // round 5 production forms of the data gradients: pipelined epilogue (stamps 2 -> 3 = the tile loop with the drains inside, 3 -> 4 = the wait, no epilogue phase)
+    run<64, 3, 3, 1, true, 1, 4, 0, true, 1>("conv3 dgrad, 2 x 4 waves, pipelined epilogue + slot registers (r5 product)", Nf, 21, 23);
+    run<64, 2, 2, 1, true, 2, 4, 0, true, 1>("conv2 dgrad, 2 x 4 waves, pipelined epilogue + slot registers (r5 product)", Nf, 23, 49);
     return 0;
 }

@@ -7,7 +7,7 @@
 #   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
 #   5. the probes behind DESIGN.md's numbers: tools/bin/ct_stamps (conv tile phases), tools/bin/gridbar2 (XCD barrier + sc1 publish),
 #      tools/bin/rnn_persist_bench_st (the persistent recurrence alone: check against a CPU recurrence, us per step, phase stamps)
-T=${1:-r04}
+T=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$T
@@ -41,6 +41,9 @@ MASTER_PORT=29877 b rehearsal --force-comm 1          # 1-GPU rehearsal of the N
 b u8_h2d --ingest u8 --h2d 1                  # every step's uint8 frames copied from PINNED HOST memory (SURVEY 8(d)'s PCIe-inclusive row)
 python tools/time_conv_reg.py > $O/conv_reg_vs_tile.txt 2>/dev/null
 ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -12 > $O/conv_reg_ablation.txt
+test -x tools/bin/cr_bench && timeout 400 tools/bin/cr_bench ablate > $O/cr_bench.txt 2>&1          # conv_reg.h forms: slot decode in registers, pipelined epilogue, loader waves (round 5)
+test -x tools/bin/cr_stamps && timeout 200 tools/bin/cr_stamps > $O/cr_stamps.txt 2>&1              # ... phase stamps of a band
+test -x tools/bin/vmcnt_probe && timeout 200 tools/bin/vmcnt_probe > $O/vmcnt_probe.txt 2>&1        # LDS-DMA then store, counted vmcnt: in-order retirement probe
 test -x tools/bin/storebench && timeout 120 tools/bin/storebench > $O/storebench.txt 2>&1
 test -x tools/bin/mixbench && timeout 120 tools/bin/mixbench > $O/mixbench.txt 2>&1
 python tools/step_timeline.py $O/stats "" 400 > $O/step_timeline.txt 2>&1
