@@ -173,6 +173,11 @@ def main():
     ap.add_argument("--h2d", type=int, default=0, help="with --ingest u8: 1 = every step's uint8 frames come from PINNED HOST memory (async H2D on a copy stream into a "
                                                       "double buffer, overlapped with the previous step) — the PCIe-inclusive row SURVEY §8(d) asks for; never the headline `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timer-stride", type=int, default=4, help="the live class timers record their HIP events on every N-th step of the timed region (1 = every step)")
+    ap.add_argument("--live-timers", default="on", choices=["on", "fenced", "off"],
+                    help="A/B of the measurement itself (never a reported configuration): 'on' (default) = the dominant group's kernel classes are timed by HIP events "
+                         "inside the timed region (timing-only events, hipEventDisableSystemFence); 'fenced' = the same with default events (rounds <= 4); 'off' = no "
+                         "events in the timed region, `roofline` comes from the survey pass")
     ap.add_argument("--force-comm", type=int, default=0, help="1-GPU REHEARSAL of the N > 1 code path (never a reported number): a 1-rank torch.distributed group and a "
                                                               "1-rank library RCCL communicator, so that the self-check, hulc_backward_allreduce in the timed loop and the bucket "
                                                               "timeline run before the first multi-GPU box meets them (tests/test_gpu_dp.py)")
@@ -378,7 +383,15 @@ def main():
     groups = {g: v for g, v in groups.items() if v}
     dom_group = max(groups.items(), key=lambda kv: kv[1]["ms"])[0] if groups else ""
     # timed region: events only around the classes of the dominant GROUP (on the engine's stream), so the timers do not perturb the rest of the step
-    eng.timers_enable(True, ",".join(groups[dom_group]["classes"]) if dom_group else "")
+    if args.live_timers == "fenced":
+        eng.set_option("timer_event_fence", 1)
+    # The live class timers are themselves a load on the stream: one timing-only event record costs ~1.8 us of stream time (a default, system-fenced event
+    # 3 us; profiles/r05_live_timer_cost.txt), 20 records per step around the dominant group's 10 launches.  They stay inside the timed region, on every
+    # `--timer-stride`-th timed step (default 4: 25 timed samples of each launch per 100 steps), so that the measurement moves the measured step by ~0.3 %.
+    tfilter = ",".join(groups[dom_group]["classes"]) if dom_group else ""
+    stride = max(1, args.timer_stride)
+    sampled = [i for i in range(args.steps) if i % stride == 0] if args.live_timers != "off" else []
+    eng.timers_enable(False)
     sc0 = eng.scaler_state() if args.dtype == "fp16" else None
     # one event per step boundary on the engine's stream (= torch's current stream): per-step device times for median / p10 / p90 next to the
     # wall-clock mean the contract's `ms_per_step` is (an event record costs no synchronisation and ~1 us of stream time)
@@ -387,6 +400,8 @@ def main():
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(args.steps):
+        if sampled and stride > 1 or i == 0:
+            eng.timers_enable(bool(sampled) and i % stride == 0, tfilter)      # a host-side flag + filter string: no stream work
         step(args.warmup + i)
         evs[i + 1].record()
     barrier()
@@ -401,7 +416,7 @@ def main():
     wps = B * world / (dt / args.steps)
     loss = eng._loss_dev.cpu().numpy().tolist()
 
-    timers = eng.timers_read(reset=True)
+    timers = eng.timers_read(reset=True) if args.live_timers != "off" else survey
     eng.timers_enable(False)
     # N > 1: one more (untimed) step with events around every bucket's collective: when each bucket was issued / finished relative to the END of
     # the backward on the engine stream (negative = hidden under the backward), per rank 0
@@ -411,6 +426,8 @@ def main():
         step(args.warmup + args.steps)
         comm_tl = eng.comm_timeline()
         eng.set_option("comm_timing", 0)
+
+    tsteps = len(sampled) if sampled else 2      # the timed steps that carried events; 'off': the survey pass's two steps
 
     def roofline(tm):
         """The dominant GEMM group (all of its kernel classes, timed live by HIP events inside the timed region); achieved = the group's
@@ -441,11 +458,11 @@ def main():
                 traffic_source = os.path.relpath(cands[-1], ROOT)
             except Exception:
                 traffic = None
-        per_class = {c: {"ms_per_step": round(tm[c]["ms"] / args.steps, 4), "launches_per_step": tm[c]["launches"] / args.steps,
+        per_class = {c: {"ms_per_step": round(tm[c]["ms"] / tsteps, 4), "launches_per_step": tm[c]["launches"] / tsteps,
                          "achieved": round((tm[c]["flops"] / 1e12 if t["bound"] == "mfma" else tm[c]["bytes"] / 1e9) / max(tm[c]["ms"] * 1e-3, 1e-12), 2)} for c in t["classes"]}
         return {"kernel": name + " = " + " + ".join(t["classes"]), "classes": per_class, "bound": t["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": t["launches"] / args.steps, "avg_launch_us": round(t["ms"] * 1e3 / max(1, t["launches"]), 2),
-                "ms_per_step": round(t["ms"] / args.steps, 4),
+                "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": t["launches"] / tsteps, "avg_launch_us": round(t["ms"] * 1e3 / max(1, t["launches"]), 2),
+                "ms_per_step": round(t["ms"] / tsteps, 4), "event_timed_steps": tsteps, "of_timed_steps": args.steps,
                 "per_launch": {"algorithmic_flops": t["flops"] / max(1, t["launches"]), "algorithmic_bytes": t["bytes"] / max(1, t["launches"])}}
 
     def step_roofline():

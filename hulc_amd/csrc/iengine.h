@@ -88,6 +88,7 @@ struct IEngine {
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
         if (name && !strcmp(name, "lazy_zero_grads")) { lazy_zero_mode = value != 0; return 0; }
+        if (name && !strcmp(name, "timer_event_fence")) { event_flags = value != 0 ? hipEventDefault : hipEventDisableSystemFence; for (auto& kv : timers) { for (auto& ev : kv.second.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } kv.second.ev.clear(); kv.second.used = 0; } return 0; }
         // "u8_fold": 1 (default; 16-bit engines) = the uint8 ingest path multiplies the exact byte values and applies x = u (2/255) - 1 in conv1's epilogue /
         // weight-gradient slabs (conv_wgrad.h Conv1Src::fold); 0 = the value x itself is staged (16-bit rounded), as in rounds 2 - 4
         if (name && !strcmp(name, "u8_fold")) { u8_fold_mode = value != 0; return 0; }
@@ -105,6 +106,7 @@ struct IEngine {
     bool timing = false;
     std::string timing_filter;      // empty = every class; else ",a,b,": only the listed classes (keeps event overhead out of the timed region)
     int timer_depth = 0;            // a group scope (e.g. the S recurrent steps) suppresses the per-launch scopes inside it
+    unsigned event_flags = hipEventDisableSystemFence;     // hulc_set_option "timer_event_fence" 1: default events (A/B of the timers' own cost)
     struct TimerScope {
         IEngine* e; IEngine::KTimer* t;
         TimerScope(IEngine* e_, const char* name, const char* bound, double flops, double bytes, int nlaunch = 1) : e(e_), t(nullptr) {
@@ -113,7 +115,9 @@ struct IEngine {
             e->timer_depth++;
             t = &e->timers[name];
             if (t->name.empty()) { t->name = name; t->bound = bound; }
-            if (t->used == t->ev.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); t->ev.emplace_back(a, b); }
+            // timing-only events: no system-scope fence when they complete (hipEventDisableSystemFence) — a default event's cache write-back + invalidate stalled the
+            // stream for 5.5 us per record behind the conv kernels (profiles/r05_host_lead.txt: 20 records = 117 us of a 3.1 ms step); timers_read synchronises the stream
+            if (t->used == t->ev.size()) { hipEvent_t a, b; hipEventCreateWithFlags(&a, e->event_flags); hipEventCreateWithFlags(&b, e->event_flags); t->ev.emplace_back(a, b); }
             t->flops += flops; t->bytes += bytes; t->launches += nlaunch;
             hipEventRecord(t->ev[t->used].first, e->st);
         }
