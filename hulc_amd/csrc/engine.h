@@ -1165,7 +1165,7 @@ struct Engine : IEngine {
             STAGE("enc_static_fwd");
             enc_fwd(encG, aG, conv1_src(*b, true), N, 64, pair ? &s2g : nullptr, tail_fused);
             x0_done = false;
-            if (tail_fused) enc_tail_fwd_both(N, !mcil && tr_fused_mode && S <= 32 && EMB == 128, S, dp);
+            if (tail_fused) enc_tail_fwd_both(N, !mcil && tr_fused_mode && S <= 64 && EMB == 128, S, dp);
             STAGE("enc_gripper_fwd");
         }
         // ---- goal encoder (goal_encoders.py:31-36 / 64-69)
@@ -1209,7 +1209,7 @@ struct Engine : IEngine {
         // ---- plan recognition transformer (plan_recognition_net.py:94-117)
         bool fused = false;
         if constexpr (std::is_same<T, h16_t>::value) {
-            fused = tr_fused_mode && S <= 32;
+            fused = tr_fused_mode && S <= 64;          // 32 < S <= 64 (config 5): two 32-row halves per window, tr_fused.h WIDE
         }
         if (!(fused && x0_done))
         hipLaunchKernelGGL((posadd_kernel<T>), dim3(cdiv((long long)N * EMB, 256)), dim3(256), 0, st, emb, pos32, B, S, EMB, xf[0], xt[0], dp, site_seed(0),
@@ -2477,7 +2477,7 @@ struct Engine : IEngine {
                 // LN2 (16-bit engines: the last layer's incoming gradient dxm / S is broadcast over the window inside the kernel)
                 const bool bc = ln_bwd_can_bcast && l == 1;
                 bool ffn_fused = false;
-                if constexpr (std::is_same<T, h16_t>::value) ffn_fused = tr_fused_mode && S <= 32;
+                if constexpr (std::is_same<T, h16_t>::value) ffn_fused = tr_fused_mode && S <= 64;       // row-wise: half windows for S > 32
                 // 16-bit fused path: every incoming gradient of the layer's four Linear layers stays in its own buffer, and the eight weight / bias
                 // gradients of both layers run as ONE row-split launch after the loop (tr_wgrads_flush) instead of 16 transposes + GEMMs
                 T *b_c = dt_c, *b_a = dt_a, *b_d = dt_c, *b_b = dt_b;
@@ -2521,7 +2521,7 @@ struct Engine : IEngine {
                 bool attn_fused = false;
                 if constexpr (std::is_same<T, h16_t>::value) {
                     static const int sw = HULC_SWITCH("HULC_TR_ATTN_BWD", 1);
-                    attn_fused = ffn_fused && defer_w && sw && EMB == 128 && NH == 8;
+                    attn_fused = ffn_fused && defer_w && sw && EMB == 128 && NH == 8 && S <= 32;       // a window's dS / P tiles of 8 heads: 115 KB of LDS at S = 32, 266 KB at 64 -> launch per op
                     if (attn_fused) {
                         TrAttnBwdP q{};
                         q.parts = dparts; q.part_stride = (long long)N * EMB; q.nparts = 4; q.y1 = y1[l]; q.st1 = st1[l]; q.n1g = tr_n1g[l]; q.dg1 = d_tr_n1g[l]; q.db1 = d_tr_n1b[l];

@@ -54,7 +54,13 @@ constexpr int TRF_XP = TRF_D * 2 + 32;          // LDS row pitch (bytes) of a [3
 constexpr int TRF_HP = TRF_HQ * 2 + 32;         // ... of the [32][512] hidden tile: 66 slots
 constexpr int TRF_QP = 3 * TRF_D * 2 + 16;      // qkv rows [32][384] 16 bit (read element-wise by the attention)
 constexpr size_t TRF_LDS = 32 * TRF_D * 4 * 2 + 32 * TRF_XP * 3 + 32 * TRF_QP + 32 * TRF_HP;
+constexpr size_t TRF_LDS_WIDE = TRF_LDS + 32 * TRF_QP;      // q k v rows of the window's OTHER 32-row half
 
+// WIDE (32 < S <= 64, BASELINE config 5): a window is two 32-row HALVES and a workgroup owns (window, half, hidden quarter).  Every phase but the attention is
+// row-wise and runs on the workgroup's own half exactly as for S <= 32; the attention needs k and v of all S rows, so phase 0 / 1 also normalise and project the
+// other half's rows (16-bit copy in the attention-output tile, which is free until phase 2 ends) into a [64][384] q k v tile, and a lane of phase 2 walks 32 keys
+// instead of 16.  The redundant work (one more QKV projection per workgroup: 24 MFMAs per wave) is small next to what a second launch chain costs.
+template <bool WIDE>
 __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) float lds_f32;
@@ -66,12 +72,15 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     lds_char* const aob = xb + 32 * TRF_XP;                    // attention output
     lds_char* const x1b = aob + 32 * TRF_XP;                   // x1
     lds_char* const qb = x1b + 32 * TRF_XP;                    // qkv
-    lds_char* const hb = qb + 32 * TRF_QP;                     // hidden quarter
+    lds_char* const hb = qb + (WIDE ? 64 : 32) * TRF_QP;       // hidden quarter
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int w = blockIdx.x / TRF_NQ, hq = blockIdx.x % TRF_NQ;
-    const int S = p.S;
-    const long long row0 = (long long)w * S;
+    const int hq = blockIdx.x % TRF_NQ;
+    const int w = WIDE ? blockIdx.x / (2 * TRF_NQ) : blockIdx.x / TRF_NQ, half = WIDE ? (blockIdx.x / TRF_NQ) & 1 : 0;
+    const int SW = p.S;                                        // rows of the window (keys of the attention)
+    const int r0 = half * 32;                                  // this workgroup's first row in its window
+    const int S = WIDE ? min(32, SW - r0) : SW;                // rows this workgroup owns
+    const long long row0 = (long long)w * SW + r0;
     const bool lead = hq == 0;
     const bool mt1 = S > 16;                                   // second 16-token tile in use
     const float keep = 1.f / (1.f - p.dp);
@@ -122,6 +131,27 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
             *(lds_f32*)(xf + (r * TRF_D + lane) * 4) = v0; *(lds_f32*)(xf + (r * TRF_D + lane + 64) * 4) = v1;
             *(lds_h16*)(xb + r * TRF_XP + lane * 2) = f2h(v0); *(lds_h16*)(xb + r * TRF_XP + (lane + 64) * 2) = f2h(v1);
         }
+        if (WIDE) {       // the other half's rows, 16 bit only (operand of its k / v projection): same arithmetic as the workgroup that owns them
+            const int o0 = 32 - r0, So = min(32, SW - o0);
+            const long long orow0 = (long long)w * SW + o0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = wave * 4 + rr;
+                float v0 = 0.f, v1 = 0.f;
+                if (r < So) {
+                    const float* xr = p.xin + (orow0 + r) * TRF_D;
+                    v0 = xr[lane]; v1 = xr[lane + 64];
+                    if (p.ln_in) {
+                        const float mean = wave_sum(v0 + v1) * (1.f / TRF_D);
+                        const float d0 = v0 - mean, d1 = v1 - mean;
+                        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / TRF_D) + 1e-5f);
+                        v0 = d0 * rstd * plg0 + plb0;
+                        v1 = d1 * rstd * plg1 + plb1;
+                    }
+                }
+                *(lds_h16*)(aob + r * TRF_XP + lane * 2) = f2h(v0); *(lds_h16*)(aob + r * TRF_XP + (lane + 64) * 2) = f2h(v1);
+            }
+        }
     }
     __syncthreads();
     // weight fragments of the later phases: they depend on nothing computed here, so they travel while QKV / attention / LN1 run
@@ -155,19 +185,50 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
                 u32x2_t o;
                 o[0] = pack2h(acc[nt][mt][0] + bb[0], acc[nt][mt][1] + bb[1]);
                 o[1] = pack2h(acc[nt][mt][2] + bb[2], acc[nt][mt][3] + bb[3]);
-                *(__attribute__((address_space(3))) u32x2_t*)(qb + m * TRF_QP + n * 2) = o;
+                *(__attribute__((address_space(3))) u32x2_t*)(qb + (r0 + m) * TRF_QP + n * 2) = o;
                 if (lead && m < S) *reinterpret_cast<u32x2_t*>(p.qkv + (row0 + m) * (3 * TRF_D) + n) = o;
+            }
+        }
+        if (WIDE) {       // the other half's rows (their q columns are computed too and never read)
+            const int o0 = 32 - r0;
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) { acc[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8_t b0 = *(__attribute__((address_space(3))) h16x8_t*)(aob + li * TRF_XP + ks * 64 + g * 16);
+                const h16x8_t b1 = *(__attribute__((address_space(3))) h16x8_t*)(aob + (16 + li) * TRF_XP + ks * 64 + g * 16);
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    acc[nt][0] = MFMA_16x16x32_H(wq[nt][ks], b0, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = MFMA_16x16x32_H(wq[nt][ks], b1, acc[nt][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int n = (3 * wave + nt) * 16 + g * 4;
+                const f32x4 bb = pbq[nt];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    u32x2_t o;
+                    o[0] = pack2h(acc[nt][mt][0] + bb[0], acc[nt][mt][1] + bb[1]);
+                    o[1] = pack2h(acc[nt][mt][2] + bb[2], acc[nt][mt][3] + bb[3]);
+                    *(__attribute__((address_space(3))) u32x2_t*)(qb + (o0 + mt * 16 + li) * TRF_QP + n * 2) = o;
+                }
             }
         }
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) pb1[nt] = *reinterpret_cast<const f32x4*>(p.b1 + hq * TRF_HQ + wave * 64 + nt * 16 + g * 4);
     // FFN weight fragments (this workgroup's hidden quarter): W1 rows hq*512 + wave*64 + nt*16 + li; W2 rows wave*16 + li, k in the quarter
+    // (WIDE: requested after the attention — with 32 scores per lane next to them the wave spilled 26 registers)
+    auto load_w1 = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W1, hq * TRF_HQ + wave * 64 + nt * 16, TRF_D, 0, lane) + ks * 512);
+            for (int ks = 0; ks < 4; ++ks)
+                w1[nt][ks] = *reinterpret_cast<const h16x8_t*>(wfrag_ptr(p.W1, hq * TRF_HQ + wave * 64 + nt * 16, TRF_D, 0, lane) + ks * 512);
+    };
+    if (!WIDE) load_w1();
     __syncthreads();
 
     TRF_STAMP(2);
@@ -181,38 +242,39 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[2 * e] = h2f_lo(a[e]); o[2 * e + 1] = h2f_hi(a[e]); o[8 + 2 * e] = h2f_lo(b[e]); o[9 + 2 * e] = h2f_hi(b[e]); }
         };
+        constexpr int HJ = WIDE ? 32 : 16;                          // keys per lane
         if (i < S) {
             float q[TRF_HD];
-            row16(qb + i * TRF_QP + h * TRF_HD * 2, q);
+            row16(qb + (r0 + i) * TRF_QP + h * TRF_HD * 2, q);
 #pragma unroll
             for (int d = 0; d < TRF_HD; ++d) q[d] *= 0.25f;
-            float sc[16];
+            float sc[HJ];
             float m = -INFINITY;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = hf * 16 + jj;
+            for (int jj = 0; jj < HJ; ++jj) {
+                const int j = hf * HJ + jj;
                 float kk[TRF_HD];
-                row16(qb + (j < S ? j : 0) * TRF_QP + (TRF_D + h * TRF_HD) * 2, kk);
+                row16(qb + (j < SW ? j : 0) * TRF_QP + (TRF_D + h * TRF_HD) * 2, kk);
                 float s = 0.f;
 #pragma unroll
                 for (int d = 0; d < TRF_HD; ++d) s += q[d] * kk[d];
-                sc[jj] = j < S ? s : -INFINITY;
+                sc[jj] = j < SW ? s : -INFINITY;
                 m = fmaxf(m, sc[jj]);
             }
             m = fmaxf(m, __shfl_xor(m, 32));
             float den = 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) { sc[jj] = (hf * 16 + jj) < S ? __expf(sc[jj] - m) : 0.f; den += sc[jj]; }
+            for (int jj = 0; jj < HJ; ++jj) { sc[jj] = (hf * HJ + jj) < SW ? __expf(sc[jj] - m) : 0.f; den += sc[jj]; }
             den += __shfl_xor(den, 32);
             const float inv = 1.f / den;
             float o[TRF_HD];
 #pragma unroll
             for (int d = 0; d < TRF_HD; ++d) o[d] = 0.f;
-            const long long pbase = (((long long)w * TRF_NH + h) * S + i) * S;
+            const long long pbase = (((long long)w * TRF_NH + h) * SW + r0 + i) * SW;
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = hf * 16 + jj;
-                if (j < S) {
+            for (int jj = 0; jj < HJ; ++jj) {
+                const int j = hf * HJ + jj;
+                if (j < SW) {
                     float pr = sc[jj] * inv;
                     if (lead) p.Pat[pbase + j] = pr;              // saved BEFORE its dropout (the backward re-derives the mask)
                     if (p.dp > 0.f) pr = hash_uniform(p.seed_att, (unsigned long long)(pbase + j)) < p.dp ? 0.f : pr * keep;
@@ -235,6 +297,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(TrLayerP p) {
     }
     __syncthreads();
 
+    if (WIDE) load_w1();
     // W2 fragments of phase 6: requested only now — together with the attention's working set they exceeded the 256 registers of a wave
     // (28 spilled: a spilled prefetch register turns the asynchronous load into load-wait-store at its issue point)
 #pragma unroll
@@ -402,9 +465,11 @@ __global__ void __launch_bounds__(512) tr_ffn_bwd_kernel(TrFfnBwdP p) {
     lds_char* const red = dhb + 32 * TRF_HP;                   // [2][8 waves][256] fp32: parameter-gradient partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int w = blockIdx.x / TRF_NQ, hq = blockIdx.x % TRF_NQ;
-    const int S = p.S;
-    const long long row0 = (long long)w * S;
+    // every phase is row-wise: a window of 32 < S <= 64 rows is walked as two 32-row halves by two workgroups per hidden quarter (w = window, S = this half's rows)
+    const int hq = blockIdx.x % TRF_NQ, nh = (p.S + 31) >> 5, wh = blockIdx.x / TRF_NQ;
+    const int w = wh / nh, r0 = (wh % nh) * 32;
+    const int S = min(32, p.S - r0);
+    const long long row0 = (long long)w * p.S + r0;
     const bool lead = hq == 0;
     const bool mt1 = S > 16;
 
@@ -771,13 +836,18 @@ static inline void launch_tr_attn_bwd(hipStream_t st, const TrAttnBwdP& p) {
 static inline void launch_tr_ffn_bwd(hipStream_t st, const TrFfnBwdP& p) {
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)tr_ffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRB_LDS); attr_set = true; }
-    hipLaunchKernelGGL(tr_ffn_bwd_kernel, dim3(p.B * TRF_NQ), dim3(512), TRB_LDS, st, p);
+    hipLaunchKernelGGL(tr_ffn_bwd_kernel, dim3(p.B * ((p.S + 31) / 32) * TRF_NQ), dim3(512), TRB_LDS, st, p);
 }
 
 static inline void launch_tr_layer_fwd(hipStream_t st, const TrLayerP& p) {
     static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)tr_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRF_LDS); attr_set = true; }
-    hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(p.B * TRF_NQ), dim3(512), TRF_LDS, st, p);
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)tr_layer_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRF_LDS);
+        hipFuncSetAttribute((const void*)tr_layer_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRF_LDS_WIDE);
+        attr_set = true;
+    }
+    if (p.S > 32) hipLaunchKernelGGL(tr_layer_fwd_kernel<true>, dim3(p.B * 2 * TRF_NQ), dim3(512), TRF_LDS_WIDE, st, p);      // 32 < S <= 64: (window, half, quarter)
+    else hipLaunchKernelGGL(tr_layer_fwd_kernel<false>, dim3(p.B * TRF_NQ), dim3(512), TRF_LDS, st, p);
 }
 
 }  // namespace HULC_NS

@@ -352,7 +352,9 @@ def test_conv_reg_dgrad2(IH, Nf, mode):
 # dropout mask from the same (seed, step, site, element) hashes, so they apply identical masks: (a) may differ by summation order and by the
 # 16-bit roundings that move (tight), (b) by 16-bit rounding altogether (loose) — a wrong mask index, a dropped bias / residual or a mis-saved
 # tensor is an O(1) error in both.  The backward (unfused kernels everywhere) consumes what the fused forward saved: gradients must agree too.
-@pytest.mark.parametrize("B,S", [(1, 4), (3, 7), (2, 16), (3, 17), (8, 32)])
+# S > 32 (BASELINE config 5, max_window 64): the forward and the FFN half of the backward walk a window as two 32-row halves (tr_fused.h WIDE), the attention
+# half of the backward stays on the launch-per-op kernels: (2, 33) = a one-row second half, (3, 48) = a ragged one, (4, 64) = config 5's window.
+@pytest.mark.parametrize("B,S", [(1, 4), (3, 7), (2, 16), (3, 17), (8, 32), (2, 33), (3, 48), (4, 64)])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_fused_transformer_layer_matches_unfused_under_dropout(B, S, dtype):
     import sys, os
@@ -361,7 +363,7 @@ def test_fused_transformer_layer_matches_unfused_under_dropout(B, S, dtype):
     from hulc_amd.engine import StepEngine
     from hulc_amd.utils import synthetic
     from test_gpu_parity import to_dev
-    dims = spec.ModelDims(kind="gcbc", max_window=32, use_clip=True)       # GCBC + CLIP: the transformer is the only path into the loss's CLIP term
+    dims = spec.ModelDims(kind="gcbc", max_window=32 if S <= 32 else 64, use_clip=True)       # GCBC + CLIP: the transformer is the only path into the loss's CLIP term
     P = spec.init_all(dims, seed=13, ln_jitter=True)
     batch = synthetic.make_batch(0, B, S, seed=31)["lang"]
     res = {}
