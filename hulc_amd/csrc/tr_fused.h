@@ -1,4 +1,4 @@
-// hulc_amd/csrc/tr_fused.h — one plan-recognition transformer encoder layer, FORWARD, as ONE launch (16-bit engines, S <= 32).
+// hulc_amd/csrc/tr_fused.h — one plan-recognition transformer encoder layer, FORWARD, as ONE launch (16-bit engines; S <= 32, and 32 < S <= 64 as two 32-row halves per window: WIDE below).
 //
 // Reference: nn.TransformerEncoderLayer(d_model 128, 8 heads, dim_feedforward 2048, dropout p, post-LN, relu) as built by
 // hulc/models/plan_encoders/plan_recognition_net.py:78-92 and run at :112 —
