@@ -435,13 +435,19 @@ def main():
         if not tm or not dom_group:
             return None
         t = group_sum(tm, MFMA_GROUPS[dom_group])
-        t["bound"] = "mfma" if "mfma" in t["bounds"] else "hbm"
+        # Which roof binds is decided by the group's ARITHMETIC INTENSITY (algorithmic FLOPs / algorithmic bytes) against the machine's ridge point
+        # (dense MFMA peak / HBM peak = 312 FLOP/B in bf16): below the ridge the time floor bytes / 8 TB/s is the larger of the two floors.  conv2 / conv3 with
+        # 32 - 64 channels of 16-bit activations sit at 157 FLOP/B (conv2: 71 GFLOP over 453 MB per pass, conv3: 66.6 over 253 MB): the HBM roof binds, although
+        # every launch is a GEMM on the matrix cores; `other_roof` carries the fraction of the roof that does not bind.
         name = dom_group
         sec = t["ms"] * 1e-3
-        if t["bound"] == "mfma":
-            ach, peak, unit = t["flops"] / sec / 1e12, MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "fp16") else 157.3, "TFLOP/s"
-        else:
-            ach, peak, unit = t["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype in ("bf16", "fp16") else 157.3
+        ai, ridge = t["flops"] / max(t["bytes"], 1.0), peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+        t["bound"] = "mfma" if ai >= ridge else "hbm"
+        roofs = {"mfma": (t["flops"] / sec / 1e12, peak_tf, "TFLOP/s"), "hbm": (t["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s")}
+        ach, peak, unit = roofs[t["bound"]]
+        ob = "hbm" if t["bound"] == "mfma" else "mfma"
+        other = {"bound": ob, "achieved": round(roofs[ob][0], 2), "peak": roofs[ob][1], "unit": roofs[ob][2], "frac": round(roofs[ob][0] / roofs[ob][1], 4)}
         # HBM bytes per launch of this class from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, corrected as
         # MI355X_MICROARCH.md §HBM prescribes).  Counters cannot be collected from inside this process: the value is the one
         # tools/refresh_profiles.sh measured for the SAME build and command and committed as profiles/rNN_pmc_traffic.json (newest round);
@@ -461,6 +467,7 @@ def main():
         per_class = {c: {"ms_per_step": round(tm[c]["ms"] / tsteps, 4), "launches_per_step": tm[c]["launches"] / tsteps,
                          "achieved": round((tm[c]["flops"] / 1e12 if t["bound"] == "mfma" else tm[c]["bytes"] / 1e9) / max(tm[c]["ms"] * 1e-3, 1e-12), 2)} for c in t["classes"]}
         return {"kernel": name + " = " + " + ".join(t["classes"]), "classes": per_class, "bound": t["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1), "other_roof": other,
                 "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": t["launches"] / tsteps, "avg_launch_us": round(t["ms"] * 1e3 / max(1, t["launches"]), 2),
                 "ms_per_step": round(t["ms"] / tsteps, 4), "event_timed_steps": tsteps, "of_timed_steps": args.steps,
                 "per_launch": {"algorithmic_flops": t["flops"] / max(1, t["launches"]), "algorithmic_bytes": t["bytes"] / max(1, t["launches"])}}
