@@ -541,12 +541,14 @@ __global__ void __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) conv_reg_kernel(Co
 }
 
 // host side: band height for two resident bands (fewest bands), stacked frames for the gripper camera's small maps
+inline int g_conv_reg_wgpc = 0;      // tools/cr_bench.hip only: workgroups per CU the band geometry is sized for (0 = the form's own: 1 for 8 waves, 2 for 4)
 template <int CK, int TA, int TB, int SI, bool REV, int OS = 1, int NWV = 8, int NBUF_ = 0, bool PKR = false, int EPI = 0, int LDR = 0>
 static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     if (EPI && (!p.dump || (REV && (!p.maskbits || p.relu || p.mask))))       // the pipelined epilogue covers the production forms only
         return launch_conv_reg<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, 0, LDR>(st, p);
     using C = ConvRegCfg<CK, TA, TB, SI>;
-    constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1), WGPC = NWV == 8 ? 1 : 2;      // band buffers per workgroup, workgroups per CU
+    constexpr int NBUF = NBUF_ ? NBUF_ : (NWV == 8 ? 2 : 1);                                  // band buffers per workgroup
+    const int WGPC = g_conv_reg_wgpc ? g_conv_reg_wgpc : (NWV == 8 ? 1 : 2);                  // workgroups per CU
     if (p.IMW != p.IMH || p.OUTW != p.OUTH) return false;
     if (!REV && (p.mask || p.maskbits || !p.relu)) return false;
     const int NI = REV ? (p.OUTH + OS - 1) / OS : p.OUTH;      // output rows to cover (REV: class rows of the largest class)
@@ -589,7 +591,7 @@ static inline bool launch_conv_reg(hipStream_t st, ConvTileP p) {
     const size_t lds = C::lds_bytes(p.VPI, p.LP, NBUF, (size_t)p.MB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI, LDR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void*)conv_reg_kernel<CK, TA, TB, SI, REV, OS, NWV, NBUF_, PKR, EPI, LDR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / (NWV == 8 ? 1 : 2) - 64);
         attr_set = true;
     }
     const int items = p.FPB > 1 ? (p.Nf + p.FPB - 1) / p.FPB : p.Nf * p.nbands;

@@ -124,6 +124,15 @@ static void bench(const char* name, int Nf, int IMH, int OUTH, bool ablate) {
     FORME(4, 0, true, 1, "2 x 4 waves, pipelined epilogue (1) + slot registers");
     FORML(0, "6 compute + 2 LOADER waves");
     if constexpr (REV) FORML(1, "6 compute + 2 LOADER waves, pipelined epilogue");
+    // workgroups per CU: the band geometry sized for 3 / 4 co-resident 4-wave workgroups (53 / 40 KB of LDS each) and for 2 co-resident 8-wave ones
+    for (int wg : {3, 4}) {
+        g_conv_reg_wgpc = wg;
+        char lb[96]; snprintf(lb, sizeof(lb), "%d x 4 waves per CU, slot registers%s", wg, REV ? ", pipelined epilogue" : "");
+        if constexpr (REV) FORME(4, 0, true, 1, lb); else FORM(4, 0, true, lb);
+    }
+    g_conv_reg_wgpc = 2;
+    FORM(8, 0, true, "2 x 8 waves per CU (2 buffers each), slot registers");
+    g_conv_reg_wgpc = 0;
     if (ablate) {
         const int flags[] = {0, 4, 8, 16, 12, 20, 24, 2};
         const char* fn[] = {"full", "no-dma", "no-epilogue", "no-mfma", "mfma-only", "epilogue-only", "dma-only", "no-compute"};
