@@ -282,7 +282,8 @@ int hulc_set_dropout(hulc_ctx* ctx, float p);
  * hulc/models/decoders/utils/rnn.py:5-14; mcil's nn.RNN plan encoder, plan_recognition_net.py:12-42) run as ONE persistent launch per layer
  * and direction in the 16-bit engines (csrc/rnn_persist.h) — it needs every CU of the GPU; 0 = one launch per time step (choose this when
  * several processes share one GPU).  "fused_transformer" (default 1): one launch per plan-recognition encoder layer in the forward of the
- * 16-bit engines (csrc/tr_fused.h; plan_recognition_net.py:98-117), 0 = the unfused kernels.  Returns non-zero for an unknown name. */
+ * 16-bit engines (csrc/tr_fused.h; plan_recognition_net.py:98-117; windows of up to 64 rows), 0 = the unfused kernels.  "timer_event_fence"
+ * (default 0): 1 = the class timers below use default (system-fenced) HIP events instead of timing-only ones.  Returns non-zero for an unknown name. */
 int hulc_set_option(hulc_ctx* ctx, const char* name, int64_t value);
 /* Reads an option back.  Besides the settable names: "persistent_rnn" reports the EFFECTIVE state (0 once a persistent launch failed its census or
  * timed out — the context then runs one launch per time step; a failed launch never reaches the weights: its optimizer step skips itself on the
