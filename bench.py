@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--h2d", type=int, default=0, help="with --ingest u8: 1 = every step's uint8 frames come from PINNED HOST memory (async H2D on a copy stream into a "
                                                       "double buffer, overlapped with the previous step) — the PCIe-inclusive row SURVEY §8(d) asks for; never the headline `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="hulc_set_option(NAME, VALUE) before the run: same-box A/B of a library switch, e.g. adam_fused_transposes=0")
     ap.add_argument("--timer-stride", type=int, default=4, help="the live class timers record their HIP events on every N-th step of the timed region (1 = every step)")
     ap.add_argument("--live-timers", default="on", choices=["on", "fenced", "off"],
                     help="A/B of the measurement itself (never a reported configuration): 'on' (default) = the dominant group's kernel classes are timed by HIP events "
@@ -223,6 +224,9 @@ def main():
     paired = bool(args.lang) and bool(args.pair)
     eng = StepEngine(dims, B if paired else Bmod, S, dtype=args.dtype, device=str(dev), dropout_p=0.0 if mcil else 0.1, seed=42, num_classes=dims.mix_classes)
     eng.set_option("persistent_rnn", args.persist)
+    for kv in args.opt:                                  # same-box A/B of a library switch (hulc_set_option); never a reported configuration
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     eng.load_numpy(spec.init_all(dims, seed=0))      # identical weights on every rank (seeded init = the DDP broadcast)
     # N > 1: the library's own RCCL communicator (hulc_backward_allreduce: reverse-forward buckets overlapped with the backward); the
     # torch.distributed group above only carries the ncclUniqueId, the barriers and the timing reduction.  HULC_DP_COMM=capi (the default)

@@ -96,6 +96,59 @@ struct Engine : IEngine {
     bool bound = false;
     T* wshadow = nullptr;                 // bf16 mode: flat compute copy of all parameters (written by the Adam kernel)
     std::vector<TrDesc> trdesc; TrDesc* trdesc_dev = nullptr; int tr_blocks = 0; unsigned short* blk2desc_dev = nullptr;
+    // round 5: Adam writes the transposed copies of the Linear weights itself (kernels.h adam_tiled_kernel).  Two sub-tables of `trdesc`: the matrices that are plain
+    // views of the 16-bit shadow (tiled by the optimizer) and the rest (packed sources: the permuted fc7, the decoder heads — still transposed by prepare_weights)
+    struct TrTable { TrDesc* desc = nullptr; unsigned short* b2d = nullptr; int blocks = 0, n = 0; };
+    TrTable tr_adam, tr_rest;
+    long long* adam_chunk_start = nullptr; int* adam_chunk_n = nullptr; int adam_chunks = 0;
+    bool adam_fuse_tr = true;               // hulc_set_option "adam_fused_transposes"
+    void set_adam_fuse(bool on) override { adam_fuse_tr = on; }
+    bool tr_fresh = false;                  // set by optim(): the shadow-sourced transposed copies are those of the current parameters
+    void tr_table_free(TrTable& t) { if (t.desc) hipFree(t.desc); if (t.b2d) hipFree(t.b2d); t = TrTable{}; }
+    bool tr_table_build(TrTable& t, std::vector<TrDesc> v) {
+        tr_table_free(t);
+        int blk = 0;
+        for (TrDesc& d : v) { d.blk0 = blk; blk += d.tiles_x * cdiv(d.R, TRT); }
+        t.blocks = blk; t.n = (int)v.size();
+        if (v.empty()) return true;
+        std::vector<unsigned short> b2d((size_t)blk);
+        for (size_t i = 0; i < v.size(); ++i) { const int end = i + 1 < v.size() ? v[i + 1].blk0 : blk; for (int b = v[i].blk0; b < end; ++b) b2d[b] = (unsigned short)i; }
+        if (hipMalloc((void**)&t.desc, sizeof(TrDesc) * v.size()) != hipSuccess || hipMalloc((void**)&t.b2d, sizeof(unsigned short) * b2d.size()) != hipSuccess) return false;
+        hipMemcpy(t.desc, v.data(), sizeof(TrDesc) * v.size(), hipMemcpyHostToDevice);
+        hipMemcpy(t.b2d, b2d.data(), sizeof(unsigned short) * b2d.size(), hipMemcpyHostToDevice);
+        return true;
+    }
+    // the optimizer's tile / chunk tables: matrices of `trdesc` whose source is a contiguous [R][C] view of the shadow with 4-element alignment are tiled; the chunk
+    // list covers the rest of [0, numel)
+    void adam_tables_build() {
+        tr_table_free(tr_adam); tr_table_free(tr_rest);
+        if (adam_chunk_start) { hipFree(adam_chunk_start); adam_chunk_start = nullptr; } if (adam_chunk_n) { hipFree(adam_chunk_n); adam_chunk_n = nullptr; }
+        adam_chunks = 0;
+        if (std::is_same<T, float>::value || !wshadow || (numel & 3)) return;
+        std::vector<TrDesc> fused, rest;
+        std::vector<std::pair<long long, long long>> rng;
+        for (const TrDesc& d : trdesc) {
+            const T* src = (const T*)d.src;
+            const long long off = src - wshadow;
+            const bool in = src >= wshadow && off + (long long)d.R * d.C <= numel && d.lds == d.C && (d.C & 3) == 0 && (off & 3) == 0 && !d.cs;
+            if (in) { fused.push_back(d); rng.emplace_back(off, off + (long long)d.R * d.C); } else rest.push_back(d);
+        }
+        std::sort(rng.begin(), rng.end());
+        for (size_t i = 0; i + 1 < rng.size(); ++i) if (rng[i].second > rng[i + 1].first) return;       // overlapping views: keep the flat kernel
+        if (fused.empty() || fused.size() > 65535) return;
+        std::vector<long long> cs; std::vector<int> cn;
+        long long pos = 0;
+        auto cover = [&](long long lo, long long hi) { for (long long x = lo; x < hi; x += ADAM_CHUNK) { cs.push_back(x); cn.push_back((int)std::min<long long>(ADAM_CHUNK, hi - x)); } };
+        for (auto& r : rng) { cover(pos, r.first); pos = r.second; }
+        cover(pos, numel);
+        if (!tr_table_build(tr_adam, fused) || !tr_table_build(tr_rest, rest)) { tr_table_free(tr_adam); tr_table_free(tr_rest); return; }
+        adam_chunks = (int)cs.size();
+        if (adam_chunks) {
+            if (hipMalloc((void**)&adam_chunk_start, sizeof(long long) * cs.size()) != hipSuccess || hipMalloc((void**)&adam_chunk_n, sizeof(int) * cn.size()) != hipSuccess) { tr_table_free(tr_adam); tr_table_free(tr_rest); adam_chunks = 0; return; }
+            hipMemcpy(adam_chunk_start, cs.data(), sizeof(long long) * cs.size(), hipMemcpyHostToDevice);
+            hipMemcpy(adam_chunk_n, cn.data(), sizeof(int) * cn.size(), hipMemcpyHostToDevice);
+        }
+    }
 
     // ---- workspace (per modality pass)
     struct EncA { T *a1, *a2, *a3, *ss, *g0, *f1; float *ssstats, *f2, *lnst; unsigned* m1bits = nullptr; unsigned* m2bits = nullptr; } aS, aG;
@@ -130,7 +183,7 @@ struct Engine : IEngine {
         KIN = dec_plan + DE + GOAL;
         maxB = cfg.max_batch; maxS = cfg.max_seq; maxN = maxB * maxS;
     }
-    ~Engine() override { for (void* p : allocs) hipFree(p); if (rp_err_host) hipHostFree((void*)rp_err_host); if (blk2desc_dev) hipFree(blk2desc_dev); if (trdesc_dev) hipFree(trdesc_dev); }
+    ~Engine() override { for (void* p : allocs) hipFree(p); if (rp_err_host) hipHostFree((void*)rp_err_host); if (blk2desc_dev) hipFree(blk2desc_dev); if (trdesc_dev) hipFree(trdesc_dev); tr_table_free(tr_adam); tr_table_free(tr_rest); if (adam_chunk_start) hipFree(adam_chunk_start); if (adam_chunk_n) hipFree(adam_chunk_n); }
     int64_t workspace_bytes() const override { return ws_bytes; }
     void set_kl_beta(float b) override { cfg.kl_beta = b; }
     void set_dropout(float p) override { cfg.dropout_p = p; }
@@ -397,6 +450,7 @@ struct Engine : IEngine {
         if (trdesc_dev) { hipFree(trdesc_dev); trdesc_dev = nullptr; }
         if (hipMalloc((void**)&trdesc_dev, sizeof(TrDesc) * trdesc.size()) != hipSuccess) alloc_failed = true;
         else hipMemcpy(trdesc_dev, trdesc.data(), sizeof(TrDesc) * trdesc.size(), hipMemcpyHostToDevice);
+        adam_tables_build();
         if (alloc_failed) { hulc_set_error("hipMalloc failed while allocating weight copies"); return 1; }
         bound = true;
         return prepare_weights();
@@ -605,7 +659,11 @@ struct Engine : IEngine {
         }
         // ... then every transposed copy — the Linear weights, the permuted fc7 and the packed heads — in ONE batched launch
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
+        else if (tr_fresh && tr_adam.n) {      // the optimizer wrote the shadow-sourced transposed copies (adam_tiled_kernel): only the packed sources are left
+            if (tr_rest.blocks) hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_rest.blocks), dim3(256), 0, st, tr_rest.desc, tr_rest.n, (const unsigned short*)tr_rest.b2d);
+        }
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
+        tr_fresh = false;
         if constexpr (std::is_same<T, h16_t>::value) {
             if (fragbatch.n) hipLaunchKernelGGL(frag_pack_kernel, dim3(frag_blocks), dim3(256), 0, st, fragbatch);
         }
@@ -2668,7 +2726,12 @@ struct Engine : IEngine {
         if (o.kind == HULC_OPT_SGD)
             hipLaunchKernelGGL(sgd_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, (long long)numel, lr, o.momentum, o.dampening, o.weight_decay, (int)(o.nesterov != 0),
                                (int)(step == 1), gscale, shadow, (const ScalerState*)scaler, (const unsigned*)rp_skip, tag);
-        else
+        else if (adam_fuse_tr && tr_adam.n && shadow) {
+            AdamArgs a{P, G, AM, AV, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale, o.weight_decay, (int)(o.kind == HULC_OPT_ADAMW), shadow, (const ScalerState*)scaler, (const unsigned*)rp_skip, tag};
+            hipLaunchKernelGGL(adam_tiled_kernel, dim3(tr_adam.blocks + adam_chunks), dim3(256), 0, st, a, (const TrDesc*)tr_adam.desc, (const unsigned short*)tr_adam.b2d, tr_adam.blocks,
+                               (const long long*)adam_chunk_start, (const int*)adam_chunk_n);
+            tr_fresh = true;
+        } else
             hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, st, P, G, AM, AV, (long long)numel, lr, b1, b2, eps, (float)bc1d, (float)sqrt(bc2d), gscale,
                                shadow, (const ScalerState*)scaler, o.weight_decay, (int)(o.kind == HULC_OPT_ADAMW), (const unsigned*)rp_skip, tag);
         if (scaler) hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, st, scaler, (const unsigned*)rp_skip, tag);

@@ -81,6 +81,7 @@ struct IEngine {
     int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
+    virtual void set_adam_fuse(bool on) = 0;
     int set_option(const char* name, long long value) {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
         if (name && !strcmp(name, "fused_transformer")) { tr_fused_mode = value != 0; return 0; }
@@ -88,6 +89,8 @@ struct IEngine {
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
         if (name && !strcmp(name, "lazy_zero_grads")) { lazy_zero_mode = value != 0; return 0; }
+        // "adam_fused_transposes" (default 1; 16-bit engines): the Adam / AdamW step writes the transposed 16-bit weight copies itself (kernels.h adam_tiled_kernel); 0 = flat pass + batched transpose
+        if (name && !strcmp(name, "adam_fused_transposes")) { set_adam_fuse(value != 0); return 0; }
         if (name && !strcmp(name, "timer_event_fence")) { event_flags = value != 0 ? hipEventDefault : hipEventDisableSystemFence; for (auto& kv : timers) { for (auto& ev : kv.second.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } kv.second.ev.clear(); kv.second.used = 0; } return 0; }
         // "u8_fold": 1 (default; 16-bit engines) = the uint8 ingest path multiplies the exact byte values and applies x = u (2/255) - 1 in conv1's epilogue /
         // weight-gradient slabs (conv_wgrad.h Conv1Src::fold); 0 = the value x itself is staged (16-bit rounded), as in rounds 2 - 4

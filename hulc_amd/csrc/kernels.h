@@ -64,11 +64,12 @@ __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __
 
 // 64x64-tile bf16 transpose: 16-byte global accesses on both sides (the 32x32 element-wise tile above moves 64-byte row
 // segments: 1.6 TB/s on the 94 MB weight set); falls back to guarded element accesses on ragged / unaligned tiles.
+DEVI void transpose_tile64_store(const TrDesc& D, int b, unsigned short (*tile)[66]);
 DEVI void transpose_tile64_h16(const TrDesc& D, int b, unsigned short (*tile)[66]) {
     const int c0 = (b % D.tiles_x) * 64, r0 = (b / D.tiles_x) * 64;
     const h16_t* src = reinterpret_cast<const h16_t*>(D.src);
     h16_t* dst = reinterpret_cast<h16_t*>(D.dst);
-    const bool vin = (D.lds % 8) == 0 && ((uintptr_t)src % 16) == 0, vout = (D.ldt % 8) == 0 && ((uintptr_t)dst % 16) == 0;
+    const bool vin = (D.lds % 8) == 0 && ((uintptr_t)src % 16) == 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = threadIdx.x + i * 256, row = q >> 3, cc = (q & 7) * 8;
@@ -84,6 +85,13 @@ DEVI void transpose_tile64_h16(const TrDesc& D, int b, unsigned short (*tile)[66
         for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(&tile[row][cc + 2 * e]) = (unsigned)v[2 * e] | ((unsigned)v[2 * e + 1] << 16);
     }
     __syncthreads();
+    transpose_tile64_store(D, b, tile);
+}
+// second half of a 64 x 64 16-bit tile transpose: the tile is in LDS (behind a barrier), pad rows / columns zero
+DEVI void transpose_tile64_store(const TrDesc& D, int b, unsigned short (*tile)[66]) {
+    const int c0 = (b % D.tiles_x) * 64, r0 = (b / D.tiles_x) * 64;
+    h16_t* dst = reinterpret_cast<h16_t*>(D.dst);
+    const bool vout = (D.ldt % 8) == 0 && ((uintptr_t)dst % 16) == 0;
     if (D.cs && threadIdx.x < 64 && c0 + (int)threadIdx.x < D.C) {      // fused bias gradient: column sums of this tile (pad rows are zeros)
         float sum = 0.f;
 #pragma unroll 16
@@ -2225,6 +2233,44 @@ __global__ void scaler_update_kernel(ScalerState* __restrict__ ss, const unsigne
 }
 
 // wd != 0: torch.optim.Adam's L2 term (g += wd p; decoupled = 0) or torch.optim.AdamW's decoupled decay (p *= 1 - lr wd before the update)
+struct AdamArgs { float* p; const float* g; float* m; float* v; float lr, b1, b2, eps, bc1, bc2_sqrt, gscale, wd; int decoupled; h16_t* shadow; const ScalerState* ss; const unsigned* skip; unsigned tag; };
+// one element quad of the Adam / AdamW step.  Floating-point contraction is OFF in here: the flat and the tiled kernel must produce the same bits, and whether
+// the compiler fuses a multiply into a following add is otherwise its choice per call site (measured: 342 k of 46 M parameters differed by one ulp after 3 steps)
+struct AdamQuad { float4 pp, gg, mm, vv; };
+DEVI void adam_load4(const AdamArgs& a, long long i, AdamQuad& q) {
+    typedef float f32x4nt __attribute__((ext_vector_type(4)));
+    q.pp = *reinterpret_cast<const float4*>(a.p + i);
+    { const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.g + i)); q.gg = make_float4(t[0], t[1], t[2], t[3]); }
+    { const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.m + i)); q.mm = make_float4(t[0], t[1], t[2], t[3]); }
+    { const f32x4nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(a.v + i)); q.vv = make_float4(t[0], t[1], t[2], t[3]); }
+}
+DEVI void adam_finish4(const AdamArgs& a, float bc1, float bc2_sqrt, float gscale, long long i, AdamQuad& q, unsigned& lo, unsigned& hi) {
+#pragma clang fp contract(off)
+    typedef float f32x4nt __attribute__((ext_vector_type(4)));
+    float4 &pp = q.pp, &gg = q.gg, &mm = q.mm, &vv = q.vv;
+    float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float gr = G[e] * gscale;
+        if (a.wd != 0.f) {
+            if (a.decoupled) P[e] *= 1.f - a.lr * a.wd;
+            else gr += a.wd * P[e];
+        }
+        Mv[e] = a.b1 * Mv[e] + (1.f - a.b1) * gr;
+        V[e] = a.b2 * V[e] + (1.f - a.b2) * gr * gr;
+        P[e] -= (a.lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + a.eps);
+    }
+    *reinterpret_cast<float4*>(a.p + i) = pp;
+    lo = pack2h(pp.x, pp.y); hi = pack2h(pp.z, pp.w);
+    if (a.shadow) *reinterpret_cast<uint2*>(a.shadow + i) = uint2{lo, hi};
+    __builtin_nontemporal_store(f32x4nt{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f32x4nt*>(a.m + i));
+    __builtin_nontemporal_store(f32x4nt{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4nt*>(a.v + i));
+}
+DEVI void adam_update4(const AdamArgs& a, float bc1, float bc2_sqrt, float gscale, long long i, unsigned& lo, unsigned& hi) {
+    AdamQuad q;
+    adam_load4(a, i, q);
+    adam_finish4(a, bc1, bc2_sqrt, gscale, i, q, lo, hi);
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, h16_t* __restrict__ shadow,
                             const ScalerState* __restrict__ ss = nullptr, float wd = 0.f, int decoupled = 0, const unsigned* __restrict__ skip = nullptr,
@@ -2237,37 +2283,62 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         bc1 = 1.f - powf(b1, t);
         bc2_sqrt = sqrtf(1.f - powf(b2, t));
     }
+    // gradient and moments are touched once per step: non-temporal loads / stores keep them from displacing the parameters and their
+    // 16-bit shadow (read next by the weight repacks and the forward) in the L2 / memory-side cache (same-box A/B: -0.014 ms/step)
+    const AdamArgs a{p, g, m, v, lr, b1, b2, eps, bc1, bc2_sqrt, gscale, wd, decoupled, shadow, ss, skip, tag};
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const long long stride = (long long)gridDim.x * blockDim.x * 4;
-    typedef float f32x4nt __attribute__((ext_vector_type(4)));
-    for (; i + 3 < n; i += stride) {
-        // gradient and moments are touched once per step: non-temporal loads / stores keep them from displacing the parameters and their
-        // 16-bit shadow (read next by the weight repacks and the forward) in the L2 / memory-side cache (same-box A/B: -0.014 ms/step)
-        float4 pp = *reinterpret_cast<float4*>(p + i), gg, mm, vv;
-        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(g + i)); gg = make_float4(a[0], a[1], a[2], a[3]); }
-        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(m + i)); mm = make_float4(a[0], a[1], a[2], a[3]); }
-        { const f32x4nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(v + i)); vv = make_float4(a[0], a[1], a[2], a[3]); }
-        float* P = &pp.x; float* G = &gg.x; float* Mv = &mm.x; float* V = &vv.x;
+    for (; i + 3 < n; i += stride) { unsigned lo, hi; adam_update4(a, bc1, bc2_sqrt, gscale, i, lo, hi); }
+}
+
+// Adam with the TRANSPOSED 16-bit weight copies written by the same pass (16-bit engines, round 5).  The backward's data-gradient GEMMs read W^T; until round 4 a
+// batched transpose re-read the fresh 16-bit shadow (94 MB) after every optimizer step and wrote 94 MB (37 us).  Here the Linear weights that have a transposed copy
+// are updated tile-wise: block = one 64 x 64 tile of one matrix (the batched transpose's own block -> tile map: TrDesc, blk2desc): p / g / m / v are read and written
+// as 16 rows x 256 contiguous bytes per pass (same per-element arithmetic and the same non-temporal hints as adam_kernel), the 16-bit values go to the shadow AND
+// into an LDS tile whose read-out is the transpose's (transpose_tile64_store).  Everything else — biases, LayerNorm and conv weights, matrices without a transposed
+// copy — is covered by 4096-element CHUNK blocks behind the tile blocks (chunk table built at bind time: the complement of the tiled matrices in the flat buffer).
+constexpr int ADAM_CHUNK = 4096;
+__global__ void __launch_bounds__(256) adam_tiled_kernel(AdamArgs a, const TrDesc* __restrict__ desc, const unsigned short* __restrict__ blk2desc, int ntile,
+                                                         const long long* __restrict__ chunk_start, const int* __restrict__ chunk_n) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
+    if (a.skip && *a.skip == a.tag) return;
+    float gscale = a.gscale, bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt;
+    if (a.ss) {
+        if (a.ss->found_inf) return;
+        gscale /= a.ss->scale;
+        const float t = (float)(a.ss->steps + 1);
+        bc1 = 1.f - powf(a.b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(a.b2, t));
+    }
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < ntile) {
+        const TrDesc D = desc[blk2desc[blockIdx.x]];
+        const int b = blockIdx.x - D.blk0;
+        const int c0 = (b % D.tiles_x) * 64, r0 = (b / D.tiles_x) * 64;
+        const long long off = reinterpret_cast<const h16_t*>(D.src) - a.shadow;       // the matrix's offset in the flat parameter buffer
+        // all four passes' 16 loads are requested before the first update (64 registers): the tile's 64 KB of p / g / m / v are in flight together
+        const int cc = (tid & 15) * 4, c = c0 + cc;
+        AdamQuad q[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float gr = G[e] * gscale;
-            if (wd != 0.f) {                    // uniform
-                if (decoupled) P[e] *= 1.f - lr * wd;
-                else gr += wd * P[e];
-            }
-            Mv[e] = b1 * Mv[e] + (1.f - b1) * gr;
-            V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
-            P[e] -= (lr / bc1) * Mv[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = r0 + ps * 16 + (tid >> 4);
+            if (r < D.R && c < D.C) adam_load4(a, off + (long long)r * D.C + c, q[ps]);       // C % 4 == 0 (checked at bind)
         }
-        *reinterpret_cast<float4*>(p + i) = pp;
-        if (shadow) {      // 16-bit compute copy of the parameters, refreshed in the same pass
-            uint2 o;
-            o.x = pack2h(pp.x, pp.y);
-            o.y = pack2h(pp.z, pp.w);
-            *reinterpret_cast<uint2*>(shadow + i) = o;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 16 + (tid >> 4), r = r0 + row;
+            unsigned lo = 0u, hi = 0u;
+            if (r < D.R && c < D.C) adam_finish4(a, bc1, bc2_sqrt, gscale, off + (long long)r * D.C + c, q[ps], lo, hi);
+            *reinterpret_cast<unsigned*>(&tile[row][cc]) = lo;
+            *reinterpret_cast<unsigned*>(&tile[row][cc + 2]) = hi;
         }
-        __builtin_nontemporal_store(f32x4nt{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f32x4nt*>(m + i));
-        __builtin_nontemporal_store(f32x4nt{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4nt*>(v + i));
+        __syncthreads();
+        transpose_tile64_store(D, b, tile);
+    } else {
+        const int j = blockIdx.x - ntile;
+        const long long start = chunk_start[j];
+        const int n = chunk_n[j];
+        for (int i = tid * 4; i + 3 < n; i += 1024) { unsigned lo, hi; adam_update4(a, bc1, bc2_sqrt, gscale, start + i, lo, hi); }
     }
 }
 

@@ -61,7 +61,7 @@ files = f"""| file | what | command |
 | `{T}_bench_n1_mcil.json` | `model=mcil` (BiRNN plan recognition): {var['mcil']['value']:.0f} windows/s, {var['mcil']['ms_per_step']} ms/step | `python bench.py --model mcil --no-cpu-baseline` |
 | `{T}_bench_n1_mcil_gru.json` | `rnn_type=nn.GRU` (BASELINE config 4's GRU plan encoder): {var['mcil_gru']['value']:.0f} windows/s, {var['mcil_gru']['ms_per_step']} ms/step (round 1: 12.44 ms) | `python bench.py --model mcil_gru --no-cpu-baseline` |
 | `{T}_kernel_stats.csv`, `{T}_kernel_stats_summary.txt` | rocprofv3 per-kernel stats of the bench command (9 steps: 2 warm-up + 2 survey + 5 timed), top 45 per step | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --preroll 0 --no-cpu-baseline`, `tools/prof_summary.py` |
-| `{T}_pmc_hbm_per_kernel.csv`, `{T}_pmc_traffic.json` | FETCH_SIZE / WRITE_SIZE per dispatch (two separate `--pmc` passes) and the per-launch HBM bytes per kernel class, `(2 x FETCH_SIZE + WRITE_SIZE) x 1024` (MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE reports half of a wide coalesced read; calibration: `adam` reads 5 and writes 3.5 arrays of 47.05 M fp32 = 1.41 GB algorithmic against {t.get('adam', 0) / 1e9:.2f} GB measured); every dispatch is counted in the FIRST class it matches, so the recurrent-step dispatches (keyed by their grid) are not in `skinny_gemm`; `bench.py` reports the dominant class's value as `roofline.traffic` | `tools/pmc_traffic.py` |
+| `{T}_pmc_hbm_per_kernel.csv`, `{T}_pmc_traffic.json` | FETCH_SIZE / WRITE_SIZE per dispatch (two separate `--pmc` passes) and the per-launch HBM bytes per kernel class, `(2 x FETCH_SIZE + WRITE_SIZE) x 1024` (MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE reports half of a wide coalesced read; calibration: `adam` reads 5 and writes 3.5 arrays of 47.05 M fp32 = 1.41 GB algorithmic (+ 0.07 GB of transposed 16-bit copies since round 5) against {t.get('adam', 0) / 1e9:.2f} GB measured); every dispatch is counted in the FIRST class it matches, so the recurrent-step dispatches (keyed by their grid) are not in `skinny_gemm`; `bench.py` reports the dominant class's value as `roofline.traffic` | `tools/pmc_traffic.py` |
 | `{T}_mfma_util.csv`, `{T}_mfma_util_summary.txt` | per kernel: MFMA-pipe utilisation, `SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES`, MFMA TFLOP/s from `SQ_INSTS_VALU_MFMA_MOPS_BF16`, LDS bank-conflict rate (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE`), wait breakdown — two SQ passes of 8 counters | `tools/pmc_sq.sh`, `tools/pmc_sq_summary.py` |
 | `{T}_step_sequence.txt` | every launch of ONE step in order (consecutive identical launches collapsed) from the same kernel trace: launches per step, which memsets / transposes / small kernels remain and how long each takes.  The per-step call counts of `{T}_kernel_stats_summary.txt` divide a 9-step profile that also holds the engine's one-time workspace zero-fills (≈160 `fillBufferAligned`) and bench.py's input generation; a step itself issues 3 memsets (gradient buffer, loss slots, the backward's zero arena) | `tools/step_seq.py` |
 | `{T}_bench_n1_fp32.json` | the fp32 PARITY engine (exact-fp32 MFMA, `v_mfma_f32_16x16x4_f32`: 1/16 of the bf16 matrix rate): {var['fp32']['value']:.0f} windows/s, {var['fp32']['ms_per_step']} ms/step | `python bench.py --dtype fp32 --steps 20 --no-cpu-baseline` |

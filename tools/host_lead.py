@@ -6,7 +6,7 @@ print("hip api columns", list(ha[0].keys()))
 api = {r["Correlation_Id"]: r for r in ha}
 kt.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last full step: find the last adam_kernel, walk back to the previous one
-idx = [i for i, r in enumerate(kt) if "adam_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(kt) if ("adam_kernel" in r["Kernel_Name"] or "adam_tiled_kernel" in r["Kernel_Name"])]
 lo, hi = idx[-2] + 1, idx[-1] + 1
 prev_end = int(kt[lo - 1]["End_Timestamp"])
 t0 = int(kt[lo]["Start_Timestamp"])

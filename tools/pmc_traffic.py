@@ -10,7 +10,7 @@ d = sys.argv[1]
 # parameter: "false>(" no longer matched "false, 8>("): the REV flag is matched as ", false," / ", true," anywhere in the argument list
 CLASSES = [("rnn_persist", ("rnn_persist_kernel",)), ("rnn_step_gemm", (("skinny_lds_kernel<2, 4, 16, false>", "[grid=262144]"), ("skinny_lds_kernel<2, 8>", "[grid=131072]"))), ("skinny_gemm", ("skinny_lds_kernel", "skinny_gemm_kernel")), ("gemm_128x128", ("gemm_glds_kernel", "gemm_kernel<unsigned short, 128, 128", "gemm_kernel<h16, 128, 128")),
            ("conv1_fwd", ("conv1_fwd_kernel",)), ("conv1_wgrad", ("conv1_wgrad_tr",)), ("conv_wgrad_tr", ("conv_wgrad_tr8_kernel", "conv_wgrad_tr_kernel<", "conv_wgrad_dma_kernel")),
-           ("conv_tile_fwd", (("conv_reg_kernel<", ", false,"), ("conv_tile_kernel<", ", false,"))), ("conv_tile_dgrad", (("conv_reg_kernel<", ", true,"), ("conv_tile_kernel<", ", true,"))), ("adam", ("adam_kernel",))]
+           ("conv_tile_fwd", (("conv_reg_kernel<", ", false,"), ("conv_tile_kernel<", ", false,"))), ("conv_tile_dgrad", (("conv_reg_kernel<", ", true,"), ("conv_tile_kernel<", ", true,"))), ("adam", ("adam_kernel", "adam_tiled_kernel"))]
 per = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob(f"{d}/pmc_{name}/**/*counter_collection.csv", recursive=True)

@@ -3,7 +3,7 @@ import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] or "adam_tiled_kernel" in r["Kernel_Name"])]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 d = collections.defaultdict(lambda: [0.0, 0])
 for r in step:

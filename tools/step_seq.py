@@ -4,7 +4,7 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] or "adam_tiled_kernel" in r["Kernel_Name"])]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 short = lambda n: n.replace("hulc_bf16::", "").replace("hulc_f16::", "").replace("void ", "").split("(")[0][:80]
 out = []

@@ -6,7 +6,7 @@ f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 start_at = sys.argv[2] if len(sys.argv) > 2 else ""
 maxn = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] or "adam_tiled_kernel" in r["Kernel_Name"])]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 short = lambda n: n.replace("hulc_bf16::", "").replace("hulc_f16::", "").replace("void ", "").split("(")[0][:60]
 t0 = int(step[0]["Start_Timestamp"])
