@@ -165,6 +165,7 @@ struct Engine : IEngine {
     float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
     T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
     T *tA, *tB; int64_t tcap;
+    T* tB2 = nullptr;                       // second transposed-operand buffer (the paired layer-1 weight-gradient GEMM reads H1^T and H0^T at once)
     float *part; int64_t partcap; float* cspart;
     // clip
     int* auxrows; T *sf_m, *im1, *g_m, *la1, *img_t, *txt_t; float *img, *txt, *dimg, *dtxt, *dsf_m, *dg_m; T *dimg_t, *dtxt_t, *dim1, *dla1;
@@ -2455,10 +2456,29 @@ struct Engine : IEngine {
                 const int mp = ldpad(SB);
                 constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // 16-bit engines: the dZ transpose adds its column sums (= both bias gradients) on the way
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp, fuse_cs ? dbih1 : nullptr, fuse_cs ? dbhh1 : nullptr);
+                bool paired = false;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    // dW_hh1 = dZ1[1:]^T H1[:-1] and dW_ih1 = dZ1^T H0 share dZ1^T up to a shift of one time step (B tokens): ONE launch that streams it once
+                    // (gemm.h gemm_glds_pair_kernel: 1.5 MB per CU instead of 2 x 1 MB); needs H0^T next to H1^T (tB2) and B % 64 == 0
+                    const bool pair_sw = gemm_pair_mode;          // hulc_set_option "gemm_pair" (default 0: measured slower than the two launches)
+                    EpiP e1 = epi(whh1.dW, true), e2 = epi(wih1.dW, true);
+                    if (pair_sw && gemm_use_glds && S > 1 && gemm_glds_pair_ok(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense<T>(tB, HID, mp), e1, e2, HID, HID, SB, B)) {
+                        if (!tB2) tB2 = alloc<T>(tcap);
+                        if (tB2) {
+                            cast_tr<T, T>(H0, HID, nullptr, 0, tB2, mp, SB, HID);
+                            e1.accumulate = grad_first(whh1.dW) ? 0 : 1; e2.accumulate = grad_first(wih1.dW) ? 0 : 1;
+                            TimerScope ts(this, "gemm_128x128", "mfma", 2.0 * HID * HID * ((double)SB + (double)(S - 1) * B), (3.0 * HID * SB) * sizeof(T) + 8.0 * HID * HID, 1);
+                            launch_gemm_glds_pair(st, dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense<T>(tB2, HID, mp), dense_out(HID), e1, e2, HID, HID, SB, B);
+                            paired = true;
+                        }
+                    }
+                }
+                if (!paired) {
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = grad_first(whh1.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
                 { EpiP ep = epi(wih1.dW, true); ep.accumulate = grad_first(wih1.dW) ? 0 : 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
+                }
                 if (!fuse_cs) colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
             }
             { EpiP ep = epi(dH0, false); ep.out2 = dZ0 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H0 + lastBH;

@@ -693,6 +693,130 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------
+// TWO NT GEMMs that share their A operand up to a shift along K, as one launch (round 5):
+//     C1[m][n] = sum_{k = sh}^{K-1} A[m][k] B1[n][k - sh]          C2[m][n] = sum_{k = 0}^{K-1} A[m][k] B2[n][k]
+// — the two weight gradients of the decoder's layer 1, dW_hh1 = dZ1[1:]^T H1[:-1] and dW_ih1 = dZ1^T H0 (A = dZ1^T, k = (t, b) token, sh = B tokens = one
+// time step).  gemm_glds_kernel is bound by the bytes a CU pulls through its load path (1 MB per 128 x 128 tile at K = 2048 -> ~28 us); here a workgroup owns
+// the 128 x 128 tile of BOTH outputs and streams A once: 1.5 MB for what took 2 MB.  Same ring, swizzle and counted waits as above with three operands per
+// stage (48 KB x 3 stages = 144 KB of LDS); sh and K are multiples of the 64-wide k-step, so B1's stage kt is simply B1's own step kt - sh / 64 (the first
+// sh / 64 steps fetch a valid dummy stage and skip B1's MFMAs).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) gemm_glds_pair_kernel(DenseLoader<h16_t> al, DenseLoader<h16_t> bl1, DenseLoader<h16_t> bl2, DenseOut om, EpiP ep1, EpiP ep2,
+                                                           int M, int N, int K, int shs, int tiles_m, int tiles_n) {
+    constexpr int NST = 3, NW = 8, STAGE = 48 * 1024, PW = 2, TM = 2, WROWS = 32;
+    extern __shared__ __attribute__((aligned(16))) char gg_smem[];
+    typedef __attribute__((address_space(3))) char lchar;
+    lchar* lds = (lchar*)gg_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    int tm, tn;
+    {
+        const int nt = tiles_m * tiles_n, per = nt / 8, rem = nt % 8;
+        const int x = blockIdx.x % 8, q = blockIdx.x / 8;
+        const int tile = x * per + min(x, rem) + q;
+        constexpr int GM = 4;
+        const int gsz = GM * tiles_n, grp = tile / gsz, first_m = grp * GM, gm = min(GM, tiles_m - first_m);
+        tm = first_m + (tile % gsz) % gm;
+        tn = (tile % gsz) / gm;
+    }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int r = lane >> 3, cs = (lane & 7) ^ (r & 6);
+    const h16_t* asrc[PW];
+    const h16_t* b1src[PW];
+    const h16_t* b2src[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        asrc[j] = al.row(min(m0 + (wave * PW + j) * 8 + r, M - 1), 0).base + cs * 8;
+        b1src[j] = bl1.row(min(n0 + (wave * PW + j) * 8 + r, N - 1), 0).base + cs * 8;
+        b2src[j] = bl2.row(min(n0 + (wave * PW + j) * 8 + r, N - 1), 0).base + cs * 8;
+    }
+    const int nk = K >> 6;
+    auto issue = [&](int kt, int buf) {
+        lchar* st = lds + buf * STAGE + wave * PW * 1024;
+        const long long ko = (long long)kt * 64, ko1 = (long long)max(kt - shs, 0) * 64;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + ko), (__attribute__((address_space(3))) void*)(st + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1src[j] + ko1), (__attribute__((address_space(3))) void*)(st + 16384 + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b2src[j] + ko), (__attribute__((address_space(3))) void*)(st + 32768 + j * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc1[TM][4], acc2[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int wm = wave >> 1, wn = wave & 1;
+    const int foff = (li >> 3) * 1024 + (li & 7) * 128;
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+        if (j < nk) issue(j, j);
+    int buf = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(NST - 2, nk - 1 - kt);             // stages in flight behind stage kt: 3 * PW = 6 DMA instructions per wave each
+        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + NST - 1 < nk) issue(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+        lchar* sa = lds + buf * STAGE + wm * (WROWS / 8) * 1024 + foff;
+        lchar* sb1 = lds + buf * STAGE + 16384 + wn * 8192 + foff;
+        lchar* sb2 = lds + buf * STAGE + 32768 + wn * 8192 + foff;
+        const bool with1 = kt >= shs;
+#pragma unroll 1
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = (((kk << 2) + g) ^ (li & 6)) << 4;
+            h16x8_t a[TM], b[4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(__attribute__((address_space(3))) h16x8_t*)(sa + i * 2048 + chunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb2 + j * 2048 + chunk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[i][j] = MFMA_16x16x32_H(b[j], a[i], acc2[i][j], 0, 0, 0);
+            if (with1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb1 + j * 2048 + chunk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc1[i][j] = MFMA_16x16x32_H(b[j], a[i], acc1[i][j], 0, 0, 0);
+            }
+        }
+        buf = buf == NST - 1 ? 0 : buf + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WROWS + i * 16 + li;
+        if (row < M) {
+            const long long obase = om.offset(row, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + g * 4;
+                if (col < N) {
+                    const float v1[4] = {acc1[i][j][0], acc1[i][j][1], acc1[i][j][2], acc1[i][j][3]};
+                    epi_store4<h16_t>(ep1, v1, row, col, N, obase + col);
+                    const float v2[4] = {acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]};
+                    epi_store4<h16_t>(ep2, v2, row, col, N, obase + col);
+                }
+            }
+        }
+    }
+}
+// both outputs [M][N] through the same DenseOut; plain epilogues only (fp32 store / accumulate: the weight-gradient form)
+static inline bool gemm_glds_pair_ok(const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b1, const DenseLoader<h16_t>& b2, const EpiP& ep1, const EpiP& ep2, int M, int N, int K, int sh) {
+    auto row_ok = [](const DenseLoader<h16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0 && l.R1 == 0x7fffffff; };
+    auto plain = [](const EpiP& e) { return e.out_f32 && !e.atomic && e.z_stride == 0 && !e.bias && !e.bias2 && !e.res && !e.mask && !e.relu && e.drop_p == 0.f && !e.out2; };
+    return K >= 192 && (K % 64) == 0 && sh > 0 && (sh % 64) == 0 && sh < K && (M % 128) == 0 && (N % 128) == 0 && row_ok(a) && row_ok(b1) && row_ok(b2) && plain(ep1) && plain(ep2);
+}
+static inline void launch_gemm_glds_pair(hipStream_t st, const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b1, const DenseLoader<h16_t>& b2, const DenseOut& om, const EpiP& ep1,
+                                         const EpiP& ep2, int M, int N, int K, int sh) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr_set = true; }
+    const int tiles_m = M / 128, tiles_n = N / 128;
+    hipLaunchKernelGGL(gemm_glds_pair_kernel, dim3(tiles_m * tiles_n), dim3(512), 144 * 1024, st, a, b1, b2, om, ep1, ep2, M, N, K, sh / 64, tiles_m, tiles_n);
+}
 static inline bool gemm_glds_ok(const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b, const EpiP& ep, int M, int N, int K) {
     auto row_ok = [](const DenseLoader<h16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0; };
     return K >= 64 && (K % 32) == 0 && ep.z_stride == 0 && row_ok(a) && row_ok(b);

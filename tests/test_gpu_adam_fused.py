@@ -72,3 +72,32 @@ def test_adam_that_writes_the_transposed_copies_equals_flat_pass_plus_transpose(
         if den > 1e-12 and float((x - y).norm()) / den > 2e-3:
             bad.append((n, float((x - y).norm()) / den))
     assert not bad, bad[:5]
+
+
+def test_paired_layer1_weight_gradient_gemm_equals_two_launches():
+    """hulc_set_option "gemm_pair": dW_hh1 and dW_ih1 of the action decoder as ONE launch that streams dZ1^T once (gemm.h gemm_glds_pair_kernel; B % 64 == 0)
+    against the two gemm_glds launches: the same products in the same k order — the two weight gradients must agree to fp32 round-off of the accumulation
+    (the pair kernel multiplies the same 64-token k-steps, so bit-identical is expected; 1e-6 relative is the gate), everything else bit-identical or noise."""
+    B, S = 64, 6
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    dev = torch.device("cuda:0")
+    mb = synth_batch(B, S, dev, 1, False)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    mb["plan_idx"] = torch.randint(0, 32, (B, 32), device=dev, generator=g, dtype=torch.int32)
+    out = {}
+    for pair in (0, 1):
+        eng = StepEngine(dims, B, S, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=1, num_classes=dims.mix_classes)
+        eng.set_option("gemm_pair", pair)
+        eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+        eng.zero_grads()
+        eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+        eng.backward()
+        torch.cuda.synchronize()
+        v = eng.views(eng.flat_grads)
+        out[pair] = {n: v[n].clone() for n in ("action_decoder.rnn.weight_hh_l1", "action_decoder.rnn.weight_ih_l1", "action_decoder.rnn.weight_hh_l0")}
+        eng.close()
+    for n in out[0]:
+        a, b = out[0][n].double(), out[1][n].double()
+        assert float(a.norm()) > 0
+        rel = float((a - b).norm() / a.norm())
+        assert rel < 1e-6, (n, rel)
