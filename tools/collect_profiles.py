@@ -106,7 +106,7 @@ r = open(os.path.join(ROOT, "README.md")).read()
 m0, m1 = "<!-- BEGIN numbers (tools/collect_profiles.py) -->", "<!-- END numbers -->"
 txt = f"""{m0}
 Round {RN} (1 x MI355X, B=64 windows, seq_len 32, bf16): **{d['value'] / 1000:.1f} k trajectory-windows/s, {d['ms_per_step']} ms/step** (median step {sm.get('median')} ms) at the
-reference's fp32 boundary (round 1: 13.7 k / 4.686 ms; round 2: 14.9 k / 4.304 ms); {var['fp32']['value'] / 1000:.2f} k on the fp32 parity engine; {var['fp16']['value'] / 1000:.1f} k in fp16 with the on-device GradScaler (the reference's `precision: 16`);
+reference's fp32 boundary (round 1: 13.7 k / 4.686 ms; round 2: 14.9 k / 4.304; round 3: 18.4 k / 3.474; round 4: 19.5 k / 3.277; the pool's boxes differ by ±2 %, see profiles/README.md); {var['fp32']['value'] / 1000:.2f} k on the fp32 parity engine; {var['fp16']['value'] / 1000:.1f} k in fp16 with the on-device GradScaler (the reference's `precision: 16`);
 {var['u8']['value'] / 1000:.1f} k with uint8 ingest ({var['u8_h2d']['value'] / 1000:.1f} k when every step's frames also cross PCIe from pinned host memory); {var['vislang']['value'] / 1000:.1f} k for 32 vis + 32 lang + CLIP as one paired pass ({var['vislang_seq']['value'] / 1000:.1f} k with the reference's one pass per
 modality); BASELINE config 5 (seq_len 64 x 32 windows, fp16): {var['s64_fp16']['value'] / 1000:.2f} k.  CPU baseline (the step on torch's CPU library kernels, host cores of
 the GPU box): {cb['value']} windows/s with {cb['cores']} threads; the reference itself did 8.0-12.2 windows/s on 8 vCPU (BASELINE.md).
