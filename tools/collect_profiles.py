@@ -8,7 +8,7 @@ O = os.path.join(ROOT, "gpurun_out", T)
 P = lambda f: os.path.join(ROOT, "profiles", f)
 copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.csv", "kernel_stats_summary.txt": "kernel_stats_summary.txt",
           "pmc_hbm_per_kernel.csv": "pmc_hbm_per_kernel.csv", "pmc_traffic.json": "pmc_traffic.json", "sq/mfma_util.csv": "mfma_util.csv",
-          "sq/summary.txt": "mfma_util_summary.txt", "ct_stamps.txt": "conv_tile_phase_stamps.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
+          "sq/summary.txt": "mfma_util_summary.txt", "gridbar2.txt": "gridbar_xcd_barrier.txt", "gridbar.txt": "gridbar_naive_barrier.txt", "step_sequence.txt": "step_sequence.txt",
           "conv_tile_gripper.txt": "conv_tile_gripper_fpb.txt", "conv_reg_vs_tile.txt": "conv_reg_vs_tile.txt", "conv_reg_ablation.txt": "conv_reg_ablation.txt",
           "step_timeline.txt": "step_timeline.txt", "rnn_persist_stamps.txt": "rnn_persist_stamps.txt",
           "storebench.txt": "storebench_write_patterns.txt", "mixbench.txt": "mixbench_conv1_traffic_shape.txt",
@@ -70,7 +70,6 @@ files = f"""| file | what | command |
 | `{T}_rnn_persist_stamps.txt` | the persistent recurrence alone (`csrc/rnn_persist.h`): every step checked against a CPU recurrence, us per step at B = 64 / 128 (S = 32) and B = 32 (S = 64), shader-clock stamps of the phases of a step (poll, payload, MFMA + LDS, barrier, epilogue, drain) | `tools/bin/rnn_persist_bench_st` (tools/rnn_persist_bench.hip, -DRP_STAMPS) |
 | `{T}_step_timeline.txt` | every launch of one step with start offset, duration, gap and queue | `tools/step_timeline.py` |
 | `{T}_conv_tile_gripper_fpb.txt` | the four conv tile kernels on the gripper camera's shapes with 1 frame per band and with the stacked bands the launch picks | `tools/time_conv_tile_gripper.py` |
-| `{T}_conv_tile_phase_stamps.txt` | shader-clock stamps of the phases of every band of the raw-tile conv kernels (what the conv work of this round was steered by) | `tools/bin/ct_stamps` (tools/ct_stamps.hip) |
 | `{T}_gridbar_xcd_barrier.txt`, `{T}_gridbar_naive_barrier.txt` | grid barrier + cross-XCD exchange cost with the fast primitives (XCD-hierarchical barrier, relaxed polls, `sc1` write-through publish) and with round 1's acquire-polled single counter | `tools/bin/gridbar2`, `tools/bin/gridbar` |
 """
 s = open(P("README.md")).read()

@@ -5,7 +5,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the bench command (9 steps: 2 warm-up + 2 survey + 5 timed)
 #   3. two SQ counter passes (tools/pmc_sq.sh): MFMA-pipe utilisation, LDS bank conflicts, wait breakdown per kernel (mfma_util.csv)
 #   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
-#   5. the probes behind DESIGN.md's numbers: tools/bin/ct_stamps (conv tile phases), tools/bin/gridbar2 (XCD barrier + sc1 publish),
+#   5. the probes behind DESIGN.md's numbers: tools/bin/gridbar2 (XCD barrier + sc1 publish),
 #      tools/bin/rnn_persist_bench_st (the persistent recurrence alone: check against a CPU recurrence, us per step, phase stamps)
 T=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
@@ -49,7 +49,6 @@ test -x tools/bin/mixbench && timeout 120 tools/bin/mixbench > $O/mixbench.txt 2
 python tools/step_timeline.py $O/stats "" 400 > $O/step_timeline.txt 2>&1
 test -x tools/bin/rnn_persist_bench_st || { mkdir -p tools/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -DRP_STAMPS tools/rnn_persist_bench.hip -o tools/bin/rnn_persist_bench_st; }
 ( timeout 120 tools/bin/rnn_persist_bench_st 64 32; timeout 120 tools/bin/rnn_persist_bench_st 128 32 | tail -5; timeout 120 tools/bin/rnn_persist_bench_st 32 64 | tail -5 ) > $O/rnn_persist_stamps.txt 2>&1
-test -x tools/bin/ct_stamps && timeout 120 tools/bin/ct_stamps > $O/ct_stamps.txt 2>&1
 test -x tools/bin/gridbar2 && timeout 120 tools/bin/gridbar2 > $O/gridbar2.txt 2>&1
 test -x tools/bin/gridbar && timeout 120 tools/bin/gridbar > $O/gridbar.txt 2>&1
 tail -1 $O/bench_n1.json | cut -c1-400
