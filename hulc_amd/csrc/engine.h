@@ -165,6 +165,7 @@ struct Engine : IEngine {
     float *demb, *dgoal, *dseqf, *dplan, *dprl, *dppx, *dxa, *dxb, *dy_f, *dxm;
     T *dprl_t, *dppl_t, *dseq_t, *dt_a, *dt_b, *dt_c, *dgl3_t;
     T *tA, *tB; int64_t tcap;
+    bool h0t_valid = false;                 // tB2 holds H0^T of the current backward (16-bit engines)
     T* tB2 = nullptr;                       // second transposed-operand buffer (the paired layer-1 weight-gradient GEMM reads H1^T and H0^T at once)
     float *part; int64_t partcap; float* cspart;
     // clip
@@ -480,6 +481,21 @@ struct Engine : IEngine {
         const dim3 grid(n0 + p.d[1].tiles_x * cdiv(Rb, TRT));
         if constexpr (std::is_same<T, float>::value) hipLaunchKernelGGL((pair_transpose_kernel<T>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(pair_transpose64_kernel, grid, dim3(256), 0, st, p);
+    }
+    // 16-bit engines: three transposes, one launch (dst leading dimension ldt for all; cs / cs2 = fused column sums of the FIRST source)
+    void transpose_triple(const T* a, long long lda, T* at, int Ra, int Ca, const T* b, long long ldb, T* bt, int Rb, int Cb, const T* c, long long ldc, T* ct, int Rc, int Cc,
+                          long long ldt, float* cs = nullptr, float* cs2 = nullptr) {
+        if constexpr (!std::is_same<T, float>::value) {
+            TrMulti m{}; m.n = 3;
+            const T* src[3] = {a, b, c}; T* dst[3] = {at, bt, ct}; const long long ld[3] = {lda, ldb, ldc}; const int R[3] = {Ra, Rb, Rc}, C[3] = {Ca, Cb, Cc};
+            int blk = 0;
+            for (int i = 0; i < 3; ++i) {
+                m.d[i].src = src[i]; m.d[i].dst = dst[i]; m.d[i].lds = ld[i]; m.d[i].ldt = ldt; m.d[i].R = R[i]; m.d[i].C = C[i]; m.d[i].tiles_x = cdiv(C[i], TRT); m.d[i].blk0 = blk;
+                blk += m.d[i].tiles_x * cdiv(R[i], TRT);
+            }
+            m.d[0].cs = cs; m.d[0].cs2 = cs2;
+            hipLaunchKernelGGL(multi_transpose64_kernel, dim3(blk), dim3(256), 0, st, m);
+        }
     }
     template <typename TS, typename TD>
     void copy2d(const TS* src, long long lds_, TD* dst, long long ldd, int R, int C, int acc, float scale = 1.f) {
@@ -2455,7 +2471,16 @@ struct Engine : IEngine {
             {
                 const int mp = ldpad(SB);
                 constexpr bool fuse_cs = std::is_same<T, h16_t>::value;     // 16-bit engines: the dZ transpose adds its column sums (= both bias gradients) on the way
+                // 16-bit engines: H0^T is needed twice (dW_ih1 here, dW_hh0 below): transposed ONCE, by the same launch as dZ1^T and H1^T, into its own buffer
+                // (was: a cast_transpose launch here and a second transpose of H0 next to dZ0 below: 4 launches -> 2)
+                bool h0t_kept = false;
+                if constexpr (std::is_same<T, h16_t>::value) {
+                    if (!tB2) tB2 = alloc<T>(tcap);
+                    if (tB2) { transpose_triple(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, H0, HID, tB2, SB, HID, mp, dbih1, dbhh1); h0t_kept = true; }
+                }
+                if (!h0t_kept)
                 transpose_pair(dZ1, HID, tA, SB, HID, H1, HID, tB, SB, HID, mp, fuse_cs ? dbih1 : nullptr, fuse_cs ? dbhh1 : nullptr);
+                h0t_valid = h0t_kept;
                 bool paired = false;
                 if constexpr (std::is_same<T, h16_t>::value) {
                     // dW_hh1 = dZ1[1:]^T H1[:-1] and dW_ih1 = dZ1^T H0 share dZ1^T up to a shift of one time step (B tokens): ONE launch that streams it once
@@ -2465,7 +2490,7 @@ struct Engine : IEngine {
                     if (pair_sw && gemm_use_glds && S > 1 && gemm_glds_pair_ok(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense<T>(tB, HID, mp), e1, e2, HID, HID, SB, B)) {
                         if (!tB2) tB2 = alloc<T>(tcap);
                         if (tB2) {
-                            cast_tr<T, T>(H0, HID, nullptr, 0, tB2, mp, SB, HID);
+                            if (!h0t_kept) cast_tr<T, T>(H0, HID, nullptr, 0, tB2, mp, SB, HID);
                             e1.accumulate = grad_first(whh1.dW) ? 0 : 1; e2.accumulate = grad_first(wih1.dW) ? 0 : 1;
                             TimerScope ts(this, "gemm_128x128", "mfma", 2.0 * HID * HID * ((double)SB + (double)(S - 1) * B), (3.0 * HID * SB) * sizeof(T) + 8.0 * HID * HID, 1);
                             launch_gemm_glds_pair(st, dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense<T>(tB2, HID, mp), dense_out(HID), e1, e2, HID, HID, SB, B);
@@ -2476,8 +2501,8 @@ struct Engine : IEngine {
                 if (!paired) {
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = grad_first(whh1.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
-                cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
-                { EpiP ep = epi(wih1.dW, true); ep.accumulate = grad_first(wih1.dW) ? 0 : 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
+                if (!h0t_kept) cast_tr<T, T>(H0, HID, nullptr, 0, tB, mp, SB, HID);
+                { EpiP ep = epi(wih1.dW, true); ep.accumulate = grad_first(wih1.dW) ? 0 : 1; gemm(dense<T>(tA, HID, mp), dense<T>(h0t_kept ? tB2 : tB, HID, mp), dense_out(HID), ep, HID, HID, SB); }
                 }
                 if (!fuse_cs) colsum(dZ1, HID, SB, HID, dbih1, dbhh1);
             }
@@ -2488,10 +2513,16 @@ struct Engine : IEngine {
             {
                 const int mp = ldpad(SB);
                 // the column sums of dZ0 over all (t, b) rows = those of dC = sum_t dZ0: both bias gradients of layer 0 ride on this transpose too
+                if (h0t_valid) {      // H0^T is still in tB2 (layer 1's launch above): dZ0^T and embg^T in one launch, no second transpose of H0
+                    transpose_pair(dZ0, HID, tA, SB, HID, embg, DE, tB, SB, DE, mp, dbih0, dbhh0);
+                    if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = grad_first(whh0.dW) ? 0 : 1;
+                      gemm(dense<T>(tA + B, HID, mp), dense<T>(tB2, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
+                } else {
                 transpose_pair(dZ0, HID, tA, SB, HID, H0, HID, tB, SB, HID, mp, std::is_same<T, h16_t>::value ? dbih0 : nullptr, std::is_same<T, h16_t>::value ? dbhh0 : nullptr);
                 if (S > 1) { EpiP ep = epi(whh0.dW, true); ep.accumulate = grad_first(whh0.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
                 cast_tr<T, T>(embg, DE, nullptr, 0, tB, mp, SB, DE);
+                }
                 { EpiP ep = epi(dwih0 + dec_plan, true); ep.accumulate = 1; gemm(dense<T>(tA, HID, mp), dense<T>(tB, DE, mp), dense_out(KIN), ep, HID, DE, SB); }
             }
             // d emb (gripper half), scattered back to (B,S,128)[..., 64:128]

@@ -149,6 +149,16 @@ __global__ void __launch_bounds__(256) pair_transpose64_kernel(TrPair pr) {
     const TrDesc D = ((int)blockIdx.x >= pr.d[1].blk0) ? pr.d[1] : pr.d[0];
     transpose_tile64_h16(D, blockIdx.x - D.blk0, tile);
 }
+// up to four transposes in one launch (round 5: the decoder's dZ1 / H1 / H0 of the layer-1 weight gradients)
+struct TrMulti { TrDesc d[4]; int n; };
+__global__ void __launch_bounds__(256) multi_transpose64_kernel(TrMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (i < m.n && (int)blockIdx.x >= m.d[i].blk0) k = i;
+    const TrDesc D = m.d[k];
+    transpose_tile64_h16(D, blockIdx.x - D.blk0, tile);
+}
 template <typename T>
 __global__ void __launch_bounds__(256) pair_transpose_kernel(TrPair pr) {
     __shared__ float tile[32][33];
