@@ -103,6 +103,7 @@ struct Engine : IEngine {
     long long* adam_chunk_start = nullptr; int* adam_chunk_n = nullptr; int adam_chunks = 0;
     bool adam_fuse_tr = true;               // hulc_set_option "adam_fused_transposes"
     void set_adam_fuse(bool on) override { adam_fuse_tr = on; }
+    bool rest_by_pack = false;              // weight_pack_kernel also writes the transposed copies of every matrix in tr_rest
     bool tr_fresh = false;                  // set by optim(): the shadow-sourced transposed copies are those of the current parameters
     void tr_table_free(TrTable& t) { if (t.desc) hipFree(t.desc); if (t.b2d) hipFree(t.b2d); t = TrTable{}; }
     bool tr_table_build(TrTable& t, std::vector<TrDesc> v) {
@@ -121,7 +122,7 @@ struct Engine : IEngine {
     // the optimizer's tile / chunk tables: matrices of `trdesc` whose source is a contiguous [R][C] view of the shadow with 4-element alignment are tiled; the chunk
     // list covers the rest of [0, numel)
     void adam_tables_build() {
-        tr_table_free(tr_adam); tr_table_free(tr_rest);
+        tr_table_free(tr_adam); tr_table_free(tr_rest); rest_by_pack = false;
         if (adam_chunk_start) { hipFree(adam_chunk_start); adam_chunk_start = nullptr; } if (adam_chunk_n) { hipFree(adam_chunk_n); adam_chunk_n = nullptr; }
         adam_chunks = 0;
         if (std::is_same<T, float>::value || !wshadow || (numel & 3)) return;
@@ -142,6 +143,13 @@ struct Engine : IEngine {
         for (auto& r : rng) { cover(pos, r.first); pos = r.second; }
         cover(pos, numel);
         if (!tr_table_build(tr_adam, fused) || !tr_table_build(tr_rest, rest)) { tr_table_free(tr_adam); tr_table_free(tr_rest); return; }
+        // every transpose the optimizer does not write comes from a matrix weight_pack_kernel packs (the permuted fc7, the decoder heads): it writes their transposed copies as well
+        rest_by_pack = true;
+        for (const TrDesc& d : rest) {
+            const bool f7 = d.src == (const void*)encG.fc7.W && d.dst == (void*)encG.fc7.Wt && d.R == 128 && d.C == 3136 && d.ldt == 128;
+            const bool hd = d.src == (const void*)wheads && d.dst == (void*)wheadsT && d.R == NHEAD && d.C == HID && d.ldt == NHEAD;
+            if (!f7 && !hd) rest_by_pack = false;
+        }
         adam_chunks = (int)cs.size();
         if (adam_chunks) {
             if (hipMalloc((void**)&adam_chunk_start, sizeof(long long) * cs.size()) != hipSuccess || hipMalloc((void**)&adam_chunk_n, sizeof(int) * cn.size()) != hipSuccess) { tr_table_free(tr_adam); tr_table_free(tr_rest); adam_chunks = 0; return; }
@@ -671,13 +679,16 @@ struct Engine : IEngine {
             // packed heads [192][2048]: prob | mean | log_scale | gripper | zero pad
             const HeadPack hp = head_pack();
             const int rows = head_rows[0] + head_rows[1] + head_rows[2] + head_rows[3];
+            // 16-bit engines: the transposed copies of the two packed matrices are written by this launch too (rest_by_pack: then no transpose launch is left behind Adam)
+            T* const f7t = rest_by_pack ? encG.fc7.Wt : (T*)nullptr;
+            T* const wht = rest_by_pack ? wheadsT : (T*)nullptr;
             hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(blkB + cdiv((long long)rows * HID, 256)), dim3(256), 0, st, d, blkA, encG.fc7.W32, encG.fc7.W, 128, 64, 49, blkB, hp,
-                               wheads, bheads, HID);
+                               wheads, bheads, HID, f7t, wht, NHEAD);
         }
         // ... then every transposed copy — the Linear weights, the permuted fc7 and the packed heads — in ONE batched launch
         if (std::is_same<T, float>::value) hipLaunchKernelGGL((batched_transpose_kernel<float, T>), dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size());
         else if (tr_fresh && tr_adam.n) {      // the optimizer wrote the shadow-sourced transposed copies (adam_tiled_kernel): only the packed sources are left
-            if (tr_rest.blocks) hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_rest.blocks), dim3(256), 0, st, tr_rest.desc, tr_rest.n, (const unsigned short*)tr_rest.b2d);
+            if (tr_rest.blocks && !rest_by_pack) hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_rest.blocks), dim3(256), 0, st, tr_rest.desc, tr_rest.n, (const unsigned short*)tr_rest.b2d);
         }
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
         tr_fresh = false;

@@ -677,7 +677,10 @@ __global__ void pack_heads_kernel(HeadPack hp, T* __restrict__ wheads, float* __
 // [blkB, ..) the packed decoder heads (pack_heads_kernel).  Their transposed copies ride on the batched transpose launch that follows.
 template <typename T>
 __global__ void __launch_bounds__(256) weight_pack_kernel(ConvPackBatch d, int blkA, const float* __restrict__ fc7_src, T* __restrict__ fc7_dst, int R7, int CH7,
-                                                          int P7, int blkB, HeadPack hp, T* __restrict__ wheads, float* __restrict__ bheads, int HID) {
+                                                          int P7, int blkB, HeadPack hp, T* __restrict__ wheads, float* __restrict__ bheads, int HID,
+                                                          T* __restrict__ fc7_dstT = nullptr, T* __restrict__ wheadsT = nullptr, int ldth = 0) {
+    // fc7_dstT / wheadsT (round 5): the TRANSPOSED copies of the two packed matrices ([CH7*P7][R7] and [HID][ldth]) written here as well — 0.8 M scattered 2-byte
+    // stores instead of a transpose launch behind this one
     const int bid = blockIdx.x;
     if (bid < blkA) {
         int c = 0;
@@ -709,7 +712,9 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(ConvPackBatch d, int b
         const int c = idx % (CH7 * P7);
         const long long r = idx / (CH7 * P7);
         const int ch = c / P7, pp = c % P7;
-        fc7_dst[r * (CH7 * P7) + pp * CH7 + ch] = from_f<T>(fc7_src[idx]);
+        const T v7 = from_f<T>(fc7_src[idx]);
+        fc7_dst[r * (CH7 * P7) + pp * CH7 + ch] = v7;
+        if (fc7_dstT) fc7_dstT[(long long)(pp * CH7 + ch) * R7 + r] = v7;
         return;
     }
     const int total_rows = hp.rows[0] + hp.rows[1] + hp.rows[2] + hp.rows[3];
@@ -719,7 +724,9 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(ConvPackBatch d, int b
     const int k = (int)(idx % HID);
     int i = 0;
     while (i < 3 && r >= hp.rows[i]) { r -= hp.rows[i]; ++i; }
-    wheads[idx] = from_f<T>(hp.w[i][(long long)r * HID + k]);
+    const T vh = from_f<T>(hp.w[i][(long long)r * HID + k]);
+    wheads[idx] = vh;
+    if (wheadsT) wheadsT[(long long)k * ldth + idx / HID] = vh;
     if (k == 0) bheads[idx / HID] = hp.b[i][r];
 }
 __global__ void unpack_heads_grad_kernel(HeadPack hp, const float* __restrict__ dw, const float* __restrict__ db, int HID, int nslab = 1, long long slab = 0) {
