@@ -103,6 +103,7 @@ struct Engine : IEngine {
     long long* adam_chunk_start = nullptr; int* adam_chunk_n = nullptr; int adam_chunks = 0;
     bool adam_fuse_tr = true;               // hulc_set_option "adam_fused_transposes"
     void set_adam_fuse(bool on) override { adam_fuse_tr = on; }
+    bool frag_by_adam = false;              // every fragment-ordered weight copy is written by adam_tiled_kernel (TrDesc::fr / frT)
     bool rest_by_pack = false;              // weight_pack_kernel also writes the transposed copies of every matrix in tr_rest
     bool tr_fresh = false;                  // set by optim(): the shadow-sourced transposed copies are those of the current parameters
     void tr_table_free(TrTable& t) { if (t.desc) hipFree(t.desc); if (t.b2d) hipFree(t.b2d); t = TrTable{}; }
@@ -122,7 +123,7 @@ struct Engine : IEngine {
     // the optimizer's tile / chunk tables: matrices of `trdesc` whose source is a contiguous [R][C] view of the shadow with 4-element alignment are tiled; the chunk
     // list covers the rest of [0, numel)
     void adam_tables_build() {
-        tr_table_free(tr_adam); tr_table_free(tr_rest); rest_by_pack = false;
+        tr_table_free(tr_adam); tr_table_free(tr_rest); rest_by_pack = false; frag_by_adam = false;
         if (adam_chunk_start) { hipFree(adam_chunk_start); adam_chunk_start = nullptr; } if (adam_chunk_n) { hipFree(adam_chunk_n); adam_chunk_n = nullptr; }
         adam_chunks = 0;
         if (std::is_same<T, float>::value || !wshadow || (numel & 3)) return;
@@ -144,6 +145,7 @@ struct Engine : IEngine {
         cover(pos, numel);
         if (!tr_table_build(tr_adam, fused) || !tr_table_build(tr_rest, rest)) { tr_table_free(tr_adam); tr_table_free(tr_rest); return; }
         // every transpose the optimizer does not write comes from a matrix weight_pack_kernel packs (the permuted fc7, the decoder heads): it writes their transposed copies as well
+        { int lf = 0; for (const TrDesc& d : fused) if (d.fr && d.frT) ++lf; frag_by_adam = fragbatch.n > 0 && 2 * lf == fragbatch.n && lf == frag_linked; }
         rest_by_pack = true;
         for (const TrDesc& d : rest) {
             const bool f7 = d.src == (const void*)encG.fc7.W && d.dst == (void*)encG.fc7.Wt && d.R == 128 && d.C == 3136 && d.ldt == 128;
@@ -318,8 +320,12 @@ struct Engine : IEngine {
             fb.src[fb.n] = L.W; fb.dst[fb.n] = L.Wfr; fb.N[fb.n] = L.N; fb.K[fb.n] = L.K; fb.blk0[fb.n] = frag_blocks; frag_blocks += frag_pack_blocks(L.N, L.K); ++fb.n;
             fb.src[fb.n] = L.Wt; fb.dst[fb.n] = L.Wtfr; fb.N[fb.n] = L.K; fb.K[fb.n] = L.N; fb.blk0[fb.n] = frag_blocks; frag_blocks += frag_pack_blocks(L.K, L.N); ++fb.n;
             fb.blk0[fb.n] = frag_blocks;
+            // the optimizer's tile pass can write both copies (kernels.h adam_tiled_kernel): remember them on the weight's transpose descriptor
+            for (TrDesc& d : trdesc)
+                if (d.dst == (void*)L.Wt && d.R == L.N && d.C == L.K && (L.N % 32) == 0 && (L.K % 32) == 0) { d.fr = L.Wfr; d.frT = L.Wtfr; ++frag_linked; }
         }
     }
+    int frag_linked = 0;                    // weights whose fragment-ordered copies ride on their transpose descriptor (2 frag jobs each)
     static bool frag_weights() { static const bool on = HULC_SWITCH("HULC_FRAG_W", 1) != 0; return on; }
     static constexpr int TRT = std::is_same<T, float>::value ? 32 : 64;     // transpose tile (bf16: 64x64, 16-byte accesses)
     void add_tr(const float* w32, const T* w, T* wt, int R, int C) {
@@ -359,7 +365,7 @@ struct Engine : IEngine {
     int bind(float* p, float* g, float* m, float* v, int64_t n_, int n, const char* const* names, const int64_t* offs,
              const int64_t* numels) override {
         P = p; G = g; AM = m; AV = v; numel = n_;
-        tab.clear(); trdesc.clear(); tr_blocks = 0; fragbatch = FragPackBatch{}; frag_blocks = 0;
+        tab.clear(); trdesc.clear(); tr_blocks = 0; fragbatch = FragPackBatch{}; frag_blocks = 0; frag_linked = 0;
         if (!std::is_same<T, float>::value && !wshadow) wshadow = alloc<T>(numel);
         for (int i = 0; i < n; ++i) tab[names[i]] = Ref{offs[i], numels[i]};
         tab_order.assign(tab.begin(), tab.end());
@@ -691,9 +697,11 @@ struct Engine : IEngine {
             if (tr_rest.blocks && !rest_by_pack) hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_rest.blocks), dim3(256), 0, st, tr_rest.desc, tr_rest.n, (const unsigned short*)tr_rest.b2d);
         }
         else hipLaunchKernelGGL(batched_transpose64_kernel, dim3(tr_blocks), dim3(256), 0, st, trdesc_dev, (int)trdesc.size(), (const unsigned short*)blk2desc_dev);
+        const bool was_fresh = tr_fresh && tr_adam.n;
         tr_fresh = false;
         if constexpr (std::is_same<T, h16_t>::value) {
-            if (fragbatch.n) hipLaunchKernelGGL(frag_pack_kernel, dim3(frag_blocks), dim3(256), 0, st, fragbatch);
+            // (the optimizer's tile pass wrote them when every frag job is linked to a tiled descriptor: frag_by_adam)
+            if (fragbatch.n && !(was_fresh && frag_by_adam)) hipLaunchKernelGGL(frag_pack_kernel, dim3(frag_blocks), dim3(256), 0, st, fragbatch);
         }
         STAGE("prepare_weights");
         if (hipGetLastError() != hipSuccess) { hulc_set_error("kernel launch failed in prepare_weights"); return 1; }

@@ -36,7 +36,9 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const TS* __restric
 }
 
 // many transposes in one launch: block b belongs to descriptor d with blk0[d] <= b < blk0[d+1]; dstT[c][r] = src[r][c]
-struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, tiles_x; float* cs = nullptr; float* cs2 = nullptr; };   // cs: optional column sums of src (bias gradient), bf16 64x64 path only, atomics
+struct TrDesc { const void* src; void* dst; long long lds, ldt; int R, C, blk0, tiles_x; float* cs = nullptr; float* cs2 = nullptr;
+                void* fr = nullptr; void* frT = nullptr; };      // fr / frT (adam_tiled_kernel only; R % 16 == 0, C % 32 == 0 and vice versa): fragment-ordered copies of src / of its transpose (gemm.h frag_pack_kernel's layout)
+   // cs: optional column sums of src (bias gradient), bf16 64x64 path only, atomics
 template <typename TS, typename TD>
 __global__ void __launch_bounds__(256) batched_transpose_kernel(const TrDesc* __restrict__ desc, int ndesc) {
     __shared__ float tile[32][33];
@@ -115,6 +117,8 @@ DEVI void transpose_tile64_store(const TrDesc& D, int b, unsigned short (*tile)[
             unsigned* vw = reinterpret_cast<unsigned*>(v);
 #pragma unroll
             for (int e = 0; e < 4; ++e) vw[e] = __builtin_amdgcn_perm(w[2 * e + 1], w[2 * e], h ? 0x07060302u : 0x05040100u);
+            if (D.frT && r + 7 < D.R)      // Wt[c][r .. r+7] as one 16-byte fragment chunk: row tile c / 16, row c % 16, k-step r / 32, lane group (r % 32) / 8
+                *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(D.frT) + ((((long long)(c >> 4) * (D.R >> 5) + (r >> 5)) * 64 + ((r & 31) >> 3) * 16 + (c & 15)) << 3)) = *reinterpret_cast<const uint4*>(v);
             if (vout && r + 7 < D.R) {
                 *reinterpret_cast<uint4*>(dst + (long long)c * D.ldt + r) = *reinterpret_cast<const uint4*>(v);
             } else {
@@ -2350,6 +2354,19 @@ __global__ void __launch_bounds__(256) adam_tiled_kernel(AdamArgs a, const TrDes
             *reinterpret_cast<unsigned*>(&tile[row][cc + 2]) = hi;
         }
         __syncthreads();
+        if (D.fr) {      // fragment-ordered copy of W: chunk (row, 8 k) -> row tile row / 16, k-step k / 32, lane (k % 32) / 8 * 16 + row % 16 (two chunks per thread)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = tid + u * 256, row = q >> 3, c8 = q & 7;
+                const int r = r0 + row, k = c0 + c8 * 8;
+                if (r < D.R && k + 7 < D.C) {
+                    uint4 v;
+                    v.x = *reinterpret_cast<const unsigned*>(&tile[row][c8 * 8]); v.y = *reinterpret_cast<const unsigned*>(&tile[row][c8 * 8 + 2]);
+                    v.z = *reinterpret_cast<const unsigned*>(&tile[row][c8 * 8 + 4]); v.w = *reinterpret_cast<const unsigned*>(&tile[row][c8 * 8 + 6]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(D.fr) + ((((long long)(r >> 4) * (D.C >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (r & 15)) << 3)) = v;
+                }
+            }
+        }
         transpose_tile64_store(D, b, tile);
     } else {
         const int j = blockIdx.x - ntile;
