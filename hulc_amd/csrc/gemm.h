@@ -766,22 +766,23 @@ __global__ void __launch_bounds__(512) gemm_glds_pair_kernel(DenseLoader<h16_t> 
 #pragma unroll 1
         for (int kk = 0; kk < 2; ++kk) {
             const int chunk = (((kk << 2) + g) ^ (li & 6)) << 4;
-            h16x8_t a[TM], b[4];
+            // all ten fragments are requested before the first MFMA (a second read phase behind B2's MFMAs exposed the LDS latency once more per k-half)
+            h16x8_t a[TM], b[4], c[4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *(__attribute__((address_space(3))) h16x8_t*)(sa + i * 2048 + chunk);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb2 + j * 2048 + chunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb1 + j * 2048 + chunk);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc2[i][j] = MFMA_16x16x32_H(b[j], a[i], acc2[i][j], 0, 0, 0);
             if (with1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *(__attribute__((address_space(3))) h16x8_t*)(sb1 + j * 2048 + chunk);
-#pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc1[i][j] = MFMA_16x16x32_H(b[j], a[i], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc1[i][j] = MFMA_16x16x32_H(c[j], a[i], acc1[i][j], 0, 0, 0);
             }
         }
         buf = buf == NST - 1 ? 0 : buf + 1;
