@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(512) ingest(const u32x4* __restrict__ buf, siz
     const unsigned ldsbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     unsigned acc = 0;
     // a step = 32 KB: 32 wave-instructions of 1 KB; wave w issues pieces w, w + 8, w + 16, w + 24
-    for (int s = 0; s < steps; ++s) {
+    for (int s = 0; MODE < 3 && s < steps; ++s) {
         const u32x4* sp = p + (size_t)s * 2048;           // 2048 vectors = 32 KB
         if (MODE == 0) {
 #pragma unroll
@@ -43,6 +43,60 @@ __global__ void __launch_bounds__(512) ingest(const u32x4* __restrict__ buf, siz
             acc ^= v[0][0] ^ v[1][3];
         }
     }
+    if (MODE >= 3 && MODE < 7) {
+        // GEMM-shaped source: the workgroup's operand is 256 rows (128 A + 128 B) of 4 KB (K = 2048 halves); a step covers RB bytes of every row, a wave instruction
+        // covers ROWS rows x RB bytes (ROWS * RB = 1 KB).  MODE 3: RB = 128 (gemm_glds_kernel: 8 rows x 128 B), 4: RB = 256, 5: RB = 512, 6: RB = 1024
+        const int RB = MODE == 3 ? 128 : (MODE == 4 ? 256 : (MODE == 5 ? 512 : 1024)), ROWS = 1024 / RB, LPR = RB / 16;      // lanes per row
+        const char* base = reinterpret_cast<const char*>(buf) + (size_t)(blockIdx.x / 16) * (size_t)(256 * 4096);
+        const int nsteps = 4096 / RB, ipw = 256 / ROWS / 8;         // steps to cover K; instructions per wave and step
+        const int r = lane / LPR, cb = (lane % LPR) * 16;
+        for (int s2 = 0; s2 < nsteps; ++s2) {
+            for (int j = 0; j < ipw; ++j) {
+                const int row = (wave * ipw + j) * ROWS + r;
+                dma16(base + (size_t)row * 4096 + (size_t)s2 * RB + cb, ldsbase + ((s2 % 3) * (256 * RB > 32768 ? 49152 : 32768) % 98304 + (wave * ipw + j) * 1024) % 98304);
+            }
+            if (s2 >= 2) { if (ipw == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (ipw == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else if (ipw == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); }
+        }
+    }
+    if (MODE >= 7) {
+        // the GEMM's k-loop skeleton on the 8 x 128 B pieces: 7 = + the counted wait and ONE s_barrier per step (3-stage ring, DMA two steps ahead), 8 = + the 12 ds_read_b128
+        // fragment reads per wave and step, 9 = + the 16 MFMAs per wave and step
+        typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const char* base = reinterpret_cast<const char*>(buf) + (size_t)(blockIdx.x / 16) * (size_t)(256 * 4096);
+        const int r = lane >> 3, cb = (lane & 7) * 16;
+        auto issue = [&](int s2, int b3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int row = (wave * 4 + j) * 8 + r; dma16(base + (size_t)row * 4096 + (size_t)s2 * 128 + cb, ldsbase + b3 * 32768 + (wave * 4 + j) * 1024); }
+        };
+        f32x4 c[2][4];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        issue(0, 0); issue(1, 1);
+        int b3 = 0;
+        for (int s2 = 0; s2 < 32; ++s2) {
+            if (s2 < 31) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s2 + 2 < 32) issue(s2 + 2, b3 == 0 ? 2 : b3 - 1);
+            if (MODE >= 8) {
+                const char* st = smem + b3 * 32768 + (wave >> 1) * 4096 + (lane & 15) * 128;
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 f[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) f[q] = *(const __attribute__((address_space(3))) u32x4*)(__attribute__((address_space(3))) char*)(st + (q < 2 ? q * 2048 : 16384 + (wave & 1) * 8192 + (q - 2) * 2048) + ((kk * 4 + (lane >> 4)) ^ (lane & 6)) * 16);
+                    if (MODE >= 9) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f[2 + j]), __builtin_bit_cast(bf16x8, f[i]), c[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) acc ^= f[q][0] ^ f[q][2];
+                    }
+                }
+            }
+            b3 = b3 == 2 ? 0 : b3 + 1;
+        }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) acc ^= __float_as_uint(c[i][j][0] + c[i][j][3]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     acc ^= *(__attribute__((address_space(3))) unsigned*)(smem + tid * 4);
@@ -57,12 +111,22 @@ int main() {
     hipFuncSetAttribute((const void*)ingest<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)ingest<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)ingest<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const char* names[3] = {"LDS-DMA only", "global -> VGPR only", "half / half interleaved"};
-    for (int mode = 0; mode < 3; ++mode) {
+    hipFuncSetAttribute((const void*)ingest<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)ingest<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)ingest<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const char* names[10] = {"LDS-DMA only", "global -> VGPR only", "half / half interleaved", "LDS-DMA, 8 rows x 128 B pieces (GEMM)", "LDS-DMA, 4 rows x 256 B pieces", "LDS-DMA, 2 rows x 512 B pieces", "LDS-DMA, 1 row x 1 KB pieces", "GEMM k-loop skeleton: DMA + wait + 1 barrier / step", "... + 12 fragment reads / wave / step", "... + 16 MFMAs / wave / step"};
+    for (int mode = 0; mode < 10; ++mode) {
         auto launch = [&]() {
             if (mode == 0) hipLaunchKernelGGL(ingest<0>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
             if (mode == 1) hipLaunchKernelGGL(ingest<1>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
             if (mode == 2) hipLaunchKernelGGL(ingest<2>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 3) hipLaunchKernelGGL(ingest<3>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 4) hipLaunchKernelGGL(ingest<4>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 5) hipLaunchKernelGGL(ingest<5>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 6) hipLaunchKernelGGL(ingest<6>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 7) hipLaunchKernelGGL(ingest<7>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 8) hipLaunchKernelGGL(ingest<8>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 9) hipLaunchKernelGGL(ingest<9>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
         };
         for (int i = 0; i < 5; ++i) launch();
         hipEventRecord(e0);
