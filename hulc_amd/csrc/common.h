@@ -22,6 +22,18 @@ void hulc_set_error(const char* fmt, ...);
 
 #define DEVI __device__ __forceinline__
 
+// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B from per-lane global addresses -> 1 KB at the wave-uniform LDS address `lds_addr`), issued as
+// inline assembly.  Round 5 (tools/gemm_probe.hip): gemm_glds_kernel at 2048^3 takes 28.7 us with __builtin_amdgcn_global_load_lds and 25.6 us with this form — the
+// same instructions, but the compiler schedules around the builtin (it drops the wait state behind `s_mov m0` by moving a VALU into it and orders the next piece's
+// address arithmetic in between).  The DMA is invisible to LLVM's waitcnt pass this way: every consumer waits with its OWN `s_waitcnt vmcnt(N)` + barrier before it
+// reads the LDS data (all kernels here do); compiler-inserted vmcnt waits stay safe, unknown extra operations can only make them wait longer.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
+}
+#endif
+
 // Kernel-routing / debugging switches.  The PRODUCTION build has none: every HULC_SWITCH("NAME", default) is the compile-time constant
 // `default`, so the library contains exactly one code path per launch site (an environment switch per A/B experiment doubled
 // an untested path each).  An experiment build (`HULC_BUILD_AB=1 python -c "import __graft_entry__ as g; g.build()"`, i.e. -DHULC_AB_SWITCHES)

@@ -405,6 +405,15 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
         }
     }
 }
+// the weight-gradient form of an epilogue: fp32 store or accumulate of the bare product (alpha 1, no bias / residual / mask / activation / dropout / second store).
+// Wave-uniform; the generic epi_store4 path costs gemm_glds_kernel 2.2 us of its 28 at 2048^3 (tools/gemm_probe.hip: flag tests, prefetch structure, 64-bit offsets)
+DEVI bool epi_is_plain_f32(const EpiP& ep) {
+    return ep.out_f32 && !ep.atomic && ep.z_stride == 0 && !ep.bias && !ep.bias2 && !ep.res && !ep.mask && !ep.relu && ep.drop_p == 0.f && !ep.out2 && ep.alpha == 1.f;
+}
+DEVI void epi_plain4(const EpiP& ep, const f32x4& acc, long long o) {
+    f32x4* op = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + o);
+    *op = ep.accumulate ? *op + acc : acc;
+}
 template <typename T>
 DEVI void epi_store4(const EpiP& ep, const float (&accv)[4], int rrow, int col, int N, long long o) {
     const EpiPre4 p = epi_prefetch4<T>(ep, rrow, col, N, o);
@@ -626,8 +635,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
         if (khalf && kt == nk - 1 && cs >= 4) ko -= 32;         // chunk beyond K: fetch a valid one instead (never multiplied)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + ko), (__attribute__((address_space(3))) void*)(st + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + ko), (__attribute__((address_space(3))) void*)(st + 16384 + j * 1024), 16, 0, 0);
+            lds_dma16(asrc[j] + ko, (unsigned)(size_t)(st + j * 1024));
+            lds_dma16(bsrc[j] + ko, (unsigned)(size_t)(st + 16384 + j * 1024));
         }
     };
     f32x4 acc[TM][4];
@@ -676,6 +685,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
         }
         buf = buf == NST - 1 ? 0 : buf + 1;
     }
+    const bool plain = epi_is_plain_f32(ep) && (om.s1 & 3) == 0 && (om.s0 & 3) == 0 && ((uintptr_t)ep.out & 15) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * WROWS + i * 16 + li;
@@ -686,6 +696,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + g * 4;
                 if (col < N) {
+                    if (plain && col + 3 < N) { epi_plain4(ep, acc[i][j], obase + col); continue; }
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     epi_store4<h16_t>(ep, v4, rrow, col, N, obase + col);
                 }
@@ -737,9 +748,9 @@ __global__ void __launch_bounds__(512) gemm_glds_pair_kernel(DenseLoader<h16_t> 
         const long long ko = (long long)kt * 64, ko1 = (long long)max(kt - shs, 0) * 64;
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + ko), (__attribute__((address_space(3))) void*)(st + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1src[j] + ko1), (__attribute__((address_space(3))) void*)(st + 16384 + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b2src[j] + ko), (__attribute__((address_space(3))) void*)(st + 32768 + j * 1024), 16, 0, 0);
+            lds_dma16(asrc[j] + ko, (unsigned)(size_t)(st + j * 1024));
+            lds_dma16(b1src[j] + ko1, (unsigned)(size_t)(st + 16384 + j * 1024));
+            lds_dma16(b2src[j] + ko, (unsigned)(size_t)(st + 32768 + j * 1024));
         }
     };
     f32x4 acc1[TM][4], acc2[TM][4];
@@ -796,6 +807,7 @@ __global__ void __launch_bounds__(512) gemm_glds_pair_kernel(DenseLoader<h16_t> 
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + g * 4;
                 if (col < N) {
+                    if (((om.s1 | om.s0) & 3) == 0 && col + 3 < N) { epi_plain4(ep1, acc1[i][j], obase + col); epi_plain4(ep2, acc2[i][j], obase + col); continue; }      // plain by gemm_glds_pair_ok
                     const float v1[4] = {acc1[i][j][0], acc1[i][j][1], acc1[i][j][2], acc1[i][j][3]};
                     epi_store4<h16_t>(ep1, v1, row, col, N, obase + col);
                     const float v2[4] = {acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]};
@@ -1004,8 +1016,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __rest
             const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
 #pragma unroll
             for (int pc = 0; pc < PCW; ++pc)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
-                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+                lds_dma16(src + pc * 64, (unsigned)(size_t)(wbase + (rg * PCW + pc) * 1024));
         }
     }
     // ---- W: fragments straight to registers (one third of the bytes)
@@ -1090,8 +1101,7 @@ __global__ void __launch_bounds__(NW * 64) gru_step_lds_kernel(GruStepP q0, GruS
             const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + kb + c * 8;
 #pragma unroll
             for (int pc = 0; pc < PCW; ++pc)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
-                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+                lds_dma16(src + pc * 64, (unsigned)(size_t)(wbase + (rg * PCW + pc) * 1024));
         }
     };
     dma_rows(gridDim.y == 1 ? 0 : blockIdx.y * (MT * 16));
@@ -1237,8 +1247,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kchunk_kernel(const h16_t*
             const h16_t* src = A + (long long)min(m0 + rg * 8 + r, M - 1) * lda + (long long)ch * KCH + kb + c * 8;
 #pragma unroll
             for (int pc = 0; pc < PCW; ++pc)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 64),
-                                                 (__attribute__((address_space(3))) void*)(wbase + (rg * PCW + pc) * 1024), 16, 0, 0);
+                lds_dma16(src + pc * 64, (unsigned)(size_t)(wbase + (rg * PCW + pc) * 1024));
         }
     };
     int wstep;

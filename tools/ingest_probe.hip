@@ -64,10 +64,17 @@ __global__ void __launch_bounds__(512) ingest(const u32x4* __restrict__ buf, siz
         typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         const char* base = reinterpret_cast<const char*>(buf) + (size_t)(blockIdx.x / 16) * (size_t)(256 * 4096);
+        const char* baseB = base + 128 * 4096;
+        if (MODE >= 11) {      // gemm_glds_kernel's own operand sharing: 16 A panels and 16 B panels of 128 rows x 4 KB, tile (tm, tn) reads A[tm] and B[tn]; XCD-aware tile order
+            const int x = blockIdx.x % 8, q = blockIdx.x / 8, tile = x * 32 + q, gsz = 4 * 16, grp = tile / gsz;
+            const int tm = grp * 4 + (tile % gsz) % 4, tn = (tile % gsz) / 4;
+            base = reinterpret_cast<const char*>(buf) + (size_t)tm * (128 * 4096);
+            baseB = reinterpret_cast<const char*>(buf) + (size_t)(16 + tn) * (128 * 4096);
+        }
         const int r = lane >> 3, cb = (lane & 7) * 16;
         auto issue = [&](int s2, int b3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int row = (wave * 4 + j) * 8 + r; dma16(base + (size_t)row * 4096 + (size_t)s2 * 128 + cb, ldsbase + b3 * 32768 + (wave * 4 + j) * 1024); }
+            for (int j = 0; j < 4; ++j) { const int row = (wave * 4 + j) * 8 + r; dma16((row < 128 ? base + (size_t)row * 4096 : baseB + (size_t)(row - 128) * 4096) + (size_t)s2 * 128 + cb, ldsbase + b3 * 32768 + (wave * 4 + j) * 1024); }
         };
         f32x4 c[2][4];
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) c[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -95,6 +102,14 @@ __global__ void __launch_bounds__(512) ingest(const u32x4* __restrict__ buf, siz
             }
             b3 = b3 == 2 ? 0 : b3 + 1;
         }
+        if (MODE >= 10) {      // + the 128 x 128 fp32 epilogue (gemm_glds_kernel's store shape: lane owns 4 consecutive columns of one row)
+            float* outp = reinterpret_cast<float*>(const_cast<u32x4*>(buf)) + (size_t)(32 * 128 * 4096) / 4 + (size_t)blockIdx.x * 16384;      // behind the panels
+            const int wm = wave >> 1, wn = wave & 1, li = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(outp + (wm * 32 + i * 16 + li) * 128 + wn * 64 + j * 16 + g * 4) = c[i][j];
+        }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) acc ^= __float_as_uint(c[i][j][0] + c[i][j][3]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -102,10 +117,19 @@ __global__ void __launch_bounds__(512) ingest(const u32x4* __restrict__ buf, siz
     acc ^= *(__attribute__((address_space(3))) unsigned*)(smem + tid * 4);
     if (acc == 0x12345678u) sink[0] = acc;
 }
-int main() {
+__global__ void fill_random(unsigned* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned s1 = (unsigned)i * 2654435761u + 12345u; s1 ^= s1 >> 15; s1 *= 2246822519u; s1 ^= s1 >> 13;
+        // two bf16 values in [-2, 2): sign + exponent 126..127 + 7 random mantissa bits
+        const unsigned lo = ((s1 & 0x80u) << 8) | ((126u + ((s1 >> 8) & 1u)) << 7) | (s1 & 0x7fu), hi = (((s1 >> 16) & 0x80u) << 8) | ((126u + ((s1 >> 25) & 1u)) << 7) | ((s1 >> 16) & 0x7fu);
+        p[i] = lo | (hi << 16);
+    }
+}
+int main(int argc, char** argv) {
     const int steps = 32;                                   // 32 x 32 KB = 1 MB per workgroup
     const size_t panel_vec = (size_t)steps * 2048;          // 1 MB panels, 16 of them
-    u32x4* buf; hipMalloc(&buf, 16 * panel_vec * 16); hipMemset(buf, 1, 16 * panel_vec * 16);
+    u32x4* buf; hipMalloc(&buf, (size_t)32 * 128 * 4096 + (size_t)256 * 65536 + 4096); hipMemset(buf, 1, (size_t)32 * 128 * 4096);
+    if (argc > 1) { hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (unsigned*)buf, 16 * panel_vec * 4); hipDeviceSynchronize(); printf("(operands: random bf16 in [-2, 2))\n"); }
     unsigned* sink; hipMalloc(&sink, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipFuncSetAttribute((const void*)ingest<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -113,9 +137,9 @@ int main() {
     hipFuncSetAttribute((const void*)ingest<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)ingest<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)ingest<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)ingest<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const char* names[10] = {"LDS-DMA only", "global -> VGPR only", "half / half interleaved", "LDS-DMA, 8 rows x 128 B pieces (GEMM)", "LDS-DMA, 4 rows x 256 B pieces", "LDS-DMA, 2 rows x 512 B pieces", "LDS-DMA, 1 row x 1 KB pieces", "GEMM k-loop skeleton: DMA + wait + 1 barrier / step", "... + 12 fragment reads / wave / step", "... + 16 MFMAs / wave / step"};
-    for (int mode = 0; mode < 10; ++mode) {
+    hipFuncSetAttribute((const void*)ingest<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipFuncSetAttribute((const void*)ingest<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const char* names[12] = {"LDS-DMA only", "global -> VGPR only", "half / half interleaved", "LDS-DMA, 8 rows x 128 B pieces (GEMM)", "LDS-DMA, 4 rows x 256 B pieces", "LDS-DMA, 2 rows x 512 B pieces", "LDS-DMA, 1 row x 1 KB pieces", "GEMM k-loop skeleton: DMA + wait + 1 barrier / step", "... + 12 fragment reads / wave / step", "... + 16 MFMAs / wave / step", "... + the 128 x 128 fp32 epilogue store", "... with the GEMM's A / B panels and XCD-aware tile order"};
+    for (int mode = 0; mode < 12; ++mode) {
         auto launch = [&]() {
             if (mode == 0) hipLaunchKernelGGL(ingest<0>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
             if (mode == 1) hipLaunchKernelGGL(ingest<1>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
@@ -127,6 +151,8 @@ int main() {
             if (mode == 7) hipLaunchKernelGGL(ingest<7>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
             if (mode == 8) hipLaunchKernelGGL(ingest<8>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
             if (mode == 9) hipLaunchKernelGGL(ingest<9>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 10) hipLaunchKernelGGL(ingest<10>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
+            if (mode == 11) hipLaunchKernelGGL(ingest<11>, dim3(256), dim3(512), 96 * 1024, 0, buf, panel_vec, steps, sink);
         };
         for (int i = 0; i < 5; ++i) launch();
         hipEventRecord(e0);
