@@ -27,6 +27,7 @@ void hulc_set_error(const char* fmt, ...);
 // same instructions, but the compiler schedules around the builtin (it drops the wait state behind `s_mov m0` by moving a VALU into it and orders the next piece's
 // address arithmetic in between).  The DMA is invisible to LLVM's waitcnt pass this way: every consumer waits with its OWN `s_waitcnt vmcnt(N)` + barrier before it
 // reads the LDS data (all kernels here do); compiler-inserted vmcnt waits stay safe, unknown extra operations can only make them wait longer.
+// Used by the GEMM family (gemm.h); conv_reg.h keeps the builtin (tools/cr_bench.hip built both ways: no difference there — its DMA phase is bound by the HBM stream).
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
     const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
