@@ -405,6 +405,42 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
         }
     }
 }
+// The 16-bit-output forms of the decoder's batched GEMMs (input projections with bias / bias2 / a broadcast residual, data gradients; each with the optional SECOND store
+// of the rows the following recurrence needs unmultiplied: relu(v) or v under a ReLU mask) as one compact function.  Same arithmetic, in the same order, as the vector
+// path of epi_prefetch4 / epi_apply4 with alpha = 1 and no mask / activation / dropout.  Why it exists: the generic path, unrolled over a wave's 8 accumulator quads, is ~12 K
+// instructions that every wave executes exactly once — tools/gemm_probe.hip: a feature-less 16-bit store costs 31.4 us through it against 24.6 us with a plain store.
+DEVI bool epi_is_fast16(const EpiP& ep) {
+    return !ep.out_f32 && !ep.accumulate && !ep.atomic && ep.z_stride == 0 && !ep.mask && !ep.relu && ep.drop_p == 0.f && ep.alpha == 1.f && (!ep.res || (ep.res_ld & 3) == 0) &&
+           ((uintptr_t)ep.out & 7) == 0 && (!ep.out2 || (((uintptr_t)ep.out2 & 7) == 0 && (ep.out2_lo & 3) == 0));
+}
+DEVI void epi_fast16_4(const EpiP& ep, const f32x4& acc, int rrow, int col, long long o) {
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias) { const float4 t = *reinterpret_cast<const float4*>(ep.bias + col); b[0] += t.x; b[1] += t.y; b[2] += t.z; b[3] += t.w; }
+    if (ep.bias2) { const float4 t = *reinterpret_cast<const float4*>(ep.bias2 + col); b[0] += t.x; b[1] += t.y; b[2] += t.z; b[3] += t.w; }
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * ep.alpha + b[r];
+    if (ep.res) {
+        const long long ro = (long long)rrow * ep.res_ld + col;
+        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; }
+        else {
+            const uint2 x = *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(ep.res) + ro);
+            v[0] += h2f_lo(x.x); v[1] += h2f_hi(x.x); v[2] += h2f_lo(x.y); v[3] += h2f_hi(x.y);
+        }
+    }
+    *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(ep.out) + o) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
+    if (ep.out2 && o >= ep.out2_lo && o < ep.out2_hi) {
+        const long long o2 = o - ep.out2_lo;
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = ep.out2_relu ? fmaxf(v[r], 0.f) : v[r];
+        if (ep.out2_mask) {
+            const uint2 m = *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(ep.out2_mask) + o2);
+            w[0] = h2f_lo(m.x) > 0.f ? w[0] : 0.f; w[1] = h2f_hi(m.x) > 0.f ? w[1] : 0.f; w[2] = h2f_lo(m.y) > 0.f ? w[2] : 0.f; w[3] = h2f_hi(m.y) > 0.f ? w[3] : 0.f;
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(ep.out2) + o2) = uint2{pack2h(w[0], w[1]), pack2h(w[2], w[3])};
+    }
+}
 // the weight-gradient form of an epilogue: fp32 store or accumulate of the bare product (alpha 1, no bias / residual / mask / activation / dropout / second store).
 // Wave-uniform; the generic epi_store4 path costs gemm_glds_kernel 2.2 us of its 28 at 2048^3 (tools/gemm_probe.hip: flag tests, prefetch structure, 64-bit offsets)
 DEVI bool epi_is_plain_f32(const EpiP& ep) {
@@ -686,6 +722,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
         buf = buf == NST - 1 ? 0 : buf + 1;
     }
     const bool plain = epi_is_plain_f32(ep) && (om.s1 & 3) == 0 && (om.s0 & 3) == 0 && ((uintptr_t)ep.out & 15) == 0;
+    const bool fast16 = epi_is_fast16(ep) && (om.s1 & 3) == 0 && (om.s0 & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * WROWS + i * 16 + li;
@@ -697,6 +734,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
                 const int col = n0 + wn * 64 + j * 16 + g * 4;
                 if (col < N) {
                     if (plain && col + 3 < N) { epi_plain4(ep, acc[i][j], obase + col); continue; }
+                    if (fast16 && col + 3 < N) { epi_fast16_4(ep, acc[i][j], rrow, col, obase + col); continue; }
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     epi_store4<h16_t>(ep, v4, rrow, col, N, obase + col);
                 }

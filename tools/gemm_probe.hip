@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(NW * 64) glds_copy(DenseLoader<h16_t> al, Dens
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + g * 4;
                 if (col < N) {
-                    if (VAR >= 1) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + obase + col) = acc[i][j]; }
+                    if (VAR == 4) { uint2 w; w.x = pack2h(acc[i][j][0], acc[i][j][1]); w.y = pack2h(acc[i][j][2], acc[i][j][3]); *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(ep.out) + obase + col) = w; }
+                    else if (VAR >= 1) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + obase + col) = acc[i][j]; }
                     else {
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     epi_store4<h16_t>(ep, v4, rrow, col, N, obase + col);
@@ -160,5 +161,6 @@ int main() {
     printf("... plain float4 epilogue:           %7.2f us\n", time_copy<1>(a, b, c, M, N, K));
     printf("... + DMA as inline asm:             %7.2f us\n", time_copy<2>(a, b, c, M, N, K));
     printf("... + both k-halves unconditionally: %7.2f us\n", time_copy<3>(a, b, c, M, N, K));
+    printf("inline-asm DMA + PLAIN 16-bit store (8-byte pieces per lane): %7.2f us\n", time_copy<4>(a, b, c, M, N, K));
     return 0;
 }
