@@ -1490,6 +1490,12 @@ struct Engine : IEngine {
             dec_fwd(pidx, B, S, nullptr, nullptr);
             // mcil_default.yaml: gripper_control false (no tcp-frame transform), discrete_gripper false (7th mixture dimension instead of the CE head)
             static const int ll_block = HULC_SWITCH("HULC_LL_BLOCK", 64);     // one wave per workgroup: 256 CUs x 1 wave instead of 64 CUs x 4 (the kernel is one long serial chain per thread)
+            // 16-bit engines: one lane per mixture component (kernels.h logistic_loss_wide_kernel: 17.9 -> ~6 us); the fp32 parity engine keeps the serial kernel's summation order
+            static const int ll_wide = HULC_SWITCH("HULC_LL_WIDE", 1);
+            if (ll_wide && !std::is_same<T, float>::value && NMIX <= 16 && NDIM <= 7)
+                hipLaunchKernelGGL((logistic_loss_wide_kernel<T>), dim3(SB), dim3(128), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
+                                   cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
+            else
             hipLaunchKernelGGL((logistic_loss_kernel<T, NMIX>), dim3(cdiv(SB * 8, ll_block)), dim3(ll_block), 0, st, heads, NHEAD, actions_of(*b), b->robot_obs, B, S, NMIX, NDIM,
                                cfg.num_classes, cfg.log_scale_min, cfg.gripper_alpha, mcil ? 0 : 1, lw / (float)(S * Bm), rowloss, a_tcp, dheads, mcil ? 0 : 1, lscale());
             if (pair) hipLaunchKernelGGL(sum_rows_pair_kernel, dim3(1), dim3(256), 0, st, rowloss, SB, B, pairBv, 1.f / (S * Bm), losses + 0, losses2 + 0);

@@ -1900,6 +1900,110 @@ __global__ void __launch_bounds__(256) logistic_loss_kernel(const float* __restr
     row_loss[gid] = loss;
 }
 
+// The same loss with one LANE per mixture component (16-bit engines, training step; round 5).  logistic_loss_kernel walks a dimension's 10 components serially in
+// one thread: ~2 100 dependent instructions per thread on one wave per SIMD (40 KB of straight-line code that every wave runs once) = 17.9 us for 2 048 tokens.
+// Here a token is a 128-thread block: thread (d = tid >> 4, k = tid & 15) owns component k of dimension d, the max / sum-exp reductions are 16-lane butterflies,
+// the per-component arithmetic is the serial kernel's line by line (every lane derives the token's tcp-frame action itself: lock-step work costs no time).  Sums over
+// the components are associated as a tree instead of left to right: last-bit differences in lz / lse.  Row losses land in the same [token][8] slots.
+template <typename T>
+__global__ void __launch_bounds__(128) logistic_loss_wide_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ actions, const float* __restrict__ robot_obs,
+                                                                 int B, int S, int NMIX, int NDIM, int num_classes, float log_scale_min, float gripper_alpha, int gripper_control,
+                                                                 float grad_scale, float* __restrict__ row_loss, float* __restrict__ a_tcp_out, T* __restrict__ dheads,
+                                                                 int discrete_gripper, const float* __restrict__ lscale) {
+    if (lscale) grad_scale *= lscale[0];
+    const int r = blockIdx.x, tid = threadIdx.x, d = tid >> 4, k = tid & 15;      // time-major row r = t*B + b
+    const int t = r / B, b = r % B;
+    const float* act = actions + ((long long)b * S + t) * 7;
+    float at[7];
+    if (gripper_control) {
+        const float* ro = robot_obs + ((long long)b * S + t) * 15;
+        float R[9], Rn[9];
+        euler_xyz(ro[3], ro[4], ro[5], R);
+        euler_xyz(ro[3] + act[3] * 0.01f, ro[4] + act[4] * 0.01f, ro[5] + act[5] * 0.01f, Rn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) at[i] = R[0 + i] * act[0] + R[3 + i] * act[1] + R[6 + i] * act[2];
+        auto Mij = [&](int i, int j) { return Rn[0 + i] * R[0 + j] + Rn[3 + i] * R[3 + j] + Rn[6 + i] * R[6 + j]; };
+        float o[3] = {atan2f(-Mij(1, 2), Mij(2, 2)), asinf(fminf(1.f, fmaxf(-1.f, Mij(0, 2)))), atan2f(-Mij(0, 1), Mij(0, 0))};
+        const float PI = 3.14159265358979323846f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (o[i] < -PI) o[i] += 2.f * PI;
+            if (o[i] > PI) o[i] -= 2.f * PI;
+            at[3 + i] = o[i] * 100.f;
+        }
+        at[6] = act[6];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) at[i] = act[i];
+    }
+    if (a_tcp_out && tid < 7) {
+        float v = at[0];
+#pragma unroll
+        for (int i = 1; i < 7; ++i) v = (tid == i) ? at[i] : v;
+        a_tcp_out[((long long)b * S + t) * 7 + tid] = v;
+    }
+    const float* hr = heads + (long long)r * ldh;
+    T* dr = dheads + (long long)r * ldh;
+    const int NO = NMIX * NDIM;
+    auto gmax = [](float v) { v = fmaxf(v, __shfl_xor(v, 8, 16)); v = fmaxf(v, __shfl_xor(v, 4, 16)); v = fmaxf(v, __shfl_xor(v, 2, 16)); return fmaxf(v, __shfl_xor(v, 1, 16)); };
+    auto gsum = [](float v) { v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); return v + __shfl_xor(v, 1, 16); };
+    float loss = 0.f;
+    if (d < NDIM) {                                          // group-uniform (16 lanes)
+        const bool live = k < NMIX;
+        const int kk = live ? k : 0;
+        const float hb = 1.f / (num_classes - 1);
+        const float logc = __logf((num_classes - 1) * 0.5f);
+        float a = at[0];
+#pragma unroll
+        for (int i = 1; i < 7; ++i) a = (d == i) ? at[i] : a;
+        const float lg = hr[d * NMIX + kk];
+        const float mlog = gmax(live ? lg : -INFINITY);
+        const float slog = gsum(live ? __expf(lg - mlog) : 0.f);
+        const float lz = mlog + __logf(slog);
+        const float mu = hr[NO + d * NMIX + kk];
+        const float lsr = hr[2 * NO + d * NMIX + kk];
+        const float ls = fmaxf(lsr, log_scale_min);
+        const float inv = __expf(-ls);
+        const float cen = a - mu;
+        const float plus = inv * (cen + hb), minus = inv * (cen - hb), mid = inv * cen;
+        const float sp = sigmoidf(plus), sm = sigmoidf(minus);
+        const float delta = sp - sm;
+        float logp, gp = 0.f, gm = 0.f, gmid = 0.f, direct = 0.f;
+        if (a < -1.f + 1e-3f) { logp = plus - softplusf(plus); gp = sigmoidf(-plus); }
+        else if (a > 1.f - 1e-3f) { logp = -softplusf(minus); gm = -sm; }
+        else if (delta > 1e-5f) { logp = __logf(fmaxf(delta, 1e-12f)); gp = sp * (1.f - sp) / delta; gm = -sm * (1.f - sm) / delta; }
+        else { logp = mid - ls - 2.f * softplusf(mid) - logc; gmid = 1.f - 2.f * sigmoidf(mid); direct = -1.f; }
+        const float dlogp_dmean = -inv * (gp + gm + gmid);
+        const float dlogp_dls = (lsr >= log_scale_min) ? (-(gp * plus + gm * minus + gmid * mid) + direct) : 0.f;
+        const float lp = logp + (lg - lz);
+        const float mx = gmax(live ? lp : -INFINITY);
+        const float se = gsum(live ? __expf(lp - mx) : 0.f);
+        const float lse = mx + __logf(se);
+        loss = -lse;
+        if (live) {
+            const float w = __expf(lp - lse);
+            const float pi = __expf(lg - lz);
+            dr[d * NMIX + k] = from_f<T>(-(w - pi) * grad_scale);
+            dr[NO + d * NMIX + k] = from_f<T>(-w * dlogp_dmean * grad_scale);
+            dr[2 * NO + d * NMIX + k] = from_f<T>(-w * dlogp_dls * grad_scale);
+        }
+    } else if (d == NDIM && discrete_gripper) {
+        const float g0 = hr[3 * NO], g1 = hr[3 * NO + 1];
+        const int lab = (at[6] == -1.f) ? 0 : (int)at[6];
+        const float m = fmaxf(g0, g1);
+        const float lz = m + __logf(__expf(g0 - m) + __expf(g1 - m));
+        loss = gripper_alpha * (lz - (lab == 0 ? g0 : g1));
+        if (k == 0) {
+            const float p0 = __expf(g0 - lz), p1 = __expf(g1 - lz);
+            dr[3 * NO] = from_f<T>(gripper_alpha * (p0 - (lab == 0 ? 1.f : 0.f)) * grad_scale);
+            dr[3 * NO + 1] = from_f<T>(gripper_alpha * (p1 - (lab == 1 ? 1.f : 0.f)) * grad_scale);
+        }
+    }
+    if (d == 7)                                              // the zero pad columns of the packed heads row
+        for (int c = 3 * NO + (discrete_gripper ? 2 : 0) + k; c < ldh; c += 16) dr[c] = from_f<T>(0.f);
+    if (k == 0) row_loss[r * 8 + d] = loss;
+}
+
 // scale * sum(x[0..n)) by one block of 256 threads (deterministic tree); the value is returned to thread 0
 DEVI float block_sum256(const float* __restrict__ x, int n, float* red) {
     float s = 0.f;
