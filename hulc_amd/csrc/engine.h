@@ -2565,6 +2565,9 @@ struct Engine : IEngine {
             }
             if (hulc) {
                 { EpiP ep = epi(dplan, true); gemm(dense<T>(dC, B, HID), dense<T>(wih0T, PLAN, HID), dense_out(PLAN), ep, B, PLAN, HID); }
+                // 16-bit engines: four waves per tile + stores into a fresh buffer (the plan columns of dW_ih0 have no other writer); the fp32 engine keeps the serial sum order
+                if (!std::is_same<T, float>::value && NCLS <= 32) hipLaunchKernelGGL((plan_scatter_grad_w4_kernel<T>), dim3(NCAT, cdiv(HID, 64)), dim3(256), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0, grads_fresh ? 1 : 0);
+                else
                 hipLaunchKernelGGL((plan_scatter_grad_lds_kernel<T>), dim3(NCAT, cdiv(HID, 64)), dim3(64), 0, st, dC, pidx, B, NCAT, NCLS, HID, KIN, dwih0);
             }
             if (mcil) {

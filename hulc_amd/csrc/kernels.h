@@ -1628,6 +1628,39 @@ __global__ void __launch_bounds__(64) plan_scatter_grad_lds_kernel(const T* __re
         if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] = old[k] + tile[cls][r];
     }
 }
+// the same with four waves per (category, 64-unit tile) — each wave scatters 16 of every 64 windows into its OWN LDS tile (the serial kernel's 64 dependent LDS
+// read-add-writes per lane were its long pole: 16.6 us for an 8 MB read-modify-write) — and plain stores when the gradient buffer is known to be zero (`store`)
+template <typename T>
+__global__ void __launch_bounds__(256) plan_scatter_grad_w4_kernel(const T* __restrict__ dC, const int* __restrict__ idx, int B, int NCAT, int NCLS, int H,
+                                                                   int KIN, float* __restrict__ dw, int store) {
+    __shared__ float tile[4][32][65];
+    __shared__ int sidx[64];
+    const int c = blockIdx.x, i0 = blockIdx.y * 64, tid = threadIdx.x, t = tid & 63, w = tid >> 6;
+    for (int k = 0; k < 32; ++k) tile[w][k][t] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        __syncthreads();
+        if (tid < 64) sidx[tid] = b0 + tid < B ? idx[(b0 + tid) * NCAT + c] : 0;
+        float v[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) { const int bb = b0 + w * 16 + b; v[b] = (bb < B && i0 + t < H) ? to_f<T>(dC[(long long)bb * H + i0 + t]) : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; ++b) tile[w][sidx[w * 16 + b]][t] += v[b];      // window order within a wave as in the serial kernel; the four partial sums meet below
+    }
+    __syncthreads();
+    const int cls = tid & 31, rs = tid >> 5;
+    float old[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = rs + 8 * k;
+        old[k] = (!store && i0 + r < H && cls < NCLS) ? dw[(long long)(i0 + r) * KIN + c * NCLS + cls] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = rs + 8 * k;
+        if (i0 + r < H && cls < NCLS) dw[(long long)(i0 + r) * KIN + c * NCLS + cls] = old[k] + ((tile[0][cls][r] + tile[1][cls][r]) + (tile[2][cls][r] + tile[3][cls][r]));
+    }
+}
 // out[r][c] = relu(x[r][c])   (act 2: tanh)
 template <typename T>
 __global__ void relu_copy_kernel(const T* __restrict__ x, T* __restrict__ out, long long n, int act = 1) {
