@@ -594,7 +594,7 @@ struct Engine : IEngine {
         if (big) launch_gemm<T, 128, 128>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
         else launch_gemm<T, 64, 64>(st, a, b, dense_out(lddw), ep, M, N, K, 1, nsplit);
     }
-    static EpiP epi(void* out, bool f32) { EpiP e; e.out = out; e.out_f32 = f32 ? 1 : 0; return e; }
+    EpiP epi(void* out, bool f32) const { EpiP e; e.out = out; e.out_f32 = f32 ? 1 : 0; e.generic_only = epilogue_fast ? 0 : 1; return e; }
 
     // Y[M][N] = X[M][K] W^T (+bias) ...
     void lin_fwd(const T* X, long long ldx, int M, const LinW& L, EpiP ep, long long ldo) {

@@ -45,6 +45,7 @@ struct EpiP {
     long long out2_lo = 0, out2_hi = 0;
     const void* out2_mask = nullptr;
     int out2_relu = 0;
+    int generic_only = 0;        // A/B: never take the compact epilogue paths (hulc_set_option "epilogue_fast" 0)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -410,23 +411,42 @@ DEVI void epi_apply4(const EpiP& ep, const EpiPre4& p, const float (&accv)[4], i
 // path of epi_prefetch4 / epi_apply4 with alpha = 1 and no mask / activation / dropout.  Why it exists: the generic path, unrolled over a wave's 8 accumulator quads, is ~12 K
 // instructions that every wave executes exactly once — tools/gemm_probe.hip: a feature-less 16-bit store costs 31.4 us through it against 24.6 us with a plain store.
 DEVI bool epi_is_fast16(const EpiP& ep) {
-    return !ep.out_f32 && !ep.accumulate && !ep.atomic && ep.z_stride == 0 && !ep.mask && !ep.relu && ep.drop_p == 0.f && ep.alpha == 1.f && (!ep.res || (ep.res_ld & 3) == 0) &&
-           ((uintptr_t)ep.out & 7) == 0 && (!ep.out2 || (((uintptr_t)ep.out2 & 7) == 0 && (ep.out2_lo & 3) == 0));
+    return !ep.generic_only && !ep.out_f32 && !ep.accumulate && !ep.atomic && ep.z_stride == 0 && !(ep.mask && ep.mask_tanh) && ep.relu != 2 && ep.drop_p == 0.f && ep.alpha == 1.f &&
+           (!ep.res || ((ep.res_ld & 3) == 0 && !ep.res_late)) && ((uintptr_t)ep.out & 7) == 0 && (!ep.mask || ((uintptr_t)ep.mask & 7) == 0) &&
+           (!ep.out2 || (((uintptr_t)ep.out2 & 7) == 0 && (ep.out2_lo & 3) == 0));
 }
-DEVI void epi_fast16_4(const EpiP& ep, const f32x4& acc, int rrow, int col, long long o) {
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ep.bias) { const float4 t = *reinterpret_cast<const float4*>(ep.bias + col); b[0] += t.x; b[1] += t.y; b[2] += t.z; b[3] += t.w; }
-    if (ep.bias2) { const float4 t = *reinterpret_cast<const float4*>(ep.bias2 + col); b[0] += t.x; b[1] += t.y; b[2] += t.z; b[3] += t.w; }
-    float v[4];
+// operands first (kernels that fetch them under their operand stream), arithmetic + stores later
+struct EpiF16Pre { float b[4], rv[4]; uint2 mk; };
+DEVI EpiF16Pre epi_fast16_pre(const EpiP& ep, int rrow, int col, long long o) {
+    EpiF16Pre p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] * ep.alpha + b[r];
+    for (int r = 0; r < 4; ++r) { p.b[r] = 0.f; p.rv[r] = 0.f; }
+    p.mk = uint2{0u, 0u};
+    if (ep.bias) { const float4 t = *reinterpret_cast<const float4*>(ep.bias + col); p.b[0] += t.x; p.b[1] += t.y; p.b[2] += t.z; p.b[3] += t.w; }
+    if (ep.bias2) { const float4 t = *reinterpret_cast<const float4*>(ep.bias2 + col); p.b[0] += t.x; p.b[1] += t.y; p.b[2] += t.z; p.b[3] += t.w; }
     if (ep.res) {
         const long long ro = (long long)rrow * ep.res_ld + col;
-        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; }
+        if (ep.res_f32) { const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.res) + ro); p.rv[0] = x.x; p.rv[1] = x.y; p.rv[2] = x.z; p.rv[3] = x.w; }
         else {
             const uint2 x = *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(ep.res) + ro);
-            v[0] += h2f_lo(x.x); v[1] += h2f_hi(x.x); v[2] += h2f_lo(x.y); v[3] += h2f_hi(x.y);
+            p.rv[0] = h2f_lo(x.x); p.rv[1] = h2f_hi(x.x); p.rv[2] = h2f_lo(x.y); p.rv[3] = h2f_hi(x.y);
         }
+    }
+    if (ep.mask) p.mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(ep.mask) + o);
+    return p;
+}
+DEVI void epi_fast16_apply(const EpiP& ep, const EpiF16Pre& p, const f32x4& acc, long long o) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * ep.alpha + p.b[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += p.rv[r];
+    if (ep.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (ep.mask) {
+        v[0] = h2f_lo(p.mk.x) > 0.f ? v[0] : 0.f; v[1] = h2f_hi(p.mk.x) > 0.f ? v[1] : 0.f; v[2] = h2f_lo(p.mk.y) > 0.f ? v[2] : 0.f; v[3] = h2f_hi(p.mk.y) > 0.f ? v[3] : 0.f;
     }
     *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(ep.out) + o) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
     if (ep.out2 && o >= ep.out2_lo && o < ep.out2_hi) {
@@ -441,10 +461,14 @@ DEVI void epi_fast16_4(const EpiP& ep, const f32x4& acc, int rrow, int col, long
         *reinterpret_cast<uint2*>(reinterpret_cast<h16_t*>(ep.out2) + o2) = uint2{pack2h(w[0], w[1]), pack2h(w[2], w[3])};
     }
 }
+DEVI void epi_fast16_4(const EpiP& ep, const f32x4& acc, int rrow, int col, long long o) {
+    const EpiF16Pre p = epi_fast16_pre(ep, rrow, col, o);
+    epi_fast16_apply(ep, p, acc, o);
+}
 // the weight-gradient form of an epilogue: fp32 store or accumulate of the bare product (alpha 1, no bias / residual / mask / activation / dropout / second store).
 // Wave-uniform; the generic epi_store4 path costs gemm_glds_kernel 2.2 us of its 28 at 2048^3 (tools/gemm_probe.hip: flag tests, prefetch structure, 64-bit offsets)
 DEVI bool epi_is_plain_f32(const EpiP& ep) {
-    return ep.out_f32 && !ep.atomic && ep.z_stride == 0 && !ep.bias && !ep.bias2 && !ep.res && !ep.mask && !ep.relu && ep.drop_p == 0.f && !ep.out2 && ep.alpha == 1.f;
+    return !ep.generic_only && ep.out_f32 && !ep.atomic && ep.z_stride == 0 && !ep.bias && !ep.bias2 && !ep.res && !ep.mask && !ep.relu && ep.drop_p == 0.f && !ep.out2 && ep.alpha == 1.f;
 }
 DEVI void epi_plain4(const EpiP& ep, const f32x4& acc, long long o) {
     f32x4* op = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + o);
@@ -1067,8 +1091,11 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __rest
     const bool ethread = tid < MT * 64 && erow < M;
     const int errow = ep.res_rowmod > 0 ? erow % ep.res_rowmod : erow;
     const long long eo = ethread ? om.offset(erow, 0) + ecol : 0;
+    // compact 16-bit epilogue (bias / residual / ReLU / ReLU mask / second store: what the MLP layers and recurrent steps use) beside the generic one
+    const bool fast16 = epi_is_fast16(ep) && ecol + 3 < N && (eo & 3) == 0;
     EpiPre4 pre;
-    if (ethread) pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo);
+    EpiF16Pre fpre;
+    if (ethread) { if (fast16) fpre = epi_fast16_pre(ep, errow, ecol, eo); else pre = epi_prefetch4<h16_t>(ep, errow, ecol, N, eo); }
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1099,8 +1126,11 @@ __global__ void __launch_bounds__(NW * 64) skinny_lds_kernel(const h16_t* __rest
         f32x4 v = red[tid];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[w * MT * 64 + tid];
+        if (fast16) epi_fast16_apply(ep, fpre, v, eo);
+        else {
         const float v4[4] = {v[0], v[1], v[2], v[3]};
         epi_apply4<h16_t>(ep, pre, v4, errow, ecol, N, eo);
+        }
     }
     KSTAMP(5);
 }

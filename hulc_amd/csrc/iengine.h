@@ -92,6 +92,7 @@ struct IEngine {
         // "gemm_pair" (default 0; 16-bit engines): the decoder's two layer-1 weight gradients, which share dZ1^T up to a shift of one time step, run as ONE launch that
         // streams the shared operand once (gemm.h gemm_glds_pair_kernel; needs the batch to be a multiple of 64 windows); 0 = two launches
         if (name && !strcmp(name, "gemm_pair")) { gemm_pair_mode = value != 0; return 0; }
+        if (name && !strcmp(name, "epilogue_fast")) { epilogue_fast = value != 0; return 0; }
         // "adam_fused_transposes" (default 1; 16-bit engines): the Adam / AdamW step writes the transposed 16-bit weight copies itself (kernels.h adam_tiled_kernel); 0 = flat pass + batched transpose
         if (name && !strcmp(name, "adam_fused_transposes")) { set_adam_fuse(value != 0); return 0; }
         if (name && !strcmp(name, "timer_event_fence")) { event_flags = value != 0 ? hipEventDefault : hipEventDisableSystemFence; for (auto& kv : timers) { for (auto& ev : kv.second.ev) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); } kv.second.ev.clear(); kv.second.used = 0; } return 0; }
@@ -109,6 +110,7 @@ struct IEngine {
     // ---- per-kernel-class HIP-event timers (bench.py roofline leg): events are recorded on `st` around the launches of a class
     struct KTimer { std::string name, bound; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double flops = 0, bytes = 0; long long launches = 0; };
     std::map<std::string, KTimer> timers;
+    bool epilogue_fast = true;              // hulc_set_option "epilogue_fast" 0: every GEMM epilogue through the generic path (A/B)
     bool gemm_pair_mode = false;            // measured SLOWER in the step (3.048 against 3.032 ms, class gemm_128x128 0.225 against 0.217 ms): off
     bool timing = false;
     std::string timing_filter;      // empty = every class; else ",a,b,": only the listed classes (keeps event overhead out of the timed region)
