@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_tr_kernel(const h16_t* __re
 //   * whole-frame bands where the frame fits (conv3: 152 KB of LDS), balanced bands otherwise (no 1-row tail band).
 // Chunk k of a thread is (dY or X, LDS offset, global offset) packed in one register; loads are unconditional (clamped).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CI, int CO, int KH, int KW, int S, int NWV, int D = 3>
+template <int CI, int CO, int KH, int KW, int S, int NWV, int D = 3, int IWC = 0>      // IWC: compile-time image width (0: run time), see conv_wgrad_dma_kernel
 __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                             float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                             int* __restrict__ work_ctr, int FPB) {
@@ -227,16 +227,16 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
     const int g = lane >> 4, a = lane & 15;
     const int prow = a >> 2;
     const int ccol = (a & 3) * 8;
-    const int nt0 = q * C::NTW;
-    // per n-tile LDS offset of its tap / channel group (wave-uniform)
+    // n-tile <-> wave as in conv_wgrad_dma_kernel: quarter q = (tap group tg, channel group cgq); tile j of a wave is tap tg * TPG + j, its LDS offset splits into a
+    // wave part (added to the image pointer) and a j part that is the same for every wave (an immediate when IW is a compile-time constant)
+    constexpr int NTG = 4 / C::CGN, TPG = KH * KW / NTG;
+    static_assert(C::CGN <= 4 && 4 % C::CGN == 0 && (KH * KW) % NTG == 0 && TPG == C::NTW && (NTG == 1 || TPG % KW == 0), "n-tile assignment");
+    const int IWk = IWC ? IWC : IW;
+    const int cgq = q % C::CGN, tg = q / C::CGN;
+    const int qoff = ((tg * TPG / KW) * IWk) * C::XS + cgq * 32;
     int toff[C::NTW];
 #pragma unroll
-    for (int j = 0; j < C::NTW; ++j) {
-        const int nt = __builtin_amdgcn_readfirstlane(nt0) + j;
-        const int tap = nt / C::CGN, cg = nt % C::CGN;
-        const int kh = tap / KW, kw = tap % KW;
-        toff[j] = (kh * IW + kw) * C::XS + cg * 32;
-    }
+    for (int j = 0; j < C::NTW; ++j) toff[j] = ((j / KW) * IWk + j % KW) * C::XS;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     u32x4_t pf[PF];
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
                 pbv[hh] += step4; uo[hh] += r4;
                 if (uo[hh] >= U) { uo[hh] -= U; pbv[hh] += wrapd; }
             }
-            auto bfrag = [&](int j) { return tr_read8(ximg + pb[0] + toff[j], ximg + pb[1] + toff[j]); };
+            auto bfrag = [&](int j) { return tr_read8(ximg + qoff + pb[0] + toff[j], ximg + qoff + pb[1] + toff[j]); };
             // B fragments run D n-tiles ahead of their MFMAs; A fragments first
             h16x8_t ring[D];
             h16x8_t af[CTH];
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(NWV * 64) conv_wgrad_tr8_kernel(const h16_t* _
 #pragma unroll
         for (int c = 0; c < CTH; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + ((tg * TPG + j) * C::CGN + cgq) * 16 + a] = acc[j][c][r];
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -378,7 +378,7 @@ DEVI void wg_lds_dma16(const void* src, lds_char* dst) {
     const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dst);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
 }
-template <int CI, int CO, int KH, int KW, int S>
+template <int CI, int CO, int KH, int KW, int S, int IWC = 0>      // IWC: the image width at compile time (0: run time) — the tap offsets of the B fragments become ds_read immediates
 __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const h16_t* __restrict__ X, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                              float* __restrict__ bias_part, const h16_t* __restrict__ zeros, int Nf, int IH, int IW, int OH, int OW,
                                                              int R, int nbands, int dbg, int* __restrict__ work_ctr) {
@@ -444,15 +444,18 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const h16_t* __rest
     const int g = lane >> 4, a = lane & 15;
     const int prow = a >> 2;
     const int ccol = (a & 3) * 8;
-    const int nt0 = q * C::NTW;
+    // n-tile <-> wave (round 5): wave quarter q owns channel group q % CGN of the taps [tg * TPG, (tg + 1) * TPG), tg = q / CGN — its n-tile j is tap tg * TPG + j.
+    // The LDS offset of tile j is then (wave part) + (j part): ((tg * TPG / KW) * IW) * XS + cgq * 32 goes into the band's base pointer once, and
+    // ((j / KW) * IW + j % KW) * XS is the same for every wave — an immediate of the ds_read when IW is a compile-time constant (IWC): 18 VALU adds per multiply step
+    // and wave gone.  (Before: tiles q * NTW .. + NTW - 1 in (tap, channel group) order: a different offset list per wave, added with VALU.)
+    constexpr int NTG = 4 / C::CGN, TPG = KH * KW / NTG;
+    static_assert(C::CGN <= 4 && 4 % C::CGN == 0 && (KH * KW) % NTG == 0 && TPG == C::NTW && (NTG == 1 || TPG % KW == 0), "n-tile assignment");
+    const int IWk = IWC ? IWC : IW;
+    const int cgq = q % C::CGN, tg = q / C::CGN;
+    const int qoff = ((tg * TPG / KW) * IWk) * C::XS + cgq * 32;          // this wave's part of every B-fragment offset
     int toff[C::NTW];
 #pragma unroll
-    for (int j = 0; j < C::NTW; ++j) {
-        const int nt = __builtin_amdgcn_readfirstlane(nt0) + j;
-        const int tap = nt / C::CGN, cg = nt % C::CGN;
-        const int kh = tap / KW, kw = tap % KW;
-        toff[j] = (kh * IW + kw) * C::XS + cg * 32;
-    }
+    for (int j = 0; j < C::NTW; ++j) toff[j] = ((j / KW) * IWk + j % KW) * C::XS;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     __shared__ int s_next[2];
     int item = blockIdx.x, iter = 0, nb = 0;
@@ -467,8 +470,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const h16_t* __rest
         const int cur = item;
         item = work_ctr ? s_next[iter & 1] : item + (int)gridDim.x;
         ++iter;
-        lds_char* const ximg = lbase + nb * bbytes;
-        lds_char* const dyimg = ximg + xslots * 16;
+        lds_char* const ximg0 = lbase + nb * bbytes;
+        lds_char* const dyimg = ximg0 + xslots * 16;
+        lds_char* const ximg = ximg0 + qoff;              // B fragments only
         nb ^= 1;
         // the next band streams in under the bias sums and the MFMAs below.  Waves 0-3 issue their pieces now, waves 4-7 (the second wave of each
         // SIMD) after their first multiply step, so that one wave per SIMD multiplies while the other spends its issue time
@@ -540,7 +544,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_dma_kernel(const h16_t* __rest
 #pragma unroll
         for (int c = 0; c < CTH; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + (nt0 + j) * 16 + a] = acc[j][c][r];
+            for (int r = 0; r < 4; ++r) out[(long long)((h * CTH + c) * 16 + g * 4 + r) * KC + ((tg * TPG + j) * C::CGN + cgq) * 16 + a] = acc[j][c][r];
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -584,11 +588,17 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
         int nb = 0; size_t lds = 0;
         const int R = conv_wgrad_dma_rows<CI, CO, KH, KW, S>(IH, IW, OH, OW, &nb, &lds);
         if (R > 0 && (long long)Nf * IH * IW * CI < (1ll << 31)) {
+            constexpr int IWS = (CI == 64 && KH == 3) ? 23 : ((CI == 32 && KH == 4) ? 49 : 0);      // the static camera's maps (200 x 200 frames): conv3 reads 23 x 23, conv2 49 x 49
             static bool attr3 = false;
-            if (!attr3) { hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<CI, CO, KH, KW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); attr3 = true; }
+            if (!attr3) {
+                hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<CI, CO, KH, KW, S, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<CI, CO, KH, KW, S, IWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                attr3 = true;
+            }
             const int grid = std::min(std::min(Nf * nb, 256), max_blocks);
             static const int dbg3 = HULC_SWITCH("HULC_WGRAD_DBG", 0);
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<CI, CO, KH, KW, S>), dim3(grid), dim3(512), lds, st, X, dY, part, bias_part, zeros, Nf, IH, IW, OH, OW, R, nb, dbg3, work_ctr);
+            if (IWS && IW == IWS) hipLaunchKernelGGL((conv_wgrad_dma_kernel<CI, CO, KH, KW, S, IWS>), dim3(grid), dim3(512), lds, st, X, dY, part, bias_part, zeros, Nf, IH, IW, OH, OW, R, nb, dbg3, work_ctr);
+            else hipLaunchKernelGGL((conv_wgrad_dma_kernel<CI, CO, KH, KW, S, 0>), dim3(grid), dim3(512), lds, st, X, dY, part, bias_part, zeros, Nf, IH, IW, OH, OW, R, nb, dbg3, work_ctr);
             return grid;
         }
     }
@@ -634,6 +644,15 @@ static inline int launch_conv_wgrad_tr(hipStream_t st, const h16_t* X, const h16
                 return grid;
             }
 #endif
+            {      // the gripper camera's maps (84 x 84 frames): conv3 reads 9 x 9, conv2 20 x 20 — the compile-time-width instance (tap offsets as ds_read immediates)
+                constexpr int IWG = (CI == 64 && KH == 3) ? 9 : ((CI == 32 && KH == 4) ? 20 : 0);
+                if (IWG && IW == IWG) {
+                    static bool ag = false;
+                    if (!ag) { hipFuncSetAttribute((const void*)conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 3, IWG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); ag = true; }
+                    hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV, 3, IWG>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
+                    return grid;
+                }
+            }
             hipLaunchKernelGGL((conv_wgrad_tr8_kernel<CI, CO, KH, KW, S, NWV>), dim3(grid), dim3(NWV * 64), lds, st, X, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb, dbg, work_ctr, fpb);
             return grid;
         }
