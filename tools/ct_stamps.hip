@@ -1,3 +1,5 @@
+// NOTE (round 5): written against the round-4 headers.  It no longer builds / runs against the current ones (the fused kernels read fragment-ordered weights since round 4's
+// last day; the conv_tile stamp build faults): kept for the profiles of rounds 2 - 4 it produced (profiles/r0[234]_*), not part of tools/refresh_profiles.sh any more.
 // tools only: per-band phase timing (shader-clock stamps, lane 0 of every wave) of the raw-tile conv kernels on random data.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ct_stamps.hip -o tools/bin/ct_stamps && tools/bin/ct_stamps
 #define HULC_CT_STAMPS 1

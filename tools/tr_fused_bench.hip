@@ -1,3 +1,5 @@
+// NOTE (round 5): written against the round-4 headers.  It no longer builds / runs against the current ones (the fused kernels read fragment-ordered weights since round 4's
+// last day; the conv_tile stamp build faults): kept for the profiles of rounds 2 - 4 it produced (profiles/r0[234]_*), not part of tools/refresh_profiles.sh any more.
 // tools/tr_fused_bench.hip — timing + phase stamps of the fused transformer encoder layer forward (hulc_amd/csrc/tr_fused.h) on random data.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRF_STAMPS tools/tr_fused_bench.hip -o tools/bin/tr_fused_bench && tools/bin/tr_fused_bench
 #include <hip/hip_runtime.h>
