@@ -101,3 +101,41 @@ def test_paired_layer1_weight_gradient_gemm_equals_two_launches():
         assert float(a.norm()) > 0
         rel = float((a - b).norm() / a.norm())
         assert rel < 1e-6, (n, rel)
+
+
+def test_compact_gemm_epilogues_equal_the_generic_one():
+    """hulc_set_option "epilogue_fast": the compact epilogue paths of the GEMM kernels (plain fp32 store / accumulate; 16-bit output with bias, residual, ReLU, ReLU mask
+    and the second store — gemm.h epi_plain4 / epi_fast16_*) against the generic epi_store4 path on a step whose decoder GEMMs take the 128 x 128 LDS-DMA kernel
+    (B = 64, S = 16: 1024 token rows).  Same arithmetic in the same order: loss and every gradient tensor agree to the run-to-run noise of the backward's atomics."""
+    B, S = 64, 16
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    dev = torch.device("cuda:0")
+    mb = synth_batch(B, S, dev, 3, False)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    mb["plan_idx"] = torch.randint(0, 32, (B, 32), device=dev, generator=g, dtype=torch.int32)
+    out = {}
+    for fast in (0, 1, 2):                               # 2: the compact paths again = the run-to-run noise of the backward (fp32 atomics in front of 16-bit roundings)
+        eng = StepEngine(dims, B, S, dtype="bf16", device="cuda:0", dropout_p=0.1, seed=1, num_classes=dims.mix_classes)
+        eng.set_option("epilogue_fast", min(fast, 1))
+        eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+        eng.zero_grads()
+        loss = eng.forward_loss(mb, False, 1.0, 3.0, step=2)["total_mod"]
+        eng.backward()
+        torch.cuda.synchronize()
+        out[fast] = dict(loss=loss, g=eng.flat_grads.clone())
+        lay = dict(eng.layout)
+        eng.close()
+    assert abs(out[0]["loss"] - out[1]["loss"]) <= 1e-6 * abs(out[0]["loss"]), (out[0]["loss"], out[1]["loss"])
+    bad, noise_max, diff_max = [], 0.0, 0.0
+    for n, (off, shape) in lay.items():
+        sz = int(np.prod(shape)) if len(shape) else 1
+        x, y, z = out[0]["g"][off:off + sz].double(), out[1]["g"][off:off + sz].double(), out[2]["g"][off:off + sz].double()
+        den = float(y.norm())
+        if den <= 1e-12:
+            continue
+        d, nz = float((x - y).norm()) / den, float((z - y).norm()) / den
+        noise_max, diff_max = max(noise_max, nz), max(diff_max, d)
+        if d > 3.0 * nz + 2e-4:
+            bad.append((n, d, nz))
+    print("generic vs compact: worst tensor %.2e; compact vs compact again: %.2e" % (diff_max, noise_max))
+    assert not bad, bad[:5]
