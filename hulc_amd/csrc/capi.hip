@@ -61,6 +61,7 @@ int hulc_bind_params(hulc_ctx* ctx, float* p, float* g, float* m, float* v, int6
 }
 int hulc_prepare_weights(hulc_ctx* ctx) { return ctx->e->prepare_weights(); }
 int hulc_zero_grads(hulc_ctx* ctx) { return ctx->e->zero_grads(); }
+int hulc_flush_grads(hulc_ctx* ctx) { return ctx->e->flush_grads(); }
 int hulc_forward_loss(hulc_ctx* ctx, const hulc_batch* b, float lw, float cw, float* out, int32_t on_host) {
     if (!ctx || !b) { hulc_set_error("hulc_forward_loss: null argument"); return 1; }
     return ctx->e->forward(b, lw, cw, out, on_host);
@@ -183,6 +184,14 @@ int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes) {
     if (!ctx || !ctx->e->comm) { hulc_set_error("hulc_comm_stats: no communicator"); return 1; }
     if (n_collectives) *n_collectives = ctx->e->comm->n_collectives;
     if (bytes) *bytes = ctx->e->comm->bytes_reduced;
+    return 0;
+}
+int hulc_comm_size(hulc_ctx* ctx, int32_t* rank, int32_t* world) {
+    if (!ctx || !ctx->e->comm) { hulc_set_error("hulc_comm_size: no communicator"); return 1; }
+    int r = -1, w = -1;
+    if (ctx->e->comm->size(&r, &w)) return 1;
+    if (rank) *rank = r;
+    if (world) *world = w;
     return 0;
 }
 int hulc_comm_timeline(hulc_ctx* ctx, double* out, int32_t cap_buckets, double* backward_us) {

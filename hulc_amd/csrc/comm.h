@@ -31,7 +31,9 @@ struct GradComm {
     typedef int (*CommDestroyFn)(Comm);
     typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
     typedef const char* (*GetErrorStringFn)(int);
-    struct Api { void* lib = nullptr; GetUniqueIdFn get_id = nullptr; CommInitRankFn init = nullptr; CommDestroyFn destroy = nullptr; AllReduceFn allreduce = nullptr; GetErrorStringFn errstr = nullptr; };
+    typedef int (*CommQueryFn)(const Comm, int*);             // ncclCommCount / ncclCommUserRank
+    struct Api { void* lib = nullptr; GetUniqueIdFn get_id = nullptr; CommInitRankFn init = nullptr; CommDestroyFn destroy = nullptr; AllReduceFn allreduce = nullptr; GetErrorStringFn errstr = nullptr;
+                 CommQueryFn count = nullptr, user_rank = nullptr; };
 
     static Api& api() { static Api a; return a; }
     static bool load_api() {
@@ -43,6 +45,7 @@ struct GradComm {
         a.get_id = (GetUniqueIdFn)dlsym(a.lib, "ncclGetUniqueId"); a.init = (CommInitRankFn)dlsym(a.lib, "ncclCommInitRank");
         a.destroy = (CommDestroyFn)dlsym(a.lib, "ncclCommDestroy"); a.allreduce = (AllReduceFn)dlsym(a.lib, "ncclAllReduce");
         a.errstr = (GetErrorStringFn)dlsym(a.lib, "ncclGetErrorString");
+        a.count = (CommQueryFn)dlsym(a.lib, "ncclCommCount"); a.user_rank = (CommQueryFn)dlsym(a.lib, "ncclCommUserRank");      // optional: hulc_comm_size
         if (!a.get_id || !a.init || !a.destroy || !a.allreduce) { hulc_set_error("RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce"); a.lib = nullptr; return false; }
         return true;
     }
@@ -110,6 +113,18 @@ struct GradComm {
         UniqueId id; memcpy(&id, unique_id, sizeof(id));
         const int rc = api().init(&comm, world, id, rank);
         if (rc != 0) { hulc_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, err(rc)); comm = nullptr; return 1; }
+        return 0;
+    }
+    // what the LIVE communicator says about itself (ncclCommCount / ncclCommUserRank), not what the host passed to init(): the evidence bench.py
+    // prints as allreduce.rccl_ranks and gates its N > 1 line on
+    int size(int* rank_out, int* world_out) const {
+        if (!comm) { hulc_set_error("hulc_comm_size: no communicator"); return 1; }
+        int w = -1, r = -1;
+        if (!api().count || !api().user_rank) { hulc_set_error("hulc_comm_size: this RCCL lacks ncclCommCount / ncclCommUserRank"); return 1; }
+        const int rc1 = api().count(comm, &w), rc2 = api().user_rank(comm, &r);
+        if (rc1 != 0 || rc2 != 0) { hulc_set_error("ncclCommCount / ncclCommUserRank failed: %s", err(rc1 ? rc1 : rc2)); return 1; }
+        if (rank_out) *rank_out = r;
+        if (world_out) *world_out = w;
         return 0;
     }
     ~GradComm() {

@@ -373,8 +373,13 @@ struct Engine : IEngine {
         // data parallelism: the "this step's gradients are garbage" vote rides in an alignment-padding element of the LAST bucket (see skip_vote_put)
         lazy.clear();
         skip_pad = -1;
-        for (const auto& kv : tab_order)
-            if (kv.first.compare(0, 19, "perceptual_encoder.") == 0 && kv.second.n % 64 != 0 && kv.second.off + kv.second.n < numel) { skip_pad = kv.second.off + kv.second.n; break; }
+        // (only a REAL padding element qualifies — hulc_bind_params accepts any 4-aligned layout, so the element behind a tensor is
+        //  padding only if the next tensor of the table starts later; a tightly packed layout has no vote word and the vote falls back to skip_pad = -1)
+        for (size_t i = 0; i < tab_order.size(); ++i) {
+            const auto& kv = tab_order[i];
+            const int64_t end = kv.second.off + kv.second.n, nxt = i + 1 < tab_order.size() ? tab_order[i + 1].second.off : numel;
+            if (kv.first.compare(0, 19, "perceptual_encoder.") == 0 && end < nxt && end < numel) { skip_pad = end; break; }
+        }
         try {
             bind_enc(encS, "perceptual_encoder.rgb_static_encoder.", false, 200);
             bind_enc(encG, "perceptual_encoder.rgb_gripper_encoder.", true, 84);
@@ -761,7 +766,12 @@ struct Engine : IEngine {
     std::vector<LazyG> lazy;
     void lazy_register(const LinW& L) {
         if (!std::is_same<T, h16_t>::value || !L.dW || (int64_t)L.N * L.K < 65536) return;
-        const int64_t off = L.dW - G, n = ((int64_t)L.N * L.K + 63) / 64 * 64;
+        const int64_t off = L.dW - G, exact = (int64_t)L.N * L.K;
+        int64_t n = (exact + 63) / 64 * 64;
+        // the rounded range may cover alignment padding only: never the first elements of the next tensor of a tightly packed layout
+        for (const auto& kv : tab_order) if (kv.second.off > off && kv.second.off < off + n) n = exact;
+        if (off + n > numel) n = exact;
+        if (n % 4 || off % 4) return;      // multi_zero_kernel clears 16-byte pieces
         for (const LazyG& z : lazy) if (z.off == off) return;
         if (lazy.size() < 30 && off >= 0 && off + n <= numel) lazy.push_back(LazyG{off, n, false});
     }
@@ -783,6 +793,11 @@ struct Engine : IEngine {
         for (LazyG& z : lazy)
             if (z.stale && z.off >= lo && z.off + z.n <= hi) { mz.p[k] = G + z.off; mz.n[k] = z.n; mx = std::max<long long>(mx, z.n); ++k; z.stale = false; }
         if (k) hipLaunchKernelGGL(multi_zero_kernel, dim3((unsigned)std::min<long long>(256, cdiv(mx, 4 * 256 * 8)), k), dim3(256), 0, s, mz);
+    }
+    int flush_grads() override {
+        if (!bound) { hulc_set_error("hulc_flush_grads before hulc_bind_params"); return 1; }
+        lazy_sweep(0, numel, st);
+        return 0;
     }
     int zero_grads() override {
         if (!bound) { hulc_set_error("hulc_zero_grads before hulc_bind_params"); return 1; }
@@ -1079,7 +1094,9 @@ struct Engine : IEngine {
             ConvTileP p{}; p.img = dy; p.IMH = g.OH; p.IMW = g.OW; p.w = c.Wd; p.out = dx; p.OUTH = g.IH; p.OUTW = g.IW; p.mask = maskbits ? nullptr : mask; p.maskbits = maskbits; p.Nf = g.Nf; p.work_ctr = next_ctr();
             bool ok = false;
             const double pin = (double)g.Nf * g.IH * g.IW, pout = (double)g.Nf * g.OH * g.OW;
-            TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + 2 * pin * c.I) * 2);
+            // algorithmic bytes as SURVEY 8(d) counts them: dY read once, dX written once, 2 B each; the ReLU mask of the layer below is read as BIT words
+            // (pin * I / 8 bytes) when the forward left them, as a second 16-bit activation read otherwise (the bit form was priced as a full read)
+            TimerScope ts(this, "conv_tile_dgrad", "mfma", 2.0 * pout * c.O * c.I * c.KH * c.KW, (pout * c.O + pin * c.I) * 2 + (maskbits ? pin * c.I / 8 : (mask ? pin * c.I * 2 : 0)));
             static const int conv_reg = HULC_SWITCH("HULC_CONV_REG", 15);      // bit 2: conv3, bit 3: conv2 data gradient on conv_reg.h
             static const int w4 = HULC_SWITCH("HULC_CONV_REG_W4", 11);         // same bits: two 256-thread workgroups per CU (NWV = 4).  conv3's data gradient (bit 2) stays on the one-workgroup form:
                                                                                // 144 weight registers + the zero-border decode spill 16 registers at 256 VGPRs (90.3 vs 83.5 us in the step, 3.470 vs 3.448 ms/step)
@@ -1786,7 +1803,11 @@ struct Engine : IEngine {
         if (mcil) {
             HIP_CHECK(hipMemcpyAsync(plan_f, plan, sizeof(float) * (PLAN / 2), hipMemcpyDefault, st));
             hipLaunchKernelGGL((cast_kernel<float, T>), dim3(1), dim3(256), 0, st, plan_f, roll_plan_c, (long long)(PLAN / 2));
-        } else if (!gcbc) HIP_CHECK(hipMemcpyAsync(roll_plan, plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+        } else if (!gcbc) {
+            HIP_CHECK(hipMemcpyAsync(roll_plan, plan, sizeof(int) * NCAT, hipMemcpyDefault, st));
+            // a caller-supplied class index is a column of the plan embedding gather in dec_fwd: keep it inside [0, NCLS)
+            hipLaunchKernelGGL(clamp_index_kernel, dim3(1), dim3(64), 0, st, roll_plan, NCAT, NCLS);
+        }
         HIP_CHECK(hipStreamSynchronize(st));
         roll_has_plan = true;
         return 0;
@@ -2285,11 +2306,13 @@ struct Engine : IEngine {
     // ---------------------------------------------------------------- gradient all-reduce buckets (comm.h)
     // Module groups of the flat buffer (hulc_amd/spec.py::layout keeps each group contiguous), in the order the backward finalises them.
     struct Bucket { int64_t lo, hi; };
-    Bucket group_range(const char* prefix) const {          // [first element, end of the last (64-padded) tensor) of the tensors named prefix*
-        int64_t lo = numel, hi = 0;
+    Bucket group_range(const char* prefix) const {          // [first element, start of the tensor behind the last one) of the tensors named prefix*: padding
+        int64_t lo = numel, hi = 0;                          // between tensors (hulc_amd.spec: 64 elements) rides with the group, a packed layout has none
         const std::string a(prefix);
-        for (const auto& kv : tab_order)
-            if (kv.first.compare(0, a.size(), a) == 0) { lo = std::min(lo, kv.second.off); hi = std::max(hi, kv.second.off + (kv.second.n + 63) / 64 * 64); }
+        for (size_t i = 0; i < tab_order.size(); ++i) {
+            const auto& kv = tab_order[i];
+            if (kv.first.compare(0, a.size(), a) == 0) { lo = std::min(lo, kv.second.off); hi = std::max(hi, i + 1 < tab_order.size() ? tab_order[i + 1].second.off : numel); }
+        }
         if (hi <= lo) return Bucket{0, 0};
         return Bucket{lo, std::min<int64_t>(hi, numel)};
     }
@@ -2318,15 +2341,20 @@ struct Engine : IEngine {
     // encoders', whose tensors leave 64-element alignment padding) is reduced, each rank writes 1.0 into ONE padding element of its gradient
     // buffer if its skip word carries this step's tag, else 0.0; after the SUM a non-zero element means "some rank failed" -> every rank
     // sets its own skip word (adam / sgd / scaler_update then return without touching p / m / v) and clears the element.
+    // A layout without such a padding element (hulc_bind_params accepts any 4-aligned, tightly packed table) votes through a word of the engine's own
+    // (vote_word): one extra 4-byte all-reduce behind the range that ends the buffer — never through an element that belongs to a tensor.
     int64_t skip_pad = -1;
+    float* vote_word = nullptr;
+    float* vote_ptr() { if (skip_pad >= 0) return G + skip_pad; if (!vote_word) vote_word = alloc<float>(64); return vote_word; }
     void skip_vote_put(hipStream_t s) {
-        if (skip_pad < 0) return;
         if (!rp_skip) rp_skip = alloc<unsigned>(64);
-        if (rp_skip) hipLaunchKernelGGL(dp_skip_put_kernel, dim3(1), dim3(1), 0, s, (const unsigned*)rp_skip, opt_seq + 1, G + skip_pad);
+        float* w = vote_ptr();
+        if (rp_skip && w) hipLaunchKernelGGL(dp_skip_put_kernel, dim3(1), dim3(1), 0, s, (const unsigned*)rp_skip, opt_seq + 1, w);
     }
     void skip_vote_get(hipStream_t s) {
-        if (skip_pad < 0 || !rp_skip) return;
-        hipLaunchKernelGGL(dp_skip_get_kernel, dim3(1), dim3(1), 0, s, G + skip_pad, rp_skip, opt_seq + 1);
+        float* w = vote_ptr();
+        if (!rp_skip || !w) return;
+        hipLaunchKernelGGL(dp_skip_get_kernel, dim3(1), dim3(1), 0, s, w, rp_skip, opt_seq + 1);
     }
     void dp_skip_vote(int phase) override { if (phase == 1) skip_vote_put(st); else if (phase == 2) skip_vote_get(st); }
     int ar_dtype = -1;          // >= 0 while a backward with overlapped all-reduce is running: bucket dtype
@@ -2335,7 +2363,7 @@ struct Engine : IEngine {
     int reduce_range(int64_t lo, int64_t hi, int dtype, int span = -1) {
         if (hi <= lo) return 0;
         GradComm& c = *comm;
-        const bool vote = skip_pad >= lo && skip_pad < hi;      // the range that carries the job-wide skip vote (the last bucket / the whole buffer)
+        const bool vote = skip_pad >= 0 ? (skip_pad >= lo && skip_pad < hi) : hi == numel;      // the range that carries the job-wide skip vote (the last bucket / the whole buffer)
         if (vote) skip_vote_put(st);
         c.gate_from(st);
         const size_t n = (size_t)(hi - lo);
@@ -2364,6 +2392,7 @@ struct Engine : IEngine {
             c.bytes_reduced += 4.0 * n;
         }
         c.n_collectives++;
+        if (vote && skip_pad < 0 && rc == 0 && vote_ptr()) rc = GradComm::api().allreduce(vote_word, vote_word, 1, GradComm::F32, GradComm::SUM, c.comm, c.cs);
         if (vote) skip_vote_get(c.cs);
         if (span >= 0) c.span_end(span);
         if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }

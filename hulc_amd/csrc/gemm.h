@@ -882,7 +882,10 @@ __global__ void __launch_bounds__(512) gemm_glds_pair_kernel(DenseLoader<h16_t> 
 // both outputs [M][N] through the same DenseOut; plain epilogues only (fp32 store / accumulate: the weight-gradient form)
 static inline bool gemm_glds_pair_ok(const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b1, const DenseLoader<h16_t>& b2, const EpiP& ep1, const EpiP& ep2, int M, int N, int K, int sh) {
     auto row_ok = [](const DenseLoader<h16_t>& l) { return (l.s0 % 8) == 0 && (l.s1 % 8) == 0 && ((uintptr_t)l.p % 16) == 0 && l.R1 == 0x7fffffff; };
-    auto plain = [](const EpiP& e) { return e.out_f32 && !e.atomic && e.z_stride == 0 && !e.bias && !e.bias2 && !e.res && !e.mask && !e.relu && e.drop_p == 0.f && !e.out2; };
+    // epi_plain4 is a 16-byte f32x4 load / store of the bare product: same conditions as the single-GEMM plain path (alpha 1, 16-byte aligned output)
+    auto plain = [](const EpiP& e) {
+        return !e.generic_only && e.out_f32 && !e.atomic && e.z_stride == 0 && !e.bias && !e.bias2 && !e.res && !e.mask && !e.relu && e.drop_p == 0.f && !e.out2 && e.alpha == 1.f && ((uintptr_t)e.out & 15) == 0;
+    };
     return K >= 192 && (K % 64) == 0 && sh > 0 && (sh % 64) == 0 && sh < K && (M % 128) == 0 && (N % 128) == 0 && row_ok(a) && row_ok(b1) && row_ok(b2) && plain(ep1) && plain(ep2);
 }
 static inline void launch_gemm_glds_pair(hipStream_t st, const DenseLoader<h16_t>& a, const DenseLoader<h16_t>& b1, const DenseLoader<h16_t>& b2, const DenseOut& om, const EpiP& ep1,

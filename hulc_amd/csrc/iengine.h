@@ -18,6 +18,7 @@ struct IEngine {
                      const int64_t* numels) = 0;
     virtual int prepare_weights(bool shadow_fresh = false) = 0;
     virtual int zero_grads() = 0;
+    virtual int flush_grads() = 0;
     virtual int forward(const hulc_batch* b, float lw, float cw, float* out, int on_host) = 0;
     virtual int forward_pair(const hulc_batch* vis, const hulc_batch* lang, float lw, float cw, float* out8, int on_host) = 0;
     virtual int backward(int part = -1) = 0;   // -1: everything; 0: all but the perceptual encoders; 1: encoders (after part 0)

@@ -2368,6 +2368,9 @@ __global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __res
 }
 // data-parallel skip vote (engine.h skip_vote_put / skip_vote_get): one alignment-padding element of the gradient buffer carries "my recurrence
 // of this step failed" through the gradients' own SUM all-reduce
+__global__ void clamp_index_kernel(int* __restrict__ idx, int n, int ncls) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) idx[i] = min(max(idx[i], 0), ncls - 1);
+}
 __global__ void dp_skip_put_kernel(const unsigned* __restrict__ skip, unsigned tag, float* __restrict__ pad) { *pad = (*skip == tag) ? 1.f : 0.f; }
 __global__ void dp_skip_get_kernel(float* __restrict__ pad, unsigned* __restrict__ skip, unsigned tag) {
     if (!(*pad == 0.f)) *skip = tag;      // any rank voted (NaN included)

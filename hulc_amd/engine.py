@@ -17,7 +17,7 @@ from . import spec
 class StepEngine:
     def __init__(self, dims: spec.ModelDims, max_batch: int, max_seq: int, dtype: str = "bf16", device: str = "cuda:0",
                  kl_beta: float = 0.01, kl_balancing_mix: float = 0.8, dropout_p: float = 0.1, num_classes: int = 10,
-                 gripper_alpha: float = 1.0, log_scale_min: float = -7.0, seed: int = 42):
+                 gripper_alpha: float = 1.0, log_scale_min: float = -7.0, seed: int = 42, layout_pad: int = 64):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("hulc_amd.StepEngine needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
@@ -25,7 +25,7 @@ class StepEngine:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.dtype = dtype
-        self.layout, self.numel = spec.layout(dims)
+        self.layout, self.numel = spec.layout(dims, layout_pad)      # layout_pad 4: the tightly packed table a C caller may bind (tests)
         dev = self.device
         self.flat_params = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.flat_grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -73,7 +73,14 @@ class StepEngine:
         L.check(self.lib.hulc_prepare_weights(self.ctx))
 
     def zero_grads(self):
+        """hulc_zero_grads.  16-bit engines (option lazy_zero_grads, default 1): the large store-first Linear weight gradients keep the previous
+        step's values until the next backward writes them / the library reads them (include/hulc_hip.h); call `flush_grads()` before reading
+        `flat_grads` yourself between zero_grads() and the end of the next backward."""
         L.check(self.lib.hulc_zero_grads(self.ctx))
+
+    def flush_grads(self):
+        """hulc_flush_grads: zero whatever zero_grads() left marked stale (no-op otherwise)."""
+        L.check(self.lib.hulc_flush_grads(self.ctx))
 
     # ---- step pieces ------------------------------------------------------------------------------------------
     @staticmethod
@@ -347,6 +354,12 @@ class StepEngine:
         if n < 0:
             L.check(1)
         return [(int(lo[i]), int(hi[i])) for i in range(n)]
+
+    def comm_size(self):
+        """(rank, world) of the live library communicator as RCCL itself reports them (hulc_comm_size)."""
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        L.check(self.lib.hulc_comm_size(self.ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def comm_stats(self) -> Dict:
         n, b = C.c_int64(), C.c_double()

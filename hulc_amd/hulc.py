@@ -490,22 +490,13 @@ class Hulc(torch.nn.Module):
         tr = getattr(self, "trainer", None)
         if tr is None:
             raise RuntimeError("num_training_steps needs module.trainer (set by Trainer.fit); pass lr_scheduler.num_training_steps >= 0 otherwise")
-        dm = getattr(tr, "datamodule", None)
+        from .trainer import epoch_batches      # the fit loop's own arithmetic: per-rank `steps_per_epoch` is not divided by the devices again, an
+        dm = getattr(tr, "datamodule", None)    # un-sharded loader is (the reference measures the un-sharded loader, hulc.py:197-199, 209-211)
         num_devices = max(1, int(getattr(tr, "world", 1)))
-        if hasattr(dm, "steps_per_epoch"):
-            # this package's datamodules state their length PER RANK (every rank draws steps_per_epoch batches of its own): not divided by the
-            # number of devices again.  The reference divides because it measures the un-sharded loader (hulc.py:197-199, 209-211)
-            dataset_size, per_rank = int(dm.steps_per_epoch), True
-        else:
-            loaders = dm.train_dataloader()
-            dataset_size, per_rank = (max(len(loaders[k]) for k in loaders) if isinstance(loaders, dict) else len(loaders)), False
-        ltb = getattr(tr, "limit_train_batches", None)
-        if isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0:
-            dataset_size = ltb
-        elif isinstance(ltb, float):
-            dataset_size = int(dataset_size * ltb)
-        effective = int(getattr(tr, "accumulate_grad_batches", 1)) * (1 if per_rank else num_devices)
-        max_estimated = (dataset_size // effective) * int(tr.max_epochs)
+        per_epoch, _ = epoch_batches(dm, getattr(tr, "limit_train_batches", None), num_devices)
+        if per_epoch == float("inf"):
+            raise RuntimeError("num_training_steps: the training loader has no len(); set lr_scheduler.num_training_steps or an int limit_train_batches")
+        max_estimated = (per_epoch // int(getattr(tr, "accumulate_grad_batches", 1))) * int(tr.max_epochs)
         if tr.max_steps and 0 < tr.max_steps < max_estimated:
             return int(tr.max_steps)
         return max_estimated

@@ -101,12 +101,13 @@ def bucket_schedule(layout, numel: int):
     library's own list, tests compare the two).  layout: name -> (offset, shape) from hulc_amd.spec.layout."""
     import numpy as np
 
-    def rng(prefixes):
+    order = sorted(layout.items(), key=lambda kv: kv[1][0])
+
+    def rng(prefixes):       # [first element, start of the tensor behind the group's last one): inter-tensor padding rides with the group
         lo, hi = numel, 0
-        for n, (off, shape) in layout.items():
+        for i, (n, (off, shape)) in enumerate(order):
             if any(n.startswith(p) for p in prefixes if p):
-                k = int(np.prod(shape)) if len(shape) else 1
-                lo, hi = min(lo, off), max(hi, off + (k + 63) // 64 * 64)
+                lo, hi = min(lo, off), max(hi, order[i + 1][1][0] if i + 1 < len(order) else numel)
         return (lo, min(hi, numel)) if hi > lo else (0, 0)
     out = []
     for g in BUCKET_GROUPS:
@@ -143,7 +144,8 @@ def setup_comm(engine, bucket_dtype: str = "fp32") -> bool:
     library path is up.  Otherwise: HULC_DP_COMM=capi (default) raises on every rank; =auto prints the reason once and returns False
     (gradients then go through torch.distributed); =torch never tries."""
     mode = comm_mode()
-    if world_size() == 1 or not torch.cuda.is_available() or mode == "torch":
+    # (`comm_rehearsal`: an engine stand-in of the CPU tests drives the three votes over gloo — tests/test_config_and_ddp.py, 8 ranks)
+    if world_size() == 1 or not (torch.cuda.is_available() or getattr(engine, "comm_rehearsal", False)) or mode == "torch":
         return False
     dev = engine.device
     err = None

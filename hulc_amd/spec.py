@@ -166,14 +166,16 @@ def param_table(d: ModelDims) -> List[Tuple[str, Tuple[int, ...], tuple]]:
     return t
 
 
-def layout(d: ModelDims):
-    """name -> (offset, shape); every tensor starts on a 64-element (256 B) boundary."""
+def layout(d: ModelDims, pad: int = 64):
+    """name -> (offset, shape); every tensor starts on a `pad`-element boundary: 64 (256 B, the default) or 4 — the tightest table
+    hulc_bind_params accepts (offsets are multiples of 4), what a C caller with its own packed buffers would bind."""
+    assert pad >= 4 and pad % 4 == 0
     off = 0
     out = {}
     for name, shape, _ in param_table(d):
         n = int(np.prod(shape)) if len(shape) else 1
         out[name] = (off, shape)
-        off += (n + 63) // 64 * 64
+        off += (n + pad - 1) // pad * pad
     return out, off
 
 

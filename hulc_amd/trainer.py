@@ -130,6 +130,47 @@ def get_last_checkpoint(log_dir: str) -> Optional[str]:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def _unsharded_loader(datamodule):
+    """The loader of a datamodule that does not shard by rank itself: train_dataloader() -> an iterable, or a {modality: iterable} dict whose
+    per-step batch is {modality: batch} (the reference's combined loader, hulc.py:433-469: the step iterates the modalities)."""
+    loaders = datamodule.train_dataloader()
+    if isinstance(loaders, dict):
+        keys = list(loaders)
+        return ({k: b for k, b in zip(keys, bs)} for bs in zip(*[loaders[k] for k in keys]))
+    return loaders
+
+
+def epoch_batches(datamodule, limit_train_batches, world: int):
+    """(steps each rank takes per epoch, per_rank) — the ONE place the epoch length is derived (hulc.py:189-212; ADVICE r5: the fit loop and
+    Hulc.num_training_steps disagreed for loaders without `steps_per_epoch`, so a warm-up schedule could reach its end before the run did).
+
+    * a datamodule with `steps_per_epoch` states its length PER RANK (every rank draws that many batches of its own): limit_train_batches applies
+      to it directly, nothing is divided by the world size (per_rank = True);
+    * any other datamodule hands out the UN-SHARDED loader the reference measures (hulc.py:197-199): size = the longest loader's len(), an int
+      limit replaces it (:201-202), a float scales it (:203-205), and each of the `world` ranks takes size // world of those batches (:209-211) —
+      Trainer.fit strides such a loader by rank (batch i goes to rank i % world), which is what Lightning's DistributedSampler does to it;
+    * a loader without len() and no int limit: (inf, False) — the epoch ends when the loader does.
+    """
+    ltb = limit_train_batches
+    ltb_int = isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0
+    if hasattr(datamodule, "steps_per_epoch"):
+        size, per_rank = int(datamodule.steps_per_epoch), True
+    else:
+        per_rank, size = False, None
+        try:
+            loaders = datamodule.train_dataloader()
+            size = max(len(loaders[k]) for k in loaders) if isinstance(loaders, dict) else len(loaders)
+        except TypeError:
+            size = None
+    if ltb_int:
+        size = ltb
+    elif size is None:
+        return float("inf"), per_rank
+    elif isinstance(ltb, float):
+        size = int(size * ltb)
+    return (size if per_rank else size // max(1, int(world))), per_rank
+
+
 class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_dir: str = "./runs", callbacks: Optional[List] = None,
                  log_every: int = 10, limit_val_batches: Optional[int] = None, check_val_every_n_epoch: int = 1, limit_train_batches=None,
@@ -153,13 +194,8 @@ class Trainer:
         self.epoch_history: List[Dict[str, float]] = []
 
     def _train_batches(self, datamodule) -> float:
-        """Batches of one training epoch after limit_train_batches — the same arithmetic Hulc.num_training_steps uses (hulc.py:201-205)."""
-        ltb = self.limit_train_batches
-        if isinstance(ltb, int) and not isinstance(ltb, bool) and ltb != 0:
-            return ltb
-        if isinstance(ltb, float) and hasattr(datamodule, "steps_per_epoch"):
-            return int(int(datamodule.steps_per_epoch) * ltb)
-        return float("inf")
+        """Optimizer steps THIS rank takes per training epoch = epoch_batches(...)[0]: ONE arithmetic for the fit loop and Hulc.num_training_steps."""
+        return epoch_batches(datamodule, self.limit_train_batches, self.world)[0]
 
     def validate(self, module, datamodule) -> Dict[str, float]:
         """Lightning's validation loop for this module: eval mode, validation_step over the val batches, mean of every `val*` metric."""
@@ -220,9 +256,14 @@ class Trainer:
                     cb.on_train_epoch_start(self, module)
             if hasattr(module, "on_train_epoch_start"):
                 module.on_train_epoch_start()
-            for bi, batch in enumerate(datamodule.train_dataloader(self.rank)):
-                if bi >= self._train_batches(datamodule):                 # Lightning's limit_train_batches (int: batches, float: fraction of the epoch)
+            n_batches, per_rank = epoch_batches(datamodule, self.limit_train_batches, self.world)
+            taken = 0
+            for bi, batch in enumerate(datamodule.train_dataloader(self.rank) if per_rank else _unsharded_loader(datamodule)):
+                if not per_rank and bi % self.world != self.rank:         # an un-sharded loader: batch i belongs to rank i % world (DistributedSampler's stride)
+                    continue
+                if taken >= n_batches:                                     # Lightning's limit_train_batches (int: batches, float: fraction of the epoch)
                     break
+                taken += 1
                 loss = module.training_step(batch, self.global_step)      # forward + loss + backward (grads accumulated)
                 self.optimizer.step()                                      # RCCL all-reduce (mean) + fused Adam
                 sched.step()

@@ -94,12 +94,24 @@ int hulc_set_stream(hulc_ctx* ctx, void* hip_stream);
 int64_t hulc_workspace_bytes(const hulc_ctx* ctx);
 
 /* Borrow the flat fp32 parameter / gradient / Adam-moment buffers (numel elements each) and the table of tensors inside
- * them.  names are the reference state_dict keys; offsets are element offsets (multiples of 4). */
+ * them.  names are the reference state_dict keys; offsets are element offsets (multiples of 4).  Tensors may be packed
+ * tightly or padded (hulc_amd.spec pads every tensor to 64 elements); the library never writes an element outside the listed tensors except
+ * ONE padding element behind a perceptual_encoder.* tensor, if the layout has one, while a data-parallel all-reduce is in flight (the job-wide
+ * skip vote of a failed persistent recurrence rides the gradients' own SUM; a layout without padding votes through a 4-byte all-reduce of its own). */
 int hulc_bind_params(hulc_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v, int64_t numel,
                      int32_t n_tensors, const char* const* names, const int64_t* offsets, const int64_t* numels);
 /* Refresh the compute-precision / packed / transposed weight copies after the fp32 parameters changed. */
 int hulc_prepare_weights(hulc_ctx* ctx);
+/* Post-condition (16-bit engines, option "lazy_zero_grads" = 1, the default): every gradient element is zero EXCEPT the large Linear weight
+ * gradients whose writers can all store instead of accumulate (plan_proposal / goal-encoder MLP weights, plan_recognition.fc_state, the decoder's
+ * weight_hh_l0 / weight_ih_l1 / weight_hh_l1): those keep the PREVIOUS step's values until their writer of the next backward stores, or until the
+ * library itself is about to read them (a bucket's all-reduce, the end of hulc_backward / hulc_backward_part, an optimizer step), which zeroes
+ * whatever is still stale.  After hulc_backward the buffer is exactly what a full memset + accumulate would have produced.  A caller that READS
+ * or reduces the bound gradient buffer itself between hulc_zero_grads and the end of the next backward calls hulc_flush_grads first (or sets
+ * hulc_set_option(ctx, "lazy_zero_grads", 0) once: hulc_zero_grads is then the plain memset). */
 int hulc_zero_grads(hulc_ctx* ctx);
+/* Zero every gradient tensor that is still marked stale (see above); a no-op when nothing is.  Enqueued on the context's stream. */
+int hulc_flush_grads(hulc_ctx* ctx);
 
 /* Forward + loss of ONE modality batch; keeps activations for hulc_backward.  loss_weight = 1/len(batch) (hulc.py:491),
  * clip_weight = clip_auxiliary_loss_beta (hulc.py:525) — used to scale the gradients in hulc_backward. */
@@ -161,6 +173,8 @@ int hulc_comm_init(hulc_ctx* ctx, const void* unique_id_host, int32_t rank, int3
 int hulc_comm_destroy(hulc_ctx* ctx);
 int hulc_comm_buckets(hulc_ctx* ctx, int64_t* lo, int64_t* hi, int32_t cap);      /* returns the number of buckets, < 0 on error */
 int hulc_comm_stats(hulc_ctx* ctx, int64_t* n_collectives, double* bytes_on_wire_per_rank);
+/* Rank and size of the LIVE communicator as RCCL reports them (ncclCommUserRank / ncclCommCount) — not an echo of hulc_comm_init's arguments. */
+int hulc_comm_size(hulc_ctx* ctx, int32_t* rank, int32_t* world);
 /* With hulc_set_option(ctx, "comm_timing", 1): the LAST hulc_backward_allreduce's buckets as seen by events on the collectives' stream.
  * out[4 i .. 4 i + 3] = {start_us, end_us of bucket i's collective relative to the END of the backward on the context's stream (negative =
  * that much of it ran hidden under the backward), bytes on the wire per rank, bucket index}; *backward_us = the backward's own duration.

@@ -186,6 +186,7 @@ def test_library_rccl_allreduce_world1_and_bucket_plan():
         tot_ref, _ = run_step(eng, batch)
         g_ref = eng.flat_grads.clone()
         eng.comm_init(eng.comm_unique_id(), 0, 1)
+        assert eng.comm_size() == (0, 1)                                                          # ncclCommUserRank / ncclCommCount of the LIVE communicator (bench.py's N > 1 gate)
         with pytest.raises(RuntimeError):
             eng.comm_init(eng.comm_unique_id(), 0, 1)                                             # one communicator per context
         # same step, last backward with the overlapped bucketed all-reduce
@@ -284,3 +285,49 @@ def test_fp16_checkpoint_resume_continues_the_trajectory():
     assert rel < 0.1, rel
     assert m2.engine.scaler_state()["taken_steps"] == 5
     m2.engine.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tightly_packed_layout_keeps_every_gradient_element_and_votes_outside_the_buffer(dtype):
+    """hulc_bind_params accepts any 4-aligned table.  With a TIGHTLY packed one (no 64-element padding) the element behind a tensor is
+    the first gradient element of the next tensor: the data-parallel skip vote must not ride there (it votes through a 4-byte all-reduce of its
+    own: 6 collectives instead of 5), the lazily zeroed ranges must not round into a neighbour, and the bucket plan must still partition the
+    buffer.  Gradients of the packed layout == gradients of the padded one, tensor by tensor; the step after it too (Adam + a second backward)."""
+    from hulc_amd import parallel, spec
+    from hulc_amd.engine import StepEngine
+    dims, P, batch, fx = load_case("hulc_tiny")
+    res = {}
+    for pad in (64, 4):
+        eng = StepEngine(dims, 2, 4, dtype=dtype, dropout_p=0.0, device="cuda:0", layout_pad=pad)
+        eng.load_numpy(P)
+        lay, numel = spec.layout(dims, pad)
+        assert eng.numel == numel and eng.comm_buckets() == parallel.bucket_schedule(lay, numel)
+        parallel.check_bucket_plan(eng.comm_buckets(), numel)
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        out = []
+        for it in range(2):
+            eng.zero_grads()
+            scopes = list(batch)
+            for i, sc in enumerate(scopes):
+                from test_gpu_parity import to_dev
+                eng.forward_loss(to_dev(batch[sc]), "lang" in sc, 1.0 / len(scopes), 3.0, step=0)
+                if i == len(scopes) - 1:
+                    eng.backward_allreduce("fp32")
+                else:
+                    eng.backward()
+            torch.cuda.synchronize()
+            out.append({n: g.copy() for n, g in grads_np(eng).items()})
+            eng.adam_step()
+        torch.cuda.synchronize()
+        res[pad] = (out, eng.comm_stats()["collectives"], {n: t.detach().cpu().numpy().copy() for n, t in eng.views(eng.flat_params).items()})
+    assert res[64][1] == 10 and res[4][1] == 12                         # the packed layout's vote is one extra 4-byte collective per backward
+    tol = 0.0 if dtype == "fp32" else 2e-2                              # fp32 engine: deterministic -> bit-identical; bf16: run-to-run atomics order
+    for it in range(2):
+        for n, g in res[64][0][it].items():
+            h = res[4][0][it][n]
+            assert np.isfinite(h).all() and (dtype != "fp32" or np.array_equal(g, h)), (it, n)
+        a = np.concatenate([res[64][0][it][n].reshape(-1) for n in res[64][0][it]]).astype(np.float64)
+        b = np.concatenate([res[4][0][it][n].reshape(-1) for n in res[64][0][it]]).astype(np.float64)
+        assert np.linalg.norm(a - b) <= tol * np.linalg.norm(a), (it, np.linalg.norm(a - b) / np.linalg.norm(a))
+    for n, p in res[64][2].items():
+        assert np.allclose(p, res[4][2][n], rtol=0, atol=0 if dtype == "fp32" else 1e-3), n

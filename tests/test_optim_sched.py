@@ -93,7 +93,25 @@ def test_trainer_takes_exactly_the_inferred_number_of_optimizer_steps():
     dm = types.SimpleNamespace(steps_per_epoch=50)
     assert Trainer(limit_train_batches=7)._train_batches(dm) == 7
     assert Trainer(limit_train_batches=0.5)._train_batches(dm) == 25
-    assert Trainer()._train_batches(dm) == float("inf")
+    assert Trainer()._train_batches(dm) == 50
+    # a datamodule WITHOUT steps_per_epoch hands out an un-sharded loader — the fit loop and num_training_steps share epoch_batches():
+    # a float limit scales len(loader), the ranks split what is left (batch i -> rank i % world), an int limit is split the same way
+    from hulc_amd.trainer import epoch_batches
+    class _DM:
+        def train_dataloader(self):
+            return {"vis": list(range(50)), "lang": list(range(37))}
+    assert epoch_batches(_DM(), None, 2) == (25, False) and epoch_batches(_DM(), 0.5, 2) == (12, False) and epoch_batches(_DM(), 9, 2) == (4, False)
+    assert epoch_batches(dm, 0.5, 2) == (25, True)
+    class _Gen:
+        def train_dataloader(self):
+            return (i for i in range(5))
+    assert epoch_batches(_Gen(), None, 1) == (float("inf"), False) and epoch_batches(_Gen(), 3, 1) == (3, False)
+    m = H.Hulc.__new__(H.Hulc)
+    for world, ltb in ((1, None), (2, 0.5), (2, 9)):
+        t = Trainer(limit_train_batches=ltb, max_epochs=3)
+        t.world, t.datamodule = world, _DM()
+        object.__setattr__(m, "trainer", t)
+        assert m.num_training_steps == t._train_batches(_DM()) * 3
     opt = H.FusedAdam(_FakeModule(), lr=1.0)
     sched = H.CosineWarmupSchedule(opt, 2, 10)
     for _ in range(25):
