@@ -2342,10 +2342,11 @@ struct Engine : IEngine {
     // buffer if its skip word carries this step's tag, else 0.0; after the SUM a non-zero element means "some rank failed" -> every rank
     // sets its own skip word (adam / sgd / scaler_update then return without touching p / m / v) and clears the element.
     // A layout without such a padding element (hulc_bind_params accepts any 4-aligned, tightly packed table) votes through a word of the engine's own
-    // (vote_word): one extra 4-byte all-reduce behind the range that ends the buffer — never through an element that belongs to a tensor.
+    // (vote_word): one extra 4-byte all-reduce behind the range that starts the buffer (the last bucket issued) — never through an element that belongs to a tensor.
     int64_t skip_pad = -1;
     float* vote_word = nullptr;
-    float* vote_ptr() { if (skip_pad >= 0) return G + skip_pad; if (!vote_word) vote_word = alloc<float>(64); return vote_word; }
+    int64_t vote_pad() const { return force_vote_word ? -1 : skip_pad; }
+    float* vote_ptr() { if (vote_pad() >= 0) return G + skip_pad; if (!vote_word) vote_word = alloc<float>(64); return vote_word; }
     void skip_vote_put(hipStream_t s) {
         if (!rp_skip) rp_skip = alloc<unsigned>(64);
         float* w = vote_ptr();
@@ -2363,7 +2364,7 @@ struct Engine : IEngine {
     int reduce_range(int64_t lo, int64_t hi, int dtype, int span = -1) {
         if (hi <= lo) return 0;
         GradComm& c = *comm;
-        const bool vote = skip_pad >= 0 ? (skip_pad >= lo && skip_pad < hi) : hi == numel;      // the range that carries the job-wide skip vote (the last bucket / the whole buffer)
+        const bool vote = vote_pad() >= 0 ? (skip_pad >= lo && skip_pad < hi) : lo == 0;      // the range that carries the job-wide skip vote: the bucket issued LAST (perceptual encoders, offset 0) / the whole buffer
         if (vote) skip_vote_put(st);
         c.gate_from(st);
         const size_t n = (size_t)(hi - lo);
@@ -2392,7 +2393,7 @@ struct Engine : IEngine {
             c.bytes_reduced += 4.0 * n;
         }
         c.n_collectives++;
-        if (vote && skip_pad < 0 && rc == 0 && vote_ptr()) rc = GradComm::api().allreduce(vote_word, vote_word, 1, GradComm::F32, GradComm::SUM, c.comm, c.cs);
+        if (vote && vote_pad() < 0 && rc == 0 && vote_ptr()) rc = GradComm::api().allreduce(vote_word, vote_word, 1, GradComm::F32, GradComm::SUM, c.comm, c.cs);
         if (vote) skip_vote_get(c.cs);
         if (span >= 0) c.span_end(span);
         if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }

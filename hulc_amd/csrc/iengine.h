@@ -79,7 +79,7 @@ struct IEngine {
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
     // "lazy_zero_grads": 1 (default; 16-bit engines) = hulc_zero_grads only marks the large store-first weight gradients stale instead of zeroing them
     // (engine.h: LazyG); 0 = the plain memset of the whole buffer.
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1;
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1, force_vote_word = 0;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
     virtual void set_adam_fuse(bool on) = 0;
@@ -103,6 +103,7 @@ struct IEngine {
         // "dp_skip_vote": for a gradient all-reduce done OUTSIDE the library (the torch.distributed fallback): 1 right before the collective that covers the
         // perceptual-encoder gradients, 2 right after it — the job-wide "a recurrence of this step failed on some rank" vote (engine.h skip_vote_put)
         if (name && !strcmp(name, "dp_skip_vote")) { dp_skip_vote((int)value); return 0; }
+        if (name && !strcmp(name, "debug_vote_word")) { force_vote_word = value != 0; return 0; }      // tests: vote through the engine's own word even if the layout has a padding element
         if (name && !strcmp(name, "debug_persist_fault")) { persist_fault = (int)value; return 0; }      // tests: the next `value` persistent launches (after the probed first one) lose a producer
         hulc_set_error("hulc_set_option: unknown option '%s'", name ? name : "(null)");
         return 1;

@@ -304,6 +304,8 @@ def test_tightly_packed_layout_keeps_every_gradient_element_and_votes_outside_th
         assert eng.numel == numel and eng.comm_buckets() == parallel.bucket_schedule(lay, numel)
         parallel.check_bucket_plan(eng.comm_buckets(), numel)
         eng.comm_init(eng.comm_unique_id(), 0, 1)
+        if pad == 4:
+            eng.set_option("debug_vote_word", 1)      # (the 1-element spatial_softmax.temperature leaves padding even at pad 4: force the no-padding vote path)
         out = []
         for it in range(2):
             eng.zero_grads()
