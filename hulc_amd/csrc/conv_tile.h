@@ -472,21 +472,6 @@ static inline bool launch_conv_tile(hipStream_t st, ConvTileP p) {
     return launch_conv_tile_nw<CK, CN, TA, TB, SI, OS, REV, 8>(st, p);
 }
 
-// ---- conv1 forward: which (channel, kernel row) of the 24 a lane group reads in k-step ks, and the row pitch of the staged band.
-// A fragment read is a ds_read_b64 (two groups of 32 lanes, bank = dword address mod 64); the 16 lanes of a lane group g read 16 pixels at a stride of
-// 8 bytes = exactly 32 consecutive banks, and the two lane groups of a 32-lane half read two DIFFERENT (c, kh) rows.  With rows kh and kh + 1 (round <= 5:
-// ck = 4 ks + g) the second group starts XRS / 4 = 104 dwords = 40 banks behind the first: 8 of the 32 banks carry two addresses and the read takes a
-// third LDS cycle (profiles/r05_mfma_util_summary.txt: conv1_fwd lds_confl 0.21).  Rows kh and kh + 4 are 4 XRS / 4 dwords apart: with XRS / 4 = 8 mod 16
-// that is 32 mod 64 — the two groups cover all 64 banks once.  So: k-step ks = (c, kh pair block): c = ks >> 1, kh = 2 (ks & 1) + (g >> 1) + 4 (g & 1)
-// (lanes 0-31 read kh, kh + 4; lanes 32-63 kh + 1, kh + 5), and the pitch is padded to 8 mod 16 dwords (static camera: 416 B as before; gripper 184 -> 224).
-// The K ORDER of the product changes with it (weights and image fragments are permuted alike): same sum, other association.  kmap = false (dbg bit 6) keeps
-// round 5's map for A/B.
-DEVI int conv1_ck(int ks, int g, bool kmap) { return kmap ? (ks >> 1) * 8 + (ks & 1) * 2 + (g >> 1) + 4 * (g & 1) : ks * 4 + g; }
-__host__ DEVI int conv1_xrs(int IW, bool kmap) {
-    int d = (IW * 2 + 16) >> 2;
-    if (kmap) while ((d & 15) != 8) ++d;
-    return d * 4;
-}
 // the multiply + epilogue of one staged band (shared by the fp32 / register-staged kernel and the uint8 LDS-DMA kernel below)
 DEVI void conv1_fwd_band_tiles(lds_char* ximg, const h16x8_t (&wf)[6][2], const int (&rowsel)[6], const float4 (&bb)[2], h16_t* __restrict__ out,
                                unsigned* __restrict__ maskbits, int f, int oh0, int R, int OH, int OW, int XRS, int dbg, int wave, int g, int li, float osc = 1.f) {
@@ -570,21 +555,20 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
     if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
     const int g = lane >> 4, li = lane & 15;
     const int XR = (R - 1) * 4 + 8;
-    const bool kmap = !(dbg & 64);
-    const int XRS = conv1_xrs(IW, kmap);
+    const int XRS = IW * 2 + 16;
     const int W4 = IW >> 2;
     h16x8_t wf[6][2];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + conv1_ck(ks, g, kmap) * 8);
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
     // ^ A-operand row m of tile ct carries output channel (m >> 2) * 8 + ct * 4 + (m & 3): with the 16x16 C/D map (row = 4 g + r) lane group g then owns
     //   the 8 CONSECUTIVE channels 8 g .. 8 g + 7 of its pixel — one 16-byte store per lane and 1 KB contiguous per wave store (two 8-byte stores to
     //   interleaved 32-byte halves of every pixel before)
     // (c, kh) row of this lane group for each k-step
     int rowsel[6];
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) { const int ck = conv1_ck(ks, g, kmap); rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
     const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
     const int nitems = Nf * nbands;
     // frame-wise (fw, experiment knob HULC_C1_FW=1): a workgroup walks the bands of one frame back to back so that the rows two bands share come
@@ -633,8 +617,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
     if (blockIdx.x == 0 && tid < 8) { if (zero8a) zero8a[tid] = 0.f; if (zero8b) zero8b[tid] = 0.f; }
     const int g = lane >> 4, li = lane & 15;
     const int XR = (R - 1) * 4 + 8;
-    const bool kmap = !(dbg & 64);
-    const int XRS = conv1_xrs(IW, kmap);
+    const int XRS = IW * 2 + 16;
     const int W4 = IW >> 2;
     lds_char* raw = ximg + 3 * XR * XRS + 64;
     const int RB = IW * 3, RP = conv1_raw_pitch16(IW);
@@ -645,10 +628,10 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + conv1_ck(ks, g, kmap) * 8);
+        for (int ct = 0; ct < 2; ++ct) wf[ks][ct] = *reinterpret_cast<const h16x8_t*>(W + ((li >> 2) * 8 + ct * 4 + (li & 3)) * 192 + ks * 32 + g * 8);
     int rowsel[6];
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) { const int ck = conv1_ck(ks, g, kmap); rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
+    for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
     const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X.X);
     const long long total = (long long)Nf * IH * RB;              // bytes of the frame buffer
@@ -730,10 +713,7 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
                                     unsigned* maskbits = nullptr, float* zero8a = nullptr, float* zero8b = nullptr) {
     // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
     //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
-    static const int kmap_sw = HULC_SWITCH("HULC_C1_KMAP", 1);   // conflict-free (c, kh) -> lane group map of the fragment reads (conv1_ck); 0 = round 5's
-    if (!kmap_sw) dbg |= 64;
-    const int XRSh = conv1_xrs(IW, !(dbg & 64));
-    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * XRSh + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch16(IW) + 16 : 0); };   // + raw uint8 rows
+    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch16(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = HULC_SWITCH("HULC_C1_LDS", 39);   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = HULC_SWITCH("HULC_C1_WG", 1024);
     int R = OH;

@@ -539,8 +539,35 @@ struct Engine : IEngine {
         }
     }
     // dense NT GEMM with tile selection
+    // ---- grouped launches (gemm.h gemm_glds_group_kernel): between gemm_group_begin() and gemm_group_end() up to three INDEPENDENT 128 x 128-tile products are
+    // collected and issued as one grid; anything else that arrives in between flushes the queue first, so program order is kept.  The caller vouches for the
+    // independence of what it brackets (no queued product reads another's output).
+    GemmGroupP gq{}; bool gq_open = false; double gq_fl = 0, gq_by = 0;
+    void gemm_group_begin() { static const int sw = HULC_SWITCH("HULC_GEMM_GROUP", 1); gq_open = sw != 0 && gemm_group_mode; gq.n = 0; gq_fl = gq_by = 0; }
+    void gemm_group_flush() {
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (gq.n == 1) { TimerScope ts(this, "gemm_128x128", "mfma", gq_fl, gq_by); launch_gemm_glds(st, gq.a[0], gq.b[0], gq.om[0], gq.ep[0], gq.M[0], gq.N[0], gq.K[0]); }
+            else if (gq.n > 1) { TimerScope ts(this, "gemm_128x128", "mfma", gq_fl, gq_by, 1); launch_gemm_glds_group(st, gq); }
+        }
+        gq.n = 0; gq_fl = gq_by = 0;
+    }
+    void gemm_group_end() { gemm_group_flush(); gq_open = false; }
     void gemm(const DenseLoader<T>& a, const DenseLoader<T>& b, const DenseOut& om, const EpiP& ep, int M, int N, int K) {
         static const bool trace = HULC_SWITCH("HULC_TRACE_GEMM", 0) != 0;
+        if constexpr (std::is_same<T, h16_t>::value) {
+            if (gq_open) {
+                const long long w128g = (long long)cdiv(M, 128) * cdiv(N, 128);
+                const bool skinny = a.R1 == 0x7fffffff && b.R1 == 0x7fffffff && ep.z_stride == 0 && skinny_ok(M, N, K, a.s1, b.s1, a.p, b.p);
+                if (!skinny && M >= 512 && N >= 128 && w128g >= 128 && gemm_use_glds && gemm_glds_ok(a, b, ep, M, N, K)) {
+                    if (gq.n == 3) gemm_group_flush();
+                    const int i = gq.n++;
+                    gq.a[i] = a; gq.b[i] = b; gq.om[i] = om; gq.ep[i] = ep; gq.M[i] = M; gq.N[i] = N; gq.K[i] = K;
+                    gq_fl += 2.0 * M * N * K; gq_by += ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
+                    return;
+                }
+                gemm_group_flush();
+            }
+        }
         if (trace) fprintf(stderr, "[gemm] M=%d N=%d K=%d lda=%lld ldb=%lld f32out=%d acc=%d atomic=%d\n", M, N, K, a.s1, b.s1, ep.out_f32, ep.accumulate, ep.atomic);
         const double fl = 2.0 * M * N * K, by = ((double)M * K + (double)N * K + (double)M * N) * sizeof(T);
         if constexpr (std::is_same<T, h16_t>::value) {
@@ -2393,7 +2420,7 @@ struct Engine : IEngine {
             c.bytes_reduced += 4.0 * n;
         }
         c.n_collectives++;
-        if (vote && vote_pad() < 0 && rc == 0 && vote_ptr()) rc = GradComm::api().allreduce(vote_word, vote_word, 1, GradComm::F32, GradComm::SUM, c.comm, c.cs);
+        if (vote && vote_pad() < 0 && rc == 0 && vote_ptr()) { rc = GradComm::api().allreduce(vote_word, vote_word, 1, GradComm::F32, GradComm::SUM, c.comm, c.cs); c.n_collectives++; c.bytes_reduced += 4.0; }
         if (vote) skip_vote_get(c.cs);
         if (span >= 0) c.span_end(span);
         if (rc != 0) { hulc_set_error("ncclAllReduce failed: %s", GradComm::err(rc)); return 1; }
@@ -2553,6 +2580,8 @@ struct Engine : IEngine {
                         }
                     }
                 }
+                // dW_hh1, dW_ih1 and (below) dH0 = dZ1 W_ih1 read dZ1 / dZ1^T, H1^T, H0^T, W_ih1^T and write three different buffers: one grouped launch
+                if (!paired && h0t_kept && fuse_cs) gemm_group_begin();
                 if (!paired) {
                 if (S > 1) { EpiP ep = epi(whh1.dW, true); ep.accumulate = grad_first(whh1.dW) ? 0 : 1;
                   gemm(dense<T>(tA + B, HID, mp), dense<T>(tB, HID, mp), dense_out(HID), ep, HID, HID, (S - 1) * B); }
@@ -2563,6 +2592,7 @@ struct Engine : IEngine {
             }
             { EpiP ep = epi(dH0, false); ep.out2 = dZ0 + lastBH; ep.out2_lo = lastBH; ep.out2_hi = lastBH + BH; ep.out2_mask = H0 + lastBH;
               gemm(dense<T>(dZ1, SB, HID), dense<T>(wih1.Wt, HID, HID), dense_out(HID), ep, SB, HID, HID); }
+            gemm_group_end();
             // layer 0 BPTT
             rnn_bwd(dH0, H0, dZ0, whh0, B, S, 1, false, false, true);
             {

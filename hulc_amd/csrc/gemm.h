@@ -657,8 +657,7 @@ static inline void launch_gemm(hipStream_t st, const AL& al, const BL& bl, const
 //   each XCD's L2 sees 4 A panels x 8 B panels instead of the whole of B.
 // ---------------------------------------------------------------------------------------------------------
 template <int NST, int NW>      // NW = 4 (wave tile 64x64) or 8 waves (wave tile 32x64: two waves per SIMD hide each other's DMA issue / LDS latency)
-__global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> al, DenseLoader<h16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
-                                                           int tiles_m, int tiles_n) {
+DEVI void gemm_glds_body(const DenseLoader<h16_t>& al, const DenseLoader<h16_t>& bl, const DenseOut& om, const EpiP& ep, int M, int N, int K, int tiles_m, int tiles_n, int bid) {
     constexpr int STAGE = 32 * 1024;
     constexpr int PW = 16 / NW;                  // 8-row pieces of each operand a wave DMAs per stage
     constexpr int TM = 8 / NW * 2 * 2 / 2;       // m-tiles per wave: 4 (NW = 4) or 2 (NW = 8)
@@ -671,7 +670,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
     int tm, tn;
     {
         const int nt = tiles_m * tiles_n, per = nt / 8, rem = nt % 8;
-        const int x = blockIdx.x % 8, q = blockIdx.x / 8;
+        const int x = bid % 8, q = bid / 8;
         const int tile = x * per + min(x, rem) + q;
         constexpr int GM = 4;
         const int gsz = GM * tiles_n, grp = tile / gsz, first_m = grp * GM, gm = min(GM, tiles_m - first_m);
@@ -765,6 +764,27 @@ __global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> a
             }
         }
     }
+}
+template <int NST, int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_glds_kernel(DenseLoader<h16_t> al, DenseLoader<h16_t> bl, DenseOut om, EpiP ep, int M, int N, int K,
+                                                           int tiles_m, int tiles_n) {
+    gemm_glds_body<NST, NW>(al, bl, om, ep, M, N, K, tiles_m, tiles_n, (int)blockIdx.x);
+}
+// ---------------------------------------------------------------------------------------------------------
+// Up to three INDEPENDENT gemm_glds problems as one launch (round 6): the decoder backward issues dW_hh1, dW_ih1 and dH0 = dZ1 W_ih1 back to
+// back — three 2048^3 products of 256 tiles each, none reading another's output.  As three launches every one of them pays the stream's kernel boundary (all 256
+// workgroups of launch i drain their epilogue stores before the first DMA of launch i + 1 is issued) and its own pipeline fill; as ONE grid of 768 workgroups a CU
+// starts its next tile the moment its previous workgroup retires.  A workgroup finds its problem from blockIdx.x (uniform: the descriptors stay in scalar
+// registers); problem p's tile order is the single launch's (first tile a multiple of 8 -> block b still runs on XCD b % 8).
+// ---------------------------------------------------------------------------------------------------------
+struct GemmGroupP { DenseLoader<h16_t> a[3], b[3]; DenseOut om[3]; EpiP ep[3]; int M[3], N[3], K[3], tm[3], tn[3], t0[3]; int n; };
+template <int NST, int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_glds_group_kernel(GemmGroupP g) {
+    const int b = (int)blockIdx.x;
+    const int p = (g.n > 2 && b >= g.t0[2]) ? 2 : ((g.n > 1 && b >= g.t0[1]) ? 1 : 0);      // uniform
+    const int bid = b - g.t0[p];
+    if (bid >= g.tm[p] * g.tn[p]) return;                 // a problem's block range is padded to a multiple of 8 (XCD alignment of the next problem)
+    gemm_glds_body<NST, NW>(g.a[p], g.b[p], g.om[p], g.ep[p], g.M[p], g.N[p], g.K[p], g.tm[p], g.tn[p], bid);
 }
 // ---------------------------------------------------------------------------------------------------------
 // TWO NT GEMMs that share their A operand up to a shift along K, as one launch (round 5):
@@ -921,6 +941,13 @@ static inline void launch_gemm_glds(hipStream_t st, const DenseLoader<h16_t>& a,
     else hipLaunchKernelGGL((gemm_glds_kernel<3, 8>), dim3(tiles_m * tiles_n), dim3(512), 96 * 1024, st, a, b, om, ep, M, N, K, tiles_m, tiles_n);
 }
 
+static inline void launch_gemm_glds_group(hipStream_t st, GemmGroupP& g) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_group_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
+    int tot = 0;
+    for (int i = 0; i < g.n; ++i) { g.tm[i] = (g.M[i] + 127) / 128; g.tn[i] = (g.N[i] + 127) / 128; g.t0[i] = tot; tot += (g.tm[i] * g.tn[i] + 7) / 8 * 8; }
+    hipLaunchKernelGGL((gemm_glds_group_kernel<3, 8>), dim3(tot), dim3(512), 96 * 1024, st, g);
+}
 // ---------------------------------------------------------------------------------------------------------
 // skinny GEMM (bf16): M <= 64 rows (the per-timestep recurrent GEMMs and every M = B MLP layer).
 //   out[M][N] = epi(A[M][K] W[N][K]^T), weight-bandwidth bound: one workgroup per 16 output columns (N/16 WGs fill

@@ -103,6 +103,37 @@ def test_paired_layer1_weight_gradient_gemm_equals_two_launches():
         assert rel < 1e-6, (n, rel)
 
 
+def test_grouped_decoder_backward_gemms_equal_three_launches():
+    """hulc_set_option "gemm_group" (default 1): dW_hh1, dW_ih1 and dH0 = dZ1 W_ih1 of the action decoder's backward as ONE grouped launch (gemm.h
+    gemm_glds_group_kernel: 3 x 256 tiles in one grid) against the three gemm_glds launches.  Same tile kernel body, same k order per tile -> the two weight gradients
+    are bit-identical; dH0 feeds layer 0's BPTT, so weight_hh_l0 / weight_ih_l0 agree bit for bit as well (S = 32: K = 2048 and 1984, and S = 6: K = 384 / 320)."""
+    for B, S in ((64, 32), (64, 6)):
+        dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+        dev = torch.device("cuda:0")
+        mb = synth_batch(B, S, dev, 1, False)
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        mb["plan_idx"] = torch.randint(0, 32, (B, 32), device=dev, generator=g, dtype=torch.int32)
+        out = {}
+        for grp in (0, 1):
+            eng = StepEngine(dims, B, S, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=1, num_classes=dims.mix_classes)
+            eng.set_option("gemm_group", grp)
+            eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+            eng.zero_grads()
+            eng.forward_loss(mb, False, 1.0, 3.0, step=0)
+            eng.backward()
+            torch.cuda.synchronize()
+            v = eng.views(eng.flat_grads)
+            out[grp] = {n: v[n].clone() for n in ("action_decoder.rnn.weight_hh_l1", "action_decoder.rnn.weight_ih_l1", "action_decoder.rnn.weight_hh_l0", "action_decoder.rnn.weight_ih_l0")}
+            eng.close()
+        for n in out[0]:
+            assert float(out[0][n].double().norm()) > 0
+            rel = float((out[0][n] - out[1][n]).double().norm() / out[0][n].double().norm())
+            if n.endswith("_l1"):
+                assert torch.equal(out[0][n], out[1][n]), (B, S, n, rel)          # the grouped products themselves: plain stores of the same tile sums
+            else:
+                assert rel < 1e-6, (B, S, n, rel)                                  # downstream of dH0 (layer 0's BPTT and its weight gradients)
+
+
 def test_compact_gemm_epilogues_equal_the_generic_one():
     """hulc_set_option "epilogue_fast": the compact epilogue paths of the GEMM kernels (plain fp32 store / accumulate; 16-bit output with bias, residual, ReLU, ReLU mask
     and the second store — gemm.h epi_plain4 / epi_fast16_*) against the generic epi_store4 path on a step whose decoder GEMMs take the 128 x 128 LDS-DMA kernel

@@ -322,7 +322,7 @@ def test_tightly_packed_layout_keeps_every_gradient_element_and_votes_outside_th
             eng.adam_step()
         torch.cuda.synchronize()
         res[pad] = (out, eng.comm_stats()["collectives"], {n: t.detach().cpu().numpy().copy() for n, t in eng.views(eng.flat_params).items()})
-    assert res[64][1] == 10 and res[4][1] == 12                         # the packed layout's vote is one extra 4-byte collective per backward
+    assert res[64][1] == 10 and res[4][1] == 12, (res[64][1], res[4][1])                         # the packed layout's vote is one extra 4-byte collective per backward
     tol = 0.0 if dtype == "fp32" else 2e-2                              # fp32 engine: deterministic -> bit-identical; bf16: run-to-run atomics order
     for it in range(2):
         for n, g in res[64][0][it].items():
