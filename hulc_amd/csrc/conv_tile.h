@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
     for (int ks = 0; ks < 6; ++ks) { const int ck = ks * 4 + g; rowsel[ks] = ((ck >> 3) * XR + (ck & 7)) * XRS; }
     const float4 bb[2] = {*reinterpret_cast<const float4*>(bias + g * 8), *reinterpret_cast<const float4*>(bias + g * 8 + 4)};
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(X.X);
-    const long long total = (long long)Nf * IH * RB;              // bytes of the frame buffer
+    const long long total = X.frames_total(Nf) * IH * RB;         // bytes of the frame buffer (the whole store when the windows are gathered by index)
     const int nitems = Nf * nbands;
     const float inv_spr = 1.f / (float)SPR;
     unsigned pe = 0;                                              // edge pixel of (row tid >> 1, side tid & 1) of the band in flight
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
         int dy = 0;
         pdx = 0; prows = rows;
         if (X.shift) { pdx = X.shift[2 * f] - X.pad; dy = X.shift[2 * f + 1] - X.pad; }
-        const long long fb = (long long)f * IH * RB;
+        const long long fb = X.frame(f) * IH * RB;
         const int nslot = rows * SPR;
         for (int n0 = wave * 64; n0 < nslot; n0 += 256) {
             const int n = n0 + lane;

@@ -695,6 +695,20 @@ struct Conv1Src {
     // (bias = bias_fold, computed by conv1_bias_fold_kernel from the 16-bit weights), the weight-gradient kernels scale their slab and subtract their
     // own bias partial before they write it.  fold == 0: the value x itself is staged (round 2 - 4).
     int fold;
+    // frame store (round 6; u8 only): X is not this batch's (Nf,H,W,C) frames but a device-resident STORE of nstore frames (whole episodes), and the
+    // batch's frame f = window f / S, step f % S lives at store index wstart[f / S] + f % S — conv1's forward and weight gradient GATHER their bands by index,
+    // no (B,S,H,W,C) tensor is materialised and nothing crosses PCIe per step (include/hulc_hip.h hulc_batch::window_start).  A start outside [0, nstore - S]
+    // is clamped (never an out-of-bounds read); shift[] stays indexed by the batch frame f.
+    const long long* wstart = nullptr;
+    int S = 1;
+    long long nstore = 0;
+    DEVI long long frame(int f) const {
+        if (!wstart) return f;
+        const int b = f / S;
+        const long long s0 = min(max(wstart[b], 0ll), nstore - (long long)S);
+        return s0 + (f - b * S);
+    }
+    DEVI long long frames_total(int Nf) const { return wstart ? nstore : (long long)Nf; }
 };
 #define CONV1_FOLD_SCALE (2.f / 255.f)
 // bias_fold[o] = b[o] - sum_k W16[o][k] over the packed 16-bit conv1 weights [32][192] (what the MFMAs multiply); one wave per output channel
@@ -758,7 +772,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     // 64 bytes and made a first version as slow as the 4x larger fp32 path; (B) a 4-pixel group is 12 contiguous bytes of a raw row
     // at a (shift-dependent) unaligned offset: four aligned LDS dwords, v_alignbyte, v_cvt_f32_ubyteN, one FMA per value
     // (b * 2/255 - 1: within one fp32 ulp of the reference's (b/255 - .5)/.5, which the fp32-mode ingest_u8_kernel keeps exactly).
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(s.X) + (long long)f * IH * IW * 3;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(s.X) + s.frame(f) * IH * IW * 3;
     int dx = 0, dy = 0;
     if (s.shift) { dx = s.shift[2 * f] - s.pad; dy = s.shift[2 * f + 1] - s.pad; }
     const int RB = IW * 3;                                            // bytes per source row (multiple of 4: IW % 4 == 0)
@@ -835,14 +849,14 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     }
 }
 // the same transform materialised as fp32 NCHW frames (fp32 parity mode, tests): out[f][c][y][x]
-__global__ void ingest_u8_kernel(const unsigned char* __restrict__ in, const int* __restrict__ shift, int pad, int Nf, int IH, int IW, float* __restrict__ out) {
+__global__ void ingest_u8_kernel(const unsigned char* __restrict__ in, const int* __restrict__ shift, int pad, int Nf, int IH, int IW, float* __restrict__ out, Conv1Src src = Conv1Src{}) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)Nf * 3 * IH * IW) return;
     const int x = (int)(idx % IW), y = (int)((idx / IW) % IH), c = (int)((idx / ((long long)IW * IH)) % 3), f = (int)(idx / ((long long)3 * IW * IH));
     int dx = 0, dy = 0;
     if (shift) { dx = shift[2 * f] - pad; dy = shift[2 * f + 1] - pad; }
     const int sy = min(max(y + dy, 0), IH - 1), sx = min(max(x + dx, 0), IW - 1);
-    out[idx] = u8_to_unit(in[(((long long)f * IH + sy) * IW + sx) * 3 + c]);
+    out[idx] = u8_to_unit(in[((src.frame(f) * IH + sy) * IW + sx) * 3 + c]);       // src: only its frame-store fields are used (frame(f) = f without a store)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1191,7 +1205,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
         int dy = 0;
         pdx = 0;
         if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
-        const unsigned char* fb = Xb + (long long)f * IH * RB;
+        const unsigned char* fb = Xb + S.frame(f) * IH * RB;
         const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
         {
             int t = tid;

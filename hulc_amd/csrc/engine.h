@@ -858,6 +858,7 @@ struct Engine : IEngine {
         // 16-bit engines: the dataloader's affine is folded out of the uint8 data path (conv_wgrad.h Conv1Src::fold); the fp32 (parity) engine converts
         // exactly like the reference (ingest_u8_kernel)
         s.fold = (s.u8 && std::is_same<T, h16_t>::value && u8_fold_mode) ? 1 : 0;
+        if (s.u8 && b.window_start) { s.wstart = reinterpret_cast<const long long*>(b.window_start); s.S = b.S; s.nstore = b.store_frames; }      // windows gathered from the frame store
         return s;
     }
     // b - sum_k W16 of the two conv1 layers (Conv1Src::fold), recomputed after every weight refresh, only when a uint8 batch asks for it
@@ -891,7 +892,7 @@ struct Engine : IEngine {
         if (!buf) buf = alloc<float>((int64_t)maxN * 3 * IH * IH);
         const long long n = (long long)Nf * 3 * IH * IH;
         float* dst = buf + frame_off * 3 * IH * IH;
-        hipLaunchKernelGGL(ingest_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(src.X), src.shift, src.pad, Nf, IH, IH, dst);
+        hipLaunchKernelGGL(ingest_u8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(src.X), src.shift, src.pad, Nf, IH, IH, dst, src);
         return dst;
     }
     // ---- paired pass (vis + lang windows of one step as ONE 2B-window pass, hulc_forward_loss_pair): rows [0, pairBv) are the vis
@@ -1444,6 +1445,8 @@ struct Engine : IEngine {
         if (!bound) { hulc_set_error("hulc_forward_loss_pair before hulc_bind_params"); return 1; }
         if (vb->is_lang || !lb->is_lang || !lb->lang) { hulc_set_error("hulc_forward_loss_pair: first batch must be the vis modality, second the lang modality with embeddings"); return 1; }
         if (vb->B != lb->B || vb->S != lb->S) { hulc_set_error("hulc_forward_loss_pair: both modalities need the same B and S (got %dx%d and %dx%d)", vb->B, vb->S, lb->B, lb->S); return 1; }
+        for (const hulc_batch* b : {vb, lb})
+            if (b->window_start && (!b->frames_u8 || b->store_frames < b->S)) { hulc_set_error("window_start (frame store) needs frames_u8 and store_frames >= S (got frames_u8=%d, store_frames=%lld, S=%d)", b->frames_u8, (long long)b->store_frames, b->S); return 1; }
         if (vb->frames_u8 != lb->frames_u8 || vb->actions_absolute != lb->actions_absolute || vb->max_rel_pos != lb->max_rel_pos || vb->max_rel_orn != lb->max_rel_orn) {
             hulc_set_error("hulc_forward_loss_pair: both modalities must use the same ingest options"); return 1; }
         if ((vb->plan_idx != nullptr) != (lb->plan_idx != nullptr) || (vb->plan_eps != nullptr) != (lb->plan_eps != nullptr)) {
@@ -1490,6 +1493,7 @@ struct Engine : IEngine {
         }
         if (b->is_lang && !b->lang) { hulc_set_error("lang modality batch without language embeddings (hulc.py:440 KeyError 'lang')"); return 1; }
         if (b->actions_absolute && !(b->max_rel_pos > 0.f && b->max_rel_orn > 0.f)) { hulc_set_error("actions_absolute needs max_rel_pos > 0 and max_rel_orn > 0 (RelativeActions, transforms.py:35-37)"); return 1; }
+        if (b->window_start && (!b->frames_u8 || b->store_frames < b->S)) { hulc_set_error("window_start (frame store) needs frames_u8 and store_frames >= S (got frames_u8=%d, store_frames=%lld, S=%d)", b->frames_u8, (long long)b->store_frames, b->S); return 1; }
         cur = *b; cur_lw = lw; cur_cw = cw; have_fwd = false; val_clip_n = 0;
         const int B = b->B, S = b->S, N = B * S, SB = S * B;
         const bool hulc = cfg.kind == HULC_KIND_HULC;
@@ -1629,6 +1633,7 @@ struct Engine : IEngine {
         if (b->actions_absolute && !(b->max_rel_pos > 0.f && b->max_rel_orn > 0.f)) { hulc_set_error("actions_absolute needs max_rel_pos > 0 and max_rel_orn > 0 (RelativeActions, transforms.py:35-37)"); return 1; }
         val_alloc();
         if (alloc_failed) { hulc_set_error("hulc_validate: workspace allocation failed"); return 1; }
+        if (b->window_start && (!b->frames_u8 || b->store_frames < b->S)) { hulc_set_error("window_start (frame store) needs frames_u8 and store_frames >= S"); return 1; }
         static const hulc_val_noise none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (!nz) nz = &none;
         cur = *b; have_fwd = false; pair = false; val_clip_n = 0;

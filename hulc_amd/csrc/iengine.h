@@ -79,7 +79,7 @@ struct IEngine {
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
     // "lazy_zero_grads": 1 (default; 16-bit engines) = hulc_zero_grads only marks the large store-first weight gradients stale instead of zeroing them
     // (engine.h: LazyG); 0 = the plain memset of the whole buffer.
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1, force_vote_word = 0, gemm_group_mode = 1;
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1, force_vote_word = 0, gemm_group_mode = 0;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
     virtual void set_adam_fuse(bool on) = 0;
@@ -93,7 +93,7 @@ struct IEngine {
         // "gemm_pair" (default 0; 16-bit engines): the decoder's two layer-1 weight gradients, which share dZ1^T up to a shift of one time step, run as ONE launch that
         // streams the shared operand once (gemm.h gemm_glds_pair_kernel; needs the batch to be a multiple of 64 windows); 0 = two launches
         if (name && !strcmp(name, "gemm_pair")) { gemm_pair_mode = value != 0; return 0; }
-        // "gemm_group" (default 1; 16-bit engines): the decoder backward's three independent 2048^3 products (dW_hh1, dW_ih1, dH0) run as ONE grouped launch (gemm.h gemm_glds_group_kernel)
+        // "gemm_group" (default 0: measured equal to the three launches, profiles/r06_ab_gemm_group.txt; 16-bit engines): the decoder backward's three independent 2048^3 products (dW_hh1, dW_ih1, dH0) as ONE grouped launch (gemm.h gemm_glds_group_kernel)
         if (name && !strcmp(name, "gemm_group")) { gemm_group_mode = value != 0; return 0; }
         if (name && !strcmp(name, "epilogue_fast")) { epilogue_fast = value != 0; return 0; }
         // "adam_fused_transposes" (default 1; 16-bit engines): the Adam / AdamW step writes the transposed 16-bit weight copies itself (kernels.h adam_tiled_kernel); 0 = flat pass + batched transpose

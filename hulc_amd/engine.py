@@ -86,7 +86,9 @@ class StepEngine:
     @staticmethod
     def _ingest_fields(mb: Dict, ptr) -> Dict:
         """uint8 (B,S,H,W,C) frames select the fused ingest path (include/hulc_hip.h: frames_u8); optional per-frame RandomShiftsAug
-        shifts `shift_static` / `shift_gripper` (B*S,2) int32 in [0, 2*pad] with pads `pad_static` (10) / `pad_gripper` (4)."""
+        shifts `shift_static` / `shift_gripper` (B*S,2) int32 in [0, 2*pad] with pads `pad_static` (10) / `pad_gripper` (4).
+        `window_start` (B,) int64 selects the FRAME STORE form (hulc_batch::window_start): rgb_static / rgb_gripper are then the device-resident
+        stores (F,H,W,3) uint8 and window b = store frames [window_start[b], window_start[b] + S) — nothing is materialised per step."""
         rel = {}
         if mb.get("actions_absolute"):        # RelativeActions (transforms.py:32-56) applied on the device
             rel = dict(actions_absolute=1, max_rel_pos=float(mb.get("max_rel_pos", 0.02)), max_rel_orn=float(mb.get("max_rel_orn", 0.05)))
@@ -98,6 +100,14 @@ class StepEngine:
         for k in ("shift_static", "shift_gripper"):
             if mb.get(k) is not None:
                 f[k] = ptr(mb[k].to(torch.int32))
+        if mb.get("window_start") is not None:
+            if mb["rgb_static"].dim() != 4 or mb["rgb_gripper"].dim() != 4 or mb["rgb_static"].shape[0] != mb["rgb_gripper"].shape[0]:
+                raise ValueError("frame store: rgb_static / rgb_gripper must be (F,H,W,3) uint8 stores of the same F next to window_start (B,)")
+            ws = mb["window_start"]
+            if not ws.is_cuda:
+                raise ValueError("frame store: window_start must live on the device")
+            f["window_start"] = ptr(ws.to(torch.int64))
+            f["store_frames"] = int(mb["rgb_static"].shape[0])
         return f
 
     def _batch_struct(self, mb: Dict, is_lang: bool, step: int, keep: list):

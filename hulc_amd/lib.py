@@ -24,7 +24,7 @@ class HulcBatch(C.Structure):
                 ("plan_idx", C.c_void_p), ("aux_rows", C.c_void_p), ("n_aux", C.c_int32), ("step", C.c_uint64),
                 ("frames_u8", C.c_int32), ("pad_static", C.c_int32), ("pad_gripper", C.c_int32), ("shift_static", C.c_void_p),
                 ("shift_gripper", C.c_void_p), ("plan_eps", C.c_void_p), ("actions_absolute", C.c_int32), ("max_rel_pos", C.c_float),
-                ("max_rel_orn", C.c_float)]
+                ("max_rel_orn", C.c_float), ("window_start", C.c_void_p), ("store_frames", C.c_int64)]
 
 
 class HulcValNoise(C.Structure):

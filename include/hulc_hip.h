@@ -81,6 +81,17 @@ typedef struct hulc_batch {
      * +-max_rel_orn and scaled, gripper unchanged.  0 = the reference's boundary (relative actions already in `actions`). */
     int32_t actions_absolute;
     float max_rel_pos, max_rel_orn;
+    /* ---- HBM-resident frame store (zero-initialise for a materialised batch) ----------------------------------
+     * window_start != NULL (requires frames_u8): rgb_static / rgb_gripper do not hold this batch's (B,S,H,W,C) frames but a device-resident STORE
+     * of `store_frames` uint8 (H,W,C) frames — whole episodes, uploaded once (CALVIN's ~2.4 M frames of both cameras are 340 GB as uint8: a split
+     * per GPU of the node fits its 288 GB) — and window b is the S consecutive store frames [window_start[b], window_start[b] + S).  conv1's forward
+     * and weight gradient gather their bands by index: no (B,S,H,W,C) tensor is materialised on either side of PCIe and nothing but B indices
+     * (+ actions / robot_obs / shifts) crosses it per step.  This replaces the reference's host-side shared-memory frame cache
+     * (README.md:85-86: ~20 minutes to fill; dataset/README.md:55-56) and its per-step uint8 -> fp32 -> H2D path.
+     * window_start: (B) int64 on the DEVICE; a start outside [0, store_frames - S] is clamped by the kernels (never an out-of-bounds read).
+     * shift_* stay (B*S,2) per batch frame.  The step is bit-identical to the same windows passed as a materialised uint8 batch. */
+    const int64_t* window_start;
+    int64_t store_frames;
 } hulc_batch;
 
 /* out_losses (device or host pointer, see `losses_on_host`): [total_mod, kl_scaled, action, clip] of this modality,

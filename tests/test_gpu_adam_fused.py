@@ -104,7 +104,7 @@ def test_paired_layer1_weight_gradient_gemm_equals_two_launches():
 
 
 def test_grouped_decoder_backward_gemms_equal_three_launches():
-    """hulc_set_option "gemm_group" (default 1): dW_hh1, dW_ih1 and dH0 = dZ1 W_ih1 of the action decoder's backward as ONE grouped launch (gemm.h
+    """hulc_set_option "gemm_group" (default 0: measured equal, profiles/r06_ab_gemm_group.txt): dW_hh1, dW_ih1 and dH0 = dZ1 W_ih1 of the action decoder's backward as ONE grouped launch (gemm.h
     gemm_glds_group_kernel: 3 x 256 tiles in one grid) against the three gemm_glds launches.  Same tile kernel body, same k order per tile -> the two weight gradients
     are bit-identical; dH0 feeds layer 0's BPTT, so weight_hh_l0 / weight_ih_l0 agree bit for bit as well (S = 32: K = 2048 and 1984, and S = 6: K = 384 / 320)."""
     for B, S in ((64, 32), (64, 6)):

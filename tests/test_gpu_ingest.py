@@ -128,3 +128,52 @@ def test_absolute_action_ingest_equals_relative_boundary():
     with pytest.raises(RuntimeError):
         eng.forward_loss(dict(common, actions=t(act_abs), actions_absolute=True, max_rel_pos=0.0), False, 1.0, 3.0)
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_frame_store_windows_equal_the_materialised_batch(dtype):
+    """hulc_batch::window_start (VERDICT r5 #10): the step on windows GATHERED by index from a device-resident uint8 frame store == the step on the same
+    windows passed as a materialised (B,S,H,W,C) batch — overlapping windows, the first and the last S frames of the store, RandomShiftsAug shifts per
+    batch frame, an out-of-range start (clamped to the last window, never an out-of-bounds read).  fp32 engine: bit for bit (deterministic);
+    bf16 engine: the loss bit for bit (the forward is deterministic), the gradients to the backward's run-to-run atomics noise.  Validation too."""
+    dims, P, batch, fx = load_case("hulc_tiny")
+    mb0 = batch["vis"]
+    B, S = mb0["actions"].shape[:2]
+    rng = np.random.default_rng(11)
+    F = 3 * S + 5
+    store_s = rng.integers(0, 256, (F, 200, 200, 3), dtype=np.uint8)
+    store_g = rng.integers(0, 256, (F, 84, 84, 3), dtype=np.uint8)
+    starts = np.array(([0, F - S, 2, 3] * B)[:B], np.int64)                # first / last window of the store, two overlapping ones
+    sh_s = rng.integers(0, 21, (B * S, 2)).astype(np.int32)
+    sh_g = rng.integers(0, 9, (B * S, 2)).astype(np.int32)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).cuda() if dt is None else torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+    common = dict(actions=t(mb0["actions"], np.float32), robot_obs=t(mb0["robot_obs"], np.float32), plan_idx=t(mb0["plan_idx"], np.int32),
+                  shift_static=t(sh_s), shift_gripper=t(sh_g), pad_static=10, pad_gripper=4)
+    idx = (starts[:, None] + np.arange(S)[None, :]).reshape(-1)
+    mat = dict(common, rgb_static=t(store_s[idx].reshape(B, S, 200, 200, 3)), rgb_gripper=t(store_g[idx].reshape(B, S, 84, 84, 3)))
+    sto = dict(common, rgb_static=t(store_s), rgb_gripper=t(store_g), window_start=t(starts))
+    l0, g0, _ = _run(dims, P, B, S, dtype, mat)
+    l1, g1, _ = _run(dims, P, B, S, dtype, sto)
+    same = lambda a, b: all(a[k] == b[k] for k in a) if dtype == "fp32" else all(abs(a[k] - b[k]) <= 1e-5 * abs(a[k]) + 1e-7 for k in a)   # (bf16: fp32 atomics in the transformer)
+    assert same(l0, l1), (l0, l1)
+    if dtype == "fp32":
+        assert torch.equal(g0, g1)
+    else:
+        l2, g2, _ = _run(dims, P, B, S, dtype, mat)                       # the materialised step again = the backward's own noise
+        noise = ((g0 - g2).double().norm() / g0.double().norm()).item()
+        rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
+        assert rel <= 3.0 * noise + 1e-5, (rel, noise)
+    # a start beyond the store is clamped to the last window; validation reads the store the same way
+    bad = starts.copy(); bad[1] = F + 100
+    eng = StepEngine(dims, B, S, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=1)
+    eng.load_numpy(P)
+    la = eng.forward_loss(dict(sto, window_start=t(bad)), False, 1.0, 3.0, step=0)
+    assert same(la, l1), (la, l1)                                          # starts[1] was already F - S
+    va = eng.validate({k: v for k, v in mat.items() if not k.startswith("shift") and k != "plan_idx"}, False, None)
+    vb = eng.validate({k: v for k, v in sto.items() if not k.startswith("shift") and k != "plan_idx"}, False, None)
+    assert abs(va["action_loss_pp"] - vb["action_loss_pp"]) <= 1e-5 * abs(va["action_loss_pp"]) and torch.equal(va["sampled_plan_idx_pp"], vb["sampled_plan_idx_pp"])
+    with pytest.raises(RuntimeError):                                      # a store shorter than one window
+        eng.forward_loss(dict(sto, rgb_static=t(store_s[:S - 1]), rgb_gripper=t(store_g[:S - 1])), False, 1.0, 3.0)
+    with pytest.raises(ValueError):                                        # stores of different lengths
+        eng.forward_loss(dict(sto, rgb_gripper=t(store_g[:F - 1])), False, 1.0, 3.0)
+    eng.close()
