@@ -44,10 +44,12 @@ MFMA_GROUPS = {
 }
 
 
-def synth_batch(B, S, dev, seed, lang=False, ingest="fp32"):
+def synth_batch(B, S, dev, seed, lang=False, ingest="fp32", store_frames=0):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     def u8img(h):
+        if ingest == "u8" and store_frames:      # HBM-resident frame store (F,H,W,C): the step's windows are gathered by index (hulc_batch::window_start)
+            return torch.cat([torch.randint(0, 256, (min(1024, store_frames - f0), h, h, 3), device=dev, generator=g, dtype=torch.int32).to(torch.uint8) for f0 in range(0, store_frames, 1024)]).contiguous()
         if ingest == "u8":      # dataset layout: uint8 (B,S,H,W,C); scale / normalise / RandomShiftsAug run inside conv1's load path
             return torch.randint(0, 256, (B, S, h, h, 3), device=dev, generator=g, dtype=torch.int32).to(torch.uint8).contiguous()
         u = torch.randint(0, 256, (B, S, 3, h, h), device=dev, generator=g, dtype=torch.int32).float()
@@ -62,6 +64,10 @@ def synth_batch(B, S, dev, seed, lang=False, ingest="fp32"):
     if ingest == "u8":
         mb.update(shift_static=torch.randint(0, 21, (B * S, 2), device=dev, generator=g, dtype=torch.int32), pad_static=10,
                   shift_gripper=torch.randint(0, 9, (B * S, 2), device=dev, generator=g, dtype=torch.int32), pad_gripper=4)
+    if ingest == "u8" and store_frames:
+        # 64 pre-drawn vectors of B random window starts (episode boundaries are the datamodule's business: any start in [0, F - S] is a valid read)
+        mb["window_starts"] = torch.randint(0, store_frames - S + 1, (64, B), device=dev, generator=g, dtype=torch.int64)
+        mb["window_start"] = mb["window_starts"][0].contiguous()
     if lang:
         l = torch.randn(B, 384, device=dev, generator=g)
         mb["lang"] = (l / l.norm(dim=-1, keepdim=True)).contiguous()
@@ -172,6 +178,8 @@ def main():
                     help="N > 1: wire format of the gradient all-reduce buckets (fp32 = the reference's; the engine's 16-bit type halves the bytes per link)")
     ap.add_argument("--h2d", type=int, default=0, help="with --ingest u8: 1 = every step's uint8 frames come from PINNED HOST memory (async H2D on a copy stream into a "
                                                       "double buffer, overlapped with the previous step) — the PCIe-inclusive row SURVEY §8(d) asks for; never the headline `value`")
+    ap.add_argument("--store", type=int, default=0, metavar="F", help="with --ingest u8: F > 0 = the frames live in a device-resident uint8 STORE of F frames per camera "
+                                                                     "and every step draws B random windows from it by index (hulc_batch::window_start): no materialised batch, no per-step H2D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="hulc_set_option(NAME, VALUE) before the run: same-box A/B of a library switch, e.g. adam_fused_transposes=0")
     ap.add_argument("--timer-stride", type=int, default=4, help="the live class timers record their HIP events on every N-th step of the timed region (1 = every step)")
@@ -247,9 +255,11 @@ def main():
     rccl_rank, rccl_ranks = (eng.comm_size() if lib_comm else (None, None))
     if lib_comm and (rccl_ranks != world or rccl_rank != rank):
         raise SystemExit(f"bench.py rank {rank}: the library communicator reports rank {rccl_rank} of {rccl_ranks}, the job is rank {rank} of {world} — refusing to print a line")
-    mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest))]
+    if args.store and (args.ingest != "u8" or args.h2d or args.store < S):
+        raise SystemExit("--store F needs --ingest u8, no --h2d, and F >= seq")
+    mods = [("vis", synth_batch(Bmod, S, dev, 1000 * rank + 1, False, args.ingest, args.store))]
     if args.lang:
-        mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest)))
+        mods.append(("lang", synth_batch(Bmod, S, dev, 1000 * rank + 2, True, args.ingest, args.store)))
     nmod = len(mods)
 
     # --h2d 1: the frames of every step cross PCIe.  Pinned host copies of the uint8 (B,S,H,W,C) frames; two device buffers per camera; the copy
@@ -296,6 +306,9 @@ def main():
             eng.backward()
 
     def _step(i):
+        if args.store:                                   # this step's windows: another pre-drawn vector of starts (a device pointer swap, no copy)
+            for _, mb in mods:
+                mb["window_start"] = mb["window_starts"][i % 64]
         eng.zero_grads()
         if paired:
             eng.forward_loss_pair(mods[0][1], mods[1][1], 0.5, 3.0, step=i, sync_losses=False)
@@ -537,7 +550,7 @@ def main():
             "config": {"workload": "%s training step, %s, B=%d windows/GPU, seq_len=%d, 200x200 static + 84x84 gripper %s frames, "
                                    "fwd+loss+bwd+%sAdam, dropout %s" % (("HULC (model=mcil: Bi%s plan recognition, continuous plan)" % ("GRU" if args.model == "mcil_gru" else "RNN")) if mcil else "HULC",
                                                                         ("32 vis + 32 lang" + ("" if mcil else " + CLIP aux") + (" as one paired pass" if paired else ", one pass per modality")) if args.lang else "vision goal only (use_clip_auxiliary_loss=false)",
-                                                                        B, S, ("uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" + (", frames copied from PINNED HOST memory every step (async H2D, double-buffered)" if args.h2d else "")) if args.ingest == "u8" else "fp32 NCHW",
+                                                                        B, S, ("uint8 HWC (scale+normalise+RandomShiftsAug fused into conv1)" + (", frames copied from PINNED HOST memory every step (async H2D, double-buffered)" if args.h2d else "") + ((", windows gathered by index from a device-resident store of %d frames per camera (new random windows every step)" % args.store) if args.store else "")) if args.ingest == "u8" else "fp32 NCHW",
                                                                         "RCCL all-reduce+" if world > 1 else "", "0.0" if mcil else "0.1"),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "last_losses": {"total_mod": loss[0], "kl": loss[1], "action": loss[2], "clip": loss[3]},
