@@ -215,18 +215,37 @@ def static_encoder_bwd(P, G, pre, c, dout):
     _conv_stack_bwd(P, G, pre, c, d)
 
 
+CONDITION_SUMS = False      # tests only: also accumulate G["abs/" + name] = sum |dY|^T |X| (weights) / sum |dY| (biases) of the six conv layers
+
+
+def _cond(G, name, x, w, dy, s):
+    """The CONDITION of a convolution's weight / bias gradient as a sum (tests/test_gpu_fullsize.py): every element of dW is a sum of N x OH x OW
+    products dY x, and kappa = || sum |dY| |x| || / || sum dY x || says by how much a relative perturbation eps of the summands (one 16-bit rounding of
+    dY = 2^-9) can move the result: ||delta dW|| <= kappa eps ||dW||.  Encoder gradients cancel heavily (kappa 10 - 40), which is what bounds the
+    full-size parity gates from below — not the kernels' own arithmetic."""
+    if not CONDITION_SUMS:
+        return
+    _, dwa, dba = conv2d_bwd(np.abs(x), w, np.abs(dy), s, need_dx=False)
+    _acc(G, "abs/" + name + ".weight", dwa)
+    _acc(G, "abs/" + name + ".bias", dba)
+
+
 def _conv_stack_bwd(P, G, pre, c, d3):
     d, dw, db = conv2d_bwd(c["a2"], P[pre + "conv_model.4.weight"], d3, 1)
     _acc(G, pre + "conv_model.4.weight", dw)
     _acc(G, pre + "conv_model.4.bias", db)
+    _cond(G, pre + "conv_model.4", c["a2"], P[pre + "conv_model.4.weight"], d3, 1)
     d = d * (c["a2"] > 0)
+    d2 = d
     d, dw, db = conv2d_bwd(c["a1"], P[pre + "conv_model.2.weight"], d, 2)
     _acc(G, pre + "conv_model.2.weight", dw)
     _acc(G, pre + "conv_model.2.bias", db)
+    _cond(G, pre + "conv_model.2", c["a1"], P[pre + "conv_model.2.weight"], d2, 2)
     d = d * (c["a1"] > 0)
     _, dw, db = conv2d_bwd(c["x"], P[pre + "conv_model.0.weight"], d, 4, need_dx=False)
     _acc(G, pre + "conv_model.0.weight", dw)
     _acc(G, pre + "conv_model.0.bias", db)
+    _cond(G, pre + "conv_model.0", c["x"], P[pre + "conv_model.0.weight"], d, 4)
 
 
 def gripper_encoder_fwd(P, pre, x):

@@ -82,6 +82,7 @@ def _work(args):
     is_lang = "lang" in scope
     dims_run = dims if w_clip else dataclasses.replace(dims, use_clip=False)      # chunked jobs never carry the CLIP term
     O.set_operand_rounding(case.get("mode"), case.get("gscale", 1.0))
+    O.CONDITION_SUMS = bool(case.get("cond", False))        # + G["abs/..."]: the conv gradients' condition sums (hulc_oracle._cond)
     G, sums, embs = {}, dict(kl=0.0, action=0.0, total=0.0, clip=0.0), {}
     for c in chunks:
         chunk = {k: np.ascontiguousarray(v[c * CH:(c + 1) * CH]) for k, v in mb.items()}
@@ -154,9 +155,9 @@ def oracle_case(case, CH=4, workers=None, P=None, batch=None):
     return {n: np.asarray(v, np.float32) for n, v in G.items()}, losses, emb_out
 
 
-def oracle_batch(seed, kind, max_window, Bt, St, CH=4, mode=None, gscale=1.0, workers=None, P=None, mb=None):
+def oracle_batch(seed, kind, max_window, Bt, St, CH=4, mode=None, gscale=1.0, workers=None, P=None, mb=None, cond=False):
     """(gradients, total loss, emb) of the vision-only batch `synthetic.make_batch(Bt, 0, St, seed=seed, edge_frac=0.05, aux_mask='all')` under
     `spec.init_all(dims, seed=seed, ln_jitter=True)`, evaluated by the numpy oracle in chunks of CH windows."""
-    G, losses, embs = oracle_case(dict(seed=seed, kind=kind, max_window=max_window, B=Bt, S=St, mode=mode, gscale=gscale), CH, workers,
+    G, losses, embs = oracle_case(dict(seed=seed, kind=kind, max_window=max_window, B=Bt, S=St, mode=mode, gscale=gscale, cond=cond), CH, workers,
                                   P=P, batch=None if mb is None else {"vis": mb})
     return G, losses["vis"]["total"], embs["vis"]

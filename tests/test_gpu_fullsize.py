@@ -435,10 +435,18 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     # the oracle runs in spawned worker processes (tests/oracle_pool.py: the same seeded parameters and batch, chunks of 4 windows spread over the
     # host's cores) — sequentially the 16 chunks take ~4 minutes on 8 cores
     from oracle_pool import oracle_batch
-    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb)
+    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb, cond=True)
+    Gabs = {n[4:]: G.pop(n) for n in [k for k in G if k.startswith("abs/")]}     # the conv gradients' condition sums (hulc_oracle._cond)
     assert abs(l["total_mod"] - loss) <= 5e-4 * abs(loss), (l, loss)
     assert rel_l2(emb, emb_q) < 2e-3, rel_l2(emb, emb_q)
     errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    # where the largest per-tensor errors come from.  kappa = || sum |dY| |x| || / || sum dY x || of a conv gradient: a relative
+    # perturbation eps of its summands moves it by up to kappa eps — err / kappa is the relative error of the SUMMANDS that explains the tensor's error
+    u = 2.0 ** -12 if dtype == "fp16" else 2.0 ** -9
+    rows = sorted(((errs[n], float(np.linalg.norm(Gabs[n]) / max(np.linalg.norm(G[n]), 1e-30)), n) for n in Gabs if n in errs), reverse=True)
+    print(f"[B={Bt} S={St} {dtype}] conv gradients: error vs rounding-aware oracle | condition kappa | error / kappa (in units of the 16-bit rounding u = {u:.1e})")
+    for e, k, n in rows:
+        print(f"    {e:.3e} | {k:8.1f} | {e / k:.2e} = {e / k / u:5.2f} u | {n.split('perceptual_encoder.')[1]}")
     top = sorted(((e, n) for n, e in errs.items()), reverse=True)
     print(f"[B={Bt} S={St} {dtype}] vs rounding-aware oracle: loss {abs(l['total_mod'] - loss) / abs(loss):.1e}, emb {rel_l2(emb, emb_q):.1e}, "
           f"median tensor {np.median([e for e, _ in top]):.2e}, worst tensors:", [(round(e, 4), n) for e, n in top[:8]])
