@@ -442,11 +442,13 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
     # where the largest per-tensor errors come from.  kappa = || sum |dY| |x| || / || sum dY x || of a conv gradient: a relative
     # perturbation eps of its summands moves it by up to kappa eps — err / kappa is the relative error of the SUMMANDS that explains the tensor's error
-    u = 2.0 ** -12 if dtype == "fp16" else 2.0 ** -9
+    u = 2.0 ** -11 if dtype == "fp16" else 2.0 ** -8          # unit roundoff of the 16-bit format (11 / 8 significant bits)
     rows = sorted(((errs[n], float(np.linalg.norm(Gabs[n]) / max(np.linalg.norm(G[n]), 1e-30)), n) for n in Gabs if n in errs), reverse=True)
     print(f"[B={Bt} S={St} {dtype}] conv gradients: error vs rounding-aware oracle | condition kappa | error / kappa (in units of the 16-bit rounding u = {u:.1e})")
     for e, k, n in rows:
         print(f"    {e:.3e} | {k:8.1f} | {e / k:.2e} = {e / k / u:5.2f} u | {n.split('perceptual_encoder.')[1]}")
+    other = sorted(((e, n) for n, e in errs.items() if n not in Gabs), reverse=True)
+    print(f"[B={Bt} S={St} {dtype}] worst NON-conv tensors:", [(round(e, 4), n) for e, n in other[:10]])
     top = sorted(((e, n) for n, e in errs.items()), reverse=True)
     print(f"[B={Bt} S={St} {dtype}] vs rounding-aware oracle: loss {abs(l['total_mod'] - loss) / abs(loss):.1e}, emb {rel_l2(emb, emb_q):.1e}, "
           f"median tensor {np.median([e for e, _ in top]):.2e}, worst tensors:", [(round(e, 4), n) for e, n in top[:8]])
