@@ -204,10 +204,12 @@ def static_encoder_bwd(P, G, pre, c, dout):
     d, dg, db = layer_norm_bwd(dout, P[pre + "ln.weight"], c["ln_cache"])
     _acc(G, pre + "ln.weight", dg)
     _acc(G, pre + "ln.bias", db)
+    _cond_lin(G, pre + "fc2", c["f1"], d)
     d, dw, db = linear_bwd(c["f1"], P[pre + "fc2.weight"], d)
     _acc(G, pre + "fc2.weight", dw)
     _acc(G, pre + "fc2.bias", db)
     d = d * (c["f1"] > 0)
+    _cond_lin(G, pre + "fc1.0", c["ss"], d)
     d, dw, db = linear_bwd(c["ss"], P[pre + "fc1.0.weight"], d)
     _acc(G, pre + "fc1.0.weight", dw)
     _acc(G, pre + "fc1.0.bias", db)
@@ -228,6 +230,15 @@ def _cond(G, name, x, w, dy, s):
     _, dwa, dba = conv2d_bwd(np.abs(x), w, np.abs(dy), s, need_dx=False)
     _acc(G, "abs/" + name + ".weight", dwa)
     _acc(G, "abs/" + name + ".bias", dba)
+
+
+def _cond_lin(G, name, x, dy):
+    """the same for a Linear layer's gradients: sum_rows |dY|^T |x| and sum_rows |dY| (the encoder tails: 2048 frame rows per step)"""
+    if not CONDITION_SUMS:
+        return
+    dy = np.abs(qg(dy))
+    _acc(G, "abs/" + name + ".weight", (dy.T @ np.abs(q(x))).astype(F32))
+    _acc(G, "abs/" + name + ".bias", dy.sum(0).astype(F32))
 
 
 def _conv_stack_bwd(P, G, pre, c, d3):
@@ -268,14 +279,17 @@ def gripper_encoder_bwd(P, G, pre, c, dout):
     d, dg, db = layer_norm_bwd(dout, P[pre + "ln.weight"], c["ln_cache"])
     _acc(G, pre + "ln.weight", dg)
     _acc(G, pre + "ln.bias", db)
+    _cond_lin(G, pre + "fc2", c["f1"], d)
     d, dw, db = linear_bwd(c["f1"], P[pre + "fc2.weight"], d)
     _acc(G, pre + "fc2.weight", dw)
     _acc(G, pre + "fc2.bias", db)
     d = d * (c["f1"] > 0)
+    _cond_lin(G, pre + "fc1.0", c["g0"], d)
     d, dw, db = linear_bwd(c["g0"], P[pre + "fc1.0.weight"], d)
     _acc(G, pre + "fc1.0.weight", dw)
     _acc(G, pre + "fc1.0.bias", db)
     d = d * (c["g0"] > 0)
+    _cond_lin(G, pre + "conv_model.7", c["flat"], d)
     d, dw, db = linear_bwd(c["flat"], P[pre + "conv_model.7.weight"], d)
     _acc(G, pre + "conv_model.7.weight", dw)
     _acc(G, pre + "conv_model.7.bias", db)

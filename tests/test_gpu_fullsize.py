@@ -410,7 +410,8 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     four-wave attention kernels) — against the ORACLE, not against the sibling engine: the numpy restatement with every GEMM / convolution
     operand and every stored 16-bit tensor rounded to the engine's format (oracle.set_operand_rounding), evaluated in chunks of 4 windows
     (every loss is a mean over windows: losses and gradients of the batch are the chunk means).  Gates = the 512-frame test's: loss 5e-4,
-    emb 2e-3, EVERY gradient tensor 5e-2 (bf16) / 3.5e-2 (fp16) relative L2; what bounds them from below is discussed there."""
+    emb 2e-3; the gradient tensors by _gate_gradients below: encoder tensors by their own condition (error / kappa <= a fraction of one 16-bit
+    rounding of the summands), everything else 3.5e-2 (bf16) / 2e-2 (fp16) relative L2."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import rel_l2
@@ -436,26 +437,10 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     # host's cores) — sequentially the 16 chunks take ~4 minutes on 8 cores
     from oracle_pool import oracle_batch
     G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb, cond=True)
-    Gabs = {n[4:]: G.pop(n) for n in [k for k in G if k.startswith("abs/")]}     # the conv gradients' condition sums (hulc_oracle._cond)
     assert abs(l["total_mod"] - loss) <= 5e-4 * abs(loss), (l, loss)
     assert rel_l2(emb, emb_q) < 2e-3, rel_l2(emb, emb_q)
-    errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
-    # where the largest per-tensor errors come from.  kappa = || sum |dY| |x| || / || sum dY x || of a conv gradient: a relative
-    # perturbation eps of its summands moves it by up to kappa eps — err / kappa is the relative error of the SUMMANDS that explains the tensor's error
-    u = 2.0 ** -11 if dtype == "fp16" else 2.0 ** -8          # unit roundoff of the 16-bit format (11 / 8 significant bits)
-    rows = sorted(((errs[n], float(np.linalg.norm(Gabs[n]) / max(np.linalg.norm(G[n]), 1e-30)), n) for n in Gabs if n in errs), reverse=True)
-    print(f"[B={Bt} S={St} {dtype}] conv gradients: error vs rounding-aware oracle | condition kappa | error / kappa (in units of the 16-bit rounding u = {u:.1e})")
-    for e, k, n in rows:
-        print(f"    {e:.3e} | {k:8.1f} | {e / k:.2e} = {e / k / u:5.2f} u | {n.split('perceptual_encoder.')[1]}")
-    other = sorted(((e, n) for n, e in errs.items() if n not in Gabs), reverse=True)
-    print(f"[B={Bt} S={St} {dtype}] worst NON-conv tensors:", [(round(e, 4), n) for e, n in other[:10]])
-    top = sorted(((e, n) for n, e in errs.items()), reverse=True)
-    print(f"[B={Bt} S={St} {dtype}] vs rounding-aware oracle: loss {abs(l['total_mod'] - loss) / abs(loss):.1e}, emb {rel_l2(emb, emb_q):.1e}, "
-          f"median tensor {np.median([e for e, _ in top]):.2e}, worst tensors:", [(round(e, 4), n) for e, n in top[:8]])
-    assert top[0][0] < (3.5e-2 if dtype == "fp16" else 5e-2), top[:5]
-    a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
-    b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
-    assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999
+    print(f"[B={Bt} S={St} {dtype}] vs rounding-aware oracle: loss {abs(l['total_mod'] - loss) / abs(loss):.1e}, emb {rel_l2(emb, emb_q):.1e}")
+    _gate_gradients(f"B={Bt} S={St} {dtype}", Gg, G, dtype)
 
 
 def _np_to_dev(mb):
@@ -468,13 +453,39 @@ def _np_to_dev(mb):
     return out
 
 
-def _per_tensor_table(tag, Gg, G, gate):
+# ---- the per-tensor gradient gates of the full-size cases ("find the 4.5e-2") --------------------------------------------------
+# Rounds 3 - 5 held EVERY gradient tensor to one number (5e-2 bf16 / 3.5e-2 fp16) and sat at 4.5e-2 on the gripper camera's conv1 weight.  The oracle
+# now also returns each encoder gradient's CONDITION as a sum (hulc_oracle._cond / _cond_lin: kappa = || sum |dY| |x| || / || sum dY x || — an
+# encoder gradient is a sum over 2048 frames x hundreds of pixels of products that cancel): a relative perturbation eps of the summands moves such a
+# tensor by up to kappa eps.  Measured at B = 64, S = 32, bf16: kappa = 271 for that conv1 weight (16 - 220 for the other conv tensors), and
+# error / kappa = 1.2e-4 ... 5.2e-4 for ALL of them — 0.03 - 0.13 of ONE bf16 rounding (unit roundoff 2^-8) of the summands; fp16 (S = 64):
+# 0.6e-4 ... 2.4e-4 = 0.13 - 0.49 of 2^-11.  Nothing systematic is left in the engine to fix or to model: the error of every encoder tensor is a
+# fraction of one operand rounding, amplified by that tensor's own cancellation, and where the two fp32 summation orders (MFMA k-blocks vs BLAS)
+# differ they move stored 16-bit activations across rounding boundaries (the floor discussed at the 512-frame test above).
+#   encoder tensors (the ones with a condition sum): error <= kappa x G_SUMMAND, G_SUMMAND = 1e-3 (bf16: a quarter of 2^-8) / 5e-4 (fp16: one 2^-11):
+#       2x above the worst measured ratio, and never more than 0.1 absolute;
+#   every other tensor: error <= G_OTHER.
+G_SUMMAND = {"bf16": 1e-3, "fp16": 5e-4}
+G_OTHER = {"bf16": 3.5e-2, "fp16": 2.0e-2}
+
+
+def _gate_gradients(tag, Gg, G, dtype="bf16"):
+    """G: the oracle's gradients incl. its "abs/<name>" condition sums (case["cond"]); prints the per-tensor table, asserts the gates above."""
     from golden_util import rel_l2
+    Gabs = {n[4:]: G.pop(n) for n in [k for k in G if k.startswith("abs/")]}
     errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    u = 2.0 ** -11 if dtype == "fp16" else 2.0 ** -8          # unit roundoff of the 16-bit format (11 / 8 significant bits)
+    rows = sorted(((errs[n], float(np.linalg.norm(Gabs[n]) / max(np.linalg.norm(G[n]), 1e-30)), n) for n in Gabs if n in errs), reverse=True)
+    print(f"[{tag}] encoder gradients: error vs rounding-aware oracle | condition kappa | error / kappa (in unit roundoffs u = {u:.1e} of the summands)")
+    for e, k, n in rows:
+        print(f"    {e:.3e} | {k:8.1f} | {e / k:.2e} = {e / k / u:5.2f} u | {n.split('perceptual_encoder.')[1]}")
+    other = sorted(((e, n) for n, e in errs.items() if n not in Gabs), reverse=True)
     top = sorted(((e, n) for n, e in errs.items()), reverse=True)
-    print(f"[{tag}] per-tensor gradient rel-L2 vs the rounding-aware oracle: median {np.median([e for e, _ in top]):.2e}, worst:",
-          [(round(e, 4), n) for e, n in top[:10]])
-    assert top[0][0] < gate, top[:6]
+    print(f"[{tag}] median tensor {np.median([e for e, _ in top]):.2e}; worst ratio error / kappa {max(e / k for e, k, _ in rows):.2e} (gate {G_SUMMAND[dtype]:.1e}); "
+          f"worst tensors without a condition sum (gate {G_OTHER[dtype]:.1e}):", [(round(e, 4), n) for e, n in other[:8]])
+    bad = [(n, e, k) for e, k, n in rows if e > min(k * G_SUMMAND[dtype], 0.1)]
+    assert not bad, bad
+    assert other[0][0] < G_OTHER[dtype], other[:5]
     a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
     b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
     assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999
@@ -487,12 +498,12 @@ def test_mcil_benchmark_shape_against_the_rounding_aware_oracle(rnn_type):
     engine: this is the size at which the 16-bit engine runs the kernels that only exist at M > 32 rows (both directions of layer 0 as ONE dual
     persistent recurrence, the paired-direction `gru_step_lds_kernel`, the GRU gate backward fused into the K-chunked carry GEMM).  The oracle
     rounds the plan encoder's operands and stored tensors where the engine does (oracle.birnn_* / bigru_*: `q` / `qg`), the N(0,1) draw is
-    injected.  Gates as for the HULC shapes: loss 5e-4, emb 2e-3, every gradient tensor 5e-2."""
+    injected.  Gates as for the HULC shapes: loss 5e-4, emb 2e-3, gradient tensors by _gate_gradients."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import rel_l2
     import oracle_pool
-    case = dict(seed=29, kind="mcil", rnn_type=rnn_type, max_window=32, B=64, S=32, mode="bf16", gscale=1.0)
+    case = dict(seed=29, kind="mcil", rnn_type=rnn_type, max_window=32, B=64, S=32, mode="bf16", gscale=1.0, cond=True)
     dims = oracle_pool.case_dims(case)
     mb = oracle_pool.case_batch(case)["vis"]
     eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3, num_classes=dims.mix_classes)
@@ -510,7 +521,7 @@ def test_mcil_benchmark_shape_against_the_rounding_aware_oracle(rnn_type):
     assert abs(l["total_mod"] - lo["total"]) <= 5e-4 * abs(lo["total"]), (l, lo)
     assert abs(l["kl"] - lo["kl"]) <= 2e-3 * abs(lo["kl"]) + 1e-7, (l, lo)
     assert rel_l2(emb, embs["vis"]) < 2e-3
-    _per_tensor_table(f"mcil {rnn_type} B=64 S=32 bf16", Gg, G, 5e-2)
+    _gate_gradients(f"mcil {rnn_type} B=64 S=32 bf16", Gg, G, "bf16")
 
 
 def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle():
@@ -521,7 +532,7 @@ def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle(
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import rel_l2
     import oracle_pool
-    case = dict(seed=31, kind="hulc", max_window=32, B=32, B_lang=32, S=32, use_clip=True, mode="bf16", gscale=1.0)
+    case = dict(seed=31, kind="hulc", max_window=32, B=32, B_lang=32, S=32, use_clip=True, mode="bf16", gscale=1.0, cond=True)
     dims = oracle_pool.case_dims(case)
     batch = oracle_pool.case_batch(case)
     eng = StepEngine(dims, 64, 32, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=3)
@@ -542,4 +553,4 @@ def test_paired_vis_lang_clip_benchmark_shape_against_the_rounding_aware_oracle(
         assert abs(got["total_mod"] - (losses[sc]["kl"] + losses[sc]["action"])) <= 5e-4 * abs(losses[sc]["total"]), (sc, got, losses[sc])
         assert abs(got["kl"] - losses[sc]["kl"]) <= 2e-3 * abs(losses[sc]["kl"]) + 1e-7, (sc, got, losses[sc])
     assert abs(ll["clip"] - losses["lang"]["clip"]) <= 2e-3 * abs(losses["lang"]["clip"]), (ll, losses["lang"])
-    _per_tensor_table("vis+lang+CLIP 32+32 S=32 bf16", Gg, G, 5e-2)
+    _gate_gradients("vis+lang+CLIP 32+32 S=32 bf16", Gg, G, "bf16")
