@@ -79,7 +79,7 @@ struct IEngine {
     // partial arena with NaN before the next backward (a slab that is read before it is written then shows up in the gradients).
     // "lazy_zero_grads": 1 (default; 16-bit engines) = hulc_zero_grads only marks the large store-first weight gradients stale instead of zeroing them
     // (engine.h: LazyG); 0 = the plain memset of the whole buffer.
-    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1, force_vote_word = 0, gemm_group_mode = 0;
+    int persist_mode = 1, tr_fused_mode = 1, persist_under_comm = 0, comm_timing = 0, poison_partials = 0, persist_fault = 0, lazy_zero_mode = 1, u8_fold_mode = 1, force_vote_word = 0, gemm_group_mode = 0, hold_buckets_mode = 1;
     virtual int get_option(const char* name, long long* value) = 0;
     virtual void dp_skip_vote(int phase) = 0;
     virtual void set_adam_fuse(bool on) = 0;
@@ -87,6 +87,10 @@ struct IEngine {
         if (name && !strcmp(name, "persistent_rnn")) { persist_mode = value != 0; return 0; }
         if (name && !strcmp(name, "fused_transformer")) { tr_fused_mode = value != 0; return 0; }
         if (name && !strcmp(name, "persist_under_comm")) { persist_under_comm = value != 0; return 0; }
+        // "dp_hold_buckets" (default 1): mcil with the tanh-RNN plan encoder under hulc_backward_allreduce — the decoder's and the plan proposal's buckets are issued BEHIND
+        // the BiRNN backward so that its four recurrences stay persistent (no RCCL kernel holds CUs yet); 0 = issue them as early as possible (round 5), the BiRNN
+        // backward then runs one launch per step unless persist_under_comm is set
+        if (name && !strcmp(name, "dp_hold_buckets")) { hold_buckets_mode = value != 0; return 0; }
         if (name && !strcmp(name, "comm_timing")) { comm_timing = value != 0; return 0; }
         if (name && !strcmp(name, "debug_poison_partials")) { poison_partials = value != 0; return 0; }
         if (name && !strcmp(name, "lazy_zero_grads")) { lazy_zero_mode = value != 0; return 0; }

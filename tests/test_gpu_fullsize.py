@@ -411,7 +411,7 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     operand and every stored 16-bit tensor rounded to the engine's format (oracle.set_operand_rounding), evaluated in chunks of 4 windows
     (every loss is a mean over windows: losses and gradients of the batch are the chunk means).  Gates = the 512-frame test's: loss 5e-4,
     emb 2e-3; the gradient tensors by _gate_gradients below: encoder tensors by their own condition (error / kappa <= a fraction of one 16-bit
-    rounding of the summands), everything else 3.5e-2 (bf16) / 2e-2 (fp16) relative L2."""
+    rounding of the summands), everything else 3e-2 (bf16) / 1.5e-2 (fp16) relative L2 (the static fc1 weight behind the spatial softmax: 4.5e-2 / 2e-2)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from golden_util import rel_l2
@@ -464,10 +464,15 @@ def _np_to_dev(mb):
 # differ they move stored 16-bit activations across rounding boundaries (the floor discussed at the 512-frame test above).
 #   the six convolutions' weights and biases: error <= kappa x G_SUMMAND, G_SUMMAND = 1e-3 (bf16: a quarter of 2^-8) / 5e-4 (fp16: one 2^-11):
 #       2x above the worst measured ratio, and never more than 0.1 absolute;
-#   every other tensor: error <= G_OTHER = 3.5e-2 (bf16; measured worst 2.8e-2: the static camera's fc1 weight behind the spatial softmax, every
-#       other one <= 1e-2) / 2e-2 (fp16; 1.1e-2, same tensor).
+#   the static camera's fc1 weight: error <= G_SS = 4.5e-2 (bf16) / 2e-2 (fp16).  Its input is the spatial softmax's expected coordinates — 128 means of
+#       x, y in [-1, 1] under a softmax over 441 activations, themselves small differences — so it carries the FORWARD error of conv3's stored 16-bit map
+#       (kappa of its own sum is 5): measured 2.8e-2 (HULC) / 3.2e-2 (mcil) / 1.4e-2 (vis + lang) bf16, 1.1e-2 fp16;
+#   every other tensor: error <= G_OTHER = 3.0e-2 (bf16; measured worst 2.3e-2: the transformer's linear1 / position table in the vis + lang + CLIP case,
+#       <= 1e-2 in the vision-only cases) / 1.5e-2 (fp16; 0.5e-2).
 G_SUMMAND = {"bf16": 1e-3, "fp16": 5e-4}
-G_OTHER = {"bf16": 3.5e-2, "fp16": 2.0e-2}
+G_SS = {"bf16": 4.5e-2, "fp16": 2.0e-2}
+G_OTHER = {"bf16": 3.0e-2, "fp16": 1.5e-2}
+SS_TENSOR = "perceptual_encoder.rgb_static_encoder.fc1.0.weight"
 
 
 def _gate_gradients(tag, Gg, G, dtype="bf16"):
@@ -490,7 +495,9 @@ def _gate_gradients(tag, Gg, G, dtype="bf16"):
           f"worst tensors without a condition sum (gate {G_OTHER[dtype]:.1e}):", [(round(e, 4), n) for e, n in other[:8]])
     bad = [(n, e, k) for e, k, n in rows if e > min(k * G_SUMMAND[dtype], 0.1)]
     assert not bad, bad
-    assert other[0][0] < G_OTHER[dtype], other[:5]
+    assert errs.get(SS_TENSOR, 0.0) < G_SS[dtype], errs.get(SS_TENSOR)
+    rest = [(e, n) for e, n in other if n != SS_TENSOR]
+    assert rest[0][0] < G_OTHER[dtype], rest[:5]
     a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
     b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
     assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999

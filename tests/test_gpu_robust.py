@@ -79,14 +79,18 @@ def test_backward_with_a_failed_persistent_launch_never_reaches_the_weights(capf
 
 
 def test_recurrences_behind_an_issued_bucket_run_per_step_and_the_timeline_is_reported():
-    """mcil: the plan encoder's BiRNN backward follows the decoder bucket.  1-rank communicator (all a 1-GPU box offers): the routing, the
-    equality of both routes and the bucket timeline are what can be checked here; tools/dp_selftest.py runs the same cases on >= 2 GPUs."""
+    """mcil: the plan encoder's BiRNN backward follows the decoder's.  Round 6 default (dp_hold_buckets 1): the decoder's and the plan proposal's
+    buckets are issued BEHIND the BiRNN backward, whose recurrences therefore stay persistent; dp_hold_buckets 0 = round 5's
+    routes: the buckets leave early and the BiRNN backward runs one launch per step (persist_under_comm 0) or persistent next to the collective
+    (persist_under_comm 1).  1-rank communicator (all a 1-GPU box offers): the routing, the equality of the three routes and the bucket timeline are
+    what can be checked here; tools/dp_selftest.py runs the same cases on >= 2 GPUs."""
     eng, mb = _setup("mcil", B=8, S=8)
     eng.comm_init(eng.comm_unique_id(), 0, 1)
     grads = {}
-    for under in (0, 1):
-        eng.set_option("persist_under_comm", under)
-        assert eng.get_option("persist_under_comm") == under
+    for under, hold in ((0, 0), (1, 0), (2, 1)):
+        eng.set_option("dp_hold_buckets", hold)
+        eng.set_option("persist_under_comm", 1 if under == 1 else 0)
+        assert eng.get_option("persist_under_comm") == (1 if under == 1 else 0)
         eng.zero_grads()
         eng.forward_loss(mb, False, 1.0, 3.0, step=0)
         eng.timers_enable(True)
@@ -103,13 +107,20 @@ def test_recurrences_behind_an_issued_bucket_run_per_step_and_the_timeline_is_re
         else:
             assert per_step == 0 and persistent >= 3, t
         tl = eng.comm_timeline()
+        if under == 2:                                             # held: both early buckets issued after the BiRNN backward, still inside the backward, in order
+            b0, b1, b2 = (next(b for b in tl["buckets"] if b["bucket"] == i) for i in (0, 1, 2))
+            assert b0["issued_at_us"] <= b1["issued_at_us"] <= b2["issued_at_us"] and b0["issued_at_us"] < 0
+            assert b0["issued_at_us"] > issued0_early, (b0, issued0_early)      # later than the early route issued it
+        elif under == 0:
+            issued0_early = next(b for b in tl["buckets"] if b["bucket"] == 0)["issued_at_us"]
         assert len(tl["buckets"]) >= 4 and tl["backward_us"] > 0
         assert all(b["done_at_us"] >= b["issued_at_us"] for b in tl["buckets"])
         assert tl["buckets"][0]["issued_at_us"] < 0                # the decoder bucket left before the backward ended
         assert sum(b["bytes"] for b in tl["buckets"]) == eng.numel * 4
         grads[under] = eng.flat_grads.clone()
-    rel = ((grads[0] - grads[1]).double().norm() / grads[1].double().norm()).item()
-    assert rel < 3e-2, rel                                         # same arithmetic, different kernels for the chains (16-bit roundings differ)
+    for a in (0, 2):
+        rel = ((grads[a] - grads[1]).double().norm() / grads[1].double().norm()).item()
+        assert rel < 3e-2, (a, rel)                                # same arithmetic, different kernels for the chains (16-bit roundings differ)
     assert eng.get_option("persistent_rnn_fallbacks") == 0
     eng.close()
 
