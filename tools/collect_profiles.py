@@ -13,7 +13,7 @@ copies = {"bench_n1.json": "bench_n1.json", "kernel_stats.csv": "kernel_stats.cs
           "step_timeline.txt": "step_timeline.txt", "rnn_persist_stamps.txt": "rnn_persist_stamps.txt",
           "storebench.txt": "storebench_write_patterns.txt", "mixbench.txt": "mixbench_conv1_traffic_shape.txt",
           "cr_bench.txt": "conv_reg_forms.txt", "cr_stamps.txt": "conv_reg_phase_stamps.txt", "vmcnt_probe.txt": "vmcnt_order_probe.txt"}
-for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d", "rehearsal"):
+for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d", "rehearsal", "u8_store", "rehearsal_mcil", "rehearsal_mcil_early"):
     copies[f"bench_n1_{k}.json"] = f"bench_n1_{k}.json"
 for src, dst in copies.items():
     if os.path.exists(os.path.join(O, src)):

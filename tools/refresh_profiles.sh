@@ -7,7 +7,7 @@
 #   4. the bench lines: N=1 default (with cpu_baseline), fp16, config-5 shapes, uint8 ingest, vis+lang, mcil variants
 #   5. the probes behind DESIGN.md's numbers: tools/bin/gridbar2 (XCD barrier + sc1 publish),
 #      tools/bin/rnn_persist_bench_st (the persistent recurrence alone: check against a CPU recurrence, us per step, phase stamps)
-T=${1:-r05}
+T=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$T
@@ -39,6 +39,9 @@ b mcil_gru --model mcil_gru
 b fp32 --dtype fp32 --steps 20                # the parity engine's throughput (v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 rate)
 MASTER_PORT=29877 b rehearsal --force-comm 1          # 1-GPU rehearsal of the N > 1 code path: allreduce.selfcheck + allreduce.timeline (issue times of the five buckets)
 b u8_h2d --ingest u8 --h2d 1                  # every step's uint8 frames copied from PINNED HOST memory (SURVEY 8(d)'s PCIe-inclusive row)
+b u8_store --ingest u8 --store 16384          # windows gathered by index from a device-resident frame store, new random windows every step (hulc_batch::window_start)
+MASTER_PORT=29878 b rehearsal_mcil --force-comm 1 --model mcil --lang 1                               # config 4 on the N > 1 code path: buckets held behind the persistent BiRNN backward
+MASTER_PORT=29879 b rehearsal_mcil_early --force-comm 1 --model mcil --lang 1 --opt dp_hold_buckets=0    # ... round 5's schedule: early buckets, BiRNN backward one launch per step
 python tools/time_conv_reg.py > $O/conv_reg_vs_tile.txt 2>/dev/null
 ABLATE=1 python tools/time_conv_reg.py 2>/dev/null | tail -12 > $O/conv_reg_ablation.txt
 test -x tools/bin/cr_bench && timeout 400 tools/bin/cr_bench ablate > $O/cr_bench.txt 2>&1          # conv_reg.h forms: slot decode in registers, pipelined epilogue, loader waves (round 5)
