@@ -551,6 +551,8 @@ class Hulc(torch.nn.Module):
         img = lambda t: t.to(device=device, non_blocking=True) if t.dtype == torch.uint8 else f(t)
         mb = dict(rgb_static=img(dataset_batch["rgb_obs"]["rgb_static"]), rgb_gripper=img(dataset_batch["rgb_obs"]["rgb_gripper"]),
                   actions=f(dataset_batch["actions"]), robot_obs=f(dataset_batch["state_info"]["robot_obs"]))
+        if dataset_batch.get("window_start") is not None:      # HBM-resident frame store (hulc_amd.utils.frame_store.FrameStore.batch): rgb_obs are the stores
+            mb["window_start"] = dataset_batch["window_start"].to(device=device, dtype=torch.int64)
         for k in ("shift_static", "shift_gripper", "pad_static", "pad_gripper"):       # optional RandomShiftsAug draws of the ingest path
             if dataset_batch.get(k) is not None:
                 mb[k] = dataset_batch[k].to(device=device) if torch.is_tensor(dataset_batch[k]) else dataset_batch[k]

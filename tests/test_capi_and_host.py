@@ -119,3 +119,33 @@ def test_bench_gpus_flag_is_checked_before_anything_runs():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_frame_store_samples_windows_inside_one_episode_and_builds_reference_batches():
+    """hulc_amd.utils.frame_store.FrameStore (host logic, CPU tensors here): every sampled window lies inside ONE episode, the batch dict has the reference's
+    keys with the stores standing in for rgb_obs, per-frame action / state tables are gathered by the same indices, materialise() returns the same frames."""
+    import numpy as np
+    import torch
+    from hulc_amd.utils.frame_store import FrameStore
+    F, S = 50, 8
+    rs = torch.arange(F, dtype=torch.uint8)[:, None, None, None].expand(F, 4, 4, 3).contiguous()      # frame f is filled with the value f
+    rg = rs[:, :2, :2].contiguous()
+    ends = [10, 13, 37, 50]                                                                        # episode 1 (3 frames) is shorter than a window
+    acts = torch.arange(F, dtype=torch.float32)[:, None].expand(F, 7).contiguous()
+    obs = torch.arange(F, dtype=torch.float32)[:, None].expand(F, 15).contiguous()
+    st = FrameStore(rs, rg, episode_ends=ends, device="cpu", actions=acts, robot_obs=obs)
+    pop = st.valid_starts(S)
+    assert pop.tolist() == list(range(0, 3)) + list(range(13, 30)) + list(range(37, 43))
+    starts = st.sample_starts(64, S, np.random.default_rng(3))
+    eid = np.searchsorted(np.asarray(ends), starts.numpy(), side="right")
+    assert np.array_equal(eid, np.searchsorted(np.asarray(ends), starts.numpy() + S - 1, side="right"))   # first and last frame in the same episode
+    b = st.batch(starts, S, shifts=True, generator=torch.Generator().manual_seed(1))
+    assert b["rgb_obs"]["rgb_static"] is st.rgb_static and b["window_start"].dtype == torch.int64 and b["actions"].shape == (64, S, 7)
+    assert torch.equal(b["actions"][:, :, 0], (starts[:, None] + torch.arange(S)[None]).float()) and torch.equal(b["state_info"]["robot_obs"][:, 0, 0], starts.float())
+    assert b["shift_static"].shape == (64 * S, 2) and int(b["shift_static"].max()) <= 20 and int(b["shift_gripper"].max()) <= 8
+    ms, mg = st.materialise(starts, S)
+    assert ms.shape == (64, S, 4, 4, 3) and torch.equal(ms[:, :, 0, 0, 0].long(), starts[:, None] + torch.arange(S)[None]) and mg.shape == (64, S, 2, 2, 3)
+    with pytest.raises(ValueError):
+        FrameStore(rs, rg, episode_ends=[10, 5, 50], device="cpu")
+    with pytest.raises(ValueError):
+        FrameStore(rs, rg, episode_ends=[3], device="cpu").valid_starts(S) if False else FrameStore(rs.float(), rg, device="cpu")

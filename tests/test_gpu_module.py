@@ -364,6 +364,38 @@ def test_uint8_frames_take_the_ingest_path():
     m.engine.close()
 
 
+def test_frame_store_batches_drive_the_module_like_materialised_uint8_batches():
+    """hulc_amd.utils.frame_store.FrameStore -> Hulc.training_step / validation_step: windows gathered by index from the device-resident store
+    (hulc_batch::window_start) give the loss, the gradients and the validation metrics of the same windows passed as materialised uint8 (B,S,H,W,3)
+    tensors — bit for bit in the fp32 engine; actions / robot_obs come from the store's per-frame tables."""
+    from hulc_amd.hulc import Hulc
+    from hulc_amd.utils.frame_store import FrameStore
+    g = torch.Generator().manual_seed(9)
+    F, Bm, Sm = 24, 3, 4
+    st = FrameStore(torch.randint(0, 256, (F, 200, 200, 3), generator=g, dtype=torch.uint8), torch.randint(0, 256, (F, 84, 84, 3), generator=g, dtype=torch.uint8),
+                    episode_ends=[9, 24], device="cuda:0", actions=torch.cat([torch.rand(F, 6, generator=g) * 2 - 1, torch.ones(F, 1)], 1), robot_obs=torch.randn(F, 15, generator=g) * 0.3)
+    starts = st.sample_starts(Bm, Sm, np.random.default_rng(2))
+    plan = torch.randint(0, 32, (Bm, 32), generator=g, dtype=torch.int32)
+    gs = torch.Generator(device="cuda:0").manual_seed(4)
+    b_store = st.batch(starts, Sm, shifts=True, generator=gs)
+    b_store["plan_idx"] = plan
+    ms, mg = st.materialise(starts, Sm)
+    b_mat = dict(b_store, rgb_obs=dict(rgb_static=ms, rgb_gripper=mg))
+    del b_mat["window_start"]
+    m = Hulc(precision="fp32", max_batch_size=Bm, max_seq_len=Sm, use_clip_auxiliary_loss=False)
+    m.eval()
+    l0 = float(m.training_step({"vis": b_mat}, 0))
+    g0 = m.engine.flat_grads.clone()
+    l1 = float(m.training_step({"vis": b_store}, 0))
+    assert l0 == l1 and torch.equal(g0, m.engine.flat_grads), (l0, l1)
+    v0 = m.validation_step({"vis": {k: v for k, v in b_mat.items() if not k.startswith("shift") and k != "plan_idx"}}, 0)
+    log0 = dict(m.logged)
+    v1 = m.validation_step({"vis": {k: v for k, v in b_store.items() if not k.startswith("shift") and k != "plan_idx"}}, 0)
+    for k in ("val_act/vis_act_loss_pp", "val_total_mae/vis_total_mae_pp"):
+        assert log0[k] == m.logged[k], (k, log0[k], m.logged[k])
+    m.engine.close()
+
+
 def test_fit_with_adamw_and_cosine_warmup_and_resume(tmp_path):
     """VERDICT r3 #9 end to end: `model/optimizer=adamw model/lr_scheduler=cosine_schedule_with_warmup` through the fit loop — the number of training
     steps is inferred from the trainer / datamodule (hulc.py:189-237), the learning rate every step equals transformers' schedule, the fused AdamW
