@@ -103,6 +103,51 @@ def test_fp32_step_matches_oracle_and_reference(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name,dtype", [("hulc_tiny", "fp32"), ("hulc_s32", "fp32"), ("hulc_s64", "fp32"), ("hulc_s32", "bf16")])
+def test_train_mode_step_matches_oracle_run_with_the_engines_dropout_masks(name, dtype):
+    """the TIMED path runs with dropout 0.1 and was pinned only statistically.  The engine's masks are counter-based (csrc/common.h
+    hash_uniform of a per-site seed, csrc/engine.h site_seed); the oracle restates that hash (hulc_oracle.engine_keep_mask) and runs the SAME train-mode step —
+    the nine dropout sites of the plan-recognition transformer, forward and backward — so train mode is held to the oracle exactly like eval mode: fp32 engine
+    loss 2e-5 and every gradient tensor 1e-3 (5e-3 for the conv sums); bf16 (fused transformer kernels) against the rounding-aware oracle, cosine > 0.995 and
+    the transformer's own tensors within 5e-2.  A wrong site index, seed or element order shows up as an O(0.3) error in the transformer's gradients."""
+    dims, P, batch, fx = load_case(name)
+    Bmax = max(mb["actions"].shape[0] for mb in batch.values())
+    S = next(iter(batch.values()))["actions"].shape[1]
+    pdrop, seed, step = 0.1, 7, 3
+    eng = _engine(dims, Bmax, S, dtype, dropout=pdrop, seed=seed)
+    eng.load_numpy(P)
+    tot, per = run_step(eng, batch, step=step)
+    Gg = grads_np(eng)
+    eng.close()
+    try:
+        O.TRAIN_DROPOUT = (pdrop, seed, step)
+        if dtype != "fp32":
+            O.set_operand_rounding(dtype)
+        losses_t, G = O.training_step(P, dims, batch)
+        O.TRAIN_DROPOUT = None
+        losses_e, _ = O.training_step(P, dims, batch, want_grads=False)
+    finally:
+        O.TRAIN_DROPOUT = None
+        O.set_operand_rounding(None)
+    assert abs(float(losses_t["total"]) - float(losses_e["total"])) > 1e-4 * abs(float(losses_e["total"]))      # the masks do something
+    errs = {n: rel_l2(Gg[n], G[n]) for n in G if np.linalg.norm(G[n]) > 1e-6}
+    tr = {n: e for n, e in errs.items() if n.startswith("plan_recognition.")}
+    if dtype == "fp32":
+        assert abs(tot - float(losses_t["total"])) <= 2e-5 * abs(float(losses_t["total"])), (tot, losses_t["total"])
+        noisy = lambda n: any(n.endswith(x) for x in FP32_NOISY)
+        worst = max((e, n) for n, e in errs.items() if not noisy(n))
+        worst_noisy = max((e, n) for n, e in errs.items() if noisy(n))
+        assert worst[0] < 1e-3, worst
+        assert worst_noisy[0] < 5e-3, worst_noisy
+    else:
+        assert abs(tot - float(losses_t["total"])) <= 2e-3 * abs(float(losses_t["total"])), (tot, losses_t["total"])
+        a = np.concatenate([Gg[n].reshape(-1) for n in G]).astype(np.float64)
+        b = np.concatenate([G[n].reshape(-1) for n in G]).astype(np.float64)
+        assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.995
+        assert max(tr.values()) < 5e-2, sorted(tr.items(), key=lambda kv: -kv[1])[:4]
+    print(f"[train mode {name} {dtype}] loss {tot:.6f} vs oracle {float(losses_t['total']):.6f} (eval {float(losses_e['total']):.6f}); transformer tensors worst {max(tr.values()):.2e}")
+
+
 def test_bf16_step_close_to_oracle():
     dims, P, batch, fx = load_case("hulc_s32")
     eng = _engine(dims, 3, 32, "bf16")
