@@ -337,7 +337,8 @@ def mlp_bwd(P, G, names, acts, d, last_relu):
 # csrc/engine.h site_seed: splitmix64 of (context seed, optimizer-step index, modality, site)).  Restated here in numpy so that the oracle can run the SAME
 # train-mode step — forward and backward — as the library: sites 0 (emb + pos), 1 + 4 l (attention weights), 2 + 4 l (after out_proj), 3 + 4 l (after the FFN
 # activation), 4 + 4 l (after linear2) of layer l; the element index is the row-major offset of the tensor the mask multiplies ((B S, 128), (B, 8, S, S), (B S, 2048)).
-TRAIN_DROPOUT = None      # None (eval mode) | (p, seed, step): modality_fwd / modality_bwd then run in train mode with the engine's masks
+TRAIN_DROPOUT = None      # None (eval mode) | (p, seed, step[, first_window]): modality_fwd / modality_bwd then run in train mode with the engine's masks;
+                          # first_window: the batch index of this call's window 0 inside the engine's batch (chunked evaluation, tests/oracle_pool.py)
 
 
 def _mix64(z):
@@ -352,10 +353,10 @@ def engine_site_seed(seed, step, is_lang, site):
         return _mix64(z)
 
 
-def engine_keep_mask(site_seed, shape, p):
-    """keep[idx] = hash_uniform(site_seed, idx) >= p for idx = row-major offsets of `shape` (fp32 arithmetic as on the device)."""
+def engine_keep_mask(site_seed, shape, p, first=0):
+    """keep[idx] = hash_uniform(site_seed, idx) >= p for idx = first + row-major offsets of `shape` (fp32 arithmetic as on the device)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(int(np.prod(shape)), dtype=np.uint64)
+        idx = np.arange(int(np.prod(shape)), dtype=np.uint64) + np.uint64(first)
         z = _mix64(np.uint64(site_seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
     h = (z >> np.uint64(32)).astype(np.uint32)
     u = ((h >> np.uint32(8)).astype(F32) + F32(0.5)) * F32(1.0 / 16777216.0)
@@ -1215,8 +1216,9 @@ def modality_fwd(P, dims, mb, is_lang):
         return dict(kl=kl, action=act, total=F32(act + kl), clip=F32(0)), c
     drop = None
     if TRAIN_DROPOUT is not None and TRAIN_DROPOUT[0] > 0:
-        pdrop, dseed, dstep = TRAIN_DROPOUT
-        drop = (pdrop, lambda site, shape: engine_keep_mask(engine_site_seed(dseed, dstep, is_lang, site), shape, pdrop))
+        pdrop, dseed, dstep = TRAIN_DROPOUT[:3]
+        b0 = TRAIN_DROPOUT[3] if len(TRAIN_DROPOUT) > 3 else 0           # every masked tensor has the window index as its slowest dimension
+        drop = (pdrop, lambda site, shape: engine_keep_mask(engine_site_seed(dseed, dstep, is_lang, site), shape, pdrop, first=b0 * (int(np.prod(shape)) // B)))
     pr_logits, seq_feat, c["pr"] = plan_recognition_fwd(P, emb, dims.heads, drop=drop)
     c["pr_logits"], c["seq_feat"] = pr_logits, seq_feat
     out = {}

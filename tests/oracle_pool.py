@@ -85,6 +85,8 @@ def _work(args):
     O.CONDITION_SUMS = bool(case.get("cond", False))        # + G["abs/..."]: the conv gradients' condition sums (hulc_oracle._cond)
     G, sums, embs = {}, dict(kl=0.0, action=0.0, total=0.0, clip=0.0), {}
     for c in chunks:
+        if case.get("dropout"):                                  # (p, seed, step): TRAIN mode with the engine's masks of windows [c CH, (c + 1) CH)
+            O.TRAIN_DROPOUT = tuple(case["dropout"]) + (c * CH,)
         chunk = {k: np.ascontiguousarray(v[c * CH:(c + 1) * CH]) for k, v in mb.items()}
         o, cache = O.modality_fwd(P, dims_run, chunk, is_lang)
         for k in sums:
@@ -155,9 +157,9 @@ def oracle_case(case, CH=4, workers=None, P=None, batch=None):
     return {n: np.asarray(v, np.float32) for n, v in G.items()}, losses, emb_out
 
 
-def oracle_batch(seed, kind, max_window, Bt, St, CH=4, mode=None, gscale=1.0, workers=None, P=None, mb=None, cond=False):
+def oracle_batch(seed, kind, max_window, Bt, St, CH=4, mode=None, gscale=1.0, workers=None, P=None, mb=None, cond=False, dropout=None):
     """(gradients, total loss, emb) of the vision-only batch `synthetic.make_batch(Bt, 0, St, seed=seed, edge_frac=0.05, aux_mask='all')` under
     `spec.init_all(dims, seed=seed, ln_jitter=True)`, evaluated by the numpy oracle in chunks of CH windows."""
-    G, losses, embs = oracle_case(dict(seed=seed, kind=kind, max_window=max_window, B=Bt, S=St, mode=mode, gscale=gscale, cond=cond), CH, workers,
+    G, losses, embs = oracle_case(dict(seed=seed, kind=kind, max_window=max_window, B=Bt, S=St, mode=mode, gscale=gscale, cond=cond, dropout=dropout), CH, workers,
                                   P=P, batch=None if mb is None else {"vis": mb})
     return G, losses["vis"]["total"], embs["vis"]

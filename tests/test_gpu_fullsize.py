@@ -403,8 +403,8 @@ def test_weight_gradient_slabs_are_written_before_they_are_summed(dtype, Bb, Ss)
     eng.close()
 
 
-@pytest.mark.parametrize("Bt,St,dtype", [(64, 32, "bf16"), (32, 64, "fp16")])
-def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
+@pytest.mark.parametrize("Bt,St,dtype,pdrop", [(64, 32, "bf16", 0.0), (32, 64, "fp16", 0.0), (64, 32, "bf16", 0.1)])
+def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype, pdrop):
     """the EXACT shapes the bench lines are quoted on — BASELINE config 2 (B = 64, S = 32, bf16: 2048 frames, 8 windows per XCD in
     the persistent recurrences, 8 frames per conv workgroup) and config 5 (B = 32, S = 64, fp16 + loss scaling, 64-row position table, the
     four-wave attention kernels) — against the ORACLE, not against the sibling engine: the numpy restatement with every GEMM / convolution
@@ -421,7 +421,9 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     P = spec.init_all(dims, seed=23, ln_jitter=True)
     mb = synthetic.make_batch(Bt, 0, St, seed=23, edge_frac=0.05, aux_mask="all")["vis"]
     gscale = 8192.0 if dtype == "fp16" else 1.0
-    eng = StepEngine(dims, Bt, St, dtype=dtype, device="cuda:0", dropout_p=0.0, seed=3)
+    # pdrop = 0.1: TRAIN mode, exactly what bench.py times (round 6) — the oracle runs with the engine's own counter-based dropout
+    # masks (hulc_oracle.TRAIN_DROPOUT: seed 3, step 0), chunk by chunk
+    eng = StepEngine(dims, Bt, St, dtype=dtype, device="cuda:0", dropout_p=pdrop, seed=3)
     if dtype == "fp16":
         eng.scaler_enable(init_scale=gscale)
     eng.load_numpy(P)
@@ -436,11 +438,11 @@ def test_benchmark_shapes_against_the_rounding_aware_oracle(Bt, St, dtype):
     # the oracle runs in spawned worker processes (tests/oracle_pool.py: the same seeded parameters and batch, chunks of 4 windows spread over the
     # host's cores) — sequentially the 16 chunks take ~4 minutes on 8 cores
     from oracle_pool import oracle_batch
-    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb, cond=True)
+    G, loss, emb_q = oracle_batch(23, "hulc", max(32, St), Bt, St, CH, dtype, gscale, P=P, mb=mb, cond=True, dropout=(pdrop, 3, 0) if pdrop > 0 else None)
     assert abs(l["total_mod"] - loss) <= 5e-4 * abs(loss), (l, loss)
     assert rel_l2(emb, emb_q) < 2e-3, rel_l2(emb, emb_q)
     print(f"[B={Bt} S={St} {dtype}] vs rounding-aware oracle: loss {abs(l['total_mod'] - loss) / abs(loss):.1e}, emb {rel_l2(emb, emb_q):.1e}")
-    _gate_gradients(f"B={Bt} S={St} {dtype}", Gg, G, dtype)
+    _gate_gradients(f"B={Bt} S={St} {dtype}" + (f" TRAIN mode, dropout {pdrop}" if pdrop > 0 else ""), Gg, G, dtype)
 
 
 def _np_to_dev(mb):
