@@ -970,6 +970,14 @@ __global__ void __launch_bounds__(256, 2) conv1_wgrad_tr_kernel(Conv1Src X, int*
     }
 }
 
+// phase ablation of the two v2 kernels below, compiled in only by tools/conv1_wgrad_probe.hip (-DHULC_W1_PROBE): bit 0 = no multiply loop, bit 1 = no prefetch of the next band,
+// bit 2 = no margin fill, bit 3 = no raw -> 16-bit conversion (the last two: uint8 kernel)
+#ifdef HULC_W1_PROBE
+__device__ int g_w1_probe = 0;
+#define W1_PROBE_SKIP(b) ((g_w1_probe & (b)) != 0)
+#else
+#define W1_PROBE_SKIP(b) false
+#endif
 // ---------------------------------------------------------------------------------------------------------------------
 // v2 of the kernel above for the fp32 NCHW boundary (the headline configuration): 8 waves, 2 workgroups per CU, and the NEXT band's
 // frames + dY rows prefetched into registers while the current band multiplies.
@@ -1080,7 +1088,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
             ++fiter;
         }
         item = frame * nbands + band;
-        if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
+        if (frame < Nf && !W1_PROBE_SKIP(2)) prefetch(item);      // in flight during the MFMAs below
         const int units = R * U;
         // run u = u0 + g -> (row ur, run uo of the row) advanced by adds (8 runs per step): a runtime division per step stood next to 6 MFMAs
         int joff[3];                                   // per n-tile: (channel, kernel row) of this lane's B rows + its column half
@@ -1090,7 +1098,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2_kernel(const float* __
         int ur, uo;
         { const int u = uh * 4 + g; ur = u / U; uo = u - ur * U; }
 #pragma unroll 1
-        for (int u0 = uh * 4; u0 < units; u0 += 8) {
+        for (int u0 = W1_PROBE_SKIP(1) ? units : uh * 4; u0 < units; u0 += 8) {
             const int u = u0 + g;
             const bool valid = u < units;
             const int r = valid ? ur : 0, ow0 = valid ? uo * 8 : 0;
@@ -1246,7 +1254,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
                 c4 += xdr; r += xdq; if (c4 >= n4) { c4 -= n4; ++r; }
             }
         }
-        if (tid < 2 * XR) {
+        if (tid < 2 * XR && !W1_PROBE_SKIP(4)) {
             const int rr = tid >> 1, side = tid & 1;
             const unsigned pxl = side ? (pe >> 8) : (pe & 0xffffffu);
             lds_char* dst = raw + rr * RP + (side ? LM + RB : 0);
@@ -1266,7 +1274,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
         __syncthreads();                                          // raw rows complete
         {
             const float sc = S.fold ? 1.f : 2.f / 255.f, of = S.fold ? 0.f : -1.f;
-            for (int e = tid; e < XR * W4; e += 512) {
+            for (int e = W1_PROBE_SKIP(8) ? XR * W4 : tid; e < XR * W4; e += 512) {
                 const int r = e / W4, c = e - r * W4;
                 u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
                 if (r < cxr) {                                    // rows below the frame stay zero
@@ -1292,7 +1300,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
             ++fiter;
         }
         item = frame * nbands + band;
-        if (frame < Nf) prefetch(item);                           // in flight during the MFMAs below
+        if (frame < Nf && !W1_PROBE_SKIP(2)) prefetch(item);      // in flight during the MFMAs below
         const int units = R * U;
         // run u = u0 + g -> (row ur, run uo of the row) advanced by adds (8 runs per step): a runtime division per step stood next to 6 MFMAs
         int joff[3];                                   // per n-tile: (channel, kernel row) of this lane's B rows + its column half
@@ -1302,7 +1310,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
         int ur, uo;
         { const int u = uh * 4 + g; ur = u / U; uo = u - ur * U; }
 #pragma unroll 1
-        for (int u0 = uh * 4; u0 < units; u0 += 8) {
+        for (int u0 = W1_PROBE_SKIP(1) ? units : uh * 4; u0 < units; u0 += 8) {
             const int u = u0 + g;
             const bool valid = u < units;
             const int r = valid ? ur : 0, ow0 = valid ? uo * 8 : 0;

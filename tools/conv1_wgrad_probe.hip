@@ -1,0 +1,53 @@
+// tools only (round 6): where does conv1's weight gradient spend its time?  The fp32-boundary kernel (conv1_wgrad_tr2_kernel, 263 us in the step for 983 MB of frames
+// + 315 MB of dY) and the uint8 one (conv1_wgrad_tr2u_kernel: 246 MB of frames) take about the SAME time — so the 4 x smaller input buys nothing and the bound must be
+// a phase they share.  Phase ablation on 2048 static-camera frames: full | no multiply loop | no prefetch of the next band | neither.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DHULC_W1_PROBE tools/conv1_wgrad_probe.hip -o tools/bin/conv1_wgrad_probe && tools/bin/conv1_wgrad_probe
+#include <cstdio>
+#include <cstdlib>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../hulc_amd/csrc/conv_wgrad.h"
+void hulc_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+using namespace hulc_bf16;
+int main() {
+    for (int cam = 0; cam < 2; ++cam) {
+        const int Nf = 2048, IH = cam ? 84 : 200, OH = (IH - 8) / 4 + 1;
+        float* x32; unsigned char* x8; h16_t* dy; float *part, *bias;
+        const size_t nx = (size_t)Nf * 3 * IH * IH, ny = (size_t)Nf * OH * OH * 32;
+        hipMalloc(&x32, nx * 4); hipMalloc(&x8, nx); hipMalloc(&dy, ny * 2); hipMalloc(&part, sizeof(float) * 512ll * 32 * 192); hipMalloc(&bias, sizeof(float) * 512 * 64);
+        {   std::vector<float> h(nx); unsigned s = 1; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 9) - (1 << 22)) * (1.f / (1 << 22)); }
+            hipMemcpy(x32, h.data(), nx * 4, hipMemcpyHostToDevice);
+            std::vector<unsigned char> b(nx); for (auto& v : b) { s = s * 1664525u + 1013904223u; v = (unsigned char)(s >> 24); }
+            hipMemcpy(x8, b.data(), nx, hipMemcpyHostToDevice);
+            std::vector<h16_t> g(ny); for (auto& v : g) { s = s * 1664525u + 1013904223u; const float f = ((int)(s >> 9) - (1 << 22)) * (0.01f / (1 << 22)); unsigned u; memcpy(&u, &f, 4); v = (h16_t)((u + 0x8000u) >> 16); }
+            hipMemcpy(dy, g.data(), ny * 2, hipMemcpyHostToDevice); }
+        int* ctr; hipMalloc(&ctr, 256);
+        int* shifts; hipMalloc(&shifts, Nf * 2 * sizeof(int));
+        {   std::vector<int> h(Nf * 2); unsigned s2 = 7; const int pad = cam ? 4 : 10; for (auto& v : h) { s2 = s2 * 1664525u + 1013904223u; v = (int)((s2 >> 8) % (2 * pad + 1)); }
+            hipMemcpy(shifts, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice); }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int u8 = 0; u8 < 2; ++u8) {
+            Conv1Src src{}; src.X = u8 ? (const void*)x8 : (const void*)x32; src.u8 = u8; src.fold = u8;
+            if (u8) { src.shift = shifts; src.pad = cam ? 4 : 10; }      // RandomShiftsAug draws as in bench.py --ingest u8
+            float t[16];
+            for (int d = 0; d < 16; ++d) t[d] = 1e30f;
+            for (int round = 0; round < 4; ++round)               // alternating rounds, minimum per arm: one arm's 10 launches in a row pick up the box's drift
+            for (int dbg : {0, 1, 2, 3, 4, 8, 12, 15}) {
+                hipMemcpyToSymbol(HIP_SYMBOL(g_w1_probe), &dbg, sizeof(int));
+                auto launch = [&]() { hipMemsetAsync(ctr, 0, 256, 0); launch_conv1_wgrad_tr(0, src, dy, part, bias, Nf, IH, IH, OH, OH, 512, ctr); };
+                for (int i = 0; i < 2; ++i) launch();
+                hipDeviceSynchronize(); hipEventRecord(e0);
+                for (int i = 0; i < 8; ++i) launch();
+                hipEventRecord(e1); hipDeviceSynchronize();
+                float ms; hipEventElapsedTime(&ms, e0, e1); t[dbg] = std::min(t[dbg], ms * 125.f);
+            }
+            const double mb = (double)Nf * (3.0 * IH * IH * (u8 ? 1 : 4) + OH * OH * 32 * 2.0) / 1e6;
+            printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 ? "u8" : "fp32", t[0], mb / t[0], mb, t[1], t[2], t[3]);
+            if (u8) printf("  | no-margin-fill %6.1f  no-conversion %6.1f  neither of those %6.1f  nothing at all (raw commit + dY staging + barriers) %6.1f", t[4], t[8], t[12], t[15]);
+            printf("\n");
+        }
+    }
+    return 0;
+}
