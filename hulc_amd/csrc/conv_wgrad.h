@@ -1371,9 +1371,225 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the uint8 kernel above with the conversion done FROM THE PREFETCH REGISTERS (tools/conv1_wgrad_probe.hip: commit + conversion were 119 of its 251 us — raw
+// rows into LDS, margins, a barrier, a second pass that reads them back — and the 4 x smaller frames bought nothing over the fp32 boundary's 261 us).  A prefetch slot is
+// the aligned 16-byte window around a 4-pixel group's 12 bytes (one dwordx4 load; 33 % more bytes requested, the overlaps hit in L2); the column shift and the replicate
+// pad are resolved per pixel from the window at the commit.  One barrier per band less, no raw rows in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PFX, int PFY>
+__global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, int* __restrict__ work_ctr, const h16_t* __restrict__ dY, float* __restrict__ part,
+                                                                  float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands) {
+    using C = Wgrad1Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int OWp = (OW + 7) & ~7, U = OWp >> 3;
+    const int XR = (R - 1) * C::S + C::KH;
+    const int XRS = IW * 2 + 16;
+    const int xbytes = C::C * XR * XRS + 512;
+    const int dypix = R * OWp + 8;
+    lds_char* ximg = (lds_char*)smem;
+    lds_char* dyimg = ximg + xbytes;
+    for (int i = tid * 16; i < xbytes + dypix * C::DYS; i += 512 * 16) *(lds_u32x4*)((lds_char*)smem + i) = u32x4_t{0u, 0u, 0u, 0u};
+    const int W4 = IW >> 2;
+    const int RB = IW * 3, n4 = RB >> 2;                          // bytes / 4-byte chunks per source row
+    const int nx = XR * W4, ny = R * OW * 4;                       // 4-pixel groups of a band (one 16-byte slot each), dY channel quarters
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(S.X);
+    // raw slot k of this thread = chunk tid + 512 k of the [XR][n4] grid: (row, chunk) advanced incrementally from slot 0's — twelve
+    // descriptor registers next to twelve slots of in-flight data spilled 17 registers at the 128-VGPR budget and serialised the prefetch
+    // ... and the compiler hoists whatever is band-invariant out of the band loop and spills it just the same (a scratch reload in front of
+    // every prefetch load waits for the loads issued before it): slot 0's (row, chunk) is recomputed per band behind an opaque copy of tid
+    const int xdq = 512 / W4, xdr = 512 - xdq * W4;                // slot k of this thread = group tid + 512 k of the [XR][W4] grid, advanced by adds
+    int yd[PFY];
+#pragma unroll
+    for (int k = 0; k < PFY; ++k) {
+        const int e = min(tid + k * 512, ny - 1);
+        const int r = e / (OW * 4), i = e - r * (OW * 4);
+        yd[k] = (r << 16) | i;
+    }
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, a = lane & 15;
+    const int prow = a >> 2, q = a & 3;
+    const int ccolA = q * 8;
+    const int nt0 = (wave & 3) * 3, uh = wave >> 2;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4_t px[PFX];                                              // slot = the aligned 16-byte window that holds a group's 12 bytes
+    u32x4_t py[PFY];
+    int xrows = 0, yrows = 0, pdx = 0;
+    auto prefetch = [&](int item) {
+        const int f = item / nbands, oh0 = (item % nbands) * R;
+        const int ih0 = oh0 * C::S;
+        xrows = min(XR, IH - ih0); yrows = min(R, OH - oh0);
+        int dy = 0;
+        pdx = 0;
+        if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
+        const unsigned char* fb = Xb + S.frame(f) * IH * RB;
+        const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
+        {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            int r = t / W4, c = t - r * W4;
+#pragma unroll
+            for (int k = 0; k < PFX; ++k) {
+                const int rr = min(r, min(XR, xrows) - 1);            // slots past the band / rows below the frame: a valid row (dropped / zeroed at the commit)
+                const int qp = min(max(c * 4 + pdx, 0), IW - 4);      // first of the four source pixels the window holds (replicate pad: clamped into the row)
+                const int a0 = min((qp * 3) & ~3, RB - 16);           // 4-byte aligned, and the 16 bytes stay inside the row (the frame buffer's last row included)
+                px[k] = *reinterpret_cast<const u32x4_t*>(fb + (long long)min(max(ih0 + rr + dy, 0), IH - 1) * RB + a0);
+                c += xdr; r += xdq; if (c >= W4) { c -= W4; ++r; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k) {
+            const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+            py[k] = *reinterpret_cast<const u32x4_t*>(yb + (min(r, yrows - 1) * OW) * C::CO + i * 8);
+        }
+    };
+    __shared__ int s_next[2];
+    int frame = blockIdx.x, fiter = 0, band = 0;
+    int item = frame * nbands;
+    if (frame < Nf) prefetch(item);
+    while (frame < Nf) {
+        if (band == 0 && work_ctr && tid == 0) s_next[fiter & 1] = (int)gridDim.x + atomicAdd(work_ctr, 1);
+        __syncthreads();                                          // previous band consumed (first pass: zero fill visible)
+        const int cxr = xrows, cyr = yrows, dx = pdx;
+        if (!W1_PROBE_SKIP(8)) {
+            // the band's 4-pixel groups straight from the prefetch registers into the 16-bit [c][row][iw] image (no raw rows in LDS, no margin fill, no barrier
+            // between a raw commit and a conversion pass): window -> the 12 bytes of pixels qp .. qp + 3 -> for output pixel k of the group the source pixel
+            // clamp(c 4 + k + dx) - qp (= k everywhere but at the row ends, where RandomShiftsAug's replicate pad repeats the edge pixel)
+            auto commit_x = [&](auto FOLD_) __attribute__((always_inline)) {      // the folded path (production) converts the byte as it is: no multiply-add
+            constexpr bool FOLD = decltype(FOLD_)::value;
+            const float sc = 2.f / 255.f, of = -1.f;
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            int r = t / W4, c = t - r * W4;
+#pragma unroll
+            for (int k = 0; k < PFX; ++k) {
+                if (t + k * 512 < nx) {
+                    u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
+                    if (r < cxr) {                                // rows below the frame stay zero
+                        const int p0 = c * 4 + dx, qp = min(max(p0, 0), IW - 4);
+                        const int a0 = min((qp * 3) & ~3, RB - 16), sh = qp * 3 - a0;      // 0 .. 4
+                        const bool s4 = sh == 4;
+                        const unsigned w0 = s4 ? px[k][1] : px[k][0], w1 = s4 ? px[k][2] : px[k][1], w2 = s4 ? px[k][3] : px[k][2], w3 = px[k][3];
+                        const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh & 3), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh & 3), d2 = __builtin_amdgcn_alignbyte(w3, w2, sh & 3);
+                        // the four source pixels as 24-bit words
+                        const unsigned P[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};
+                        float v[12];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int si = min(max(p0 + kk, 0), IW - 1) - qp;       // 0 .. 3
+                            const unsigned pw = si == 0 ? P[0] : (si == 1 ? P[1] : (si == 2 ? P[2] : P[3]));
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) { const float x = (float)((pw >> (8 * ch)) & 0xffu); v[kk * 3 + ch] = FOLD ? x : fmaf(x, sc, of); }
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = pack2h(v[ch], v[3 + ch]); ov[ch][1] = pack2h(v[6 + ch], v[9 + ch]); }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + r) * XRS + c * 8) = ov[ch];
+                }
+                c += xdr; r += xdq; if (c >= W4) { c -= W4; ++r; }
+            }
+            };
+            if (S.fold) commit_x(std::true_type{}); else commit_x(std::false_type{});
+        }
+#pragma unroll
+        for (int k = 0; k < PFY; ++k)
+            if (tid + k * 512 < ny) {
+                const int r = yd[k] >> 16, i = yd[k] & 0xffff;
+                const u32x4_t v = r < cyr ? py[k] : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += h2f_lo(v[e]); bsum[2 * e + 1] += h2f_hi(v[e]); }
+                *(lds_u32x4*)(dyimg + (r * OWp + (i >> 2)) * C::DYS + (i & 3) * 16) = v;
+            }
+        __syncthreads();
+        if (++band == nbands) {
+            band = 0;
+            frame = work_ctr ? s_next[fiter & 1] : frame + (int)gridDim.x;
+            ++fiter;
+        }
+        item = frame * nbands + band;
+        if (frame < Nf && !W1_PROBE_SKIP(2)) prefetch(item);      // in flight during the MFMAs below
+        const int units = R * U;
+        // run u = u0 + g -> (row ur, run uo of the row) advanced by adds (8 runs per step): a runtime division per step stood next to 6 MFMAs
+        int joff[3];                                   // per n-tile: (channel, kernel row) of this lane's B rows + its column half
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int nt = nt0 + j; joff[j] = ((nt >> 2) * XR + (nt & 3) * 2 + (q >> 1)) * XRS + (q & 1) * 8; }
+        const int q8 = 8 / U, r8 = 8 - q8 * U;
+        int ur, uo;
+        { const int u = uh * 4 + g; ur = u / U; uo = u - ur * U; }
+#pragma unroll 1
+        for (int u0 = W1_PROBE_SKIP(1) ? units : uh * 4; u0 < units; u0 += 8) {
+            const int u = u0 + g;
+            const bool valid = u < units;
+            const int r = valid ? ur : 0, ow0 = valid ? uo * 8 : 0;
+            ur += q8; uo += r8;
+            if (uo >= U) { uo -= U; ++ur; }
+            const int pixA = valid ? r * OWp + ow0 : R * OWp;
+            lds_char* abase = dyimg + (pixA + prow) * C::DYS + ccolA;
+            h16x8_t af[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) af[c] = tr_read8(abase + c * 32, abase + 4 * C::DYS + c * 32);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                lds_char* bbase = ximg + joff[j] + (r * C::S) * XRS + (ow0 + prow) * C::S * 2;
+                const h16x8_t bf = tr_read8(bbase, bbase + 4 * C::S * 2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[j][c] = MFMA_16x16x32_H(af[c], bf, acc[j][c], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the bias partial of this workgroup first (Conv1Src::fold needs it for the slab), then the two unit halves (waves w and w + 4) are summed
+    // through LDS and one slab per workgroup is written
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);
+    float* dbw = redf + 6144;                                    // [CO]: this workgroup's bias-gradient partial (24 KB in: behind redf's 16 KB and red's 24 KB)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) redf[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < C::CO) {
+        const int cgrp = tid >> 3, e = tid & 7;
+        float sacc = 0.f;
+        for (int t = cgrp; t < 512; t += 4) sacc += redf[t * 8 + e];
+        unsafeAtomicAdd(bias_part + tid, sacc);
+        dbw[tid] = sacc;
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (uh == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) red[((wave & 3) * 6 + j * 2 + c) * 64 + lane] = acc[j][c];
+    }
+    __syncthreads();
+    if (uh == 0) {
+        float* out = part + (long long)blockIdx.x * C::CO * 192;
+        const float fsc = S.fold ? CONV1_FOLD_SCALE : 1.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 v = acc[j][c] + red[((wave & 3) * 6 + j * 2 + c) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = c * 16 + g * 4 + r;
+                    out[(long long)co * 192 + (nt0 + j) * 16 + a] = S.fold ? fmaf(v[r], fsc, -dbw[co]) : v[r];      // dW = (2/255) (dY * u) - db (x) 1
+                }
+            }
+    }
+}
+
+inline int g_conv1_wgrad_u8reg = -1;      // tools/conv1_wgrad_probe.hip only: 0 / 1 force the uint8 kernel form (-1: the build's own)
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
     static const int v2 = HULC_SWITCH("HULC_W1_V2", 1);
+    static const int u8reg_sw = HULC_SWITCH("HULC_W1_U8REG", 1);      // uint8: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel); 0 = round 5's raw rows through LDS
     if (v2 && !X.u8 && (IW % 4) == 0) {
         // tallest band whose images fit 2 workgroups per CU and whose chunks fit the prefetch slots (8 frame + 2 dY registers of 16 B per thread:
         // 10 + 3 slots spilled 46 registers of in-flight data at the 128-VGPR budget of 2 x 8 waves per CU, which serialised the prefetch)
@@ -1391,6 +1607,25 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
             if (!attr2) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2_kernel<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2 = true; }
             const int grid = std::min(std::min(Nf, 512), max_blocks);
             hipLaunchKernelGGL((conv1_wgrad_tr2_kernel<6, 2>), dim3(grid), dim3(512), lds, st, reinterpret_cast<const float*>(X.X), work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
+            return grid;
+        }
+    }
+    if (v2 && X.u8 && (IW % 4) == 0 && IW >= 8 && (g_conv1_wgrad_u8reg < 0 ? u8reg_sw : g_conv1_wgrad_u8reg)) {
+        // uint8 boundary, round 6: 4 window slots of 16 bytes + 2 dY slots per thread, converted from the registers (conv1_wgrad_tr2r_kernel); no raw rows in LDS
+        int R = OH;
+        auto fits = [&](int r) {
+            const int XR = (r - 1) * Wgrad1Cfg::S + Wgrad1Cfg::KH;
+            return Wgrad1Cfg::lds_bytes(r, IW, OW, false) <= (size_t)79 * 1024 && (long long)XR * (IW / 4) <= 4 * 512 && (long long)r * OW * 4 <= 2 * 512 && r < 128;
+        };
+        while (R > 1 && !fits(R)) --R;
+        if (fits(R)) {
+            const int nb = (OH + R - 1) / R;
+            R = (OH + nb - 1) / nb;
+            const size_t lds = std::max<size_t>(Wgrad1Cfg::lds_bytes(R, IW, OW, false), 32 * 1024);      // (>= the epilogue's reduction areas: 24.6 KB)
+            static bool attr2r = false;
+            if (!attr2r) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2r_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2r = true; }
+            const int grid = std::min(std::min(Nf, 512), max_blocks);
+            hipLaunchKernelGGL((conv1_wgrad_tr2r_kernel<4, 2>), dim3(grid), dim3(512), lds, st, X, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
             return grid;
         }
     }

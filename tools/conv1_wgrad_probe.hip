@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 #include "../hulc_amd/csrc/conv_wgrad.h"
 void hulc_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 using namespace hulc_bf16;
@@ -28,8 +29,9 @@ int main() {
         {   std::vector<int> h(Nf * 2); unsigned s2 = 7; const int pad = cam ? 4 : 10; for (auto& v : h) { s2 = s2 * 1664525u + 1013904223u; v = (int)((s2 >> 8) % (2 * pad + 1)); }
             hipMemcpy(shifts, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice); }
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int u8 = 0; u8 < 2; ++u8) {
-            Conv1Src src{}; src.X = u8 ? (const void*)x8 : (const void*)x32; src.u8 = u8; src.fold = u8;
+        for (int u8 = 0; u8 < 3; ++u8) {                          // 0: fp32 boundary, 1: uint8 with raw rows through LDS (round 5), 2: uint8 converted from the prefetch registers (round 6)
+            g_conv1_wgrad_u8reg = u8 == 2;
+            Conv1Src src{}; src.X = u8 ? (const void*)x8 : (const void*)x32; src.u8 = u8 != 0; src.fold = u8 != 0;
             if (u8) { src.shift = shifts; src.pad = cam ? 4 : 10; }      // RandomShiftsAug draws as in bench.py --ingest u8
             float t[16];
             for (int d = 0; d < 16; ++d) t[d] = 1e30f;
@@ -43,9 +45,19 @@ int main() {
                 hipEventRecord(e1); hipDeviceSynchronize();
                 float ms; hipEventElapsedTime(&ms, e0, e1); t[dbg] = std::min(t[dbg], ms * 125.f);
             }
+            if (u8) {                                             // the two uint8 forms must produce the same slabs (same products, same order): compare after a full launch
+                int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_w1_probe), &z, sizeof(int));
+                hipMemsetAsync(ctr, 0, 256, 0); hipMemsetAsync(bias, 0, sizeof(float) * 512 * 64, 0);
+                const int grid = launch_conv1_wgrad_tr(0, src, dy, part, bias, Nf, IH, IH, OH, OH, 512, nullptr);      // static frame order: slabs comparable
+                std::vector<float> h((size_t)grid * 32 * 192); hipMemcpy(h.data(), part, h.size() * 4, hipMemcpyDeviceToHost);
+                static std::vector<float> ref;
+                if (u8 == 1) ref = h;
+                else { double dmax = 0, n = 0; for (size_t i = 0; i < h.size(); ++i) { dmax = std::max(dmax, (double)fabsf(h[i] - ref[i])); n = std::max(n, (double)fabsf(ref[i])); }
+                       printf("         u8reg vs u8 slabs: max |diff| %.3g (max |value| %.3g, %d slabs)\n", dmax, n, grid); }
+            }
             const double mb = (double)Nf * (3.0 * IH * IH * (u8 ? 1 : 4) + OH * OH * 32 * 2.0) / 1e6;
-            printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 ? "u8" : "fp32", t[0], mb / t[0], mb, t[1], t[2], t[3]);
-            if (u8) printf("  | no-margin-fill %6.1f  no-conversion %6.1f  neither of those %6.1f  nothing at all (raw commit + dY staging + barriers) %6.1f", t[4], t[8], t[12], t[15]);
+            printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 == 0 ? "fp32" : (u8 == 1 ? "u8" : "u8reg"), t[0], mb / t[0], mb, t[1], t[2], t[3]);
+            if (u8 == 1) printf("  | no-margin-fill %6.1f  no-conversion %6.1f  neither of those %6.1f  nothing at all (raw commit + dY staging + barriers) %6.1f", t[4], t[8], t[12], t[15]);
             printf("\n");
         }
     }
