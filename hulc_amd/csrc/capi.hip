@@ -310,7 +310,7 @@ int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* 
                      int32_t OUTH, int32_t relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvTileP p{}; p.img = (const h16_t*)img; p.IMH = p.IMW = IMH; p.w = (const h16_t*)w; p.out = (h16_t*)out; p.OUTH = p.OUTW = OUTH;
-    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & (30 | 64 | 128); p.Nf = Nf;
+    p.bias = bias; p.mask = (const h16_t*)mask; p.relu = relu & 1; p.dbg = relu & (30 | 64 | 128 | 256); p.Nf = Nf;
     // modes 7..9 = the production forms: 7 = mode 1 that also EMITS the ReLU bitmask of its output into `mask` (unsigned[Nf][OUTH][OUTW][2]);
     // 8 / 9 = modes 2 / 3 with `mask` = ReLU bitmask words (2 / 1 per output pixel) staged through LDS.  relu bit 5 (32): dynamic work claiming.
     if (mode == 7) { p.mask = nullptr; p.bits_out = (unsigned*)mask; mode = 1; }

@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
         const int ih0 = oh0 * 4;
         const int rows = min(XR, IH - ih0);
         __syncthreads();
-        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);
+        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64, (dbg & 256) != 0);      // dbg bit 8: uint8 converted from registers (no raw rows)
         __syncthreads();
         conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li, (X.u8 && X.fold) ? CONV1_FOLD_SCALE : 1.f);
     }
@@ -674,7 +674,13 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
         const int f = item / nbands, b = item % nbands;
         const int oh0 = b * R;
         const int rows = prows, dx = pdx;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this band's raw rows (and edge pixels) have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this band's raw rows (and edge pixels) have landed — THIS wave's share of them
+        // Round 6 fix: a row's last data slot carries 8 bytes of the FOLLOWING row, and those land on the first 8 bytes of the row's RIGHT margin.  The margins were
+        // filled right here, behind this wave's own vmcnt(0) only: a slower wave's DMA piece could land AFTER the fill and put the neighbour row's bytes back into the
+        // margin — with a positive column shift ~2.5e-5 of a launch's outputs (the three rightmost output columns of some rows) came out wrong by O(0.1), differently
+        // from run to run (tools/time_conv1_u8reg.py found it: two runs of this kernel disagreed with each other; torch agrees with neither before the fix).
+        // Every wave's pieces must have landed before a margin is written: one more barrier, only for frames that read the margins.
+        if (dx != 0) __syncthreads();
         if (dx != 0 && tid < 2 * rows) {                          // replicate margins (F.pad(..., "replicate"))
             const int rr = tid >> 1, side = tid & 1;
             const unsigned px = side ? (pe >> 8) : (pe & 0xffffffu);
@@ -713,7 +719,11 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
                                     unsigned* maskbits = nullptr, float* zero8a = nullptr, float* zero8b = nullptr) {
     // (tried: an 8-wave, 2-workgroups-per-CU version with the next band prefetched in registers like conv1_wgrad_tr2_kernel — 4.355 vs 4.341
     //  ms/step on one box: with 4 resident workgroups per CU the staging of one already overlaps the MFMAs of the others; not kept)
-    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + (X.u8 ? (size_t)XR * conv1_raw_pitch16(IW) + 16 : 0); };   // + raw uint8 rows
+    // uint8, round 6: HULC_C1_U8REG (or dbg bit 8) = the register-staged kernel with the conversion from 16-byte windows (conv1_stage_band regconv: no raw rows in LDS)
+    static const int u8reg = HULC_SWITCH("HULC_C1_U8REG", 0);
+    const bool regconv = X.u8 && (u8reg || (dbg & 256)) && (IW % 4) == 0 && IW >= 8 && ((uintptr_t)X.X & 3) == 0;
+    if (regconv) dbg |= 256; else dbg &= ~256;
+    auto lds_of = [&](int R) { const int XR = (R - 1) * 4 + 8; return (size_t)3 * XR * (IW * 2 + 16) + 64 + ((X.u8 && !regconv) ? (size_t)XR * conv1_raw_pitch16(IW) + 16 : 0); };   // + raw uint8 rows
     static const int lds_kb = HULC_SWITCH("HULC_C1_LDS", 39);   // 4 workgroups per CU: one stages while others multiply (255 vs 299 us at 2 per CU)
     static const int max_wg = HULC_SWITCH("HULC_C1_WG", 1024);
     int R = OH;
@@ -731,7 +741,7 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
     }
     const int items = Nf * nbands;
     static const int u8dma = HULC_SWITCH("HULC_C1_U8DMA", 1);
-    if (X.u8 && u8dma && (IW * 3) % 4 == 0 && ((uintptr_t)X.X & 3) == 0) {
+    if (X.u8 && !regconv && u8dma && (IW * 3) % 4 == 0 && ((uintptr_t)X.X & 3) == 0) {
         static bool a2 = false;
         if (!a2) { hipFuncSetAttribute((const void*)conv1_fwd_u8dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
         hipLaunchKernelGGL(conv1_fwd_u8dma_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);

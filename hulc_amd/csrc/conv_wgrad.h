@@ -729,7 +729,35 @@ struct Step256 {
     DEVI explicit Step256(int n_) : n(n_), dq(256 / n_), dr(256 % n_) {}
     DEVI void adv(RowCol& p) const { p.c += dr; p.r += dq; if (p.c >= n) { p.c -= n; ++p.r; } }
 };
-DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw) {
+// ---- uint8 frames converted FROM REGISTERS (round 6): a 4-pixel group (12 bytes of an interleaved RGB row at a shift-dependent byte offset) is fetched as the aligned
+// 16-byte WINDOW around it — conv1_window_off gives the window's byte offset in the source row, clamped so that it stays inside the row (the frame buffer's last row
+// included) — and conv1_window_group turns the window into the group's three 4-value planes: window -> the 12 bytes of source pixels qp .. qp + 3 -> for output pixel k
+// the source pixel clamp(c 4 + k + dx, 0, IW - 1) - qp (= k everywhere but at the row ends, where RandomShiftsAug's replicate pad repeats the edge pixel).
+DEVI int conv1_window_off(int c, int dx, int IW, int RB) {
+    const int qp = min(max(c * 4 + dx, 0), IW - 4);
+    return min((qp * 3) & ~3, RB - 16);
+}
+template <bool FOLD>
+DEVI void conv1_window_group(const u32x4_t& w, int c, int dx, int IW, int RB, unsigned (&lo)[3], unsigned (&hi)[3]) {
+    const float sc = 2.f / 255.f, of = -1.f;
+    const int p0 = c * 4 + dx, qp = min(max(p0, 0), IW - 4);
+    const int a0 = min((qp * 3) & ~3, RB - 16), sh = qp * 3 - a0;      // 0 .. 4
+    const bool s4 = sh == 4;
+    const unsigned w0 = s4 ? w[1] : w[0], w1 = s4 ? w[2] : w[1], w2 = s4 ? w[3] : w[2], w3 = w[3];
+    const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh & 3), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh & 3), d2 = __builtin_amdgcn_alignbyte(w3, w2, sh & 3);
+    const unsigned P[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};      // the four source pixels as 24-bit words
+    float v[12];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int si = min(max(p0 + kk, 0), IW - 1) - qp;       // 0 .. 3
+        const unsigned pw = si == 0 ? P[0] : (si == 1 ? P[1] : (si == 2 ? P[2] : P[3]));
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { const float x = (float)((pw >> (8 * ch)) & 0xffu); v[kk * 3 + ch] = FOLD ? x : fmaf(x, sc, of); }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { lo[ch] = pack2h(v[ch], v[3 + ch]); hi[ch] = pack2h(v[6 + ch], v[9 + ch]); }
+}
+DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw, bool regconv = false) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const int W4 = IW >> 2;                                           // 4-pixel groups per row
     const Step256 sq(W4);
@@ -776,6 +804,30 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     int dx = 0, dy = 0;
     if (s.shift) { dx = s.shift[2 * f] - s.pad; dy = s.shift[2 * f + 1] - s.pad; }
     const int RB = IW * 3;                                            // bytes per source row (multiple of 4: IW % 4 == 0)
+    if (regconv) {
+        // one pass: NU windows in flight per thread, converted from the registers into the [c][row][iw] image (no raw rows in LDS, no margins, no barrier in between)
+        constexpr int NU = 6;
+        RowCol p = q0;
+        while (p.r < rows) {
+            RowCol e[NU];
+            u32x4_t w[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                e[u] = p; sq.adv(p);
+                const bool in = e[u].r < rows;
+                w[u] = *reinterpret_cast<const u32x4_t*>(base + (long long)min(max(ih0 + (in ? e[u].r : rows - 1) + dy, 0), IH - 1) * RB + conv1_window_off(in ? e[u].c : 0, dx, IW, RB));
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                if (e[u].r < rows) {
+                    unsigned lo[3], hi[3];
+                    if (s.fold) conv1_window_group<true>(w[u], e[u].c, dx, IW, RB, lo, hi); else conv1_window_group<false>(w[u], e[u].c, dx, IW, RB, lo, hi);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + e[u].r) * XRS + e[u].c * 8) = u32x2_t{lo[ch], hi[ch]};
+                }
+        }
+        return;
+    }
     const int RP = conv1_raw_pitch(IW);
     constexpr int LM = CONV1_RAW_MARGIN * 3;                          // byte offset of pixel 0 in a raw row (multiple of 8)
     if ((RB & 7) == 0 && ((uintptr_t)base & 7) == 0) {
@@ -1437,9 +1489,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
 #pragma unroll
             for (int k = 0; k < PFX; ++k) {
                 const int rr = min(r, min(XR, xrows) - 1);            // slots past the band / rows below the frame: a valid row (dropped / zeroed at the commit)
-                const int qp = min(max(c * 4 + pdx, 0), IW - 4);      // first of the four source pixels the window holds (replicate pad: clamped into the row)
-                const int a0 = min((qp * 3) & ~3, RB - 16);           // 4-byte aligned, and the 16 bytes stay inside the row (the frame buffer's last row included)
-                px[k] = *reinterpret_cast<const u32x4_t*>(fb + (long long)min(max(ih0 + rr + dy, 0), IH - 1) * RB + a0);
+                px[k] = *reinterpret_cast<const u32x4_t*>(fb + (long long)min(max(ih0 + rr + dy, 0), IH - 1) * RB + conv1_window_off(c, pdx, IW, RB));
                 c += xdr; r += xdq; if (c >= W4) { c -= W4; ++r; }
             }
         }
@@ -1463,7 +1513,6 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
             // clamp(c 4 + k + dx) - qp (= k everywhere but at the row ends, where RandomShiftsAug's replicate pad repeats the edge pixel)
             auto commit_x = [&](auto FOLD_) __attribute__((always_inline)) {      // the folded path (production) converts the byte as it is: no multiply-add
             constexpr bool FOLD = decltype(FOLD_)::value;
-            const float sc = 2.f / 255.f, of = -1.f;
             int t = tid;
             asm volatile("" : "+v"(t));
             int r = t / W4, c = t - r * W4;
@@ -1472,23 +1521,10 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
                 if (t + k * 512 < nx) {
                     u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
                     if (r < cxr) {                                // rows below the frame stay zero
-                        const int p0 = c * 4 + dx, qp = min(max(p0, 0), IW - 4);
-                        const int a0 = min((qp * 3) & ~3, RB - 16), sh = qp * 3 - a0;      // 0 .. 4
-                        const bool s4 = sh == 4;
-                        const unsigned w0 = s4 ? px[k][1] : px[k][0], w1 = s4 ? px[k][2] : px[k][1], w2 = s4 ? px[k][3] : px[k][2], w3 = px[k][3];
-                        const unsigned d0 = __builtin_amdgcn_alignbyte(w1, w0, sh & 3), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh & 3), d2 = __builtin_amdgcn_alignbyte(w3, w2, sh & 3);
-                        // the four source pixels as 24-bit words
-                        const unsigned P[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};
-                        float v[12];
+                        unsigned lo[3], hi[3];
+                        conv1_window_group<FOLD>(px[k], c, dx, IW, RB, lo, hi);
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int si = min(max(p0 + kk, 0), IW - 1) - qp;       // 0 .. 3
-                            const unsigned pw = si == 0 ? P[0] : (si == 1 ? P[1] : (si == 2 ? P[2] : P[3]));
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) { const float x = (float)((pw >> (8 * ch)) & 0xffu); v[kk * 3 + ch] = FOLD ? x : fmaf(x, sc, of); }
-                        }
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = pack2h(v[ch], v[3 + ch]); ov[ch][1] = pack2h(v[6 + ch], v[9 + ch]); }
+                        for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = lo[ch]; ov[ch][1] = hi[ch]; }
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + r) * XRS + c * 8) = ov[ch];

@@ -177,3 +177,36 @@ def test_frame_store_windows_equal_the_materialised_batch(dtype):
     with pytest.raises(ValueError):                                        # stores of different lengths
         eng.forward_loss(dict(sto, rgb_gripper=t(store_g[:F - 1])), False, 1.0, 3.0)
     eng.close()
+
+
+@pytest.mark.parametrize("IH,pad", [(200, 10), (84, 4)])
+def test_u8_conv1_forward_at_launch_scale_matches_a_direct_convolution_and_itself(IH, pad):
+    """Round 6: conv1's uint8 forward on 2048 frames with random RandomShiftsAug shifts — the LDS-DMA kernel the step uses, twice, and the register-staged kernel
+    (16-byte windows, dbg bit 8) — against torch's convolution of the shifted / clamped / normalised frames.  The small ingest fixtures (8 frames) never showed
+    what this size does: a row's last DMA piece spills 8 bytes of the next row onto the row's right margin, and the margin fill raced with slower waves' pieces
+    (positive column shifts: the three rightmost output columns of some rows wrong by O(0.1), differently per run).  Gates: both kernels within bf16 rounding of
+    torch on sampled frames incl. the buffer's last, the two DMA runs and the register kernel bit-identical."""
+    from hulc_amd import lib as L
+    lib = L.load()
+    Nf, OH = 2048, (IH - 8) // 4 + 1
+    g = torch.Generator(device="cuda").manual_seed(IH)
+    w = (torch.randn(32, 192, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(32, device="cuda", generator=g) * 0.1
+    x = torch.randint(0, 256, (Nf, IH, IH, 3), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+    sh = torch.randint(0, 2 * pad + 1, (Nf, 2), device="cuda", generator=g, dtype=torch.int32)
+    sh[0] = torch.tensor([0, 2 * pad]); sh[1] = torch.tensor([2 * pad, 0]); sh[Nf - 1] = torch.tensor([2 * pad, 2 * pad])
+    outs = [torch.zeros(Nf, OH, OH, 32, device="cuda", dtype=torch.bfloat16) for _ in range(3)]
+    for o, dbg in zip(outs, (0, 256, 0)):
+        L.check(lib.hulc_k_conv_tile(6, x.data_ptr(), w.data_ptr(), b.data_ptr(), sh.data_ptr(), o.data_ptr(), Nf, IH, OH, dbg, None))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]), int((outs[0] != outs[2]).sum())           # the same launch twice
+    assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())           # same arithmetic on the same 16-bit operands
+    idx = torch.arange(IH, device="cuda")
+    W = w.float().reshape(32, 3, 8, 8)
+    right = [int(f) for f in torch.nonzero(sh[:, 0] > pad).reshape(-1)[:6]]          # positive column shifts: the frames the race hit
+    for f in [0, 1, Nf - 1] + right:
+        dx, dy = int(sh[f, 0]) - pad, int(sh[f, 1]) - pad
+        fr = (x[f].float()[(idx + dy).clamp(0, IH - 1)][:, (idx + dx).clamp(0, IH - 1)] * (2 / 255) - 1).permute(2, 0, 1)
+        ref = torch.relu(torch.nn.functional.conv2d(fr.to(torch.bfloat16).float()[None], W, b, stride=4))[0].permute(1, 2, 0)
+        err = float((outs[0][f].float() - ref).abs().max())
+        assert err < 2e-2, (f, sh[f].tolist(), err)                                  # bf16 output rounding of values up to ~3
