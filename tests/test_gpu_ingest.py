@@ -210,3 +210,27 @@ def test_u8_conv1_forward_at_launch_scale_matches_a_direct_convolution_and_itsel
         ref = torch.relu(torch.nn.functional.conv2d(fr.to(torch.bfloat16).float()[None], W, b, stride=4))[0].permute(1, 2, 0)
         err = float((outs[0][f].float() - ref).abs().max())
         assert err < 2e-2, (f, sh[f].tolist(), err)                                  # bf16 output rounding of values up to ~3
+
+
+@pytest.mark.parametrize("ingest", ["fp32", "u8"])
+def test_encoder_forward_is_run_to_run_identical_at_benchmark_size(ingest):
+    """The perceptual encoders' forward has no atomics: at the benchmark's size (B = 64, S = 32: 2048 frames per camera, bf16) two forwards of the same batch must give
+    the same `emb` bit for bit, with the fp32 boundary and with uint8 frames + RandomShiftsAug shifts.  (A race in a staging path shows up here long before it moves a
+    loss: round 6's margin race of the uint8 forward changed ~4 000 of 157 M conv1 outputs per launch.)"""
+    sys.path.insert(0, ROOT)
+    from bench import synth_batch
+    from hulc_amd import spec
+    dims = spec.ModelDims(kind="hulc", max_window=32, use_clip=False)
+    dev = torch.device("cuda:0")
+    B, S = 64, 32
+    mb = synth_batch(B, S, dev, 5, False, ingest)
+    eng = StepEngine(dims, B, S, dtype="bf16", device="cuda:0", dropout_p=0.0, seed=1)
+    eng.load_numpy(spec.init_all(dims, seed=0, ln_jitter=True))
+    embs = []
+    for _ in range(3):
+        eng.zero_grads()
+        eng.forward_loss(mb, False, 1.0, 3.0, step=0, sync_losses=False)
+        torch.cuda.synchronize()
+        embs.append(eng.get_tensor("emb", B * S * 128).copy())
+    eng.close()
+    assert np.array_equal(embs[0], embs[1]) and np.array_equal(embs[0], embs[2]), (int((embs[0] != embs[1]).sum()), int((embs[0] != embs[2]).sum()))
