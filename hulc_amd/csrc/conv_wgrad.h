@@ -1536,7 +1536,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
         }
 #pragma unroll
         for (int k = 0; k < PFY; ++k)
-            if (tid + k * 512 < ny) {
+            if (tid + k * 512 < ny && !W1_PROBE_SKIP(16)) {
                 const int r = yd[k] >> 16, i = yd[k] & 0xffff;
                 const u32x4_t v = r < cyr ? py[k] : u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll

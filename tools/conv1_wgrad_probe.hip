@@ -33,10 +33,10 @@ int main() {
             g_conv1_wgrad_u8reg = u8 == 2;
             Conv1Src src{}; src.X = u8 ? (const void*)x8 : (const void*)x32; src.u8 = u8 != 0; src.fold = u8 != 0;
             if (u8) { src.shift = shifts; src.pad = cam ? 4 : 10; }      // RandomShiftsAug draws as in bench.py --ingest u8
-            float t[16];
-            for (int d = 0; d < 16; ++d) t[d] = 1e30f;
+            float t[32];
+            for (int d = 0; d < 32; ++d) t[d] = 1e30f;
             for (int round = 0; round < 4; ++round)               // alternating rounds, minimum per arm: one arm's 10 launches in a row pick up the box's drift
-            for (int dbg : {0, 1, 2, 3, 4, 8, 12, 15}) {
+            for (int dbg : {0, 1, 2, 3, 4, 8, 12, 15, 11, 19, 27}) {
                 hipMemcpyToSymbol(HIP_SYMBOL(g_w1_probe), &dbg, sizeof(int));
                 auto launch = [&]() { hipMemsetAsync(ctr, 0, 256, 0); launch_conv1_wgrad_tr(0, src, dy, part, bias, Nf, IH, IH, OH, OH, 512, ctr); };
                 for (int i = 0; i < 2; ++i) launch();
@@ -57,6 +57,7 @@ int main() {
             }
             const double mb = (double)Nf * (3.0 * IH * IH * (u8 ? 1 : 4) + OH * OH * 32 * 2.0) / 1e6;
             printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 == 0 ? "fp32" : (u8 == 1 ? "u8" : "u8reg"), t[0], mb / t[0], mb, t[1], t[2], t[3]);
+            if (u8 == 2) printf("  | of 'neither': without the conversion %6.1f  without the dY staging %6.1f  without both (barriers + band bookkeeping) %6.1f", t[11], t[19], t[27]);
             if (u8 == 1) printf("  | no-margin-fill %6.1f  no-conversion %6.1f  neither of those %6.1f  nothing at all (raw commit + dY staging + barriers) %6.1f", t[4], t[8], t[12], t[15]);
             printf("\n");
         }
