@@ -61,13 +61,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"hulc_amd: {LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
+    # HULC_LIB_PATH: another BUILD of the same library (an older commit's, an experiment's) for same-box A/B runs of whole builds (tools/ab_lib.sh); never a fallback —
+    # a path that does not exist is an error like a missing in-tree build
+    path = os.environ.get("HULC_LIB_PATH") or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"hulc_amd: {path} not built — run `python -c 'import __graft_entry__ as g; g.build()'`; "
                            "there is no CPU fallback for the product path")
     # torch ships its own libamdhip64; it must be the HIP runtime of the process.  Loading this library first would pull in
     # /opt/rocm's copy and a later `import torch` then sees no device ("hulc_ctx_create: no HIP device visible").
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.hulc_last_error.restype = C.c_char_p
     lib.hulc_workspace_bytes.restype = C.c_int64
     lib.hulc_ctx_create.argtypes = [C.POINTER(HulcConfig), C.POINTER(C.c_void_p)]
@@ -78,7 +81,10 @@ def load():
                                      C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.hulc_prepare_weights.argtypes = [C.c_void_p]
     lib.hulc_zero_grads.argtypes = [C.c_void_p]
-    lib.hulc_flush_grads.argtypes = [C.c_void_p]
+    if os.environ.get("HULC_LIB_PATH") and not hasattr(lib, "hulc_flush_grads"):      # an older build under A/B: the entry points it predates stay unbound
+        lib.hulc_zero_grads.argtypes = [C.c_void_p]
+    else:
+        lib.hulc_flush_grads.argtypes = [C.c_void_p]
     lib.hulc_forward_loss.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
     lib.hulc_forward_loss_pair.argtypes = [C.c_void_p, C.POINTER(HulcBatch), C.POINTER(HulcBatch), C.c_float, C.c_float, C.c_void_p, C.c_int32]
     lib.hulc_backward.argtypes = [C.c_void_p]
@@ -91,7 +97,8 @@ def load():
     lib.hulc_comm_destroy.argtypes = [C.c_void_p]
     lib.hulc_comm_buckets.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.hulc_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
-    lib.hulc_comm_size.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if hasattr(lib, "hulc_comm_size") or not os.environ.get("HULC_LIB_PATH"):
+        lib.hulc_comm_size.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.hulc_comm_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double)]
     lib.hulc_allreduce_grads.argtypes = [C.c_void_p, C.c_int32]
     lib.hulc_backward_allreduce.argtypes = [C.c_void_p, C.c_int32]
