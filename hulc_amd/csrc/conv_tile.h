@@ -544,7 +544,7 @@ DEVI void conv1_fwd_band_tiles(lds_char* ximg, const h16x8_t (&wf)[6][2], const 
 // of 4x); the 32x192 weight matrix lives in registers as MFMA A fragments (12 per lane); an image fragment (16 output pixels
 // x 8 kw of one (c,kh) row) is two 8-byte LDS reads.  K order = (c, kh, kw) = torch's weight order.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MINW>
+template <int MINW, bool REGCONV = false>
 __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const h16_t* __restrict__ W, const float* __restrict__ bias,
                                                            h16_t* __restrict__ out, int Nf, int IH, int IW, int OH, int OW, int R, int nbands, int dbg,
                                                            unsigned* __restrict__ maskbits, float* __restrict__ zero8a = nullptr, float* __restrict__ zero8b = nullptr) {
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256, MINW) conv1_fwd_kernel(Conv1Src X, const 
         const int ih0 = oh0 * 4;
         const int rows = min(XR, IH - ih0);
         __syncthreads();
-        if (!(dbg & 4)) conv1_stage_band(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64, (dbg & 256) != 0);      // dbg bit 8: uint8 converted from registers (no raw rows)
+        if (!(dbg & 4)) conv1_stage_band<REGCONV>(X, f, ih0, rows, IH, IW, ximg, XR, XRS, tid, ximg + 3 * XR * XRS + 64);      // REGCONV: uint8 converted from registers (no raw rows)
         __syncthreads();
         conv1_fwd_band_tiles(ximg, wf, rowsel, bb, out, maskbits, f, oh0, R, OH, OW, XRS, dbg, wave, g, li, (X.u8 && X.fold) ? CONV1_FOLD_SCALE : 1.f);
     }
@@ -745,6 +745,12 @@ static inline void launch_conv1_fwd(hipStream_t st, const Conv1Src& X, const h16
         static bool a2 = false;
         if (!a2) { hipFuncSetAttribute((const void*)conv1_fwd_u8dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a2 = true; }
         hipLaunchKernelGGL(conv1_fwd_u8dma_kernel, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
+        return;
+    }
+    if (regconv) {       // uint8 cross-check path (tests, tools/time_conv1_u8reg.py): its own instance, so that the window code does not weigh on the fp32 kernel's registers
+        static bool a3 = false;
+        if (!a3) { hipFuncSetAttribute((const void*)conv1_fwd_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a3 = true; }
+        hipLaunchKernelGGL((conv1_fwd_kernel<4, true>), dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);
         return;
     }
     if (occ >= 4) hipLaunchKernelGGL(conv1_fwd_kernel<4>, dim3(items < max_wg ? items : max_wg), dim3(256), lds_of(R), st, X, W, bias, out, Nf, IH, IW, OH, OW, R, nbands, dbg, maskbits, zero8a, zero8b);

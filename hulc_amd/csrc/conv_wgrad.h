@@ -757,7 +757,8 @@ DEVI void conv1_window_group(const u32x4_t& w, int c, int dx, int IW, int RB, un
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) { lo[ch] = pack2h(v[ch], v[3 + ch]); hi[ch] = pack2h(v[6 + ch], v[9 + ch]); }
 }
-DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw, bool regconv = false) {
+template <bool REGCONV = false>      // compile-time: the window path must not sit (as dead code with live registers) inside the 128-VGPR fp32 forward kernel — it cost that kernel 16 more spills
+DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const int W4 = IW >> 2;                                           // 4-pixel groups per row
     const Step256 sq(W4);
@@ -804,7 +805,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     int dx = 0, dy = 0;
     if (s.shift) { dx = s.shift[2 * f] - s.pad; dy = s.shift[2 * f + 1] - s.pad; }
     const int RB = IW * 3;                                            // bytes per source row (multiple of 4: IW % 4 == 0)
-    if (regconv) {
+    if constexpr (REGCONV) {
         // one pass: NU windows in flight per thread, converted from the registers into the [c][row][iw] image (no raw rows in LDS, no margins, no barrier in between)
         constexpr int NU = 6;
         RowCol p = q0;
