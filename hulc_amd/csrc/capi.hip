@@ -305,6 +305,28 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     return 0;
 }
 
+// conv1's weight gradient from uint8 (Nf,IH,IH,3) frames alone (tests): dW (32,192) [torch (o, c, kh, kw) order] and db (32) of the frames after ScaleImageTensor / Normalize /
+// RandomShiftsAug — form 0: raw rows through LDS (conv1_wgrad_tr2u_kernel), 1: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel); fold = Conv1Src::fold
+int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, const void* dY, float* dw_out, float* db_out, int32_t Nf, int32_t IH, int32_t form, int32_t fold, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    float *part = nullptr, *bias = nullptr;
+    if (hipMalloc(&part, sizeof(float) * 512ll * 32 * 192) != hipSuccess || hipMalloc(&bias, sizeof(float) * 64) != hipSuccess) { hulc_set_error("hulc_k_conv1_wgrad_u8: hipMalloc failed"); return 1; }
+    hipMemsetAsync(bias, 0, sizeof(float) * 64, st);
+    Conv1Src src{}; src.X = X; src.shift = shifts; src.u8 = 1; src.pad = pad; src.fold = fold != 0;
+    const int OH = (IH - 8) / 4 + 1;
+    const int keep = g_conv1_wgrad_u8reg;
+    g_conv1_wgrad_u8reg = form != 0;
+    const int ns = launch_conv1_wgrad_tr(st, src, (const h16_t*)dY, part, bias, Nf, IH, IH, OH, OH, 512);
+    g_conv1_wgrad_u8reg = keep;
+    hipMemsetAsync(dw_out, 0, sizeof(float) * 32 * 192, st);
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((32 * 192 + 1023) / 1024), dim3(256), 0, st, part, ns, (long long)32 * 192, dw_out, 32, 192, 1, 1, 0);
+    hipMemcpyAsync(db_out, bias, sizeof(float) * 32, hipMemcpyDeviceToDevice, st);
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(part); hipFree(bias);
+    if (e != hipSuccess) { hulc_set_error("hulc_k_conv1_wgrad_u8: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
 // raw-tile conv kernels alone (bf16 NHWC): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of (1)
 int hulc_k_conv_tile(int32_t mode, const void* img, const void* w, const float* bias, const void* mask, void* out, int32_t Nf, int32_t IMH,
                      int32_t OUTH, int32_t relu, void* stream) {

@@ -334,6 +334,8 @@ int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_
 /* conv weight-gradient kernel alone (bf16 NHWC activations): which = 2 (4x4 s2, 32->64) or 3 (3x3 s1, 64->64); square frames of
  * side IH; out = fp32 [64][KH*KW*CI] in packed (kh,kw,ci) order, overwritten. Synchronises. */
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* hip_stream);
+/* conv1's weight / bias gradient from uint8 (Nf,IH,IH,3) frames + RandomShiftsAug shifts alone (bf16 engine's kernels; form 0: raw rows through LDS, 1: conversion from the prefetch registers) */
+int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, const void* dY, float* dw_out, float* db_out, int32_t Nf, int32_t IH, int32_t form, int32_t fold, void* hip_stream);
 /* raw-tile conv kernels alone (bf16 NHWC, square frames): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of
  * (1). img side IMH, out side OUTH; w = packed weights as produced by hulc_prepare_weights (fwd [co][(kh,kw,ci)], dgrad per-parity
  * [class][ci][(a,b,co)]); bias fp32 / mask bf16 optional. Asynchronous on hip_stream.

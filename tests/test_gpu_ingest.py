@@ -212,6 +212,50 @@ def test_u8_conv1_forward_at_launch_scale_matches_a_direct_convolution_and_itsel
         assert err < 2e-2, (f, sh[f].tolist(), err)                                  # bf16 output rounding of values up to ~3
 
 
+@pytest.mark.parametrize("IH,pad", [(200, 10), (84, 4)])
+def test_u8_conv1_weight_gradient_at_launch_scale_matches_torch(IH, pad):
+    """Round 6: conv1's weight / bias gradient from uint8 frames on 2048 frames with random RandomShiftsAug shifts — the kernel the step uses (conversion from the
+    prefetch registers, conv1_wgrad_tr2r_kernel), round 5's form (raw rows through LDS, tr2u) and both without the affine fold — against an fp64 torch reference
+    dW[o][c][kh][kw] = sum dY[n][oh][ow][o] x[n][c][4 oh + kh][4 ow + kw] over the shifted / clamped / normalised frames.  With the fold the MFMA operand is the exact
+    byte, so the only error is the fp32 accumulation (and atomics' order); without it x is rounded to bf16 first and the reference rounds the same way."""
+    from hulc_amd import lib as L
+    lib = L.load()
+    Nf, OH = 2048, (IH - 8) // 4 + 1
+    g = torch.Generator(device="cuda").manual_seed(IH + 1)
+    x = torch.randint(0, 256, (Nf, IH, IH, 3), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+    sh = torch.randint(0, 2 * pad + 1, (Nf, 2), device="cuda", generator=g, dtype=torch.int32)
+    sh[0] = torch.tensor([0, 2 * pad]); sh[1] = torch.tensor([2 * pad, 0]); sh[Nf - 1] = torch.tensor([2 * pad, 2 * pad])
+    dY = (torch.randn(Nf, OH, OH, 32, device="cuda", generator=g) * (torch.arange(32, device="cuda") % 5 + 1)).to(torch.bfloat16)
+    idx = torch.arange(IH, device="cuda")
+    refs = {1: torch.zeros(32, 3, 8, 8, dtype=torch.float64, device="cuda"), 0: torch.zeros(32, 3, 8, 8, dtype=torch.float64, device="cuda")}
+    for f0 in range(0, Nf, 256):
+        rows = (idx[None, :] + (sh[f0:f0 + 256, 1:2] - pad)).clamp(0, IH - 1).long()          # [n][y]
+        cols = (idx[None, :] + (sh[f0:f0 + 256, 0:1] - pad)).clamp(0, IH - 1).long()          # [n][x]
+        xs = x[f0:f0 + 256][torch.arange(256, device="cuda")[:, None, None], rows[:, :, None], cols[:, None, :]]      # (n, y, x, c)
+        xe = (xs.double() * (2 / 255) - 1).permute(0, 3, 1, 2)
+        xr = (xs.float() * (2 / 255) - 1).to(torch.bfloat16).double().permute(0, 3, 1, 2)
+        d = dY[f0:f0 + 256].double()
+        for fold, xx in ((1, xe), (0, xr)):
+            for kh in range(8):
+                for kw in range(8):
+                    refs[fold][:, :, kh, kw] += torch.einsum("nhwd,nchw->dc", d, xx[:, :, kh:kh + 4 * OH:4, kw:kw + 4 * OH:4])
+    refb = dY.double().sum(dim=(0, 1, 2))
+    got = {}
+    for form in (1, 0):
+        for fold in (1, 0):
+            gw = torch.zeros(32, 192, device="cuda"); gb = torch.zeros(32, device="cuda")
+            L.check(lib.hulc_k_conv1_wgrad_u8(x.data_ptr(), sh.data_ptr(), pad, dY.data_ptr(), gw.data_ptr(), gb.data_ptr(), Nf, IH, form, fold, None))
+            torch.cuda.synchronize()
+            ref = refs[fold].reshape(32, -1)
+            err = float((gw.double() - ref).abs().max() / ref.abs().max())
+            errb = float((gb.double() - refb).abs().max() / refb.abs().max())
+            got[(form, fold)] = gw
+            assert err < (2e-5 if fold else 1e-4), (form, fold, err)
+            assert errb < 1e-5, (form, fold, errb)
+    # the two forms feed the MFMAs the same operands in the same order; only the slab atomics' order differs
+    assert float((got[(1, 1)] - got[(0, 1)]).abs().max() / got[(1, 1)].abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("ingest", ["fp32", "u8"])
 def test_encoder_forward_is_run_to_run_identical_at_benchmark_size(ingest):
     """The perceptual encoders' forward has no atomics: at the benchmark's size (B = 64, S = 32: 2048 frames per camera, bf16) two forwards of the same batch must give
