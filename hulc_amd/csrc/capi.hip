@@ -306,7 +306,7 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
 }
 
 // conv1's weight gradient from uint8 (Nf,IH,IH,3) frames alone (tests): dW (32,192) [torch (o, c, kh, kw) order] and db (32) of the frames after ScaleImageTensor / Normalize /
-// RandomShiftsAug — form 0: raw rows through LDS (conv1_wgrad_tr2u_kernel), 1: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel); fold = Conv1Src::fold
+// RandomShiftsAug — form 0: raw rows through LDS (conv1_wgrad_tr2u_kernel), 1: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel), 2: the same with interior / row-end slots; fold = Conv1Src::fold
 int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, const void* dY, float* dw_out, float* db_out, int32_t Nf, int32_t IH, int32_t form, int32_t fold, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     float *part = nullptr, *bias = nullptr;
@@ -315,7 +315,7 @@ int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, con
     Conv1Src src{}; src.X = X; src.shift = shifts; src.u8 = 1; src.pad = pad; src.fold = fold != 0;
     const int OH = (IH - 8) / 4 + 1;
     const int keep = g_conv1_wgrad_u8reg;
-    g_conv1_wgrad_u8reg = form != 0;
+    g_conv1_wgrad_u8reg = form;
     const int ns = launch_conv1_wgrad_tr(st, src, (const h16_t*)dY, part, bias, Nf, IH, IH, OH, OH, 512);
     g_conv1_wgrad_u8reg = keep;
     hipMemsetAsync(dw_out, 0, sizeof(float) * 32 * 192, st);

@@ -757,6 +757,27 @@ DEVI void conv1_window_group(const u32x4_t& w, int c, int dx, int IW, int RB, un
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) { lo[ch] = pack2h(v[ch], v[3 + ch]); hi[ch] = pack2h(v[6 + ch], v[9 + ch]); }
 }
+// The same for a group that no shift can push against a row end (conv1_interior_groups): source pixel k of the group is pixel qp + k, qp = 4 c + dx, the window starts at
+// (3 qp) & ~3 and the group's 12 bytes at offset sh = (3 qp) & 3 = (3 dx) & 3 of it — ONE value per frame.  3 alignbyte + 12 byte conversions + 6 packs against the ~ 80
+// instructions of the clamps and per-pixel selects above (the conversion was VALU-bound: tools/conv1_wgrad_probe.hip).
+template <bool FOLD>
+DEVI void conv1_window_group_interior(const u32x4_t& w, int sh, unsigned (&lo)[3], unsigned (&hi)[3]) {
+    const float sc = 2.f / 255.f, of = -1.f;
+    const unsigned d[3] = {__builtin_amdgcn_alignbyte(w[1], w[0], sh), __builtin_amdgcn_alignbyte(w[2], w[1], sh), __builtin_amdgcn_alignbyte(w[3], w[2], sh)};
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float x = (float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu); v[i] = FOLD ? x : fmaf(x, sc, of); }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { lo[ch] = pack2h(v[ch], v[3 + ch]); hi[ch] = pack2h(v[6 + ch], v[9 + ch]); }
+}
+// groups [cl, cl + wi) of a row's IW / 4 are interior for every shift |dx| <= pad: 4 c - pad >= 0 and 4 c + pad <= IW - 6 (all four pixels inside the row, the window
+// not clamped at the row's last 16 bytes); at most `cap` of them, centred.  wi <= 0: no interior (tiny frames).
+static inline __host__ __device__ void conv1_interior_groups(int IW, int pad, int cap, int& cl, int& wi) {
+    const int lo = (pad + 3) >> 2, hi = (IW - 6 - pad) >= 0 ? (IW - 6 - pad) / 4 + 1 : 0;      // [lo, hi)
+    wi = hi - lo < cap ? hi - lo : cap;
+    cl = wi > 0 ? lo + (hi - lo - wi) / 2 : 0;
+    if (wi < 0) wi = 0;
+}
 template <bool REGCONV = false>      // compile-time: the window path must not sit (as dead code with live registers) inside the 128-VGPR fp32 forward kernel — it cost that kernel 16 more spills
 DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, int IW, lds_char* ximg, int XR, int XRS, int tid, lds_char* raw) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -1430,7 +1451,10 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
 // the aligned 16-byte window around a 4-pixel group's 12 bytes (one dwordx4 load; 33 % more bytes requested, the overlaps hit in L2); the column shift and the replicate
 // pad are resolved per pixel from the window at the commit.  One barrier per band less, no raw rows in LDS.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PFX, int PFY>
+// SPLIT (round 6, second pass): slots 0 .. PFX - 2 hold INTERIOR groups only (conv1_interior_groups: no clamp, no per-pixel select, one alignbyte shift per frame),
+// slot PFX - 1 the few groups next to the row ends (threads [0, XR * edge groups per row)) with the general conversion — the slot index is an unrolled compile-time
+// constant, so no wave pays the slow path for its interior lanes.  Same LDS image, same slabs.
+template <int PFX, int PFY, bool SPLIT = false>
 __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, int* __restrict__ work_ctr, const h16_t* __restrict__ dY, float* __restrict__ part,
                                                                   float* __restrict__ bias_part, int Nf, int IH, int IW, int OH, int OW, int R, int nbands) {
     using C = Wgrad1Cfg;
@@ -1454,6 +1478,12 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
     // ... and the compiler hoists whatever is band-invariant out of the band loop and spills it just the same (a scratch reload in front of
     // every prefetch load waits for the loads issued before it): slot 0's (row, chunk) is recomputed per band behind an opaque copy of tid
     const int xdq = 512 / W4, xdr = 512 - xdq * W4;                // slot k of this thread = group tid + 512 k of the [XR][W4] grid, advanced by adds
+    // SPLIT: interior groups [cl, cl + WI) of every row in slots 0 .. PFX - 2 ([XR][WI] grid), the WE = W4 - WI others in slot PFX - 1 ([XR][WE] grid)
+    int cl = 0, WI = 0;
+    if (SPLIT) conv1_interior_groups(IW, S.pad, ((PFX - 1) * 512) / XR, cl, WI);
+    const int WE = W4 - WI, ni = XR * WI, ne = XR * WE;
+    const int idq = SPLIT ? 512 / max(WI, 1) : 0, idr = 512 - idq * WI;
+    const float invWI = 1.f / (float)max(WI, 1), invWE = 1.f / (float)max(WE, 1);
     int yd[PFY];
 #pragma unroll
     for (int k = 0; k < PFY; ++k) {
@@ -1483,7 +1513,20 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
         if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
         const unsigned char* fb = Xb + S.frame(f) * IH * RB;
         const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
-        {
+        if constexpr (SPLIT) {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            const int rmax = min(XR, xrows) - 1;
+            int r = wg_fdiv(t, invWI), ci = t - r * WI;
+            const int off0 = 12 * cl + 3 * pdx;                      // 3 (4 c + dx) = the group's first byte in its row
+#pragma unroll
+            for (int k = 0; k < PFX - 1; ++k) {
+                px[k] = *reinterpret_cast<const u32x4_t*>(fb + (long long)min(max(ih0 + min(r, rmax) + dy, 0), IH - 1) * RB + ((off0 + 12 * ci) & ~3));
+                ci += idr; r += idq; if (ci >= WI) { ci -= WI; ++r; }
+            }
+            const int re = wg_fdiv(t, invWE), ce = t - re * WE, c = ce < cl ? ce : ce + WI;
+            px[PFX - 1] = *reinterpret_cast<const u32x4_t*>(fb + (long long)min(max(ih0 + min(re, rmax) + dy, 0), IH - 1) * RB + conv1_window_off(c, pdx, IW, RB));
+        } else {
             int t = tid;
             asm volatile("" : "+v"(t));
             int r = t / W4, c = t - r * W4;
@@ -1516,6 +1559,38 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
             constexpr bool FOLD = decltype(FOLD_)::value;
             int t = tid;
             asm volatile("" : "+v"(t));
+            if constexpr (SPLIT) {
+                const int shu = (3 * dx) & 3;
+                int r = wg_fdiv(t, invWI), ci = t - r * WI;
+#pragma unroll
+                for (int k = 0; k < PFX - 1; ++k) {
+                    if (t + k * 512 < ni) {
+                        u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
+                        if (r < cxr) {
+                            unsigned lo[3], hi[3];
+                            conv1_window_group_interior<FOLD>(px[k], shu, lo, hi);
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = lo[ch]; ov[ch][1] = hi[ch]; }
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + r) * XRS + (cl + ci) * 8) = ov[ch];
+                    }
+                    ci += idr; r += idq; if (ci >= WI) { ci -= WI; ++r; }
+                }
+                if (t < ne) {
+                    const int re = wg_fdiv(t, invWE), ce = t - re * WE, c = ce < cl ? ce : ce + WI;
+                    u32x2_t ov[3] = {u32x2_t{0u, 0u}, u32x2_t{0u, 0u}, u32x2_t{0u, 0u}};
+                    if (re < cxr) {
+                        unsigned lo[3], hi[3];
+                        conv1_window_group<FOLD>(px[PFX - 1], c, dx, IW, RB, lo, hi);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { ov[ch][0] = lo[ch]; ov[ch][1] = hi[ch]; }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + re) * XRS + c * 8) = ov[ch];
+                }
+                return;
+            }
             int r = t / W4, c = t - r * W4;
 #pragma unroll
             for (int k = 0; k < PFX; ++k) {
@@ -1626,7 +1701,7 @@ inline int g_conv1_wgrad_u8reg = -1;      // tools/conv1_wgrad_probe.hip only: 0
 static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const h16_t* dY, float* part, float* bias_part, int Nf, int IH, int IW, int OH,
                                         int OW, int max_blocks, int* work_ctr = nullptr) {
     static const int v2 = HULC_SWITCH("HULC_W1_V2", 1);
-    static const int u8reg_sw = HULC_SWITCH("HULC_W1_U8REG", 1);      // uint8: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel); 0 = round 5's raw rows through LDS
+    static const int u8reg_sw = HULC_SWITCH("HULC_W1_U8REG", 2);      // uint8: 2 = conversion from the prefetch registers with interior / row-end slots (conv1_wgrad_tr2r_kernel<3, 2, true>), 1 = one general slot kind, 0 = round 5's raw rows through LDS
     if (v2 && !X.u8 && (IW % 4) == 0) {
         // tallest band whose images fit 2 workgroups per CU and whose chunks fit the prefetch slots (8 frame + 2 dY registers of 16 B per thread:
         // 10 + 3 slots spilled 46 registers of in-flight data at the 128-VGPR budget of 2 x 8 waves per CU, which serialised the prefetch)
@@ -1647,7 +1722,30 @@ static inline int launch_conv1_wgrad_tr(hipStream_t st, const Conv1Src& X, const
             return grid;
         }
     }
-    if (v2 && X.u8 && (IW % 4) == 0 && IW >= 8 && (g_conv1_wgrad_u8reg < 0 ? u8reg_sw : g_conv1_wgrad_u8reg)) {
+    const int u8form = g_conv1_wgrad_u8reg < 0 ? u8reg_sw : g_conv1_wgrad_u8reg;
+    if (v2 && X.u8 && (IW % 4) == 0 && IW >= 8 && u8form >= 2) {
+        // round 6, second pass: 2 slots of interior groups (fast conversion) + 1 slot of row-end groups + 2 dY slots per thread (conv1_wgrad_tr2r_kernel<3, 2, true>)
+        int R = OH;
+        auto fits = [&](int r) {
+            const int XR = (r - 1) * Wgrad1Cfg::S + Wgrad1Cfg::KH;
+            int cl, wi;
+            conv1_interior_groups(IW, X.pad, (2 * 512) / XR, cl, wi);
+            return Wgrad1Cfg::lds_bytes(r, IW, OW, false) <= (size_t)79 * 1024 && wi >= 1 && (long long)XR * wi <= 2 * 512 && (long long)XR * (IW / 4 - wi) <= 512 &&
+                   (long long)r * OW * 4 <= 2 * 512 && r < 128;
+        };
+        while (R > 1 && !fits(R)) --R;
+        if (fits(R)) {
+            const int nb = (OH + R - 1) / R;
+            R = (OH + nb - 1) / nb;
+            const size_t lds = std::max<size_t>(Wgrad1Cfg::lds_bytes(R, IW, OW, false), 32 * 1024);
+            static bool attr2s = false;
+            if (!attr2s) { hipFuncSetAttribute((const void*)conv1_wgrad_tr2r_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr2s = true; }
+            const int grid = std::min(std::min(Nf, 512), max_blocks);
+            hipLaunchKernelGGL((conv1_wgrad_tr2r_kernel<3, 2, true>), dim3(grid), dim3(512), lds, st, X, work_ctr, dY, part, bias_part, Nf, IH, IW, OH, OW, R, nb);
+            return grid;
+        }
+    }
+    if (v2 && X.u8 && (IW % 4) == 0 && IW >= 8 && u8form) {
         // uint8 boundary, round 6: 4 window slots of 16 bytes + 2 dY slots per thread, converted from the registers (conv1_wgrad_tr2r_kernel); no raw rows in LDS
         int R = OH;
         auto fits = [&](int r) {

@@ -215,7 +215,7 @@ def test_u8_conv1_forward_at_launch_scale_matches_a_direct_convolution_and_itsel
 @pytest.mark.parametrize("IH,pad", [(200, 10), (84, 4)])
 def test_u8_conv1_weight_gradient_at_launch_scale_matches_torch(IH, pad):
     """Round 6: conv1's weight / bias gradient from uint8 frames on 2048 frames with random RandomShiftsAug shifts — the kernel the step uses (conversion from the
-    prefetch registers, conv1_wgrad_tr2r_kernel), round 5's form (raw rows through LDS, tr2u) and both without the affine fold — against an fp64 torch reference
+    prefetch registers, conv1_wgrad_tr2r_kernel, with interior / row-end slots), the same kernel with one general slot kind, round 5's form (raw rows through LDS, tr2u) and both without the affine fold — against an fp64 torch reference
     dW[o][c][kh][kw] = sum dY[n][oh][ow][o] x[n][c][4 oh + kh][4 ow + kw] over the shifted / clamped / normalised frames.  With the fold the MFMA operand is the exact
     byte, so the only error is the fp32 accumulation (and atomics' order); without it x is rounded to bf16 first and the reference rounds the same way."""
     from hulc_amd import lib as L
@@ -241,7 +241,7 @@ def test_u8_conv1_weight_gradient_at_launch_scale_matches_torch(IH, pad):
                     refs[fold][:, :, kh, kw] += torch.einsum("nhwd,nchw->dc", d, xx[:, :, kh:kh + 4 * OH:4, kw:kw + 4 * OH:4])
     refb = dY.double().sum(dim=(0, 1, 2))
     got = {}
-    for form in (1, 0):
+    for form in (2, 1, 0):
         for fold in (1, 0):
             gw = torch.zeros(32, 192, device="cuda"); gb = torch.zeros(32, device="cuda")
             L.check(lib.hulc_k_conv1_wgrad_u8(x.data_ptr(), sh.data_ptr(), pad, dY.data_ptr(), gw.data_ptr(), gb.data_ptr(), Nf, IH, form, fold, None))
@@ -254,6 +254,8 @@ def test_u8_conv1_weight_gradient_at_launch_scale_matches_torch(IH, pad):
             assert errb < 1e-5, (form, fold, errb)
     # the two forms feed the MFMAs the same operands in the same order; only the slab atomics' order differs
     assert float((got[(1, 1)] - got[(0, 1)]).abs().max() / got[(1, 1)].abs().max()) < 2e-6
+    assert float((got[(2, 1)] - got[(1, 1)]).abs().max() / got[(1, 1)].abs().max()) < 2e-6
+    assert float((got[(2, 0)] - got[(1, 0)]).abs().max() / got[(1, 0)].abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("ingest", ["fp32", "u8"])

@@ -29,8 +29,8 @@ int main() {
         {   std::vector<int> h(Nf * 2); unsigned s2 = 7; const int pad = cam ? 4 : 10; for (auto& v : h) { s2 = s2 * 1664525u + 1013904223u; v = (int)((s2 >> 8) % (2 * pad + 1)); }
             hipMemcpy(shifts, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice); }
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int u8 = 0; u8 < 3; ++u8) {                          // 0: fp32 boundary, 1: uint8 with raw rows through LDS (round 5), 2: uint8 converted from the prefetch registers (round 6)
-            g_conv1_wgrad_u8reg = u8 == 2;
+        for (int u8 = 0; u8 < 4; ++u8) {                          // 0: fp32 boundary, 1: uint8 with raw rows through LDS (round 5), 2: uint8 converted from the prefetch registers (round 6), 3: the same with interior / row-end slots
+            g_conv1_wgrad_u8reg = u8 <= 1 ? 0 : u8 - 1;
             Conv1Src src{}; src.X = u8 ? (const void*)x8 : (const void*)x32; src.u8 = u8 != 0; src.fold = u8 != 0;
             if (u8) { src.shift = shifts; src.pad = cam ? 4 : 10; }      // RandomShiftsAug draws as in bench.py --ingest u8
             float t[32];
@@ -53,11 +53,11 @@ int main() {
                 static std::vector<float> ref;
                 if (u8 == 1) ref = h;
                 else { double dmax = 0, n = 0; for (size_t i = 0; i < h.size(); ++i) { dmax = std::max(dmax, (double)fabsf(h[i] - ref[i])); n = std::max(n, (double)fabsf(ref[i])); }
-                       printf("         u8reg vs u8 slabs: max |diff| %.3g (max |value| %.3g, %d slabs)\n", dmax, n, grid); }
+                       printf("         u8reg / u8spl vs u8 slabs: max |diff| %.3g (max |value| %.3g, %d slabs)\n", dmax, n, grid); }
             }
             const double mb = (double)Nf * (3.0 * IH * IH * (u8 ? 1 : 4) + OH * OH * 32 * 2.0) / 1e6;
-            printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 == 0 ? "fp32" : (u8 == 1 ? "u8" : "u8reg"), t[0], mb / t[0], mb, t[1], t[2], t[3]);
-            if (u8 == 2) printf("  | of 'neither': without the conversion %6.1f  without the dY staging %6.1f  without both (barriers + band bookkeeping) %6.1f", t[11], t[19], t[27]);
+            printf("%-8s %-5s full %6.1f us (%4.2f TB/s of %4.0f MB)  no-multiply %6.1f  no-prefetch %6.1f  neither %6.1f", cam ? "gripper" : "static", u8 == 0 ? "fp32" : (u8 == 1 ? "u8" : (u8 == 2 ? "u8reg" : "u8spl")), t[0], mb / t[0], mb, t[1], t[2], t[3]);
+            if (u8 >= 2) printf("  | of 'neither': without the conversion %6.1f  without the dY staging %6.1f  without both (barriers + band bookkeeping) %6.1f", t[11], t[19], t[27]);
             if (u8 == 1) printf("  | no-margin-fill %6.1f  no-conversion %6.1f  neither of those %6.1f  nothing at all (raw commit + dY staging + barriers) %6.1f", t[4], t[8], t[12], t[15]);
             printf("\n");
         }
