@@ -1511,6 +1511,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
         int dy = 0;
         pdx = 0;
         if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
+        if (SPLIT) pdx = min(max(pdx, -S.pad), S.pad);               // the interior slots assume |dx| <= pad (the contract of hulc_batch::shift_*): an out-of-contract value must not read past a row
         const unsigned char* fb = Xb + S.frame(f) * IH * RB;
         const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
         if constexpr (SPLIT) {
