@@ -48,6 +48,11 @@ for name, pred in groups:
 var = {k: J("_" + k) for k in ("fp16", "s64", "s64_fp16", "s64_fp16_vislang", "u8", "vislang", "vislang_seq", "mcil", "mcil_gru", "fp32", "u8_h2d")}
 sm, rs = d.get("step_ms") or {}, d.get("roofline_step") or {}
 sc = var["s64_fp16"].get("loss_scaler") or {}
+u8_store_row = ""
+if os.path.exists(P(f"{T}_bench_n1_u8_store.json")):
+    us = J("_u8_store")
+    u8_store_row = (f"| `{T}_bench_n1_u8_store.json` | uint8 frames from an HBM-resident frame store (`hulc_batch::window_start`: B new random windows per step gathered by index, nothing crosses PCIe, "
+                    f"no (B,S,H,W,C) tensor is materialised): {us['value']:.0f} windows/s, {us['ms_per_step']} ms/step | `python bench.py --ingest u8 --store 16384 --no-cpu-baseline` |\n")
 files = f"""| file | what | command |
 |---|---|---|
 | `{T}_bench_n1.json` | the bench line (N=1): **{d['value']:.0f} windows/s, {d['ms_per_step']} ms/step**, `roofline` + `cpu_baseline` objects | `python bench.py` |
@@ -55,8 +60,8 @@ files = f"""| file | what | command |
 | `{T}_bench_n1_s64_fp16.json` | BASELINE config 5's shape AND precision: seq_len 64, 32 windows/GPU, fp16 + loss scaling: **{var['s64_fp16']['value']:.0f} windows/s, {var['s64_fp16']['ms_per_step']} ms/step** (scale {sc.get('scale')}, {sc.get('skipped_in_timed_region')} step(s) skipped in the timed region) | `python bench.py --seq 64 --batch 32 --dtype fp16 --no-cpu-baseline` |
 | `{T}_bench_n1_s64_fp16_vislang.json` | config 5 with 16 vis + 16 lang windows + CLIP loss (paired pass): {var['s64_fp16_vislang']['value']:.0f} windows/s, {var['s64_fp16_vislang']['ms_per_step']} ms/step | `… --seq 64 --batch 32 --dtype fp16 --lang 1` |
 | `{T}_bench_n1_s64.json` | seq_len 64, 32 windows/GPU in bf16: {var['s64']['value']:.0f} windows/s, {var['s64']['ms_per_step']} ms/step | `python bench.py --seq 64 --batch 32 --no-cpu-baseline` |
-| `{T}_bench_n1_u8.json` | uint8 (B,S,H,W,C) ingest, transforms fused into conv1 (SURVEY §8(f) row 1): {var['u8']['value']:.0f} windows/s | `python bench.py --ingest u8 --no-cpu-baseline` |
-| `{T}_bench_n1_vislang.json` | 32 vis + 32 lang + CLIP (BASELINE config 3 per GPU), one paired pass: {var['vislang']['value']:.0f} windows/s, {var['vislang']['ms_per_step']} ms/step | `python bench.py --lang 1 --no-cpu-baseline` |
+| `{T}_bench_n1_u8.json` | uint8 (B,S,H,W,C) ingest, transforms fused into conv1 (SURVEY §8(f) row 1): {var['u8']['value']:.0f} windows/s, {var['u8']['ms_per_step']} ms/step (boxes differ by ±2 %: the same-box ratio to the fp32 boundary is in `r06_ab_fp32_vs_u8_final.txt`) | `python bench.py --ingest u8 --no-cpu-baseline` |
+{u8_store_row}| `{T}_bench_n1_vislang.json` | 32 vis + 32 lang + CLIP (BASELINE config 3 per GPU), one paired pass: {var['vislang']['value']:.0f} windows/s, {var['vislang']['ms_per_step']} ms/step | `python bench.py --lang 1 --no-cpu-baseline` |
 | `{T}_bench_n1_vislang_seq.json` | the same, one pass per modality (the reference's order): {var['vislang_seq']['value']:.0f} windows/s, {var['vislang_seq']['ms_per_step']} ms/step | `python bench.py --lang 1 --pair 0 --no-cpu-baseline` |
 | `{T}_bench_n1_mcil.json` | `model=mcil` (BiRNN plan recognition): {var['mcil']['value']:.0f} windows/s, {var['mcil']['ms_per_step']} ms/step | `python bench.py --model mcil --no-cpu-baseline` |
 | `{T}_bench_n1_mcil_gru.json` | `rnn_type=nn.GRU` (BASELINE config 4's GRU plan encoder): {var['mcil_gru']['value']:.0f} windows/s, {var['mcil_gru']['ms_per_step']} ms/step (round 1: 12.44 ms) | `python bench.py --model mcil_gru --no-cpu-baseline` |
