@@ -829,6 +829,42 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     if constexpr (REGCONV) {
         // one pass: NU windows in flight per thread, converted from the registers into the [c][row][iw] image (no raw rows in LDS, no margins, no barrier in between)
         constexpr int NU = 6;
+        // interior groups first (conv1_interior_groups: no clamp, no per-pixel select, one alignbyte shift per frame — see conv1_wgrad_tr2r_kernel), then the row ends
+        int cl, WI;
+        conv1_interior_groups(IW, s.pad, W4, cl, WI);
+        if (WI > 0 && dx >= -s.pad && dx <= s.pad) {
+            const Step256 si(WI);
+            const int shu = (3 * dx) & 3, off0 = 12 * cl + 3 * dx;
+            RowCol p{tid / WI, tid % WI};
+            while (p.r < rows) {
+                RowCol e[NU];
+                u32x4_t w[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    e[u] = p; si.adv(p);
+                    const bool in = e[u].r < rows;
+                    w[u] = *reinterpret_cast<const u32x4_t*>(base + (long long)min(max(ih0 + (in ? e[u].r : rows - 1) + dy, 0), IH - 1) * RB + ((off0 + 12 * (in ? e[u].c : 0)) & ~3));
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (e[u].r < rows) {
+                        unsigned lo[3], hi[3];
+                        if (s.fold) conv1_window_group_interior<true>(w[u], shu, lo, hi); else conv1_window_group_interior<false>(w[u], shu, lo, hi);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + e[u].r) * XRS + (cl + e[u].c) * 8) = u32x2_t{lo[ch], hi[ch]};
+                    }
+            }
+            const int WE = W4 - WI;
+            for (int i = tid; i < rows * WE; i += 256) {
+                const int r = i / WE, ce = i - r * WE, c = ce < cl ? ce : ce + WI;
+                const u32x4_t w = *reinterpret_cast<const u32x4_t*>(base + (long long)min(max(ih0 + r + dy, 0), IH - 1) * RB + conv1_window_off(c, dx, IW, RB));
+                unsigned lo[3], hi[3];
+                if (s.fold) conv1_window_group<true>(w, c, dx, IW, RB, lo, hi); else conv1_window_group<false>(w, c, dx, IW, RB, lo, hi);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) *(__attribute__((address_space(3))) u32x2_t*)(ximg + (ch * XR + r) * XRS + c * 8) = u32x2_t{lo[ch], hi[ch]};
+            }
+            return;
+        }
         RowCol p = q0;
         while (p.r < rows) {
             RowCol e[NU];
