@@ -305,6 +305,14 @@ int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, 
     return 0;
 }
 
+// host arithmetic only (no device needed): the interior group range the uint8 conv1 kernels convert without clamps (conv_wgrad.h::conv1_interior_groups)
+int hulc_k_conv1_interior_groups(int32_t IW, int32_t pad, int32_t cap, int32_t* first, int32_t* count) {
+    int cl = 0, wi = 0;
+    conv1_interior_groups(IW, pad, cap, cl, wi);
+    *first = cl; *count = wi;
+    return 0;
+}
+
 // conv1's weight gradient from uint8 (Nf,IH,IH,3) frames alone (tests): dW (32,192) [torch (o, c, kh, kw) order] and db (32) of the frames after ScaleImageTensor / Normalize /
 // RandomShiftsAug — form 0: raw rows through LDS (conv1_wgrad_tr2u_kernel), 1: conversion from the prefetch registers (conv1_wgrad_tr2r_kernel), 2: the same with interior / row-end slots; fold = Conv1Src::fold
 int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, const void* dY, float* dw_out, float* db_out, int32_t Nf, int32_t IH, int32_t form, int32_t fold, void* stream) {

@@ -51,7 +51,7 @@ class HulcSbertConfig(C.Structure):
 
 EXPORTS = ["hulc_last_error", "hulc_ctx_create", "hulc_ctx_destroy", "hulc_set_stream", "hulc_workspace_bytes",
            "hulc_bind_params", "hulc_prepare_weights", "hulc_zero_grads", "hulc_flush_grads", "hulc_forward_loss", "hulc_forward_loss_pair", "hulc_backward", "hulc_backward_part",
-           "hulc_adam_step", "hulc_optimizer_step", "hulc_comm_unique_id", "hulc_comm_prepare", "hulc_comm_init", "hulc_comm_destroy", "hulc_comm_buckets", "hulc_comm_stats", "hulc_comm_size", "hulc_comm_timeline", "hulc_allreduce_grads", "hulc_backward_allreduce", "hulc_scaler_enable", "hulc_scaler_get", "hulc_scaler_set", "hulc_validate", "hulc_clip_gt_encode", "hulc_clip_gt_scores", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_rollout_get_goal", "hulc_rollout_set_state", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_set_option", "hulc_get_option", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv1_wgrad_u8", "hulc_k_conv_tile", "hulc_k_skinny", "hulc_k_attention", "hulc_k_rnn_persist", "hulc_k_rnn_persist_flag_words"]
+           "hulc_adam_step", "hulc_optimizer_step", "hulc_comm_unique_id", "hulc_comm_prepare", "hulc_comm_init", "hulc_comm_destroy", "hulc_comm_buckets", "hulc_comm_stats", "hulc_comm_size", "hulc_comm_timeline", "hulc_allreduce_grads", "hulc_backward_allreduce", "hulc_scaler_enable", "hulc_scaler_get", "hulc_scaler_set", "hulc_validate", "hulc_clip_gt_encode", "hulc_clip_gt_scores", "hulc_rollout_reset", "hulc_rollout_plan", "hulc_rollout_act", "hulc_rollout_get_goal", "hulc_rollout_set_state", "hulc_sbert_create", "hulc_sbert_destroy", "hulc_sbert_set_stream", "hulc_sbert_bind", "hulc_sbert_encode", "hulc_set_kl_beta", "hulc_set_dropout", "hulc_set_option", "hulc_get_option", "hulc_timers_enable", "hulc_timers_read", "hulc_get_tensor", "hulc_get_plan_idx", "hulc_k_gemm_nt", "hulc_k_cast", "hulc_k_trread_probe", "hulc_k_conv_wgrad", "hulc_k_conv1_wgrad_u8", "hulc_k_conv1_interior_groups", "hulc_k_conv_tile", "hulc_k_skinny", "hulc_k_attention", "hulc_k_rnn_persist", "hulc_k_rnn_persist_flag_words"]
 
 _lib = None
 
@@ -132,6 +132,7 @@ def load():
                                    C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
     lib.hulc_k_conv_wgrad.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     if hasattr(lib, "hulc_k_conv1_wgrad_u8") or not os.environ.get("HULC_LIB_PATH"):
+        lib.hulc_k_conv1_interior_groups.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.hulc_k_conv1_wgrad_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.hulc_k_conv_tile.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_void_p]

@@ -335,6 +335,9 @@ int hulc_k_gemm_nt(int32_t dtype, const void* A, const void* B, float* C, int32_
  * side IH; out = fp32 [64][KH*KW*CI] in packed (kh,kw,ci) order, overwritten. Synchronises. */
 int hulc_k_conv_wgrad(int32_t which, const void* X, const void* dY, float* out, int32_t Nf, int32_t IH, void* hip_stream);
 /* conv1's weight / bias gradient from uint8 (Nf,IH,IH,3) frames + RandomShiftsAug shifts alone (bf16 engine's kernels; form 0: raw rows through LDS, 1: conversion from the prefetch registers) */
+/* host arithmetic only: groups [first, first + count) of a row's IW / 4 four-pixel groups that no RandomShiftsAug shift |dx| <= pad can push against a row end
+ * (at most `cap` of them): the uint8 conv1 kernels convert these without clamps; tests check the property the kernels rely on */
+int hulc_k_conv1_interior_groups(int32_t IW, int32_t pad, int32_t cap, int32_t* first, int32_t* count);
 int hulc_k_conv1_wgrad_u8(const void* X, const int32_t* shifts, int32_t pad, const void* dY, float* dw_out, float* db_out, int32_t Nf, int32_t IH, int32_t form, int32_t fold, void* hip_stream);
 /* raw-tile conv kernels alone (bf16 NHWC, square frames): mode 0 fwd 3x3/s1 64->64, 1 fwd 4x4/s2 32->64, 2 dgrad of (0), 3 dgrad of
  * (1). img side IMH, out side OUTH; w = packed weights as produced by hulc_prepare_weights (fwd [co][(kh,kw,ci)], dgrad per-parity

@@ -149,3 +149,29 @@ def test_frame_store_samples_windows_inside_one_episode_and_builds_reference_bat
         FrameStore(rs, rg, episode_ends=[10, 5, 50], device="cpu")
     with pytest.raises(ValueError):
         FrameStore(rs, rg, episode_ends=[3], device="cpu").valid_starts(S) if False else FrameStore(rs.float(), rg, device="cpu")
+
+
+def test_conv1_interior_groups_never_touch_a_row_end():
+    """The uint8 conv1 kernels convert `interior` 4-pixel groups without clamps (conv_wgrad.h::conv1_interior_groups, round 6): for every column shift |dx| <= pad a group's four
+    source pixels 4 c + dx .. + 3 must lie inside the row and its aligned 16-byte window (3 (4 c + dx)) & ~3 .. + 15 inside the row's 3 IW bytes — otherwise the kernel would read
+    past the row (past the buffer, for the last row of the last frame).  Host arithmetic of the library, no GPU needed."""
+    import ctypes as C
+    from hulc_amd import lib as L
+    lib = L.load()
+    for IW in (8, 12, 16, 32, 84, 100, 200, 224):
+        for pad in (0, 1, 3, 4, 10, 16):
+            for cap in (1, 5, 18, 42, 1000):
+                first, count = C.c_int32(-1), C.c_int32(-1)
+                assert lib.hulc_k_conv1_interior_groups(IW, pad, cap, C.byref(first), C.byref(count)) == 0
+                f, n = first.value, count.value
+                assert 0 <= n <= cap and (n == 0 or (0 <= f and f + n <= IW // 4)), (IW, pad, cap, f, n)
+                for c in range(f, f + n):
+                    for dx in (-pad, 0, pad):
+                        p0 = 4 * c + dx
+                        assert p0 >= 0 and p0 + 3 <= IW - 1, (IW, pad, c, dx)
+                        assert ((3 * p0) & ~3) + 16 <= 3 * IW, (IW, pad, c, dx)
+    # the two cameras of the benchmark: most of a row is interior
+    for IW, pad, want in ((200, 10, 44), (84, 4, 18)):
+        first, count = C.c_int32(), C.c_int32()
+        lib.hulc_k_conv1_interior_groups(IW, pad, 1000, C.byref(first), C.byref(count))
+        assert count.value == want, (IW, pad, count.value)
