@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(256, 4) conv1_fwd_u8dma_kernel(Conv1Src X, con
         const int rows = min(XR, IH - ih0);
         int dy = 0;
         pdx = 0; prows = rows;
-        if (X.shift) { pdx = X.shift[2 * f] - X.pad; dy = X.shift[2 * f + 1] - X.pad; }
+        X.offsets(f, pdx, dy);
         const long long fb = X.frame(f) * IH * RB;
         const int nslot = rows * SPR;
         for (int n0 = wave * 64; n0 < nslot; n0 += 256) {

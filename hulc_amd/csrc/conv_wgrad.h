@@ -709,6 +709,12 @@ struct Conv1Src {
         return s0 + (f - b * S);
     }
     DEVI long long frames_total(int Nf) const { return wstart ? nstore : (long long)Nf; }
+    // frame f's RandomShiftsAug offsets (dx, dy) = shift - pad; a column shift outside the contract's [0, 2 pad] is clamped (every uint8 kernel, forward and backward alike: the
+    // staged replicate margins / the interior groups of the register kernels assume |dx| <= pad); rows are clamped per row, any dy is safe
+    DEVI void offsets(int f, int& dx, int& dy) const {
+        dx = dy = 0;
+        if (shift) { dx = min(max(shift[2 * f] - pad, -pad), pad); dy = shift[2 * f + 1] - pad; }
+    }
 };
 #define CONV1_FOLD_SCALE (2.f / 255.f)
 // bias_fold[o] = b[o] - sum_k W16[o][k] over the packed 16-bit conv1 weights [32][192] (what the MFMAs multiply); one wave per output channel
@@ -824,7 +830,7 @@ DEVI void conv1_stage_band(const Conv1Src& s, int f, int ih0, int rows, int IH, 
     // (b * 2/255 - 1: within one fp32 ulp of the reference's (b/255 - .5)/.5, which the fp32-mode ingest_u8_kernel keeps exactly).
     const unsigned char* base = reinterpret_cast<const unsigned char*>(s.X) + s.frame(f) * IH * IW * 3;
     int dx = 0, dy = 0;
-    if (s.shift) { dx = s.shift[2 * f] - s.pad; dy = s.shift[2 * f + 1] - s.pad; }
+    s.offsets(f, dx, dy);
     const int RB = IW * 3;                                            // bytes per source row (multiple of 4: IW % 4 == 0)
     if constexpr (REGCONV) {
         // one pass: NU windows in flight per thread, converted from the registers into the [c][row][iw] image (no raw rows in LDS, no margins, no barrier in between)
@@ -964,7 +970,7 @@ __global__ void ingest_u8_kernel(const unsigned char* __restrict__ in, const int
     if (idx >= (long long)Nf * 3 * IH * IW) return;
     const int x = (int)(idx % IW), y = (int)((idx / IW) % IH), c = (int)((idx / ((long long)IW * IH)) % 3), f = (int)(idx / ((long long)3 * IW * IH));
     int dx = 0, dy = 0;
-    if (shift) { dx = shift[2 * f] - pad; dy = shift[2 * f + 1] - pad; }
+    if (shift) { dx = min(max(shift[2 * f] - pad, -pad), pad); dy = shift[2 * f + 1] - pad; }      // as Conv1Src::offsets
     const int sy = min(max(y + dy, 0), IH - 1), sx = min(max(x + dx, 0), IW - 1);
     out[idx] = u8_to_unit(in[((src.frame(f) * IH + sy) * IW + sx) * 3 + c]);       // src: only its frame-store fields are used (frame(f) = f without a store)
 }
@@ -1322,7 +1328,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2u_kernel(Conv1Src S, in
         xrows = min(XR, IH - ih0); yrows = min(R, OH - oh0);
         int dy = 0;
         pdx = 0;
-        if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
+        S.offsets(f, pdx, dy);
         const unsigned char* fb = Xb + S.frame(f) * IH * RB;
         const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
         {
@@ -1546,8 +1552,7 @@ __global__ void __launch_bounds__(512, 4) conv1_wgrad_tr2r_kernel(Conv1Src S, in
         xrows = min(XR, IH - ih0); yrows = min(R, OH - oh0);
         int dy = 0;
         pdx = 0;
-        if (S.shift) { pdx = S.shift[2 * f] - S.pad; dy = S.shift[2 * f + 1] - S.pad; }
-        if (SPLIT) pdx = min(max(pdx, -S.pad), S.pad);               // the interior slots assume |dx| <= pad (the contract of hulc_batch::shift_*): an out-of-contract value must not read past a row
+        S.offsets(f, pdx, dy);
         const unsigned char* fb = Xb + S.frame(f) * IH * RB;
         const h16_t* yb = dY + ((long long)f * OH + oh0) * OW * C::CO;
         if constexpr (SPLIT) {

@@ -67,7 +67,8 @@ typedef struct hulc_batch {
      * frames_u8 != 0: rgb_static / rgb_gripper point to uint8 (B,S,H,W,C) frames as stored in the dataset; the dataloader transforms of
      * conf/datamodule/transforms/rand_shift.yaml — ScaleImageTensor (x/255), Normalize(0.5, 0.5) and RandomShiftsAug
      * (hulc/utils/transforms.py:8-29; pad 10 / 4) — are applied inside conv1's load path (bf16 mode) instead of on the CPU.
-     * shift_*: (B*S,2) int32 (sx, sy) in [0, 2*pad] per frame, device memory; NULL = no augmentation (the validation transforms). */
+     * shift_*: (B*S,2) int32 (sx, sy) in [0, 2*pad] per frame, device memory; NULL = no augmentation (the validation transforms).
+     * With shifts, pad_* must lie in [0, 16] (the replicate margin the kernels stage; a larger pad is an error); a shift outside [0, 2*pad] is clamped. */
     int32_t frames_u8;
     int32_t pad_static, pad_gripper;
     const int32_t* shift_static;

@@ -94,6 +94,13 @@ def test_u8_ingest_validation_without_augmentation():
     eng.load_numpy(P)
     a = eng.validate(dict(common, rgb_static=t(O.ingest_u8(fs)), rgb_gripper=t(O.ingest_u8(fg))), False, None)
     b = eng.validate(dict(common, rgb_static=t(fs), rgb_gripper=t(fg)), False, None)
+    # a RandomShiftsAug pad beyond the kernels' staged replicate margin (16 pixels) is refused, in training and in validation
+    sh = torch.zeros(B * S, 2, dtype=torch.int32, device="cuda")
+    bad = dict(common, rgb_static=t(fs), rgb_gripper=t(fg), shift_static=sh, shift_gripper=sh, pad_static=20, pad_gripper=4)
+    with pytest.raises(RuntimeError):
+        eng.forward_loss(bad, False, 1.0, 3.0)
+    with pytest.raises(RuntimeError):
+        eng.validate(bad, False, None)
     eng.close()
     assert abs(a["action_loss_pp"] - b["action_loss_pp"]) <= 2e-4 * abs(a["action_loss_pp"])
     assert torch.equal(a["sampled_plan_idx_pp"], b["sampled_plan_idx_pp"])
